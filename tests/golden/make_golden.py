@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Generate the committed golden fixtures in tests/golden/.
+
+Runs ONLY in the build container (it imports the reference's Python from /root/reference, which
+never travels to the GPU box).  Nothing here is copied from the reference: the fixtures are DATA --
+bytes the reference's own ``kaldi_io`` writes / arrays it decodes, and the output stream the
+reference's own ``Model.make_embedding`` (local/tf/models.py:356-432) produces when its TensorFlow
+session is replaced by a stub whose ``Session.run`` evaluates the fp64 oracle forward.
+
+Fixtures
+  ark_io.npz            bytes written by reference write_mat/write_vec_flt (FM, DM, FV, DV), a
+                        hand-built 'CM ' record and an ascii record + what reference read_mat decodes
+  make_embedding.npz    for (min_chunk, chunk) settings: utterance lengths, the chunk lengths each
+                        key was run with, and the exact output ark bytes of the reference driver
+  forward_default.npz   fp64-oracle x-vectors (default + dilated topology, trained-like weights from
+                        seed) for T in {25,200,400,1000}; sub-sampled per-layer tensors for T=25
+Usage:  python tests/golden/make_golden.py
+"""
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/local/tf"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd"))
+
+from oracle import oracle  # noqa: E402
+from xvector_amd import synthetic, topology  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fixture_inputs import (CONTROL_FEAT, CONTROL_LENGTHS, CONTROL_SEED, CONTROL_SETTINGS, FWD_SEED, FWD_T,  # noqa: E402
+                            control_inputs)
+
+
+def import_reference():
+    """Import the reference's kaldi_io / models with the minimum of sys.modules shims."""
+    import _thread
+    sys.modules.setdefault("thread", _thread)          # ze_utils.py:10 is python-2 'import thread'
+    tf = types.ModuleType("tensorflow")
+
+    class _Tensor(object):
+        def __init__(self, name, shape=None):
+            self.name, self.shape = name, shape
+
+    class _Graph(object):
+        def __init__(self, num_classes):
+            self.num_classes = num_classes
+
+        def get_tensor_by_name(self, name):
+            return _Tensor(name, (None, self.num_classes) if name == "input_y:0" else None)
+
+        def get_operation_by_name(self, name):
+            return _Tensor(name)
+
+    class Session(object):
+        forward = None          # set by the driver: f(mat[T,F]) -> float64[E]
+        log = None
+
+        def __init__(self, config=None, graph=None):
+            self.graph = _Graph(8)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def run(self, fetch, feed_dict=None):
+            assert fetch.name == "embed_layer-0/scores:0"          # models.py:159,414
+            x = [v for k, v in feed_dict.items() if getattr(k, "name", "") == "input_x:0"][0]
+            assert x.ndim == 3 and x.shape[0] == 1                  # batch 1, models.py:410
+            Session.log.append(int(x.shape[1]))
+            return Session.forward(x[0]).astype(np.float32)[None, :]
+
+    class _Saver(object):
+        def restore(self, sess, path):
+            pass
+
+    tf.Session = Session
+    tf.ConfigProto = lambda **kw: types.SimpleNamespace()
+    tf.train = types.SimpleNamespace(import_meta_graph=lambda path: _Saver())
+    tfp = types.ModuleType("tensorflow.python")
+    tfpf = types.ModuleType("tensorflow.python.framework")
+    tfpf.ops = types.SimpleNamespace()
+    sys.modules["tensorflow"] = tf
+    sys.modules["tensorflow.python"] = tfp
+    sys.modules["tensorflow.python.framework"] = tfpf
+    sys.path.insert(0, REF)
+    import kaldi_io as ref_kaldi_io
+    import models as ref_models
+    sys.path.remove(REF)
+    # keep our own modules importable under their names afterwards
+    for m in ("kaldi_io", "models", "ze_utils", "tf_block"):
+        sys.modules["ref_" + m] = sys.modules.pop(m)
+    return ref_kaldi_io, ref_models, Session
+
+
+class _Log(object):
+    def info(self, *a):
+        pass
+
+    def warning(self, *a):
+        pass
+
+
+def golden_ark_io(ref_io, out):
+    rng = np.random.default_rng(7)
+    fm = rng.standard_normal((6, 23)).astype(np.float32)
+    dm = rng.standard_normal((4, 5))
+    fv = rng.standard_normal(512).astype(np.float32)
+    dv = rng.standard_normal(7)
+    bio = io.BytesIO(); bio.mode = "wb"
+    ref_io.write_mat(bio, fm, key="utt-a.1")
+    ref_io.write_mat(bio, dm, key="utt_b/2")
+    ref_io.write_mat(bio, np.zeros((0, 23), np.float32), key="empty")
+    mat_ark = bio.getvalue()
+    bio = io.BytesIO(); bio.mode = "wb"
+    ref_io.write_vec_flt(bio, fv, key="spk1")
+    ref_io.write_vec_flt(bio, dv, key="spk2")
+    vec_ark = bio.getvalue()
+    # hand-built 'CM ' record (Kaldi CompressedMatrix format 1): global header, per-column
+    # percentile headers (uint16), column-major uint8 payload
+    rows, cols = 9, 4
+    hdr = np.array([(-3.5, 7.25)], dtype="<f4").tobytes() + np.array([rows, cols], "<i4").tobytes()
+    pct = np.sort(rng.integers(0, 65536, size=(cols, 4)), axis=1).astype("<u2")
+    data = rng.integers(0, 256, size=(cols, rows)).astype(np.uint8)
+    data[0, :4] = [0, 64, 65, 192]
+    data[1, :3] = [193, 255, 128]
+    cm_ark = b"cm1 " + b"\x00BCM " + hdr + pct.tobytes() + data.tobytes()
+    cm_dec = [m for _, m in ref_io.read_mat_ark(io.BytesIO(cm_ark))][0]
+    txt_ark = b"txt1  [\n  1.5 -2 3e-1\n  4 5 6.25 ]\n"
+    txt_dec = [m for _, m in ref_io.read_mat_ark(io.BytesIO(txt_ark))][0]
+    vec_txt = b"vtx  [ 1 2.5 -3 ]\n"
+    vec_txt_dec = [v for _, v in ref_io.read_vec_flt_ark(io.BytesIO(vec_txt))][0]
+    np.savez_compressed(out, fm=fm, dm=dm, fv=fv, dv=dv,
+                        mat_ark=np.frombuffer(mat_ark, np.uint8), vec_ark=np.frombuffer(vec_ark, np.uint8),
+                        cm_ark=np.frombuffer(cm_ark, np.uint8), cm_dec=np.asarray(cm_dec),
+                        txt_ark=np.frombuffer(txt_ark, np.uint8), txt_dec=np.asarray(txt_dec),
+                        vec_txt=np.frombuffer(vec_txt, np.uint8), vec_txt_dec=np.asarray(vec_txt_dec))
+    print("ark_io: mat_ark %d B, vec_ark %d B, cm %s" % (len(mat_ark), len(vec_ark), cm_dec.shape))
+
+
+def golden_make_embedding(ref_io, ref_models, Session, out):
+    topo = synthetic.SMALL_TOPOLOGY
+    weights = synthetic.trained_like(topo, CONTROL_FEAT, num_classes=8, seed=CONTROL_SEED)
+    utts = control_inputs()
+    bio = io.BytesIO(); bio.mode = "wb"
+    for k, m in utts:
+        ref_io.write_mat(bio, m, key=k)
+    in_ark = bio.getvalue()
+    Session.forward = staticmethod(lambda x: oracle.forward(x, weights, topo, np.float64))
+    res = {}
+    for si, (min_chunk, chunk) in enumerate(CONTROL_SETTINGS):
+        Session.log = []
+        so = io.BytesIO(); so.mode = "wb"
+        ref_models.Model().make_embedding(io.BytesIO(in_ark), so, "/nonexistent", min_chunk, chunk, False, _Log())
+        res["out_ark_%d" % si] = np.frombuffer(so.getvalue(), np.uint8)
+        res["chunk_lens_%d" % si] = np.array(Session.log, np.int64)
+        print("make_embedding[min=%d chunk=%d]: %d chunks run, %d B out" %
+              (min_chunk, chunk, len(Session.log), len(so.getvalue())))
+    np.savez_compressed(out, settings=np.array(CONTROL_SETTINGS, np.int64),
+                        lengths=np.array(CONTROL_LENGTHS, np.int64), seed=CONTROL_SEED, feat=CONTROL_FEAT, **res)
+
+
+def golden_forward(out):
+    res = {}
+    for tname, topo in (("default", topology.get("ModelWithoutDropout")),
+                        ("dilated", topology.get("ModelWithoutDropoutTdnn")),
+                        ("prelu", topology.get("ModelWithoutDropoutPRelu")),
+                        ("lrelu", topology.get("ModelL2LossWithoutDropoutLRelu"))):
+        weights = synthetic.trained_like(topo, 23, seed=FWD_SEED)
+        rng = np.random.default_rng(FWD_SEED + 1)
+        for T in (FWD_T if tname in ("default", "dilated") else [25, 200]):
+            x = (rng.standard_normal((T, 23)) * 3.0).astype(np.float32)
+            e1, inter = oracle.forward(x, weights, topo, np.float64, embedding_index=1, return_intermediates=True)
+            e0 = inter[6]
+            chk = oracle.forward_numpy(x, weights, topo, 0)
+            assert oracle.rel_l2(e0, chk) < 1e-12, (tname, T, oracle.rel_l2(e0, chk))
+            res["%s_T%d_e0" % (tname, T)] = e0
+            res["%s_T%d_e1" % (tname, T)] = e1
+            if T == 25:
+                for li in range(5):
+                    res["%s_T25_layer%d_sub" % (tname, li)] = inter[li][:, ::16].copy()
+                res["%s_T25_pooled" % tname] = inter[5]
+            print("forward %s T=%d |e0|=%.4f" % (tname, T, np.linalg.norm(e0)))
+    np.savez_compressed(out, seed=FWD_SEED, **res)
+
+
+def main():
+    ref_io, ref_models, Session = import_reference()
+    golden_ark_io(ref_io, os.path.join(HERE, "ark_io.npz"))
+    golden_make_embedding(ref_io, ref_models, Session, os.path.join(HERE, "make_embedding.npz"))
+    golden_forward(os.path.join(HERE, "forward_default.npz"))
+
+
+if __name__ == "__main__":
+    main()

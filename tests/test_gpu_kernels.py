@@ -1,0 +1,218 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes) against the CPU oracle.
+
+Tolerance: the north star asks for 1e-4 relative L2 on the final embedding; the per-kernel checks here
+are much tighter (fp32 MFMA is an exact-product fp32 fma chain): 2e-6 relative L2 against the fp64
+oracle for the GEMM kernels, 2e-6 for pooling, bit-exact for the chunk average.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_GEMM = 2e-6
+TOL_POOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def env(oracle_mod):
+    import torch
+    from xvector_amd import engine, hiplib
+    hiplib.require_gpu()
+    return dict(torch=torch, hiplib=hiplib, engine=engine, oracle=oracle_mod, dev=torch.device("cuda:0"))
+
+
+def _rand_bn(rng, c):
+    return ((1 + 0.1 * rng.standard_normal(c)).astype(np.float32), (0.1 * rng.standard_normal(c)).astype(np.float32),
+            (0.2 * rng.standard_normal(c)).astype(np.float32), np.exp(0.2 * rng.standard_normal(c)).astype(np.float32))
+
+
+def _run_layer(env, mats, w, b, bn, act, alpha, K, dil, preact=False):
+    """Pack `mats` with gap rows, run xv_tdnn_layer_f32, return per-chunk outputs and the full y."""
+    torch, hiplib, engine, dev = env["torch"], env["hiplib"], env["engine"], env["dev"]
+    gap = max(1, (K - 1) * dil // 2)
+    layout = engine.BatchLayout([m.shape[0] for m in mats], gap)
+    host = np.zeros((layout.rows, mats[0].shape[1]), np.float32)
+    layout.pack(mats, host)
+    x = torch.from_numpy(host).to(dev)
+    rv = torch.from_numpy(layout.row_valid()).to(dev)
+    cin, cout = w.shape[1], w.shape[2]
+    wp = hiplib.pack_weights(torch.from_numpy(np.ascontiguousarray(w.reshape(K * cin, cout))).to(dev))
+    bias = torch.from_numpy(b).to(dev)
+    scale = shift = None
+    if bn is not None:
+        scale, shift = hiplib.fold_bn(*(torch.from_numpy(a).to(dev) for a in bn), 1e-3)
+    al = None if alpha is None else torch.from_numpy(np.atleast_1d(alpha).astype(np.float32)).to(dev)
+    # poison the output so that unwritten elements are caught
+    y = torch.full((layout.rows, cout), float("nan"), dtype=torch.float32, device=dev)
+    ypre = torch.full_like(y, float("nan")) if preact else None
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+    hiplib.tdnn_layer(x, wp, bias, scale, shift, code, al, K, dil, rv, y, ypre)
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy()
+    outs = [yh[s:s + n] for s, n in zip(layout.row_start, layout.row_len)]
+    return outs, yh, layout, (ypre.cpu().numpy() if preact else None)
+
+
+@pytest.mark.parametrize("cin,cout,K,dil,act", [
+    (23, 512, 5, 1, "relu"),        # layer 0: scalar-load path, Cin not a multiple of 4
+    (512, 512, 5, 1, "relu"),       # layer 1
+    (512, 512, 7, 1, "relu"),       # layer 2
+    (512, 512, 1, 1, "relu"),       # layer 3
+    (512, 1536, 1, 1, "relu"),      # layer 4
+    (512, 512, 3, 2, "relu"),       # dilated variant layer 1
+    (512, 512, 3, 3, "relu"),       # dilated variant layer 2
+    (64, 48, 5, 1, "prelu"),        # Cout not a multiple of 128/32, PReLU epilogue
+    (40, 200, 3, 1, "lrelu"),       # Cin not a multiple of 32 (vector path with a ragged last slab)
+    (5, 32, 5, 1, "none"),
+])
+def test_tdnn_layer_matches_oracle(env, cin, cout, K, dil, act):
+    oracle = env["oracle"]
+    rng = np.random.default_rng(cin * 1000 + cout + K * 7 + dil)
+    lens = [25, 1, 130, 257, 64, 3]           # chunks shorter than the halo and spanning tile boundaries
+    mats = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in lens]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = None
+    if act == "lrelu":
+        alpha = np.array([0.2], np.float32)
+    elif act == "prelu":
+        alpha = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    outs, yh, layout, _ = _run_layer(env, mats, w, b, bn, act, alpha, K, dil)
+    for m, got in zip(mats, outs):
+        ref = oracle.tdnn_layer(m, w, b, bn, act, alpha, dil, np.float64)
+        assert np.isfinite(got).all()
+        assert oracle.rel_l2(got, ref) < TOL_GEMM
+    # gap rows must be written as exact zeros (the invariant the next layer relies on)
+    valid = layout.row_valid().astype(bool)
+    assert (yh[~valid] == 0).all()
+
+
+def test_tdnn_layer_batch1_equals_batched_bitwise(env):
+    """The reference runs batch 1 (models.py:410-414); a chunk's rows must not depend on its batch
+    neighbours: identical bits alone and inside a batch."""
+    rng = np.random.default_rng(5)
+    K, cin, cout = 5, 512, 512
+    mats = [(rng.standard_normal((t, cin))).astype(np.float32) for t in (200, 37, 311)]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    outs, _, _, _ = _run_layer(env, mats, w, b, bn, "relu", None, K, 1)
+    for m, got in zip(mats, outs):
+        alone, _, _, _ = _run_layer(env, [m], w, b, bn, "relu", None, K, 1)
+        assert np.array_equal(alone[0], got)
+
+
+def test_tdnn_preact_output_and_no_bn(env):
+    oracle = env["oracle"]
+    rng = np.random.default_rng(11)
+    mats = [(rng.standard_normal((90, 128))).astype(np.float32)]
+    w = (rng.standard_normal((1, 128, 256)) / np.sqrt(128)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    outs, yh, layout, pre = _run_layer(env, mats, w, b, None, "relu", None, 1, 1, preact=True)
+    ref_pre = oracle.tdnn_layer(mats[0], w, b, None, "none", None, 1, np.float64)
+    s = layout.row_start[0]
+    assert oracle.rel_l2(pre[s:s + 90], ref_pre) < TOL_GEMM
+    assert oracle.rel_l2(outs[0], np.maximum(ref_pre, 0)) < TOL_GEMM
+
+
+@pytest.mark.parametrize("C,lens,split", [
+    (1536, [25, 200, 400, 1, 7, 33, 512], 512),       # direct path (max_len <= split)
+    (1536, [25, 2000, 513, 10000, 100], 512),         # split path + merge kernel
+    (48, [5, 64, 300], 512),                          # C < 64: partially filled wave
+    (1536, [1000, 999], 128),
+])
+def test_stats_pool_matches_oracle(env, C, lens, split):
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(C + sum(lens))
+    # post-ReLU/BN-like data: point mass + large per-channel mean offsets (stresses the variance)
+    mats = [(np.maximum(rng.standard_normal((t, C)), 0) * 1.7 + 3.0 * rng.standard_normal(C)).astype(np.float32) for t in lens]
+    layout = engine.BatchLayout(lens, 3)
+    host = np.full((layout.rows, C), 1e6, np.float32)      # garbage in the gaps must not matter
+    for s, m in zip(layout.row_start, mats):
+        host[s:s + m.shape[0]] = m
+    h = torch.from_numpy(host).to(dev)
+    rs = torch.from_numpy(layout.row_start).to(dev)
+    rl = torch.from_numpy(layout.row_len).to(dev)
+    out = torch.full((len(lens), 2 * C), float("nan"), dtype=torch.float32, device=dev)
+    need = hiplib.stats_pool_workspace_bytes(C, len(lens), max(lens), split)
+    assert (need > 0) == (max(lens) > split)
+    ws = torch.empty(max(need // 4, 1), dtype=torch.float32, device=dev)
+    hiplib.stats_pool(h, rs, rl, len(lens), max(lens), split, 1e-5, out, ws)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i, m in enumerate(mats):
+        ref = oracle.stats_pool(m, 1e-5, np.float64)
+        assert oracle.rel_l2(got[i, :C], ref[:C]) < TOL_POOL
+        assert oracle.rel_l2(got[i, C:], ref[C:]) < TOL_POOL
+
+
+def test_stats_pool_constant_channel_is_exact(env):
+    """A dead-ReLU channel is constant over time: mean exact, std == sqrt(eps) exactly."""
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    T, C = 300, 64
+    host = np.tile(np.linspace(-2, 2, C).astype(np.float32), (T, 1))
+    h = torch.from_numpy(host).to(dev)
+    rs = torch.zeros(1, dtype=torch.int32, device=dev)
+    rl = torch.full((1,), T, dtype=torch.int32, device=dev)
+    out = torch.empty((1, 2 * C), dtype=torch.float32, device=dev)
+    hiplib.stats_pool(h, rs, rl, 1, T, 512, 1e-5, out, None)
+    got = out.cpu().numpy()[0]
+    assert np.array_equal(got[:C], host[0])
+    assert np.array_equal(got[C:], np.full(C, np.sqrt(np.float32(1e-5)), np.float32))
+
+
+def test_fc_matches_oracle(env):
+    torch, hiplib, oracle, dev = env["torch"], env["hiplib"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(3)
+    B, In, Out = 77, 3072, 512
+    x = rng.standard_normal((B, In)).astype(np.float32)
+    w = (rng.standard_normal((In, Out)) / np.sqrt(In)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(Out)).astype(np.float32)
+    bn = _rand_bn(rng, Out)
+    xd = torch.from_numpy(x).to(dev)
+    wp = hiplib.pack_weights(torch.from_numpy(w).to(dev))
+    assert np.array_equal(wp.cpu().numpy(), w.T)
+    scale, shift = hiplib.fold_bn(*(torch.from_numpy(a).to(dev) for a in bn), 1e-3)
+    y = torch.empty((B, Out), dtype=torch.float32, device=dev)
+    ypre = torch.empty_like(y)
+    hiplib.fc(xd, wp, torch.from_numpy(b).to(dev), scale, shift, 1, None, y, ypre)
+    torch.cuda.synchronize()
+    ref_pre = oracle.fc(x, w, b, np.float64)
+    ref = oracle.act_bn(ref_pre, bn, "relu", None, np.float64)
+    assert oracle.rel_l2(ypre.cpu().numpy(), ref_pre) < TOL_GEMM
+    assert oracle.rel_l2(y.cpu().numpy(), ref) < TOL_GEMM
+
+
+def test_chunk_average_bit_exact(env):
+    torch, hiplib, oracle, dev = env["torch"], env["hiplib"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(9)
+    D = 512
+    segs = [1, 3, 1, 4, 2]
+    lens = [rng.integers(25, 10001, size=n).astype(np.int32) for n in segs]
+    embs = [rng.standard_normal((n, D)).astype(np.float32) * 5 for n in segs]
+    e = torch.from_numpy(np.concatenate(embs)).to(dev)
+    seg = torch.tensor(np.concatenate([[0], np.cumsum(segs)]), dtype=torch.int32, device=dev)
+    cl = torch.from_numpy(np.concatenate(lens)).to(dev)
+    out = torch.empty((len(segs), D), dtype=torch.float32, device=dev)
+    hiplib.chunk_average(e, seg, cl, len(segs), out)
+    got = out.cpu().numpy()
+    for i in range(len(segs)):
+        ref = oracle.chunk_average(embs[i], lens[i], np.float32)
+        assert np.array_equal(got[i], ref), i
+        # and the NumPy expression of the reference itself (models.py:398,418-421)
+        acc, tot = 0, 0.0
+        for ln, ev in zip(lens[i], embs[i]):
+            tot += int(ln)
+            acc = acc + int(ln) * ev
+        acc = acc / tot
+        assert np.array_equal(got[i], acc.astype(np.float32))
+
+
+def test_bad_arguments_fail_loudly(env):
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    x = torch.zeros((10, 8), dtype=torch.float32, device=dev)
+    wp = torch.zeros((8, 9 * 8), dtype=torch.float32, device=dev)
+    y = torch.zeros((10, 8), dtype=torch.float32, device=dev)
+    with pytest.raises(hiplib.XvectorHipError):
+        hiplib.tdnn_layer(x, wp, None, None, None, 1, None, 9, 2, None, y)      # (K-1)*dil = 16 > 8

@@ -1,0 +1,593 @@
+// xv_kernels.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI of libxvector_hip.so.
+//
+// Hot path of BUTSpeechFIT/x-vector-kaldi-tf's extraction (local/tf/models.py:50-94 evaluated by
+// local/tf/models.py:414), written for CDNA4 from scratch:
+//   tdnn_gemm_kernel   implicit-im2col GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), 128x128 tile,
+//                      4 wave64 per workgroup (2x2 waves, 2x2 MFMA tiles each), the dilated temporal
+//                      context window staged ONCE per channel slab in LDS and re-used by all K taps,
+//                      double-buffered LDS with register prefetch, fused bias/act/BN/gap-mask epilogue
+//   stats_pool_kernel  HBM-bound mean/std reduction: one wave64 per (chunk, split, 64 channels),
+//                      16 B/lane loads, blocked two-pass + Chan merges, wave shuffle combine
+//   chunk_average, pack_weights, fold_bn   small helpers
+// See include/xvector_hip.h for the ABI contract and DESIGN.md for the layout / roofline notes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <type_traits>
+
+#include "xvector_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *where)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return (int)e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TDNN / FC GEMM
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128;        // frames per workgroup tile
+constexpr int BN = 128;        // output channels per workgroup tile
+constexpr int BK = 32;         // input channels per LDS stage
+constexpr int LDS_LD = 36;     // padded LDS row (floats): 144 B keeps ds_read_b128 conflict-free
+constexpr int MAX_SPAN = 8;    // (K-1)*dilation limit -> A tile holds BM+8 rows
+constexpr int A_ROWS = BM + MAX_SPAN;
+constexpr int NT = 256;
+
+struct GemmParams {
+    const float *x;
+    long R;
+    int cin, ldx;
+    const float *wp;
+    int kred;
+    const float *bias, *scale, *shift;
+    int act;
+    const float *alpha;
+    int K, dil, cout;
+    const uint8_t *valid;
+    float *y;
+    int ldy;
+    float *ypre;
+    int n_mt, n_nt;
+};
+
+constexpr size_t GEMM_LDS_BYTES = (size_t)(2 * A_ROWS * LDS_LD + 2 * BN * LDS_LD) * sizeof(float) + BM;
+
+__device__ __forceinline__ float apply_act(float z, int act, float a)
+{
+    switch (act) {
+    case XV_ACT_RELU: return fmaxf(z, 0.0f);
+    case XV_ACT_LRELU: return z > 0.0f ? z : a * z;
+    case XV_ACT_PRELU: return fmaxf(z, 0.0f) + a * fminf(z, 0.0f);
+    default: return z;
+    }
+}
+
+// VEC: Cin % 4 == 0 and 16-B aligned rows -> dwordx4 staging loads; otherwise dword loads (the
+// 23-dim MFCC input layer).
+template <bool VEC>
+__global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                                 // [2][A_ROWS][LDS_LD]
+    float *Bs = smem + 2 * A_ROWS * LDS_LD;           // [2][BN][LDS_LD]
+    uint8_t *Ms = (uint8_t *)(Bs + 2 * BN * LDS_LD);  // [BM] row-valid bytes
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // XCD-aware tile order: hardware places block b on XCD b%8; give each XCD a contiguous run of
+    // logical tiles so that the n_nt tiles sharing one A panel sit on one L2 (bijective form).
+    const int nwg = p.n_mt * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int span = (p.K - 1) * p.dil;
+    const int left = span >> 1;
+    const int rowsA = BM + span;
+    const int n_chunks = (p.cin + BK - 1) / BK;
+    const int n_stages = n_chunks * p.K;
+
+    if (tid < BM) {
+        const long gr = m0 + tid;
+        Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
+    }
+
+    constexpr int B_REGS = VEC ? 4 : 16;
+    constexpr int A_REGS = VEC ? 5 : 17;
+    typedef typename std::conditional<VEC, f32x4, float>::type stage_t;
+    stage_t breg[B_REGS];
+    stage_t areg[A_REGS];
+
+    auto load_b = [&](int chunk, int tap) {
+        const int c0 = chunk * BK;
+#pragma unroll
+        for (int j = 0; j < B_REGS; ++j) {
+            const int f = tid + NT * j;
+            if constexpr (VEC) {
+                const int col = f >> 3, qq = f & 7;
+                const int gcol = n0 + col, c = c0 + qq * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gcol < p.cout && c < p.cin)
+                    v = *reinterpret_cast<const f32x4 *>(p.wp + (size_t)gcol * p.kred + (size_t)tap * p.cin + c);
+                breg[j] = v;
+            } else {
+                const int col = f >> 5, cc = f & 31;
+                const int gcol = n0 + col, c = c0 + cc;
+                float v = 0.f;
+                if (gcol < p.cout && c < p.cin) v = p.wp[(size_t)gcol * p.kred + (size_t)tap * p.cin + c];
+                breg[j] = v;
+            }
+        }
+    };
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * BK;
+#pragma unroll
+        for (int j = 0; j < A_REGS; ++j) {
+            const int f = tid + NT * j;
+            if constexpr (VEC) {
+                const int lr = f >> 3, qq = f & 7;
+                const long gr = m0 - left + lr;
+                const int c = c0 + qq * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (lr < rowsA && gr >= 0 && gr < p.R && c < p.cin)
+                    v = *reinterpret_cast<const f32x4 *>(p.x + (size_t)gr * p.ldx + c);
+                areg[j] = v;
+            } else {
+                const int lr = f >> 5, cc = f & 31;
+                const long gr = m0 - left + lr;
+                const int c = c0 + cc;
+                float v = 0.f;
+                if (lr < rowsA && gr >= 0 && gr < p.R && c < p.cin) v = p.x[(size_t)gr * p.ldx + c];
+                areg[j] = v;
+            }
+        }
+    };
+    auto store_b = [&](int buf) {
+        float *dst = Bs + buf * (BN * LDS_LD);
+#pragma unroll
+        for (int j = 0; j < B_REGS; ++j) {
+            const int f = tid + NT * j;
+            if constexpr (VEC)
+                *reinterpret_cast<f32x4 *>(dst + (f >> 3) * LDS_LD + (f & 7) * 4) = breg[j];
+            else
+                dst[(f >> 5) * LDS_LD + (f & 31)] = breg[j];
+        }
+    };
+    auto store_a = [&](int buf) {
+        float *dst = As + buf * (A_ROWS * LDS_LD);
+#pragma unroll
+        for (int j = 0; j < A_REGS; ++j) {
+            const int f = tid + NT * j;
+            if constexpr (VEC) {
+                const int lr = f >> 3;
+                if (lr < A_ROWS) *reinterpret_cast<f32x4 *>(dst + lr * LDS_LD + (f & 7) * 4) = areg[j];
+            } else {
+                const int lr = f >> 5;
+                if (lr < A_ROWS) dst[lr * LDS_LD + (f & 31)] = areg[j];
+            }
+        }
+    };
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+    // prologue: stage 0
+    load_a(0);
+    load_b(0, 0);
+    store_a(0);
+    store_b(0);
+    __syncthreads();
+
+    int chunk = 0, tap = 0;
+    for (int s = 0; s < n_stages; ++s) {
+        int nchunk = chunk, ntap = tap + 1;
+        if (ntap == p.K) { ntap = 0; nchunk = chunk + 1; }
+        const bool has_next = (s + 1) < n_stages;
+        const bool new_a = has_next && (ntap == 0);
+        if (has_next) {
+            load_b(nchunk, ntap);
+            if (new_a) load_a(nchunk);
+        }
+
+        const float *Ab = As + (chunk & 1) * (A_ROWS * LDS_LD) +
+                          (wr * 64 + (lane & 31) + tap * p.dil) * LDS_LD + (lane >> 5) * 4;
+        const float *Bb = Bs + (s & 1) * (BN * LDS_LD) + (wc * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Ab + kk * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(Ab + 32 * LDS_LD + kk * 8);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Bb + kk * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(Bb + 32 * LDS_LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
+            }
+        }
+
+        if (has_next) {
+            store_b((s + 1) & 1);
+            if (new_a) store_a(nchunk & 1);
+        }
+        __syncthreads();
+        chunk = nchunk;
+        tap = ntap;
+    }
+
+    // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int colb = n0 + wc * 64 + (lane & 31);
+    const int rowb = wr * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int gc = colb + cb * 32;
+        if (gc >= p.cout) continue;
+        const float bias = p.bias ? p.bias[gc] : 0.f;
+        const float sc = p.scale ? p.scale[gc] : 1.f;
+        const float sh = p.shift ? p.shift[gc] : 0.f;
+        const float al = (p.act == XV_ACT_LRELU) ? p.alpha[0] : (p.act == XV_ACT_PRELU ? p.alpha[gc] : 0.f);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const f32x16 &a = (rb == 0) ? (cb == 0 ? acc00 : acc01) : (cb == 0 ? acc10 : acc11);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = rowb + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+                const long gr = m0 + lr;
+                if (gr >= p.R) continue;
+                const float z = a[reg] + bias;
+                if (p.ypre) p.ypre[(size_t)gr * p.ldy + gc] = z;
+                if (p.y) {
+                    float v = apply_act(z, p.act, al) * sc + sh;
+                    if (!Ms[lr]) v = 0.f;
+                    p.y[(size_t)gr * p.ldy + gc] = v;
+                }
+            }
+        }
+    }
+}
+
+int launch_gemm(const GemmParams &p0, hipStream_t st)
+{
+    GemmParams p = p0;
+    if (p.R <= 0 || p.cout <= 0) return 0;
+    if (p.cin <= 0 || p.K <= 0 || (p.K & 1) == 0 || p.dil <= 0) return fail(XV_ERR_BAD_ARG, "tdnn: K must be odd, dims > 0");
+    if ((p.K - 1) * p.dil > MAX_SPAN) return fail(XV_ERR_UNSUPPORTED, "tdnn: (K-1)*dilation > 8 unsupported");
+    if (p.ldx < p.cin || p.ldy < p.cout) return fail(XV_ERR_BAD_ARG, "tdnn: leading dimension too small");
+    if ((p.act == XV_ACT_LRELU || p.act == XV_ACT_PRELU) && !p.alpha) return fail(XV_ERR_BAD_ARG, "tdnn: act_alpha is NULL");
+    p.kred = p.K * p.cin;
+    p.n_mt = (int)((p.R + BM - 1) / BM);
+    p.n_nt = (p.cout + BN - 1) / BN;
+    const bool vec = (p.cin % 4 == 0) && (p.ldx % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) && (((uintptr_t)p.wp) % 16 == 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)tdnn_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        e = hipFuncSetAttribute((const void *)tdnn_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)(p.n_mt * p.n_nt));
+    if (vec)
+        hipLaunchKernelGGL(tdnn_gemm_kernel<true>, grid, dim3(NT), GEMM_LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL(tdnn_gemm_kernel<false>, grid, dim3(NT), GEMM_LDS_BYTES, st, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_kernel launch");
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics pooling
+// ------------------------------------------------------------------------------------------------
+struct Stat4 {
+    f32x4 mean, m2;
+    float n;
+};
+
+// merge a block of `m` values per channel given as (block mean, block M2) into the running stats
+__device__ __forceinline__ void chan_merge(Stat4 &s, const f32x4 bmean, const f32x4 bm2, float m)
+{
+    const float nn = s.n + m;
+    if (nn > 0.f) {
+        const float w = m / nn;
+        const f32x4 d = bmean - s.mean;
+        s.mean += d * w;
+        s.m2 += bm2 + d * d * (s.n * w);
+        s.n = nn;
+    }
+}
+
+constexpr int POOL_UNROLL = 8;
+
+// One wave64 per (chunk b, time split sp, 64-channel group).  lane = (phase = lane>>4 : which of 4
+// interleaved rows, cg = lane&15 : which float4 of the 64 channels).  A wave instruction therefore
+// reads 4 rows x 256 contiguous bytes; a 4-wave workgroup covers a 256-channel slab.
+__global__ __launch_bounds__(256) void stats_pool_kernel(const float *__restrict__ h, long ldh, int C,
+                                                         const int *__restrict__ row_start,
+                                                         const int *__restrict__ row_len, int split_rows,
+                                                         int max_splits, float eps, float *__restrict__ out,
+                                                         float *__restrict__ partial)
+{
+    const int b = blockIdx.z, sp = blockIdx.y;
+    const int len = row_len[b];
+    const int begin = sp * split_rows;
+    if (begin >= len) return;
+    const int n_rows = min(split_rows, len - begin);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int phase = lane >> 4;
+    const int c = (blockIdx.x * 4 + wave) * 64 + (lane & 15) * 4;
+    if (c >= C) return;          // C % 4 == 0: whole float4 in or out (lanes of other phases agree)
+    const float *base = h + ((size_t)row_start[b] + begin) * ldh + c;
+
+    Stat4 s;
+    s.mean = (f32x4){0.f, 0.f, 0.f, 0.f};
+    s.m2 = s.mean;
+    s.n = 0.f;
+
+    int r = phase;
+    // full blocks: 8 rows per lane (rows r, r+4, ..., r+28)
+    for (; r + 4 * (POOL_UNROLL - 1) < n_rows; r += 4 * POOL_UNROLL) {
+        f32x4 v[POOL_UNROLL];
+#pragma unroll
+        for (int i = 0; i < POOL_UNROLL; ++i)
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)(r + 4 * i) * ldh));
+        f32x4 sum = v[0];
+#pragma unroll
+        for (int i = 1; i < POOL_UNROLL; ++i) sum += v[i];
+        const f32x4 bm = sum * (1.0f / POOL_UNROLL);
+        f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < POOL_UNROLL; ++i) {
+            const f32x4 d = v[i] - bm;
+            m2 += d * d;
+        }
+        chan_merge(s, bm, m2, (float)POOL_UNROLL);
+    }
+    // tail: fewer than 8 rows left for this lane
+    if (r < n_rows) {
+        f32x4 v[POOL_UNROLL];
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < POOL_UNROLL; ++i) {
+            const bool ok = (r + 4 * i) < n_rows;
+            v[i] = ok ? *reinterpret_cast<const f32x4 *>(base + (size_t)(r + 4 * i) * ldh) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            m += ok ? 1 : 0;
+        }
+        f32x4 sum = v[0];
+#pragma unroll
+        for (int i = 1; i < POOL_UNROLL; ++i) sum += v[i];
+        const float fm = (float)m;
+        const f32x4 bm = sum / fm;
+        f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < POOL_UNROLL; ++i) {
+            const f32x4 d = v[i] - bm;
+            if ((r + 4 * i) < n_rows) m2 += d * d;
+        }
+        chan_merge(s, bm, m2, fm);
+    }
+
+    // combine the 4 row phases of the wave: shuffle-xor 16 then 32 (Chan merge of (n, mean, M2))
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        Stat4 o;
+        o.n = __shfl_xor(s.n, off, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o.mean[i] = __shfl_xor(s.mean[i], off, 64);
+            o.m2[i] = __shfl_xor(s.m2[i], off, 64);
+        }
+        chan_merge(s, o.mean, o.m2, o.n);
+    }
+    if (phase != 0) return;
+    if (max_splits == 1) {
+        const f32x4 var = s.m2 / s.n;
+        f32x4 sd;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sd[i] = sqrtf(var[i] + eps);
+        float *o = out + (size_t)b * 2 * C;
+        *reinterpret_cast<f32x4 *>(o + c) = s.mean;
+        *reinterpret_cast<f32x4 *>(o + C + c) = sd;
+    } else {
+        float *pm = partial + ((size_t)b * max_splits + sp) * 2 * C;
+        *reinterpret_cast<f32x4 *>(pm + c) = s.mean;
+        *reinterpret_cast<f32x4 *>(pm + C + c) = s.m2;
+    }
+}
+
+// second stage for split chunks: merge the per-split (mean, M2) in split order, finalize
+__global__ void stats_pool_merge_kernel(const float *__restrict__ partial, int C, const int *__restrict__ row_len,
+                                        int split_rows, int max_splits, float eps, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int len = row_len[b];
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int sp = 0; sp * split_rows < len; ++sp) {
+        const float m = (float)min(split_rows, len - sp * split_rows);
+        const float *pm = partial + ((size_t)b * max_splits + sp) * 2 * C;
+        const float bm = pm[c], bm2 = pm[C + c];
+        const float nn = n + m;
+        const float w = m / nn;
+        const float d = bm - mean;
+        mean += d * w;
+        m2 += bm2 + d * d * (n * w);
+        n = nn;
+    }
+    out[(size_t)b * 2 * C + c] = mean;
+    out[(size_t)b * 2 * C + C + c] = sqrtf(m2 / n + eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+// float32 op order of NumPy in local/tf/models.py:418-421: p = len*e (rounded), acc += p (rounded),
+// acc /= total.  __fmul_rn/__fadd_rn/__fdiv_rn forbid FMA contraction.
+__global__ void chunk_average_kernel(const float *__restrict__ e, const int *__restrict__ seg_start,
+                                     const int *__restrict__ chunk_len, int dim, float *__restrict__ out)
+{
+    const int u = blockIdx.y;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dim) return;
+    const int s0 = seg_start[u], s1 = seg_start[u + 1];
+    float acc = 0.f;
+    double tot = 0.0;
+    for (int i = s0; i < s1; ++i) {
+        const float w = (float)chunk_len[i];
+        acc = __fadd_rn(acc, __fmul_rn(w, e[(size_t)i * dim + d]));
+        tot += (double)chunk_len[i];
+    }
+    out[(size_t)u * dim + d] = __fdiv_rn(acc, (float)tot);
+}
+
+__global__ void pack_weights_kernel(const float *__restrict__ w, int kred, int cout, float *__restrict__ wp)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)kred * cout) return;
+    const int n = (int)(i / kred), k = (int)(i - (size_t)n * kred);
+    wp[i] = w[(size_t)k * cout + n];
+}
+
+__global__ void fold_bn_kernel(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                               int c, float *scale, float *shift)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float s = __fmul_rn(gamma[i], __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var[i], eps))));
+    scale[i] = s;
+    shift[i] = __fsub_rn(beta[i], __fmul_rn(mean[i], s));
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, what);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int xv_version(void) { return 1; }
+
+const char *xv_last_error(void) { return g_err; }
+
+int xv_pack_weights_f32(const float *w, int kred, int cout, float *wp, void *stream)
+{
+    if (!w || !wp || kred <= 0 || cout <= 0) return fail(XV_ERR_BAD_ARG, "pack_weights: bad argument");
+    const size_t n = (size_t)kred * cout;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, kred, cout, wp);
+    return check_launch("pack_weights_kernel");
+}
+
+int xv_fold_bn_f32(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int c,
+                   float *scale, float *shift, void *stream)
+{
+    if (!gamma || !beta || !mean || !var || !scale || !shift || c <= 0) return fail(XV_ERR_BAD_ARG, "fold_bn: bad argument");
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, c, scale, shift);
+    return check_launch("fold_bn_kernel");
+}
+
+int xv_tdnn_layer_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias,
+                      const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K,
+                      int dilation, int cout, const uint8_t *row_valid, float *y, int ldy, float *y_preact,
+                      void *stream)
+{
+    if (!x || !wp || (!y && !y_preact)) return fail(XV_ERR_BAD_ARG, "tdnn: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn: unknown act_kind");
+    GemmParams p{};
+    p.x = x; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wp = wp;
+    p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
+    p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid; p.y = y; p.ldy = ldy; p.ypre = y_preact;
+    return launch_gemm(p, (hipStream_t)stream);
+}
+
+int xv_fc_f32(const float *x, int nrows, int in_dim, const float *wp, const float *bias, const float *bn_scale,
+              const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y, float *y_preact,
+              void *stream)
+{
+    return xv_tdnn_layer_f32(x, nrows, in_dim, in_dim, wp, bias, bn_scale, bn_shift, act_kind, act_alpha, 1, 1,
+                             out_dim, nullptr, y, out_dim, y_preact, stream);
+}
+
+size_t xv_stats_pool_workspace_bytes(int c, int nchunks, int max_len, int split_rows)
+{
+    if (split_rows <= 0 || max_len <= split_rows) return 0;
+    const size_t splits = ((size_t)max_len + split_rows - 1) / split_rows;
+    return (size_t)nchunks * splits * 2 * (size_t)c * sizeof(float);
+}
+
+int xv_stats_pool_f32(const float *h, int64_t ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
+                      int max_len, int split_rows, float eps, float *out, void *workspace, void *stream)
+{
+    if (nchunks <= 0) return 0;
+    if (!h || !row_start || !row_len || !out) return fail(XV_ERR_BAD_ARG, "stats_pool: NULL pointer");
+    if (c <= 0 || (c & 3) || (ldh & 3) || (((uintptr_t)h) & 15) || (((uintptr_t)out) & 15))
+        return fail(XV_ERR_BAD_ARG, "stats_pool: C, ldh must be multiples of 4 and h/out 16-byte aligned");
+    if (split_rows <= 0 || max_len <= 0) return fail(XV_ERR_BAD_ARG, "stats_pool: split_rows/max_len must be > 0");
+    const int max_splits = (max_len + split_rows - 1) / split_rows;
+    if (max_splits > 1 && !workspace) return fail(XV_ERR_BAD_ARG, "stats_pool: workspace required for split chunks");
+    if (max_splits > 65535) return fail(XV_ERR_UNSUPPORTED, "stats_pool: too many splits");
+    hipStream_t st = (hipStream_t)stream;
+    // grid.z is limited to 65535: loop over slices of chunks
+    for (int b0 = 0; b0 < nchunks; b0 += 65535) {
+        const int nb = min(65535, nchunks - b0);
+        const dim3 grid((c + 255) / 256, max_splits, nb);
+        hipLaunchKernelGGL(stats_pool_kernel, grid, dim3(256), 0, st, h, (long)ldh, c, row_start + b0, row_len + b0,
+                           split_rows, max_splits, eps, out + (size_t)b0 * 2 * c,
+                           (float *)workspace + (size_t)b0 * max_splits * 2 * c);
+        int rc = check_launch("stats_pool_kernel");
+        if (rc) return rc;
+        if (max_splits > 1) {
+            hipLaunchKernelGGL(stats_pool_merge_kernel, dim3((c + 255) / 256, nb), dim3(256), 0, st,
+                               (const float *)workspace + (size_t)b0 * max_splits * 2 * c, c, row_len + b0, split_rows,
+                               max_splits, eps, out + (size_t)b0 * 2 * c);
+            rc = check_launch("stats_pool_merge_kernel");
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+int xv_chunk_average_f32(const float *e, const int32_t *seg_start, const int32_t *chunk_len, int nutts, int dim, float *out,
+                         void *stream)
+{
+    if (nutts <= 0) return 0;
+    if (!e || !seg_start || !chunk_len || !out || dim <= 0) return fail(XV_ERR_BAD_ARG, "chunk_average: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int u0 = 0; u0 < nutts; u0 += 65535) {
+        const int nu = min(65535, nutts - u0);
+        hipLaunchKernelGGL(chunk_average_kernel, dim3((dim + 255) / 256, nu), dim3(256), 0, st, e, seg_start + u0, chunk_len,
+                           dim, out + (size_t)u0 * dim);
+        int rc = check_launch("chunk_average_kernel");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

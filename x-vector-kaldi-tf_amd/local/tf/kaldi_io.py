@@ -1,0 +1,404 @@
+"""Kaldi table I/O for the MI355X x-vector extractor (drop-in for the reference module of the
+same name on the extraction path).
+
+Mirrors the subset of ``local/tf/kaldi_io.py`` of BUTSpeechFIT/x-vector-kaldi-tf that
+``Model.make_embedding`` / ``extract_embedding.py`` touch -- same function names, argument
+meaning and exceptions -- re-implemented around a buffered exact-read helper and vectorised
+NumPy decoding (the reference reads keys a byte at a time and decodes compressed matrices column
+by column in Python):
+
+=====================  =========================================  ===========================
+here                   replaces (reference file:line)              notes
+=====================  =========================================  ===========================
+open_or_fd             local/tf/kaldi_io.py:50-80                 ark:/scp: prefixes, :offset,
+                                                                   ``cmd |`` / ``| cmd`` pipes, .gz
+popen                  local/tf/kaldi_io.py:84-117                SubprocessFailed on rc>0
+read_key               local/tf/kaldi_io.py:120-133
+read_mat_ark/read_mat  local/tf/kaldi_io.py:372-410
+_read_mat_binary       local/tf/kaldi_io.py:413-437               FM / DM / CM (+CM2, CM3)
+_read_mat_ascii        local/tf/kaldi_io.py:440-452
+_read_compressed_mat   local/tf/kaldi_io.py:455-502               float32 arithmetic as Kaldi
+read_mat_scp           local/tf/kaldi_io.py:350-369
+write_mat              local/tf/kaldi_io.py:506-542
+read_vec_flt[_ark|_scp] local/tf/kaldi_io.py:225-305
+write_vec_flt          local/tf/kaldi_io.py:309-343               'FV '/'DV ' framing
+=====================  =========================================  ===========================
+
+Int vectors, posteriors, confusion-network times and segment bool-vectors (reference lines
+139-218, 553-697) are ASR types the x-vector path never reads: out of scope.
+"""
+import gzip
+import io
+import re
+import struct
+import subprocess
+import threading
+
+import numpy as np
+
+__all__ = ["open_or_fd", "popen", "TableWriter", "read_key", "read_mat", "read_mat_ark", "read_mat_scp", "write_mat",
+           "read_vec_flt", "read_vec_flt_ark", "read_vec_flt_scp", "write_vec_flt",
+           "UnsupportedDataType", "UnknownVectorHeader", "UnknownMatrixHeader", "BadSampleSize",
+           "BadInputFormat", "SubprocessFailed"]
+
+
+class UnsupportedDataType(Exception):
+    pass
+
+
+class UnknownVectorHeader(Exception):
+    pass
+
+
+class UnknownMatrixHeader(Exception):
+    pass
+
+
+class BadSampleSize(Exception):
+    pass
+
+
+class BadInputFormat(Exception):
+    pass
+
+
+class SubprocessFailed(Exception):
+    pass
+
+
+_SPECIFIER = re.compile(r"^(ark|scp)(,scp|,b|,t|,n?f|,n?p|,b?o|,n?s|,n?cs)*:")
+_OFFSET = re.compile(r":[0-9]+$")
+_KEY_OK = re.compile(r"^[\.\/a-zA-Z0-9_-]+$")
+
+
+# ------------------------------------------------------------------------------------------------
+# opening things
+# ------------------------------------------------------------------------------------------------
+def popen(cmd, mode="rb"):
+    """Run ``cmd`` through the shell and return the pipe end matching ``mode``.  A helper thread
+    waits for the child and raises SubprocessFailed when it exits with a positive status."""
+    if not isinstance(cmd, str):
+        raise TypeError("invalid cmd type (%s, expected string)" % type(cmd))
+    if mode not in ("r", "w", "rb", "wb"):
+        raise ValueError("invalid mode %s" % mode)
+    reading = mode[0] == "r"
+    proc = subprocess.Popen(cmd, shell=True,
+                            stdout=subprocess.PIPE if reading else None,
+                            stdin=None if reading else subprocess.PIPE)
+
+    def _reap():
+        rc = proc.wait()
+        if rc > 0:
+            raise SubprocessFailed("cmd %s returned %d !" % (cmd, rc))
+
+    threading.Thread(target=_reap, daemon=True).start()
+    end = proc.stdout if reading else proc.stdin
+    return io.TextIOWrapper(end) if len(mode) == 1 else end
+
+
+def open_or_fd(file, mode="rb"):
+    """Open a Kaldi rxfilename / wxfilename (or pass an already opened stream through).
+
+    Accepts an optional ``ark:`` / ``scp:`` (with options) prefix, ``path:offset``, a trailing
+    ``|`` (read from command), a leading ``|`` (write to command) and ``.gz`` files."""
+    if not isinstance(file, str):
+        return file                       # already a stream
+    offset = None
+    if _SPECIFIER.search(file):
+        file = file.split(":", 1)[1]
+    if _OFFSET.search(file):
+        file, offset = file.rsplit(":", 1)
+    if file.endswith("|"):
+        fd = popen(file[:-1], "rb")
+    elif file.startswith("|"):
+        fd = popen(file[1:], "wb")
+    elif file.rsplit(".", 1)[-1] == "gz":
+        fd = gzip.open(file, mode)
+    else:
+        fd = open(file, mode)
+    if offset is not None:
+        fd.seek(int(offset))
+    return fd
+
+
+def _read_exact(fd, n):
+    """fd.read(n) that tolerates short reads from pipes; returns fewer bytes only at EOF."""
+    buf = fd.read(n)
+    if buf is None:
+        buf = b""
+    if len(buf) == n or not buf:
+        return buf
+    parts = [buf]
+    got = len(buf)
+    while got < n:
+        more = fd.read(n - got)
+        if not more:
+            break
+        parts.append(more)
+        got += len(more)
+    return b"".join(parts)
+
+
+# ------------------------------------------------------------------------------------------------
+# keys
+# ------------------------------------------------------------------------------------------------
+def read_key(fd):
+    """Next utterance key of an ark stream, or None at end of stream."""
+    chars = []
+    while True:
+        ch = fd.read(1)
+        if not ch or ch == b" ":
+            break
+        chars.append(ch)
+    key = b"".join(chars).decode().strip()
+    if key == "":
+        return None
+    assert _KEY_OK.match(key) is not None, "malformed key %r" % key
+    return key
+
+
+# ------------------------------------------------------------------------------------------------
+# float vectors
+# ------------------------------------------------------------------------------------------------
+def _read_vec_flt_binary(fd):
+    tag = _read_exact(fd, 3).decode()
+    if tag == "FV ":
+        dt = np.dtype("<f4")
+    elif tag == "DV ":
+        dt = np.dtype("<f8")
+    else:
+        raise UnknownVectorHeader("The header contained '%s'" % tag)
+    assert _read_exact(fd, 1) == b"\x04"
+    (dim,) = struct.unpack("<i", _read_exact(fd, 4))
+    return np.frombuffer(_read_exact(fd, dim * dt.itemsize), dtype=dt)
+
+
+def read_vec_flt(file_or_fd):
+    """One Kaldi float vector, binary ('FV '/'DV ') or text ('[ 1 2 3 ]')."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        flag = _read_exact(fd, 2)
+        if flag == b"\x00B":
+            return _read_vec_flt_binary(fd)
+        toks = (flag + fd.readline()).decode().strip().split()
+        toks = [t for t in toks if t not in ("[", "]")]
+        return np.array(toks, dtype=float)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_vec_flt_ark(file_or_fd):
+    """Generator of (key, vector) over an ark file / stream."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        key = read_key(fd)
+        while key:
+            yield key, read_vec_flt(fd)
+            key = read_key(fd)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_vec_flt_scp(file_or_fd):
+    """Generator of (key, vector) following a Kaldi scp."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        for line in fd:
+            if isinstance(line, bytes):
+                line = line.decode()
+            key, rxfile = line.strip("\n").split(" ", 1)
+            yield key, read_vec_flt(rxfile.strip())
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def _write_header(fd, key, tag):
+    if key != "":
+        fd.write((key + " ").encode())
+        if hasattr(fd, "note_key"):
+            fd.note_key(key)              # TableWriter: the scp offset points just past "key "
+    fd.write(b"\x00B" + tag)
+
+
+class TableWriter(object):
+    """Write-only stream producing an ark file AND its scp index (``key path:offset`` per record),
+    i.e. what the reference obtains by piping into Kaldi's ``copy-vector ark:- ark,scp:A,S``
+    (local/tf/extract_xvectors.sh:74-88) -- without needing the Kaldi binary.  ``scp_ark_name`` is the
+    ark path to print inside the scp (defaults to ``ark_path``)."""
+
+    mode = "wb"
+
+    def __init__(self, ark_path, scp_path, scp_ark_name=None):
+        self._ark = open(ark_path, "wb")
+        self._scp = open(scp_path, "wt")
+        self._name = scp_ark_name or ark_path
+        self._pos = 0
+
+    def write(self, data):
+        self._ark.write(data)
+        self._pos += len(data)
+
+    def note_key(self, key):
+        self._scp.write("%s %s:%d\n" % (key, self._name, self._pos))
+
+    def close(self):
+        self._ark.close()
+        self._scp.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def write_vec_flt(file_or_fd, v, key=""):
+    """Write a binary Kaldi vector: ``key␠`` + ``\\0B`` + ``FV␠``|``DV␠`` + ``\\4`` + uint32 dim +
+    little-endian payload."""
+    fd = open_or_fd(file_or_fd, mode="wb")
+    try:
+        v = np.asarray(v)
+        if v.dtype == np.float32:
+            tag = b"FV "
+        elif v.dtype == np.float64:
+            tag = b"DV "
+        else:
+            raise UnsupportedDataType("'%s', please use 'float32' or 'float64'" % v.dtype)
+        _write_header(fd, key, tag)
+        fd.write(b"\x04" + struct.pack("<I", v.shape[0]))
+        fd.write(np.ascontiguousarray(v).astype(v.dtype.newbyteorder("<"), copy=False).tobytes())
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# float matrices
+# ------------------------------------------------------------------------------------------------
+_U16_STEP = np.float32(1.52590218966964e-05)     # 1/65535, the constant Kaldi's compressed-matrix uses
+
+
+def _read_compressed_mat(fd, fmt):
+    """Kaldi CompressedMatrix.  'CM ' = per-column percentile headers + column-major uint8 with a
+    3-segment piecewise-linear decode; 'CM2' = row-major uint16; 'CM3' = row-major uint8.
+    All arithmetic in float32, as Kaldi (and the reference under NumPy>=2) evaluates it."""
+    hdr = _read_exact(fd, 16)
+    gmin, grange = np.frombuffer(hdr[:8], dtype="<f4")
+    rows, cols = (int(v) for v in np.frombuffer(hdr[8:], dtype="<i4"))
+    if fmt == "CM ":
+        pct = np.frombuffer(_read_exact(fd, cols * 8), dtype="<u2").reshape(cols, 4)
+        q = (gmin + grange * _U16_STEP * pct.astype(np.float32)).astype(np.float32)   # [cols,4]
+        p0, p25, p75, p100 = (q[:, i:i + 1] for i in range(4))
+        u = np.frombuffer(_read_exact(fd, cols * rows), dtype=np.uint8).reshape(cols, rows)
+        uf = u.astype(np.float32)
+        lo = p0 + (p25 - p0) / np.float32(64.) * uf
+        mid = p25 + (p75 - p25) / np.float32(128.) * (uf - np.float32(64.))
+        hi = p75 + (p100 - p75) / np.float32(63.) * (uf - np.float32(192.))
+        out = np.where(u <= 64, lo, np.where(u <= 192, mid, hi)).astype(np.float32)
+        return out.T
+    if fmt == "CM2":
+        u = np.frombuffer(_read_exact(fd, rows * cols * 2), dtype="<u2").reshape(rows, cols)
+        return (gmin + grange * _U16_STEP * u.astype(np.float32)).astype(np.float32)
+    if fmt == "CM3":
+        u = np.frombuffer(_read_exact(fd, rows * cols), dtype=np.uint8).reshape(rows, cols)
+        return (gmin + grange * np.float32(1.0 / 255.0) * u.astype(np.float32)).astype(np.float32)
+    raise UnknownMatrixHeader("The header contained '%s'" % fmt)
+
+
+def _read_mat_binary(fd):
+    tag = _read_exact(fd, 3).decode()
+    if tag.startswith("CM"):
+        return _read_compressed_mat(fd, tag)
+    if tag == "FM ":
+        dt = np.dtype("<f4")
+    elif tag == "DM ":
+        dt = np.dtype("<f8")
+    else:
+        raise UnknownMatrixHeader("The header contained '%s'" % tag)
+    dims = _read_exact(fd, 10)
+    _, rows, _, cols = struct.unpack("<bibi", dims)
+    payload = _read_exact(fd, rows * cols * dt.itemsize)
+    return np.frombuffer(payload, dtype=dt).reshape(rows, cols)
+
+
+def _read_mat_ascii(fd):
+    rows = []
+    while True:
+        line = fd.readline()
+        if isinstance(line, bytes):
+            line = line.decode()
+        if len(line) == 0:
+            raise BadInputFormat            # unexpected end of stream
+        toks = line.split()
+        if not toks:
+            continue
+        closing = toks[-1] == "]"
+        if closing:
+            toks = toks[:-1]
+        rows.append(np.array(toks, dtype="float32"))
+        if closing:
+            return np.vstack(rows)
+
+
+def read_mat(file_or_fd):
+    """One Kaldi matrix, binary (FM/DM/CM*) or text."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        flag = _read_exact(fd, 2)
+        if flag == b"\x00B":
+            return _read_mat_binary(fd)
+        assert flag == b" ["
+        return _read_mat_ascii(fd)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_mat_ark(file_or_fd):
+    """Generator of (key, matrix) over an ark file / stream."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        key = read_key(fd)
+        while key:
+            yield key, read_mat(fd)
+            key = read_key(fd)
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def read_mat_scp(file_or_fd):
+    """Generator of (key, matrix) following a Kaldi scp (``key path[:offset]`` per line)."""
+    fd = open_or_fd(file_or_fd)
+    try:
+        for line in fd:
+            if isinstance(line, bytes):
+                line = line.decode()
+            key, rxfile = line.strip("\n").split(" ", 1)
+            yield key, read_mat(rxfile.strip())
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def write_mat(file_or_fd, m, key=""):
+    """Write a binary Kaldi matrix ('FM '/'DM ', row-major)."""
+    fd = open_or_fd(file_or_fd, mode="wb")
+    try:
+        m = np.asarray(m)
+        if m.dtype == np.float32:
+            tag = b"FM "
+        elif m.dtype == np.float64:
+            tag = b"DM "
+        else:
+            raise UnsupportedDataType("'%s', please use 'float32' or 'float64'" % m.dtype)
+        _write_header(fd, key, tag)
+        fd.write(b"\x04" + struct.pack("<I", m.shape[0]) + b"\x04" + struct.pack("<I", m.shape[1]))
+        fd.write(np.ascontiguousarray(m).astype(m.dtype.newbyteorder("<"), copy=False).tobytes())
+    finally:
+        if fd is not file_or_fd:
+            fd.close()

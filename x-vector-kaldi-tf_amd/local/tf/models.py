@@ -1,0 +1,196 @@
+"""MI355X-native twin of the reference's ``local/tf/models.py`` for the extraction path.
+
+Same class names, constructor and method signatures as BUTSpeechFIT/x-vector-kaldi-tf so that
+``local/tf/train_dnn.py`` (``eval('models.%s()' % name).build_model(...)``, train_dnn.py:492-494) and
+``local/tf/extract_embedding.py`` (``Model().make_embedding(...)``, extract_embedding.py:129-132) can
+import this module unchanged:
+
+=======================  ====================================  =======================================
+method                   reference                              here
+=======================  ====================================  =======================================
+build_model              local/tf/models.py:25-128 (+variants)  reference initialisers -> model dir
+save_model               local/tf/models.py:130-141             weight dict -> model dir (+ ``done``)
+load_model               local/tf/models.py:143-162             model dir -> weights resident in HBM
+make_embedding           local/tf/models.py:356-432             ark stream -> batched HIP forward -> ark
+get_models_weights       local/tf/models.py:180-214             {tf variable name: ndarray}
+print_models_params      local/tf/models.py:171-178
+train_one_iteration/eval local/tf/models.py:216-354             NOT on this path
+=======================  ====================================  =======================================
+
+There is no TensorFlow and no CPU path: the forward graph runs as hand-written gfx950 kernels behind
+``libxvector_hip.so`` (include/xvector_hip.h); without that library or without a GPU every compute
+method raises.  ``use_gpu`` is accepted for signature compatibility (the reference's shell driver always
+passes ``--use-gpu=no``, extract_xvectors.sh:76,85) and ignored: the extractor always runs on the GPU
+selected by ``XVECTOR_DEVICE`` / ``LOCAL_RANK`` (default ``cuda:0``).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _PKG_ROOT not in sys.path:
+    sys.path.insert(0, _PKG_ROOT)
+
+import kaldi_io  # noqa: E402  (the sibling module, as in the reference)
+from xvector_amd import engine, synthetic, topology, weights as wio  # noqa: E402
+
+VAR2STD_EPSILON = topology.VAR2STD_EPSILON        # models.py:16
+
+
+def _device():
+    dev = os.environ.get("XVECTOR_DEVICE")
+    if dev:
+        return dev
+    return "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+
+
+class Model(object):
+    """Default topology: 5 frame-level layers [512,512,512,512,1536], kernels [5,5,7,1,1],
+    statistics pooling, 2 segment-level layers (models.py:27-29)."""
+
+    window_frames = 1 << 20          # utterances are read from the stream in windows of ~1M frames
+    max_batch_rows = 131072
+
+    def __init__(self):
+        self.graph = None            # kept for attribute compatibility (models.py:22-23)
+        self.device_model = None
+        self.num_classes = None
+
+    # -- topology --------------------------------------------------------------------------------
+    @classmethod
+    def class_topology(cls):
+        return topology.get(cls.__name__)
+
+    # -- build / save / load ---------------------------------------------------------------------
+    def build_model(self, num_classes, input_feature_dim, output_dir, logger=None):
+        if logger is not None:
+            logger.info("Start building the model ...")
+        topo = self.class_topology()
+        self.num_classes = num_classes
+        seed = int(os.environ.get("XVECTOR_INIT_SEED", "0"))
+        w = synthetic.reference_init(topo, input_feature_dim, num_classes, seed=seed)
+        self.save_model(dict(weights=w, topology=topo, model_class=type(self).__name__,
+                             num_classes=num_classes, feat_dim=input_feature_dim), output_dir, logger)
+        if logger is not None:
+            logger.info("Building finished.")
+
+    @staticmethod
+    def save_model(sess, output_dir, logger):
+        """``sess`` is the TF session in the reference (models.py:131); here it is the state dict
+        {weights, topology, model_class, num_classes, feat_dim}."""
+        if logger is not None:
+            logger.info("Start saving graph ...")
+        wio.save_model_dir(output_dir, sess["weights"], sess["topology"], sess["model_class"],
+                           sess["num_classes"], sess["feat_dim"])
+        if logger is not None:
+            logger.info("Graph saved in path: %s" % os.path.join(output_dir, "model"))
+
+    def load_model(self, sess, input_dir, logger):
+        """Load ``input_dir`` and make the weights resident on the GPU.  ``sess`` (a TF session in the
+        reference, models.py:143) is accepted and ignored."""
+        if logger is not None:
+            logger.info("Start loading graph ...")
+        w, meta = wio.load_model_dir(input_dir)
+        self.meta = meta
+        self.num_classes = meta["num_classes"]
+        self.embedding_index = int(os.environ.get("XVECTOR_EMBEDDING_INDEX", "0"))   # models.py:159-160
+        self.device_model = engine.DeviceModel(w, meta["topology"], _device(), self.embedding_index)
+        if logger is not None:
+            logger.info("Graph restored from path: %s" % input_dir)
+
+    def create_one_hot_output_matrix(self, labels):          # models.py:164-169
+        one_hot = np.zeros((len(labels), self.num_classes), dtype=np.int32)
+        one_hot[np.arange(len(labels)), np.asarray(labels, dtype=np.int64)] = 1
+        return one_hot
+
+    def print_models_params(self, input_dir, logger=None):
+        w, meta = wio.load_model_dir(input_dir)
+        print('\n\nThe components are:\n')
+        for name in wio.expected_names(meta["topology"]):
+            if name.rsplit('/', 1)[-1] not in ("mean:0", "variance:0"):       # trainable variables only
+                print(name)
+        print('\n')
+
+    def get_models_weights(self, input_dir, logger=None):
+        w, _ = wio.load_model_dir(input_dir)
+        return w
+
+    # -- not on the extraction path ----------------------------------------------------------------
+    def train_one_iteration(self, data_loader, args, logger):
+        raise NotImplementedError("training (models.py:216-305) is outside the extraction hot path of this build")
+
+    def eval(self, data_loader, input_dir, use_gpu, logger):
+        raise NotImplementedError("diagnostics (models.py:307-354) are outside the extraction hot path of this build")
+
+    # -- the hot path ------------------------------------------------------------------------------
+    def make_embedding(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger):
+        start_time = time.time()
+        self.load_model(None, model_dir, logger)
+        ex = engine.Extractor(self.device_model, min_chunk_size, chunk_size, max_batch_rows=self.max_batch_rows)
+
+        total_segments = 0
+        num_fail = 0
+        num_success = 0
+        compute_time = 0.0
+
+        def flush(keys, mats):
+            nonlocal num_fail, num_success, compute_time
+            t0 = time.time()
+            vecs = ex.extract(mats)
+            compute_time += time.time() - t0
+            for key, mat, vec in zip(keys, mats, vecs):
+                if vec is None:
+                    if mat.shape[0] == 0:
+                        logger.warning("Zero-length utterance: '%s'" % key)
+                    else:
+                        logger.warning("Minimum chunk size of %d is greater than the number of rows in utterance: %s" %
+                                       (min_chunk_size, key))
+                    num_fail += 1
+                    continue
+                kaldi_io.write_vec_flt(output_stream, vec, key=key)
+                num_success += 1
+
+        keys, mats, frames = [], [], 0
+        for key, mat in kaldi_io.read_mat_ark(input_stream):
+            total_segments += 1
+            keys.append(key)
+            mats.append(np.ascontiguousarray(mat, dtype=np.float32))
+            frames += mat.shape[0]
+            if frames >= self.window_frames:
+                flush(keys, mats)
+                keys, mats, frames = [], [], 0
+        if keys:
+            flush(keys, mats)
+
+        st = ex.stats
+        logger.info("Processed %d features of average size %d frames. Done %d and failed %d" %
+                    (total_segments, st["frames"] / max(total_segments, 1), num_success, num_fail))
+        logger.info("Total time for neural network computations is %.2f minutes." % (compute_time / 60.0))
+        logger.info("Elapsed time for extracting whole embeddings is %.2f minutes." %
+                    ((time.time() - start_time) / 60.0))
+
+
+class ModelWithoutDropout(Model):                     # models.py:436
+    pass
+
+
+class ModelWithoutDropoutTdnn(Model):                 # models.py:538  (dilated)
+    pass
+
+
+class ModelWithoutDropoutPRelu(Model):                # models.py:643
+    pass
+
+
+class ModelL2LossWithoutDropoutPRelu(Model):          # models.py:746
+    pass
+
+
+class ModelL2LossWithoutDropoutLRelu(Model):          # models.py:866
+    pass
+
+
+class ModelL2LossWithoutDropoutReluHeInit(Model):     # models.py:1118
+    pass

@@ -1,0 +1,273 @@
+"""Host side of the extraction hot path: chunk planning, ragged batching and the kernel sequence.
+
+What the reference does per utterance inside ``Model.make_embedding`` (local/tf/models.py:373-423) --
+validate the length, cut into chunks, one ``sess.run`` per chunk at batch 1, length-weighted average --
+is done here for MANY utterances at once: chunks are packed into one ragged ``[R, C]`` matrix with zero
+gap rows between them (see include/xvector_hip.h) and pushed through
+
+    5 x xv_tdnn_layer_f32  ->  xv_stats_pool_f32  ->  xv_fc_f32 (embed_layer-0; optional embed_layer-1)
+    ->  xv_chunk_average_f32
+
+PyTorch is used for device memory, streams and H2D/D2H copies only; every arithmetic step of the path
+is one of the HIP kernels behind the C ABI.
+"""
+import math
+
+import numpy as np
+
+from . import hiplib
+from . import topology as tp
+
+
+# ------------------------------------------------------------------------------------------------
+# chunk planning -- local/tf/models.py:377-407
+# ------------------------------------------------------------------------------------------------
+def plan_chunks(num_rows, min_chunk_size, chunk_size):
+    """[(start, length), ...] of the chunks the reference would run for an utterance of ``num_rows``
+    frames, or None when it rejects the utterance (zero length / shorter than ``min_chunk_size``,
+    models.py:378-387: a warning, nothing is written for the key)."""
+    if num_rows == 0 or num_rows < min_chunk_size:
+        return None
+    this_chunk = chunk_size
+    if num_rows < chunk_size:            # models.py:389-392
+        this_chunk = num_rows
+    elif chunk_size == -1:               # models.py:393-394
+        this_chunk = num_rows
+    num_chunks = int(math.ceil(num_rows / float(this_chunk)))       # models.py:396
+    plan = []
+    for i in range(num_chunks):
+        length = min(this_chunk, num_rows - i * this_chunk)          # models.py:405 (tail is NOT shifted back)
+        if length < min_chunk_size:                                   # models.py:406-407
+            continue
+        plan.append((i * this_chunk, length))
+    return plan
+
+
+class BatchLayout(object):
+    """Row layout of one ragged batch: chunk b owns rows [row_start[b], row_start[b]+row_len[b]);
+    ``gap`` zero rows precede the first chunk and follow every chunk."""
+
+    def __init__(self, lengths, gap):
+        lengths = np.asarray(lengths, dtype=np.int64)
+        self.gap = int(gap)
+        self.row_len = lengths.astype(np.int32)
+        starts = np.empty(len(lengths), dtype=np.int64)
+        if len(lengths):
+            starts[0] = gap
+            np.cumsum(lengths[:-1] + gap, out=starts[1:])
+            starts[1:] += gap
+        self.row_start = starts.astype(np.int32)
+        self.rows = int(gap + (lengths + gap).sum())
+        self.nchunks = len(lengths)
+        self.max_len = int(lengths.max()) if len(lengths) else 0
+        assert self.rows < 2 ** 31
+
+    def row_valid(self):
+        m = np.zeros(self.rows, dtype=np.uint8)
+        for s, n in zip(self.row_start, self.row_len):
+            m[s:s + n] = 1
+        return m
+
+    def pack(self, mats, out):
+        """Copy the chunk matrices into ``out[rows, F]`` (gap rows zeroed)."""
+        out[:self.rows] = 0
+        for s, m in zip(self.row_start, mats):
+            out[s:s + m.shape[0]] = m
+
+
+# ------------------------------------------------------------------------------------------------
+# device model
+# ------------------------------------------------------------------------------------------------
+class DeviceModel(object):
+    """Weights of one model directory resident in HBM in kernel layout, plus reusable activation
+    buffers.  ``weights`` is keyed by the TF variable names (weights.py)."""
+
+    POOL_SPLIT_ROWS = 512
+
+    def __init__(self, weights, topo, device="cuda:0", embedding_index=0):
+        import torch
+        hiplib.require_gpu()
+        self.torch = torch
+        self.device = torch.device(device)
+        self.topo = topo
+        self.embedding_index = int(embedding_index)
+        self.gap = tp.max_halo(topo)
+        self.act = tp.ACT_CODES[topo.get("activation", "relu")]
+        self.feat_dim = int(weights["frame_level_info_layer-0/w:0"].shape[1])
+        self.layers = []
+        with torch.cuda.device(self.device):
+            for i, (k, d) in enumerate(zip(topo["kernel_sizes"], topo["dilations"])):
+                sc = "frame_level_info_layer-%d" % i
+                w = weights[sc + "/w:0"]
+                assert w.shape[0] == k, "kernel size mismatch in %s" % sc
+                self.layers.append(self._prep(weights, sc, w.reshape(-1, w.shape[2]), k, d))
+            self.embed = []
+            for j in range(len(topo["embedding_sizes"])):
+                sc = "embed_layer-%d" % j
+                self.embed.append(self._prep(weights, sc, weights[sc + "/w:0"], 1, 1))
+            torch.cuda.synchronize()
+        self.pooled_dim = 2 * self.layers[-1]["cout"]
+        self.embed_dim = self.embed[self.embedding_index]["cout"]
+        self._cap_rows = 0
+        self._cap_chunks = 0
+        self._pool_ws = None
+
+    def _dev(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def _prep(self, weights, scope, w2d, k, d):
+        layer = dict(K=k, dil=d, cin=w2d.shape[0] // k, cout=w2d.shape[1])
+        layer["wp"] = hiplib.pack_weights(self._dev(w2d))
+        layer["bias"] = self._dev(weights[scope + "/b:0"])
+        layer["scale"], layer["shift"] = hiplib.fold_bn(*(self._dev(weights["%s/%s:0" % (scope, n)])
+                                                          for n in ("gamma", "beta", "mean", "variance")),
+                                                        tp.BN_EPSILON)
+        layer["alpha"] = None
+        if self.act == tp.ACT_LRELU:
+            layer["alpha"] = self._dev(np.array([self.topo.get("lrelu_alpha", 0.2)]))
+        elif self.act == tp.ACT_PRELU:
+            layer["alpha"] = self._dev(weights[scope + "/prelu/prelu:0"])
+        return layer
+
+    # -- buffers ----------------------------------------------------------------------------------
+    def reserve(self, rows, nchunks, max_len=None):
+        """(Re)allocate activation buffers for batches of up to ``rows`` rows / ``nchunks`` chunks."""
+        torch = self.torch
+        if rows > self._cap_rows:
+            self._cap_rows = int(rows)
+            widths = sorted(set(l["cout"] for l in self.layers[:-1]))
+            wmax = max(widths) if widths else self.layers[-1]["cout"]
+            self._ping = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
+            self._pong = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
+            self._last = torch.empty((self._cap_rows, self.layers[-1]["cout"]), dtype=torch.float32, device=self.device)
+        if nchunks > self._cap_chunks:
+            self._cap_chunks = int(nchunks)
+            self._pooled = torch.empty((self._cap_chunks, self.pooled_dim), dtype=torch.float32, device=self.device)
+            self._e0 = torch.empty((self._cap_chunks, self.embed[0]["cout"]), dtype=torch.float32, device=self.device)
+            self._a0 = torch.empty_like(self._e0)
+            self._pool_ws = None
+        if max_len is not None:
+            need = hiplib.stats_pool_workspace_bytes(self.layers[-1]["cout"], self._cap_chunks, max_len, self.POOL_SPLIT_ROWS)
+            if need and (self._pool_ws is None or self._pool_ws.numel() * 4 < need):
+                self._pool_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+
+    def _view(self, buf, rows, width):
+        # contiguous [rows, width] view on the front of a flat buffer
+        return buf.view(-1)[: rows * width].view(rows, width)
+
+    # -- the kernel sequence ----------------------------------------------------------------------
+    def forward_packed(self, x, row_start, row_len, row_valid, nchunks, max_len, out):
+        """x[R,F] (gap rows zero), int32 row_start/row_len[nchunks], uint8 row_valid[R] -> writes the
+        chunk embeddings into out[nchunks, E].  All arguments are device tensors; nothing is allocated
+        when ``reserve`` was called with sufficient capacity."""
+        R = x.shape[0]
+        self.reserve(R, nchunks, max_len)
+        h = x
+        bufs = (self._ping, self._pong)
+        for i, L in enumerate(self.layers):
+            last = i == len(self.layers) - 1
+            y = self._view(self._last if last else bufs[i & 1], R, L["cout"])
+            hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
+                              row_valid, y)
+            h = y
+        pooled = self._pooled[:nchunks]
+        hiplib.stats_pool(h, row_start, row_len, nchunks, max_len, self.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON, pooled,
+                          self._pool_ws)
+        E0 = self.embed[0]
+        if self.embedding_index == 0:
+            # embed_layer-0/scores IS the x-vector (local/tf/models.py:159,414): pre-activation output
+            hiplib.fc(pooled, E0["wp"], E0["bias"], None, None, tp.ACT_NONE, None, None, out)
+        else:
+            a0 = self._a0[:nchunks]
+            hiplib.fc(pooled, E0["wp"], E0["bias"], E0["scale"], E0["shift"], self.act, E0["alpha"], a0, None)
+            E1 = self.embed[1]
+            hiplib.fc(a0, E1["wp"], E1["bias"], None, None, tp.ACT_NONE, None, None, out)
+        return out
+
+    def intermediates_packed(self, x, row_valid):
+        """Debug/test helper: per-layer outputs [R, Cout] for a packed batch (allocates)."""
+        torch = self.torch
+        outs = []
+        h = x
+        for L in self.layers:
+            y = torch.empty((x.shape[0], L["cout"]), dtype=torch.float32, device=self.device)
+            hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
+                              row_valid, y)
+            outs.append(y)
+            h = y
+        return outs
+
+
+# ------------------------------------------------------------------------------------------------
+# extractor: utterances in, x-vectors out
+# ------------------------------------------------------------------------------------------------
+class Extractor(object):
+    """Batches the chunk plans of many utterances (length-bucketed), runs them and averages per
+    utterance.  Output order == input order, rejected utterances yield ``None`` vectors."""
+
+    def __init__(self, model, min_chunk_size, chunk_size, max_batch_rows=131072, max_batch_chunks=4096):
+        self.model = model
+        self.min_chunk_size = int(min_chunk_size)
+        self.chunk_size = int(chunk_size)
+        self.max_batch_rows = int(max_batch_rows)
+        self.max_batch_chunks = int(max_batch_chunks)
+        self.stats = dict(batches=0, chunks=0, frames=0, rows=0)
+        self._pin = None
+
+    def _pinned(self, rows, feat):
+        torch = self.model.torch
+        if self._pin is None or self._pin.shape[0] < rows or self._pin.shape[1] != feat:
+            self._pin = torch.empty((max(rows, 1024), feat), dtype=torch.float32).pin_memory()
+        return self._pin
+
+    def extract(self, mats):
+        """mats: list of float32 [T, F] arrays.  Returns a list of float32[E] (or None) per input."""
+        torch = self.model.torch
+        model = self.model
+        dev = model.device
+        plans = [plan_chunks(m.shape[0], self.min_chunk_size, self.chunk_size) for m in mats]
+        # chunk table, utterances ordered by length so that batches are length-homogeneous
+        order = sorted((i for i, p in enumerate(plans) if p), key=lambda i: mats[i].shape[0])
+        c_utt, c_start, c_len = [], [], []
+        seg_start = [0]
+        for u in order:
+            for s, n in plans[u]:
+                c_utt.append(u); c_start.append(s); c_len.append(n)
+            seg_start.append(len(c_utt))
+        nch = len(c_utt)
+        results = [None] * len(mats)
+        if nch == 0:
+            return results
+        gap = model.gap
+        with torch.cuda.device(dev):
+            E_all = torch.empty((nch, model.embed_dim), dtype=torch.float32, device=dev)
+            b0 = 0
+            while b0 < nch:
+                rows, b1 = gap, b0
+                while b1 < nch and b1 - b0 < self.max_batch_chunks and (b1 == b0 or rows + c_len[b1] + gap <= self.max_batch_rows):
+                    rows += c_len[b1] + gap
+                    b1 += 1
+                layout = BatchLayout(c_len[b0:b1], gap)
+                feat = mats[c_utt[b0]].shape[1]
+                pin = self._pinned(layout.rows, feat)
+                host = pin.numpy()
+                layout.pack([mats[c_utt[i]][c_start[i]:c_start[i] + c_len[i]] for i in range(b0, b1)], host)
+                x = pin[:layout.rows].to(dev, non_blocking=True)
+                rs = torch.from_numpy(layout.row_start).to(dev, non_blocking=True)
+                rl = torch.from_numpy(layout.row_len).to(dev, non_blocking=True)
+                rv = torch.from_numpy(layout.row_valid()).to(dev, non_blocking=True)
+                model.forward_packed(x, rs, rl, rv, layout.nchunks, layout.max_len, E_all[b0:b1])
+                torch.cuda.current_stream().synchronize()      # the pinned staging buffer is reused next batch
+                self.stats["batches"] += 1
+                self.stats["chunks"] += layout.nchunks
+                self.stats["frames"] += int(layout.row_len.sum())
+                self.stats["rows"] += layout.rows
+                b0 = b1
+            seg = torch.tensor(seg_start, dtype=torch.int32, device=dev)
+            cl = torch.tensor(c_len, dtype=torch.int32, device=dev)
+            out = torch.empty((len(order), model.embed_dim), dtype=torch.float32, device=dev)
+            hiplib.chunk_average(E_all, seg, cl, len(order), out)
+            host_out = out.cpu().numpy()
+        for j, u in enumerate(order):
+            results[u] = host_out[j]
+        return results

@@ -1,0 +1,140 @@
+"""Seeded synthetic weights and utterances (data generation for tests and bench.py; there is no
+network for checkpoints or corpora).  NOT a compute path: the BN calibration below is plain NumPy
+used once to manufacture "trained-like" running statistics; the extractor never calls it.
+
+* ``reference_init``      -- the reference's initialisers: ``truncated_normal(stddev=0.1)`` weights,
+                             ``b = 0.1``, BN gamma=1 beta=0 mean=0 variance=1, Xavier output layer
+                             (local/tf/models.py:56-58,82-84,98-100; local/tf/tf_block.py:10-14).
+* ``trained_like``        -- the same shapes with fan-in-scaled weights, non-trivial gamma/beta and BN
+                             running statistics calibrated on a random 2000-frame input, so that BN is
+                             exercised and activations stay O(1) through the stack.
+* ``make_utterances``     -- ``float32 [T,F]`` MFCC-like matrices, T uniform in [tmin, tmax].
+"""
+import numpy as np
+
+from . import topology as tp
+
+
+def _truncated_normal(rng, shape, std):
+    a = rng.standard_normal(size=shape)
+    bad = np.abs(a) > 2.0
+    while bad.any():
+        a[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(a) > 2.0
+    return (a * std).astype(np.float32)
+
+
+def _shapes(topo, feat_dim):
+    prev = feat_dim
+    for i, (k, c) in enumerate(zip(topo["kernel_sizes"], topo["layer_sizes"])):
+        yield "frame_level_info_layer-%d" % i, (k, prev, c)
+        prev = c
+    prev *= 2
+    for j, c in enumerate(topo["embedding_sizes"]):
+        yield "embed_layer-%d" % j, (prev, c)
+        prev = c
+
+
+def reference_init(topo, feat_dim, num_classes, seed=0):
+    rng = np.random.default_rng(seed)
+    w = {}
+    last = feat_dim
+    for scope, shape in _shapes(topo, feat_dim):
+        c = shape[-1]
+        w[scope + "/w:0"] = _truncated_normal(rng, shape, 0.1)
+        w[scope + "/b:0"] = np.full(c, 0.1, np.float32)
+        w[scope + "/gamma:0"] = np.ones(c, np.float32)
+        w[scope + "/beta:0"] = np.zeros(c, np.float32)
+        w[scope + "/mean:0"] = np.zeros(c, np.float32)
+        w[scope + "/variance:0"] = np.ones(c, np.float32)
+        if topo.get("activation") == "prelu":
+            w[scope + "/prelu/prelu:0"] = np.full(c, 0.1, np.float32)     # tf_block.py:45-46
+        last = c
+    lim = np.sqrt(6.0 / (last + num_classes))                             # xavier_initializer (uniform)
+    w["output/w:0"] = rng.uniform(-lim, lim, size=(last, num_classes)).astype(np.float32)
+    w["output/b:0"] = np.full(num_classes, 0.1, np.float32)
+    return w
+
+
+def _act(z, topo, alpha):
+    a = topo.get("activation", "relu")
+    if a == "relu":
+        return np.maximum(z, 0.0)
+    if a == "lrelu":
+        return np.maximum(topo.get("lrelu_alpha", 0.2) * z, z)
+    if a == "prelu":
+        return np.maximum(z, 0.0) + alpha * np.minimum(z, 0.0)
+    return z
+
+
+def trained_like(topo, feat_dim, num_classes=64, seed=0, calib_frames=2000, input_scale=3.0):
+    rng = np.random.default_rng(seed)
+    w = {}
+    h = (rng.standard_normal((calib_frames, feat_dim)) * input_scale)
+    prev = feat_dim
+    for i, (k, d, c) in enumerate(zip(topo["kernel_sizes"], topo["dilations"], topo["layer_sizes"])):
+        sc = "frame_level_info_layer-%d" % i
+        std = np.sqrt(2.0 / (k * prev))
+        wt = _truncated_normal(rng, (k, prev, c), std)
+        b = (0.1 + 0.05 * rng.standard_normal(c)).astype(np.float32)
+        gamma = (1.0 + 0.1 * rng.standard_normal(c)).astype(np.float32)
+        beta = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        alpha = (0.1 + 0.02 * rng.standard_normal(c)).astype(np.float32)
+        # calibration pass (float64 NumPy): z on the random input, zero padded as one utterance
+        T = h.shape[0]
+        left = (k - 1) * d // 2
+        hp = np.zeros((T + (k - 1) * d, prev))
+        hp[left:left + T] = h
+        z = np.zeros((T, c)) + b.astype(np.float64)
+        for kk in range(k):
+            z += hp[kk * d:kk * d + T] @ wt[kk].astype(np.float64)
+        r = _act(z, topo, alpha.astype(np.float64))
+        mean = r.mean(0)
+        var = r.var(0)
+        # perturb the running stats a little: a trained net's moving averages never match one batch
+        mean_f = (mean * (1.0 + 0.05 * rng.standard_normal(c))).astype(np.float32)
+        var_f = (var * np.exp(0.1 * rng.standard_normal(c)) + 1e-4).astype(np.float32)
+        s = gamma.astype(np.float64) / np.sqrt(var_f.astype(np.float64) + tp.BN_EPSILON)
+        h = r * s + (beta.astype(np.float64) - mean_f.astype(np.float64) * s)
+        w[sc + "/w:0"], w[sc + "/b:0"] = wt, b
+        w[sc + "/gamma:0"], w[sc + "/beta:0"] = gamma, beta
+        w[sc + "/mean:0"], w[sc + "/variance:0"] = mean_f, var_f
+        if topo.get("activation") == "prelu":
+            w[sc + "/prelu/prelu:0"] = alpha
+        prev = c
+    prev *= 2
+    for j, c in enumerate(topo["embedding_sizes"]):
+        sc = "embed_layer-%d" % j
+        w[sc + "/w:0"] = _truncated_normal(rng, (prev, c), np.sqrt(1.0 / prev))
+        w[sc + "/b:0"] = (0.1 + 0.05 * rng.standard_normal(c)).astype(np.float32)
+        w[sc + "/gamma:0"] = (1.0 + 0.1 * rng.standard_normal(c)).astype(np.float32)
+        w[sc + "/beta:0"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        w[sc + "/mean:0"] = (0.3 + 0.1 * rng.standard_normal(c)).astype(np.float32)
+        w[sc + "/variance:0"] = np.exp(0.2 * rng.standard_normal(c)).astype(np.float32)
+        if topo.get("activation") == "prelu":
+            w[sc + "/prelu/prelu:0"] = (0.1 + 0.02 * rng.standard_normal(c)).astype(np.float32)
+        prev = c
+    lim = np.sqrt(6.0 / (prev + num_classes))
+    w["output/w:0"] = rng.uniform(-lim, lim, size=(prev, num_classes)).astype(np.float32)
+    w["output/b:0"] = np.full(num_classes, 0.1, np.float32)
+    return w
+
+
+def utterance_lengths(n, tmin, tmax, seed=1234):
+    rng = np.random.default_rng(seed)
+    return rng.integers(tmin, tmax + 1, size=n).astype(np.int64)
+
+
+def make_utterances(n, tmin, tmax, feat_dim=23, seed=1234, scale=3.0, key_fmt="utt%06d"):
+    """[(key, float32[T,F])...] -- BASELINE configs: seed 1234, x ~ N(0,1)*3 (MFCC-like after CMVN)."""
+    lens = utterance_lengths(n, tmin, tmax, seed)
+    rng = np.random.default_rng(seed + 1)
+    out = []
+    for i, T in enumerate(lens):
+        out.append((key_fmt % i, (rng.standard_normal((int(T), feat_dim)) * scale).astype(np.float32)))
+    return out
+
+
+SMALL_TOPOLOGY = dict(layer_sizes=[32, 32, 32, 32, 48], kernel_sizes=[5, 5, 7, 1, 1],
+                      dilations=[1, 1, 1, 1, 1], embedding_sizes=[16, 16], activation="relu",
+                      lrelu_alpha=0.2)

@@ -1,0 +1,63 @@
+"""Topologies of the reference's model classes that share the extraction graph.
+
+Each entry restates the constants of one ``build_model`` in the reference's
+``local/tf/models.py`` (line numbers below); all of them share ``Model``'s load / extract code, so
+on the extraction path a class is fully described by these numbers.
+"""
+import copy
+
+BN_EPSILON = 1e-3          # local/tf/tf_block.py:9   batch_norm_wrapper(epsilon=1e-3)
+VAR2STD_EPSILON = 1e-5     # local/tf/models.py:16
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
+ACT_CODES = {"none": ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU, "prelu": ACT_PRELU}
+
+_BASE = dict(
+    layer_sizes=[512, 512, 512, 512, 1536],     # models.py:27
+    kernel_sizes=[5, 5, 7, 1, 1],               # models.py:28
+    dilations=[1, 1, 1, 1, 1],
+    embedding_sizes=[512, 512],                 # models.py:29
+    activation="relu",
+    lrelu_alpha=0.2,                            # models.py:912
+)
+
+TOPOLOGIES = {
+    # class name in the reference           : constants
+    "Model":                                 dict(_BASE),                                    # models.py:20-128
+    "ModelWithoutDropout":                   dict(_BASE),                                    # models.py:436-534
+    "ModelWithoutDropoutTdnn":               dict(_BASE, kernel_sizes=[5, 3, 3, 1, 1],       # models.py:538-639
+                                                  dilations=[1, 2, 3, 1, 1]),
+    "ModelWithoutDropoutPRelu":              dict(_BASE, activation="prelu"),                # models.py:643-742
+    "ModelL2LossWithoutDropoutPRelu":        dict(_BASE, activation="prelu"),                # models.py:746-862
+    "ModelL2LossWithoutDropoutLRelu":        dict(_BASE, activation="lrelu"),                # models.py:866-981
+    "ModelL2LossWithoutDropoutReluHeInit":   dict(_BASE),                                    # models.py:1118-1244
+}
+
+
+def get(name):
+    if name not in TOPOLOGIES:
+        raise KeyError("unknown model class '%s' (attention pooling is out of scope)" % name)
+    return copy.deepcopy(TOPOLOGIES[name])
+
+
+def max_halo(topo):
+    """Largest one-sided SAME padding over the frame-level layers: (K-1)*d/2 (all K odd)."""
+    return max((k - 1) * d // 2 for k, d in zip(topo["kernel_sizes"], topo["dilations"]))
+
+
+def flops_per_frame(topo, feat_dim):
+    """Algorithmic FLOPs/frame of the frame-level layers (2*MAC, full taps at padded edges)."""
+    f, prev = 0, feat_dim
+    for k, c in zip(topo["kernel_sizes"], topo["layer_sizes"]):
+        f += 2 * k * prev * c
+        prev = c
+    return f
+
+
+def flops_per_utt(topo, embedding_index=0):
+    """Algorithmic FLOPs of the segment-level part for one chunk (embed-0, optionally embed-1)."""
+    pooled = 2 * topo["layer_sizes"][-1]
+    f = 2 * pooled * topo["embedding_sizes"][0]
+    if embedding_index == 1:
+        f += 2 * topo["embedding_sizes"][0] * topo["embedding_sizes"][1]
+    return f

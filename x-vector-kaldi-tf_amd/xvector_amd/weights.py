@@ -1,0 +1,88 @@
+"""Model-directory weight container.
+
+The reference persists a TF1 checkpoint (``model.meta/.index/.data-*`` + a ``done`` marker,
+``local/tf/models.py:130-141``) and every caller only tests that ``model.meta`` and ``done`` exist and
+are non-empty (``local/tf/ze_utils.py:561-567``, ``local/tf/extract_embedding.py:88``,
+``local/tf/extract_xvectors.sh:44``).  This build keeps that file contract and stores
+
+* ``model.meta``          -- JSON: format tag, class name, topology, num_classes, feat_dim
+* ``model.weights.npz``   -- float32 arrays keyed by the TF variable names the reference's h5 export
+                             enumerates (``local/tf/models.py:199-213``):
+                             ``frame_level_info_layer-{i}/{w,b,gamma,beta,mean,variance}:0``,
+                             ``embed_layer-{j}/{w,b,gamma,beta,mean,variance}:0``, ``output/{w,b}:0``,
+                             optional ``.../prelu/prelu:0``
+* ``done``                -- the marker the drivers look for.
+"""
+import json
+import os
+
+import numpy as np
+
+FORMAT_TAG = "xvector-amd-weights-v1"
+META = "model.meta"
+WEIGHTS = "model.weights.npz"
+DONE = "done"
+
+
+def expected_names(topo):
+    names = []
+    for i in range(len(topo["layer_sizes"])):
+        sc = "frame_level_info_layer-%d" % i
+        names += ["%s/%s:0" % (sc, n) for n in ("w", "b", "gamma", "beta", "mean", "variance")]
+        if topo.get("activation") == "prelu":
+            names.append("%s/prelu/prelu:0" % sc)
+    for j in range(len(topo["embedding_sizes"])):
+        sc = "embed_layer-%d" % j
+        names += ["%s/%s:0" % (sc, n) for n in ("w", "b", "gamma", "beta", "mean", "variance")]
+        if topo.get("activation") == "prelu":
+            names.append("%s/prelu/prelu:0" % sc)
+    names += ["output/w:0", "output/b:0"]
+    return names
+
+
+def save_model_dir(output_dir, weights, topo, class_name, num_classes, feat_dim):
+    os.makedirs(output_dir, exist_ok=True)
+    missing = [n for n in expected_names(topo) if n not in weights]
+    if missing:
+        raise KeyError("weights missing for: %s" % ", ".join(missing))
+    arrays = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items()}
+    tmp = os.path.join(output_dir, WEIGHTS + ".tmp.npz")
+    np.savez(tmp, **arrays)
+    os.replace(tmp, os.path.join(output_dir, WEIGHTS))
+    meta = dict(format=FORMAT_TAG, model_class=class_name, topology=topo,
+                num_classes=int(num_classes), feat_dim=int(feat_dim))
+    with open(os.path.join(output_dir, META), "wt") as fid:
+        json.dump(meta, fid, indent=1, sort_keys=True)
+        fid.write("\n")
+    with open(os.path.join(output_dir, DONE), "wt") as fid:      # models.py:138-139
+        fid.write("done")
+
+
+def is_correct_model_dir(model_dir):
+    """Same predicate as the reference's ``ze_utils.is_correct_model_dir`` (ze_utils.py:561-567)."""
+    for name in (META, DONE):
+        p = os.path.join(model_dir, name)
+        if not os.path.exists(p) or os.path.getsize(p) == 0:
+            return False
+    return True
+
+
+def load_model_dir(input_dir):
+    """-> (weights dict, meta dict).  Raises with a clear message on a TF checkpoint directory."""
+    meta_path = os.path.join(input_dir, META)
+    if not os.path.exists(meta_path):
+        raise IOError("no %s in '%s'" % (META, input_dir))
+    with open(meta_path, "rb") as fid:
+        raw = fid.read()
+    try:
+        meta = json.loads(raw.decode("utf-8"))
+        assert meta.get("format") == FORMAT_TAG
+    except Exception:
+        raise IOError("'%s' is not an %s model directory (a TensorFlow MetaGraphDef cannot be read "
+                      "without TensorFlow; export the variables by name to %s)" % (input_dir, FORMAT_TAG, WEIGHTS))
+    with np.load(os.path.join(input_dir, WEIGHTS)) as z:
+        weights = {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
+    missing = [n for n in expected_names(meta["topology"]) if n not in weights]
+    if missing:
+        raise KeyError("model dir '%s' lacks variables: %s" % (input_dir, ", ".join(missing)))
+    return weights, meta
