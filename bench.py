@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py -- x-vector extraction throughput on MI355X (BASELINE.json metric: utterances/sec ==
+x-vectors/sec, 512-d; % of MFMA peak on the TDNN GEMMs; % of HBM peak on statistics pooling).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (per GPU, weak scaling): BASELINE.json configs[1] -- 10,000 synthetic utterances of 23-dim
+MFCC, T ~ U{200..400} (seed 1234 + rank), default x-vector topology with seeded trained-like weights,
+512-d embedding (``embed_layer-0/scores``).  One STEP = one pass of the hot path over that whole set:
+for every ragged batch 5x TDNN GEMM -> statistics pooling -> segment FC, then the length-weighted chunk
+average, then (N > 1) the single RCCL gather of the [10000, 512] blocks to rank 0.  Inputs (packed
+feature batches) are resident in HBM before the timed region starts; nothing is skipped or cached.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (tdnn_gemm_kernel<true>, fp32-input
+MFMA, peak 157.3 TFLOP/s) from algorithmic FLOPs / HIP-event time measured inside the timed region;
+``roofline_pool`` is the same for the HBM-bound pooling kernel; ``cpu_baseline`` is a torch-CPU fp32 port
+of the reference forward (batch 1, like the reference) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd"))
+
+MFMA_F32_PEAK = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+HBM_PEAK = 8.0e12             # same guide: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--utts", type=int, default=10000, help="utterances per GPU (configs[1]: 10000)")
+    ap.add_argument("--tmin", type=int, default=200)
+    ap.add_argument("--tmax", type=int, default=400)
+    ap.add_argument("--batch-rows", type=int, default=131072)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline timing (0 = skip)")
+    ap.add_argument("--parity-utts", type=int, default=6)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from xvector_amd import dist as xdist, engine, hiplib, synthetic, topology as tp
+
+    rank, world = xdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    hiplib.require_gpu()
+    dev = torch.device("cuda:%d" % local)
+    torch.cuda.set_device(dev)
+
+    topo = tp.get("ModelWithoutDropout")
+    feat = 23
+    weights = synthetic.trained_like(topo, feat, seed=1)
+    model = engine.DeviceModel(weights, topo, dev)
+    gap = model.gap
+
+    # ---- synthetic workload resident in HBM: ragged batches in kernel layout -------------------
+    lens = synthetic.utterance_lengths(args.utts, args.tmin, args.tmax, 1234 + rank)
+    order = np.argsort(lens, kind="stable")                       # length-bucketed batches
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    batches = []
+    b0 = 0
+    while b0 < len(order):
+        rows, b1 = gap, b0
+        while b1 < len(order) and (b1 == b0 or rows + lens[order[b1]] + gap <= args.batch_rows):
+            rows += int(lens[order[b1]]) + gap
+            b1 += 1
+        lay = engine.BatchLayout(lens[order[b0:b1]], gap)
+        rv = torch.from_numpy(lay.row_valid()).to(dev)
+        x = torch.randn((lay.rows, feat), generator=gen, device=dev, dtype=torch.float32) * 3.0
+        x *= rv[:, None].to(torch.float32)                        # gap rows are zero by contract
+        batches.append(dict(x=x, rs=torch.from_numpy(lay.row_start).to(dev), rl=torch.from_numpy(lay.row_len).to(dev),
+                            rv=rv, n=lay.nchunks, max_len=lay.max_len, lo=b0, hi=b1, rows=lay.rows,
+                            frames=int(lay.row_len.sum()), lay=lay))
+        b0 = b1
+    n_utts = len(order)
+    frames = int(lens.sum())
+    model.reserve(max(b["rows"] for b in batches), max(b["n"] for b in batches), max(b["max_len"] for b in batches))
+    E_all = torch.empty((n_utts, model.embed_dim), dtype=torch.float32, device=dev)
+    seg = torch.arange(n_utts + 1, dtype=torch.int32, device=dev)              # one chunk per utterance (T < 10000)
+    clen = torch.from_numpy(lens[order].astype(np.int32)).to(dev)
+    xvec = torch.empty_like(E_all)
+    counts = [n_utts] * world
+
+    n_steps_total = args.warmup + args.steps
+    ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in batches] for _ in range(n_steps_total)]
+
+    def step(si):
+        for bi, b in enumerate(batches):
+            e = ev[si][bi]
+            R = b["rows"]
+            h = b["x"]
+            bufs = (model._ping, model._pong)
+            e[0].record()
+            for i, L in enumerate(model.layers):
+                if i == 1:
+                    e[1].record()
+                y = model._view(model._last if i == len(model.layers) - 1 else bufs[i & 1], R, L["cout"])
+                hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], model.act, L["alpha"], L["K"], L["dil"],
+                                  b["rv"], y)
+                h = y
+            e[2].record()
+            pooled = model._pooled[:b["n"]]
+            hiplib.stats_pool(h, b["rs"], b["rl"], b["n"], b["max_len"], model.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON, pooled,
+                              model._pool_ws)
+            e[3].record()
+            E0 = model.embed[0]
+            hiplib.fc(pooled, E0["wp"], E0["bias"], None, None, tp.ACT_NONE, None, None, E_all[b["lo"]:b["hi"]])
+            e[4].record()
+        hiplib.chunk_average(E_all, seg, clen, n_utts, xvec)
+        if world > 1:
+            return xdist.gather_blocks(xvec, counts, 0)
+        return [xvec]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for si in range(args.warmup):
+        step(si)
+    fence()
+    t0 = time.perf_counter()
+    for si in range(args.warmup, n_steps_total):
+        step(si)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- per-kernel time from the HIP events recorded inside the timed region ------------------
+    t_l0 = t_gemm = t_pool = 0.0
+    for si in range(args.warmup, n_steps_total):
+        for bi in range(len(batches)):
+            e = ev[si][bi]
+            t_l0 += e[0].elapsed_time(e[1])
+            t_gemm += e[1].elapsed_time(e[2]) + e[3].elapsed_time(e[4])
+            t_pool += e[2].elapsed_time(e[3])
+    t_l0, t_gemm, t_pool = (t * 1e-3 for t in (t_l0, t_gemm, t_pool))
+    prev = feat
+    per_frame = []
+    for k, c in zip(topo["kernel_sizes"], topo["layer_sizes"]):
+        per_frame.append(2 * k * prev * c)
+        prev = c
+    fl_gemm = (sum(per_frame[1:]) * frames + tp.flops_per_utt(topo) * n_utts) * args.steps      # tdnn_gemm_kernel<true>
+    n_gemm_launch = 5 * len(batches) * args.steps
+    C = topo["layer_sizes"][-1]
+    by_pool = (4 * C * frames + 4 * 2 * C * n_utts) * args.steps
+    fl_total = (tp.flops_per_frame(topo, feat) * frames + tp.flops_per_utt(topo) * n_utts)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("tdnn_gemm_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "utterances/sec (= x-vectors/sec, 512-d) on synthetic 23-dim MFCC, T~U[200,400]",
+        "value": n_utts * world * args.steps / dt,
+        "unit": "utt/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d utts/GPU, 23-dim MFCC, T~U{%d..%d}, default x-vector topology "
+                               "[512,512,512,512,1536] k=[5,5,7,1,1], 512-d embed_layer-0" % (n_utts, args.tmin, args.tmax),
+                   "utts_per_gpu": n_utts, "frames_per_gpu": frames, "batches_per_step": len(batches),
+                   "batch_rows": args.batch_rows, "parallelism": "utterance-sharded x%d, one RCCL gather" % world},
+        "frames_per_s": frames * world * args.steps / dt,
+        "algorithmic_tflops": fl_total * world * args.steps / dt / 1e12,
+        "roofline": {"kernel": "tdnn_gemm_kernel<true> (layers 1-4 + embed FC)", "bound": "mfma",
+                     "achieved": fl_gemm / t_gemm / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": fl_gemm / t_gemm / MFMA_F32_PEAK, "traffic": traffic,
+                     "avg_launch_ms": t_gemm / n_gemm_launch * 1e3, "launches": n_gemm_launch,
+                     "algorithmic_gflop_per_launch": fl_gemm / n_gemm_launch / 1e9,
+                     "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"},
+        "roofline_pool": {"kernel": "stats_pool_kernel", "bound": "hbm", "achieved": by_pool / t_pool / 1e9,
+                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": by_pool / t_pool / HBM_PEAK,
+                          "avg_launch_ms": t_pool / (len(batches) * args.steps) * 1e3,
+                          "algorithmic_mb_per_launch": by_pool / (len(batches) * args.steps) / 1e6},
+        "layer0_ms_per_step": t_l0 / args.steps * 1e3,
+    }
+
+    if args.cpu_budget > 0:
+        from oracle import oracle, torch_ref
+        # parity spot check (oracle as the checker): a few utterances of the resident workload
+        worst = 0.0
+        got = xvec.cpu().numpy()
+        for j in np.linspace(0, batches[0]["n"] - 1, args.parity_utts).astype(int):
+            lay = batches[0]["lay"]
+            s, n = int(lay.row_start[j]), int(lay.row_len[j])
+            m = batches[0]["x"][s:s + n].cpu().numpy()
+            worst = max(worst, oracle.rel_l2(got[j], oracle.embed_utterance(m, weights, topo, 25, 10000, np.float64)))
+        out["parity_rel_l2_max_vs_fp64_oracle"] = worst
+    if args.cpu_budget > 0 and world == 1:
+        from oracle import torch_ref
+        sample_lens = synthetic.utterance_lengths(32, args.tmin, args.tmax, 1234)
+        rng = np.random.default_rng(99)
+        mats = [(rng.standard_normal((int(T), feat)) * 3.0).astype(np.float32) for T in sample_lens]
+        ncores = os.cpu_count() or 1
+        import torch as _t
+        nthr = min(ncores, max(1, _t.get_num_threads()))
+        v_all, n_all, _ = torch_ref.time_baseline(weights, topo, mats, nthr, args.cpu_budget)
+        v_2, n_2, _ = torch_ref.time_baseline(weights, topo, mats, 2, max(2.0, args.cpu_budget / 2))
+        out["cpu_baseline"] = {"value": v_all, "unit": "utt/s", "cores": nthr, "kind": "port",
+                               "sample": "torch-CPU fp32 port of the reference forward, batch 1 per utterance, %d utterances "
+                                         "cycled from a 32-utt slice of the same length distribution for %.0f s on %d threads "
+                                         "(host has %d logical cores)" % (n_all, args.cpu_budget, nthr, ncores),
+                               "reference_faithful_2_threads": {"value": v_2, "unit": "utt/s", "cores": 2,
+                                                                "note": "TF session config of local/tf/models.py:361-363"}}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

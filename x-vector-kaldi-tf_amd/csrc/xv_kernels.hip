@@ -352,15 +352,21 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < POOL_UNROLL; ++i)
             v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(base + (size_t)(r + 4 * i) * ldh));
-        f32x4 sum = v[0];
+        // block statistics about v[0] (shifted): exact for constant channels, no cancellation
+        f32x4 d[POOL_UNROLL];
+        f32x4 sumd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 1; i < POOL_UNROLL; ++i) sum += v[i];
-        const f32x4 bm = sum * (1.0f / POOL_UNROLL);
-        f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 1; i < POOL_UNROLL; ++i) {
+            d[i] = v[i] - v[0];
+            sumd += d[i];
+        }
+        const f32x4 md = sumd * (1.0f / POOL_UNROLL);
+        const f32x4 bm = v[0] + md;
+        f32x4 m2 = md * md;                 // element 0: (0 - md)^2
 #pragma unroll
-        for (int i = 0; i < POOL_UNROLL; ++i) {
-            const f32x4 d = v[i] - bm;
-            m2 += d * d;
+        for (int i = 1; i < POOL_UNROLL; ++i) {
+            const f32x4 e = d[i] - md;
+            m2 += e * e;
         }
         chan_merge(s, bm, m2, (float)POOL_UNROLL);
     }
@@ -374,16 +380,18 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const float *__restrict
             v[i] = ok ? *reinterpret_cast<const f32x4 *>(base + (size_t)(r + 4 * i) * ldh) : (f32x4){0.f, 0.f, 0.f, 0.f};
             m += ok ? 1 : 0;
         }
-        f32x4 sum = v[0];
+        const float fm = (float)m;          // m >= 1: v[0] is always a real row
+        f32x4 sumd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 1; i < POOL_UNROLL; ++i) sum += v[i];
-        const float fm = (float)m;
-        const f32x4 bm = sum / fm;
-        f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 1; i < POOL_UNROLL; ++i)
+            if ((r + 4 * i) < n_rows) sumd += v[i] - v[0];
+        const f32x4 md = sumd / fm;
+        const f32x4 bm = v[0] + md;
+        f32x4 m2 = md * md;
 #pragma unroll
-        for (int i = 0; i < POOL_UNROLL; ++i) {
-            const f32x4 d = v[i] - bm;
-            if ((r + 4 * i) < n_rows) m2 += d * d;
+        for (int i = 1; i < POOL_UNROLL; ++i) {
+            const f32x4 e = (v[i] - v[0]) - md;
+            if ((r + 4 * i) < n_rows) m2 += e * e;
         }
         chan_merge(s, bm, m2, fm);
     }

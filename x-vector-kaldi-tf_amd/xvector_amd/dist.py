@@ -1,0 +1,102 @@
+"""Utterance sharding across the GPUs of one node + the single gather at the end.
+
+The reference's only multi-worker mechanism on this path is ``nj`` independent processes over disjoint
+utterance shards whose outputs are concatenated (local/tf/extract_xvectors.sh:63-65,83-88,92-95).  The
+MI355X equivalent: one process per GPU (``torch.distributed``, backend "nccl" == RCCL over xGMI), a
+deterministic frame-balanced partition every rank can recompute, NO collective on the data path, and
+ONE gather of the ``[N_r, E]`` fp32 embedding blocks to rank 0, which restores input order and writes
+the ark.  Keys and rejected-utterance flags need no communication: they follow from the lengths.
+"""
+import heapq
+import os
+
+import numpy as np
+
+
+def env_world():
+    """(rank, world_size, local_rank) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the environment if WORLD_SIZE > 1.  Returns (rank, world)."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def partition_lpt(lengths, world):
+    """Greedy longest-processing-time partition of utterances over ``world`` ranks balancing the number
+    of frames.  Deterministic (ties: lower index first, lower rank first).  Returns a list of ``world``
+    int64 index arrays, each sorted ascending (so every shard keeps input order)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    order = np.lexsort((np.arange(len(lengths)), -lengths))       # by length desc, then index asc
+    heap = [(0, r) for r in range(world)]
+    heapq.heapify(heap)
+    shards = [[] for _ in range(world)]
+    for i in order:
+        load, r = heapq.heappop(heap)
+        shards[r].append(int(i))
+        heapq.heappush(heap, (load + int(lengths[i]), r))
+    return [np.array(sorted(s), dtype=np.int64) for s in shards]
+
+
+def gather_blocks(local, counts, dst=0, group=None):
+    """ONE collective: gather the per-rank ``[counts[r], E]`` blocks on ``dst``.  Blocks are padded to
+    ``max(counts)`` rows so that a single fixed-shape ``dist.gather`` moves everything (each peer->root
+    transfer rides its own xGMI link).  Returns the list of un-padded blocks on ``dst``, else None."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    assert local.shape[0] == counts[rank]
+    if world == 1:
+        return [local]
+    cap = int(max(counts))
+    padded = local
+    if local.shape[0] != cap:
+        padded = torch.zeros((cap, local.shape[1]), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+    padded = padded.contiguous()
+    bucket = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bucket, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [b[: counts[r]] for r, b in enumerate(bucket)]
+
+
+def unshard(blocks, shards, total, dim):
+    """Inverse of the partition on the root: blocks[r][j] is utterance shards[r][j]."""
+    import torch
+    out = torch.empty((total, dim), dtype=blocks[0].dtype, device=blocks[0].device)
+    for blk, idx in zip(blocks, shards):
+        if len(idx):
+            out[torch.as_tensor(idx, device=out.device)] = blk
+    return out
+
+
+def sharded_extract(lengths, extract_shard, dim, device, group=None):
+    """Run ``extract_shard(indices) -> tensor[len(indices), dim]`` on this rank's shard of the
+    utterances and gather everything on rank 0 in input order.  Returns the ``[N, dim]`` tensor on rank
+    0 and None elsewhere.  ``extract_shard`` must return a row for every index (rejected utterances:
+    any filler; the caller drops them by length)."""
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    shards = partition_lpt(lengths, world)
+    local = extract_shard(shards[rank])
+    assert local.shape == (len(shards[rank]), dim)
+    blocks = gather_blocks(local.to(device), [len(s) for s in shards], 0, group)
+    if rank != 0:
+        return None
+    return unshard(blocks, shards, len(lengths), dim)
