@@ -223,16 +223,19 @@ def main():
         rng = np.random.default_rng(99)
         mats = [(rng.standard_normal((int(T), feat)) * 3.0).astype(np.float32) for T in sample_lens]
         ncores = os.cpu_count() or 1
-        import torch as _t
-        nthr = min(ncores, max(1, _t.get_num_threads()))
-        v_all, n_all, _ = torch_ref.time_baseline(weights, topo, mats, nthr, args.cpu_budget)
-        v_2, n_2, _ = torch_ref.time_baseline(weights, topo, mats, 2, max(2.0, args.cpu_budget / 2))
-        out["cpu_baseline"] = {"value": v_all, "unit": "utt/s", "cores": nthr, "kind": "port",
-                               "sample": "torch-CPU fp32 port of the reference forward, batch 1 per utterance, %d utterances "
-                                         "cycled from a 32-utt slice of the same length distribution for %.0f s on %d threads "
-                                         "(host has %d logical cores)" % (n_all, args.cpu_budget, nthr, ncores),
-                               "reference_faithful_2_threads": {"value": v_2, "unit": "utt/s", "cores": 2,
-                                                                "note": "TF session config of local/tf/models.py:361-363"}}
+        # batch-1 forwards do not scale to hundreds of threads: sweep a few thread counts (2 = the reference's TF
+        # session config, local/tf/models.py:361-363) and report the best one as the baseline
+        sweep = sorted(set(t for t in (2, 8, 32) if t <= ncores))
+        per = max(2.0, args.cpu_budget / (len(sweep) + 1))
+        res = {t: torch_ref.time_baseline(weights, topo, mats, t, per) for t in sweep}
+        best = max(res, key=lambda t: res[t][0])
+        out["cpu_baseline"] = {"value": res[best][0], "unit": "utt/s", "cores": best, "kind": "port",
+                               "sample": "torch-CPU fp32 (oneDNN) port of the reference forward, batch 1 per utterance as "
+                                         "local/tf/models.py:401-414 runs it; a 32-utterance slice of the same length "
+                                         "distribution cycled for %.0f s per thread count; best of threads=%s reported; host "
+                                         "has %d logical cores" % (per, sweep, ncores),
+                               "by_threads": {str(t): res[t][0] for t in sweep},
+                               "reference_faithful_2_threads": res.get(2, (None,))[0]}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

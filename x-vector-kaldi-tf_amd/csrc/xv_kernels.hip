@@ -456,6 +456,7 @@ __global__ void stats_pool_merge_kernel(const float *__restrict__ partial, int C
 __global__ void chunk_average_kernel(const float *__restrict__ e, const int *__restrict__ seg_start,
                                      const int *__restrict__ chunk_len, int dim, float *__restrict__ out)
 {
+#pragma clang fp contract(off)      // hipcc contracts a*b+c into fma by default; NumPy does not
     const int u = blockIdx.y;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= dim) return;
@@ -464,10 +465,12 @@ __global__ void chunk_average_kernel(const float *__restrict__ e, const int *__r
     double tot = 0.0;
     for (int i = s0; i < s1; ++i) {
         const float w = (float)chunk_len[i];
-        acc = __fadd_rn(acc, __fmul_rn(w, e[(size_t)i * dim + d]));
+        float prod = w * e[(size_t)i * dim + d];
+        asm volatile("" : "+v"(prod));      // opaque to the optimiser: product is rounded before the add
+        acc = acc + prod;
         tot += (double)chunk_len[i];
     }
-    out[(size_t)u * dim + d] = __fdiv_rn(acc, (float)tot);
+    out[(size_t)u * dim + d] = acc / (float)tot;      // IEEE-correct fp32 division (hipcc default)
 }
 
 __global__ void pack_weights_kernel(const float *__restrict__ w, int kred, int cout, float *__restrict__ wp)
@@ -481,11 +484,14 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, int kred, int c
 __global__ void fold_bn_kernel(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
                                int c, float *scale, float *shift)
 {
+#pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c) return;
-    const float s = __fmul_rn(gamma[i], __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(var[i], eps))));
+    const float s = gamma[i] * (1.0f / sqrtf(var[i] + eps));
+    float ms = mean[i] * s;
+    asm volatile("" : "+v"(ms));
     scale[i] = s;
-    shift[i] = __fsub_rn(beta[i], __fmul_rn(mean[i], s));
+    shift[i] = beta[i] - ms;
 }
 
 int check_launch(const char *what)
