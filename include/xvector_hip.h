@@ -14,7 +14,12 @@
  *    (hipStream_t passed as void*; NULL = the null stream).
  *  - return value: 0 on success, otherwise a hipError_t / negative argument-error code;
  *    xv_last_error() returns a thread-local message.  No exceptions cross the ABI.
- *  - all arithmetic is IEEE fp32 (f32-input MFMA: exact fp32 products, fp32 accumulation).
+ *  - arithmetic: the *_f32 GEMM entry points are exact IEEE fp32 (f32-input MFMA: exact fp32 products, fp32
+ *    accumulation).  The *_bf16x3 twins compute the same fp32-in / fp32-out contraction with every operand
+ *    split x = hi + lo into two bf16 and the product accumulated in fp32 as hi*hi + hi*lo + lo*hi on the
+ *    bf16 matrix cores (16x the f32-MFMA rate; the dropped lo*lo term is ~2^-16 relative): measured
+ *    ~3e-6 relative L2 on the x-vector against the fp64 oracle, inside the 1e-4 parity bar.  Pooling,
+ *    epilogues and the chunk average are fp32 in both.
  *
  * Ragged batch layout ("packed rows with gaps")
  *    A batch of utterance chunks is ONE row-major matrix x[R, C].  Chunk b owns rows
@@ -73,6 +78,18 @@ int xv_tdnn_layer_f32(const float *x, int64_t R, int cin, int ldx, const float *
                       const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha,
                       int K, int dilation, int cout, const uint8_t *row_valid, float *y, int ldy,
                       float *y_preact, void *stream);
+
+/* bf16x3 split-precision twins of xv_pack_weights_f32 / xv_tdnn_layer_f32 / xv_fc_f32 (same semantics, same
+ * operands except the weights, which are pre-split into two bf16 planes wp_hi/wp_lo[Cout][K*Cin] by
+ * xv_pack_weights_bf16x3; activations stay fp32 in HBM and are split while staged).  Cin % 8 == 0. */
+int xv_pack_weights_bf16x3(const float *w, int kred, int cout, uint16_t *wp_hi, uint16_t *wp_lo, void *stream);
+int xv_tdnn_layer_bf16x3(const float *x, int64_t R, int cin, int ldx, const uint16_t *wp_hi, const uint16_t *wp_lo,
+                         const float *bias, const float *bn_scale, const float *bn_shift, int act_kind,
+                         const float *act_alpha, int K, int dilation, int cout, const uint8_t *row_valid, float *y, int ldy,
+                         float *y_preact, void *stream);
+int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const uint16_t *wp_hi, const uint16_t *wp_lo, const float *bias,
+                 const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y,
+                 float *y_preact, void *stream);
 
 /* Statistics pooling.  Replaces tf.nn.moments(h, 1) + tf.sqrt(var + 1e-5) + tf.concat
  * (local/tf/models.py:16,75-76):  out[b] = [ mean_t h[t,:]  ||  sqrt(mean_t (h-mean)^2 + eps) ]

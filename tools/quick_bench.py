@@ -14,7 +14,7 @@ def main():
     lens = synthetic.utterance_lengths(nutt, 200, 400, 1234)
     layout = engine.BatchLayout(lens, model.gap)
     dev = model.device
-    x = torch.randn((layout.rows, 23), device=dev) * 3
+    x = torch.randn((layout.rows, model.in_dim), device=dev) * 3; x[:, 23:] = 0
     rv = torch.from_numpy(layout.row_valid()).to(dev)
     x *= rv[:, None].float()
     rs = torch.from_numpy(layout.row_start).to(dev); rl = torch.from_numpy(layout.row_len).to(dev)

@@ -53,6 +53,7 @@ struct GemmParams {
     long R;
     int cin, ldx;
     const float *wp;
+    const uint16_t *wph, *wpl;   // bf16x3 path: hi / lo bf16 planes of the packed weights
     int kred;
     const float *bias, *scale, *shift;
     int act;
@@ -74,6 +75,42 @@ __device__ __forceinline__ float apply_act(float z, int act, float a)
     case XV_ACT_LRELU: return z > 0.0f ? z : a * z;
     case XV_ACT_PRELU: return fmaxf(z, 0.0f) + a * fminf(z, 0.0f);
     default: return z;
+    }
+}
+
+// Fused epilogue shared by the fp32 and the bf16x3 GEMM kernels.
+// D layout of a 32x32 MFMA tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+__device__ __forceinline__ void gemm_epilogue(const GemmParams &p, const uint8_t *Ms, long m0, int n0, int wr, int wc,
+                                              int lane, const f32x16 &acc00, const f32x16 &acc01, const f32x16 &acc10,
+                                              const f32x16 &acc11)
+{
+    const int colb = n0 + wc * 64 + (lane & 31);
+    const int rowb = wr * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int gc = colb + cb * 32;
+        if (gc >= p.cout) continue;
+        const float bias = p.bias ? p.bias[gc] : 0.f;
+        const float sc = p.scale ? p.scale[gc] : 1.f;
+        const float sh = p.shift ? p.shift[gc] : 0.f;
+        const float al = (p.act == XV_ACT_LRELU) ? p.alpha[0] : (p.act == XV_ACT_PRELU ? p.alpha[gc] : 0.f);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const f32x16 &a = (rb == 0) ? (cb == 0 ? acc00 : acc01) : (cb == 0 ? acc10 : acc11);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = rowb + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+                const long gr = m0 + lr;
+                if (gr >= p.R) continue;
+                const float z = a[reg] + bias;
+                if (p.ypre) p.ypre[(size_t)gr * p.ldy + gc] = z;
+                if (p.y) {
+                    float v = apply_act(z, p.act, al) * sc + sh;
+                    if (!Ms[lr]) v = 0.f;
+                    p.y[(size_t)gr * p.ldy + gc] = v;
+                }
+            }
+        }
     }
 }
 
@@ -237,35 +274,200 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
         tap = ntap;
     }
 
-    // epilogue: D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int colb = n0 + wc * 64 + (lane & 31);
-    const int rowb = wr * 64 + 4 * (lane >> 5);
+    gemm_epilogue(p, Ms, m0, n0, wr, wc, lane, acc00, acc01, acc10, acc11);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16x3 split-precision GEMM: every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi));
+// the product is accumulated in fp32 as lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (the lo*lo
+// term, ~2^-16 relative, is dropped).  Activations stay fp32 in HBM and are split while staging; the
+// weights are split once at load time (xv_pack_weights_bf16x3).  Same tiling / halo re-use / epilogue
+// as the fp32 kernel; LDS rows are 32 bf16 (64 B) with the 16-byte slots XOR-swizzled by (row>>2)&3
+// so ds_read_b128 fragment reads are conflict-free without padding.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XROW = 32;   // bf16 per LDS row
+constexpr size_t GEMM3_LDS_BYTES = (size_t)(2 * 2 * A_ROWS * XROW + 2 * 2 * BN * XROW) * 2 + BM;
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * XROW + ((slot ^ ((row >> 2) & 3)) << 3); }
+
+__global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16 *Ah = reinterpret_cast<__bf16 *>(smem);        // [2][A_ROWS][32]
+    __bf16 *Al = Ah + 2 * A_ROWS * XROW;
+    __bf16 *Bh = Al + 2 * A_ROWS * XROW;                  // [2][BN][32]
+    __bf16 *Bl = Bh + 2 * BN * XROW;
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(Bl + 2 * BN * XROW);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nwg = p.n_mt * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int span = (p.K - 1) * p.dil;
+    const int left = span >> 1;
+    const int rowsA = BM + span;
+    const int n_chunks = (p.cin + BK - 1) / BK;
+    const int n_stages = n_chunks * p.K;
+
+    if (tid < BM) {
+        const long gr = m0 + tid;
+        Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
+    }
+
+    f32x4 areg[5];
+    bf16x8 bhreg[2], blreg[2];
+
+    auto load_b = [&](int chunk, int tap) {
+        const int c0 = chunk * BK;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int gc = colb + cb * 32;
-        if (gc >= p.cout) continue;
-        const float bias = p.bias ? p.bias[gc] : 0.f;
-        const float sc = p.scale ? p.scale[gc] : 1.f;
-        const float sh = p.shift ? p.shift[gc] : 0.f;
-        const float al = (p.act == XV_ACT_LRELU) ? p.alpha[0] : (p.act == XV_ACT_PRELU ? p.alpha[gc] : 0.f);
+        for (int j = 0; j < 2; ++j) {
+            const int f = tid + NT * j;
+            const int col = f >> 2, slot = f & 3;
+            const int gcol = n0 + col, c = c0 + slot * 8;
+            bf16x8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gcol < p.cout && c < p.cin) {
+                const size_t off = (size_t)gcol * p.kred + (size_t)tap * p.cin + c;
+                vh = *reinterpret_cast<const bf16x8 *>(p.wph + off);
+                vl = *reinterpret_cast<const bf16x8 *>(p.wpl + off);
+            }
+            bhreg[j] = vh;
+            blreg[j] = vl;
+        }
+    };
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * BK;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const f32x16 &a = (rb == 0) ? (cb == 0 ? acc00 : acc01) : (cb == 0 ? acc10 : acc11);
+        for (int j = 0; j < 5; ++j) {
+            const int f = tid + NT * j;
+            const int lr = f >> 3, qq = f & 7;
+            const long gr = m0 - left + lr;
+            const int c = c0 + qq * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (lr < rowsA && gr >= 0 && gr < p.R && c < p.cin)
+                v = *reinterpret_cast<const f32x4 *>(p.x + (size_t)gr * p.ldx + c);
+            areg[j] = v;
+        }
+    };
+    auto store_b = [&](int buf) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int lr = rowb + rb * 32 + (reg & 3) + 8 * (reg >> 2);
-                const long gr = m0 + lr;
-                if (gr >= p.R) continue;
-                const float z = a[reg] + bias;
-                if (p.ypre) p.ypre[(size_t)gr * p.ldy + gc] = z;
-                if (p.y) {
-                    float v = apply_act(z, p.act, al) * sc + sh;
-                    if (!Ms[lr]) v = 0.f;
-                    p.y[(size_t)gr * p.ldy + gc] = v;
+        for (int j = 0; j < 2; ++j) {
+            const int f = tid + NT * j;
+            const int o = buf * (BN * XROW) + swz(f >> 2, f & 3);
+            *reinterpret_cast<bf16x8 *>(Bh + o) = bhreg[j];
+            *reinterpret_cast<bf16x8 *>(Bl + o) = blreg[j];
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int f = tid + NT * j;
+            const int lr = f >> 3, qq = f & 7;
+            if (lr < A_ROWS) {
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hi[i] = (__bf16)areg[j][i];
+                    lo[i] = (__bf16)(areg[j][i] - (float)hi[i]);
                 }
+                const int o = buf * (A_ROWS * XROW) + swz(lr, qq >> 1) + (qq & 1) * 4;
+                *reinterpret_cast<bf16x4 *>(Ah + o) = hi;
+                *reinterpret_cast<bf16x4 *>(Al + o) = lo;
             }
         }
+    };
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+    load_a(0);
+    load_b(0, 0);
+    store_a(0);
+    store_b(0);
+    __syncthreads();
+
+    int chunk = 0, tap = 0;
+    for (int s = 0; s < n_stages; ++s) {
+        int nchunk = chunk, ntap = tap + 1;
+        if (ntap == p.K) { ntap = 0; nchunk = chunk + 1; }
+        const bool has_next = (s + 1) < n_stages;
+        const bool new_a = has_next && (ntap == 0);
+        if (has_next) {
+            load_b(nchunk, ntap);
+            if (new_a) load_a(nchunk);
+        }
+
+        const int arow = wr * 64 + (lane & 31) + tap * p.dil;
+        const int brow = wc * 64 + (lane & 31);
+        const int abase = (chunk & 1) * (A_ROWS * XROW);
+        const int bbase = (s & 1) * (BN * XROW);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ks * 2 + (lane >> 5);
+            const int oa0 = abase + swz(arow, slot), oa1 = abase + swz(arow + 32, slot);
+            const int ob0 = bbase + swz(brow, slot), ob1 = bbase + swz(brow + 32, slot);
+            const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(Ah + oa0), al0 = *reinterpret_cast<const bf16x8 *>(Al + oa0);
+            const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(Ah + oa1), al1 = *reinterpret_cast<const bf16x8 *>(Al + oa1);
+            const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(Bh + ob0), bl0 = *reinterpret_cast<const bf16x8 *>(Bl + ob0);
+            const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(Bh + ob1), bl1 = *reinterpret_cast<const bf16x8 *>(Bl + ob1);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
+        }
+
+        if (has_next) {
+            store_b((s + 1) & 1);
+            if (new_a) store_a(nchunk & 1);
+        }
+        __syncthreads();
+        chunk = nchunk;
+        tap = ntap;
     }
+    gemm_epilogue(p, Ms, m0, n0, wr, wc, lane, acc00, acc01, acc10, acc11);
+}
+
+int launch_gemm3(const GemmParams &p0, hipStream_t st)
+{
+    GemmParams p = p0;
+    if (p.R <= 0 || p.cout <= 0) return 0;
+    if (p.cin <= 0 || p.K <= 0 || (p.K & 1) == 0 || p.dil <= 0) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: K must be odd, dims > 0");
+    if ((p.K - 1) * p.dil > MAX_SPAN) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: (K-1)*dilation > 8 unsupported");
+    if (p.ldx < p.cin || p.ldy < p.cout) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: leading dimension too small");
+    if ((p.cin & 7) || (p.ldx & 3) || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.wph) & 15) || (((uintptr_t)p.wpl) & 15))
+        return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: Cin must be a multiple of 8, ldx of 4, pointers 16-byte aligned");
+    if ((p.act == XV_ACT_LRELU || p.act == XV_ACT_PRELU) && !p.alpha) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: act_alpha is NULL");
+    p.kred = p.K * p.cin;
+    p.n_mt = (int)((p.R + BM - 1) / BM);
+    p.n_nt = (p.cout + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)tdnn_gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(tdnn_gemm_bf16x3_kernel, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(NT), GEMM3_LDS_BYTES, st, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_bf16x3_kernel launch");
 }
 
 int launch_gemm(const GemmParams &p0, hipStream_t st)
@@ -481,6 +683,20 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, int kred, int c
     wp[i] = w[(size_t)k * cout + n];
 }
 
+// split + transpose: w[kred, cout] fp32 -> hi/lo bf16 planes [cout][kred]
+__global__ void pack_weights_bf16x3_kernel(const float *__restrict__ w, int kred, int cout, uint16_t *__restrict__ wh,
+                                           uint16_t *__restrict__ wl)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)kred * cout) return;
+    const int n = (int)(i / kred), k = (int)(i - (size_t)n * kred);
+    const float x = w[(size_t)k * cout + n];
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    wh[i] = __builtin_bit_cast(uint16_t, hi);
+    wl[i] = __builtin_bit_cast(uint16_t, lo);
+}
+
 __global__ void fold_bn_kernel(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
                                int c, float *scale, float *shift)
 {
@@ -507,7 +723,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 1; }
+int xv_version(void) { return 2; }
 
 const char *xv_last_error(void) { return g_err; }
 
@@ -547,6 +763,38 @@ int xv_fc_f32(const float *x, int nrows, int in_dim, const float *wp, const floa
 {
     return xv_tdnn_layer_f32(x, nrows, in_dim, in_dim, wp, bias, bn_scale, bn_shift, act_kind, act_alpha, 1, 1,
                              out_dim, nullptr, y, out_dim, y_preact, stream);
+}
+
+
+int xv_pack_weights_bf16x3(const float *w, int kred, int cout, uint16_t *wp_hi, uint16_t *wp_lo, void *stream)
+{
+    if (!w || !wp_hi || !wp_lo || kred <= 0 || cout <= 0) return fail(XV_ERR_BAD_ARG, "pack_weights_bf16x3: bad argument");
+    const size_t n = (size_t)kred * cout;
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, kred,
+                       cout, wp_hi, wp_lo);
+    return check_launch("pack_weights_bf16x3_kernel");
+}
+
+int xv_tdnn_layer_bf16x3(const float *x, int64_t R, int cin, int ldx, const uint16_t *wp_hi, const uint16_t *wp_lo,
+                         const float *bias, const float *bn_scale, const float *bn_shift, int act_kind,
+                         const float *act_alpha, int K, int dilation, int cout, const uint8_t *row_valid, float *y, int ldy,
+                         float *y_preact, void *stream)
+{
+    if (!x || !wp_hi || !wp_lo || (!y && !y_preact)) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: unknown act_kind");
+    GemmParams p{};
+    p.x = x; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wph = wp_hi; p.wpl = wp_lo;
+    p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
+    p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid; p.y = y; p.ldy = ldy; p.ypre = y_preact;
+    return launch_gemm3(p, (hipStream_t)stream);
+}
+
+int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const uint16_t *wp_hi, const uint16_t *wp_lo, const float *bias,
+                 const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y,
+                 float *y_preact, void *stream)
+{
+    return xv_tdnn_layer_bf16x3(x, nrows, in_dim, in_dim, wp_hi, wp_lo, bias, bn_scale, bn_shift, act_kind, act_alpha, 1, 1,
+                                out_dim, nullptr, y, out_dim, y_preact, stream);
 }
 
 size_t xv_stats_pool_workspace_bytes(int c, int nchunks, int max_len, int split_rows)

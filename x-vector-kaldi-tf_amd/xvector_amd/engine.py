@@ -72,7 +72,7 @@ class BatchLayout(object):
         """Copy the chunk matrices into ``out[rows, F]`` (gap rows zeroed)."""
         out[:self.rows] = 0
         for s, m in zip(self.row_start, mats):
-            out[s:s + m.shape[0]] = m
+            out[s:s + m.shape[0], :m.shape[1]] = m
 
 
 # ------------------------------------------------------------------------------------------------
@@ -84,9 +84,13 @@ class DeviceModel(object):
 
     POOL_SPLIT_ROWS = 512
 
-    def __init__(self, weights, topo, device="cuda:0", embedding_index=0):
+    def __init__(self, weights, topo, device="cuda:0", embedding_index=0, precision="fp32"):
+        """precision: "fp32" = exact fp32 MFMA GEMMs; "bf16x3" = split-precision bf16 MFMA GEMMs (fp32-class
+        accuracy, ~3e-6 rel-L2 on the x-vector; see include/xvector_hip.h)."""
         import torch
         hiplib.require_gpu()
+        assert precision in ("fp32", "bf16x3")
+        self.precision = precision
         self.torch = torch
         self.device = torch.device(device)
         self.topo = topo
@@ -94,12 +98,20 @@ class DeviceModel(object):
         self.gap = tp.max_halo(topo)
         self.act = tp.ACT_CODES[topo.get("activation", "relu")]
         self.feat_dim = int(weights["frame_level_info_layer-0/w:0"].shape[1])
+        # features are packed with the column count rounded up to a multiple of 4 (23 -> 24, extra columns
+        # zero, matching zero weight rows) so that layer 0 takes the 16-byte vector staging path
+        pad_to = 8 if precision == "bf16x3" else 4
+        self.in_dim = (self.feat_dim + pad_to - 1) // pad_to * pad_to
         self.layers = []
         with torch.cuda.device(self.device):
             for i, (k, d) in enumerate(zip(topo["kernel_sizes"], topo["dilations"])):
                 sc = "frame_level_info_layer-%d" % i
                 w = weights[sc + "/w:0"]
                 assert w.shape[0] == k, "kernel size mismatch in %s" % sc
+                if i == 0 and self.in_dim != self.feat_dim:
+                    wpad = np.zeros((k, self.in_dim, w.shape[2]), np.float32)
+                    wpad[:, :self.feat_dim] = w
+                    w = wpad
                 self.layers.append(self._prep(weights, sc, w.reshape(-1, w.shape[2]), k, d))
             self.embed = []
             for j in range(len(topo["embedding_sizes"])):
@@ -111,13 +123,17 @@ class DeviceModel(object):
         self._cap_rows = 0
         self._cap_chunks = 0
         self._pool_ws = None
+        self._a0 = None
 
     def _dev(self, a):
         return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
     def _prep(self, weights, scope, w2d, k, d):
         layer = dict(K=k, dil=d, cin=w2d.shape[0] // k, cout=w2d.shape[1])
-        layer["wp"] = hiplib.pack_weights(self._dev(w2d))
+        if self.precision == "bf16x3" and layer["cin"] % 8 == 0:
+            layer["wp"] = hiplib.pack_weights_bf16x3(self._dev(w2d))      # (hi, lo) planes
+        else:
+            layer["wp"] = hiplib.pack_weights(self._dev(w2d))
         layer["bias"] = self._dev(weights[scope + "/b:0"])
         layer["scale"], layer["shift"] = hiplib.fold_bn(*(self._dev(weights["%s/%s:0" % (scope, n)])
                                                           for n in ("gamma", "beta", "mean", "variance")),
@@ -143,8 +159,6 @@ class DeviceModel(object):
         if nchunks > self._cap_chunks:
             self._cap_chunks = int(nchunks)
             self._pooled = torch.empty((self._cap_chunks, self.pooled_dim), dtype=torch.float32, device=self.device)
-            self._e0 = torch.empty((self._cap_chunks, self.embed[0]["cout"]), dtype=torch.float32, device=self.device)
-            self._a0 = torch.empty_like(self._e0)
             self._pool_ws = None
         if max_len is not None:
             need = hiplib.stats_pool_workspace_bytes(self.layers[-1]["cout"], self._cap_chunks, max_len, self.POOL_SPLIT_ROWS)
@@ -156,10 +170,10 @@ class DeviceModel(object):
         return buf.view(-1)[: rows * width].view(rows, width)
 
     # -- the kernel sequence ----------------------------------------------------------------------
-    def forward_packed(self, x, row_start, row_len, row_valid, nchunks, max_len, out):
-        """x[R,F] (gap rows zero), int32 row_start/row_len[nchunks], uint8 row_valid[R] -> writes the
-        chunk embeddings into out[nchunks, E].  All arguments are device tensors; nothing is allocated
-        when ``reserve`` was called with sufficient capacity."""
+    def frame_level(self, x, row_start, row_len, row_valid, nchunks, max_len, pooled):
+        """Frame-level part for ONE ragged batch: x[R,in_dim] (gap rows zero) -> 5 TDNN layers -> statistics
+        pooling, written to pooled[nchunks, 2*C_last].  Device tensors only; no allocation when ``reserve`` was
+        called with sufficient capacity."""
         R = x.shape[0]
         self.reserve(R, nchunks, max_len)
         h = x
@@ -170,19 +184,32 @@ class DeviceModel(object):
             hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
                               row_valid, y)
             h = y
-        pooled = self._pooled[:nchunks]
         hiplib.stats_pool(h, row_start, row_len, nchunks, max_len, self.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON, pooled,
                           self._pool_ws)
+        return pooled
+
+    def segment_level(self, pooled, out):
+        """Segment-level part for ANY number of chunks at once (run once per window so the GEMM has enough rows to
+        fill the chip): pooled[N, 2*C_last] -> out[N, E]."""
+        n = pooled.shape[0]
         E0 = self.embed[0]
         if self.embedding_index == 0:
             # embed_layer-0/scores IS the x-vector (local/tf/models.py:159,414): pre-activation output
             hiplib.fc(pooled, E0["wp"], E0["bias"], None, None, tp.ACT_NONE, None, None, out)
         else:
-            a0 = self._a0[:nchunks]
+            if self._a0 is None or self._a0.shape[0] < n:
+                self._a0 = self.torch.empty((n, E0["cout"]), dtype=self.torch.float32, device=self.device)
+            a0 = self._a0[:n]
             hiplib.fc(pooled, E0["wp"], E0["bias"], E0["scale"], E0["shift"], self.act, E0["alpha"], a0, None)
             E1 = self.embed[1]
             hiplib.fc(a0, E1["wp"], E1["bias"], None, None, tp.ACT_NONE, None, None, out)
         return out
+
+    def forward_packed(self, x, row_start, row_len, row_valid, nchunks, max_len, out):
+        """frame_level + segment_level for one batch (tests / smoke; the extractor runs the FC per window)."""
+        self.reserve(x.shape[0], nchunks, max_len)
+        pooled = self.frame_level(x, row_start, row_len, row_valid, nchunks, max_len, self._pooled[:nchunks])
+        return self.segment_level(pooled, out)
 
     def intermediates_packed(self, x, row_valid):
         """Debug/test helper: per-layer outputs [R, Cout] for a packed batch (allocates)."""
@@ -241,6 +268,7 @@ class Extractor(object):
         gap = model.gap
         with torch.cuda.device(dev):
             E_all = torch.empty((nch, model.embed_dim), dtype=torch.float32, device=dev)
+            P_all = torch.empty((nch, model.pooled_dim), dtype=torch.float32, device=dev)
             b0 = 0
             while b0 < nch:
                 rows, b1 = gap, b0
@@ -248,21 +276,22 @@ class Extractor(object):
                     rows += c_len[b1] + gap
                     b1 += 1
                 layout = BatchLayout(c_len[b0:b1], gap)
-                feat = mats[c_utt[b0]].shape[1]
-                pin = self._pinned(layout.rows, feat)
+                assert mats[c_utt[b0]].shape[1] == model.feat_dim, "feature dimension does not match the model"
+                pin = self._pinned(layout.rows, model.in_dim)
                 host = pin.numpy()
                 layout.pack([mats[c_utt[i]][c_start[i]:c_start[i] + c_len[i]] for i in range(b0, b1)], host)
                 x = pin[:layout.rows].to(dev, non_blocking=True)
                 rs = torch.from_numpy(layout.row_start).to(dev, non_blocking=True)
                 rl = torch.from_numpy(layout.row_len).to(dev, non_blocking=True)
                 rv = torch.from_numpy(layout.row_valid()).to(dev, non_blocking=True)
-                model.forward_packed(x, rs, rl, rv, layout.nchunks, layout.max_len, E_all[b0:b1])
+                model.frame_level(x, rs, rl, rv, layout.nchunks, layout.max_len, P_all[b0:b1])
                 torch.cuda.current_stream().synchronize()      # the pinned staging buffer is reused next batch
                 self.stats["batches"] += 1
                 self.stats["chunks"] += layout.nchunks
                 self.stats["frames"] += int(layout.row_len.sum())
                 self.stats["rows"] += layout.rows
                 b0 = b1
+            model.segment_level(P_all, E_all)
             seg = torch.tensor(seg_start, dtype=torch.int32, device=dev)
             cl = torch.tensor(c_len, dtype=torch.int32, device=dev)
             out = torch.empty((len(order), model.embed_dim), dtype=torch.float32, device=dev)

@@ -10,11 +10,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libxvector_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
-           "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32")
+           "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32",
+           "xv_pack_weights_bf16x3", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3")
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
@@ -52,6 +53,12 @@ def load():
     lib.xv_stats_pool_f32.argtypes = [vp, i64, ci, vp, vp, ci, ci, ci, cf, vp, vp, vp]
     lib.xv_fc_f32.restype = ci
     lib.xv_fc_f32.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
+    lib.xv_pack_weights_bf16x3.restype = ci
+    lib.xv_pack_weights_bf16x3.argtypes = [vp, ci, ci, vp, vp, vp]
+    lib.xv_tdnn_layer_bf16x3.restype = ci
+    lib.xv_tdnn_layer_bf16x3.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
+    lib.xv_fc_bf16x3.restype = ci
+    lib.xv_fc_bf16x3.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
     lib.xv_chunk_average_f32.restype = ci
     lib.xv_chunk_average_f32.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     if lib.xv_version() != ABI_VERSION:
@@ -104,6 +111,18 @@ def pack_weights(w2d):
     return wp
 
 
+def pack_weights_bf16x3(w2d):
+    """w2d: [Kred, Cout] fp32 -> (hi, lo) bf16 planes [Cout, Kred] (stored as int16 tensors)."""
+    import torch
+    lib = require_gpu()
+    _f32(w2d, "w")
+    kred, cout = w2d.shape
+    hi = torch.empty((cout, kred), dtype=torch.int16, device=w2d.device)
+    lo = torch.empty((cout, kred), dtype=torch.int16, device=w2d.device)
+    _check(lib.xv_pack_weights_bf16x3(_ptr(w2d), kred, cout, _ptr(hi), _ptr(lo), _stream()), "xv_pack_weights_bf16x3")
+    return hi, lo
+
+
 def fold_bn(gamma, beta, mean, var, eps):
     import torch
     lib = require_gpu()
@@ -119,17 +138,24 @@ def fold_bn(gamma, beta, mean, var, eps):
 def tdnn_layer(x, wp, bias, scale, shift, act, alpha, K, dilation, row_valid, y, y_preact=None, rows=None):
     """x[R,Cin] -> y[R,Cout] (both contiguous 2-D cuda float32; only the first `rows` rows if given)."""
     lib = require_gpu()
-    _f32(x, "x"); _f32(wp, "wp")
+    _f32(x, "x")
+    split = isinstance(wp, tuple)
+    w0 = wp[0] if split else _f32(wp, "wp")
     R = x.shape[0] if rows is None else int(rows)
     cin = x.shape[1]
-    cout = wp.shape[0]
-    assert wp.shape[1] == K * cin, "packed weight shape %s does not match K=%d Cin=%d" % (tuple(wp.shape), K, cin)
+    cout = w0.shape[0]
+    assert w0.shape[1] == K * cin, "packed weight shape %s does not match K=%d Cin=%d" % (tuple(w0.shape), K, cin)
     out = y if y is not None else y_preact
     assert out.shape[1] == cout and out.shape[0] >= R
     if y is not None and y_preact is not None:
         assert y.shape[1] == y_preact.shape[1]
     if row_valid is not None:
         assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    if split:
+        _check(lib.xv_tdnn_layer_bf16x3(_ptr(x), R, cin, x.stride(0), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(scale),
+                                        _ptr(shift), int(act), _ptr(alpha), int(K), int(dilation), cout, _ptr(row_valid),
+                                        _ptr(y), out.stride(0), _ptr(y_preact), _stream()), "xv_tdnn_layer_bf16x3")
+        return
     _check(lib.xv_tdnn_layer_f32(_ptr(x), R, cin, x.stride(0), _ptr(wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
                                  _ptr(alpha), int(K), int(dilation), cout, _ptr(row_valid), _ptr(y), out.stride(0),
                                  _ptr(y_preact), _stream()), "xv_tdnn_layer_f32")
@@ -155,13 +181,19 @@ def stats_pool(h, row_start, row_len, nchunks, max_len, split_rows, eps, out, wo
 
 def fc(x, wp, bias, scale, shift, act, alpha, y, y_preact, rows=None):
     lib = require_gpu()
-    _f32(x, "x"); _f32(wp, "wp")
+    _f32(x, "x")
+    split = isinstance(wp, tuple)
+    w0 = wp[0] if split else _f32(wp, "wp")
     n = x.shape[0] if rows is None else int(rows)
-    out_dim, in_dim = wp.shape
+    out_dim, in_dim = w0.shape
     assert x.shape[1] == in_dim
     for t in (y, y_preact):
         if t is not None:
             _f32(t, "y"); assert t.shape[1] == out_dim and t.shape[0] >= n
+    if split:
+        _check(lib.xv_fc_bf16x3(_ptr(x), n, in_dim, _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+                                _ptr(alpha), out_dim, _ptr(y), _ptr(y_preact), _stream()), "xv_fc_bf16x3")
+        return
     _check(lib.xv_fc_f32(_ptr(x), n, in_dim, _ptr(wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act), _ptr(alpha),
                          out_dim, _ptr(y), _ptr(y_preact), _stream()), "xv_fc_f32")
 
