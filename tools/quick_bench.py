@@ -8,9 +8,11 @@ from xvector_amd import engine, hiplib, synthetic, topology as tp
 
 def main():
     nutt = int(sys.argv[1]) if len(sys.argv) > 1 else 430
+    prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
     topo = tp.get("ModelWithoutDropout")
     w = synthetic.trained_like(topo, 23, seed=1)
-    model = engine.DeviceModel(w, topo, "cuda:0")
+    model = engine.DeviceModel(w, topo, "cuda:0", precision=prec)
+    print("precision:", prec)
     lens = synthetic.utterance_lengths(nutt, 200, 400, 1234)
     layout = engine.BatchLayout(lens, model.gap)
     dev = model.device
@@ -32,6 +34,14 @@ def main():
     fl = tp.flops_per_frame(topo, 23) * frames + tp.flops_per_utt(topo) * nutt
     print("batch: %d utts, %d frames, %d rows; forward %.3f ms -> %.1f utt/s, %.1f TFLOP/s (%.1f%% of 157.3)" %
           (nutt, frames, layout.rows, dt * 1e3, nutt / dt, fl / dt / 1e12, fl / dt / 157.3e12 * 100))
+    if prec != "fp32":
+        ref_model = engine.DeviceModel(w, topo, "cuda:0", precision="fp32")
+        xr = x[:, :ref_model.in_dim].contiguous() if ref_model.in_dim != model.in_dim else x
+        out_ref = torch.empty_like(out)
+        ref_model.forward_packed(xr, rs, rl, rv, layout.nchunks, layout.max_len, out_ref)
+        torch.cuda.synchronize()
+        d = (out.double() - out_ref.double()).norm(dim=1) / out_ref.double().norm(dim=1)
+        print("  %s vs fp32 x-vectors: rel-L2 max %.3e mean %.3e" % (prec, d.max().item(), d.mean().item()))
     # per kernel
     h = x; bufs = (model._ping, model._pong)
     ev = lambda: torch.cuda.Event(enable_timing=True)
