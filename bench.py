@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd"))
 
 MFMA_F32_PEAK = 157.3e12      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+MFMA_BF16_PEAK = 2.5e15       # same guide: dense bf16 MFMA (AMD's 5 PF figure is 2:1 sparse)
 HBM_PEAK = 8.0e12             # same guide: HBM3E 8 TB/s spec
 
 
@@ -45,6 +46,9 @@ def parse():
     ap.add_argument("--batch-rows", type=int, default=131072)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--parity-utts", type=int, default=6)
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="GEMM arithmetic: bf16x3 = split-precision bf16 MFMA with fp32 accumulate (fp32-class accuracy, "
+                         "default); fp32 = exact fp32-input MFMA")
     return ap.parse_args()
 
 
@@ -65,7 +69,7 @@ def main():
     topo = tp.get("ModelWithoutDropout")
     feat = 23
     weights = synthetic.trained_like(topo, feat, seed=1)
-    model = engine.DeviceModel(weights, topo, dev)
+    model = engine.DeviceModel(weights, topo, dev, precision=args.precision)
     gap = model.gap
 
     # ---- synthetic workload resident in HBM: ragged batches in kernel layout -------------------
@@ -181,19 +185,28 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "f32 in/out, GEMMs as bf16x3 split MFMA (hi*hi+hi*lo+lo*hi) with f32 accumulate",
+        "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %d utts/GPU, 23-dim MFCC, T~U{%d..%d}, default x-vector topology "
                                "[512,512,512,512,1536] k=[5,5,7,1,1], 512-d embed_layer-0" % (n_utts, args.tmin, args.tmax),
                    "utts_per_gpu": n_utts, "frames_per_gpu": frames, "batches_per_step": len(batches),
-                   "batch_rows": args.batch_rows, "parallelism": "utterance-sharded x%d, one RCCL gather" % world},
+                   "batch_rows": args.batch_rows, "precision": args.precision,
+                   "parallelism": "utterance-sharded x%d, one RCCL gather" % world},
         "frames_per_s": frames * world * args.steps / dt,
         "algorithmic_tflops": fl_total * world * args.steps / dt / 1e12,
-        "roofline": {"kernel": "tdnn_gemm_kernel<true> (5 TDNN layers per batch + embed FC per step)", "bound": "mfma",
-                     "achieved": fl_gemm / t_gemm / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": fl_gemm / t_gemm / MFMA_F32_PEAK, "traffic": traffic,
-                     "avg_launch_ms": t_gemm / n_gemm_launch * 1e3, "launches": n_gemm_launch,
-                     "algorithmic_gflop_per_launch": fl_gemm / n_gemm_launch / 1e9,
-                     "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"},
+        "roofline": dict({"bound": "mfma", "achieved": fl_gemm / t_gemm / 1e12, "unit": "TFLOP/s", "traffic": traffic,
+                          "avg_launch_ms": t_gemm / n_gemm_launch * 1e3, "launches": n_gemm_launch,
+                          "algorithmic_gflop_per_launch": fl_gemm / n_gemm_launch / 1e9,
+                          "frac_of_fp32_mfma_peak_157.3": fl_gemm / t_gemm / MFMA_F32_PEAK},
+                         **({"kernel": "tdnn_gemm_kernel<true> (5 TDNN layers per batch + embed FC per step)",
+                             "peak": MFMA_F32_PEAK / 1e12, "frac": fl_gemm / t_gemm / MFMA_F32_PEAK,
+                             "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"}
+                            if args.precision == "fp32" else
+                            {"kernel": "tdnn_gemm_bf16x3_kernel (5 TDNN layers per batch + embed FC per step)",
+                             "peak": MFMA_BF16_PEAK / 3 / 1e12, "frac": 3 * fl_gemm / t_gemm / MFMA_BF16_PEAK,
+                             "executed_bf16_tflops": 3 * fl_gemm / t_gemm / 1e12,
+                             "peak_note": "achieved = ALGORITHMIC (fp32-contraction) FLOPs; every product costs 3 bf16 MFMAs, so "
+                                          "peak = 2.5 PFLOP/s dense bf16 MFMA / 3 and frac = executed bf16 FLOPs / 2.5 PF"})),
         "roofline_pool": {"kernel": "stats_pool_kernel", "bound": "hbm", "achieved": by_pool / t_pool / 1e9,
                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": by_pool / t_pool / HBM_PEAK,
                           "avg_launch_ms": t_pool / (len(batches) * args.steps) * 1e3,
@@ -208,7 +221,7 @@ def main():
         for j in np.linspace(0, batches[0]["n"] - 1, args.parity_utts).astype(int):
             lay = batches[0]["lay"]
             s, n = int(lay.row_start[j]), int(lay.row_len[j])
-            m = batches[0]["x"][s:s + n].cpu().numpy()
+            m = batches[0]["x"][s:s + n, :feat].cpu().numpy()
             worst = max(worst, oracle.rel_l2(got[j], oracle.embed_utterance(m, weights, topo, 25, 10000, np.float64)))
         out["parity_rel_l2_max_vs_fp64_oracle"] = worst
     if args.cpu_budget > 0 and world == 1:

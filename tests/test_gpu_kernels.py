@@ -9,7 +9,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TOL_GEMM = 2e-6
+TOL_GEMM = 2e-6          # exact-fp32 MFMA path
+TOL_GEMM3 = 2e-5         # bf16x3 split path (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-17 per operand
 TOL_POOL = 2e-6
 
 
@@ -26,7 +27,7 @@ def _rand_bn(rng, c):
             (0.2 * rng.standard_normal(c)).astype(np.float32), np.exp(0.2 * rng.standard_normal(c)).astype(np.float32))
 
 
-def _run_layer(env, mats, w, b, bn, act, alpha, K, dil, preact=False):
+def _run_layer(env, mats, w, b, bn, act, alpha, K, dil, preact=False, precision="fp32"):
     """Pack `mats` with gap rows, run xv_tdnn_layer_f32, return per-chunk outputs and the full y."""
     torch, hiplib, engine, dev = env["torch"], env["hiplib"], env["engine"], env["dev"]
     gap = max(1, (K - 1) * dil // 2)
@@ -36,7 +37,8 @@ def _run_layer(env, mats, w, b, bn, act, alpha, K, dil, preact=False):
     x = torch.from_numpy(host).to(dev)
     rv = torch.from_numpy(layout.row_valid()).to(dev)
     cin, cout = w.shape[1], w.shape[2]
-    wp = hiplib.pack_weights(torch.from_numpy(np.ascontiguousarray(w.reshape(K * cin, cout))).to(dev))
+    w2d = torch.from_numpy(np.ascontiguousarray(w.reshape(K * cin, cout))).to(dev)
+    wp = hiplib.pack_weights_bf16x3(w2d) if precision == "bf16x3" else hiplib.pack_weights(w2d)
     bias = torch.from_numpy(b).to(dev)
     scale = shift = None
     if bn is not None:
@@ -86,6 +88,48 @@ def test_tdnn_layer_matches_oracle(env, cin, cout, K, dil, act):
     # gap rows must be written as exact zeros (the invariant the next layer relies on)
     valid = layout.row_valid().astype(bool)
     assert (yh[~valid] == 0).all()
+
+
+@pytest.mark.parametrize("cin,cout,K,dil,act", [
+    (24, 512, 5, 1, "relu"),        # layer 0 with the 23 MFCC dims padded to 24 columns
+    (512, 512, 5, 1, "relu"),
+    (512, 512, 7, 1, "relu"),
+    (512, 1536, 1, 1, "relu"),
+    (512, 512, 3, 3, "relu"),       # dilated
+    (64, 48, 5, 1, "prelu"),        # ragged Cout
+    (40, 200, 3, 2, "lrelu"),       # Cin not a multiple of 32
+])
+def test_tdnn_layer_bf16x3_matches_oracle(env, cin, cout, K, dil, act):
+    oracle = env["oracle"]
+    rng = np.random.default_rng(cin * 1000 + cout + K * 7 + dil + 1)
+    lens = [25, 1, 130, 257, 64, 3]
+    mats = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in lens]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = None
+    if act == "lrelu":
+        alpha = np.array([0.2], np.float32)
+    elif act == "prelu":
+        alpha = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    outs, yh, layout, _ = _run_layer(env, mats, w, b, bn, act, alpha, K, dil, precision="bf16x3")
+    for m, got in zip(mats, outs):
+        ref = oracle.tdnn_layer(m, w, b, bn, act, alpha, dil, np.float64)
+        assert np.isfinite(got).all()
+        assert oracle.rel_l2(got, ref) < TOL_GEMM3
+    assert (yh[~layout.row_valid().astype(bool)] == 0).all()
+    # batch-1 == batched, bit for bit, also on the split path
+    alone, _, _, _ = _run_layer(env, [mats[2]], w, b, bn, act, alpha, K, dil, precision="bf16x3")
+    assert np.array_equal(alone[0], outs[2])
+
+
+def test_bf16x3_rejects_unaligned_cin(env):
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    x = torch.zeros((10, 20), dtype=torch.float32, device=dev)
+    wp = hiplib.pack_weights_bf16x3(torch.zeros((20, 8), dtype=torch.float32, device=dev))
+    y = torch.zeros((10, 8), dtype=torch.float32, device=dev)
+    with pytest.raises(hiplib.XvectorHipError):
+        hiplib.tdnn_layer(x, wp, None, None, None, 1, None, 1, 1, None, y)       # Cin % 8 != 0
 
 
 def test_tdnn_layer_batch1_equals_batched_bitwise(env):
@@ -182,6 +226,11 @@ def test_fc_matches_oracle(env):
     ref = oracle.act_bn(ref_pre, bn, "relu", None, np.float64)
     assert oracle.rel_l2(ypre.cpu().numpy(), ref_pre) < TOL_GEMM
     assert oracle.rel_l2(y.cpu().numpy(), ref) < TOL_GEMM
+    hiplib.fc(xd, hiplib.pack_weights_bf16x3(torch.from_numpy(w).to(dev)), torch.from_numpy(b).to(dev), scale, shift, 1,
+              None, y, ypre)
+    torch.cuda.synchronize()
+    assert oracle.rel_l2(ypre.cpu().numpy(), ref_pre) < TOL_GEMM3
+    assert oracle.rel_l2(y.cpu().numpy(), ref) < TOL_GEMM3
 
 
 def test_chunk_average_bit_exact(env):

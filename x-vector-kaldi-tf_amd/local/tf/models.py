@@ -96,7 +96,9 @@ class Model(object):
         self.meta = meta
         self.num_classes = meta["num_classes"]
         self.embedding_index = int(os.environ.get("XVECTOR_EMBEDDING_INDEX", "0"))   # models.py:159-160
-        self.device_model = engine.DeviceModel(w, meta["topology"], _device(), self.embedding_index)
+        # GEMM arithmetic: "bf16x3" (default; split-precision bf16 MFMA, ~6e-6 rel-L2 vs fp32) or "fp32" (exact)
+        self.precision = os.environ.get("XVECTOR_PRECISION", "bf16x3")
+        self.device_model = engine.DeviceModel(w, meta["topology"], _device(), self.embedding_index, self.precision)
         if logger is not None:
             logger.info("Graph restored from path: %s" % input_dir)
 

@@ -84,7 +84,7 @@ class DeviceModel(object):
 
     POOL_SPLIT_ROWS = 512
 
-    def __init__(self, weights, topo, device="cuda:0", embedding_index=0, precision="fp32"):
+    def __init__(self, weights, topo, device="cuda:0", embedding_index=0, precision="bf16x3"):
         """precision: "fp32" = exact fp32 MFMA GEMMs; "bf16x3" = split-precision bf16 MFMA GEMMs (fp32-class
         accuracy, ~3e-6 rel-L2 on the x-vector; see include/xvector_hip.h)."""
         import torch
