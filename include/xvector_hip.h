@@ -79,17 +79,39 @@ int xv_tdnn_layer_f32(const float *x, int64_t R, int cin, int ldx, const float *
                       int K, int dilation, int cout, const uint8_t *row_valid, float *y, int ldy,
                       float *y_preact, void *stream);
 
-/* bf16x3 split-precision twins of xv_pack_weights_f32 / xv_tdnn_layer_f32 / xv_fc_f32 (same semantics, same
- * operands except the weights, which are pre-split into two bf16 planes wp_hi/wp_lo[Cout][K*Cin] by
- * xv_pack_weights_bf16x3; activations stay fp32 in HBM and are split while staged).  Cin % 8 == 0. */
-int xv_pack_weights_bf16x3(const float *w, int kred, int cout, uint16_t *wp_hi, uint16_t *wp_lo, void *stream);
-int xv_tdnn_layer_bf16x3(const float *x, int64_t R, int cin, int ldx, const uint16_t *wp_hi, const uint16_t *wp_lo,
-                         const float *bias, const float *bn_scale, const float *bn_shift, int act_kind,
-                         const float *act_alpha, int K, int dilation, int cout, const uint8_t *row_valid, float *y, int ldy,
-                         float *y_preact, void *stream);
-int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const uint16_t *wp_hi, const uint16_t *wp_lo, const float *bias,
-                 const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y,
-                 float *y_preact, void *stream);
+/* ---- bf16x3 split-precision twins (same contraction, fp32-class accuracy, bf16 matrix cores) ----------------
+ *
+ * Tensor formats for xv_tdnn_layer_bf16x3:
+ *   XV_FMT_F32    row-major fp32, row stride ld (Cin, ld multiples of 4, 16-byte aligned).
+ *   XV_FMT_SPLIT  "split" activations: for row r and 32-channel slab s, 128 bytes at
+ *                 ((r * ceil(C/32) + s) * 128): 8 slots of 16 B; logical slot t = plane*4 + (k>>3) holds channels
+ *                 s*32 + 8*(k>>3) .. +7 of plane hi (0) / lo (1) as bf16; it is stored at physical slot
+ *                 t ^ ((r>>1)&7).  value = float(hi) + float(lo).  Same bytes/element as fp32.  The halo tile of a
+ *                 layer is then a linear global->LDS DMA.  A split INPUT buffer must be readable (and finite, e.g.
+ *                 zero) for rows [-XV_SPLIT_PAD_BEFORE, R + XV_SPLIT_PAD_AFTER) around the pointer to row 0;
+ *                 channels >= C inside the last slab are written as zero by the producing layer.
+ *   xv_split_row_bytes(C) = ceil(C/32)*128.  xv_split_encode_f32 / xv_split_decode_f32 convert fp32 rows <-> split
+ *   (tooling and tests; the layers read/write the format directly).
+ * Weights: xv_pack_weights_bf16x3 turns TF's w[K,Cin,Cout] into xv_packed_weights_bf16x3_bytes(K,Cin,Cout) bytes of
+ *   16 KB tiles, one per (128-column tile, 32-channel slab, tap) in K-loop order, each [hi 128x64 B][lo 128x64 B]. */
+#define XV_FMT_F32 0
+#define XV_FMT_SPLIT 1
+#define XV_SPLIT_PAD_BEFORE 8
+#define XV_SPLIT_PAD_AFTER 136
+size_t xv_packed_weights_bf16x3_bytes(int K, int cin, int cout);
+int xv_pack_weights_bf16x3(const float *w, int K, int cin, int cout, void *wt, void *stream);
+size_t xv_split_row_bytes(int channels);
+int xv_split_encode_f32(const float *x, int64_t R, int c, int ldx, void *xs, void *stream);
+int xv_split_decode_f32(const void *xs, int64_t R, int c, float *x, int ldx, void *stream);
+/* Same semantics as xv_tdnn_layer_f32; x / y in the given formats (ldx / ldy used for XV_FMT_F32 only); y may be
+ * NULL when only y_preact (always fp32 rows, stride ldpre) is wanted. */
+int xv_tdnn_layer_bf16x3(const void *x, int x_format, int64_t R, int cin, int ldx, const void *wt, const float *bias,
+                         const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation,
+                         int cout, const uint8_t *row_valid, void *y, int y_format, int ldy, float *y_preact, int ldpre,
+                         void *stream);
+/* xv_fc_f32 twin: fp32 rows in, fp32 rows out; wt = xv_pack_weights_bf16x3(w, 1, In, Out). */
+int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const void *wt, const float *bias, const float *bn_scale,
+                 const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y, float *y_preact, void *stream);
 
 /* Statistics pooling.  Replaces tf.nn.moments(h, 1) + tf.sqrt(var + 1e-5) + tf.concat
  * (local/tf/models.py:16,75-76):  out[b] = [ mean_t h[t,:]  ||  sqrt(mean_t (h-mean)^2 + eps) ]

@@ -27,8 +27,9 @@ def _rand_bn(rng, c):
             (0.2 * rng.standard_normal(c)).astype(np.float32), np.exp(0.2 * rng.standard_normal(c)).astype(np.float32))
 
 
-def _run_layer(env, mats, w, b, bn, act, alpha, K, dil, preact=False, precision="fp32"):
-    """Pack `mats` with gap rows, run xv_tdnn_layer_f32, return per-chunk outputs and the full y."""
+def _run_layer(env, mats, w, b, bn, act, alpha, K, dil, preact=False, precision="fp32", fmt="f32"):
+    """Pack `mats` with gap rows, run xv_tdnn_layer_f32 / _bf16x3 (fmt: tensor format of x and y on the bf16x3
+    path), return per-chunk outputs and the full y as fp32."""
     torch, hiplib, engine, dev = env["torch"], env["hiplib"], env["engine"], env["dev"]
     gap = max(1, (K - 1) * dil // 2)
     layout = engine.BatchLayout([m.shape[0] for m in mats], gap)
@@ -37,8 +38,10 @@ def _run_layer(env, mats, w, b, bn, act, alpha, K, dil, preact=False, precision=
     x = torch.from_numpy(host).to(dev)
     rv = torch.from_numpy(layout.row_valid()).to(dev)
     cin, cout = w.shape[1], w.shape[2]
-    w2d = torch.from_numpy(np.ascontiguousarray(w.reshape(K * cin, cout))).to(dev)
-    wp = hiplib.pack_weights_bf16x3(w2d) if precision == "bf16x3" else hiplib.pack_weights(w2d)
+    if precision == "bf16x3":
+        wp = hiplib.pack_weights_bf16x3(torch.from_numpy(np.ascontiguousarray(w)).to(dev))
+    else:
+        wp = hiplib.pack_weights(torch.from_numpy(np.ascontiguousarray(w.reshape(K * cin, cout))).to(dev))
     bias = torch.from_numpy(b).to(dev)
     scale = shift = None
     if bn is not None:
@@ -48,7 +51,14 @@ def _run_layer(env, mats, w, b, bn, act, alpha, K, dil, preact=False, precision=
     y = torch.full((layout.rows, cout), float("nan"), dtype=torch.float32, device=dev)
     ypre = torch.full_like(y, float("nan")) if preact else None
     code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
-    hiplib.tdnn_layer(x, wp, bias, scale, shift, code, al, K, dil, rv, y, ypre)
+    if precision == "bf16x3" and fmt == "split":
+        xin = hiplib.SplitBuf(layout.rows, cin, dev)
+        hiplib.split_encode(x, xin)
+        yout = hiplib.SplitBuf(layout.rows, cout, dev)
+        hiplib.tdnn_layer(xin, wp, bias, scale, shift, code, al, K, dil, rv, yout, ypre, rows=layout.rows)
+        y = hiplib.split_decode(yout, layout.rows)
+    else:
+        hiplib.tdnn_layer(x, wp, bias, scale, shift, code, al, K, dil, rv, y, ypre)
     torch.cuda.synchronize()
     yh = y.cpu().numpy()
     outs = [yh[s:s + n] for s, n in zip(layout.row_start, layout.row_len)]
@@ -90,6 +100,7 @@ def test_tdnn_layer_matches_oracle(env, cin, cout, K, dil, act):
     assert (yh[~valid] == 0).all()
 
 
+@pytest.mark.parametrize("fmt", ["f32", "split"])
 @pytest.mark.parametrize("cin,cout,K,dil,act", [
     (24, 512, 5, 1, "relu"),        # layer 0 with the 23 MFCC dims padded to 24 columns
     (512, 512, 5, 1, "relu"),
@@ -99,7 +110,7 @@ def test_tdnn_layer_matches_oracle(env, cin, cout, K, dil, act):
     (64, 48, 5, 1, "prelu"),        # ragged Cout
     (40, 200, 3, 2, "lrelu"),       # Cin not a multiple of 32
 ])
-def test_tdnn_layer_bf16x3_matches_oracle(env, cin, cout, K, dil, act):
+def test_tdnn_layer_bf16x3_matches_oracle(env, cin, cout, K, dil, act, fmt):
     oracle = env["oracle"]
     rng = np.random.default_rng(cin * 1000 + cout + K * 7 + dil + 1)
     lens = [25, 1, 130, 257, 64, 3]
@@ -112,24 +123,53 @@ def test_tdnn_layer_bf16x3_matches_oracle(env, cin, cout, K, dil, act):
         alpha = np.array([0.2], np.float32)
     elif act == "prelu":
         alpha = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
-    outs, yh, layout, _ = _run_layer(env, mats, w, b, bn, act, alpha, K, dil, precision="bf16x3")
+    outs, yh, layout, _ = _run_layer(env, mats, w, b, bn, act, alpha, K, dil, precision="bf16x3", fmt=fmt)
     for m, got in zip(mats, outs):
         ref = oracle.tdnn_layer(m, w, b, bn, act, alpha, dil, np.float64)
         assert np.isfinite(got).all()
         assert oracle.rel_l2(got, ref) < TOL_GEMM3
     assert (yh[~layout.row_valid().astype(bool)] == 0).all()
     # batch-1 == batched, bit for bit, also on the split path
-    alone, _, _, _ = _run_layer(env, [mats[2]], w, b, bn, act, alpha, K, dil, precision="bf16x3")
+    alone, _, _, _ = _run_layer(env, [mats[2]], w, b, bn, act, alpha, K, dil, precision="bf16x3", fmt=fmt)
     assert np.array_equal(alone[0], outs[2])
 
 
-def test_bf16x3_rejects_unaligned_cin(env):
+def test_split_format_roundtrip_and_layout(env):
+    """xv_split_encode_f32 / xv_split_decode_f32 against a NumPy statement of the documented layout
+    (include/xvector_hip.h): slot t = plane*4 + (k>>3) stored at t ^ ((r>>1)&7), value = hi + lo."""
     torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
-    x = torch.zeros((10, 20), dtype=torch.float32, device=dev)
-    wp = hiplib.pack_weights_bf16x3(torch.zeros((20, 8), dtype=torch.float32, device=dev))
+    rng = np.random.default_rng(21)
+    R, C = 37, 72                                   # 3 slabs, last one ragged
+    x = (rng.standard_normal((R, C)) * 5).astype(np.float32)
+    buf = hiplib.SplitBuf(R, C, dev)
+    hiplib.split_encode(torch.from_numpy(x).to(dev), buf)
+    back = hiplib.split_decode(buf, R).cpu().numpy()
+    assert np.abs(back - x).max() <= np.abs(x).max() * 2.0 ** -16
+    raw = buf.base.cpu().numpy()[hiplib.SPLIT_PAD_BEFORE * buf.row_bytes:].view(np.uint16)
+
+    def bf16_rne(a):
+        u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+    hi = bf16_rne(x)
+    lo = bf16_rne(x - (hi.astype(np.uint32) << 16).view(np.float32))
+    for r in (0, 1, 2, 9, 36):
+        for c in (0, 7, 8, 31, 32, 71):
+            s, k = c >> 5, c & 31
+            for plane, want in ((0, hi[r, c]), (1, lo[r, c])):
+                phys = (plane * 4 + (k >> 3)) ^ ((r >> 1) & 7)
+                got = raw[((r * 3 + s) * 128 + phys * 16) // 2 + (k & 7)]
+                assert got == want, (r, c, plane)
+    assert not buf.base[:hiplib.SPLIT_PAD_BEFORE * buf.row_bytes].any()          # padding rows stay zero
+
+
+def test_bf16x3_rejects_unaligned_fp32_input(env):
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    x = torch.zeros((10, 23), dtype=torch.float32, device=dev)
+    wp = hiplib.pack_weights_bf16x3(torch.zeros((1, 23, 8), dtype=torch.float32, device=dev))
     y = torch.zeros((10, 8), dtype=torch.float32, device=dev)
     with pytest.raises(hiplib.XvectorHipError):
-        hiplib.tdnn_layer(x, wp, None, None, None, 1, None, 1, 1, None, y)       # Cin % 8 != 0
+        hiplib.tdnn_layer(x, wp, None, None, None, 1, None, 1, 1, None, y)       # fp32 rows need Cin % 4 == 0
 
 
 def test_tdnn_layer_batch1_equals_batched_bitwise(env):
@@ -226,7 +266,7 @@ def test_fc_matches_oracle(env):
     ref = oracle.act_bn(ref_pre, bn, "relu", None, np.float64)
     assert oracle.rel_l2(ypre.cpu().numpy(), ref_pre) < TOL_GEMM
     assert oracle.rel_l2(y.cpu().numpy(), ref) < TOL_GEMM
-    hiplib.fc(xd, hiplib.pack_weights_bf16x3(torch.from_numpy(w).to(dev)), torch.from_numpy(b).to(dev), scale, shift, 1,
+    hiplib.fc(xd, hiplib.pack_weights_bf16x3(torch.from_numpy(w[None]).to(dev)), torch.from_numpy(b).to(dev), scale, shift, 1,
               None, y, ypre)
     torch.cuda.synchronize()
     assert oracle.rel_l2(ypre.cpu().numpy(), ref_pre) < TOL_GEMM3

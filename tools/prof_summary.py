@@ -33,7 +33,29 @@ def pmc(path, flt=None):
         print("%-70s %-28s %7d %16.1f %18.1f %12.0f" % (short(n)[:70], c, k, a, s, d))
 
 
+def dispatches(path, flt, limit=40):
+    """Per-dispatch counter values (one line per dispatch, counters as columns), for telling layers apart."""
+    cur = sqlite3.connect(path).cursor()
+    rows = {}
+    names = []
+    for did, kn, grid, cn, val, dur in cur.execute(
+            "select dispatch_id, kernel_name, grid_size, counter_name, value, duration from counters_collection order by dispatch_id"):
+        if flt not in kn:
+            continue
+        rows.setdefault(did, dict(grid=grid, dur=dur))[cn] = val
+        if cn not in names:
+            names.append(cn)
+    print("%8s %10s %10s " % ("dispatch", "grid", "dur_us") + " ".join("%22s" % n[-22:] for n in names))
+    for i, (did, r) in enumerate(sorted(rows.items())):
+        if i >= limit:
+            break
+        print("%8d %10d %10.1f " % (did, r["grid"], r["dur"] / 1e3) + " ".join("%22.0f" % r.get(n, float("nan")) for n in names))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "dispatches":
+        dispatches(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 40)
+        sys.exit(0)
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
     else:

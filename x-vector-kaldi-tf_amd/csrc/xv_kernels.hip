@@ -53,7 +53,6 @@ struct GemmParams {
     long R;
     int cin, ldx;
     const float *wp;
-    const uint16_t *wph, *wpl;   // bf16x3 path: hi / lo bf16 planes of the packed weights
     int kred;
     const float *bias, *scale, *shift;
     int act;
@@ -278,33 +277,66 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16x3 split-precision GEMM: every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi));
-// the product is accumulated in fp32 as lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (the lo*lo
-// term, ~2^-16 relative, is dropped).  Activations stay fp32 in HBM and are split while staging; the
-// weights are split once at load time (xv_pack_weights_bf16x3).  Same tiling / halo re-use / epilogue
-// as the fp32 kernel; LDS rows are 32 bf16 (64 B) with the 16-byte slots XOR-swizzled by (row>>2)&3
-// so ds_read_b128 fragment reads are conflict-free without padding.
+// bf16x3 split-precision GEMM (v2: DMA-fed).
+//
+// Every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); products are accumulated in
+// fp32 as lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (the lo*lo term, ~2^-16 relative, is dropped).
+//
+// Operand formats (all produced on the GPU, see include/xvector_hip.h):
+//  * weights: xv_pack_weights_bf16x3 writes one 16 KB tile per (column tile, channel slab, tap) in exactly the
+//    LDS image order ([hi: 128 cols x 64 B][lo: 128 x 64 B], 16-B slots XOR-swizzled by (col>>2)&3), tiles
+//    ordered as the K-loop walks them -> a stage's B operand is ONE linear 16 KB global->LDS DMA.
+//  * activations between layers: "split" format -- per row and 32-channel slab 128 B = [4 hi slots | 4 lo slots]
+//    of 8 bf16, slots XOR-swizzled by (row>>1)&7 -> the (128+(K-1)d)-row halo tile of a slab is a linear DMA of
+//    128 B per row, re-used by all K taps; same bytes per element as fp32.
+//  * the first layer / the segment FC read plain fp32 rows and split them while staging (FP32 A mode).
+// Mainloop per stage and wave: 4 B-DMA + ~1 A-DMA instructions, 16 ds_read_b128, 24 MFMAs, one barrier.
+// Epilogue: accumulators -> LDS (fp32 tile) -> bias/act/BN/gap-mask -> 16-byte stores (fp32 rows or split).
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XROW = 32;   // bf16 per LDS row
-constexpr size_t GEMM3_LDS_BYTES = (size_t)(2 * 2 * A_ROWS * XROW + 2 * 2 * BN * XROW) * 2 + BM;
+constexpr int SROW = 128;                         // bytes per (row, 32-channel slab): LDS A row and HBM split row-slab
+constexpr int A3_BYTES = A_ROWS * SROW;           // 17408
+constexpr int B3_PLANE = BN * 64;                 // 8192
+constexpr int B3_BYTES = 2 * B3_PLANE;            // 16384: [hi tile][lo tile]
+constexpr int T_LD = BN + 4;                      // epilogue fp32 tile row (floats)
+constexpr size_t GEMM3_LDS_BYTES = (size_t)2 * A3_BYTES + 2 * B3_BYTES + BM;
+static_assert((size_t)BM * T_LD * 4 <= (size_t)2 * A3_BYTES + 2 * B3_BYTES, "epilogue tile must fit below the row mask");
 
-__device__ __forceinline__ int swz(int row, int slot) { return row * XROW + ((slot ^ ((row >> 2) & 3)) << 3); }
+struct Gemm3Params {
+    const void *x;        // fp32 rows (x_split == 0) or split buffer (row 0 of it)
+    int x_split;
+    long R;
+    int cin, ldx, xchunks;
+    const uint8_t *wt;    // tiled bf16x3 weights
+    const float *bias, *scale, *shift;
+    int act;
+    const float *alpha;
+    int K, dil, cout;
+    const uint8_t *valid;
+    void *y;              // fp32 rows or split buffer (may be NULL when only ypre is wanted)
+    int y_split, ldy, ychunks;
+    float *ypre;          // fp32 rows, stride ldpre (optional)
+    int ldpre;
+    int n_mt, n_nt, n_chunks;
+};
 
-__global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const GemmParams p)
+#define XV_GLDS16(gptr, lptr)                                                                                   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                    \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <bool SPLIT_A>
+__global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16 *Ah = reinterpret_cast<__bf16 *>(smem);        // [2][A_ROWS][32]
-    __bf16 *Al = Ah + 2 * A_ROWS * XROW;
-    __bf16 *Bh = Al + 2 * A_ROWS * XROW;                  // [2][BN][32]
-    __bf16 *Bl = Bh + 2 * BN * XROW;
-    uint8_t *Ms = reinterpret_cast<uint8_t *>(Bl + 2 * BN * XROW);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *Abuf = lds;                                  // [2][A_ROWS][128 B]
+    char *Bbuf = lds + 2 * A3_BYTES;                   // [2][hi 8 KB | lo 8 KB]
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + 2 * A3_BYTES + 2 * B3_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
     const int nwg = p.n_mt * p.n_nt;
@@ -319,35 +351,43 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const GemmParam
     const int span = (p.K - 1) * p.dil;
     const int left = span >> 1;
     const int rowsA = BM + span;
-    const int n_chunks = (p.cin + BK - 1) / BK;
-    const int n_stages = n_chunks * p.K;
+    const int n_stages = p.n_chunks * p.K;
+    const int goff = (int)((m0 - left) & 15);          // LDS row lr <-> global row gr: (gr & 15) == (lr + goff) & 15
 
     if (tid < BM) {
         const long gr = m0 + tid;
         Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
     }
 
-    f32x4 areg[5];
-    bf16x8 bhreg[2], blreg[2];
-
-    auto load_b = [&](int chunk, int tap) {
-        const int c0 = chunk * BK;
+    // ---- B: one 16 KB tile per stage, 4 x 1 KB DMA pieces per wave ---------------------------------------
+    const uint8_t *bsrc = p.wt + (size_t)nt * n_stages * B3_BYTES + wave * 4096 + lane * 16;
+    auto dma_b = [&](int buf) {
+        char *dst = Bbuf + buf * B3_BYTES + wave * 4096;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int f = tid + NT * j;
-            const int col = f >> 2, slot = f & 3;
-            const int gcol = n0 + col, c = c0 + slot * 8;
-            bf16x8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gcol < p.cout && c < p.cin) {
-                const size_t off = (size_t)gcol * p.kred + (size_t)tap * p.cin + c;
-                vh = *reinterpret_cast<const bf16x8 *>(p.wph + off);
-                vl = *reinterpret_cast<const bf16x8 *>(p.wpl + off);
-            }
-            bhreg[j] = vh;
-            blreg[j] = vl;
-        }
+        for (int j = 0; j < 4; ++j) XV_GLDS16(bsrc + j * 1024, dst + j * 1024);
+        bsrc += B3_BYTES;
     };
+
+    // ---- A (split input): halo tile = rowsA rows x 128 B, DMA pieces of 8 rows --------------------------
+    const size_t xrow_bytes = (size_t)p.xchunks * SROW;
+    const uint8_t *asrc = nullptr;
+    if constexpr (SPLIT_A)
+        asrc = reinterpret_cast<const uint8_t *>(p.x) + (m0 - left + wave * 8 + (lane >> 3)) * (long)xrow_bytes + (lane & 7) * 16;
+    const int n_pieces = (rowsA + 7) >> 3;             // <= 17
+    auto dma_a = [&](int buf) {
+        char *dst = Abuf + buf * A3_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int piece = wave + 4 * j;
+            if (piece < n_pieces) XV_GLDS16(asrc + (size_t)(32 * j) * xrow_bytes, dst + j * 4096);
+        }
+        asrc += SROW;                                   // next 32-channel slab
+    };
+
+    // ---- A (fp32 input): load rows, split to hi/lo while writing the same LDS image -----------------------
+    f32x4 areg[5];
     auto load_a = [&](int chunk) {
+        const float *xf = reinterpret_cast<const float *>(p.x);
         const int c0 = chunk * BK;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -356,18 +396,8 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const GemmParam
             const long gr = m0 - left + lr;
             const int c = c0 + qq * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (lr < rowsA && gr >= 0 && gr < p.R && c < p.cin)
-                v = *reinterpret_cast<const f32x4 *>(p.x + (size_t)gr * p.ldx + c);
+            if (lr < rowsA && gr >= 0 && gr < p.R && c < p.cin) v = *reinterpret_cast<const f32x4 *>(xf + (size_t)gr * p.ldx + c);
             areg[j] = v;
-        }
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int f = tid + NT * j;
-            const int o = buf * (BN * XROW) + swz(f >> 2, f & 3);
-            *reinterpret_cast<bf16x8 *>(Bh + o) = bhreg[j];
-            *reinterpret_cast<bf16x8 *>(Bl + o) = blreg[j];
         }
     };
     auto store_a = [&](int buf) {
@@ -382,20 +412,32 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const GemmParam
                     hi[i] = (__bf16)areg[j][i];
                     lo[i] = (__bf16)(areg[j][i] - (float)hi[i]);
                 }
-                const int o = buf * (A_ROWS * XROW) + swz(lr, qq >> 1) + (qq & 1) * 4;
-                *reinterpret_cast<bf16x4 *>(Ah + o) = hi;
-                *reinterpret_cast<bf16x4 *>(Al + o) = lo;
+                const int sw = ((lr + goff) & 15) >> 1;
+                char *row = Abuf + buf * A3_BYTES + lr * SROW + (qq & 1) * 8;
+                *reinterpret_cast<bf16x4 *>(row + (((qq >> 1)) ^ sw) * 16) = hi;
+                *reinterpret_cast<bf16x4 *>(row + ((4 + (qq >> 1)) ^ sw) * 16) = lo;
             }
         }
     };
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
-    load_a(0);
-    load_b(0, 0);
-    store_a(0);
-    store_b(0);
+    // prologue: stage 0
+    dma_b(0);
+    if constexpr (SPLIT_A) {
+        dma_a(0);
+    } else {
+        load_a(0);
+        store_a(0);
+    }
     __syncthreads();
+
+    // fragment addressing (B is stage-invariant up to the buffer toggle)
+    const int arow0 = wr * 64 + (lane & 31);
+    const int brow = wc * 64 + (lane & 31);
+    const int kh = lane >> 5;
+    const int boff0 = brow * 64, boff1 = (brow + 32) * 64;
+    const int bsw0 = (brow >> 2) & 3, bsw1 = ((brow + 32) >> 2) & 3;
 
     int chunk = 0, tap = 0;
     for (int s = 0; s < n_stages; ++s) {
@@ -404,23 +446,29 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const GemmParam
         const bool has_next = (s + 1) < n_stages;
         const bool new_a = has_next && (ntap == 0);
         if (has_next) {
-            load_b(nchunk, ntap);
-            if (new_a) load_a(nchunk);
+            dma_b((s + 1) & 1);
+            if (new_a) {
+                if constexpr (SPLIT_A) dma_a(nchunk & 1);
+                else load_a(nchunk);
+            }
         }
 
-        const int arow = wr * 64 + (lane & 31) + tap * p.dil;
-        const int brow = wc * 64 + (lane & 31);
-        const int abase = (chunk & 1) * (A_ROWS * XROW);
-        const int bbase = (s & 1) * (BN * XROW);
+        const char *Ab = Abuf + (chunk & 1) * A3_BYTES;
+        const char *Bb = Bbuf + (s & 1) * B3_BYTES;
+        const int lr0 = arow0 + tap * p.dil, lr1 = lr0 + 32;
+        const int sw0 = ((lr0 + goff) & 15) >> 1, sw1 = ((lr1 + goff) & 15) >> 1;
+        const char *a0 = Ab + lr0 * SROW, *a1 = Ab + lr1 * SROW;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int slot = ks * 2 + (lane >> 5);
-            const int oa0 = abase + swz(arow, slot), oa1 = abase + swz(arow + 32, slot);
-            const int ob0 = bbase + swz(brow, slot), ob1 = bbase + swz(brow + 32, slot);
-            const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(Ah + oa0), al0 = *reinterpret_cast<const bf16x8 *>(Al + oa0);
-            const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(Ah + oa1), al1 = *reinterpret_cast<const bf16x8 *>(Al + oa1);
-            const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(Bh + ob0), bl0 = *reinterpret_cast<const bf16x8 *>(Bl + ob0);
-            const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(Bh + ob1), bl1 = *reinterpret_cast<const bf16x8 *>(Bl + ob1);
+            const int t = ks * 2 + kh;
+            const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(a0 + ((t ^ sw0) << 4));
+            const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(a0 + (((t + 4) ^ sw0) << 4));
+            const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(a1 + ((t ^ sw1) << 4));
+            const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(a1 + (((t + 4) ^ sw1) << 4));
+            const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(Bb + boff0 + ((t ^ bsw0) << 4));
+            const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(Bb + B3_PLANE + boff0 + ((t ^ bsw0) << 4));
+            const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(Bb + boff1 + ((t ^ bsw1) << 4));
+            const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(Bb + B3_PLANE + boff1 + ((t ^ bsw1) << 4));
             acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
             acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
@@ -435,37 +483,141 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const GemmParam
             acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
         }
 
-        if (has_next) {
-            store_b((s + 1) & 1);
+        if constexpr (!SPLIT_A) {
             if (new_a) store_a(nchunk & 1);
         }
         __syncthreads();
         chunk = nchunk;
         tap = ntap;
     }
-    gemm_epilogue(p, Ms, m0, n0, wr, wc, lane, acc00, acc01, acc10, acc11);
+
+    // ---- epilogue: accumulators -> LDS fp32 tile (the operand buffers are dead after the last barrier) ------
+    float *T = reinterpret_cast<float *>(lds);
+    {
+        const int col = wc * 64 + (lane & 31);
+        const int rowb = wr * 64 + 4 * (lane >> 5);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int rr = rowb + (reg & 3) + 8 * (reg >> 2);
+            T[rr * T_LD + col] = acc00[reg];
+            T[rr * T_LD + col + 32] = acc01[reg];
+            T[(rr + 32) * T_LD + col] = acc10[reg];
+            T[(rr + 32) * T_LD + col + 32] = acc11[reg];
+        }
+    }
+    __syncthreads();
+
+    const int cg = tid & 15;                            // 8-channel group of the 128-column tile
+    const int gc0 = n0 + cg * 8;
+    float bias[8], sc[8], sh[8], al[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gc = gc0 + i;
+        const bool ok = gc < p.cout;
+        bias[i] = (ok && p.bias) ? p.bias[gc] : 0.f;
+        sc[i] = (ok && p.scale) ? p.scale[gc] : 1.f;
+        sh[i] = (ok && p.shift) ? p.shift[gc] : 0.f;
+        al[i] = (p.act == XV_ACT_LRELU) ? p.alpha[0] : ((p.act == XV_ACT_PRELU && ok) ? p.alpha[gc] : 0.f);
+    }
+    const bool full = gc0 + 8 <= p.cout;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int lr = (tid >> 4) + 16 * j;
+        const long gr = m0 + lr;
+        if (gr >= p.R) continue;
+        const f32x4 t0 = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8 + 4);
+        float z[8], v[8];
+        const bool live = Ms[lr] != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            z[i] = (i < 4 ? t0[i] : t1[i - 4]) + bias[i];
+            const float a = apply_act(z[i], p.act, al[i]) * sc[i] + sh[i];
+            v[i] = (live && (gc0 + i) < p.cout) ? a : 0.f;
+        }
+        if (p.ypre) {
+            float *o = p.ypre + (size_t)gr * p.ldpre + gc0;
+            if (full && !(p.ldpre & 3)) {
+                *reinterpret_cast<f32x4 *>(o) = (f32x4){z[0], z[1], z[2], z[3]};
+                *reinterpret_cast<f32x4 *>(o + 4) = (f32x4){z[4], z[5], z[6], z[7]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (gc0 + i < p.cout) o[i] = z[i];
+            }
+        }
+        if (p.y) {
+            if (p.y_split) {
+                const int ch = gc0 >> 5;
+                if (ch < p.ychunks) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        hi[i] = (__bf16)v[i];
+                        lo[i] = (__bf16)(v[i] - (float)hi[i]);
+                    }
+                    const int sw = (int)(gr >> 1) & 7;
+                    const int slot = cg & 3;
+                    char *row = reinterpret_cast<char *>(p.y) + ((size_t)gr * p.ychunks + ch) * SROW;
+                    *reinterpret_cast<bf16x8 *>(row + ((slot ^ sw) << 4)) = hi;
+                    *reinterpret_cast<bf16x8 *>(row + (((4 + slot) ^ sw) << 4)) = lo;
+                }
+            } else {
+                float *o = reinterpret_cast<float *>(p.y) + (size_t)gr * p.ldy + gc0;
+                if (full && !(p.ldy & 3)) {
+                    *reinterpret_cast<f32x4 *>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (gc0 + i < p.cout) o[i] = v[i];
+                }
+            }
+        }
+    }
 }
 
-int launch_gemm3(const GemmParams &p0, hipStream_t st)
+int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
 {
-    GemmParams p = p0;
+    Gemm3Params p = p0;
     if (p.R <= 0 || p.cout <= 0) return 0;
     if (p.cin <= 0 || p.K <= 0 || (p.K & 1) == 0 || p.dil <= 0) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: K must be odd, dims > 0");
     if ((p.K - 1) * p.dil > MAX_SPAN) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: (K-1)*dilation > 8 unsupported");
-    if (p.ldx < p.cin || p.ldy < p.cout) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: leading dimension too small");
-    if ((p.cin & 7) || (p.ldx & 3) || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.wph) & 15) || (((uintptr_t)p.wpl) & 15))
-        return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: Cin must be a multiple of 8, ldx of 4, pointers 16-byte aligned");
     if ((p.act == XV_ACT_LRELU || p.act == XV_ACT_PRELU) && !p.alpha) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: act_alpha is NULL");
-    p.kred = p.K * p.cin;
+    p.n_chunks = (p.cin + BK - 1) / BK;
+    if (p.x_split) {
+        p.xchunks = p.n_chunks;
+        if (((uintptr_t)p.x) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: split input must be 16-byte aligned");
+    } else {
+        if (p.ldx < p.cin) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: ldx < cin");
+        if ((p.cin & 3) || (p.ldx & 3) || (((uintptr_t)p.x) & 15))
+            return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: fp32 input needs Cin and ldx multiples of 4 and a 16-byte aligned pointer");
+    }
+    if (p.y) {
+        if (p.y_split) {
+            p.ychunks = (p.cout + 31) / 32;
+            if (((uintptr_t)p.y) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: split output must be 16-byte aligned");
+        } else if (p.ldy < p.cout || (((uintptr_t)p.y) & 15)) {
+            return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: ldy < cout or output not 16-byte aligned");
+        }
+    }
+    if (p.ypre && (p.ldpre < p.cout || (((uintptr_t)p.ypre) & 15))) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: bad y_preact");
+    if (((uintptr_t)p.wt) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: packed weights must be 16-byte aligned");
     p.n_mt = (int)((p.R + BM - 1) / BM);
     p.n_nt = (p.cout + BN - 1) / BN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)tdnn_gemm_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)tdnn_gemm_bf16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        e = hipFuncSetAttribute((const void *)tdnn_gemm_bf16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
         attr_done = true;
     }
-    hipLaunchKernelGGL(tdnn_gemm_bf16x3_kernel, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(NT), GEMM3_LDS_BYTES, st, p);
+    const dim3 grid((unsigned)(p.n_mt * p.n_nt));
+    if (p.x_split)
+        hipLaunchKernelGGL(tdnn_gemm_bf16x3_kernel<true>, grid, dim3(NT), GEMM3_LDS_BYTES, st, p);
+    else
+        hipLaunchKernelGGL(tdnn_gemm_bf16x3_kernel<false>, grid, dim3(NT), GEMM3_LDS_BYTES, st, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_bf16x3_kernel launch");
 }
@@ -683,18 +835,57 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, int kred, int c
     wp[i] = w[(size_t)k * cout + n];
 }
 
-// split + transpose: w[kred, cout] fp32 -> hi/lo bf16 planes [cout][kred]
-__global__ void pack_weights_bf16x3_kernel(const float *__restrict__ w, int kred, int cout, uint16_t *__restrict__ wh,
-                                           uint16_t *__restrict__ wl)
+// w[K, cin, cout] fp32 -> tiled bf16x3 weights: tile (nt, chunk, tap) = 16 KB [hi 128x64B][lo 128x64B], slots swizzled
+__global__ void pack_weights_bf16x3_kernel(const float *__restrict__ w, int K, int cin, int cout, int n_chunks,
+                                           uint8_t *__restrict__ wt, size_t total)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)kred * cout) return;
-    const int n = (int)(i / kred), k = (int)(i - (size_t)n * kred);
-    const float x = w[(size_t)k * cout + n];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one (tile, col, k) element
+    if (i >= total) return;
+    const int k = (int)(i & 31);
+    const int n = (int)((i >> 5) & 127);
+    const size_t tile = i >> 12;
+    const int tap = (int)(tile % K);
+    const int chunk = (int)((tile / K) % n_chunks);
+    const int nt = (int)(tile / ((size_t)K * n_chunks));
+    const int c = chunk * 32 + k, gn = nt * 128 + n;
+    const float x = (c < cin && gn < cout) ? w[((size_t)tap * cin + c) * cout + gn] : 0.f;
     const __bf16 hi = (__bf16)x;
     const __bf16 lo = (__bf16)(x - (float)hi);
-    wh[i] = __builtin_bit_cast(uint16_t, hi);
-    wl[i] = __builtin_bit_cast(uint16_t, lo);
+    uint8_t *t = wt + tile * B3_BYTES + n * 64 + (((k >> 3) ^ ((n >> 2) & 3)) << 4) + (k & 7) * 2;
+    *reinterpret_cast<uint16_t *>(t) = __builtin_bit_cast(uint16_t, hi);
+    *reinterpret_cast<uint16_t *>(t + B3_PLANE) = __builtin_bit_cast(uint16_t, lo);
+}
+
+// fp32 rows -> split format (test / tooling helper; the layers write the format themselves)
+__global__ void split_encode_kernel(const float *__restrict__ x, long R, int c, int ldx, uint8_t *__restrict__ xs, int chunks)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * chunks * 32) return;
+    const int k = (int)(i & 31);
+    const int ch = (int)((i >> 5) % chunks);
+    const long r = (long)(i / ((size_t)32 * chunks));
+    const int cc = ch * 32 + k;
+    const float v = cc < c ? x[(size_t)r * ldx + cc] : 0.f;
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const int sw = (int)(r >> 1) & 7;
+    uint8_t *row = xs + ((size_t)r * chunks + ch) * SROW + (k & 7) * 2;
+    *reinterpret_cast<uint16_t *>(row + (((k >> 3) ^ sw) << 4)) = __builtin_bit_cast(uint16_t, hi);
+    *reinterpret_cast<uint16_t *>(row + (((4 + (k >> 3)) ^ sw) << 4)) = __builtin_bit_cast(uint16_t, lo);
+}
+
+__global__ void split_decode_kernel(const uint8_t *__restrict__ xs, long R, int c, int chunks, float *__restrict__ x, int ldx)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * c) return;
+    const long r = (long)(i / c);
+    const int cc = (int)(i - (size_t)r * c);
+    const int ch = cc >> 5, k = cc & 31;
+    const int sw = (int)(r >> 1) & 7;
+    const uint8_t *row = xs + ((size_t)r * chunks + ch) * SROW + (k & 7) * 2;
+    const uint16_t h = *reinterpret_cast<const uint16_t *>(row + (((k >> 3) ^ sw) << 4));
+    const uint16_t l = *reinterpret_cast<const uint16_t *>(row + (((4 + (k >> 3)) ^ sw) << 4));
+    x[(size_t)r * ldx + cc] = __builtin_bit_cast(float, (uint32_t)h << 16) + __builtin_bit_cast(float, (uint32_t)l << 16);
 }
 
 __global__ void fold_bn_kernel(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
@@ -723,7 +914,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 2; }
+int xv_version(void) { return 3; }
 
 const char *xv_last_error(void) { return g_err; }
 
@@ -766,35 +957,67 @@ int xv_fc_f32(const float *x, int nrows, int in_dim, const float *wp, const floa
 }
 
 
-int xv_pack_weights_bf16x3(const float *w, int kred, int cout, uint16_t *wp_hi, uint16_t *wp_lo, void *stream)
+size_t xv_packed_weights_bf16x3_bytes(int K, int cin, int cout)
 {
-    if (!w || !wp_hi || !wp_lo || kred <= 0 || cout <= 0) return fail(XV_ERR_BAD_ARG, "pack_weights_bf16x3: bad argument");
-    const size_t n = (size_t)kred * cout;
-    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, kred,
-                       cout, wp_hi, wp_lo);
+    if (K <= 0 || cin <= 0 || cout <= 0) return 0;
+    return (size_t)((cout + BN - 1) / BN) * ((cin + BK - 1) / BK) * K * B3_BYTES;
+}
+
+int xv_pack_weights_bf16x3(const float *w, int K, int cin, int cout, void *wt, void *stream)
+{
+    if (!w || !wt || K <= 0 || cin <= 0 || cout <= 0) return fail(XV_ERR_BAD_ARG, "pack_weights_bf16x3: bad argument");
+    const int n_chunks = (cin + BK - 1) / BK;
+    const size_t total = xv_packed_weights_bf16x3_bytes(K, cin, cout) / 4;      // 4 bytes (hi+lo) per element
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, K,
+                       cin, cout, n_chunks, (uint8_t *)wt, total);
     return check_launch("pack_weights_bf16x3_kernel");
 }
 
-int xv_tdnn_layer_bf16x3(const float *x, int64_t R, int cin, int ldx, const uint16_t *wp_hi, const uint16_t *wp_lo,
-                         const float *bias, const float *bn_scale, const float *bn_shift, int act_kind,
-                         const float *act_alpha, int K, int dilation, int cout, const uint8_t *row_valid, float *y, int ldy,
-                         float *y_preact, void *stream)
+size_t xv_split_row_bytes(int channels) { return channels <= 0 ? 0 : (size_t)((channels + 31) / 32) * SROW; }
+
+int xv_split_encode_f32(const float *x, int64_t R, int c, int ldx, void *xs, void *stream)
 {
-    if (!x || !wp_hi || !wp_lo || (!y && !y_preact)) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: NULL pointer");
+    if (R <= 0) return 0;
+    if (!x || !xs || c <= 0 || ldx < c) return fail(XV_ERR_BAD_ARG, "split_encode: bad argument");
+    const int chunks = (c + 31) / 32;
+    const size_t n = (size_t)R * chunks * 32;
+    hipLaunchKernelGGL(split_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long)R, c, ldx,
+                       (uint8_t *)xs, chunks);
+    return check_launch("split_encode_kernel");
+}
+
+int xv_split_decode_f32(const void *xs, int64_t R, int c, float *x, int ldx, void *stream)
+{
+    if (R <= 0) return 0;
+    if (!x || !xs || c <= 0 || ldx < c) return fail(XV_ERR_BAD_ARG, "split_decode: bad argument");
+    const size_t n = (size_t)R * c;
+    hipLaunchKernelGGL(split_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)xs, (long)R, c, (c + 31) / 32, x, ldx);
+    return check_launch("split_decode_kernel");
+}
+
+int xv_tdnn_layer_bf16x3(const void *x, int x_format, int64_t R, int cin, int ldx, const void *wt, const float *bias,
+                         const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation,
+                         int cout, const uint8_t *row_valid, void *y, int y_format, int ldy, float *y_preact, int ldpre,
+                         void *stream)
+{
+    if (!x || !wt || (!y && !y_preact)) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: NULL pointer");
     if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: unknown act_kind");
-    GemmParams p{};
-    p.x = x; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wph = wp_hi; p.wpl = wp_lo;
+    if ((x_format != XV_FMT_F32 && x_format != XV_FMT_SPLIT) || (y_format != XV_FMT_F32 && y_format != XV_FMT_SPLIT))
+        return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: unknown tensor format");
+    Gemm3Params p{};
+    p.x = x; p.x_split = x_format == XV_FMT_SPLIT; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wt = (const uint8_t *)wt;
     p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
-    p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid; p.y = y; p.ldy = ldy; p.ypre = y_preact;
+    p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid;
+    p.y = y; p.y_split = y_format == XV_FMT_SPLIT; p.ldy = ldy; p.ypre = y_preact; p.ldpre = ldpre;
     return launch_gemm3(p, (hipStream_t)stream);
 }
 
-int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const uint16_t *wp_hi, const uint16_t *wp_lo, const float *bias,
-                 const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y,
-                 float *y_preact, void *stream)
+int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const void *wt, const float *bias, const float *bn_scale,
+                 const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y, float *y_preact, void *stream)
 {
-    return xv_tdnn_layer_bf16x3(x, nrows, in_dim, in_dim, wp_hi, wp_lo, bias, bn_scale, bn_shift, act_kind, act_alpha, 1, 1,
-                                out_dim, nullptr, y, out_dim, y_preact, stream);
+    return xv_tdnn_layer_bf16x3(x, XV_FMT_F32, nrows, in_dim, in_dim, wt, bias, bn_scale, bn_shift, act_kind, act_alpha, 1, 1,
+                                out_dim, nullptr, y, XV_FMT_F32, out_dim, y_preact, out_dim, stream);
 }
 
 size_t xv_stats_pool_workspace_bytes(int c, int nchunks, int max_len, int split_rows)

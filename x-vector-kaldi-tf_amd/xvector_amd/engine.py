@@ -100,8 +100,7 @@ class DeviceModel(object):
         self.feat_dim = int(weights["frame_level_info_layer-0/w:0"].shape[1])
         # features are packed with the column count rounded up to a multiple of 4 (23 -> 24, extra columns
         # zero, matching zero weight rows) so that layer 0 takes the 16-byte vector staging path
-        pad_to = 8 if precision == "bf16x3" else 4
-        self.in_dim = (self.feat_dim + pad_to - 1) // pad_to * pad_to
+        self.in_dim = (self.feat_dim + 3) // 4 * 4
         self.layers = []
         with torch.cuda.device(self.device):
             for i, (k, d) in enumerate(zip(topo["kernel_sizes"], topo["dilations"])):
@@ -112,11 +111,11 @@ class DeviceModel(object):
                     wpad = np.zeros((k, self.in_dim, w.shape[2]), np.float32)
                     wpad[:, :self.feat_dim] = w
                     w = wpad
-                self.layers.append(self._prep(weights, sc, w.reshape(-1, w.shape[2]), k, d))
+                self.layers.append(self._prep(weights, sc, w, k, d))
             self.embed = []
             for j in range(len(topo["embedding_sizes"])):
                 sc = "embed_layer-%d" % j
-                self.embed.append(self._prep(weights, sc, weights[sc + "/w:0"], 1, 1))
+                self.embed.append(self._prep(weights, sc, weights[sc + "/w:0"][None, :, :], 1, 1))
             torch.cuda.synchronize()
         self.pooled_dim = 2 * self.layers[-1]["cout"]
         self.embed_dim = self.embed[self.embedding_index]["cout"]
@@ -128,12 +127,12 @@ class DeviceModel(object):
     def _dev(self, a):
         return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
-    def _prep(self, weights, scope, w2d, k, d):
-        layer = dict(K=k, dil=d, cin=w2d.shape[0] // k, cout=w2d.shape[1])
-        if self.precision == "bf16x3" and layer["cin"] % 8 == 0:
-            layer["wp"] = hiplib.pack_weights_bf16x3(self._dev(w2d))      # (hi, lo) planes
+    def _prep(self, weights, scope, w3d, k, d):
+        layer = dict(K=k, dil=d, cin=w3d.shape[1], cout=w3d.shape[2])
+        if self.precision == "bf16x3":
+            layer["wp"] = hiplib.pack_weights_bf16x3(self._dev(w3d))                  # tiled hi/lo bf16
         else:
-            layer["wp"] = hiplib.pack_weights(self._dev(w2d))
+            layer["wp"] = hiplib.pack_weights(self._dev(w3d.reshape(-1, w3d.shape[2])))
         layer["bias"] = self._dev(weights[scope + "/b:0"])
         layer["scale"], layer["shift"] = hiplib.fold_bn(*(self._dev(weights["%s/%s:0" % (scope, n)])
                                                           for n in ("gamma", "beta", "mean", "variance")),
@@ -153,8 +152,13 @@ class DeviceModel(object):
             self._cap_rows = int(rows)
             widths = sorted(set(l["cout"] for l in self.layers[:-1]))
             wmax = max(widths) if widths else self.layers[-1]["cout"]
-            self._ping = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
-            self._pong = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
+            if self.precision == "bf16x3":
+                # hidden activations live in the split-bf16 format (zero padding rows included)
+                self._ping = hiplib.SplitBuf(self._cap_rows, wmax, self.device)
+                self._pong = hiplib.SplitBuf(self._cap_rows, wmax, self.device)
+            else:
+                self._ping = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
+                self._pong = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
             self._last = torch.empty((self._cap_rows, self.layers[-1]["cout"]), dtype=torch.float32, device=self.device)
         if nchunks > self._cap_chunks:
             self._cap_chunks = int(nchunks)
@@ -166,7 +170,9 @@ class DeviceModel(object):
                 self._pool_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
 
     def _view(self, buf, rows, width):
-        # contiguous [rows, width] view on the front of a flat buffer
+        # contiguous [rows, width] view on the front of a flat buffer (fp32) / narrower split view
+        if isinstance(buf, hiplib.SplitBuf):
+            return buf if buf.channels == width else buf.view(width)
         return buf.view(-1)[: rows * width].view(rows, width)
 
     # -- the kernel sequence ----------------------------------------------------------------------
@@ -182,7 +188,7 @@ class DeviceModel(object):
             last = i == len(self.layers) - 1
             y = self._view(self._last if last else bufs[i & 1], R, L["cout"])
             hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
-                              row_valid, y)
+                              row_valid, y, rows=R)
             h = y
         hiplib.stats_pool(h, row_start, row_len, nchunks, max_len, self.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON, pooled,
                           self._pool_ws)
@@ -212,15 +218,20 @@ class DeviceModel(object):
         return self.segment_level(pooled, out)
 
     def intermediates_packed(self, x, row_valid):
-        """Debug/test helper: per-layer outputs [R, Cout] for a packed batch (allocates)."""
+        """Debug/test helper: per-layer outputs as fp32 [R, Cout] for a packed batch (allocates)."""
         torch = self.torch
+        R = x.shape[0]
         outs = []
         h = x
-        for L in self.layers:
-            y = torch.empty((x.shape[0], L["cout"]), dtype=torch.float32, device=self.device)
+        for i, L in enumerate(self.layers):
+            last = i == len(self.layers) - 1
+            if self.precision == "bf16x3" and not last:
+                y = hiplib.SplitBuf(R, L["cout"], self.device)
+            else:
+                y = torch.empty((R, L["cout"]), dtype=torch.float32, device=self.device)
             hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
-                              row_valid, y)
-            outs.append(y)
+                              row_valid, y, rows=R)
+            outs.append(hiplib.split_decode(y, R) if isinstance(y, hiplib.SplitBuf) else y)
             h = y
         return outs
 

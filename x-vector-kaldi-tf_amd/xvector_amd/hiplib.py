@@ -10,12 +10,16 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libxvector_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
            "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32",
-           "xv_pack_weights_bf16x3", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3")
+           "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_split_row_bytes", "xv_split_encode_f32",
+           "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3")
+
+FMT_F32, FMT_SPLIT = 0, 1
+SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 136
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
@@ -53,12 +57,20 @@ def load():
     lib.xv_stats_pool_f32.argtypes = [vp, i64, ci, vp, vp, ci, ci, ci, cf, vp, vp, vp]
     lib.xv_fc_f32.restype = ci
     lib.xv_fc_f32.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
+    lib.xv_packed_weights_bf16x3_bytes.restype = sz
+    lib.xv_packed_weights_bf16x3_bytes.argtypes = [ci, ci, ci]
     lib.xv_pack_weights_bf16x3.restype = ci
-    lib.xv_pack_weights_bf16x3.argtypes = [vp, ci, ci, vp, vp, vp]
+    lib.xv_pack_weights_bf16x3.argtypes = [vp, ci, ci, ci, vp, vp]
+    lib.xv_split_row_bytes.restype = sz
+    lib.xv_split_row_bytes.argtypes = [ci]
+    lib.xv_split_encode_f32.restype = ci
+    lib.xv_split_encode_f32.argtypes = [vp, i64, ci, ci, vp, vp]
+    lib.xv_split_decode_f32.restype = ci
+    lib.xv_split_decode_f32.argtypes = [vp, i64, ci, vp, ci, vp]
     lib.xv_tdnn_layer_bf16x3.restype = ci
-    lib.xv_tdnn_layer_bf16x3.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
+    lib.xv_tdnn_layer_bf16x3.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp]
     lib.xv_fc_bf16x3.restype = ci
-    lib.xv_fc_bf16x3.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
+    lib.xv_fc_bf16x3.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
     lib.xv_chunk_average_f32.restype = ci
     lib.xv_chunk_average_f32.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     if lib.xv_version() != ABI_VERSION:
@@ -111,16 +123,94 @@ def pack_weights(w2d):
     return wp
 
 
-def pack_weights_bf16x3(w2d):
-    """w2d: [Kred, Cout] fp32 -> (hi, lo) bf16 planes [Cout, Kred] (stored as int16 tensors)."""
+class Packed3(object):
+    """Tiled bf16x3 weights of one layer (xv_pack_weights_bf16x3) + the shape they were packed for."""
+
+    def __init__(self, wt, K, cin, cout):
+        self.wt, self.K, self.cin, self.cout = wt, K, cin, cout
+
+
+def pack_weights_bf16x3(w3d):
+    """w3d: [K, Cin, Cout] fp32 (TF layout; FC: [1, In, Out]) -> Packed3."""
     import torch
     lib = require_gpu()
-    _f32(w2d, "w")
-    kred, cout = w2d.shape
-    hi = torch.empty((cout, kred), dtype=torch.int16, device=w2d.device)
-    lo = torch.empty((cout, kred), dtype=torch.int16, device=w2d.device)
-    _check(lib.xv_pack_weights_bf16x3(_ptr(w2d), kred, cout, _ptr(hi), _ptr(lo), _stream()), "xv_pack_weights_bf16x3")
-    return hi, lo
+    _f32(w3d, "w")
+    K, cin, cout = w3d.shape
+    nbytes = int(lib.xv_packed_weights_bf16x3_bytes(K, cin, cout))
+    wt = torch.empty(nbytes, dtype=torch.uint8, device=w3d.device)
+    _check(lib.xv_pack_weights_bf16x3(_ptr(w3d), K, cin, cout, _ptr(wt), _stream()), "xv_pack_weights_bf16x3")
+    return Packed3(wt, K, cin, cout)
+
+
+class SplitBuf(object):
+    """Device buffer in the split activation format with the zero padding rows the layer kernels may read
+    (rows [-SPLIT_PAD_BEFORE, rows + SPLIT_PAD_AFTER))."""
+
+    def __init__(self, rows, channels, device):
+        import torch
+        self.rows, self.channels = int(rows), int(channels)
+        self.row_bytes = int(load().xv_split_row_bytes(self.channels))
+        self.base = torch.zeros((SPLIT_PAD_BEFORE + self.rows + SPLIT_PAD_AFTER) * self.row_bytes, dtype=torch.uint8, device=device)
+        self.ptr = self.base.data_ptr() + SPLIT_PAD_BEFORE * self.row_bytes      # row 0
+
+    def view(self, channels):
+        """Same storage seen as a buffer of ``channels`` channels per row (<= allocated width)."""
+        v = object.__new__(SplitBuf)
+        v.rows, v.channels, v.base = self.rows, int(channels), self.base
+        v.row_bytes = int(load().xv_split_row_bytes(v.channels))
+        assert v.row_bytes <= self.row_bytes
+        v.ptr = self.base.data_ptr() + SPLIT_PAD_BEFORE * v.row_bytes
+        return v
+
+
+def split_encode(x, buf, rows=None):
+    """fp32 rows x[R, C] -> buf (SplitBuf)."""
+    lib = require_gpu()
+    _f32(x, "x")
+    R = x.shape[0] if rows is None else int(rows)
+    assert R <= buf.rows and x.shape[1] == buf.channels
+    _check(lib.xv_split_encode_f32(_ptr(x), R, x.shape[1], x.stride(0), ctypes.c_void_p(buf.ptr), _stream()), "xv_split_encode_f32")
+
+
+def split_decode(buf, rows, out=None):
+    """SplitBuf -> fp32 tensor [rows, C]."""
+    import torch
+    lib = require_gpu()
+    if out is None:
+        out = torch.empty((rows, buf.channels), dtype=torch.float32, device=buf.base.device)
+    _check(lib.xv_split_decode_f32(ctypes.c_void_p(buf.ptr), int(rows), buf.channels, _ptr(out), out.stride(0), _stream()),
+           "xv_split_decode_f32")
+    return out
+
+
+def tdnn_layer3(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y, y_preact=None):
+    """bf16x3 layer.  x / y: contiguous fp32 tensors [>=R, C] (XV_FMT_F32) or SplitBuf (XV_FMT_SPLIT); w: Packed3."""
+    lib = require_gpu()
+    assert isinstance(w, Packed3)
+    xs, ys = isinstance(x, SplitBuf), isinstance(y, SplitBuf)
+    if xs:
+        assert x.channels == w.cin and x.rows >= R
+        xp, ldx = ctypes.c_void_p(x.ptr), 0
+    else:
+        _f32(x, "x"); assert x.shape[1] == w.cin and x.shape[0] >= R
+        xp, ldx = _ptr(x), x.stride(0)
+    if y is None:
+        yp, ldy = None, 0
+    elif ys:
+        assert y.channels == w.cout and y.rows >= R
+        yp, ldy = ctypes.c_void_p(y.ptr), 0
+    else:
+        _f32(y, "y"); assert y.shape[1] == w.cout and y.shape[0] >= R
+        yp, ldy = _ptr(y), y.stride(0)
+    ldpre = 0
+    if y_preact is not None:
+        _f32(y_preact, "y_preact"); assert y_preact.shape[1] == w.cout and y_preact.shape[0] >= R
+        ldpre = y_preact.stride(0)
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_layer_bf16x3(xp, FMT_SPLIT if xs else FMT_F32, int(R), w.cin, ldx, _ptr(w.wt), _ptr(bias), _ptr(scale),
+                                    _ptr(shift), int(act), _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), yp,
+                                    FMT_SPLIT if ys else FMT_F32, ldy, _ptr(y_preact), ldpre, _stream()), "xv_tdnn_layer_bf16x3")
 
 
 def fold_bn(gamma, beta, mean, var, eps):
@@ -138,24 +228,22 @@ def fold_bn(gamma, beta, mean, var, eps):
 def tdnn_layer(x, wp, bias, scale, shift, act, alpha, K, dilation, row_valid, y, y_preact=None, rows=None):
     """x[R,Cin] -> y[R,Cout] (both contiguous 2-D cuda float32; only the first `rows` rows if given)."""
     lib = require_gpu()
+    if isinstance(wp, Packed3):
+        assert wp.K == K
+        R = int(rows) if rows is not None else (x.rows if isinstance(x, SplitBuf) else x.shape[0])
+        return tdnn_layer3(x, R, wp, bias, scale, shift, act, alpha, dilation, row_valid, y, y_preact)
     _f32(x, "x")
-    split = isinstance(wp, tuple)
-    w0 = wp[0] if split else _f32(wp, "wp")
+    _f32(wp, "wp")
     R = x.shape[0] if rows is None else int(rows)
     cin = x.shape[1]
-    cout = w0.shape[0]
-    assert w0.shape[1] == K * cin, "packed weight shape %s does not match K=%d Cin=%d" % (tuple(w0.shape), K, cin)
+    cout = wp.shape[0]
+    assert wp.shape[1] == K * cin, "packed weight shape %s does not match K=%d Cin=%d" % (tuple(wp.shape), K, cin)
     out = y if y is not None else y_preact
     assert out.shape[1] == cout and out.shape[0] >= R
     if y is not None and y_preact is not None:
         assert y.shape[1] == y_preact.shape[1]
     if row_valid is not None:
         assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
-    if split:
-        _check(lib.xv_tdnn_layer_bf16x3(_ptr(x), R, cin, x.stride(0), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(scale),
-                                        _ptr(shift), int(act), _ptr(alpha), int(K), int(dilation), cout, _ptr(row_valid),
-                                        _ptr(y), out.stride(0), _ptr(y_preact), _stream()), "xv_tdnn_layer_bf16x3")
-        return
     _check(lib.xv_tdnn_layer_f32(_ptr(x), R, cin, x.stride(0), _ptr(wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
                                  _ptr(alpha), int(K), int(dilation), cout, _ptr(row_valid), _ptr(y), out.stride(0),
                                  _ptr(y_preact), _stream()), "xv_tdnn_layer_f32")
@@ -182,16 +270,17 @@ def stats_pool(h, row_start, row_len, nchunks, max_len, split_rows, eps, out, wo
 def fc(x, wp, bias, scale, shift, act, alpha, y, y_preact, rows=None):
     lib = require_gpu()
     _f32(x, "x")
-    split = isinstance(wp, tuple)
-    w0 = wp[0] if split else _f32(wp, "wp")
+    split = isinstance(wp, Packed3)
+    if not split:
+        _f32(wp, "wp")
     n = x.shape[0] if rows is None else int(rows)
-    out_dim, in_dim = w0.shape
+    out_dim, in_dim = (wp.cout, wp.cin) if split else wp.shape
     assert x.shape[1] == in_dim
     for t in (y, y_preact):
         if t is not None:
             _f32(t, "y"); assert t.shape[1] == out_dim and t.shape[0] >= n
     if split:
-        _check(lib.xv_fc_bf16x3(_ptr(x), n, in_dim, _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+        _check(lib.xv_fc_bf16x3(_ptr(x), n, in_dim, _ptr(wp.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
                                 _ptr(alpha), out_dim, _ptr(y), _ptr(y_preact), _stream()), "xv_fc_bf16x3")
         return
     _check(lib.xv_fc_f32(_ptr(x), n, in_dim, _ptr(wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act), _ptr(alpha),
