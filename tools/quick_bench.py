@@ -7,7 +7,7 @@ import torch
 from xvector_amd import engine, hiplib, synthetic, topology as tp
 
 def main():
-    nutt = int(sys.argv[1]) if len(sys.argv) > 1 else 430
+    nutt = int(sys.argv[1]) if len(sys.argv) > 1 else 428
     prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
     topo = tp.get("ModelWithoutDropout")
     w = synthetic.trained_like(topo, 23, seed=1)

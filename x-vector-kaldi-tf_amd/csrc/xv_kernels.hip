@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -320,13 +321,17 @@ struct Gemm3Params {
     float *ypre;          // fp32 rows, stride ldpre (optional)
     int ldpre;
     int n_mt, n_nt, n_chunks;
+    int nt_major;
+    int dbg;      // ablation switches (XV_DBG env; 0 in production): 1 skip B DMA, 2 skip A DMA, 4 skip MFMAs, 8 skip frag reads
 };
 
 #define XV_GLDS16(gptr, lptr)                                                                                   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                    \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-template <bool SPLIT_A>
+// PW: A-halo DMA pieces (8 rows = 1 KB each) every wave issues per stage on the split-input path; the (<=17)-piece
+// halo tile of the NEXT slab is spread evenly over the stages of the current slab (K=1: 4, K=3: 3, K=5: 2, K=7: 1).
+template <bool SPLIT_A, int PW>
 __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -339,12 +344,32 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
+    // XCD-aware tile order.  Hardware places block b on XCD b%8; every XCD gets a contiguous run [start, start+cnt)
+    // of logical tile ids L = mt*n_nt + nt (bijective chunking).  Inside the run the order is either
+    //   nt fastest  (small weights: the n_nt column tiles sharing an A panel run together, all weights fit L2), or
+    //   nt slowest  (weights > L2: the ~64 blocks resident on an XCD share ONE column tile's weight panel, which
+    //                then stays L2-resident however far the blocks drift apart; A panels are re-streamed instead).
     const int nwg = p.n_mt * p.n_nt;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    int mt, nt;
+    if (!p.nt_major) {
+        const int wg = start + idx;
+        mt = wg / p.n_nt;
+        nt = wg - mt * p.n_nt;
+    } else {
+        const int end = start + (xcd < r ? q + 1 : q);
+        int j = idx, L0 = start;
+        for (nt = 0; nt < p.n_nt; ++nt) {
+            L0 = start + ((nt - start % p.n_nt + p.n_nt) % p.n_nt);       // first id of the run in column tile nt
+            const int cnt = L0 < end ? (end - L0 + p.n_nt - 1) / p.n_nt : 0;
+            if (j < cnt) break;
+            j -= cnt;
+        }
+        mt = (L0 + j * p.n_nt) / p.n_nt;
+    }
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
 
@@ -422,16 +447,6 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
-    // prologue: stage 0
-    dma_b(0);
-    if constexpr (SPLIT_A) {
-        dma_a(0);
-    } else {
-        load_a(0);
-        store_a(0);
-    }
-    __syncthreads();
-
     // fragment addressing (B is stage-invariant up to the buffer toggle)
     const int arow0 = wr * 64 + (lane & 31);
     const int brow = wc * 64 + (lane & 31);
@@ -439,57 +454,154 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     const int boff0 = brow * 64, boff1 = (brow + 32) * 64;
     const int bsw0 = (brow >> 2) & 3, bsw1 = ((brow + 32) >> 2) & 3;
 
-    int chunk = 0, tap = 0;
-    for (int s = 0; s < n_stages; ++s) {
-        int nchunk = chunk, ntap = tap + 1;
-        if (ntap == p.K) { ntap = 0; nchunk = chunk + 1; }
-        const bool has_next = (s + 1) < n_stages;
-        const bool new_a = has_next && (ntap == 0);
-        if (has_next) {
-            dma_b((s + 1) & 1);
-            if (new_a) {
-                if constexpr (SPLIT_A) dma_a(nchunk & 1);
-                else load_a(nchunk);
-            }
-        }
-
-        const char *Ab = Abuf + (chunk & 1) * A3_BYTES;
-        const char *Bb = Bbuf + (s & 1) * B3_BYTES;
-        const int lr0 = arow0 + tap * p.dil, lr1 = lr0 + 32;
+    struct Frags {            // fragments of one k-step (16 of the 32 channels of a stage): 8 x 4 VGPRs
+        bf16x8 ah0, al0, ah1, al1, bh0, bl0, bh1, bl1;
+    };
+    auto load_frags = [&](Frags &F, int st, int ch, int tp, int ks) {
+        const char *Ab = Abuf + (ch & 1) * A3_BYTES;
+        const char *Bb = Bbuf + (st & 1) * B3_BYTES;
+        const int lr0 = arow0 + tp * p.dil, lr1 = lr0 + 32;
         const int sw0 = ((lr0 + goff) & 15) >> 1, sw1 = ((lr1 + goff) & 15) >> 1;
         const char *a0 = Ab + lr0 * SROW, *a1 = Ab + lr1 * SROW;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int t = ks * 2 + kh;
-            const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(a0 + ((t ^ sw0) << 4));
-            const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(a0 + (((t + 4) ^ sw0) << 4));
-            const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(a1 + ((t ^ sw1) << 4));
-            const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(a1 + (((t + 4) ^ sw1) << 4));
-            const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(Bb + boff0 + ((t ^ bsw0) << 4));
-            const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(Bb + B3_PLANE + boff0 + ((t ^ bsw0) << 4));
-            const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(Bb + boff1 + ((t ^ bsw1) << 4));
-            const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(Bb + B3_PLANE + boff1 + ((t ^ bsw1) << 4));
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
-        }
+        const int t = ks * 2 + kh;
+        F.al0 = *reinterpret_cast<const bf16x8 *>(a0 + (((t + 4) ^ sw0) << 4));
+        F.bh0 = *reinterpret_cast<const bf16x8 *>(Bb + boff0 + ((t ^ bsw0) << 4));
+        F.bh1 = *reinterpret_cast<const bf16x8 *>(Bb + boff1 + ((t ^ bsw1) << 4));
+        F.al1 = *reinterpret_cast<const bf16x8 *>(a1 + (((t + 4) ^ sw1) << 4));
+        F.ah0 = *reinterpret_cast<const bf16x8 *>(a0 + ((t ^ sw0) << 4));
+        F.bl0 = *reinterpret_cast<const bf16x8 *>(Bb + B3_PLANE + boff0 + ((t ^ bsw0) << 4));
+        F.bl1 = *reinterpret_cast<const bf16x8 *>(Bb + B3_PLANE + boff1 + ((t ^ bsw1) << 4));
+        F.ah1 = *reinterpret_cast<const bf16x8 *>(a1 + ((t ^ sw1) << 4));
+    };
+    auto mma = [&](const Frags &F) {
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.al0, F.bh0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.al0, F.bh1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.al1, F.bh0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.al1, F.bh1, acc11, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah0, F.bl0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah0, F.bl1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah1, F.bl0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah1, F.bl1, acc11, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah0, F.bh0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah0, F.bh1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah1, F.bh0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah1, F.bh1, acc11, 0, 0, 0);
+    };
 
-        if constexpr (!SPLIT_A) {
-            if (new_a) store_a(nchunk & 1);
+    // Register-level software pipeline at k-step granularity (two 32-VGPR fragment sets F, G):
+    //   iteration s:  G <- LDS(stage s, k-step 1) | 12 MFMAs on F (stage s, k-step 0)
+    //                 barrier B(s)   [stage s fully read by everybody; stage s+1 landed]
+    //                 DMA(stage s+2) into the buffers of stage s | F <- LDS(stage s+1, k-step 0) | 12 MFMAs on G
+    // Each MFMA group hides the LDS latency of the other set's reads; a DMA has a full stage to land.
+    int c1 = 0, t1 = 0;                       // (chunk, tap) of stage s+1
+    auto advance = [&](int &c, int &t) { if (++t == p.K) { t = 0; ++c; } };
+
+    dma_b(0);
+    if constexpr (SPLIT_A) dma_a(0);
+    else { load_a(0); store_a(0); }
+    advance(c1, t1);
+    if (n_stages > 1) {
+        dma_b(1);
+        if (t1 == 0) {
+            if constexpr (SPLIT_A) dma_a(1);
+            else { load_a(1); store_a(1); }
         }
-        __syncthreads();
-        chunk = nchunk;
-        tap = ntap;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    Frags F = {}, G = {};
+    load_frags(F, 0, 0, 0, 0);
+
+    int c0 = 0, t0 = 0;                       // (chunk, tap) of stage s
+    int c2 = c1, t2 = t1;                     // (chunk, tap) of stage s+2
+    advance(c2, t2);
+    if constexpr (SPLIT_A) {
+        // Straight-line iteration body (no branches): DMA is issued unconditionally (clamped at the tail, where it
+        // rewrites identical bytes), so that sched_group_barrier can interleave every memory instruction with the
+        // MFMAs of the same wave: the wave overlaps its own memory issue instead of relying on the co-resident block.
+        const uint8_t *bnext = bsrc;                         // tile of stage min(s+2, n_stages-1)
+        if (n_stages <= 2) bnext = bsrc - B3_BYTES;
+        const uint8_t *abase = reinterpret_cast<const uint8_t *>(p.x) + (m0 - left + (lane >> 3)) * (long)xrow_bytes + (lane & 7) * 16;
+        for (int s = 0; s < n_stages; ++s) {
+            // ---- phase 1: G <- LDS(stage s, k-step 1) interleaved with the 12 MFMAs on F ---------------------------
+            load_frags(G, s, c0, t0, 1);
+            mma(F);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                  // B(s): stage s fully read by everybody, stage s+1 landed
+            // ---- phase 2: DMA(s+2), F <- LDS(stage s+1, k-step 0), 12 MFMAs on G ------------------------------------
+            {
+                char *dst = Bbuf + (s & 1) * B3_BYTES + wave * 4096;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) XV_GLDS16(bnext + j * 1024, dst + j * 1024);
+                bnext += (s + 3 < n_stages) ? B3_BYTES : 0;
+                // A halo of slab `ca`: K == 1 -> the slab of stage s+2 (all pieces now); K > 1 -> the next slab,
+                // pieces spread over taps 0..K-2 of the current slab (tap K-1 re-issues the last piece, harmlessly)
+                int ca = (p.K == 1) ? s + 2 : c0 + 1;
+                ca = ca < p.n_chunks ? ca : p.n_chunks - 1;
+                const int tslot = (p.K == 1) ? 0 : t0;
+                char *adst = Abuf + (ca & 1) * A3_BYTES;
+                const uint8_t *ag = abase + (size_t)ca * SROW;
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                    int piece = (tslot * 4 + wave) * PW + j;
+                    piece = piece < n_pieces ? piece : n_pieces - 1;
+                    XV_GLDS16(ag + (size_t)(piece * 8) * xrow_bytes, adst + piece * 1024);
+                }
+            }
+            {
+                const int s1 = (s + 1 < n_stages) ? s + 1 : s;           // tail: harmless re-read
+                const int cc = (s + 1 < n_stages) ? c1 : c0, tt = (s + 1 < n_stages) ? t1 : t0;
+                load_frags(F, s1, cc, tt, 0);
+            }
+            mma(G);
+#pragma unroll
+            for (int i = 0; i < 4 + PW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // 1 VMEM (LDS-DMA piece)
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 12 - (8 + PW) > 0 ? 12 - (8 + PW) : 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = c1; t0 = t1;
+            advance(c1, t1);
+        }
+    } else {
+        for (int s = 0; s < n_stages; ++s) {
+            load_frags(G, s, c0, t0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(F);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                  // B(s)
+            const bool dma2 = (s + 2) < n_stages;
+            const bool newa2 = dma2 && (t2 == 0);
+            if (dma2) {
+                dma_b(s & 1);
+                if (newa2) load_a(c2);
+            }
+            if (s + 1 < n_stages) load_frags(F, s + 1, c1, t1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(G);
+            __builtin_amdgcn_sched_barrier(0);
+            if (newa2) store_a(c2 & 1);
+            c0 = c1; t0 = t1;
+            advance(c1, t1);
+            advance(c2, t2);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     // ---- epilogue: accumulators -> LDS fp32 tile (the operand buffers are dead after the last barrier) ------
     float *T = reinterpret_cast<float *>(lds);
@@ -605,19 +717,37 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
     if (((uintptr_t)p.wt) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: packed weights must be 16-byte aligned");
     p.n_mt = (int)((p.R + BM - 1) / BM);
     p.n_nt = (p.cout + BN - 1) / BN;
+    {
+        // weights of the whole layer vs the 4 MiB per-XCD L2 (leave room for the A stream)
+        static const char *env = getenv("XV_NT_MAJOR");
+        const size_t wbytes = (size_t)p.n_nt * p.n_chunks * p.K * B3_BYTES;
+        p.nt_major = env ? atoi(env) : 0;       // measured: nt-fastest wins on every layer of the default topology
+        (void)wbytes;
+        static const char *dbg = getenv("XV_DBG");
+        p.dbg = dbg ? atoi(dbg) : 0;
+    }
+    typedef void (*kern_t)(const Gemm3Params);
+    kern_t kern;
+    if (!p.x_split) kern = tdnn_gemm_bf16x3_kernel<false, 0>;
+    else if (p.K == 1) kern = tdnn_gemm_bf16x3_kernel<true, 4>;
+    else {
+        const int n_pieces = (BM + (p.K - 1) * p.dil + 7) / 8;
+        const int pw = (n_pieces + 4 * (p.K - 1) - 1) / (4 * (p.K - 1));
+        kern = pw <= 1 ? tdnn_gemm_bf16x3_kernel<true, 1> : pw == 2 ? tdnn_gemm_bf16x3_kernel<true, 2>
+             : pw == 3 ? tdnn_gemm_bf16x3_kernel<true, 3> : tdnn_gemm_bf16x3_kernel<true, 4>;
+        if (pw > 4) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: halo tile too large for the DMA schedule");
+    }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)tdnn_gemm_bf16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-        e = hipFuncSetAttribute((const void *)tdnn_gemm_bf16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        const kern_t all[] = {tdnn_gemm_bf16x3_kernel<false, 0>, tdnn_gemm_bf16x3_kernel<true, 1>, tdnn_gemm_bf16x3_kernel<true, 2>,
+                              tdnn_gemm_bf16x3_kernel<true, 3>, tdnn_gemm_bf16x3_kernel<true, 4>};
+        for (kern_t k : all) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        }
         attr_done = true;
     }
-    const dim3 grid((unsigned)(p.n_mt * p.n_nt));
-    if (p.x_split)
-        hipLaunchKernelGGL(tdnn_gemm_bf16x3_kernel<true>, grid, dim3(NT), GEMM3_LDS_BYTES, st, p);
-    else
-        hipLaunchKernelGGL(tdnn_gemm_bf16x3_kernel<false>, grid, dim3(NT), GEMM3_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(NT), GEMM3_LDS_BYTES, st, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_bf16x3_kernel launch");
 }
