@@ -109,20 +109,7 @@ def main():
 
     def step(si):
         for bi, b in enumerate(batches):
-            e = ev[si][bi]
-            R = b["rows"]
-            h = b["x"]
-            bufs = (model._ping, model._pong)
-            e[0].record()
-            for i, L in enumerate(model.layers):
-                y = model._view(model._last if i == len(model.layers) - 1 else bufs[i & 1], R, L["cout"])
-                hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], model.act, L["alpha"], L["K"], L["dil"],
-                                  b["rv"], y)
-                h = y
-            e[1].record()
-            hiplib.stats_pool(h, b["rs"], b["rl"], b["n"], b["max_len"], model.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON,
-                              P_all[b["lo"]:b["hi"]], model._pool_ws)
-            e[2].record()
+            model.frame_level(b["x"], b["rs"], b["rl"], b["rv"], b["n"], b["max_len"], P_all[b["lo"]:b["hi"]], events=ev[si][bi])
         ev_fc[si][0].record()
         model.segment_level(P_all, E_all)                 # embed_layer-0 once over all chunks of the step
         ev_fc[si][1].record()

@@ -176,22 +176,29 @@ class DeviceModel(object):
         return buf.view(-1)[: rows * width].view(rows, width)
 
     # -- the kernel sequence ----------------------------------------------------------------------
-    def frame_level(self, x, row_start, row_len, row_valid, nchunks, max_len, pooled):
+    def frame_level(self, x, row_start, row_len, row_valid, nchunks, max_len, pooled, events=None):
         """Frame-level part for ONE ragged batch: x[R,in_dim] (gap rows zero) -> 5 TDNN layers -> statistics
         pooling, written to pooled[nchunks, 2*C_last].  Device tensors only; no allocation when ``reserve`` was
-        called with sufficient capacity."""
+        called with sufficient capacity.  ``events``: optional 3 torch.cuda.Event recorded before the first layer,
+        after the last layer and after pooling (bench.py's per-kernel timing)."""
         R = x.shape[0]
         self.reserve(R, nchunks, max_len)
         h = x
         bufs = (self._ping, self._pong)
+        if events is not None:
+            events[0].record()
         for i, L in enumerate(self.layers):
             last = i == len(self.layers) - 1
             y = self._view(self._last if last else bufs[i & 1], R, L["cout"])
             hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
                               row_valid, y, rows=R)
             h = y
+        if events is not None:
+            events[1].record()
         hiplib.stats_pool(h, row_start, row_len, nchunks, max_len, self.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON, pooled,
                           self._pool_ws)
+        if events is not None:
+            events[2].record()
         return pooled
 
     def segment_level(self, pooled, out):
