@@ -148,3 +148,37 @@ def test_roundtrip_random():
     back = dict(kaldi_io.read_mat_ark(io.BytesIO(bio.getvalue())))
     assert list(back) == list(mats)
     assert all(np.array_equal(back[k], mats[k]) for k in mats)
+
+
+def test_buffered_stream_hands_back_unread_bytes(g):
+    """read_mat_ark reads ahead in blocks; when the caller stops early on a seekable stream the position is restored
+    to the first unread record, so interleaving with other readers keeps working."""
+    bio = io.BytesIO(g["mat_ark"].tobytes())
+    gen = kaldi_io.read_mat_ark(bio)
+    k, m = next(gen)
+    assert k == "utt-a.1"
+    gen.close()
+    assert kaldi_io.read_key(bio) == "utt_b/2"
+
+
+def test_write_vec_flt_batch_equals_per_key_writes(g):
+    a, b = io.BytesIO(), io.BytesIO()
+    keys = ["k1", "k2", "k3"]
+    vecs = [g["fv"], g["fv"] * 2, g["fv"][:7].copy()]
+    for k, v in zip(keys, vecs):
+        kaldi_io.write_vec_flt(a, v, key=k)
+    kaldi_io.write_vec_flt_batch(b, keys, vecs)
+    assert a.getvalue() == b.getvalue()
+    with pytest.raises(kaldi_io.UnsupportedDataType):
+        kaldi_io.write_vec_flt_batch(io.BytesIO(), ["x"], [np.zeros(3)])
+
+
+def test_pipe_and_large_stream_through_buffered_reader(tmp_path):
+    rng = np.random.default_rng(1)
+    mats = {"u%05d" % i: rng.standard_normal((int(rng.integers(1, 400)), 23)).astype(np.float32) for i in range(300)}
+    ark = tmp_path / "big.ark"
+    with open(ark, "wb") as f:
+        for k, m in mats.items():
+            kaldi_io.write_mat(f, m, key=k)
+    got = dict(kaldi_io.read_mat_ark("ark:cat %s |" % ark))
+    assert list(got) == list(mats) and all(np.array_equal(got[k], mats[k]) for k in mats)

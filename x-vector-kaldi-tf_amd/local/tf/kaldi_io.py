@@ -37,7 +37,7 @@ import threading
 import numpy as np
 
 __all__ = ["open_or_fd", "popen", "TableWriter", "read_key", "read_mat", "read_mat_ark", "read_mat_scp", "write_mat",
-           "read_vec_flt", "read_vec_flt_ark", "read_vec_flt_scp", "write_vec_flt",
+           "read_vec_flt", "read_vec_flt_ark", "read_vec_flt_scp", "write_vec_flt", "write_vec_flt_batch",
            "UnsupportedDataType", "UnknownVectorHeader", "UnknownMatrixHeader", "BadSampleSize",
            "BadInputFormat", "SubprocessFailed"]
 
@@ -121,6 +121,85 @@ def open_or_fd(file, mode="rb"):
     return fd
 
 
+class _BufferedStream(object):
+    """Read-ahead wrapper used by the ark generators: the reference reads keys one byte at a time through
+    ``fd.read(1)``; this pulls the stream in 4 MiB blocks and serves ``read`` / ``readline`` / key scans from memory.
+    Whatever was read ahead is handed back to a seekable ``fd`` (``seek`` to the logical position) on ``detach``."""
+
+    BLOCK = 1 << 22
+
+    def __init__(self, fd):
+        self.fd = fd
+        self.buf = b""
+        self.pos = 0
+
+    def _fill(self, need):
+        """Make at least ``need`` bytes available after pos (fewer only at end of stream)."""
+        avail = len(self.buf) - self.pos
+        if avail >= need:
+            return
+        parts = [self.buf[self.pos:]]
+        while avail < need:
+            blk = self.fd.read(max(self.BLOCK, need - avail))
+            if not blk:
+                break
+            parts.append(blk)
+            avail += len(blk)
+        self.buf = b"".join(parts)
+        self.pos = 0
+
+    def read(self, n=-1):
+        if n is None or n < 0:
+            rest = self.buf[self.pos:] + self.fd.read()
+            self.buf, self.pos = b"", 0
+            return rest
+        self._fill(n)
+        out = self.buf[self.pos:self.pos + n]
+        self.pos += len(out)
+        return out
+
+    def readline(self):
+        while True:
+            i = self.buf.find(b"\n", self.pos)
+            if i >= 0:
+                out = self.buf[self.pos:i + 1]
+                self.pos = i + 1
+                return out
+            before = len(self.buf) - self.pos
+            self._fill(before + 1)
+            if len(self.buf) - self.pos == before:          # end of stream
+                out = self.buf[self.pos:]
+                self.pos = len(self.buf)
+                return out
+
+    def read_token(self):
+        """Bytes up to (not including) the next space, consuming the space; b"" at end of stream."""
+        while True:
+            i = self.buf.find(b" ", self.pos)
+            if i >= 0:
+                out = self.buf[self.pos:i]
+                self.pos = i + 1
+                return out
+            before = len(self.buf) - self.pos
+            self._fill(before + 1)
+            if len(self.buf) - self.pos == before:
+                out = self.buf[self.pos:]
+                self.pos = len(self.buf)
+                return out
+
+    def detach(self):
+        unread = len(self.buf) - self.pos
+        if unread:
+            try:
+                self.fd.seek(-unread, 1)
+            except Exception:
+                pass                                          # pipes: the read-ahead is simply dropped with the generator
+        self.buf, self.pos = b"", 0
+
+    def close(self):
+        self.fd.close()
+
+
 def _read_exact(fd, n):
     """fd.read(n) that tolerates short reads from pipes; returns fewer bytes only at EOF."""
     buf = fd.read(n)
@@ -144,13 +223,16 @@ def _read_exact(fd, n):
 # ------------------------------------------------------------------------------------------------
 def read_key(fd):
     """Next utterance key of an ark stream, or None at end of stream."""
-    chars = []
-    while True:
-        ch = fd.read(1)
-        if not ch or ch == b" ":
-            break
-        chars.append(ch)
-    key = b"".join(chars).decode().strip()
+    if isinstance(fd, _BufferedStream):
+        key = fd.read_token().decode().strip()
+    else:
+        chars = []
+        while True:
+            ch = fd.read(1)
+            if not ch or ch == b" ":
+                break
+            chars.append(ch)
+        key = b"".join(chars).decode().strip()
     if key == "":
         return None
     assert _KEY_OK.match(key) is not None, "malformed key %r" % key
@@ -190,15 +272,18 @@ def read_vec_flt(file_or_fd):
 
 def read_vec_flt_ark(file_or_fd):
     """Generator of (key, vector) over an ark file / stream."""
-    fd = open_or_fd(file_or_fd)
+    raw = open_or_fd(file_or_fd)
+    fd = raw if isinstance(raw, _BufferedStream) else _BufferedStream(raw)
     try:
         key = read_key(fd)
         while key:
             yield key, read_vec_flt(fd)
             key = read_key(fd)
     finally:
-        if fd is not file_or_fd:
-            fd.close()
+        if raw is not file_or_fd:
+            raw.close()
+        elif fd is not raw:
+            fd.detach()
 
 
 def read_vec_flt_scp(file_or_fd):
@@ -271,6 +356,29 @@ def write_vec_flt(file_or_fd, v, key=""):
         _write_header(fd, key, tag)
         fd.write(b"\x04" + struct.pack("<I", v.shape[0]))
         fd.write(np.ascontiguousarray(v).astype(v.dtype.newbyteorder("<"), copy=False).tobytes())
+    finally:
+        if fd is not file_or_fd:
+            fd.close()
+
+
+def write_vec_flt_batch(file_or_fd, keys, vecs):
+    """Write many float32 vectors as consecutive binary records (same bytes as write_vec_flt per key) with one
+    ``write`` call per batch; falls back to per-record writes for index-building streams (TableWriter)."""
+    fd = open_or_fd(file_or_fd, mode="wb")
+    try:
+        if hasattr(fd, "note_key"):
+            for k, v in zip(keys, vecs):
+                write_vec_flt(fd, v, key=k)
+            return
+        parts = []
+        for k, v in zip(keys, vecs):
+            v = np.asarray(v)
+            if v.dtype != np.float32:
+                raise UnsupportedDataType("'%s', write_vec_flt_batch expects float32" % v.dtype)
+            parts.append((k + " ").encode() if k != "" else b"")
+            parts.append(b"\x00BFV \x04" + struct.pack("<I", v.shape[0]))
+            parts.append(np.ascontiguousarray(v).astype("<f4", copy=False).tobytes())
+        fd.write(b"".join(parts))
     finally:
         if fd is not file_or_fd:
             fd.close()
@@ -359,16 +467,19 @@ def read_mat(file_or_fd):
 
 
 def read_mat_ark(file_or_fd):
-    """Generator of (key, matrix) over an ark file / stream."""
-    fd = open_or_fd(file_or_fd)
+    """Generator of (key, matrix) over an ark file / stream (block-buffered: see _BufferedStream)."""
+    raw = open_or_fd(file_or_fd)
+    fd = raw if isinstance(raw, _BufferedStream) else _BufferedStream(raw)
     try:
         key = read_key(fd)
         while key:
             yield key, read_mat(fd)
             key = read_key(fd)
     finally:
-        if fd is not file_or_fd:
-            fd.close()
+        if raw is not file_or_fd:
+            raw.close()
+        elif fd is not raw:
+            fd.detach()
 
 
 def read_mat_scp(file_or_fd):

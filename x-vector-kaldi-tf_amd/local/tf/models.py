@@ -142,6 +142,7 @@ class Model(object):
             t0 = time.time()
             vecs = ex.extract(mats)
             compute_time += time.time() - t0
+            ok_keys, ok_vecs = [], []
             for key, mat, vec in zip(keys, mats, vecs):
                 if vec is None:
                     if mat.shape[0] == 0:
@@ -151,8 +152,10 @@ class Model(object):
                                        (min_chunk_size, key))
                     num_fail += 1
                     continue
-                kaldi_io.write_vec_flt(output_stream, vec, key=key)
-                num_success += 1
+                ok_keys.append(key)
+                ok_vecs.append(vec)
+            kaldi_io.write_vec_flt_batch(output_stream, ok_keys, ok_vecs)      # same bytes as write_vec_flt per key
+            num_success += len(ok_keys)
 
         keys, mats, frames = [], [], 0
         for key, mat in kaldi_io.read_mat_ark(input_stream):

@@ -62,17 +62,30 @@ class BatchLayout(object):
         self.max_len = int(lengths.max()) if len(lengths) else 0
         assert self.rows < 2 ** 31
 
-    def row_valid(self):
-        m = np.zeros(self.rows, dtype=np.uint8)
-        for s, n in zip(self.row_start, self.row_len):
-            m[s:s + n] = 1
+    def row_valid(self, out=None):
+        """uint8[rows]: 1 for frames, 0 for gap rows (one vectorised np.repeat)."""
+        n = self.nchunks
+        vals = np.zeros(2 * n + 1, dtype=np.uint8)
+        vals[1::2] = 1
+        reps = np.full(2 * n + 1, self.gap, dtype=np.int64)
+        reps[1::2] = self.row_len
+        m = np.repeat(vals, reps)
+        if out is not None:
+            out[:self.rows] = m
+            return out[:self.rows]
         return m
 
     def pack(self, mats, out):
-        """Copy the chunk matrices into ``out[rows, F]`` (gap rows zeroed)."""
-        out[:self.rows] = 0
-        for s, m in zip(self.row_start, mats):
-            out[s:s + m.shape[0], :m.shape[1]] = m
+        """Copy the chunk matrices into ``out[rows, >=F]`` and zero the gap rows.  Columns >= F of ``out`` are not
+        touched (callers keep them zero).  One np.concatenate instead of a Python loop over chunks."""
+        if not mats:
+            out[:self.rows] = 0
+            return
+        F = mats[0].shape[1]
+        z = np.zeros((self.gap, F), dtype=out.dtype)
+        parts = [z] * (2 * len(mats) + 1)
+        parts[1::2] = mats
+        np.concatenate(parts, axis=0, out=out[:self.rows, :F])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -248,7 +261,12 @@ class DeviceModel(object):
 # ------------------------------------------------------------------------------------------------
 class Extractor(object):
     """Batches the chunk plans of many utterances (length-bucketed), runs them and averages per
-    utterance.  Output order == input order, rejected utterances yield ``None`` vectors."""
+    utterance.  Output order == input order, rejected utterances yield ``None`` vectors.
+
+    Host packing and the H2D copies of batch i+1 overlap the kernels of batch i: ``NBUF`` pinned staging sets are
+    rotated, copies go through a dedicated HIP stream, and the compute stream waits on the copy's event."""
+
+    NBUF = 3
 
     def __init__(self, model, min_chunk_size, chunk_size, max_batch_rows=131072, max_batch_chunks=4096):
         self.model = model
@@ -257,13 +275,23 @@ class Extractor(object):
         self.max_batch_rows = int(max_batch_rows)
         self.max_batch_chunks = int(max_batch_chunks)
         self.stats = dict(batches=0, chunks=0, frames=0, rows=0)
-        self._pin = None
+        self._stage = None
+        self._copy_stream = None
 
-    def _pinned(self, rows, feat):
+    def _staging(self, rows, nchunks):
+        """NBUF pinned sets: features [rows, in_dim] (padding columns zeroed once), row_valid[rows], meta int32[2, chunks]."""
         torch = self.model.torch
-        if self._pin is None or self._pin.shape[0] < rows or self._pin.shape[1] != feat:
-            self._pin = torch.empty((max(rows, 1024), feat), dtype=torch.float32).pin_memory()
-        return self._pin
+        if self._stage is None or self._stage[0]["x"].shape[0] < rows or self._stage[0]["meta"].shape[1] < nchunks:
+            rows = max(rows, 1024)
+            nchunks = max(nchunks, 64)
+            self._stage = []
+            for _ in range(self.NBUF):
+                self._stage.append(dict(x=torch.zeros((rows, self.model.in_dim), dtype=torch.float32).pin_memory(),
+                                        rv=torch.zeros(rows, dtype=torch.uint8).pin_memory(),
+                                        meta=torch.zeros((2, nchunks), dtype=torch.int32).pin_memory(), event=None))
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.model.device)
+        return self._stage
 
     def extract(self, mats):
         """mats: list of float32 [T, F] arrays.  Returns a list of float32[E] (or None) per input."""
@@ -284,37 +312,54 @@ class Extractor(object):
         if nch == 0:
             return results
         gap = model.gap
+        # batch boundaries
+        bounds, b0 = [], 0
+        while b0 < nch:
+            rows, b1 = gap, b0
+            while b1 < nch and b1 - b0 < self.max_batch_chunks and (b1 == b0 or rows + c_len[b1] + gap <= self.max_batch_rows):
+                rows += c_len[b1] + gap
+                b1 += 1
+            bounds.append((b0, b1, rows))
+            b0 = b1
+        stage = self._staging(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds))
         with torch.cuda.device(dev):
+            compute = torch.cuda.current_stream()
             E_all = torch.empty((nch, model.embed_dim), dtype=torch.float32, device=dev)
             P_all = torch.empty((nch, model.pooled_dim), dtype=torch.float32, device=dev)
-            b0 = 0
-            while b0 < nch:
-                rows, b1 = gap, b0
-                while b1 < nch and b1 - b0 < self.max_batch_chunks and (b1 == b0 or rows + c_len[b1] + gap <= self.max_batch_rows):
-                    rows += c_len[b1] + gap
-                    b1 += 1
+            model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), max(c_len))
+            keep = []                                   # device inputs stay referenced until the window is done
+            for bi, (b0, b1, _) in enumerate(bounds):
                 layout = BatchLayout(c_len[b0:b1], gap)
                 assert mats[c_utt[b0]].shape[1] == model.feat_dim, "feature dimension does not match the model"
-                pin = self._pinned(layout.rows, model.in_dim)
-                host = pin.numpy()
-                layout.pack([mats[c_utt[i]][c_start[i]:c_start[i] + c_len[i]] for i in range(b0, b1)], host)
-                x = pin[:layout.rows].to(dev, non_blocking=True)
-                rs = torch.from_numpy(layout.row_start).to(dev, non_blocking=True)
-                rl = torch.from_numpy(layout.row_len).to(dev, non_blocking=True)
-                rv = torch.from_numpy(layout.row_valid()).to(dev, non_blocking=True)
-                model.frame_level(x, rs, rl, rv, layout.nchunks, layout.max_len, P_all[b0:b1])
-                torch.cuda.current_stream().synchronize()      # the pinned staging buffer is reused next batch
+                st = stage[bi % self.NBUF]
+                if st["event"] is not None:
+                    st["event"].synchronize()            # the copy that last read this pinned set has finished
+                layout.pack([mats[c_utt[i]][c_start[i]:c_start[i] + c_len[i]] for i in range(b0, b1)], st["x"].numpy())
+                layout.row_valid(st["rv"].numpy())
+                meta = st["meta"].numpy()
+                meta[0, :layout.nchunks] = layout.row_start
+                meta[1, :layout.nchunks] = layout.row_len
+                with torch.cuda.stream(self._copy_stream):
+                    x = st["x"][:layout.rows].to(dev, non_blocking=True)
+                    rv = st["rv"][:layout.rows].to(dev, non_blocking=True)
+                    md = st["meta"][:, :layout.nchunks].to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                st["event"] = ev
+                compute.wait_event(ev)
+                model.frame_level(x, md[0], md[1], rv, layout.nchunks, layout.max_len, P_all[b0:b1])
+                keep.append((x, rv, md))
                 self.stats["batches"] += 1
                 self.stats["chunks"] += layout.nchunks
                 self.stats["frames"] += int(layout.row_len.sum())
                 self.stats["rows"] += layout.rows
-                b0 = b1
             model.segment_level(P_all, E_all)
             seg = torch.tensor(seg_start, dtype=torch.int32, device=dev)
             cl = torch.tensor(c_len, dtype=torch.int32, device=dev)
             out = torch.empty((len(order), model.embed_dim), dtype=torch.float32, device=dev)
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
             host_out = out.cpu().numpy()
+            del keep
         for j, u in enumerate(order):
             results[u] = host_out[j]
         return results
