@@ -321,8 +321,6 @@ struct Gemm3Params {
     float *ypre;          // fp32 rows, stride ldpre (optional)
     int ldpre;
     int n_mt, n_nt, n_chunks;
-    int nt_major;
-    int dbg;      // ablation switches (XV_DBG env; 0 in production): 1 skip B DMA, 2 skip A DMA, 4 skip MFMAs, 8 skip frag reads
 };
 
 #define XV_GLDS16(gptr, lptr)                                                                                   \
@@ -344,32 +342,16 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
-    // XCD-aware tile order.  Hardware places block b on XCD b%8; every XCD gets a contiguous run [start, start+cnt)
-    // of logical tile ids L = mt*n_nt + nt (bijective chunking).  Inside the run the order is either
-    //   nt fastest  (small weights: the n_nt column tiles sharing an A panel run together, all weights fit L2), or
-    //   nt slowest  (weights > L2: the ~64 blocks resident on an XCD share ONE column tile's weight panel, which
-    //                then stays L2-resident however far the blocks drift apart; A panels are re-streamed instead).
+    // XCD-aware tile order.  Hardware places block b on XCD b%8; every XCD gets a contiguous run of logical tile ids
+    // L = mt*n_nt + nt (bijective chunking), column tiles fastest, so the n_nt tiles sharing an A panel run close
+    // together on one L2.  (Measured alternatives that did NOT help: column-tile-major order to pin one weight panel
+    // in L2 (-3 %), persistent workgroups (-4 %), de-synchronised start delays (0 %), s_setprio around the MFMAs (0 %).)
     const int nwg = p.n_mt * p.n_nt;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    int mt, nt;
-    if (!p.nt_major) {
-        const int wg = start + idx;
-        mt = wg / p.n_nt;
-        nt = wg - mt * p.n_nt;
-    } else {
-        const int end = start + (xcd < r ? q + 1 : q);
-        int j = idx, L0 = start;
-        for (nt = 0; nt < p.n_nt; ++nt) {
-            L0 = start + ((nt - start % p.n_nt + p.n_nt) % p.n_nt);       // first id of the run in column tile nt
-            const int cnt = L0 < end ? (end - L0 + p.n_nt - 1) / p.n_nt : 0;
-            if (j < cnt) break;
-            j -= cnt;
-        }
-        mt = (L0 + j * p.n_nt) / p.n_nt;
-    }
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
 
@@ -627,11 +609,13 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
         const int gc = gc0 + i;
         const bool ok = gc < p.cout;
         bias[i] = (ok && p.bias) ? p.bias[gc] : 0.f;
-        sc[i] = (ok && p.scale) ? p.scale[gc] : 1.f;
+        // channels beyond Cout (ragged last tile) get scale = shift = 0 so they come out as exact zeros
+        sc[i] = ok ? (p.scale ? p.scale[gc] : 1.f) : 0.f;
         sh[i] = (ok && p.shift) ? p.shift[gc] : 0.f;
         al[i] = (p.act == XV_ACT_LRELU) ? p.alpha[0] : ((p.act == XV_ACT_PRELU && ok) ? p.alpha[gc] : 0.f);
     }
     const bool full = gc0 + 8 <= p.cout;
+    const int act = p.act;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int lr = (tid >> 4) + 16 * j;
@@ -640,12 +624,15 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
         const f32x4 t0 = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8);
         const f32x4 t1 = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8 + 4);
         float z[8], v[8];
-        const bool live = Ms[lr] != 0;
+        const float keep = Ms[lr] ? 1.f : 0.f;          // gap rows: one multiply per element instead of a select
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             z[i] = (i < 4 ? t0[i] : t1[i - 4]) + bias[i];
-            const float a = apply_act(z[i], p.act, al[i]) * sc[i] + sh[i];
-            v[i] = (live && (gc0 + i) < p.cout) ? a : 0.f;
+            float a;
+            if (act == XV_ACT_RELU) a = fmaxf(z[i], 0.f);
+            else if (act == XV_ACT_NONE) a = z[i];
+            else a = apply_act(z[i], act, al[i]);
+            v[i] = (a * sc[i] + sh[i]) * keep;
         }
         if (p.ypre) {
             float *o = p.ypre + (size_t)gr * p.ldpre + gc0;
@@ -717,15 +704,6 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
     if (((uintptr_t)p.wt) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: packed weights must be 16-byte aligned");
     p.n_mt = (int)((p.R + BM - 1) / BM);
     p.n_nt = (p.cout + BN - 1) / BN;
-    {
-        // weights of the whole layer vs the 4 MiB per-XCD L2 (leave room for the A stream)
-        static const char *env = getenv("XV_NT_MAJOR");
-        const size_t wbytes = (size_t)p.n_nt * p.n_chunks * p.K * B3_BYTES;
-        p.nt_major = env ? atoi(env) : 0;       // measured: nt-fastest wins on every layer of the default topology
-        (void)wbytes;
-        static const char *dbg = getenv("XV_DBG");
-        p.dbg = dbg ? atoi(dbg) : 0;
-    }
     typedef void (*kern_t)(const Gemm3Params);
     kern_t kern;
     if (!p.x_split) kern = tdnn_gemm_bf16x3_kernel<false, 0>;
