@@ -114,13 +114,13 @@ def main():
         model.segment_level(P_all, E_all)                 # embed_layer-0 once over all chunks of the step
         ev_fc[si][1].record()
         hiplib.chunk_average(E_all, seg, clen, n_utts, xvec)
-        if world > 1:
+        if dist.is_initialized():
             return xdist.gather_blocks(xvec, counts, 0)
         return [xvec]
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +132,7 @@ def main():
         step(si)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -153,7 +153,7 @@ def main():
     fl_total = (tp.flops_per_frame(topo, feat) * frames + tp.flops_per_utt(topo) * n_utts)
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -177,7 +177,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: %d utts/GPU, 23-dim MFCC, T~U{%d..%d}, default x-vector topology "
                                "[512,512,512,512,1536] k=[5,5,7,1,1], 512-d embed_layer-0" % (n_utts, args.tmin, args.tmax),
                    "utts_per_gpu": n_utts, "frames_per_gpu": frames, "batches_per_step": len(batches),
-                   "batch_rows": args.batch_rows, "precision": args.precision,
+                   "batch_rows": args.batch_rows, "precision": args.precision, "dist_initialized": bool(dist.is_initialized()),
                    "parallelism": "utterance-sharded x%d, one RCCL gather" % world},
         "frames_per_s": frames * world * args.steps / dt,
         "algorithmic_tflops": fl_total * world * args.steps / dt / 1e12,
@@ -231,7 +231,7 @@ def main():
                                "by_threads": {str(t): res[t][0] for t in sweep},
                                "reference_faithful_2_threads": res.get(2, (None,))[0]}
     print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

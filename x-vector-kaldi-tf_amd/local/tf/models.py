@@ -137,11 +137,41 @@ class Model(object):
         num_success = 0
         compute_time = 0.0
 
+        # Multi-GPU (one process per GPU, torchrun): every rank reads the same stream, extracts only its
+        # frame-balanced shard of each window and ONE gather per window brings the x-vectors to rank 0, which
+        # alone writes (the role of split_data.sh + nj jobs + `cat xvector.*.scp`, extract_xvectors.sh:63-95).
+        from xvector_amd import dist as xdist
+        rank, world = xdist.init_process_group()
+
+        def extract_window(mats):
+            if world == 1:
+                return ex.extract(mats)
+            import torch
+            dev = self.device_model.device
+            lens = [m.shape[0] for m in mats]
+            dim = self.device_model.embed_dim
+
+            def shard_fn(idx):
+                vecs = ex.extract([mats[i] for i in idx])
+                out = torch.zeros((len(idx), dim), dtype=torch.float32)
+                for j, v in enumerate(vecs):
+                    if v is not None:
+                        out[j] = torch.from_numpy(v)
+                return out.to(dev)
+
+            full = xdist.sharded_extract(lens, shard_fn, dim, dev)
+            if rank != 0:
+                return None
+            host = full.cpu().numpy()
+            return [host[i] if engine.plan_chunks(lens[i], min_chunk_size, chunk_size) else None for i in range(len(mats))]
+
         def flush(keys, mats):
             nonlocal num_fail, num_success, compute_time
             t0 = time.time()
-            vecs = ex.extract(mats)
+            vecs = extract_window(mats)
             compute_time += time.time() - t0
+            if vecs is None:                      # non-root rank: nothing to write
+                return
             ok_keys, ok_vecs = [], []
             for key, mat, vec in zip(keys, mats, vecs):
                 if vec is None:

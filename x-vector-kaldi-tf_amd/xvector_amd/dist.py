@@ -24,7 +24,8 @@ def init_process_group(backend=None):
     import torch
     import torch.distributed as dist
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("XV_FORCE_DIST") == "1" and "RANK" in os.environ      # 1-rank group (tests the RCCL path on one GPU)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -61,7 +62,7 @@ def gather_blocks(local, counts, dst=0, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     assert local.shape[0] == counts[rank]
-    if world == 1:
+    if not dist.is_initialized():
         return [local]
     cap = int(max(counts))
     padded = local
