@@ -1,0 +1,243 @@
+"""Read the reference's TensorFlow-1 checkpoints without TensorFlow.
+
+``Model.save_model`` of the reference calls ``tf.train.Saver().save(sess, '<dir>/model')``
+(local/tf/models.py:134-137), which writes a *tensor bundle*:
+
+* ``model.index``                 -- an SSTable (LevelDB table format): sorted ``key -> value`` entries in
+                                     prefix-compressed blocks; key "" holds a BundleHeaderProto, every other key
+                                     is a variable name (``frame_level_info_layer-0/w``, no ``:0``) whose value is
+                                     a BundleEntryProto {dtype, shape, shard_id, offset, size, crc32c};
+* ``model.data-00000-of-00001``   -- the raw little-endian tensor bytes, addressed by (offset, size);
+* ``model.meta``                  -- the MetaGraphDef (not needed: the graph is re-stated by the kernels).
+
+This module parses those two published formats directly (varints, block restarts, footer magic
+0xdb4775248b80fb57; protobuf wire format for the two tiny messages; optional snappy blocks) and maps the
+variables onto the TF-name-keyed weight dict the extractor loads.  What a checkpoint does NOT record is the
+topology's dilation / activation (graph attributes): those come from the model CLASS NAME, which the
+reference's driver stores next to the model (``<nnet_dir>/model_name.txt``, local/tf/train_dnn.py:495).
+
+PARITY NOTE: TensorFlow cannot run here, so there is no reference-written checkpoint to pin against; the
+reader is tested against a bundle writer that follows the same published layouts (tests/test_tf_checkpoint.py),
+including multi-block tables, prefix-compressed keys, Adam slot variables and snappy-compressed blocks.
+"""
+import os
+import struct
+
+import numpy as np
+
+from . import topology as tp
+
+TABLE_MAGIC = 0xdb4775248b80fb57
+_DTYPES = {1: np.dtype("<f4"), 2: np.dtype("<f8"), 3: np.dtype("<i4"), 9: np.dtype("<i8"), 19: np.dtype("<f2")}
+
+
+# ------------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------------
+def _varint(buf, pos):
+    result = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        result |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return result, pos
+        shift += 7
+
+
+def _snappy_decompress(data):
+    """Minimal snappy (raw format) decoder: varint length, then literal / copy elements."""
+    n, pos = _varint(data, 0)
+    out = bytearray()
+    while pos < len(data):
+        tag = data[pos]
+        pos += 1
+        kind = tag & 3
+        if kind == 0:                                  # literal
+            ln = tag >> 2
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(data[pos:pos + nb], "little")
+                pos += nb
+            ln += 1
+            out += data[pos:pos + ln]
+            pos += ln
+            continue
+        if kind == 1:                                  # copy, 1-byte offset
+            ln = ((tag >> 2) & 7) + 4
+            off = ((tag >> 5) << 8) | data[pos]
+            pos += 1
+        elif kind == 2:                                # copy, 2-byte offset
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(data[pos:pos + 2], "little")
+            pos += 2
+        else:                                          # copy, 4-byte offset
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(data[pos:pos + 4], "little")
+            pos += 4
+        if off == 0 or off > len(out):
+            raise ValueError("corrupt snappy block")
+        for _ in range(ln):                            # overlapping copies are legal
+            out.append(out[-off])
+    if len(out) != n:
+        raise ValueError("snappy length mismatch")
+    return bytes(out)
+
+
+def _read_block(buf, offset, size):
+    """Block contents (without the 5-byte trailer), decompressed if needed."""
+    raw = buf[offset:offset + size]
+    ctype = buf[offset + size]
+    if ctype == 0:
+        return raw
+    if ctype == 1:
+        return _snappy_decompress(raw)
+    raise ValueError("unsupported table block compression type %d" % ctype)
+
+
+def _block_entries(block):
+    """Yield (key, value) from one table block (prefix-compressed keys, restart array at the end)."""
+    (num_restarts,) = struct.unpack_from("<I", block, len(block) - 4)
+    limit = len(block) - 4 - 4 * num_restarts
+    pos = 0
+    key = b""
+    while pos < limit:
+        shared, pos = _varint(block, pos)
+        non_shared, pos = _varint(block, pos)
+        vlen, pos = _varint(block, pos)
+        key = key[:shared] + block[pos:pos + non_shared]
+        pos += non_shared
+        yield key, block[pos:pos + vlen]
+        pos += vlen
+
+
+def read_table(path):
+    """All (key, value) pairs of an SSTable file, in key order."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    if len(buf) < 48 or struct.unpack_from("<Q", buf, len(buf) - 8)[0] != TABLE_MAGIC:
+        raise ValueError("'%s' is not a TensorFlow/LevelDB table (bad magic)" % path)
+    footer = buf[-48:]
+    _, pos = _varint(footer, 0)            # metaindex handle: offset
+    _, pos = _varint(footer, pos)          #                   size
+    idx_off, pos = _varint(footer, pos)
+    idx_size, pos = _varint(footer, pos)
+    out = []
+    for _, handle in _block_entries(_read_block(buf, idx_off, idx_size)):
+        off, p = _varint(handle, 0)
+        size, p = _varint(handle, p)
+        out.extend(_block_entries(_read_block(buf, off, size)))
+    return out
+
+
+def _parse_proto(buf):
+    """Flat protobuf wire parse -> {field: [values]} (varint / 64-bit / length-delimited / 32-bit)."""
+    out = {}
+    pos = 0
+    while pos < len(buf):
+        tag, pos = _varint(buf, pos)
+        field, wt = tag >> 3, tag & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 1:
+            v = buf[pos:pos + 8]; pos += 8
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            v = buf[pos:pos + ln]; pos += ln
+        elif wt == 5:
+            v = buf[pos:pos + 4]; pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        out.setdefault(field, []).append(v)
+    return out
+
+
+def _entry(value):
+    """BundleEntryProto -> (dtype enum, shape tuple, shard_id, offset, size)."""
+    m = _parse_proto(value)
+    dims = []
+    for shape in m.get(2, []):
+        for dim in _parse_proto(shape).get(2, []):
+            size = _parse_proto(dim).get(1, [0])[0]
+            dims.append(size if size < (1 << 63) else size - (1 << 64))
+    g = lambda f: m.get(f, [0])[0]
+    return g(1), tuple(dims), g(3), g(4), g(5)
+
+
+# ------------------------------------------------------------------------------------------------
+# bundle -> arrays -> weight dict
+# ------------------------------------------------------------------------------------------------
+def read_bundle(prefix):
+    """{variable name: ndarray} for the tensor bundle ``<prefix>.index`` + ``<prefix>.data-*``."""
+    entries = read_table(prefix + ".index")
+    if not entries or entries[0][0] != b"":
+        raise ValueError("'%s.index' has no bundle header" % prefix)
+    header = _parse_proto(entries[0][1])
+    num_shards = header.get(1, [1])[0]
+    if header.get(2, [0])[0] != 0:
+        raise ValueError("big-endian tensor bundles are not supported")
+    shards = {}
+    out = {}
+    for key, value in entries[1:]:
+        dtype, shape, shard, offset, size = _entry(value)
+        if dtype not in _DTYPES:
+            continue                                    # strings / resources: never model weights
+        if shard not in shards:
+            shards[shard] = np.memmap("%s.data-%05d-of-%05d" % (prefix, shard, num_shards), dtype=np.uint8, mode="r")
+        dt = _DTYPES[dtype]
+        count = int(np.prod(shape)) if shape else 1
+        if count * dt.itemsize != size:
+            raise ValueError("bundle entry '%s': size %d does not match shape %s" % (key.decode(), size, shape))
+        out[key.decode()] = np.frombuffer(shards[shard][offset:offset + size].tobytes(), dtype=dt).reshape(shape)
+    return out
+
+
+def guess_class_name(model_dir):
+    """The driver writes the class name to <nnet_dir>/model_name.txt (train_dnn.py:495); model dirs are its
+    children (model_0, model_final, ...).  XVECTOR_MODEL_CLASS overrides."""
+    env = os.environ.get("XVECTOR_MODEL_CLASS")
+    if env:
+        return env
+    for d in (model_dir, os.path.dirname(os.path.abspath(model_dir))):
+        p = os.path.join(d, "model_name.txt")
+        if os.path.exists(p):
+            name = open(p).read().strip()
+            if name:
+                return name
+    return "ModelWithoutDropout"                        # the class the reference recipe trains (run_xvector.sh:90)
+
+
+def weights_from_bundle(arrays, class_name):
+    """Map bundle variables to (weights keyed by TF names with ':0', topology, num_classes, feat_dim); the
+    topology's kernel sizes / widths are cross-checked against the variable shapes."""
+    topo = tp.get(class_name)
+    w = {}
+    for name, arr in arrays.items():
+        if "/Adam" in name or name in ("beta1_power", "beta2_power"):
+            continue                                    # optimizer slots (models.py:112)
+        w[name + ":0"] = np.ascontiguousarray(arr, dtype=np.float32)
+    n_layers = len(topo["layer_sizes"])
+    for i in range(n_layers):
+        key = "frame_level_info_layer-%d/w:0" % i
+        if key not in w:
+            raise KeyError("checkpoint has no variable '%s'" % key[:-2])
+        k, cin, cout = w[key].shape
+        if k != topo["kernel_sizes"][i] or cout != topo["layer_sizes"][i]:
+            raise ValueError("%s has shape %s but class %s expects kernel %d, %d channels (wrong model class? set "
+                             "XVECTOR_MODEL_CLASS or model_name.txt)" % (key, w[key].shape, class_name,
+                                                                           topo["kernel_sizes"][i], topo["layer_sizes"][i]))
+    if topo["activation"] == "prelu" and "frame_level_info_layer-0/prelu/prelu:0" not in w:
+        raise ValueError("class %s expects PReLU variables, the checkpoint has none" % class_name)
+    feat_dim = int(w["frame_level_info_layer-0/w:0"].shape[1])
+    num_classes = int(w["output/w:0"].shape[1]) if "output/w:0" in w else 0
+    return w, topo, num_classes, feat_dim
+
+
+def load_tf_model_dir(model_dir, class_name=None):
+    """-> (weights, meta) like weights.load_model_dir, straight from a TF checkpoint directory."""
+    prefix = os.path.join(model_dir, "model")
+    class_name = class_name or guess_class_name(model_dir)
+    w, topo, num_classes, feat_dim = weights_from_bundle(read_bundle(prefix), class_name)
+    meta = dict(format="tensorflow-checkpoint", model_class=class_name, topology=topo, num_classes=num_classes,
+                feat_dim=feat_dim)
+    return w, meta

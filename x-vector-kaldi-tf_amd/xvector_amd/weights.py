@@ -12,6 +12,9 @@ are non-empty (``local/tf/ze_utils.py:561-567``, ``local/tf/extract_embedding.py
                              ``embed_layer-{j}/{w,b,gamma,beta,mean,variance}:0``, ``output/{w,b}:0``,
                              optional ``.../prelu/prelu:0``
 * ``done``                -- the marker the drivers look for.
+
+A directory written by the reference itself (TF1 ``Saver``: ``model.meta`` protobuf + ``model.index`` +
+``model.data-00000-of-00001``) is also accepted by ``load_model_dir``: see ``tf_checkpoint.py``.
 """
 import json
 import os
@@ -78,8 +81,17 @@ def load_model_dir(input_dir):
         meta = json.loads(raw.decode("utf-8"))
         assert meta.get("format") == FORMAT_TAG
     except Exception:
-        raise IOError("'%s' is not an %s model directory (a TensorFlow MetaGraphDef cannot be read "
-                      "without TensorFlow; export the variables by name to %s)" % (input_dir, FORMAT_TAG, WEIGHTS))
+        # not ours: a directory written by the reference's tf.train.Saver (model.meta = MetaGraphDef,
+        # model.index + model.data-* = tensor bundle) is read directly, without TensorFlow
+        if os.path.exists(os.path.join(input_dir, "model.index")):
+            from . import tf_checkpoint
+            weights, meta = tf_checkpoint.load_tf_model_dir(input_dir)
+            missing = [n for n in expected_names(meta["topology"]) if n not in weights]
+            if missing:
+                raise KeyError("TF checkpoint in '%s' lacks variables: %s" % (input_dir, ", ".join(missing)))
+            return weights, meta
+        raise IOError("'%s' is neither an %s model directory nor a TensorFlow checkpoint directory (no model.index)"
+                      % (input_dir, FORMAT_TAG))
     with np.load(os.path.join(input_dir, WEIGHTS)) as z:
         weights = {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
     missing = [n for n in expected_names(meta["topology"]) if n not in weights]
