@@ -50,7 +50,7 @@ class Model(object):
     """Default topology: 5 frame-level layers [512,512,512,512,1536], kernels [5,5,7,1,1],
     statistics pooling, 2 segment-level layers (models.py:27-29)."""
 
-    window_frames = 1 << 20          # utterances are read from the stream in windows of ~1M frames
+    window_frames = 1 << 21          # utterances are read from the stream in windows of ~2M frames
     max_batch_rows = 131072
 
     def __init__(self):
@@ -187,16 +187,37 @@ class Model(object):
             kaldi_io.write_vec_flt_batch(output_stream, ok_keys, ok_vecs)      # same bytes as write_vec_flt per key
             num_success += len(ok_keys)
 
-        keys, mats, frames = [], [], 0
-        for key, mat in kaldi_io.read_mat_ark(input_stream):
-            total_segments += 1
-            keys.append(key)
-            mats.append(np.ascontiguousarray(mat, dtype=np.float32))
-            frames += mat.shape[0]
-            if frames >= self.window_frames:
-                flush(keys, mats)
+        # A reader thread parses the next window of the ark stream while the GPU works on the current one
+        # (bounded queue: at most 2 parsed windows in memory).  Order is preserved; a parse error is re-raised here.
+        import queue
+        import threading
+        windows = queue.Queue(maxsize=2)
+
+        def reader():
+            try:
                 keys, mats, frames = [], [], 0
-        if keys:
+                for key, mat in kaldi_io.read_mat_ark(input_stream):
+                    keys.append(key)
+                    mats.append(np.ascontiguousarray(mat, dtype=np.float32))
+                    frames += mat.shape[0]
+                    if frames >= self.window_frames:
+                        windows.put((keys, mats))
+                        keys, mats, frames = [], [], 0
+                if keys:
+                    windows.put((keys, mats))
+                windows.put(None)
+            except BaseException as e:          # noqa: B902 -- forwarded to the consumer
+                windows.put(e)
+
+        threading.Thread(target=reader, daemon=True).start()
+        while True:
+            item = windows.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            keys, mats = item
+            total_segments += len(keys)
             flush(keys, mats)
 
         st = ex.stats
