@@ -138,7 +138,7 @@ class DeviceModel(object):
         self._a0 = None
 
     def _dev(self, a):
-        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        return self.torch.as_tensor(np.array(a, dtype=np.float32, order="C")).to(self.device)     # copy: sources may be read-only
 
     def _prep(self, weights, scope, w3d, k, d):
         layer = dict(K=k, dil=d, cin=w3d.shape[1], cout=w3d.shape[2])
