@@ -55,3 +55,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(d, f), errors="ignore").read()
                 assert "import oracle" not in src and "from oracle" not in src and "xv_oracle" not in src, os.path.join(d, f)
+
+
+def test_host_library_loads_and_scans():
+    """libxvector_host.so (native ark scanner) is built by build() and agrees with the pure-Python reader."""
+    import io
+    import numpy as np
+    import kaldi_io
+    lib = kaldi_io._host_lib()
+    assert lib is not None and lib.xv_host_version() == 1
+    rng = np.random.default_rng(0)
+    bio = io.BytesIO()
+    mats = [("k%d" % i, rng.standard_normal((int(rng.integers(0, 40)), 23)).astype(np.float32)) for i in range(50)]
+    for i, (k, m) in enumerate(mats):
+        kaldi_io.write_mat(bio, m.astype(np.float64) if i == 17 else m, key=k)        # one DM record in the middle
+    got = list(kaldi_io.read_mat_ark(io.BytesIO(bio.getvalue())))
+    assert [k for k, _ in got] == [k for k, _ in mats]
+    assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(got, mats))
+    assert got[17][1].dtype == np.float64 and got[16][1].dtype == np.float32

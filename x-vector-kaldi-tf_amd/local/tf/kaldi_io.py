@@ -27,8 +27,10 @@ write_vec_flt          local/tf/kaldi_io.py:309-343               'FV '/'DV ' fr
 Int vectors, posteriors, confusion-network times and segment bool-vectors (reference lines
 139-218, 553-697) are ASR types the x-vector path never reads: out of scope.
 """
+import ctypes
 import gzip
 import io
+import os
 import re
 import struct
 import subprocess
@@ -466,15 +468,81 @@ def read_mat(file_or_fd):
             fd.close()
 
 
+_HOST_LIB = False          # False = not tried yet, None = unavailable
+
+
+def _host_lib():
+    """libxvector_host.so (csrc/xv_host.cpp): native scan of binary float-matrix records.  Optional: without it the
+    generic per-record Python reader below is used."""
+    global _HOST_LIB
+    if _HOST_LIB is False:
+        _HOST_LIB = None
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libxvector_host.so")
+        if os.path.exists(path) and os.environ.get("XVECTOR_NO_HOST_LIB") != "1":
+            try:
+                lib = ctypes.CDLL(path)
+                lib.xv_ark_scan_fm.restype = ctypes.c_int
+                lib.xv_ark_scan_fm.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int] + \
+                    [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+                _HOST_LIB = lib
+            except OSError:
+                _HOST_LIB = None
+    return _HOST_LIB
+
+
+_SCAN_MAX = 8192
+
+
+def _scan_fm_records(fd, lib):
+    """Yield (key, matrix) for the run of binary 'FM ' records at the stream position, using the native scanner on
+    whole buffered blocks; returns when the next record is something else (or at end of stream)."""
+    key_off = np.empty(_SCAN_MAX, np.int64); key_len = np.empty(_SCAN_MAX, np.int32)
+    data_off = np.empty(_SCAN_MAX, np.int64); rows = np.empty(_SCAN_MAX, np.int32); cols = np.empty(_SCAN_MAX, np.int32)
+    nxt, stop = ctypes.c_size_t(0), ctypes.c_int(0)
+    want = 1
+    while True:
+        fd._fill(want)
+        buf, pos = fd.buf, fd.pos
+        if len(buf) == pos:
+            return                                              # end of stream
+        n = lib.xv_ark_scan_fm(buf, pos, len(buf), _SCAN_MAX, key_off.ctypes.data, key_len.ctypes.data, data_off.ctypes.data,
+                               rows.ctypes.data, cols.ctypes.data, ctypes.byref(nxt), ctypes.byref(stop))
+        for i in range(n):
+            ko, do, r, c = int(key_off[i]), int(data_off[i]), int(rows[i]), int(cols[i])
+            key = buf[ko:ko + int(key_len[i])].decode().strip()
+            assert _KEY_OK.match(key) is not None, "malformed key %r" % key
+            fd.pos = do + r * c * 4                             # consumed up to here if the caller stops now
+            yield key, np.frombuffer(buf, dtype="<f4", count=r * c, offset=do).reshape(r, c)
+        fd.pos = nxt.value
+        if stop.value == 1:
+            return                                              # a different record type follows
+        if stop.value == 0:
+            avail = len(buf) - fd.pos
+            if n == 0:
+                want = max(2 * avail, fd.BLOCK)                 # one record larger than what is buffered: grow
+            else:
+                want = avail + 1
+            before = avail
+            fd._fill(want)
+            if len(fd.buf) - fd.pos == before:                  # nothing more to read
+                return
+
+
 def read_mat_ark(file_or_fd):
-    """Generator of (key, matrix) over an ark file / stream (block-buffered: see _BufferedStream)."""
+    """Generator of (key, matrix) over an ark file / stream (block-buffered: see _BufferedStream; runs of binary
+    float matrices are located by the native scanner when libxvector_host.so is present)."""
     raw = open_or_fd(file_or_fd)
     fd = raw if isinstance(raw, _BufferedStream) else _BufferedStream(raw)
+    lib = _host_lib()
     try:
-        key = read_key(fd)
-        while key:
+        while True:
+            if lib is not None:
+                for item in _scan_fm_records(fd, lib):
+                    yield item
+            key = read_key(fd)                                  # generic path: one record of any supported type
+            if not key:
+                break
             yield key, read_mat(fd)
-            key = read_key(fd)
     finally:
         if raw is not file_or_fd:
             raw.close()

@@ -354,8 +354,8 @@ class Extractor(object):
                 self.stats["frames"] += int(layout.row_len.sum())
                 self.stats["rows"] += layout.rows
             model.segment_level(P_all, E_all)
-            seg = torch.tensor(seg_start, dtype=torch.int32, device=dev)
-            cl = torch.tensor(c_len, dtype=torch.int32, device=dev)
+            seg = torch.from_numpy(np.asarray(seg_start, dtype=np.int32)).to(dev)
+            cl = torch.from_numpy(np.asarray(c_len, dtype=np.int32)).to(dev)
             out = torch.empty((len(order), model.embed_dim), dtype=torch.float32, device=dev)
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
             host_out = out.cpu().numpy()
