@@ -507,9 +507,10 @@ def _scan_fm_records(fd, lib):
             return                                              # end of stream
         n = lib.xv_ark_scan_fm(buf, pos, len(buf), _SCAN_MAX, key_off.ctypes.data, key_len.ctypes.data, data_off.ctypes.data,
                                rows.ctypes.data, cols.ctypes.data, ctypes.byref(nxt), ctypes.byref(stop))
-        for i in range(n):
-            ko, do, r, c = int(key_off[i]), int(data_off[i]), int(rows[i]), int(cols[i])
-            key = buf[ko:ko + int(key_len[i])].decode().strip()
+        kos, kls, dos = key_off[:n].tolist(), key_len[:n].tolist(), data_off[:n].tolist()
+        rs, cs = rows[:n].tolist(), cols[:n].tolist()
+        for ko, kl, do, r, c in zip(kos, kls, dos, rs, cs):
+            key = buf[ko:ko + kl].decode().strip()
             assert _KEY_OK.match(key) is not None, "malformed key %r" % key
             fd.pos = do + r * c * 4                             # consumed up to here if the caller stops now
             yield key, np.frombuffer(buf, dtype="<f4", count=r * c, offset=do).reshape(r, c)
