@@ -18,6 +18,7 @@ from __future__ import print_function
 import argparse
 import logging
 import os
+import re
 import sys
 import traceback
 
@@ -36,45 +37,58 @@ _handler.setFormatter(logging.Formatter("%(asctime)s [%(pathname)s:%(lineno)s - 
 logger.addHandler(_handler)
 
 
+# (flag, dest, type, default, required, choices, help) -- the reference's command line, extract_embedding.py:50-70
+_FLAGS = (
+    ("--use-gpu", "use_gpu", str, "no", False, ("yes", "no"), "Accepted for compatibility; the extractor always runs on the GPU."),
+    ("--min-chunk-size", "min_chunk_size", int, 100, False, None, "Minimum chunk-size allowed when extracting xvectors."),
+    ("--chunk-size", "chunk_size", int, -1, False, None,
+     "If set, extracts xvectors from specified chunk-size, and averages.  If not set, extracts an xvector from all "
+     "available features."),
+    ("--feature-rspecifier", "feature_rspecifier", str, None, True, None, "Kaldi rspecifier of the input features."),
+    ("--vector-wspecifier", "vector_wspecifier", str, None, True, None,
+     "Kaldi wspecifier for the x-vectors (ark, ark pipe, or ark,scp:A,S)."),
+    ("--model-dir", "model_dir", str, None, True, None, "Model directory (model.meta + weights + done)."),
+)
+
+
 def get_args(argv=None):
-    parser = argparse.ArgumentParser(
-        description="Extract x-vectors from Kaldi features with the MI355X-native extractor.",
-        formatter_class=argparse.ArgumentDefaultsHelpFormatter, conflict_handler='resolve')
-    parser.add_argument("--use-gpu", type=str, dest='use_gpu', choices=["yes", "no"], default="no",
-                        help="Accepted for compatibility; the extractor always runs on the GPU.")
-    parser.add_argument("--min-chunk-size", type=int, dest='min_chunk_size', default=100,
-                        help="Minimum chunk-size allowed when extracting xvectors.")
-    parser.add_argument("--chunk-size", type=int, dest='chunk_size', default=-1,
-                        help="If set, extracts xvectors from specified chunk-size, and averages.  "
-                             "If not set, extracts an xvector from all available features.")
-    parser.add_argument("--feature-rspecifier", type=str, dest='feature_rspecifier', required=True,
-                        help="Kaldi rspecifier of the input features.")
-    parser.add_argument("--vector-wspecifier", type=str, dest='vector_wspecifier', required=True,
-                        help="Kaldi wspecifier for the x-vectors (ark, ark pipe, or ark,scp:A,S).")
-    parser.add_argument("--model-dir", type=str, dest='model_dir', required=True,
-                        help="Model directory (model.meta + weights + done).")
+    parser = argparse.ArgumentParser(description="Extract x-vectors from Kaldi features with the MI355X-native extractor.",
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter, conflict_handler='resolve')
+    for flag, dest, typ, default, required, choices, text in _FLAGS:
+        kw = dict(dest=dest, type=typ, help=text)
+        if required:
+            kw["required"] = True
+        else:
+            kw["default"] = default
+        if choices:
+            kw["choices"] = list(choices)
+        parser.add_argument(flag, **kw)
     return process_args(parser.parse_args(argv))
 
 
 def process_args(args):
     args.model_dir = args.model_dir.strip()
-    if args.model_dir == '' or not os.path.exists(os.path.join(args.model_dir, 'model.meta')):
+    if not args.model_dir or not os.path.exists(os.path.join(args.model_dir, 'model.meta')):
         raise Exception("This scripts expects the input model was exist in '{0}' directory.".format(args.model_dir))
     return args
 
 
+_PAIRED = re.compile(r"^(?P<head>.*?)(?P<kind>ark,scp|scp,ark):(?P<first>[^,\s]+),(?P<second>[^,\s]+)$", re.S)
+
+
 def process_wspecifier(wspecifier):
-    """-> (temporary wspecifier, final ark, final scp); (wspecifier, None, None) when there is nothing to rename."""
-    parts = wspecifier.split()
-    head = ''.join(p + ' ' for p in parts[:-1])
-    last = parts[-1]
-    if last.startswith('ark,scp:'):
-        ark, scp = last[8:].split(',')
-        return head + 'ark,scp:%s.tmp.ark,%s.tmp.scp' % (ark, scp), ark, scp
-    if last.startswith('scp,ark:'):
-        scp, ark = last[8:].split(',')
-        return head + 'scp,ark:%s.tmp.scp,%s.tmp.ark' % (scp, ark), ark, scp
-    return wspecifier, None, None
+    """-> (temporary wspecifier, final ark, final scp); (wspecifier, None, None) when there is nothing to rename.
+    Only the LAST whitespace-separated token may be the paired table (extract_embedding.py:94-108)."""
+    tokens = wspecifier.split()
+    m = _PAIRED.match(tokens[-1]) if tokens else None
+    if m is None or m.group("head"):
+        return wspecifier, None, None
+    first, second = m.group("first"), m.group("second")
+    ark, scp = (first, second) if m.group("kind") == "ark,scp" else (second, first)
+    tmp = {"ark": ark + ".tmp.ark", "scp": scp + ".tmp.scp"}
+    a, b = m.group("kind").split(",")
+    prefix = "".join(t + " " for t in tokens[:-1])
+    return "%s%s:%s,%s" % (prefix, m.group("kind"), tmp[a], tmp[b]), ark, scp
 
 
 def _open_output(wspecifier, ark, scp):
