@@ -138,6 +138,50 @@ int xv_fc_f32(const float *x, int nrows, int in_dim, const float *wp, const floa
 int xv_chunk_average_f32(const float *e, const int32_t *seg_start, const int32_t *chunk_len, int nutts, int dim,
                          float *out, void *stream);
 
+/* ---- training step (reference Model.train_one_iteration, local/tf/models.py:216-305) ----------
+ * The forward GEMMs and the input-gradient GEMMs are xv_tdnn_layer_f32 / xv_fc_f32 (dgrad = the same kernel with the
+ * taps flipped and Cin/Cout swapped in the weights); the entry points below add the rest.  fp32 storage, reductions
+ * accumulate in fp64.  Workspaces are caller-provided device buffers. */
+
+/* Per-chunk (mean, BIASED variance) over the rows of each chunk: out[B, 2C] = [mean || var].  Same kernel and arguments
+ * as xv_stats_pool_f32 without the sqrt(var+eps).  With xv_merge_moments_f32 this is tf.nn.moments over all frames of
+ * the minibatch (local/tf/tf_block.py:19). */
+int xv_chunk_moments_f32(const float *h, int64_t ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
+                         int max_len, int split_rows, float *out, void *workspace, void *stream);
+int xv_merge_moments_f32(const float *chunk_mean_var, const int32_t *row_len, int nchunks, int c, float *mean, float *var,
+                         void *stream);
+/* y[r,:] = row_valid[r] ? x[r,:]*scale + shift : 0   (batch-norm with batch statistics folded by xv_fold_bn_f32). */
+int xv_rows_affine_f32(const float *x, int ldx, int64_t R, int c, const float *scale, const float *shift,
+                       const uint8_t *row_valid, float *y, int ldy, void *stream);
+/* Weight gradient of a TDNN/FC layer: dw[k,ci,co] = sum_r x[r + (k-(K-1)/2)*dilation, ci] * dz[r, co]  (TF layout
+ * [K,Cin,Cout]; rows outside [0,R) read as zero; gap rows of x and dz are zero by contract). */
+size_t xv_wgrad_workspace_bytes(int64_t R, int cin, int cout, int K);
+int xv_wgrad_f32(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation,
+                 float *dw, void *workspace, void *stream);
+/* sum_a[c] = sum_r a[r,c];  sum_ab[c] = sum_r a[r,c]*b[r,c]  (b, sum_ab may be NULL). */
+size_t xv_col_sums_workspace_bytes(int64_t R, int c);
+int xv_col_sums_f32(const float *a, int lda, const float *b, int ldb, int64_t R, int c, float *sum_a, float *sum_ab,
+                    void *workspace, void *stream);
+/* Batch-norm backward through the activation (closed form): given dh = dL/d(BN output), r = activation output, the
+ * batch statistics and sum_dh = sum_r dh, sum_dh_r = sum_r dh*r, writes dgamma, dbeta and dz = dL/d(pre-activation)
+ * (gap rows zero).  coef_ws: 3*c floats.  act_kind: NONE / RELU / LRELU(act_alpha). */
+int xv_bn_act_backward_f32(const float *dh, const float *r, int ld, int64_t R, int c, const float *sum_dh,
+                           const float *sum_dh_r, const float *mean, const float *var, const float *gamma, float eps,
+                           float n_frames, int act_kind, float act_alpha, const uint8_t *row_valid, float *dgamma,
+                           float *dbeta, float *coef_ws, float *dz, void *stream);
+/* Gradient of statistics pooling: dh[t,c] = dmu[c]/T + dsig[c]*(h[t,c]-mu[c])/(T*sig[c]); dh gap rows are zeroed. */
+int xv_pool_backward_f32(const float *h, int ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
+                         int64_t R, const float *pooled, const float *dpooled, float *dh, void *stream);
+/* tf.nn.softmax_cross_entropy_with_logits + reduce_mean + accuracy (local/tf/models.py:106-117):
+ * loss_acc[0] = mean loss, loss_acc[1] = accuracy; dlogits (may be NULL) = (softmax - onehot)/nrows.  row_ws: 2*nrows. */
+int xv_softmax_ce_f32(const float *logits, const int32_t *labels, int nrows, int nclasses, float *loss_acc, float *row_ws,
+                      float *dlogits, void *stream);
+/* tf.train.AdamOptimizer dense update with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the caller. */
+int xv_adam_f32(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1, float beta2, float eps,
+                void *stream);
+/* moving = moving*decay + batch*(1-decay)   (local/tf/tf_block.py:20-21). */
+int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,130 @@
+"""Training-step oracle (torch CPU, float64 autograd).  TEST INFRASTRUCTURE ONLY -- never imported by the product.
+
+Restates the training graph of the reference (BUTSpeechFIT/x-vector-kaldi-tf) for the model classes without
+dropout, following the TF op definitions at its call sites:
+
+* forward, train phase          local/tf/models.py:466-500 (ModelWithoutDropout), 569-605 (Tdnn), 895-960 (LRelu)
+* batch-norm train branch       local/tf/tf_block.py:18-23: moments over every axis but the last (biased variance),
+                                normalise with the BATCH statistics, moving <- moving*decay + batch*(1-decay), decay 0.95
+                                (models.py:65,482)
+* loss / accuracy               local/tf/models.py:106-117: mean softmax cross-entropy, argmax accuracy
+* optimiser                     tf.train.AdamOptimizer(learning_rate) defaults beta1=0.9 beta2=0.999 epsilon=1e-8
+                                (models.py:112): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMAs; var -= lr_t*m/(sqrt(v)+eps)
+* eval phase                    same graph with the moving statistics (tf_block.py:25-26), models.py:307-354
+
+PARITY STATUS: TensorFlow is absent, so this is pinned only by construction from the op definitions (and, for the
+eval-phase frame-level part, by agreeing with the extraction oracle oracle/oracle.py); stated in DESIGN.md.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPSILON = 1e-3
+VAR2STD_EPSILON = 1e-5
+BN_DECAY = 0.95
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8
+
+
+def trainable_names(topo):
+    names = []
+    scopes = ["frame_level_info_layer-%d" % i for i in range(len(topo["layer_sizes"]))] + \
+             ["embed_layer-%d" % j for j in range(len(topo["embedding_sizes"]))]
+    for sc in scopes:
+        names += ["%s/%s:0" % (sc, n) for n in ("w", "b", "gamma", "beta")]
+        if topo.get("activation") == "prelu":
+            names.append("%s/prelu/prelu:0" % sc)
+    return names + ["output/w:0", "output/b:0"]
+
+
+def _act(z, topo, alpha):
+    a = topo.get("activation", "relu")
+    if a == "relu":
+        return F.relu(z)
+    if a == "lrelu":
+        return torch.maximum(topo.get("lrelu_alpha", 0.2) * z, z)
+    return F.relu(z) + alpha * torch.clamp(z, max=0.0)
+
+
+def forward(params, stats, topo, x, labels, train):
+    """x[B,T,F] float64 tensor, labels int64[B].  Returns (loss, accuracy, new_stats, embedding0)."""
+    new_stats = {}
+
+    def bn(r, scope, axes):
+        g, b = params[scope + "/gamma:0"], params[scope + "/beta:0"]
+        if train:
+            mean = r.mean(dim=axes)
+            var = ((r - mean) ** 2).mean(dim=axes)
+            new_stats[scope + "/mean:0"] = stats[scope + "/mean:0"] * BN_DECAY + mean.detach() * (1 - BN_DECAY)
+            new_stats[scope + "/variance:0"] = stats[scope + "/variance:0"] * BN_DECAY + var.detach() * (1 - BN_DECAY)
+        else:
+            mean, var = stats[scope + "/mean:0"], stats[scope + "/variance:0"]
+        inv = g / torch.sqrt(var + BN_EPSILON)
+        return r * inv + (b - mean * inv)
+
+    h = x.transpose(1, 2)                                            # [B, C, T]
+    for i, (K, d) in enumerate(zip(topo["kernel_sizes"], topo["dilations"])):
+        sc = "frame_level_info_layer-%d" % i
+        w = params[sc + "/w:0"].permute(2, 1, 0)                      # [Cout, Cin, K]
+        z = F.conv1d(h, w, params[sc + "/b:0"], padding=(K - 1) * d // 2, dilation=d)
+        alpha = params.get(sc + "/prelu/prelu:0")
+        r = _act(z, topo, alpha.view(1, -1, 1) if alpha is not None else None)
+        h = bn(r.transpose(1, 2), sc, (0, 1)).transpose(1, 2)
+    ht = h.transpose(1, 2)                                           # [B, T, C]
+    mu = ht.mean(dim=1)
+    var = ((ht - mu.unsqueeze(1)) ** 2).mean(dim=1)
+    h = torch.cat([mu, torch.sqrt(var + VAR2STD_EPSILON)], dim=1)
+    e0 = None
+    for j in range(len(topo["embedding_sizes"])):
+        sc = "embed_layer-%d" % j
+        s = h @ params[sc + "/w:0"] + params[sc + "/b:0"]
+        if j == 0:
+            e0 = s
+        alpha = params.get(sc + "/prelu/prelu:0")
+        h = bn(_act(s, topo, alpha), sc, (0,))
+    logits = h @ params["output/w:0"] + params["output/b:0"]
+    loss = F.cross_entropy(logits, labels, reduction="mean")
+    acc = (logits.argmax(dim=1) == labels).double().mean()
+    return loss, acc, new_stats, e0
+
+
+def to_torch(weights, requires_grad_names=()):
+    out = {}
+    for k, v in weights.items():
+        t = torch.tensor(np.asarray(v, dtype=np.float64))
+        if k in requires_grad_names:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def eval_batch(weights, topo, x, labels):
+    p = to_torch(weights)
+    with torch.no_grad():
+        loss, acc, _, e0 = forward(p, p, topo, torch.tensor(np.asarray(x, np.float64)), torch.tensor(np.asarray(labels, np.int64)),
+                                   train=False)
+    return float(loss), float(acc), e0.numpy()
+
+
+def train_step(weights, adam, topo, x, labels, lr):
+    """One optimizer step.  weights: {name: ndarray} (all variables incl. moving stats); adam: {"t": int, "m": {...},
+    "v": {...}} (t = number of steps already taken).  Returns (loss, acc, new_weights, new_adam, grads)."""
+    names = trainable_names(topo)
+    p = to_torch(weights, names)
+    loss, acc, new_stats, _ = forward(p, p, topo, torch.tensor(np.asarray(x, np.float64)),
+                                      torch.tensor(np.asarray(labels, np.int64)), train=True)
+    grads = torch.autograd.grad(loss, [p[n] for n in names])
+    t = adam["t"] + 1
+    lr_t = lr * np.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+    new_w = {k: np.array(v, dtype=np.float64) for k, v in weights.items()}
+    new_adam = {"t": t, "m": {}, "v": {}}
+    gout = {}
+    for n, g in zip(names, grads):
+        g = g.numpy()
+        gout[n] = g
+        m = ADAM_B1 * adam["m"].get(n, 0.0) + (1 - ADAM_B1) * g
+        v = ADAM_B2 * adam["v"].get(n, 0.0) + (1 - ADAM_B2) * g * g
+        new_adam["m"][n], new_adam["v"][n] = m, v
+        new_w[n] = new_w[n] - lr_t * m / (np.sqrt(v) + ADAM_EPS)
+    for k, v in new_stats.items():
+        new_w[k] = v.numpy()
+    return float(loss.detach()), float(acc), new_w, new_adam, gout

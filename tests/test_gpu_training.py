@@ -1,0 +1,103 @@
+"""Training step on the GPU vs the torch-CPU float64 autograd oracle (oracle/train_ref.py).
+
+Tolerances: fp32 kernels against an fp64 oracle -- loss 1e-5 relative, every gradient tensor 2e-4 relative L2 (the
+deepest chains go through 7 batch-norm backward passes), weights after 3 Adam steps within 2 % of the total update."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from oracle import train_ref
+    from xvector_amd import hiplib, synthetic, topology, trainer
+    hiplib.require_gpu()
+    return dict(torch=torch, ref=train_ref, synthetic=synthetic, topology=topology, trainer=trainer, hiplib=hiplib)
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _setup(env, cls, widths=(64, 64, 64, 64, 96), emb=(32, 32), classes=10, feat=23, seed=0):
+    topo = env["topology"].get(cls)
+    topo["layer_sizes"] = list(widths); topo["embedding_sizes"] = list(emb)
+    w = env["synthetic"].trained_like(topo, feat, num_classes=classes, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    return topo, w, rng
+
+
+@pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelL2LossWithoutDropoutLRelu"])
+def test_eval_batch_matches_oracle(env, cls):
+    topo, w, rng = _setup(env, cls)
+    x = (rng.standard_normal((6, 57, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, 6)
+    tr = env["trainer"].Trainer(w, topo)
+    loss, acc = tr.eval_batch(x, lab)
+    rl, ra, _ = env["ref"].eval_batch(w, topo, x, lab)
+    assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)) and acc == pytest.approx(ra)
+
+
+@pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelL2LossWithoutDropoutLRelu"])
+def test_gradients_match_autograd(env, cls):
+    topo, w, rng = _setup(env, cls, seed=3)
+    B, T = 8, 211
+    x = (rng.standard_normal((B, T, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, B)
+    tr = env["trainer"].Trainer(w, topo)
+    loss, acc, grads = tr.gradients(x, lab)
+    rl, ra, new_w, _, rg = env["ref"].train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3)
+    assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)) and acc == pytest.approx(ra)
+    worst = {n: _rel(grads[n].cpu().numpy(), rg[n]) for n in rg}
+    bad = {n: e for n, e in worst.items() if e > 2e-4}
+    assert not bad, bad
+    # moving statistics were updated with decay 0.95 (tf_block.py:20-21)
+    for sc in ("frame_level_info_layer-2", "embed_layer-1"):
+        for v in ("mean", "variance"):
+            n = "%s/%s:0" % (sc, v)
+            assert _rel(tr.P[n].cpu().numpy(), new_w[n]) < 1e-5, n
+
+
+def test_three_adam_steps_follow_the_oracle(env):
+    topo, w, rng = _setup(env, "ModelWithoutDropout", seed=7)
+    tr = env["trainer"].Trainer(w, topo)
+    ref_w, ref_adam = {k: np.array(v, np.float64) for k, v in w.items()}, {"t": 0, "m": {}, "v": {}}
+    lr = 2e-3
+    for step in range(3):
+        B, T = 8, int(rng.integers(200, 230))
+        x = (rng.standard_normal((B, T, 23)) * 3).astype(np.float16)          # the loaders hand out float16 (examples_io.py:165)
+        lab = rng.integers(0, 10, B)
+        loss, acc = tr.step(x, lab, lr)
+        rl, ra, ref_w, ref_adam, _ = env["ref"].train_step(ref_w, ref_adam, topo, x.astype(np.float64), lab, lr)
+        assert abs(loss - rl) < 2e-4 * max(1.0, abs(rl)), (step, loss, rl)
+    got, adam = tr.export()
+    assert adam["t"] == 3
+    for n in env["ref"].trainable_names(topo):
+        delta = np.linalg.norm(ref_w[n] - w[n])
+        assert np.linalg.norm(got[n] - ref_w[n]) < 0.02 * delta + 1e-7, n
+
+
+def test_wgrad_and_reductions_unit(env):
+    """xv_wgrad_f32 / xv_col_sums_f32 on their own, incl. the split + ordered-merge path (R > 4096) and a ragged Cin."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    rng = np.random.default_rng(11)
+    for (R, cin, cout, K, d) in ((300, 24, 64, 5, 1), (9000, 64, 96, 3, 2), (70, 96, 10, 1, 1)):
+        x = rng.standard_normal((R, cin)).astype(np.float32)
+        dz = rng.standard_normal((R, cout)).astype(np.float32)
+        dw = torch.empty((K, cin, cout), dtype=torch.float32, device="cuda:0")
+        hiplib.wgrad(torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda(), K, d, dw)
+        ref = np.zeros((K, cin, cout))
+        left = (K - 1) * d // 2
+        for k in range(K):
+            s = k * d - left
+            lo, hi = max(0, -s), min(R, R - s)
+            ref[k] = x[lo + s:hi + s].astype(np.float64).T @ dz[lo:hi].astype(np.float64)
+        assert _rel(dw.cpu().numpy(), ref) < 2e-6, (R, cin, cout, K, d)
+        sa = torch.empty(cout, dtype=torch.float32, device="cuda:0"); sab = torch.empty_like(sa)
+        b = rng.standard_normal((R, cout)).astype(np.float32)
+        hiplib.col_sums(torch.from_numpy(dz).cuda(), torch.from_numpy(b).cuda(), sa, sab)
+        assert _rel(sa.cpu().numpy(), dz.astype(np.float64).sum(0)) < 1e-6
+        assert _rel(sab.cpu().numpy(), (dz.astype(np.float64) * b).sum(0)) < 1e-6

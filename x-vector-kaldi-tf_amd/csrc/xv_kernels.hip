@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const float *__restrict
                                                          const int *__restrict__ row_start,
                                                          const int *__restrict__ row_len, int split_rows,
                                                          int max_splits, float eps, float *__restrict__ out,
-                                                         float *__restrict__ partial)
+                                                         float *__restrict__ partial, int raw)
 {
     const int b = blockIdx.z, sp = blockIdx.y;
     const int len = row_len[b];
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const float *__restrict
         const f32x4 var = s.m2 / s.n;
         f32x4 sd;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sd[i] = sqrtf(var[i] + eps);
+        for (int i = 0; i < 4; ++i) sd[i] = raw ? var[i] : sqrtf(var[i] + eps);      // raw: (mean, biased variance)
         float *o = out + (size_t)b * 2 * C;
         *reinterpret_cast<f32x4 *>(o + c) = s.mean;
         *reinterpret_cast<f32x4 *>(o + C + c) = sd;
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const float *__restrict
 
 // second stage for split chunks: merge the per-split (mean, M2) in split order, finalize
 __global__ void stats_pool_merge_kernel(const float *__restrict__ partial, int C, const int *__restrict__ row_len,
-                                        int split_rows, int max_splits, float eps, float *__restrict__ out)
+                                        int split_rows, int max_splits, float eps, float *__restrict__ out, int raw)
 {
     const int b = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -908,7 +908,7 @@ __global__ void stats_pool_merge_kernel(const float *__restrict__ partial, int C
         n = nn;
     }
     out[(size_t)b * 2 * C + c] = mean;
-    out[(size_t)b * 2 * C + C + c] = sqrtf(m2 / n + eps);
+    out[(size_t)b * 2 * C + C + c] = raw ? m2 / n : sqrtf(m2 / n + eps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1023,7 +1023,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 3; }
+int xv_version(void) { return 4; }
 
 const char *xv_last_error(void) { return g_err; }
 
@@ -1136,8 +1136,8 @@ size_t xv_stats_pool_workspace_bytes(int c, int nchunks, int max_len, int split_
     return (size_t)nchunks * splits * 2 * (size_t)c * sizeof(float);
 }
 
-int xv_stats_pool_f32(const float *h, int64_t ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
-                      int max_len, int split_rows, float eps, float *out, void *workspace, void *stream)
+static int stats_pool_impl(const float *h, int64_t ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
+                           int max_len, int split_rows, float eps, float *out, void *workspace, void *stream, int raw)
 {
     if (nchunks <= 0) return 0;
     if (!h || !row_start || !row_len || !out) return fail(XV_ERR_BAD_ARG, "stats_pool: NULL pointer");
@@ -1154,19 +1154,33 @@ int xv_stats_pool_f32(const float *h, int64_t ldh, int c, const int32_t *row_sta
         const dim3 grid((c + 255) / 256, max_splits, nb);
         hipLaunchKernelGGL(stats_pool_kernel, grid, dim3(256), 0, st, h, (long)ldh, c, row_start + b0, row_len + b0,
                            split_rows, max_splits, eps, out + (size_t)b0 * 2 * c,
-                           (float *)workspace + (size_t)b0 * max_splits * 2 * c);
+                           (float *)workspace + (size_t)b0 * max_splits * 2 * c, raw);
         int rc = check_launch("stats_pool_kernel");
         if (rc) return rc;
         if (max_splits > 1) {
             hipLaunchKernelGGL(stats_pool_merge_kernel, dim3((c + 255) / 256, nb), dim3(256), 0, st,
                                (const float *)workspace + (size_t)b0 * max_splits * 2 * c, c, row_len + b0, split_rows,
-                               max_splits, eps, out + (size_t)b0 * 2 * c);
+                               max_splits, eps, out + (size_t)b0 * 2 * c, raw);
             rc = check_launch("stats_pool_merge_kernel");
             if (rc) return rc;
         }
     }
     return 0;
 }
+
+int xv_stats_pool_f32(const float *h, int64_t ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
+                      int max_len, int split_rows, float eps, float *out, void *workspace, void *stream)
+{
+    return stats_pool_impl(h, ldh, c, row_start, row_len, nchunks, max_len, split_rows, eps, out, workspace, stream, 0);
+}
+
+int xv_chunk_moments_f32(const float *h, int64_t ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
+                         int max_len, int split_rows, float *out, void *workspace, void *stream)
+{
+    return stats_pool_impl(h, ldh, c, row_start, row_len, nchunks, max_len, split_rows, 0.f, out, workspace, stream, 1);
+}
+
+void xv_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
 int xv_chunk_average_f32(const float *e, const int32_t *seg_start, const int32_t *chunk_len, int nutts, int dim, float *out,
                          void *stream)

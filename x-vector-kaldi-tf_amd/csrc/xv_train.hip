@@ -1,0 +1,471 @@
+// xv_train.hip -- gfx950 kernels for the TRAINING step (reference: Model.train_one_iteration,
+// local/tf/models.py:216-305, graph local/tf/models.py:466-534, BN train branch local/tf/tf_block.py:18-23).
+//
+// The two dense GEMMs of a layer's forward and input-gradient reuse the inference kernel (xv_tdnn_layer_f32: dgrad is
+// the same implicit-im2col GEMM with tap-flipped, transposed weights).  This file adds what training needs on top:
+//   wgrad_kernel          dW[k,c,o] = sum_r x[r+(k-(K-1)/2)d, c] * dz[r,o]   (fp32 MFMA, reduction over rows, split + ordered merge)
+//   col_sums_kernel       per-channel sum_r a, sum_r a*b with fp64 accumulators (db, BN-backward statistics)
+//   merge_moments_kernel  per-chunk (mean, var) -> batch (mean, biased var)   (tf.nn.moments over all frames)
+//   rows_affine_kernel    y = valid ? x*scale + shift : 0                      (BN with batch statistics)
+//   bn_coeffs / bn_act_backward  closed-form BN backward through the activation
+//   pool_backward_kernel  gradient of [mean || sqrt(var+eps)] w.r.t. every frame
+//   softmax_ce_kernel     loss / accuracy / dlogits of tf.nn.softmax_cross_entropy_with_logits + reduce_mean
+//   adam_kernel, ema_kernel
+// Everything is fp32 storage; reductions accumulate in fp64.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "xvector_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+extern "C" void xv_internal_set_error(const char *msg);
+
+namespace {
+
+int tfail(int code, const char *msg)
+{
+    xv_internal_set_error(msg);          // shared with xv_last_error() (xv_kernels.hip)
+    return code;
+}
+int tcheck(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    xv_internal_set_error(buf);
+    return (int)e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: D[cin 128][cout 128] per (tap, tile) accumulated over a range of rows
+// ------------------------------------------------------------------------------------------------
+constexpr int WT = 128;      // tile edge (channels)
+constexpr int WR = 32;       // rows per step
+constexpr int WLD = WT + 4;  // LDS row stride (floats): the two 32-lane halves of a ds_read_b32 land 4 banks apart
+
+struct WgradParams {
+    const float *x;
+    const float *dz;
+    long R;
+    int cin, ldx, cout, lddz, K, dil;
+    int n_ct, n_ot;      // tiles along cin / cout
+    long rows_per_split;
+    float *out;          // [nsplit][K][cin][cout] (or dw itself when nsplit == 1)
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(16))) float As[WR * WLD];
+    __shared__ __attribute__((aligned(16))) float Bs[WR * WLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    int t = blockIdx.x;
+    const int ot = t % p.n_ot; t /= p.n_ot;
+    const int ct = t % p.n_ct; t /= p.n_ct;
+    const int k = t;
+    const int c0 = ct * WT, o0 = ot * WT;
+    const long shift = (long)(k - (p.K - 1) / 2) * p.dil;
+    const long r_begin = (long)blockIdx.y * p.rows_per_split;
+    const long r_end = min(p.R, r_begin + p.rows_per_split);
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const bool vec = !(p.cin & 3) && !(p.ldx & 3) && !(p.cout & 3) && !(p.lddz & 3);
+    for (long r0 = r_begin; r0 < r_end; r0 += WR) {
+        // stage 32 rows x 128 channels of x (shifted by the tap) and of dz
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j;
+            const int rr = f >> 5, q = f & 31;           // row, float4 index
+            const long ra = r0 + rr + shift, rb = r0 + rr;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            const int ca = c0 + q * 4, cb = o0 + q * 4;
+            if (rb < r_end) {
+                if (vec) {
+                    if (ra >= 0 && ra < p.R && ca < p.cin) va = *reinterpret_cast<const f32x4 *>(p.x + (size_t)ra * p.ldx + ca);
+                    if (cb < p.cout) vb = *reinterpret_cast<const f32x4 *>(p.dz + (size_t)rb * p.lddz + cb);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (ra >= 0 && ra < p.R && ca + i < p.cin) va[i] = p.x[(size_t)ra * p.ldx + ca + i];
+                        if (cb + i < p.cout) vb[i] = p.dz[(size_t)rb * p.lddz + cb + i];
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4 *>(As + rr * WLD + q * 4) = va;
+            *reinterpret_cast<f32x4 *>(Bs + rr * WLD + q * 4) = vb;
+        }
+        __syncthreads();
+        const float *ap = As + (lane >> 5) * WLD + wi * 64 + (lane & 31);
+        const float *bp = Bs + (lane >> 5) * WLD + wj * 64 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < WR / 2; ++kk) {
+            const float a0 = ap[kk * 2 * WLD], a1 = ap[kk * 2 * WLD + 32];
+            const float b0 = bp[kk * 2 * WLD], b1 = bp[kk * 2 * WLD + 32];
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D: col = lane&31 (cout), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cin)
+    float *out = p.out + ((size_t)blockIdx.y * p.K + k) * (size_t)p.cin * p.cout;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+            const f32x16 &a = bi == 0 ? (bj == 0 ? acc00 : acc01) : (bj == 0 ? acc10 : acc11);
+            const int o = o0 + wj * 64 + bj * 32 + (lane & 31);
+            if (o >= p.cout) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int c = c0 + wi * 64 + bi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (c < p.cin) out[(size_t)c * p.cout + o] = a[reg];
+            }
+        }
+}
+
+__global__ void sum_splits_kernel(const float *__restrict__ part, size_t n, int nsplit, float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int j = 0; j < nsplit; ++j) s += part[(size_t)j * n + i];      // fixed order: deterministic
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums with fp64 accumulation: out_a[c] = sum_r a[r,c], out_ab[c] = sum_r a[r,c]*b[r,c]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_sums_kernel(const float *__restrict__ a, const float *__restrict__ b, long R, int C,
+                                                       int lda, int ldb, long rows_per_split, double *__restrict__ part)
+{
+    __shared__ double sa[4][64], sb[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const long r0 = (long)blockIdx.y * rows_per_split, r1 = min(R, r0 + rows_per_split);
+    double s = 0.0, sab = 0.0;
+    if (c < C)
+        for (long r = r0 + ty; r < r1; r += 4) {
+            const float av = a[(size_t)r * lda + c];
+            s += av;
+            if (b) sab += (double)av * (double)b[(size_t)r * ldb + c];
+        }
+    sa[ty][tx] = s;
+    sb[ty][tx] = sab;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double *o = part + (size_t)blockIdx.y * 2 * C;
+        o[c] = sa[0][tx] + sa[1][tx] + sa[2][tx] + sa[3][tx];
+        o[C + c] = sb[0][tx] + sb[1][tx] + sb[2][tx] + sb[3][tx];
+    }
+}
+
+__global__ void col_sums_merge_kernel(const double *__restrict__ part, int C, int nsplit, float *__restrict__ out_a,
+                                      float *__restrict__ out_ab)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sab = 0.0;
+    for (int j = 0; j < nsplit; ++j) {
+        s += part[(size_t)j * 2 * C + c];
+        sab += part[(size_t)j * 2 * C + C + c];
+    }
+    out_a[c] = (float)s;
+    if (out_ab) out_ab[c] = (float)sab;
+}
+
+// per-chunk (mean, biased var) -> moments over all frames of all chunks (Chan merge in chunk order, fp64)
+__global__ void merge_moments_kernel(const float *__restrict__ cm, const int *__restrict__ row_len, int nchunks, int C,
+                                     float *__restrict__ mean, float *__restrict__ var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double n = 0.0, mu = 0.0, m2 = 0.0;
+    for (int b = 0; b < nchunks; ++b) {
+        const double m = (double)row_len[b];
+        if (m <= 0.0) continue;
+        const double bm = cm[(size_t)b * 2 * C + c], bv = cm[(size_t)b * 2 * C + C + c];
+        const double nn = n + m, d = bm - mu;
+        mu += d * (m / nn);
+        m2 += bv * m + d * d * (n * m / nn);
+        n = nn;
+    }
+    mean[c] = (float)mu;
+    var[c] = (float)(n > 0.0 ? m2 / n : 0.0);
+}
+
+__global__ void rows_affine_kernel(const float *__restrict__ x, long R, int C, int ldx, const float *__restrict__ scale,
+                                   const float *__restrict__ shift, const uint8_t *__restrict__ valid, float *__restrict__ y, int ldy)
+{
+    const size_t n = (size_t)R * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const long r = (long)(i / C);
+        const int c = (int)(i - (size_t)r * C);
+        const float v = x[(size_t)r * ldx + c] * scale[c] + shift[c];
+        y[(size_t)r * ldy + c] = (!valid || valid[r]) ? v : 0.f;
+    }
+}
+
+// BN backward through the activation, closed form.  With xhat = (r-mean)*rstd, N frames:
+//   dbeta = sum dh ; dgamma = sum dh*xhat = rstd*(sum dh*r - mean*sum dh)
+//   dr = gamma*rstd*(dh - dbeta/N - xhat*dgamma/N) = A*dh + B*r + Cc
+__global__ void bn_coeffs_kernel(const float *sum_dh, const float *sum_dh_r, const float *mean, const float *var,
+                                 const float *gamma, float eps, float n_frames, int C, float *dgamma, float *dbeta, float *coefA,
+                                 float *coefB, float *coefC)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double rstd = 1.0 / sqrt((double)var[c] + (double)eps);
+    const double db = sum_dh[c];
+    const double dg = rstd * ((double)sum_dh_r[c] - (double)mean[c] * db);
+    const double g = gamma[c], N = n_frames;
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+    coefA[c] = (float)(g * rstd);
+    coefB[c] = (float)(-g * rstd * rstd * dg / N);
+    coefC[c] = (float)(-g * rstd * db / N + g * rstd * rstd * (double)mean[c] * dg / N);
+}
+
+__global__ void bn_act_backward_kernel(const float *__restrict__ dh, const float *__restrict__ r, long R, int C, int ld,
+                                       const float *__restrict__ coefA, const float *__restrict__ coefB,
+                                       const float *__restrict__ coefC, int act, float alpha, const uint8_t *__restrict__ valid,
+                                       float *__restrict__ dz)
+{
+    const size_t n = (size_t)R * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const long row = (long)(i / C);
+        const int c = (int)(i - (size_t)row * C);
+        const size_t o = (size_t)row * ld + c;
+        const float rv = r[o];
+        float dr = coefA[c] * dh[o] + coefB[c] * rv + coefC[c];
+        // activation derivative from the activation OUTPUT (sign(r) == sign(z) for relu / leaky relu with alpha > 0)
+        if (act == XV_ACT_RELU) dr = rv > 0.f ? dr : 0.f;
+        else if (act == XV_ACT_LRELU) dr = rv > 0.f ? dr : alpha * dr;
+        dz[o] = (!valid || valid[row]) ? dr : 0.f;
+    }
+}
+
+// d[mean || sqrt(var+eps)] / d h[t,c]:  dmu/T + dsig*(h-mu)/(T*sig)
+__global__ void pool_backward_kernel(const float *__restrict__ h, int ldh, int C, const int *__restrict__ row_start,
+                                     const int *__restrict__ row_len, const float *__restrict__ pooled,
+                                     const float *__restrict__ dpooled, float *__restrict__ dh)
+{
+    const int b = blockIdx.y;
+    const int T = row_len[b];
+    const size_t base = (size_t)row_start[b];
+    const float invT = 1.0f / (float)T;
+    const float *mu = pooled + (size_t)b * 2 * C, *sig = mu + C;
+    const float *dmu = dpooled + (size_t)b * 2 * C, *dsig = dmu + C;
+    const size_t n = (size_t)T * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / C), c = (int)(i - (size_t)t * C);
+        const size_t o = (base + t) * ldh + c;
+        dh[o] = dmu[c] * invT + dsig[c] * (h[o] - mu[c]) * invT / sig[c];
+    }
+}
+
+// one wave64 per row of logits
+__global__ __launch_bounds__(64) void softmax_ce_kernel(const float *__restrict__ logits, const int *__restrict__ labels, int B,
+                                                        int N, float *__restrict__ row_loss, float *__restrict__ row_correct,
+                                                        float *__restrict__ dlogits)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float *z = logits + (size_t)b * N;
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int j = lane; j < N; j += 64)
+        if (z[j] > mx) { mx = z[j]; arg = j; }
+    for (int off = 32; off; off >>= 1) {
+        const float om = __shfl_xor(mx, off, 64);
+        const int oa = __shfl_xor(arg, off, 64);
+        if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }        // first maximum, like tf.argmax
+    }
+    double s = 0.0;
+    for (int j = lane; j < N; j += 64) s += exp((double)z[j] - (double)mx);
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off, 64);
+    const int lab = labels[b];
+    const double lse = log(s) + (double)mx;
+    if (lane == 0) {
+        row_loss[b] = (float)(lse - (double)z[lab]);
+        row_correct[b] = arg == lab ? 1.f : 0.f;
+    }
+    if (dlogits) {
+        const double invB = 1.0 / (double)B;
+        for (int j = lane; j < N; j += 64) {
+            const double pj = exp((double)z[j] - lse);
+            dlogits[(size_t)b * N + j] = (float)((pj - (j == lab ? 1.0 : 0.0)) * invB);
+        }
+    }
+}
+
+__global__ void mean2_kernel(const float *a, const float *b, int n, float *out)      // out[0]=mean(a), out[1]=mean(b), in order
+{
+    if (threadIdx.x || blockIdx.x) return;
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < n; ++i) { sa += a[i]; sb += b[i]; }
+    out[0] = (float)(sa / n);
+    out[1] = (float)(sb / n);
+}
+
+// tf.train.AdamOptimizer._apply_dense:  m,v EMAs; var -= lr_t * m / (sqrt(v) + eps),  lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            size_t n, float lr_t, float b1, float b2, float eps)
+{
+#pragma clang fp contract(off)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] * b1 + gi * (1.0f - b1);
+    const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+__global__ void ema_kernel(float *__restrict__ moving, const float *__restrict__ batch, int n, float decay)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) moving[i] = moving[i] * decay + batch[i] * (1.0f - decay);
+}
+
+inline unsigned gs_blocks(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+}  // namespace
+
+extern "C" {
+
+size_t xv_wgrad_workspace_bytes(int64_t R, int cin, int cout, int K)
+{
+    const long splits = R <= 4096 ? 1 : (R + 4095) / 4096;
+    return splits <= 1 ? 0 : (size_t)splits * K * cin * (size_t)cout * sizeof(float);
+}
+
+int xv_wgrad_f32(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation, float *dw,
+                 void *workspace, void *stream)
+{
+    if (!x || !dz || !dw || R <= 0 || cin <= 0 || cout <= 0 || K <= 0 || !(K & 1) || dilation <= 0)
+        return tfail(XV_ERR_BAD_ARG, "wgrad: bad argument");
+    WgradParams p{};
+    p.x = x; p.dz = dz; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.cout = cout; p.lddz = lddz; p.K = K; p.dil = dilation;
+    p.n_ct = (cin + WT - 1) / WT; p.n_ot = (cout + WT - 1) / WT;
+    const long splits = R <= 4096 ? 1 : (R + 4095) / 4096;
+    p.rows_per_split = ((R + splits - 1) / splits + WR - 1) / WR * WR;
+    if (splits > 1 && !workspace) return tfail(XV_ERR_BAD_ARG, "wgrad: workspace required");
+    p.out = splits > 1 ? (float *)workspace : dw;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(K * p.n_ct * p.n_ot), (unsigned)splits), dim3(256), 0, st, p);
+    int rc = tcheck("wgrad_kernel");
+    if (rc) return rc;
+    if (splits > 1) {
+        const size_t n = (size_t)K * cin * cout;
+        hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)workspace, n,
+                           (int)splits, dw);
+        rc = tcheck("sum_splits_kernel");
+    }
+    return rc;
+}
+
+size_t xv_col_sums_workspace_bytes(int64_t R, int c) { return (size_t)((R + 2047) / 2048) * 2 * (size_t)c * sizeof(double); }
+
+int xv_col_sums_f32(const float *a, int lda, const float *b, int ldb, int64_t R, int c, float *sum_a, float *sum_ab, void *workspace,
+                    void *stream)
+{
+    if (!a || !sum_a || !workspace || R <= 0 || c <= 0 || (b && !sum_ab)) return tfail(XV_ERR_BAD_ARG, "col_sums: bad argument");
+    const int splits = (int)((R + 2047) / 2048);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(col_sums_kernel, dim3((c + 63) / 64, splits), dim3(256), 0, st, a, b, (long)R, c, lda, ldb, 2048L,
+                       (double *)workspace);
+    int rc = tcheck("col_sums_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(col_sums_merge_kernel, dim3((c + 255) / 256), dim3(256), 0, st, (const double *)workspace, c, splits, sum_a,
+                       b ? sum_ab : nullptr);
+    return tcheck("col_sums_merge_kernel");
+}
+
+int xv_merge_moments_f32(const float *chunk_mean_var, const int32_t *row_len, int nchunks, int c, float *mean, float *var, void *stream)
+{
+    if (!chunk_mean_var || !row_len || !mean || !var || nchunks <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "merge_moments: bad argument");
+    hipLaunchKernelGGL(merge_moments_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunk_mean_var, row_len, nchunks,
+                       c, mean, var);
+    return tcheck("merge_moments_kernel");
+}
+
+int xv_rows_affine_f32(const float *x, int ldx, int64_t R, int c, const float *scale, const float *shift, const uint8_t *row_valid,
+                       float *y, int ldy, void *stream)
+{
+    if (!x || !y || !scale || !shift || R <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "rows_affine: bad argument");
+    hipLaunchKernelGGL(rows_affine_kernel, dim3(gs_blocks((size_t)R * c)), dim3(256), 0, (hipStream_t)stream, x, (long)R, c, ldx, scale,
+                       shift, row_valid, y, ldy);
+    return tcheck("rows_affine_kernel");
+}
+
+int xv_bn_act_backward_f32(const float *dh, const float *r, int ld, int64_t R, int c, const float *sum_dh, const float *sum_dh_r,
+                           const float *mean, const float *var, const float *gamma, float eps, float n_frames, int act_kind,
+                           float act_alpha, const uint8_t *row_valid, float *dgamma, float *dbeta, float *coef_ws, float *dz,
+                           void *stream)
+{
+    if (!dh || !r || !sum_dh || !sum_dh_r || !mean || !var || !gamma || !dgamma || !dbeta || !coef_ws || !dz || R <= 0 || c <= 0)
+        return tfail(XV_ERR_BAD_ARG, "bn_act_backward: bad argument");
+    if (act_kind == XV_ACT_PRELU) return tfail(XV_ERR_UNSUPPORTED, "bn_act_backward: PReLU training is not implemented");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, st, sum_dh, sum_dh_r, mean, var, gamma, eps, n_frames, c,
+                       dgamma, dbeta, coef_ws, coef_ws + c, coef_ws + 2 * c);
+    int rc = tcheck("bn_coeffs_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_act_backward_kernel, dim3(gs_blocks((size_t)R * c)), dim3(256), 0, st, dh, r, (long)R, c, ld, coef_ws,
+                       coef_ws + c, coef_ws + 2 * c, act_kind, act_alpha, row_valid, dz);
+    return tcheck("bn_act_backward_kernel");
+}
+
+int xv_pool_backward_f32(const float *h, int ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks, int64_t R,
+                         const float *pooled, const float *dpooled, float *dh, void *stream)
+{
+    if (!h || !row_start || !row_len || !pooled || !dpooled || !dh || nchunks <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "pool_backward: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dh, 0, (size_t)R * ldh * sizeof(float), st);      // gap rows carry no gradient
+    if (e != hipSuccess) return tfail((int)e, "pool_backward: memset failed");
+    for (int b0 = 0; b0 < nchunks; b0 += 65535) {
+        const int nb = nchunks - b0 < 65535 ? nchunks - b0 : 65535;
+        hipLaunchKernelGGL(pool_backward_kernel, dim3(64, nb), dim3(256), 0, st, h, ldh, c, row_start + b0, row_len + b0,
+                           pooled + (size_t)b0 * 2 * c, dpooled + (size_t)b0 * 2 * c, dh);
+        int rc = tcheck("pool_backward_kernel");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int xv_softmax_ce_f32(const float *logits, const int32_t *labels, int nrows, int nclasses, float *loss_acc, float *row_ws,
+                      float *dlogits, void *stream)
+{
+    if (!logits || !labels || !loss_acc || !row_ws || nrows <= 0 || nclasses <= 0) return tfail(XV_ERR_BAD_ARG, "softmax_ce: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(nrows), dim3(64), 0, st, logits, labels, nrows, nclasses, row_ws, row_ws + nrows, dlogits);
+    int rc = tcheck("softmax_ce_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mean2_kernel, dim3(1), dim3(64), 0, st, (const float *)row_ws, (const float *)(row_ws + nrows), nrows, loss_acc);
+    return tcheck("mean2_kernel");
+}
+
+int xv_adam_f32(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1, float beta2, float eps,
+                void *stream)
+{
+    if (!param || !grad || !m || !v || n <= 0) return tfail(XV_ERR_BAD_ARG, "adam: bad argument");
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (size_t)n,
+                       lr_t, beta1, beta2, eps);
+    return tcheck("adam_kernel");
+}
+
+int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream)
+{
+    if (!moving || !batch || n <= 0) return tfail(XV_ERR_BAD_ARG, "ema: bad argument");
+    hipLaunchKernelGGL(ema_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, moving, batch, n, decay);
+    return tcheck("ema_kernel");
+}
+
+}  // extern "C"

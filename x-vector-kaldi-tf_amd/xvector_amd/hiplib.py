@@ -10,13 +10,17 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libxvector_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
            "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32",
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_split_row_bytes", "xv_split_encode_f32",
-           "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3")
+           "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
+           # training step
+           "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
+           "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
+           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32")
 
 FMT_F32, FMT_SPLIT = 0, 1
 SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 136
@@ -73,6 +77,30 @@ def load():
     lib.xv_fc_bf16x3.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
     lib.xv_chunk_average_f32.restype = ci
     lib.xv_chunk_average_f32.argtypes = [vp, vp, vp, ci, ci, vp, vp]
+    lib.xv_chunk_moments_f32.restype = ci
+    lib.xv_chunk_moments_f32.argtypes = [vp, i64, ci, vp, vp, ci, ci, ci, vp, vp, vp]
+    lib.xv_merge_moments_f32.restype = ci
+    lib.xv_merge_moments_f32.argtypes = [vp, vp, ci, ci, vp, vp, vp]
+    lib.xv_rows_affine_f32.restype = ci
+    lib.xv_rows_affine_f32.argtypes = [vp, ci, i64, ci, vp, vp, vp, vp, ci, vp]
+    lib.xv_wgrad_workspace_bytes.restype = sz
+    lib.xv_wgrad_workspace_bytes.argtypes = [i64, ci, ci, ci]
+    lib.xv_wgrad_f32.restype = ci
+    lib.xv_wgrad_f32.argtypes = [vp, ci, vp, ci, i64, ci, ci, ci, ci, vp, vp, vp]
+    lib.xv_col_sums_workspace_bytes.restype = sz
+    lib.xv_col_sums_workspace_bytes.argtypes = [i64, ci]
+    lib.xv_col_sums_f32.restype = ci
+    lib.xv_col_sums_f32.argtypes = [vp, ci, vp, ci, i64, ci, vp, vp, vp, vp]
+    lib.xv_bn_act_backward_f32.restype = ci
+    lib.xv_bn_act_backward_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp]
+    lib.xv_pool_backward_f32.restype = ci
+    lib.xv_pool_backward_f32.argtypes = [vp, ci, ci, vp, vp, ci, i64, vp, vp, vp, vp]
+    lib.xv_softmax_ce_f32.restype = ci
+    lib.xv_softmax_ce_f32.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+    lib.xv_adam_f32.restype = ci
+    lib.xv_adam_f32.argtypes = [vp, vp, vp, vp, i64, cf, cf, cf, cf, vp]
+    lib.xv_ema_f32.restype = ci
+    lib.xv_ema_f32.argtypes = [vp, vp, ci, cf, vp]
     if lib.xv_version() != ABI_VERSION:
         raise XvectorHipError("libxvector_hip.so ABI version %d != expected %d" % (lib.xv_version(), ABI_VERSION))
     _lib = lib
@@ -296,3 +324,97 @@ def chunk_average(e, seg_start, chunk_len, nutts, out):
     assert out.shape[1] == dim and out.shape[0] >= nutts and seg_start.numel() >= nutts + 1
     _check(lib.xv_chunk_average_f32(_ptr(e), _ptr(seg_start), _ptr(chunk_len), int(nutts), dim, _ptr(out), _stream()),
            "xv_chunk_average_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# training-step wrappers
+# ------------------------------------------------------------------------------------------------
+def _ws(nbytes, device):
+    import torch
+    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device)
+
+
+def chunk_moments(h, row_start, row_len, nchunks, max_len, out, split_rows=512):
+    """out[B, 2C] = per-chunk [mean || biased variance]."""
+    lib = require_gpu()
+    _f32(h, "h"); _f32(out, "out")
+    c = h.shape[1]
+    ws = _ws(stats_pool_workspace_bytes(c, nchunks, max_len, split_rows), h.device)
+    _check(lib.xv_chunk_moments_f32(_ptr(h), h.stride(0), c, _ptr(row_start), _ptr(row_len), int(nchunks), int(max_len),
+                                    int(split_rows), _ptr(out), _ptr(ws), _stream()), "xv_chunk_moments_f32")
+
+
+def merge_moments(cm, row_len, nchunks, mean, var):
+    lib = require_gpu()
+    c = cm.shape[1] // 2
+    _check(lib.xv_merge_moments_f32(_ptr(_f32(cm, "cm")), _ptr(row_len), int(nchunks), c, _ptr(mean), _ptr(var), _stream()),
+           "xv_merge_moments_f32")
+
+
+def rows_affine(x, scale, shift, row_valid, y, rows=None):
+    lib = require_gpu()
+    R = x.shape[0] if rows is None else int(rows)
+    _check(lib.xv_rows_affine_f32(_ptr(_f32(x, "x")), x.stride(0), R, x.shape[1], _ptr(scale), _ptr(shift), _ptr(row_valid),
+                                  _ptr(_f32(y, "y")), y.stride(0), _stream()), "xv_rows_affine_f32")
+
+
+def wgrad(x, dz, K, dilation, dw):
+    """dw[K, Cin, Cout] (contiguous) = sum_r x[r + tap shift] (x) dz[r]."""
+    lib = require_gpu()
+    _f32(x, "x"); _f32(dz, "dz"); _f32(dw, "dw")
+    R, cin = x.shape
+    cout = dz.shape[1]
+    assert dz.shape[0] == R and tuple(dw.shape) == (K, cin, cout)
+    ws = _ws(lib.xv_wgrad_workspace_bytes(R, cin, cout, K), x.device)
+    _check(lib.xv_wgrad_f32(_ptr(x), x.stride(0), _ptr(dz), dz.stride(0), R, cin, cout, int(K), int(dilation), _ptr(dw), _ptr(ws),
+                            _stream()), "xv_wgrad_f32")
+
+
+def col_sums(a, b, sum_a, sum_ab=None):
+    lib = require_gpu()
+    _f32(a, "a")
+    R, c = a.shape
+    ws = _ws(lib.xv_col_sums_workspace_bytes(R, c), a.device)
+    _check(lib.xv_col_sums_f32(_ptr(a), a.stride(0), _ptr(b), b.stride(0) if b is not None else 0, R, c, _ptr(sum_a), _ptr(sum_ab),
+                               _ptr(ws), _stream()), "xv_col_sums_f32")
+
+
+def bn_act_backward(dh, r, sum_dh, sum_dh_r, mean, var, gamma, eps, n_frames, act, alpha, row_valid, dgamma, dbeta, dz):
+    import torch
+    lib = require_gpu()
+    R, c = dh.shape
+    coef = torch.empty(3 * c, dtype=torch.float32, device=dh.device)
+    _check(lib.xv_bn_act_backward_f32(_ptr(_f32(dh, "dh")), _ptr(_f32(r, "r")), dh.stride(0), R, c, _ptr(sum_dh), _ptr(sum_dh_r),
+                                      _ptr(mean), _ptr(var), _ptr(gamma), float(eps), float(n_frames), int(act), float(alpha),
+                                      _ptr(row_valid), _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_f32(dz, "dz")), _stream()),
+           "xv_bn_act_backward_f32")
+
+
+def pool_backward(h, row_start, row_len, nchunks, pooled, dpooled, dh):
+    lib = require_gpu()
+    _check(lib.xv_pool_backward_f32(_ptr(_f32(h, "h")), h.stride(0), h.shape[1], _ptr(row_start), _ptr(row_len), int(nchunks),
+                                    h.shape[0], _ptr(_f32(pooled, "pooled")), _ptr(_f32(dpooled, "dpooled")), _ptr(_f32(dh, "dh")),
+                                    _stream()), "xv_pool_backward_f32")
+
+
+def softmax_ce(logits, labels, loss_acc, dlogits=None):
+    import torch
+    lib = require_gpu()
+    B, N = logits.shape
+    assert labels.dtype == torch.int32
+    ws = torch.empty(2 * B, dtype=torch.float32, device=logits.device)
+    _check(lib.xv_softmax_ce_f32(_ptr(_f32(logits, "logits")), _ptr(labels), B, N, _ptr(loss_acc), _ptr(ws), _ptr(dlogits), _stream()),
+           "xv_softmax_ce_f32")
+
+
+def adam(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
+    lib = require_gpu()
+    n = param.numel()
+    assert grad.numel() == n and m.numel() == n and v.numel() == n and param.is_contiguous() and grad.is_contiguous()
+    _check(lib.xv_adam_f32(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), n, float(lr_t), float(beta1), float(beta2), float(eps), _stream()),
+           "xv_adam_f32")
+
+
+def ema(moving, batch, decay):
+    lib = require_gpu()
+    _check(lib.xv_ema_f32(_ptr(moving), _ptr(batch), moving.numel(), float(decay), _stream()), "xv_ema_f32")

@@ -1,0 +1,233 @@
+"""Training / evaluation step on the MI355X.
+
+Host side of what ``Model.train_one_iteration`` / ``Model.eval`` run per minibatch in the reference
+(local/tf/models.py:243-289 / 325-343): forward in train or eval phase, softmax cross-entropy loss + accuracy,
+backward, Adam, batch-norm moving-average updates.  Every arithmetic step is a kernel behind the C ABI
+(include/xvector_hip.h, "training step" section): the forward and input-gradient GEMMs are the exact-fp32 inference
+kernel (dgrad = same kernel, taps flipped + Cin/Cout swapped), plus wgrad, reductions, BN/pooling backward, softmax-CE,
+Adam.  PyTorch holds the device buffers and does layout shuffles (flip/permute) only.
+
+Covers the model classes without dropout (``ModelWithoutDropout`` -- the one the recipe trains, run_xvector.sh:90 --
+its Tdnn and LRelu variants).  Class ``Model`` (dropout) trains only with ``dropout_proportion == 0``; PReLU and the
+L2-loss terms of the ``ModelL2Loss*`` classes are not implemented (they raise).
+"""
+import math
+
+import numpy as np
+
+from . import hiplib
+from . import topology as tp
+from .engine import BatchLayout
+
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8          # tf.train.AdamOptimizer defaults (models.py:112)
+BN_DECAY = 0.95                                        # batch_norm_wrapper(h, decay=0.95, ...)  models.py:65
+
+
+class Trainer(object):
+    def __init__(self, weights, topo, device="cuda:0", adam=None):
+        import torch
+        hiplib.require_gpu()
+        self.torch = torch
+        self.device = torch.device(device)
+        self.topo = topo
+        self.act = tp.ACT_CODES[topo.get("activation", "relu")]
+        if self.act == tp.ACT_PRELU:
+            raise NotImplementedError("training with PReLU is not implemented in this build")
+        self.alpha = float(topo.get("lrelu_alpha", 0.2)) if self.act == tp.ACT_LRELU else 0.0
+        self.alpha_t = torch.tensor([self.alpha], dtype=torch.float32, device=self.device) if self.act == tp.ACT_LRELU else None
+        self.gap = tp.max_halo(topo)
+        self.P = {k: torch.as_tensor(np.array(v, dtype=np.float32, order="C")).to(self.device) for k, v in weights.items()}
+        self.feat_dim = int(self.P["frame_level_info_layer-0/w:0"].shape[1])
+        self.in_dim = (self.feat_dim + 3) // 4 * 4
+        self.num_classes = int(self.P["output/w:0"].shape[1])
+        self.frame_scopes = ["frame_level_info_layer-%d" % i for i in range(len(topo["layer_sizes"]))]
+        self.embed_scopes = ["embed_layer-%d" % j for j in range(len(topo["embedding_sizes"]))]
+        self.trainable = []
+        for sc in self.frame_scopes + self.embed_scopes:
+            self.trainable += ["%s/%s:0" % (sc, n) for n in ("w", "b", "gamma", "beta")]
+        self.trainable += ["output/w:0", "output/b:0"]
+        self.t = int(adam["t"]) if adam else 0
+        z = lambda n: torch.zeros_like(self.P[n])
+        self.m = {n: (torch.as_tensor(np.array(adam["m"][n], np.float32)).to(self.device) if adam and n in adam["m"] else z(n))
+                  for n in self.trainable}
+        self.v = {n: (torch.as_tensor(np.array(adam["v"][n], np.float32)).to(self.device) if adam and n in adam["v"] else z(n))
+                  for n in self.trainable}
+        self._packed = None
+        self._layouts = {}
+
+    # -- weights in kernel layout (re-packed after every optimizer step) -----------------------------------------
+    def _w3(self, scope, k):
+        w = self.P[scope + "/w:0"]
+        if w.dim() == 2:
+            w = w.unsqueeze(0)
+        if scope == self.frame_scopes[0] and self.in_dim != self.feat_dim:
+            pad = self.torch.zeros((w.shape[0], self.in_dim - self.feat_dim, w.shape[2]), dtype=w.dtype, device=w.device)
+            w = self.torch.cat([w, pad], dim=1)
+        return w.contiguous()
+
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        pk = {}
+        for sc in self.frame_scopes + self.embed_scopes + ["output"]:
+            w = self._w3(sc, None)                                           # [K, Cin, Cout]
+            K, cin, cout = w.shape
+            pk[sc] = hiplib.pack_weights(w.reshape(K * cin, cout))
+            # dgrad: dx[r,c] = sum_{k,o} dz[r - (k-(K-1)/2)d, o] w[k,c,o]  == the forward kernel on w'[k',o,c] = w[K-1-k',c,o]
+            wt = w.flip(0).permute(0, 2, 1).contiguous()                     # [K, Cout, Cin]
+            pk[sc + "/T"] = hiplib.pack_weights(wt.reshape(K * cout, cin))
+        self._packed = pk
+        return pk
+
+    def _layout(self, B, T):
+        key = (B, T)
+        if key not in self._layouts:
+            torch = self.torch
+            lay = BatchLayout([T] * B, self.gap)
+            self._layouts[key] = dict(lay=lay, rs=torch.from_numpy(lay.row_start).to(self.device),
+                                      rl=torch.from_numpy(lay.row_len).to(self.device),
+                                      rv=torch.from_numpy(lay.row_valid()).to(self.device),
+                                      one_start=torch.zeros(1, dtype=torch.int32, device=self.device),
+                                      one_len=torch.full((1,), B, dtype=torch.int32, device=self.device))
+        return self._layouts[key]
+
+    def _bn_scopes_stats(self, r, scope, L, rows_per_chunk, nchunks, train, valid, frame_level):
+        """BN (train: batch statistics + moving-average update; eval: moving statistics) applied to r -> h."""
+        torch = self.torch
+        C = r.shape[1]
+        if train:
+            cm = torch.empty((nchunks, 2 * C), dtype=torch.float32, device=self.device)
+            rs, rl = (L["rs"], L["rl"]) if frame_level else (L["one_start"], L["one_len"])
+            hiplib.chunk_moments(r, rs, rl, nchunks, rows_per_chunk, cm)
+            mean = torch.empty(C, dtype=torch.float32, device=self.device)
+            var = torch.empty_like(mean)
+            hiplib.merge_moments(cm, rl, nchunks, mean, var)
+            hiplib.ema(self.P[scope + "/mean:0"], mean, BN_DECAY)
+            hiplib.ema(self.P[scope + "/variance:0"], var, BN_DECAY)
+        else:
+            mean, var = self.P[scope + "/mean:0"], self.P[scope + "/variance:0"]
+        scale, shift = hiplib.fold_bn(self.P[scope + "/gamma:0"], self.P[scope + "/beta:0"], mean, var, tp.BN_EPSILON)
+        h = torch.empty_like(r)
+        hiplib.rows_affine(r, scale, shift, valid, h)
+        return h, mean, var
+
+    # -- forward ---------------------------------------------------------------------------------------------------
+    def _forward(self, x, labels, train, want_grad):
+        torch = self.torch
+        x = np.asarray(x)
+        B, T, F = x.shape
+        assert F == self.feat_dim, "feature dimension %d does not match the model (%d)" % (F, self.feat_dim)
+        L = self._layout(B, T)
+        lay = L["lay"]
+        host = np.zeros((lay.rows, self.in_dim), np.float32)
+        view = host[self.gap:self.gap + B * (T + self.gap)].reshape(B, T + self.gap, self.in_dim)
+        view[:, :T, :F] = x.astype(np.float32)
+        X = torch.from_numpy(host).to(self.device)
+        pk = self._pack()
+        S = dict(L=L, B=B, T=T, R=lay.rows, X=X, r=[], h=[X], mean=[], var=[])
+        for i, sc in enumerate(self.frame_scopes):
+            K, d = self.topo["kernel_sizes"][i], self.topo["dilations"][i]
+            C = self.topo["layer_sizes"][i]
+            r = torch.empty((lay.rows, C), dtype=torch.float32, device=self.device)
+            hiplib.tdnn_layer(S["h"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act, self.alpha_t, K, d, L["rv"], r)
+            h, mean, var = self._bn_scopes_stats(r, sc, L, T, B, train, L["rv"], True)
+            S["r"].append(r); S["h"].append(h); S["mean"].append(mean); S["var"].append(var)
+        Cl = self.topo["layer_sizes"][-1]
+        pooled = torch.empty((B, 2 * Cl), dtype=torch.float32, device=self.device)
+        hiplib.stats_pool(S["h"][-1], L["rs"], L["rl"], B, T, 512, tp.VAR2STD_EPSILON, pooled,
+                          hiplib._ws(hiplib.stats_pool_workspace_bytes(Cl, B, T, 512), self.device))
+        S["pooled"] = pooled
+        S["e_in"], S["e_r"], S["e_mean"], S["e_var"] = [pooled], [], [], []
+        for j, sc in enumerate(self.embed_scopes):
+            C = self.topo["embedding_sizes"][j]
+            r = torch.empty((B, C), dtype=torch.float32, device=self.device)
+            hiplib.fc(S["e_in"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act, self.alpha_t, r, None)
+            a, mean, var = self._bn_scopes_stats(r, sc, L, B, 1, train, None, False)
+            S["e_r"].append(r); S["e_in"].append(a); S["e_mean"].append(mean); S["e_var"].append(var)
+        logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)
+        hiplib.fc(S["e_in"][-1], pk["output"], self.P["output/b:0"], None, None, tp.ACT_NONE, None, None, logits)
+        lab = torch.from_numpy(np.asarray(labels, dtype=np.int32)).to(self.device)
+        loss_acc = torch.empty(2, dtype=torch.float32, device=self.device)
+        dlogits = torch.empty_like(logits) if want_grad else None
+        hiplib.softmax_ce(logits, lab, loss_acc, dlogits)
+        S["dlogits"] = dlogits
+        S["loss_acc"] = loss_acc
+        return S
+
+    def eval_batch(self, x, labels):
+        """(loss, accuracy) of one minibatch in the eval phase (moving BN statistics)."""
+        la = self._forward(x, labels, train=False, want_grad=False)["loss_acc"].cpu().numpy()
+        return float(la[0]), float(la[1])
+
+    # -- backward + Adam -------------------------------------------------------------------------------------------
+    def _dense_backward(self, scope, x_in, dz, K, dil, grads, need_dx, valid):
+        """dW, db (and dx) of  z = conv(x_in, W) + b  given dz."""
+        torch = self.torch
+        pk = self._pack()
+        R, cin = x_in.shape
+        cout = dz.shape[1]
+        dw = torch.empty((K, cin, cout), dtype=torch.float32, device=self.device)
+        hiplib.wgrad(x_in, dz, K, dil, dw)
+        db = torch.empty(cout, dtype=torch.float32, device=self.device)
+        hiplib.col_sums(dz, None, db)
+        w = self.P[scope + "/w:0"]
+        if scope == self.frame_scopes[0]:
+            dw = dw[:, :self.feat_dim, :].contiguous()                   # drop the padding column
+        grads[scope + "/w:0"] = dw.reshape(w.shape)
+        grads[scope + "/b:0"] = db
+        if not need_dx:
+            return None
+        dx = torch.empty((R, cin), dtype=torch.float32, device=self.device)
+        hiplib.tdnn_layer(dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid, dx)
+        return dx
+
+    def _bn_backward(self, scope, dh, r, mean, var, n_frames, valid, grads):
+        torch = self.torch
+        C = r.shape[1]
+        s1 = torch.empty(C, dtype=torch.float32, device=self.device)
+        s2 = torch.empty_like(s1)
+        hiplib.col_sums(dh, r, s1, s2)
+        dgamma, dbeta = torch.empty_like(s1), torch.empty_like(s1)
+        dz = torch.empty_like(r)
+        hiplib.bn_act_backward(dh, r, s1, s2, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames, self.act, self.alpha,
+                               valid, dgamma, dbeta, dz)
+        grads[scope + "/gamma:0"] = dgamma
+        grads[scope + "/beta:0"] = dbeta
+        return dz
+
+    def gradients(self, x, labels):
+        """Forward (train phase, updates the moving statistics) + backward.  Returns (loss, acc, {name: grad tensor})."""
+        torch = self.torch
+        S = self._forward(x, labels, train=True, want_grad=True)
+        L, B, T = S["L"], S["B"], S["T"]
+        grads = {}
+        d = self._dense_backward("output", S["e_in"][-1], S["dlogits"], 1, 1, grads, True, None)
+        for j in reversed(range(len(self.embed_scopes))):
+            sc = self.embed_scopes[j]
+            dz = self._bn_backward(sc, d, S["e_r"][j], S["e_mean"][j], S["e_var"][j], float(B), None, grads)
+            d = self._dense_backward(sc, S["e_in"][j], dz, 1, 1, grads, True, None)
+        dh = torch.empty_like(S["h"][-1])
+        hiplib.pool_backward(S["h"][-1], L["rs"], L["rl"], B, S["pooled"], d, dh)
+        for i in reversed(range(len(self.frame_scopes))):
+            sc = self.frame_scopes[i]
+            dz = self._bn_backward(sc, dh, S["r"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads)
+            dh = self._dense_backward(sc, S["h"][i], dz, self.topo["kernel_sizes"][i], self.topo["dilations"][i], grads, i > 0,
+                                      L["rv"])
+        la = S["loss_acc"].cpu().numpy()
+        return float(la[0]), float(la[1]), grads
+
+    def step(self, x, labels, learning_rate):
+        """One optimizer step on a minibatch x[B,T,F] (float16/32), labels[B].  Returns (loss, accuracy)."""
+        loss, acc, grads = self.gradients(x, labels)
+        self.t += 1
+        lr_t = learning_rate * math.sqrt(1.0 - ADAM_B2 ** self.t) / (1.0 - ADAM_B1 ** self.t)
+        for n in self.trainable:
+            hiplib.adam(self.P[n], grads[n].contiguous(), self.m[n], self.v[n], lr_t, ADAM_B1, ADAM_B2, ADAM_EPS)
+        self._packed = None
+        return loss, acc
+
+    def export(self):
+        """-> (weights {tf name: float32 ndarray}, adam {"t", "m", "v"}) for the model directory."""
+        w = {k: v.cpu().numpy() for k, v in self.P.items()}
+        adam = dict(t=self.t, m={k: v.cpu().numpy() for k, v in self.m.items()}, v={k: v.cpu().numpy() for k, v in self.v.items()})
+        return w, adam
