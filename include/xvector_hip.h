@@ -179,6 +179,10 @@ int xv_softmax_ce_f32(const float *logits, const int32_t *labels, int nrows, int
 /* tf.train.AdamOptimizer dense update with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the caller. */
 int xv_adam_f32(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1, float beta2, float eps,
                 void *stream);
+/* y += a*x and out[0] = sum x^2: the L2 penalty of the ModelL2Loss* classes, beta*(0.1|1)*tf.nn.l2_loss(w)
+ * (local/tf/models.py:811-842): gradient g += beta*coef*w, loss += beta*coef*sumsq/2. */
+int xv_axpy_f32(float *y, const float *x, float a, int64_t n, void *stream);
+int xv_sumsq_f32(const float *x, int64_t n, float *out, void *stream);
 /* moving = moving*decay + batch*(1-decay)   (local/tf/tf_block.py:20-21). */
 int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream);
 

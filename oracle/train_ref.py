@@ -83,6 +83,12 @@ def forward(params, stats, topo, x, labels, train):
         h = bn(_act(s, topo, alpha), sc, (0,))
     logits = h @ params["output/w:0"] + params["output/b:0"]
     loss = F.cross_entropy(logits, labels, reduction="mean")
+    beta = topo.get("l2_beta", 0.0)
+    if beta:                                                           # models.py:811-842: tf.nn.l2_loss(t) = sum(t**2)/2
+        l2 = 0.0
+        for sc, coef in (("embed_layer-0", 0.1), ("embed_layer-1", 1.0), ("output", 1.0)):
+            l2 = l2 + coef * 0.5 * ((params[sc + "/w:0"] ** 2).sum() + (params[sc + "/b:0"] ** 2).sum())
+        loss = loss + beta * l2
     acc = (logits.argmax(dim=1) == labels).double().mean()
     return loss, acc, new_stats, e0
 

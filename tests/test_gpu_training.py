@@ -62,22 +62,36 @@ def test_gradients_match_autograd(env, cls):
 
 
 def test_three_adam_steps_follow_the_oracle(env):
+    """Adam normalises every element by its own gradient history (update ~ lr*sign(g) on the first step), so elements
+    whose gradient is at rounding-noise level are ill-conditioned in ANY implementation; they are masked out (a gradient
+    element counts as well-conditioned when |g| > 1e-3 * rms(g) of its tensor at every step)."""
     topo, w, rng = _setup(env, "ModelWithoutDropout", seed=7)
     tr = env["trainer"].Trainer(w, topo)
     ref_w, ref_adam = {k: np.array(v, np.float64) for k, v in w.items()}, {"t": 0, "m": {}, "v": {}}
+    names = env["ref"].trainable_names(topo)
+    ok = {n: np.ones(np.shape(w[n]), bool) for n in names}
     lr = 2e-3
     for step in range(3):
         B, T = 8, int(rng.integers(200, 230))
         x = (rng.standard_normal((B, T, 23)) * 3).astype(np.float16)          # the loaders hand out float16 (examples_io.py:165)
         lab = rng.integers(0, 10, B)
         loss, acc = tr.step(x, lab, lr)
-        rl, ra, ref_w, ref_adam, _ = env["ref"].train_step(ref_w, ref_adam, topo, x.astype(np.float64), lab, lr)
+        rl, ra, ref_w, ref_adam, g = env["ref"].train_step(ref_w, ref_adam, topo, x.astype(np.float64), lab, lr)
         assert abs(loss - rl) < 2e-4 * max(1.0, abs(rl)), (step, loss, rl)
+        for n in names:
+            ok[n] &= np.abs(g[n]) > 1e-3 * np.sqrt(np.mean(g[n] ** 2))
     got, adam = tr.export()
     assert adam["t"] == 3
-    for n in env["ref"].trainable_names(topo):
-        delta = np.linalg.norm(ref_w[n] - w[n])
-        assert np.linalg.norm(got[n] - ref_w[n]) < 0.02 * delta + 1e-7, n
+    covered = sum(int(m.sum()) for m in ok.values()) / sum(m.size for m in ok.values())
+    assert covered > 0.9, covered
+    for n in names:
+        m = ok[n]
+        if not m.any():
+            continue
+        delta = np.abs(ref_w[n] - w[n])[m]
+        err = np.abs(got[n] - ref_w[n])[m]
+        assert np.linalg.norm(err) < 0.02 * np.linalg.norm(delta) + 1e-7, (n, np.linalg.norm(err), np.linalg.norm(delta))
+        assert _rel(adam["m"][n][m], ref_adam["m"][n][m]) < 1e-3 and _rel(adam["v"][n][m], ref_adam["v"][n][m]) < 1e-3, n
 
 
 def test_wgrad_and_reductions_unit(env):
@@ -101,3 +115,76 @@ def test_wgrad_and_reductions_unit(env):
         hiplib.col_sums(torch.from_numpy(dz).cuda(), torch.from_numpy(b).cuda(), sa, sab)
         assert _rel(sa.cpu().numpy(), dz.astype(np.float64).sum(0)) < 1e-6
         assert _rel(sab.cpu().numpy(), (dz.astype(np.float64) * b).sum(0)) < 1e-6
+
+
+def test_l2_loss_class_gradients(env):
+    """ModelL2LossWithoutDropoutLRelu: loss and gradients include beta*(0.1*l2(embed-0) + l2(embed-1) + l2(output))."""
+    topo, w, rng = _setup(env, "ModelL2LossWithoutDropoutLRelu", seed=13)
+    assert topo["l2_beta"] == 0.0002
+    for n in ("embed_layer-1/w:0", "output/w:0"):
+        w[n] = w[n] * 20                                   # make the penalty numerically visible
+    B, T = 6, 60
+    x = (rng.standard_normal((B, T, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, B)
+    tr = env["trainer"].Trainer(w, topo)
+    loss, acc, grads = tr.gradients(x, lab)
+    rl, ra, _, _, rg = env["ref"].train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3)
+    assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl))
+    for n in ("embed_layer-0/w:0", "embed_layer-1/w:0", "embed_layer-1/b:0", "output/w:0", "output/b:0"):
+        assert _rel(grads[n].cpu().numpy(), rg[n]) < 2e-4, n
+    el, _ = tr.eval_batch(x, lab)
+    assert abs(el - env["ref"].eval_batch(w, topo, x, lab)[0]) < 1e-5 * max(1.0, abs(el))
+
+
+def test_model_train_one_iteration_and_eval_api(env, tmp_path, caplog):
+    """The drop-in methods: build_model -> train_one_iteration (2 iterations, optimizer state carried over through the
+    model directory) -> eval, with the data_loader duck type of the reference (count / pop) and its log lines."""
+    import argparse
+    import logging
+    import queue
+    import models
+    from xvector_amd import weights as wio
+
+    class Loader(object):                                  # examples_io.DataLoader duck type (examples_io.py:213-221)
+        def __init__(self, batches):
+            self.batches, self.count = list(batches), len(batches)
+
+        def pop(self, timeout=30):
+            if not self.batches:
+                raise queue.Empty
+            return self.batches.pop(0)
+
+    rng = np.random.default_rng(21)
+    spk = rng.standard_normal((8, 23)) * 2
+    def batches(n):
+        out = []
+        for _ in range(n):
+            lab = rng.integers(0, 8, 16)
+            T = int(rng.integers(200, 260))
+            x = (spk[lab][:, None, :] + rng.standard_normal((16, T, 23))).astype(np.float16)
+            out.append((x, lab.astype(np.int32)))
+        return out
+
+    d0, d1, d2 = (str(tmp_path / n) for n in ("model_0", "model_1", "model_2"))
+    m = models.ModelWithoutDropout()
+    m.build_model(8, 23, d0, None)
+    log = logging.getLogger("train_api")
+    log.setLevel(logging.INFO)
+    caplog.set_level(logging.INFO, logger="train_api")
+    args = argparse.Namespace(learning_rate=1e-3, print_interval=2, dropout_proportion=0.0, input_dir=d0, output_dir=d1, random_seed=0)
+    val = batches(2)
+    m.eval(Loader(val), d0, True, log)
+    m.train_one_iteration(Loader(batches(6) + [(None, None)]), args, log)
+    assert wio.is_correct_model_dir(d1) and wio.load_optimizer_state(d1)["t"] == 6
+    args.input_dir, args.output_dir = d1, d2
+    m.train_one_iteration(Loader(batches(6)), args, log)
+    assert wio.load_optimizer_state(d2)["t"] == 12
+    m.eval(Loader(val), d2, True, log)
+    text = caplog.text
+    assert "Average training loss for minibatches 1-2 is" in text and "Overall average objective function is" in text
+    assert "batch_data is None for the minibatch index 6" in text
+    import re
+    losses = [float(v) for v in re.findall(r"Overall average loss is ([0-9.]+) over", text)]
+    assert len(losses) == 2 and losses[1] < losses[0]          # 12 Adam steps on separable synthetic speakers reduce the loss
+    # the trained directory still extracts
+    assert wio.load_model_dir(d2)[1]["model_class"] == "ModelWithoutDropout"

@@ -1023,7 +1023,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 4; }
+int xv_version(void) { return 5; }
 
 const char *xv_last_error(void) { return g_err; }
 

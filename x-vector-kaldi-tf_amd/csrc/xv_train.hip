@@ -334,6 +334,26 @@ __global__ void ema_kernel(float *__restrict__ moving, const float *__restrict__
     if (i < n) moving[i] = moving[i] * decay + batch[i] * (1.0f - decay);
 }
 
+__global__ void axpy_kernel(float *__restrict__ y, const float *__restrict__ x, float a, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float *__restrict__ x, size_t n, float *__restrict__ out)
+{
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) s += (double)x[i] * (double)x[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 512; k; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sh[0];
+}
+
 inline unsigned gs_blocks(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 }  // namespace
@@ -459,6 +479,20 @@ int xv_adam_f32(float *param, const float *grad, float *m, float *v, int64_t n, 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, (size_t)n,
                        lr_t, beta1, beta2, eps);
     return tcheck("adam_kernel");
+}
+
+int xv_axpy_f32(float *y, const float *x, float a, int64_t n, void *stream)
+{
+    if (!y || !x || n <= 0) return tfail(XV_ERR_BAD_ARG, "axpy: bad argument");
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x, a, (size_t)n);
+    return tcheck("axpy_kernel");
+}
+
+int xv_sumsq_f32(const float *x, int64_t n, float *out, void *stream)
+{
+    if (!x || !out || n <= 0) return tfail(XV_ERR_BAD_ARG, "sumsq: bad argument");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (size_t)n, out);
+    return tcheck("sumsq_kernel");
 }
 
 int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream)

@@ -14,7 +14,7 @@ load_model               local/tf/models.py:143-162             model dir -> wei
 make_embedding           local/tf/models.py:356-432             ark stream -> batched HIP forward -> ark
 get_models_weights       local/tf/models.py:180-214             {tf variable name: ndarray}
 print_models_params      local/tf/models.py:171-178
-train_one_iteration/eval local/tf/models.py:216-354             NOT on this path
+train_one_iteration/eval local/tf/models.py:216-354             HIP training / eval step
 =======================  ====================================  =======================================
 
 There is no TensorFlow and no CPU path: the forward graph runs as hand-written gfx950 kernels behind
@@ -119,12 +119,126 @@ class Model(object):
         w, _ = wio.load_model_dir(input_dir)
         return w
 
-    # -- not on the extraction path ----------------------------------------------------------------
+    # -- training / diagnostics ---------------------------------------------------------
+    def _trainer(self, input_dir, logger):
+        from xvector_amd import trainer
+        if logger is not None:
+            logger.info("Start loading graph ...")
+        w, meta = wio.load_model_dir(input_dir)
+        self.meta = meta
+        self.num_classes = meta["num_classes"]
+        tr = trainer.Trainer(w, meta["topology"], _device(), wio.load_optimizer_state(input_dir))
+        if logger is not None:
+            logger.info("Graph restored from path: %s" % input_dir)
+        return tr
+
+    @staticmethod
+    def _pop(data_loader, minibatch_idx, logger, what):
+        import queue
+        try:
+            batch_data, labels = data_loader.pop()
+        except queue.Empty:                                        # models.py:248-250
+            logger.warning('Timeout reach when reading %s %d' % (what, minibatch_idx))
+            return None, None
+        if batch_data is None:                                     # models.py:251-253
+            logger.warning('batch_data is None for %s %d' % (what, minibatch_idx))
+        return batch_data, labels
+
     def train_one_iteration(self, data_loader, args, logger):
-        raise NotImplementedError("training (models.py:216-305) is outside the extraction hot path of this build")
+        """Twin of models.py:216-305: one pass over ``data_loader`` (``.count`` minibatches of ``[B,T,F]`` float16/32 +
+        int labels), Adam with ``args.learning_rate``, then the model (and the optimizer slots) are saved to
+        ``args.output_dir``.  Reads the same ``args`` fields as the reference (learning_rate, print_interval,
+        dropout_proportion, input_dir, output_dir, random_seed) and prints the same log lines (they are regex-parsed by
+        ze_utils.py:126-127,498-499)."""
+        learning_rate = args.learning_rate
+        print_interval = args.print_interval
+        if float(getattr(args, "dropout_proportion", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError("dropout (class Model, models.py:70-72) is not implemented in this build; "
+                                      "use a *WithoutDropout class or dropout_proportion 0")
+        tr = self._trainer(args.input_dir, logger)
+        minibatch_count = data_loader.count
+        start_minibatch = 1
+        total_segments, minibatch_segments = 0, 0
+        total_loss, minibatch_loss = 0, 0
+        total_objective, minibatch_objective = 0, 0
+        total_accuracy, minibatch_accuracy = 0, 0
+        total_segments_len = 0
+        total_gpu_waiting = 0.0
+        total_disk_waiting = 0.0
+        start_time = time.time()
+        for minibatch_idx in range(minibatch_count):
+            disk_waiting = time.time()
+            batch_data, labels = self._pop(data_loader, minibatch_idx, logger, 'the minibatch index')
+            total_disk_waiting += time.time() - disk_waiting
+            if batch_data is None:
+                continue
+            minibatch_segments += batch_data.shape[0]
+            total_segments += batch_data.shape[0]
+            total_segments_len += batch_data.shape[1]
+            gpu_waiting = time.time()
+            loss, accuracy = tr.step(batch_data, labels, learning_rate)
+            total_gpu_waiting += time.time() - gpu_waiting
+            objective = -loss
+            total_loss += loss
+            minibatch_loss += loss
+            total_objective += objective
+            minibatch_objective += objective
+            total_accuracy += accuracy
+            minibatch_accuracy += accuracy
+            end_minibatch = minibatch_idx + 1
+            if end_minibatch % print_interval == 0:
+                cnt = end_minibatch - start_minibatch + 1
+                logger.info("Average training loss for minibatches %d-%d is %.4f over %d segments. Also, the "
+                            "average training accuracy for these minibatches is %.4f and the average "
+                            "objective function for these minibatches is %.4f. Average DISK waiting: %.1f "
+                            "secs and average GPU waiting: %.1f secs for each minibatch." %
+                            (start_minibatch, end_minibatch, minibatch_loss / cnt, minibatch_segments, minibatch_accuracy / cnt,
+                             minibatch_objective / cnt, total_disk_waiting / cnt, total_gpu_waiting / cnt))
+                start_minibatch = end_minibatch + 1
+                minibatch_segments = 0
+                minibatch_loss = 0
+                minibatch_accuracy = 0
+                minibatch_objective = 0
+                total_gpu_waiting = 0.0
+                total_disk_waiting = 0.0
+        logger.info("Processed %d segments of average size %d into %d minibatches. Avg minibatch size was %d." %
+                    (total_segments, total_segments_len / minibatch_count, minibatch_count, total_segments / minibatch_count))
+        logger.info("Overall average training loss is %.4f over %d segments. Also, the overall "
+                    "average training accuracy is %.4f." % (total_loss / minibatch_count, total_segments,
+                                                            total_accuracy / minibatch_count))
+        logger.info("Overall average objective function is %.4f over %d segments." %
+                    (total_objective / minibatch_count, total_segments))
+        w, adam = tr.export()
+        self.save_model(dict(weights=w, topology=self.meta["topology"], model_class=self.meta["model_class"],
+                             num_classes=self.meta["num_classes"], feat_dim=self.meta["feat_dim"]), args.output_dir, logger)
+        wio.save_optimizer_state(args.output_dir, adam)
+        logger.info("Elapsed time for processing whole training minibatches is %.2f minutes." %
+                    ((time.time() - start_time) / 60.0))
 
     def eval(self, data_loader, input_dir, use_gpu, logger):
-        raise NotImplementedError("diagnostics (models.py:307-354) are outside the extraction hot path of this build")
+        """Twin of models.py:307-354: loss / accuracy over ``data_loader`` in the eval phase (moving BN statistics)."""
+        tr = self._trainer(input_dir, logger)
+        minibatch_count = data_loader.count
+        total_segments = 0
+        total_loss = 0
+        total_accuracy = 0
+        total_segments_len = 0
+        start_time = time.time()
+        for minibatch_idx in range(minibatch_count):
+            batch_data, labels = self._pop(data_loader, minibatch_idx, logger, 'minibatch index')
+            if batch_data is None:
+                continue
+            total_segments += batch_data.shape[0]
+            total_segments_len += batch_data.shape[1]
+            loss, accuracy = tr.eval_batch(batch_data, labels)
+            total_loss += loss
+            total_accuracy += accuracy
+        logger.info("Processed %d segments of average size %d into %d minibatches. Avg minibatch size was %d." %
+                    (total_segments, total_segments_len / minibatch_count, minibatch_count, total_segments / minibatch_count))
+        logger.info("Overall average loss is %.4f over %d segments. Also, the overall "
+                    "average accuracy is %.4f." % (total_loss / minibatch_count, total_segments, total_accuracy / minibatch_count))
+        logger.info("Elapsed time for processing whole training minibatches is %.2f minutes." %
+                    ((time.time() - start_time) / 60.0))
 
     # -- the hot path ------------------------------------------------------------------------------
     def make_embedding(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger):

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libxvector_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -20,7 +20,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
-           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32")
+           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_f32")
 
 FMT_F32, FMT_SPLIT = 0, 1
 SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 136
@@ -101,6 +101,10 @@ def load():
     lib.xv_adam_f32.argtypes = [vp, vp, vp, vp, i64, cf, cf, cf, cf, vp]
     lib.xv_ema_f32.restype = ci
     lib.xv_ema_f32.argtypes = [vp, vp, ci, cf, vp]
+    lib.xv_axpy_f32.restype = ci
+    lib.xv_axpy_f32.argtypes = [vp, vp, cf, i64, vp]
+    lib.xv_sumsq_f32.restype = ci
+    lib.xv_sumsq_f32.argtypes = [vp, i64, vp, vp]
     if lib.xv_version() != ABI_VERSION:
         raise XvectorHipError("libxvector_hip.so ABI version %d != expected %d" % (lib.xv_version(), ABI_VERSION))
     _lib = lib
@@ -418,3 +422,15 @@ def adam(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
 def ema(moving, batch, decay):
     lib = require_gpu()
     _check(lib.xv_ema_f32(_ptr(moving), _ptr(batch), moving.numel(), float(decay), _stream()), "xv_ema_f32")
+
+
+def axpy(y, x, a):
+    lib = require_gpu()
+    assert y.numel() == x.numel() and y.is_contiguous() and x.is_contiguous()
+    _check(lib.xv_axpy_f32(_ptr(y), _ptr(x), float(a), y.numel(), _stream()), "xv_axpy_f32")
+
+
+def sumsq(x, out):
+    lib = require_gpu()
+    assert x.is_contiguous()
+    _check(lib.xv_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "xv_sumsq_f32")

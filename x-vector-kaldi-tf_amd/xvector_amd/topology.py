@@ -19,6 +19,7 @@ _BASE = dict(
     embedding_sizes=[512, 512],                 # models.py:29
     activation="relu",
     lrelu_alpha=0.2,                            # models.py:912
+    l2_beta=0.0,                                # training only: loss += l2_beta*(0.1*l2(embed-0) + l2(embed-1) + l2(output))
 )
 
 TOPOLOGIES = {
@@ -28,9 +29,9 @@ TOPOLOGIES = {
     "ModelWithoutDropoutTdnn":               dict(_BASE, kernel_sizes=[5, 3, 3, 1, 1],       # models.py:538-639
                                                   dilations=[1, 2, 3, 1, 1]),
     "ModelWithoutDropoutPRelu":              dict(_BASE, activation="prelu"),                # models.py:643-742
-    "ModelL2LossWithoutDropoutPRelu":        dict(_BASE, activation="prelu"),                # models.py:746-862
-    "ModelL2LossWithoutDropoutLRelu":        dict(_BASE, activation="lrelu"),                # models.py:866-981
-    "ModelL2LossWithoutDropoutReluHeInit":   dict(_BASE),                                    # models.py:1118-1244
+    "ModelL2LossWithoutDropoutPRelu":        dict(_BASE, activation="prelu", l2_beta=0.0002),   # models.py:746-862 (beta :756)
+    "ModelL2LossWithoutDropoutLRelu":        dict(_BASE, activation="lrelu", l2_beta=0.0002),   # models.py:866-981 (beta :876)
+    "ModelL2LossWithoutDropoutReluHeInit":   dict(_BASE, l2_beta=0.0002),                       # models.py:1118-1244 (beta :1128)
 }
 
 

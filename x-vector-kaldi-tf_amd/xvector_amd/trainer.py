@@ -54,6 +54,20 @@ class Trainer(object):
                   for n in self.trainable}
         self._packed = None
         self._layouts = {}
+        self.l2_beta = float(topo.get("l2_beta", 0.0))
+        self.l2_terms = (("embed_layer-0", 0.1), ("embed_layer-1", 1.0), ("output", 1.0))       # models.py:811-832
+
+    def _l2_value(self):
+        """beta * sum coef * tf.nn.l2_loss(t) over the penalised tensors (0 for classes without the L2 term)."""
+        if not self.l2_beta:
+            return 0.0
+        torch = self.torch
+        names = [sc + s for sc, _ in self.l2_terms for s in ("/w:0", "/b:0")]
+        out = torch.empty(len(names), dtype=torch.float32, device=self.device)
+        for i, n in enumerate(names):
+            hiplib.sumsq(self.P[n], out[i:i + 1])
+        v = out.cpu().numpy().astype(np.float64)
+        return float(self.l2_beta * sum(coef * 0.5 * (v[2 * i] + v[2 * i + 1]) for i, (_, coef) in enumerate(self.l2_terms)))
 
     # -- weights in kernel layout (re-packed after every optimizer step) -----------------------------------------
     def _w3(self, scope, k):
@@ -157,7 +171,7 @@ class Trainer(object):
     def eval_batch(self, x, labels):
         """(loss, accuracy) of one minibatch in the eval phase (moving BN statistics)."""
         la = self._forward(x, labels, train=False, want_grad=False)["loss_acc"].cpu().numpy()
-        return float(la[0]), float(la[1])
+        return float(la[0]) + self._l2_value(), float(la[1])
 
     # -- backward + Adam -------------------------------------------------------------------------------------------
     def _dense_backward(self, scope, x_in, dz, K, dil, grads, need_dx, valid):
@@ -213,8 +227,15 @@ class Trainer(object):
             dz = self._bn_backward(sc, dh, S["r"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads)
             dh = self._dense_backward(sc, S["h"][i], dz, self.topo["kernel_sizes"][i], self.topo["dilations"][i], grads, i > 0,
                                       L["rv"])
+        if self.l2_beta:
+            for sc, coef in self.l2_terms:
+                for suffix in ("/w:0", "/b:0"):
+                    g = grads[sc + suffix]
+                    if not g.is_contiguous():
+                        g = grads[sc + suffix] = g.contiguous()
+                    hiplib.axpy(g, self.P[sc + suffix], self.l2_beta * coef)
         la = S["loss_acc"].cpu().numpy()
-        return float(la[0]), float(la[1]), grads
+        return float(la[0]) + self._l2_value(), float(la[1]), grads
 
     def step(self, x, labels, learning_rate):
         """One optimizer step on a minibatch x[B,T,F] (float16/32), labels[B].  Returns (loss, accuracy)."""

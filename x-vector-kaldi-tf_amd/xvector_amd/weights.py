@@ -61,6 +61,37 @@ def save_model_dir(output_dir, weights, topo, class_name, num_classes, feat_dim)
         fid.write("done")
 
 
+OPTIMIZER = "model.optimizer.npz"
+
+
+def save_optimizer_state(output_dir, adam):
+    """Adam slots (the reference's Saver stores them as <var>/Adam, <var>/Adam_1, beta{1,2}_power in the same
+    checkpoint, models.py:134-137, so that the next iteration resumes them): {"t", "m": {name: arr}, "v": {...}}."""
+    arrays = {"t": np.array(int(adam["t"]), np.int64)}
+    for k, v in adam["m"].items():
+        arrays["m/" + k] = np.asarray(v, np.float32)
+    for k, v in adam["v"].items():
+        arrays["v/" + k] = np.asarray(v, np.float32)
+    tmp = os.path.join(output_dir, OPTIMIZER + ".tmp.npz")
+    np.savez(tmp, **arrays)
+    os.replace(tmp, os.path.join(output_dir, OPTIMIZER))
+
+
+def load_optimizer_state(input_dir):
+    """-> adam dict or None (fresh optimizer) when the directory has no optimizer state."""
+    p = os.path.join(input_dir, OPTIMIZER)
+    if not os.path.exists(p):
+        return None
+    adam = {"t": 0, "m": {}, "v": {}}
+    with np.load(p) as z:
+        for k in z.files:
+            if k == "t":
+                adam["t"] = int(z[k])
+            else:
+                adam[k[0]][k[2:]] = np.asarray(z[k], np.float32)
+    return adam
+
+
 def is_correct_model_dir(model_dir):
     """Same predicate as the reference's ``ze_utils.is_correct_model_dir`` (ze_utils.py:561-567)."""
     for name in (META, DONE):
