@@ -46,10 +46,71 @@ def parse():
     ap.add_argument("--batch-rows", type=int, default=131072)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--parity-utts", type=int, default=6)
+    ap.add_argument("--mode", choices=["extract", "train"], default="extract",
+                    help="extract = the headline benchmark (default); train = BASELINE configs[4]: training steps on synthetic "
+                         "64-chunk minibatches (SURVEY §8f-1), reported as chunks/s")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = split-precision bf16 MFMA with fp32 accumulate (fp32-class accuracy, "
                          "default); fp32 = exact fp32-input MFMA")
     return ap.parse_args()
+
+
+def bench_train(args, rank, world, dev, topo, feat):
+    """BASELINE configs[4]: minibatches of 64 chunks, one length T~U{200..400} per minibatch (create_egs.py:508-513), 64
+    synthetic speakers, softmax-CE head as in models.py:96-113, Adam; data parallel over ranks with one gradient
+    all-reduce per step.  A step = forward + backward + (all-reduce) + Adam on one resident minibatch per rank."""
+    import torch
+    import torch.distributed as dist
+    from xvector_amd import synthetic, topology as tp, trainer
+    B, n_spk = 64, 64
+    weights = synthetic.reference_init(topo, feat, n_spk, seed=1)
+    for k in list(weights):                                   # fan-in scaled start so that activations stay O(1)
+        if k.endswith("/w:0") and weights[k].ndim == 3:
+            weights[k] = (weights[k] * (np.sqrt(2.0 / (weights[k].shape[0] * weights[k].shape[1])) / 0.1)).astype(np.float32)
+    tr = trainer.Trainer(weights, topo, dev)
+    rng = np.random.default_rng(1234 + rank)
+    n_total = args.warmup + args.steps
+    spk = rng.standard_normal((n_spk, feat)) * 2
+    batches = []
+    for _ in range(n_total):
+        T = int(rng.integers(args.tmin, args.tmax + 1))
+        lab = rng.integers(0, n_spk, B)
+        batches.append(((spk[lab][:, None, :] + rng.standard_normal((B, T, feat)) * 3).astype(np.float16), lab.astype(np.int32)))
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for i in range(args.warmup):
+        tr.step(batches[i][0], batches[i][1], 1e-3)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_total):
+        losses.append(tr.step(batches[i][0], batches[i][1], 1e-3)[0])
+    fence()
+    dt = time.perf_counter() - t0
+    if dist.is_initialized():
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    frames = sum(b[0].shape[1] for b in batches[args.warmup:]) * B
+    flops = 3.0 * (tp.flops_per_frame(topo, feat) * frames + B * args.steps * (tp.flops_per_utt(topo, 1) + 2 * 512 * n_spk))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training chunks/sec (64-chunk minibatches, 200-400 frames, 64-way softmax-CE, Adam)",
+            "value": B * world * args.steps / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: training, B=64 chunks/minibatch/GPU, T~U{%d..%d}, 64 speakers, "
+                                   "ModelWithoutDropout topology, softmax-CE (AM-softmax is not in the reference)" % (args.tmin, args.tmax),
+                       "parallelism": "data parallel x%d, one bucketed gradient all-reduce per step" % world},
+            "steps_per_s": args.steps / dt, "frames_per_s": frames * world / dt,
+            "approx_tflops_fwd_bwd": flops * world / dt / 1e12, "first_loss": losses[0], "last_loss": losses[-1]}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main():
@@ -68,6 +129,8 @@ def main():
 
     topo = tp.get("ModelWithoutDropout")
     feat = 23
+    if args.mode == "train":
+        return bench_train(args, rank, world, dev, topo, feat)
     weights = synthetic.trained_like(topo, feat, seed=1)
     model = engine.DeviceModel(weights, topo, dev, precision=args.precision)
     gap = model.gap

@@ -237,9 +237,30 @@ class Trainer(object):
         la = S["loss_acc"].cpu().numpy()
         return float(la[0]) + self._l2_value(), float(la[1]), grads
 
+    def _allreduce(self, grads):
+        """Data parallelism (one process per GPU): ONE bucketed RCCL all-reduce of all gradients (24.5 MB fp32 for the
+        default topology), averaged over ranks -- the reference's own multi-job scheme never exchanges anything (its
+        model averaging is a stub, ze_utils.py:164-183), so this is build-defined.  BN statistics stay per replica."""
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return grads
+        torch = self.torch
+        world = dist.get_world_size()
+        flat = torch.cat([grads[n].reshape(-1) for n in self.trainable])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if world > 1:
+            hiplib.axpy(flat, flat, 1.0 / world - 1.0)              # flat /= world
+        out, o = {}, 0
+        for n in self.trainable:
+            k = grads[n].numel()
+            out[n] = flat[o:o + k].view(grads[n].shape)
+            o += k
+        return out
+
     def step(self, x, labels, learning_rate):
         """One optimizer step on a minibatch x[B,T,F] (float16/32), labels[B].  Returns (loss, accuracy)."""
         loss, acc, grads = self.gradients(x, labels)
+        grads = self._allreduce(grads)
         self.t += 1
         lr_t = learning_rate * math.sqrt(1.0 - ADAM_B2 ** self.t) / (1.0 - ADAM_B1 ** self.t)
         for n in self.trainable:
