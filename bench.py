@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--mode", choices=["extract", "train"], default="extract",
                     help="extract = the headline benchmark (default); train = BASELINE configs[4]: training steps on synthetic "
                          "64-chunk minibatches (SURVEY §8f-1), reported as chunks/s")
+    ap.add_argument("--train-precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="--mode train: arithmetic of the forward / input-gradient GEMMs")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = split-precision bf16 MFMA with fp32 accumulate (fp32-class accuracy, "
                          "default); fp32 = exact fp32-input MFMA")
@@ -67,7 +69,7 @@ def bench_train(args, rank, world, dev, topo, feat):
     for k in list(weights):                                   # fan-in scaled start so that activations stay O(1)
         if k.endswith("/w:0") and weights[k].ndim == 3:
             weights[k] = (weights[k] * (np.sqrt(2.0 / (weights[k].shape[0] * weights[k].shape[1])) / 0.1)).astype(np.float32)
-    tr = trainer.Trainer(weights, topo, dev)
+    tr = trainer.Trainer(weights, topo, dev, precision=args.train_precision)
     rng = np.random.default_rng(1234 + rank)
     n_total = args.warmup + args.steps
     spk = rng.standard_normal((n_spk, feat)) * 2
@@ -103,7 +105,8 @@ def bench_train(args, rank, world, dev, topo, feat):
             "metric": "training chunks/sec (64-chunk minibatches, 200-400 frames, 64-way softmax-CE, Adam)",
             "value": B * world * args.steps / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.train_precision == "fp32" else "f32 (fwd/dgrad GEMMs as bf16x3 split MFMA, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: training, B=64 chunks/minibatch/GPU, T~U{%d..%d}, 64 speakers, "
                                    "ModelWithoutDropout topology, softmax-CE (AM-softmax is not in the reference)" % (args.tmin, args.tmax),
                        "parallelism": "data parallel x%d, one bucketed gradient all-reduce per step" % world},

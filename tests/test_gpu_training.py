@@ -188,3 +188,17 @@ def test_model_train_one_iteration_and_eval_api(env, tmp_path, caplog):
     assert len(losses) == 2 and losses[1] < losses[0]          # 12 Adam steps on separable synthetic speakers reduce the loss
     # the trained directory still extracts
     assert wio.load_model_dir(d2)[1]["model_class"] == "ModelWithoutDropout"
+
+
+def test_bf16x3_training_gradients(env):
+    """Forward / dgrad GEMMs on the split-precision kernel: gradients stay within 1e-3 relative L2 of fp64 autograd."""
+    topo, w, rng = _setup(env, "ModelWithoutDropout", seed=5)
+    B, T = 8, 203
+    x = (rng.standard_normal((B, T, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, B)
+    tr = env["trainer"].Trainer(w, topo, precision="bf16x3")
+    loss, acc, grads = tr.gradients(x, lab)
+    rl, ra, _, _, rg = env["ref"].train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3)
+    assert abs(loss - rl) < 1e-4 * max(1.0, abs(rl))
+    bad = {n: _rel(grads[n].cpu().numpy(), rg[n]) for n in rg}
+    assert max(bad.values()) < 1e-3, bad

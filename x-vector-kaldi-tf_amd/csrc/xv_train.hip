@@ -75,31 +75,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     const bool vec = !(p.cin & 3) && !(p.ldx & 3) && !(p.cout & 3) && !(p.lddz & 3);
-    for (long r0 = r_begin; r0 < r_end; r0 += WR) {
-        // stage 32 rows x 128 channels of x (shifted by the tap) and of dz
+    f32x4 va[4], vb[4];
+    // 32 rows x 128 channels of x (shifted by the tap) and of dz -> registers (prefetched one step ahead)
+    auto load = [&](long r0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int f = tid + 256 * j;
             const int rr = f >> 5, q = f & 31;           // row, float4 index
             const long ra = r0 + rr + shift, rb = r0 + rr;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             const int ca = c0 + q * 4, cb = o0 + q * 4;
             if (rb < r_end) {
                 if (vec) {
-                    if (ra >= 0 && ra < p.R && ca < p.cin) va = *reinterpret_cast<const f32x4 *>(p.x + (size_t)ra * p.ldx + ca);
-                    if (cb < p.cout) vb = *reinterpret_cast<const f32x4 *>(p.dz + (size_t)rb * p.lddz + cb);
+                    if (ra >= 0 && ra < p.R && ca < p.cin) a = *reinterpret_cast<const f32x4 *>(p.x + (size_t)ra * p.ldx + ca);
+                    if (cb < p.cout) b = *reinterpret_cast<const f32x4 *>(p.dz + (size_t)rb * p.lddz + cb);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if (ra >= 0 && ra < p.R && ca + i < p.cin) va[i] = p.x[(size_t)ra * p.ldx + ca + i];
-                        if (cb + i < p.cout) vb[i] = p.dz[(size_t)rb * p.lddz + cb + i];
+                        if (ra >= 0 && ra < p.R && ca + i < p.cin) a[i] = p.x[(size_t)ra * p.ldx + ca + i];
+                        if (cb + i < p.cout) b[i] = p.dz[(size_t)rb * p.lddz + cb + i];
                     }
                 }
             }
-            *reinterpret_cast<f32x4 *>(As + rr * WLD + q * 4) = va;
-            *reinterpret_cast<f32x4 *>(Bs + rr * WLD + q * 4) = vb;
+            va[j] = a;
+            vb[j] = b;
+        }
+    };
+    load(r_begin);
+    for (long r0 = r_begin; r0 < r_end; r0 += WR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j;
+            *reinterpret_cast<f32x4 *>(As + (f >> 5) * WLD + (f & 31) * 4) = va[j];
+            *reinterpret_cast<f32x4 *>(Bs + (f >> 5) * WLD + (f & 31) * 4) = vb[j];
         }
         __syncthreads();
+        if (r0 + WR < r_end) load(r0 + WR);              // in flight under the 64 MFMAs below
         const float *ap = As + (lane >> 5) * WLD + wi * 64 + (lane & 31);
         const float *bp = Bs + (lane >> 5) * WLD + wj * 64 + (lane & 31);
 #pragma unroll
@@ -142,27 +153,53 @@ __global__ void sum_splits_kernel(const float *__restrict__ part, size_t n, int 
 // ------------------------------------------------------------------------------------------------
 // column sums with fp64 accumulation: out_a[c] = sum_r a[r,c], out_ab[c] = sum_r a[r,c]*b[r,c]
 // ------------------------------------------------------------------------------------------------
+constexpr long CS_ROWS = 128;      // rows per split: R = 19.6k frames -> ~150 splits x C/256 blocks
+
+// block = 4 waves; a wave covers 256 channels (float4 per lane) of one row per load; waves take interleaved rows
 __global__ __launch_bounds__(256) void col_sums_kernel(const float *__restrict__ a, const float *__restrict__ b, long R, int C,
                                                        int lda, int ldb, long rows_per_split, double *__restrict__ part)
 {
-    __shared__ double sa[4][64], sb[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    __shared__ double sa[4][256], sb[4][256];
+    const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
     const long r0 = (long)blockIdx.y * rows_per_split, r1 = min(R, r0 + rows_per_split);
-    double s = 0.0, sab = 0.0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, sab[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool vec = c + 4 <= C && !(lda & 3) && !(ldb & 3);
     if (c < C)
         for (long r = r0 + ty; r < r1; r += 4) {
-            const float av = a[(size_t)r * lda + c];
-            s += av;
-            if (b) sab += (double)av * (double)b[(size_t)r * ldb + c];
+            float av[4], bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(a + (size_t)r * lda + c);
+                av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3];
+                if (b) {
+                    const f32x4 u = *reinterpret_cast<const f32x4 *>(b + (size_t)r * ldb + c);
+                    bv[0] = u[0]; bv[1] = u[1]; bv[2] = u[2]; bv[3] = u[3];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    av[i] = c + i < C ? a[(size_t)r * lda + c + i] : 0.f;
+                    if (b) bv[i] = c + i < C ? b[(size_t)r * ldb + c + i] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[i] += av[i];
+                sab[i] += (double)av[i] * (double)bv[i];
+            }
         }
-    sa[ty][tx] = s;
-    sb[ty][tx] = sab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sa[ty][lane * 4 + i] = s[i];
+        sb[ty][lane * 4 + i] = sab[i];
+    }
     __syncthreads();
-    if (ty == 0 && c < C) {
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < C) {
         double *o = part + (size_t)blockIdx.y * 2 * C;
-        o[c] = sa[0][tx] + sa[1][tx] + sa[2][tx] + sa[3][tx];
-        o[C + c] = sb[0][tx] + sb[1][tx] + sb[2][tx] + sb[3][tx];
+        const int t = threadIdx.x;
+        o[cc] = sa[0][t] + sa[1][t] + sa[2][t] + sa[3][t];
+        o[C + cc] = sb[0][t] + sb[1][t] + sb[2][t] + sb[3][t];
     }
 }
 
@@ -391,15 +428,15 @@ int xv_wgrad_f32(const float *x, int ldx, const float *dz, int lddz, int64_t R, 
     return rc;
 }
 
-size_t xv_col_sums_workspace_bytes(int64_t R, int c) { return (size_t)((R + 2047) / 2048) * 2 * (size_t)c * sizeof(double); }
+size_t xv_col_sums_workspace_bytes(int64_t R, int c) { return (size_t)((R + CS_ROWS - 1) / CS_ROWS) * 2 * (size_t)c * sizeof(double); }
 
 int xv_col_sums_f32(const float *a, int lda, const float *b, int ldb, int64_t R, int c, float *sum_a, float *sum_ab, void *workspace,
                     void *stream)
 {
     if (!a || !sum_a || !workspace || R <= 0 || c <= 0 || (b && !sum_ab)) return tfail(XV_ERR_BAD_ARG, "col_sums: bad argument");
-    const int splits = (int)((R + 2047) / 2048);
+    const int splits = (int)((R + CS_ROWS - 1) / CS_ROWS);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(col_sums_kernel, dim3((c + 63) / 64, splits), dim3(256), 0, st, a, b, (long)R, c, lda, ldb, 2048L,
+    hipLaunchKernelGGL(col_sums_kernel, dim3((c + 255) / 256, splits), dim3(256), 0, st, a, b, (long)R, c, lda, ldb, CS_ROWS,
                        (double *)workspace);
     int rc = tcheck("col_sums_kernel");
     if (rc) return rc;

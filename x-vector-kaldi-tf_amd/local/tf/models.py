@@ -127,7 +127,8 @@ class Model(object):
         w, meta = wio.load_model_dir(input_dir)
         self.meta = meta
         self.num_classes = meta["num_classes"]
-        tr = trainer.Trainer(w, meta["topology"], _device(), wio.load_optimizer_state(input_dir))
+        tr = trainer.Trainer(w, meta["topology"], _device(), wio.load_optimizer_state(input_dir),
+                             precision=os.environ.get("XVECTOR_TRAIN_PRECISION", "fp32"))
         if logger is not None:
             logger.info("Graph restored from path: %s" % input_dir)
         return tr

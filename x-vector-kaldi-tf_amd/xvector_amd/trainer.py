@@ -24,9 +24,14 @@ BN_DECAY = 0.95                                        # batch_norm_wrapper(h, d
 
 
 class Trainer(object):
-    def __init__(self, weights, topo, device="cuda:0", adam=None):
+    def __init__(self, weights, topo, device="cuda:0", adam=None, precision="fp32"):
+        """precision: arithmetic of the forward and input-gradient GEMMs -- "fp32" (exact fp32 MFMA) or "bf16x3" (split
+        bf16 MFMA with fp32 accumulate, fp32 rows in/out; ~1e-5 relative on every activation/gradient).  Weight
+        gradients, reductions, BN, loss and Adam are fp32/fp64-accumulated either way."""
         import torch
         hiplib.require_gpu()
+        assert precision in ("fp32", "bf16x3")
+        self.precision = precision
         self.torch = torch
         self.device = torch.device(device)
         self.topo = topo
@@ -86,10 +91,14 @@ class Trainer(object):
         for sc in self.frame_scopes + self.embed_scopes + ["output"]:
             w = self._w3(sc, None)                                           # [K, Cin, Cout]
             K, cin, cout = w.shape
-            pk[sc] = hiplib.pack_weights(w.reshape(K * cin, cout))
             # dgrad: dx[r,c] = sum_{k,o} dz[r - (k-(K-1)/2)d, o] w[k,c,o]  == the forward kernel on w'[k',o,c] = w[K-1-k',c,o]
             wt = w.flip(0).permute(0, 2, 1).contiguous()                     # [K, Cout, Cin]
-            pk[sc + "/T"] = hiplib.pack_weights(wt.reshape(K * cout, cin))
+            if self.precision == "bf16x3" and cin % 4 == 0 and cout % 4 == 0:
+                pk[sc] = hiplib.pack_weights_bf16x3(w)
+                pk[sc + "/T"] = hiplib.pack_weights_bf16x3(wt)
+            else:
+                pk[sc] = hiplib.pack_weights(w.reshape(K * cin, cout))
+                pk[sc + "/T"] = hiplib.pack_weights(wt.reshape(K * cout, cin))
         self._packed = pk
         return pk
 
