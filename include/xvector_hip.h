@@ -109,6 +109,21 @@ int xv_tdnn_layer_bf16x3(const void *x, int x_format, int64_t R, int cin, int ld
                          const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation,
                          int cout, const uint8_t *row_valid, void *y, int y_format, int ldy, float *y_preact, int ldpre,
                          void *stream);
+/* Last frame-level layer fused with the first half of statistics pooling (models.py:66-76 / 482-486 in one pass):
+ * the same GEMM as xv_tdnn_layer_bf16x3, but instead of storing y[R, Cout] the epilogue reduces every block of 8
+ * consecutive rows (global rows 8i..8i+7, valid rows only) to per-channel (mean, M2 = sum (v-mean)^2) and writes
+ *     block_stats[ceil(R/8)][2][Cout]  fp32   (xv_block_stats_bytes(R, Cout) bytes, 16-byte aligned)
+ * -- a quarter of the bytes of y, and y is never re-read.  Every chunk must START ON A ROW THAT IS A MULTIPLE OF 8 (gap
+ * rows pad up to it), so that a block never mixes two chunks and the result does not depend on batch composition.
+ * xv_stats_pool_blocks_f32 merges the blocks of each chunk in order (fp64) into out[B, 2*Cout] = [mean | sqrt(var+eps)],
+ * the same quantity as xv_stats_pool_f32; a chunk whose row_start is not a multiple of 8 yields NaN. */
+size_t xv_block_stats_bytes(int64_t R, int cout);
+int xv_tdnn_layer_pool_bf16x3(const void *x, int x_format, int64_t R, int cin, int ldx, const void *wt, const float *bias,
+                              const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K,
+                              int dilation, int cout, const uint8_t *row_valid, float *block_stats, void *stream);
+int xv_stats_pool_blocks_f32(const float *block_stats, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
+                             float eps, float *out, void *stream);
+
 /* xv_fc_f32 twin: fp32 rows in, fp32 rows out; wt = xv_pack_weights_bf16x3(w, 1, In, Out). */
 int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const void *wt, const float *bias, const float *bn_scale,
                  const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y, float *y_preact, void *stream);

@@ -231,6 +231,60 @@ def test_stats_pool_matches_oracle(env, C, lens, split):
         assert oracle.rel_l2(got[i, C:], ref[C:]) < TOL_POOL
 
 
+@pytest.mark.parametrize("fmt", ["f32", "split"])
+@pytest.mark.parametrize("cin,cout,K,dil,act,lens", [
+    (512, 1536, 1, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),      # layer 4 of the default topology
+    (64, 200, 3, 1, "prelu", [300, 25, 64]),                          # ragged Cout, K > 1
+    (40, 48, 5, 2, "lrelu", [1200, 33]),                               # long chunk: many blocks per chunk
+])
+def test_tdnn_layer_pool_blocks_match_oracle(env, fmt, cin, cout, K, dil, act, lens):
+    """xv_tdnn_layer_pool_bf16x3 + xv_stats_pool_blocks_f32 == statistics pooling of the layer output (fp64 oracle)."""
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(cin + cout + K + len(lens))
+    mats = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in lens]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = None
+    if act == "lrelu":
+        alpha = np.array([0.2], np.float32)
+    elif act == "prelu":
+        alpha = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    gap = max(1, (K - 1) * dil // 2)
+    layout = engine.BatchLayout(lens, gap, hiplib.POOL_BLOCK_ROWS)
+    assert (layout.row_start % 8 == 0).all()
+    host = np.zeros((layout.rows, cin), np.float32)
+    layout.pack(mats, host)
+    x = torch.from_numpy(host).to(dev)
+    rv = torch.from_numpy(layout.row_valid()).to(dev)
+    wp = hiplib.pack_weights_bf16x3(torch.from_numpy(w).to(dev))
+    scale, shift = hiplib.fold_bn(*(torch.from_numpy(a).to(dev) for a in bn), 1e-3)
+    al = None if alpha is None else torch.from_numpy(alpha).to(dev)
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+    xin = x
+    if fmt == "split":
+        xin = hiplib.SplitBuf(layout.rows, cin, dev)
+        hiplib.split_encode(x, xin)
+    blk = torch.full((hiplib.block_stats_floats(layout.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
+    hiplib.tdnn_layer_pool(xin, layout.rows, wp, torch.from_numpy(b).to(dev), scale, shift, code, al, dil, rv, blk)
+    out = torch.full((len(lens), 2 * cout), float("nan"), dtype=torch.float32, device=dev)
+    rs, rl = torch.from_numpy(layout.row_start).to(dev), torch.from_numpy(layout.row_len).to(dev)
+    hiplib.stats_pool_blocks(blk, cout, rs, rl, len(lens), 1e-5, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    for i, m in enumerate(mats):
+        ref = oracle.stats_pool(oracle.tdnn_layer(m, w, b, bn, act, alpha, dil, np.float64), 1e-5, np.float64)
+        assert oracle.rel_l2(got[i, :cout], ref[:cout]) < TOL_GEMM3, (i, lens[i])
+        assert oracle.rel_l2(got[i, cout:], ref[cout:]) < TOL_GEMM3, (i, lens[i])
+    # a chunk that does not start on a block boundary is refused loudly (NaN), its neighbours are unaffected
+    rs_bad = layout.row_start.copy()
+    rs_bad[1] += 1
+    hiplib.stats_pool_blocks(blk, cout, torch.from_numpy(rs_bad).to(dev), rl, len(lens), 1e-5, out)
+    bad = out.cpu().numpy()
+    assert np.isnan(bad[1]).all() and np.array_equal(bad[0], got[0]) and np.array_equal(bad[2:], got[2:])
+
+
 def test_stats_pool_constant_channel_is_exact(env):
     """A dead-ReLU channel is constant over time: mean exact, std == sqrt(eps) exactly."""
     torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]

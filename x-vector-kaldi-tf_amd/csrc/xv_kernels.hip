@@ -303,7 +303,7 @@ constexpr int A3_BYTES = A_ROWS * SROW;           // 17408
 constexpr int B3_PLANE = BN * 64;                 // 8192
 constexpr int B3_BYTES = 2 * B3_PLANE;            // 16384: [hi tile][lo tile]
 constexpr int T_LD = BN + 4;                      // epilogue fp32 tile row (floats)
-constexpr size_t GEMM3_LDS_BYTES = (size_t)2 * A3_BYTES + 2 * B3_BYTES + BM;
+constexpr size_t GEMM3_LDS_BYTES = (size_t)2 * A3_BYTES + 2 * B3_BYTES + BM + 4 * BN * sizeof(float);   // + row mask + epilogue params
 static_assert((size_t)BM * T_LD * 4 <= (size_t)2 * A3_BYTES + 2 * B3_BYTES, "epilogue tile must fit below the row mask");
 
 struct Gemm3Params {
@@ -321,6 +321,7 @@ struct Gemm3Params {
     int y_split, ldy, ychunks;
     float *ypre;          // fp32 rows, stride ldpre (optional)
     int ldpre;
+    float *blk;           // POOL epilogue: per-8-row-block (mean, M2) planes [ceil(R/8)][2][cout]
     int n_mt, n_nt, n_chunks;
 };
 
@@ -330,13 +331,16 @@ struct Gemm3Params {
 
 // PW: A-halo DMA pieces (8 rows = 1 KB each) every wave issues per stage on the split-input path; the (<=17)-piece
 // halo tile of the NEXT slab is spread evenly over the stages of the current slab (K=1: 4, K=3: 3, K=5: 2, K=7: 1).
-template <bool SPLIT_A, int PW>
+// POOL: the layer output is not stored; the epilogue reduces every 8-row block of the tile to per-channel (mean, M2)
+// for the statistics pooling that follows the last frame-level layer (see stats_pool_blocks_kernel).
+template <bool SPLIT_A, int PW, bool POOL>
 __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *Abuf = lds;                                  // [2][A_ROWS][128 B]
     char *Bbuf = lds + 2 * A3_BYTES;                   // [2][hi 8 KB | lo 8 KB]
     uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + 2 * A3_BYTES + 2 * B3_BYTES);
+    float *Ps = reinterpret_cast<float *>(lds + 2 * A3_BYTES + 2 * B3_BYTES + BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -365,6 +369,18 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     if (tid < BM) {
         const long gr = m0 + tid;
         Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
+    }
+    // epilogue parameters of the tile's 128 columns, staged now so that their latency hides behind the main loop:
+    // [bias | BN scale | BN shift | alpha], alpha such that act(z) = max(z,0) + alpha*min(z,0) for none (1), relu (0), prelu.
+    // Columns beyond Cout (ragged last tile) get scale = shift = 0 so they come out as exact zeros.
+    if (tid >= BM && tid < BM + BN) {
+        const int c = tid - BM, gc = n0 + c;
+        const bool ok = gc < p.cout;
+        Ps[c] = (ok && p.bias) ? p.bias[gc] : 0.f;
+        Ps[BN + c] = ok ? (p.scale ? p.scale[gc] : 1.f) : 0.f;
+        Ps[2 * BN + c] = (ok && p.shift) ? p.shift[gc] : 0.f;
+        Ps[3 * BN + c] = p.act == XV_ACT_NONE ? 1.f : p.act == XV_ACT_LRELU ? p.alpha[0]
+                       : (p.act == XV_ACT_PRELU && ok) ? p.alpha[gc] : 0.f;
     }
 
     // ---- B: one 16 KB tile per stage, 4 x 1 KB DMA pieces per wave ---------------------------------------
@@ -605,18 +621,122 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     const int cg = tid & 15;                            // 8-channel group of the 128-column tile
     const int gc0 = n0 + cg * 8;
     float bias[8], sc[8], sh[8], al[8];
+    {
+        const f32x4 *P4 = reinterpret_cast<const f32x4 *>(Ps) + cg * 2;
+        const f32x4 q0 = P4[0], q1 = P4[1], q2 = P4[BN / 4], q3 = P4[BN / 4 + 1], q4 = P4[2 * BN / 4], q5 = P4[2 * BN / 4 + 1],
+                    q6 = P4[3 * BN / 4], q7 = P4[3 * BN / 4 + 1];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int gc = gc0 + i;
-        const bool ok = gc < p.cout;
-        bias[i] = (ok && p.bias) ? p.bias[gc] : 0.f;
-        // channels beyond Cout (ragged last tile) get scale = shift = 0 so they come out as exact zeros
-        sc[i] = ok ? (p.scale ? p.scale[gc] : 1.f) : 0.f;
-        sh[i] = (ok && p.shift) ? p.shift[gc] : 0.f;
-        al[i] = (p.act == XV_ACT_LRELU) ? p.alpha[0] : ((p.act == XV_ACT_PRELU && ok) ? p.alpha[gc] : 0.f);
+        for (int i = 0; i < 4; ++i) {
+            bias[i] = q0[i]; bias[4 + i] = q1[i];
+            sc[i] = q2[i]; sc[4 + i] = q3[i];
+            sh[i] = q4[i]; sh[4 + i] = q5[i];
+            al[i] = q6[i]; al[4 + i] = q7[i];
+        }
     }
     const bool full = gc0 + 8 <= p.cout;
-    const int act = p.act;
+    const bool lrelu = p.act == XV_ACT_LRELU;           // tf.nn.leaky_relu is max(alpha*z, z) for ANY alpha
+    auto activate = [&](float z, float a) { return lrelu ? fmaxf(a * z, z) : fmaxf(z, 0.f) + a * fminf(z, 0.f); };
+    if constexpr (POOL) {
+        // thread = (8-row block tid>>4 of the tile, 8 channels): statistics of the block's valid rows, shifted by the
+        // block's first row so that s2 - s1^2/n does not cancel.  Blocks are aligned to global row multiples of 8;
+        // callers start every chunk on such a row, so a block never mixes two chunks and its statistics do not depend
+        // on where the chunk sits in the batch.
+        const int blk = tid >> 4;
+        if (m0 + blk * 8 >= p.R) return;
+        float v0[8], s1[8], s2[8];
+        float n = 0.f;
+        f32x4 tv[8][2];
+        float keep[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lr = blk * 8 + j;
+            tv[j][0] = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8);
+            tv[j][1] = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8 + 4);
+            keep[j] = Ms[lr] ? 1.f : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto rows = [&](auto LRELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                n += keep[j];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
+                    const float a = decltype(LRELU)::value ? fmaxf(al[i] * z, z) : fmaxf(z, 0.f) + al[i] * fminf(z, 0.f);
+                    const float v = a * sc[i] + sh[i];
+                    if (j == 0) { v0[i] = v; s1[i] = 0.f; s2[i] = 0.f; }
+                    else {
+                        const float d = (v - v0[i]) * keep[j];
+                        s1[i] += d;
+                        s2[i] += d * d;
+                    }
+                }
+            }
+        };
+        if (lrelu) rows(std::true_type{});
+        else rows(std::false_type{});
+        // row 0 of a block is valid whenever any row is (chunks start on block boundaries, gaps follow the frames)
+        const float rn = n > 0.f ? 1.f / n : 0.f;
+        float mean[8], m2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            mean[i] = n > 0.f ? v0[i] + s1[i] * rn : 0.f;
+            m2[i] = fmaxf(s2[i] - s1[i] * s1[i] * rn, 0.f);
+        }
+        float *o = p.blk + ((size_t)((m0 >> 3) + blk) * 2) * p.cout + gc0;
+        if (full && !(p.cout & 3)) {
+            *reinterpret_cast<f32x4 *>(o) = (f32x4){mean[0], mean[1], mean[2], mean[3]};
+            *reinterpret_cast<f32x4 *>(o + 4) = (f32x4){mean[4], mean[5], mean[6], mean[7]};
+            *reinterpret_cast<f32x4 *>(o + p.cout) = (f32x4){m2[0], m2[1], m2[2], m2[3]};
+            *reinterpret_cast<f32x4 *>(o + p.cout + 4) = (f32x4){m2[4], m2[5], m2[6], m2[7]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (gc0 + i < p.cout) { o[i] = mean[i]; o[p.cout + i] = m2[i]; }
+        }
+        return;
+    }
+    if (p.y && p.y_split && !p.ypre && n0 + BN <= p.cout) {
+        // fast path (hidden layers): full-width tile into the split format, straight-line.  Rows >= R of the last tile
+        // land in the buffer's zero padding (XV_SPLIT_PAD_AFTER >= BM) and are written as zeros (keep == 0).
+        const int ch = gc0 >> 5, slot = cg & 3;
+        char *ybase = reinterpret_cast<char *>(p.y) + (size_t)ch * SROW;
+        const size_t yrow = (size_t)p.ychunks * SROW;
+        // all 16 LDS reads first: the LDS pipe is kept busy by the co-resident workgroup's main loop, so a round trip costs
+        // ~1 us under load -- pay it once, not once per row
+        f32x4 tv[8][2];
+        float keep[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lr = (tid >> 4) + 16 * j;
+            tv[j][0] = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8);
+            tv[j][1] = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8 + 4);
+            keep[j] = Ms[lr] ? 1.f : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto rows = [&](auto LRELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long gr = m0 + (tid >> 4) + 16 * j;
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
+                    const float a = decltype(LRELU)::value ? fmaxf(al[i] * z, z) : fmaxf(z, 0.f) + al[i] * fminf(z, 0.f);
+                    const float v = (a * sc[i] + sh[i]) * keep[j];
+                    hi[i] = (__bf16)v;
+                    lo[i] = (__bf16)(v - (float)hi[i]);
+                }
+                const int sw = (int)(gr >> 1) & 7;
+                char *row = ybase + (size_t)gr * yrow;
+                __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8 *>(row + ((slot ^ sw) << 4)));
+                __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8 *>(row + (((4 + slot) ^ sw) << 4)));
+            }
+        };
+        if (lrelu) rows(std::true_type{});
+        else rows(std::false_type{});
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int lr = (tid >> 4) + 16 * j;
@@ -629,11 +749,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             z[i] = (i < 4 ? t0[i] : t1[i - 4]) + bias[i];
-            float a;
-            if (act == XV_ACT_RELU) a = fmaxf(z[i], 0.f);
-            else if (act == XV_ACT_NONE) a = z[i];
-            else a = apply_act(z[i], act, al[i]);
-            v[i] = (a * sc[i] + sh[i]) * keep;
+            v[i] = (activate(z[i], al[i]) * sc[i] + sh[i]) * keep;
         }
         if (p.ypre) {
             float *o = p.ypre + (size_t)gr * p.ldpre + gc0;
@@ -707,19 +823,32 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
     p.n_nt = (p.cout + BN - 1) / BN;
     typedef void (*kern_t)(const Gemm3Params);
     kern_t kern;
-    if (!p.x_split) kern = tdnn_gemm_bf16x3_kernel<false, 0>;
-    else if (p.K == 1) kern = tdnn_gemm_bf16x3_kernel<true, 4>;
-    else {
-        const int n_pieces = (BM + (p.K - 1) * p.dil + 7) / 8;
-        const int pw = (n_pieces + 4 * (p.K - 1) - 1) / (4 * (p.K - 1));
-        kern = pw <= 1 ? tdnn_gemm_bf16x3_kernel<true, 1> : pw == 2 ? tdnn_gemm_bf16x3_kernel<true, 2>
-             : pw == 3 ? tdnn_gemm_bf16x3_kernel<true, 3> : tdnn_gemm_bf16x3_kernel<true, 4>;
-        if (pw > 4) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: halo tile too large for the DMA schedule");
+    int pw = 0;
+    if (p.x_split) {
+        pw = 4;
+        if (p.K > 1) {
+            const int n_pieces = (BM + (p.K - 1) * p.dil + 7) / 8;
+            pw = (n_pieces + 4 * (p.K - 1) - 1) / (4 * (p.K - 1));
+            if (pw > 4) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: halo tile too large for the DMA schedule");
+            if (pw < 1) pw = 1;
+        }
+    }
+    if (p.blk) {
+        kern = pw == 0 ? tdnn_gemm_bf16x3_kernel<false, 0, true> : pw == 1 ? tdnn_gemm_bf16x3_kernel<true, 1, true>
+             : pw == 2 ? tdnn_gemm_bf16x3_kernel<true, 2, true> : pw == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, true>
+             : tdnn_gemm_bf16x3_kernel<true, 4, true>;
+    } else {
+        kern = pw == 0 ? tdnn_gemm_bf16x3_kernel<false, 0, false> : pw == 1 ? tdnn_gemm_bf16x3_kernel<true, 1, false>
+             : pw == 2 ? tdnn_gemm_bf16x3_kernel<true, 2, false> : pw == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, false>
+             : tdnn_gemm_bf16x3_kernel<true, 4, false>;
     }
     static bool attr_done = false;
     if (!attr_done) {
-        const kern_t all[] = {tdnn_gemm_bf16x3_kernel<false, 0>, tdnn_gemm_bf16x3_kernel<true, 1>, tdnn_gemm_bf16x3_kernel<true, 2>,
-                              tdnn_gemm_bf16x3_kernel<true, 3>, tdnn_gemm_bf16x3_kernel<true, 4>};
+        const kern_t all[] = {tdnn_gemm_bf16x3_kernel<false, 0, false>, tdnn_gemm_bf16x3_kernel<true, 1, false>,
+                              tdnn_gemm_bf16x3_kernel<true, 2, false>, tdnn_gemm_bf16x3_kernel<true, 3, false>,
+                              tdnn_gemm_bf16x3_kernel<true, 4, false>, tdnn_gemm_bf16x3_kernel<false, 0, true>,
+                              tdnn_gemm_bf16x3_kernel<true, 1, true>, tdnn_gemm_bf16x3_kernel<true, 2, true>,
+                              tdnn_gemm_bf16x3_kernel<true, 3, true>, tdnn_gemm_bf16x3_kernel<true, 4, true>};
         for (kern_t k : all) {
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
@@ -911,6 +1040,40 @@ __global__ void stats_pool_merge_kernel(const float *__restrict__ partial, int C
     out[(size_t)b * 2 * C + C + c] = raw ? m2 / n : sqrtf(m2 / n + eps);
 }
 
+// finalize for the POOL epilogue of the bf16x3 GEMM: chunk b = the 8-row blocks row_start[b]/8 ... in order (all full but
+// the last); per channel  mean = sum n_i*mean_i / N,  var = sum(M2_i + n_i*mean_i^2)/N - mean^2  in fp64 (the inputs are
+// fp32, so the subtraction loses nothing that matters), out = [mean | sqrt(var + eps)].  A chunk that does not start on a
+// multiple of 8 rows was not reduced block-wise by the epilogue: its outputs are set to NaN.
+__global__ void stats_pool_blocks_kernel(const float *__restrict__ blk, int C, const int *__restrict__ row_start,
+                                         const int *__restrict__ row_len, float eps, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int rs = row_start[b], len = row_len[b];
+    float *o = out + (size_t)b * 2 * C;
+    if ((rs & 7) || len <= 0) {
+        o[c] = __builtin_nanf("");
+        o[C + c] = __builtin_nanf("");
+        return;
+    }
+    const float *pb = blk + (size_t)(rs >> 3) * 2 * C + c;
+    const int nb = (len + 7) >> 3;
+    double S = 0.0, Q = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < nb; ++i) {
+        const double m = (double)__builtin_nontemporal_load(pb + (size_t)i * 2 * C);
+        const double m2 = (double)__builtin_nontemporal_load(pb + (size_t)i * 2 * C + C);
+        const double n = (double)min(8, len - 8 * i);
+        S += n * m;
+        Q += m2 + n * m * m;
+    }
+    const double mean = S / (double)len;
+    const double var = fmax(Q / (double)len - mean * mean, 0.0);
+    o[c] = (float)mean;
+    o[C + c] = sqrtf((float)var + eps);
+}
+
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
@@ -1023,7 +1186,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 5; }
+int xv_version(void) { return 6; }
 
 const char *xv_last_error(void) { return g_err; }
 
@@ -1120,6 +1283,44 @@ int xv_tdnn_layer_bf16x3(const void *x, int x_format, int64_t R, int cin, int ld
     p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid;
     p.y = y; p.y_split = y_format == XV_FMT_SPLIT; p.ldy = ldy; p.ypre = y_preact; p.ldpre = ldpre;
     return launch_gemm3(p, (hipStream_t)stream);
+}
+
+size_t xv_block_stats_bytes(int64_t R, int cout)
+{
+    if (R <= 0 || cout <= 0) return 0;
+    return (size_t)((R + 7) / 8) * 2 * (size_t)cout * sizeof(float);
+}
+
+int xv_tdnn_layer_pool_bf16x3(const void *x, int x_format, int64_t R, int cin, int ldx, const void *wt, const float *bias,
+                              const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K,
+                              int dilation, int cout, const uint8_t *row_valid, float *block_stats, void *stream)
+{
+    if (!x || !wt || !block_stats) return fail(XV_ERR_BAD_ARG, "tdnn_pool_bf16x3: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_pool_bf16x3: unknown act_kind");
+    if (x_format != XV_FMT_F32 && x_format != XV_FMT_SPLIT) return fail(XV_ERR_BAD_ARG, "tdnn_pool_bf16x3: unknown tensor format");
+    if (((uintptr_t)block_stats) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_pool_bf16x3: block_stats must be 16-byte aligned");
+    Gemm3Params p{};
+    p.x = x; p.x_split = x_format == XV_FMT_SPLIT; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wt = (const uint8_t *)wt;
+    p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
+    p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid;
+    p.blk = block_stats;
+    return launch_gemm3(p, (hipStream_t)stream);
+}
+
+int xv_stats_pool_blocks_f32(const float *block_stats, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
+                             float eps, float *out, void *stream)
+{
+    if (nchunks <= 0) return 0;
+    if (!block_stats || !row_start || !row_len || !out || c <= 0) return fail(XV_ERR_BAD_ARG, "stats_pool_blocks: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int b0 = 0; b0 < nchunks; b0 += 65535) {
+        const int nb = min(65535, nchunks - b0);
+        hipLaunchKernelGGL(stats_pool_blocks_kernel, dim3((c + 255) / 256, nb), dim3(256), 0, st, block_stats, c, row_start + b0,
+                           row_len + b0, eps, out + (size_t)b0 * 2 * c);
+        int rc = check_launch("stats_pool_blocks_kernel");
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const void *wt, const float *bias, const float *bn_scale,

@@ -43,21 +43,32 @@ def plan_chunks(num_rows, min_chunk_size, chunk_size):
     return plan
 
 
-class BatchLayout(object):
-    """Row layout of one ragged batch: chunk b owns rows [row_start[b], row_start[b]+row_len[b]);
-    ``gap`` zero rows precede the first chunk and follow every chunk."""
+def slot_rows(lengths, gap, align=1):
+    """Rows a chunk occupies in a batch: its frames, >= ``gap`` zero rows, padded so the next chunk starts on a multiple
+    of ``align`` rows."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    return (lengths + gap + align - 1) // align * align
 
-    def __init__(self, lengths, gap):
+
+class BatchLayout(object):
+    """Row layout of one ragged batch: chunk b owns rows [row_start[b], row_start[b]+row_len[b]); at least ``gap`` zero
+    rows precede the first chunk and follow every chunk, and every chunk starts on a multiple of ``align`` rows
+    (``align=8`` for the fused pooling epilogue, include/xvector_hip.h)."""
+
+    def __init__(self, lengths, gap, align=1):
         lengths = np.asarray(lengths, dtype=np.int64)
         self.gap = int(gap)
+        self.align = int(align)
         self.row_len = lengths.astype(np.int32)
+        self.lead = (self.gap + self.align - 1) // self.align * self.align
+        self.slots = slot_rows(lengths, self.gap, self.align)
         starts = np.empty(len(lengths), dtype=np.int64)
         if len(lengths):
-            starts[0] = gap
-            np.cumsum(lengths[:-1] + gap, out=starts[1:])
-            starts[1:] += gap
+            starts[0] = self.lead
+            np.cumsum(self.slots[:-1], out=starts[1:])
+            starts[1:] += self.lead
         self.row_start = starts.astype(np.int32)
-        self.rows = int(gap + (lengths + gap).sum())
+        self.rows = int(self.lead + self.slots.sum())
         self.nchunks = len(lengths)
         self.max_len = int(lengths.max()) if len(lengths) else 0
         assert self.rows < 2 ** 31
@@ -67,8 +78,10 @@ class BatchLayout(object):
         n = self.nchunks
         vals = np.zeros(2 * n + 1, dtype=np.uint8)
         vals[1::2] = 1
-        reps = np.full(2 * n + 1, self.gap, dtype=np.int64)
+        reps = np.empty(2 * n + 1, dtype=np.int64)
+        reps[0] = self.lead
         reps[1::2] = self.row_len
+        reps[2::2] = self.slots - self.row_len
         m = np.repeat(vals, reps)
         if out is not None:
             out[:self.rows] = m
@@ -82,9 +95,13 @@ class BatchLayout(object):
             out[:self.rows] = 0
             return
         F = mats[0].shape[1]
-        z = np.zeros((self.gap, F), dtype=out.dtype)
-        parts = [z] * (2 * len(mats) + 1)
+        z = np.zeros((self.gap + self.align, F), dtype=out.dtype)
+        parts = [z[:self.lead]] * (2 * len(mats) + 1)
         parts[1::2] = mats
+        if self.align > 1:
+            parts[2::2] = [z[:g] for g in (self.slots - self.row_len).tolist()]
+        elif self.lead != self.gap:
+            raise AssertionError
         np.concatenate(parts, axis=0, out=out[:self.rows, :F])
 
 
@@ -97,13 +114,18 @@ class DeviceModel(object):
 
     POOL_SPLIT_ROWS = 512
 
-    def __init__(self, weights, topo, device="cuda:0", embedding_index=0, precision="bf16x3"):
+    def __init__(self, weights, topo, device="cuda:0", embedding_index=0, precision="bf16x3", fused_pool=None):
         """precision: "fp32" = exact fp32 MFMA GEMMs; "bf16x3" = split-precision bf16 MFMA GEMMs (fp32-class
-        accuracy, ~3e-6 rel-L2 on the x-vector; see include/xvector_hip.h)."""
+        accuracy, ~3e-6 rel-L2 on the x-vector; see include/xvector_hip.h).  fused_pool (default: on for bf16x3): the
+        last frame-level layer reduces its output to 8-row block statistics in the GEMM epilogue instead of storing it
+        (xv_tdnn_layer_pool_bf16x3); batches must then be laid out with ``align`` = 8."""
         import torch
         hiplib.require_gpu()
         assert precision in ("fp32", "bf16x3")
         self.precision = precision
+        self.fused_pool = (precision == "bf16x3") if fused_pool is None else bool(fused_pool)
+        assert not (self.fused_pool and precision != "bf16x3"), "fused pooling exists on the bf16x3 path only"
+        self.align = hiplib.POOL_BLOCK_ROWS if self.fused_pool else 1
         self.torch = torch
         self.device = torch.device(device)
         self.topo = topo
@@ -172,12 +194,16 @@ class DeviceModel(object):
             else:
                 self._ping = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
                 self._pong = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
-            self._last = torch.empty((self._cap_rows, self.layers[-1]["cout"]), dtype=torch.float32, device=self.device)
+            if self.fused_pool:
+                self._last = torch.empty(hiplib.block_stats_floats(self._cap_rows, self.layers[-1]["cout"]), dtype=torch.float32,
+                                         device=self.device)
+            else:
+                self._last = torch.empty((self._cap_rows, self.layers[-1]["cout"]), dtype=torch.float32, device=self.device)
         if nchunks > self._cap_chunks:
             self._cap_chunks = int(nchunks)
             self._pooled = torch.empty((self._cap_chunks, self.pooled_dim), dtype=torch.float32, device=self.device)
             self._pool_ws = None
-        if max_len is not None:
+        if max_len is not None and not self.fused_pool:
             need = hiplib.stats_pool_workspace_bytes(self.layers[-1]["cout"], self._cap_chunks, max_len, self.POOL_SPLIT_ROWS)
             if need and (self._pool_ws is None or self._pool_ws.numel() * 4 < need):
                 self._pool_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
@@ -202,14 +228,21 @@ class DeviceModel(object):
             events[0].record()
         for i, L in enumerate(self.layers):
             last = i == len(self.layers) - 1
+            if last and self.fused_pool:
+                hiplib.tdnn_layer_pool(h, R, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"],
+                                       row_valid, self._last)
+                break
             y = self._view(self._last if last else bufs[i & 1], R, L["cout"])
             hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
                               row_valid, y, rows=R)
             h = y
         if events is not None:
             events[1].record()
-        hiplib.stats_pool(h, row_start, row_len, nchunks, max_len, self.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON, pooled,
-                          self._pool_ws)
+        if self.fused_pool:
+            hiplib.stats_pool_blocks(self._last, self.layers[-1]["cout"], row_start, row_len, nchunks, tp.VAR2STD_EPSILON, pooled)
+        else:
+            hiplib.stats_pool(h, row_start, row_len, nchunks, max_len, self.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON, pooled,
+                              self._pool_ws)
         if events is not None:
             events[2].record()
         return pooled
@@ -311,13 +344,15 @@ class Extractor(object):
         results = [None] * len(mats)
         if nch == 0:
             return results
-        gap = model.gap
+        gap, align = model.gap, model.align
+        slots = slot_rows(c_len, gap, align).tolist()
+        lead = (gap + align - 1) // align * align
         # batch boundaries
         bounds, b0 = [], 0
         while b0 < nch:
-            rows, b1 = gap, b0
-            while b1 < nch and b1 - b0 < self.max_batch_chunks and (b1 == b0 or rows + c_len[b1] + gap <= self.max_batch_rows):
-                rows += c_len[b1] + gap
+            rows, b1 = lead, b0
+            while b1 < nch and b1 - b0 < self.max_batch_chunks and (b1 == b0 or rows + slots[b1] <= self.max_batch_rows):
+                rows += slots[b1]
                 b1 += 1
             bounds.append((b0, b1, rows))
             b0 = b1
@@ -329,7 +364,7 @@ class Extractor(object):
             model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), max(c_len))
             keep = []                                   # device inputs stay referenced until the window is done
             for bi, (b0, b1, _) in enumerate(bounds):
-                layout = BatchLayout(c_len[b0:b1], gap)
+                layout = BatchLayout(c_len[b0:b1], gap, align)
                 assert mats[c_utt[b0]].shape[1] == model.feat_dim, "feature dimension does not match the model"
                 st = stage[bi % self.NBUF]
                 if st["event"] is not None:

@@ -9,14 +9,15 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libxvector_hip.so")
-ABI_VERSION = 5
+SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
+ABI_VERSION = 6
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
            "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32",
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_split_row_bytes", "xv_split_encode_f32",
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
+           "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32",
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
@@ -75,6 +76,12 @@ def load():
     lib.xv_tdnn_layer_bf16x3.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp]
     lib.xv_fc_bf16x3.restype = ci
     lib.xv_fc_bf16x3.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
+    lib.xv_block_stats_bytes.restype = ctypes.c_size_t
+    lib.xv_block_stats_bytes.argtypes = [i64, ci]
+    lib.xv_tdnn_layer_pool_bf16x3.restype = ci
+    lib.xv_tdnn_layer_pool_bf16x3.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
+    lib.xv_stats_pool_blocks_f32.restype = ci
+    lib.xv_stats_pool_blocks_f32.argtypes = [vp, ci, vp, vp, ci, cf, vp, vp]
     lib.xv_chunk_average_f32.restype = ci
     lib.xv_chunk_average_f32.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     lib.xv_chunk_moments_f32.restype = ci
@@ -243,6 +250,43 @@ def tdnn_layer3(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y,
     _check(lib.xv_tdnn_layer_bf16x3(xp, FMT_SPLIT if xs else FMT_F32, int(R), w.cin, ldx, _ptr(w.wt), _ptr(bias), _ptr(scale),
                                     _ptr(shift), int(act), _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), yp,
                                     FMT_SPLIT if ys else FMT_F32, ldy, _ptr(y_preact), ldpre, _stream()), "xv_tdnn_layer_bf16x3")
+
+
+POOL_BLOCK_ROWS = 8      # chunks fed to tdnn_layer_pool must start on a multiple of this many rows
+
+
+def block_stats_floats(rows, cout):
+    return int(load().xv_block_stats_bytes(int(rows), int(cout))) // 4
+
+
+def tdnn_layer_pool(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, block_stats):
+    """Last frame-level layer with the block-statistics epilogue (bf16x3 only): block_stats = flat fp32 tensor of
+    >= block_stats_floats(R, w.cout) elements, laid out [ceil(R/8)][2][Cout]."""
+    lib = require_gpu()
+    assert isinstance(w, Packed3)
+    if isinstance(x, SplitBuf):
+        assert x.channels == w.cin and x.rows >= R
+        xp, ldx, fmt = ctypes.c_void_p(x.ptr), 0, FMT_SPLIT
+    else:
+        _f32(x, "x"); assert x.shape[1] == w.cin and x.shape[0] >= R
+        xp, ldx, fmt = _ptr(x), x.stride(0), FMT_F32
+    _f32(block_stats, "block_stats")
+    assert block_stats.numel() >= block_stats_floats(R, w.cout), "block_stats too small"
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_layer_pool_bf16x3(xp, fmt, int(R), w.cin, ldx, _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+                                         _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), _ptr(block_stats), _stream()),
+           "xv_tdnn_layer_pool_bf16x3")
+
+
+def stats_pool_blocks(block_stats, c, row_start, row_len, nchunks, eps, out):
+    import torch
+    lib = require_gpu()
+    _f32(block_stats, "block_stats"); _f32(out, "out")
+    assert row_start.dtype == torch.int32 and row_len.dtype == torch.int32 and row_start.is_cuda and row_len.is_cuda
+    assert out.shape[1] == 2 * c and out.shape[0] >= nchunks
+    _check(lib.xv_stats_pool_blocks_f32(_ptr(block_stats), int(c), _ptr(row_start), _ptr(row_len), int(nchunks), float(eps),
+                                        _ptr(out), _stream()), "xv_stats_pool_blocks_f32")
 
 
 def fold_bn(gamma, beta, mean, var, eps):
