@@ -198,6 +198,15 @@ int xv_adam_f32(float *param, const float *grad, float *m, float *v, int64_t n, 
  * (local/tf/models.py:811-842): gradient g += beta*coef*w, loss += beta*coef*sumsq/2. */
 int xv_axpy_f32(float *y, const float *x, float a, int64_t n, void *stream);
 int xv_sumsq_f32(const float *x, int64_t n, float *out, void *stream);
+/* tf.nn.dropout(x, keep_prob) in place on x[R, C] (models.py:70-72, 92-94): element (r, c) is kept (and scaled by
+ * 1/keep_prob) iff the top 32 bits of splitmix64(seed ^ 0x9E3779B97F4A7C15*(r*C + c + 1)) < keep_prob*2^32, else zeroed.
+ * Stateless: the same call on the gradient buffer is the backward pass.  keep_prob == 1 is a no-op. */
+int xv_dropout_f32(float *x, int ldx, int64_t R, int c, uint64_t seed, float keep_prob, void *stream);
+
+/* PReLU backward (tf_block.py:38-47): on entry dr = dL/d(activation output), z = pre-activation; on exit
+ * dr = dL/dz = dr * (z > 0 ? 1 : alpha[c]) and z = dr_in * min(z, 0), whose column sums (xv_col_sums_f32) are dL/dalpha. */
+int xv_prelu_backward_f32(float *dr, float *z, int ld, int64_t R, int c, const float *alpha, void *stream);
+
 /* moving = moving*decay + batch*(1-decay)   (local/tf/tf_block.py:20-21). */
 int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream);
 

@@ -45,9 +45,18 @@ def _act(z, topo, alpha):
     return F.relu(z) + alpha * torch.clamp(z, max=0.0)
 
 
-def forward(params, stats, topo, x, labels, train):
-    """x[B,T,F] float64 tensor, labels int64[B].  Returns (loss, accuracy, new_stats, embedding0)."""
+def forward(params, stats, topo, x, labels, train, dropout=None):
+    """x[B,T,F] float64 tensor, labels int64[B].  Returns (loss, accuracy, new_stats, embedding0).
+    dropout: None or {scope: (keep_mask tensor broadcastable to the layer output [B,T,C] / [B,C], keep_prob)} -- the
+    tf.nn.dropout sites of class Model (models.py:70-72, 92-94: after BN of every layer but the last of its group), with
+    the mask handed in (TF's random stream cannot be reproduced; the GPU build uses a counter-based mask)."""
     new_stats = {}
+
+    def drop(h, scope):
+        if not (train and dropout and scope in dropout):
+            return h
+        mask, keep = dropout[scope]
+        return h * mask / keep
 
     def bn(r, scope, axes):
         g, b = params[scope + "/gamma:0"], params[scope + "/beta:0"]
@@ -68,7 +77,7 @@ def forward(params, stats, topo, x, labels, train):
         z = F.conv1d(h, w, params[sc + "/b:0"], padding=(K - 1) * d // 2, dilation=d)
         alpha = params.get(sc + "/prelu/prelu:0")
         r = _act(z, topo, alpha.view(1, -1, 1) if alpha is not None else None)
-        h = bn(r.transpose(1, 2), sc, (0, 1)).transpose(1, 2)
+        h = drop(bn(r.transpose(1, 2), sc, (0, 1)), sc).transpose(1, 2)
     ht = h.transpose(1, 2)                                           # [B, T, C]
     mu = ht.mean(dim=1)
     var = ((ht - mu.unsqueeze(1)) ** 2).mean(dim=1)
@@ -80,7 +89,7 @@ def forward(params, stats, topo, x, labels, train):
         if j == 0:
             e0 = s
         alpha = params.get(sc + "/prelu/prelu:0")
-        h = bn(_act(s, topo, alpha), sc, (0,))
+        h = drop(bn(_act(s, topo, alpha), sc, (0,)), sc)
     logits = h @ params["output/w:0"] + params["output/b:0"]
     loss = F.cross_entropy(logits, labels, reduction="mean")
     beta = topo.get("l2_beta", 0.0)
@@ -111,13 +120,15 @@ def eval_batch(weights, topo, x, labels):
     return float(loss), float(acc), e0.numpy()
 
 
-def train_step(weights, adam, topo, x, labels, lr):
+def train_step(weights, adam, topo, x, labels, lr, dropout=None):
     """One optimizer step.  weights: {name: ndarray} (all variables incl. moving stats); adam: {"t": int, "m": {...},
     "v": {...}} (t = number of steps already taken).  Returns (loss, acc, new_weights, new_adam, grads)."""
     names = trainable_names(topo)
     p = to_torch(weights, names)
+    if dropout:
+        dropout = {k: (torch.tensor(np.asarray(m, np.float64)), float(keep)) for k, (m, keep) in dropout.items()}
     loss, acc, new_stats, _ = forward(p, p, topo, torch.tensor(np.asarray(x, np.float64)),
-                                      torch.tensor(np.asarray(labels, np.int64)), train=True)
+                                      torch.tensor(np.asarray(labels, np.int64)), train=True, dropout=dropout)
     grads = torch.autograd.grad(loss, [p[n] for n in names])
     t = adam["t"] + 1
     lr_t = lr * np.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)

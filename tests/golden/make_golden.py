@@ -12,6 +12,8 @@ Fixtures
                         hand-built 'CM ' record and an ascii record + what reference read_mat decodes
   make_embedding.npz    for (min_chunk, chunk) settings: utterance lengths, the chunk lengths each
                         key was run with, and the exact output ark bytes of the reference driver
+  schedules.npz         reference ze_utils.get_learning_rate / get_dropout_edit_string (ze_utils.py:111-120, 310-443)
+                        evaluated on grids of arguments (SURVEY §8c golden 4)
   forward_default.npz   fp64-oracle x-vectors (default + dilated topology, trained-like weights from
                         seed) for T in {25,200,400,1000}; sub-sampled per-layer tensors for T=25
 Usage:  python tests/golden/make_golden.py
@@ -191,8 +193,42 @@ def golden_forward(out):
     np.savez_compressed(out, seed=FWD_SEED, **res)
 
 
+def golden_schedules(out):
+    ref = sys.modules["ref_ze_utils"]
+    lr_args, lr_vals = [], []
+    for num_iters in (1, 7, 120):
+        for num_jobs in (1, 3, 8):
+            total = 4 * num_iters + 3
+            for it in sorted(set([0, 1, num_iters // 2, max(num_iters - 2, 0), num_iters - 1])):
+                for done in (0, it * 2, total - 1, total):
+                    for ini, fin in ((0.001, 0.0001), (3e-4, 3e-4), (1e-3, 2e-5)):
+                        lr_args.append((it, num_jobs, num_iters, done, total, ini, fin))
+                        lr_vals.append(ref.get_learning_rate(it, num_jobs, num_iters, done, total, ini, fin))
+    scheds = ["0,0@0.10,0.1@0.50,0", "0.0,0.3,0.0", "0.2,0.2", "0,0.5@0.25,0.5@0.25,0.1@0.8,0", "0.1,0@0.0,0.4@1.0,0.2"]
+    fracs = [0.0, 0.05, 0.1, 0.25, 0.3, 0.5, 0.75, 0.8, 0.999, 1.0]
+    table = np.array([[ref.get_dropout_edit_string(sc, f) for f in fracs] for sc in scheds], dtype=np.float64)
+    bad = ["0.1", "0,0.1@0.7,0.2@0.3,0", "0,0.2@1.5,0", "0,x@0.5,0"]
+    bad_raises = []
+    for b in bad:
+        try:
+            ref.get_dropout_edit_string(b, 0.5)
+            bad_raises.append(0)
+        except Exception:
+            bad_raises.append(1)
+    assert ref.get_dropout_edit_string(None, 0.3) is None
+    np.savez_compressed(out, lr_args=np.array(lr_args, np.float64), lr_vals=np.array(lr_vals, np.float64),
+                        schedules=np.array(scheds), fractions=np.array(fracs), dropout_table=table,
+                        bad_schedules=np.array(bad), bad_raises=np.array(bad_raises))
+    print("schedules: %d learning rates, %dx%d dropout table, bad strings raise: %s" %
+          (len(lr_vals), table.shape[0], table.shape[1], bad_raises))
+
+
 def main():
     ref_io, ref_models, Session = import_reference()
+    if sys.argv[1:] == ["schedules"]:            # leaves the other (byte-stable) fixtures untouched
+        golden_schedules(os.path.join(HERE, "schedules.npz"))
+        return
+    golden_schedules(os.path.join(HERE, "schedules.npz"))
     golden_ark_io(ref_io, os.path.join(HERE, "ark_io.npz"))
     golden_make_embedding(ref_io, ref_models, Session, os.path.join(HERE, "make_embedding.npz"))
     golden_forward(os.path.join(HERE, "forward_default.npz"))

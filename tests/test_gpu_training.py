@@ -41,7 +41,8 @@ def test_eval_batch_matches_oracle(env, cls):
     assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)) and acc == pytest.approx(ra)
 
 
-@pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelL2LossWithoutDropoutLRelu"])
+@pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelL2LossWithoutDropoutLRelu",
+                                 "ModelWithoutDropoutPRelu", "ModelL2LossWithoutDropoutPRelu"])
 def test_gradients_match_autograd(env, cls):
     topo, w, rng = _setup(env, cls, seed=3)
     B, T = 8, 211
@@ -59,6 +60,69 @@ def test_gradients_match_autograd(env, cls):
         for v in ("mean", "variance"):
             n = "%s/%s:0" % (sc, v)
             assert _rel(tr.P[n].cpu().numpy(), new_w[n]) < 1e-5, n
+
+
+def test_dropout_mask_kernel_matches_its_numpy_restatement(env):
+    """xv_dropout_f32: kept elements scaled by 1/keep, the rest zero, mask == hiplib.dropout_mask_reference bit for bit;
+    the kept fraction is keep_prob to sampling accuracy; keep_prob 1 is the identity; applying it twice == backward."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    R, C = 777, 96
+    x = torch.randn((R, C), device="cuda") + 3.0
+    for keep, seed in ((0.9, 12345), (0.5, 2 ** 63 + 17), (0.25, 7)):
+        y = x.clone()
+        hiplib.dropout(y, seed, keep)
+        mask = hiplib.dropout_mask_reference(seed, R, C, keep)
+        assert np.array_equal(y.cpu().numpy() != 0, mask)
+        np.testing.assert_allclose(y.cpu().numpy()[mask], (x.cpu().numpy() * np.float32(1.0 / np.float32(keep)))[mask], rtol=1e-6)
+        assert abs(mask.mean() - keep) < 4 * np.sqrt(keep * (1 - keep) / mask.size)
+    y = x.clone()
+    hiplib.dropout(y, 1, 1.0)
+    assert torch.equal(y, x)
+    # strided view (ld > C)
+    big = torch.randn((R, C + 32), device="cuda")
+    v = big[:, :C]
+    ref = v.clone()
+    hiplib.dropout(v, 99, 0.8)
+    m = hiplib.dropout_mask_reference(99, R, C, 0.8)
+    assert np.array_equal(v.cpu().numpy() != 0, m & (ref.cpu().numpy() != 0))
+
+
+def test_class_model_dropout_gradients(env):
+    """Class Model (models.py:20-128): dropout after BN of frame layers 0..3 and embed layer 0.  The oracle gets the SAME
+    masks (from the NumPy restatement of the kernel's counter-based generator) -> loss and every gradient agree."""
+    topo, w, rng = _setup(env, "Model", seed=11)
+    assert topo["dropout"]
+    B, T = 8, 120
+    x = (rng.standard_normal((B, T, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, B)
+    tr = env["trainer"].Trainer(w, topo)
+    keep, seed = 0.8, 4242
+    loss, acc, grads = tr.gradients(x, lab, dropout_proportion=1.0 - keep, seed=seed)
+    lay = tr._layout(B, T)["lay"]
+    masks = {}
+    for n, (kind, idx) in enumerate(tr._dropout_sites()):
+        s64 = tr.dropout_seed(seed, 0, n)
+        if kind == "frame":
+            C = topo["layer_sizes"][idx]
+            full = env["hiplib"].dropout_mask_reference(s64, lay.rows, C, keep)
+            m = np.stack([full[s:s + T] for s in lay.row_start])                       # [B, T, C]
+            masks["frame_level_info_layer-%d" % idx] = (m, keep)
+        else:
+            C = topo["embedding_sizes"][idx]
+            masks["embed_layer-%d" % idx] = (env["hiplib"].dropout_mask_reference(s64, B, C, keep), keep)
+    assert set(masks) == {"frame_level_info_layer-0", "frame_level_info_layer-1", "frame_level_info_layer-2",
+                          "frame_level_info_layer-3", "embed_layer-0"}
+    rl, ra, _, _, rg = env["ref"].train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3, dropout=masks)
+    assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)) and acc == pytest.approx(ra)
+    bad = {n: _rel(grads[n].cpu().numpy(), rg[n]) for n in rg if _rel(grads[n].cpu().numpy(), rg[n]) > 2e-4}
+    assert not bad, bad
+    # dropout changes the result (the masks are really applied), eval ignores it, the no-dropout classes ignore the argument
+    l0, _, _ = env["trainer"].Trainer(w, topo).gradients(x, lab)
+    assert abs(l0 - loss) > 1e-3
+    topo2, w2, _ = _setup(env, "ModelWithoutDropout", seed=11)
+    a = env["trainer"].Trainer(w2, topo2).gradients(x, lab, dropout_proportion=0.3, seed=1)[0]
+    b = env["trainer"].Trainer(w2, topo2).gradients(x, lab)[0]
+    assert a == b
 
 
 def test_three_adam_steps_follow_the_oracle(env):

@@ -128,3 +128,24 @@ def test_synthetic_generators_are_deterministic():
     w1 = synthetic.trained_like(synthetic.SMALL_TOPOLOGY, 5, seed=3)
     w2 = synthetic.trained_like(synthetic.SMALL_TOPOLOGY, 5, seed=3)
     assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+
+
+def test_schedules_match_reference_goldens():
+    """local/tf/ze_utils.py twin: learning-rate and dropout schedules == values recorded from the reference's own
+    functions (tests/golden/make_golden.py schedules)."""
+    import ze_utils
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "schedules.npz")) as g:
+        for a, v in zip(g["lr_args"], g["lr_vals"]):
+            got = ze_utils.get_learning_rate(int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), float(a[5]), float(a[6]))
+            assert got == v, (a, got, v)                      # same formula, same float64 op order -> identical
+        for sc, row in zip(g["schedules"], g["dropout_table"]):
+            for f, v in zip(g["fractions"], row):
+                assert ze_utils.get_dropout_edit_string(str(sc), float(f)) == v, (sc, f)
+        for sc, raises in zip(g["bad_schedules"], g["bad_raises"]):
+            assert raises == 1
+            with pytest.raises(Exception):
+                ze_utils.get_dropout_edit_string(str(sc), 0.5)
+    assert ze_utils.get_dropout_edit_string(None, 0.3) is None
+    # SURVEY §8c example: '0,0@0.10,0.1@0.50,0' -> 0.05 at f = 0.3 and 0.75
+    assert abs(ze_utils.get_dropout_edit_string("0,0@0.10,0.1@0.50,0", 0.3) - 0.05) < 1e-12
+    assert abs(ze_utils.get_dropout_edit_string("0,0@0.10,0.1@0.50,0", 0.75) - 0.05) < 1e-12

@@ -30,10 +30,12 @@ def traced(text):
 
 def _traced(text):
     t = text.replace("if (p.ypre) {", "if (false) {")
+    assert t.count("if (p.y && p.y_split && !p.ypre && n0 + BN <= p.cout) {") == 1
+    t = t.replace("if (p.y && p.y_split && !p.ypre && n0 + BN <= p.cout) {", "if (p.y && p.y_split && n0 + BN <= p.cout) {")
     a0 = "    if (tid < BM) {\n        const long gr = m0 + tid;\n        Ms[tid] ="
     assert t.count(a0) == 1
-    t = t.replace(a0, "    long long *trc = reinterpret_cast<long long *>(p.ypre) + (size_t)blockIdx.x * 8;\n"
-                      "    if (tid == 0) { trc[0] = wall_clock64(); trc[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); trc[5] = wg; trc[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }\n" + a0)
+    t = t.replace(a0, "    long long *trc = reinterpret_cast<long long *>(p.ypre) + (size_t)blockIdx.x * 8;  /*clk*/\n"
+                      "    if (tid == 0) { trc[0] = wall_clock64(); trc[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); trc[5] = (long long)wg | ((long long)(__builtin_readcyclecounter() & 0xffffffffffll) << 24); trc[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }\n" + a0)
     a1 = "    Frags F = {}, G = {};\n    load_frags(F, 0, 0, 0, 0);"
     assert t.count(a1) == 1
     t = t.replace(a1, "    if (tid == 0) trc[1] = wall_clock64();\n" + a1)
@@ -47,16 +49,15 @@ def _traced(text):
     b1 = "    const int cg = tid & 15;                            // 8-channel group of the 128-column tile"
     assert t.count(b1) == 1
     t = t.replace(b1, "    if (tid == 0) trc[7] = wall_clock64();\n" + b1)
-    b2 = "    const bool full = gc0 + 8 <= p.cout;"
-    assert t.count(b2) == 1
-    t = t.replace(b2, b2 + "\n    { float sink = 0.f; for (int i = 0; i < 8; ++i) sink += bias[i] + sc[i] + sh[i] + al[i]; if (sink == 1.2345f) trc[4] = 0; }\n    if (tid == 0) trc[4] = (trc[4] & 0xffffffff) | (wall_clock64() << 32);")
     f1 = "        else rows(std::false_type{});\n        return;"
     assert t.count(f1) == 1
     t = t.replace(f1, "        else rows(std::false_type{});\n        if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n"
-                      "        __builtin_amdgcn_s_waitcnt(0);\n        if (tid == 0) trc[3] = wall_clock64();\n        return;")
+                      "        __builtin_amdgcn_s_waitcnt(0);\n        if (tid == 0) { trc[3] = wall_clock64(); trc[4] = (trc[4] & 0xffffff) | ((long long)(__builtin_readcyclecounter() & 0xffffffffffll) << 24); }\n        return;")
     t = t.replace("    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();", "    if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();")
     return t
 variants["trace"] = traced(base)
+variants["trace_noAB"] = traced(variants["noAB"])
+variants["trace_hotAB"] = traced(variants["hotAB"])
 ST1 = "\n                __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8 *>(row + ((slot ^ sw) << 4)));"
 ST2 = "\n                __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8 *>(row + (((4 + slot) ^ sw) << 4)));"
 assert base.count(ST1) == 1 and base.count(ST2) == 1
@@ -71,6 +72,24 @@ variants["nowait_nobarrier"] = base.replace(W, "            ;")
 H = "        __builtin_amdgcn_sched_barrier(0);\n        auto rows = [&](auto LRELU) {"
 assert base.count(H) == 2
 variants["nohoist"] = base.replace(H, "        auto rows = [&](auto LRELU) {")
+RB = ["        F.bh0 = *reinterpret_cast<const bf16x8 *>(Bb + boff0 + ((t ^ bsw0) << 4));",
+      "        F.bh1 = *reinterpret_cast<const bf16x8 *>(Bb + boff1 + ((t ^ bsw1) << 4));",
+      "        F.bl0 = *reinterpret_cast<const bf16x8 *>(Bb + B3_PLANE + boff0 + ((t ^ bsw0) << 4));",
+      "        F.bl1 = *reinterpret_cast<const bf16x8 *>(Bb + B3_PLANE + boff1 + ((t ^ bsw1) << 4));"]
+RA = ["        F.al0 = *reinterpret_cast<const bf16x8 *>(a0 + (((t + 4) ^ sw0) << 4));",
+      "        F.al1 = *reinterpret_cast<const bf16x8 *>(a1 + (((t + 4) ^ sw1) << 4));",
+      "        F.ah0 = *reinterpret_cast<const bf16x8 *>(a0 + ((t ^ sw0) << 4));",
+      "        F.ah1 = *reinterpret_cast<const bf16x8 *>(a1 + ((t ^ sw1) << 4));"]
+t = base
+for l in RB:
+    assert t.count(l) == 1
+    t = t.replace(l, "        if (ks == 0) {" + l.strip() + " }")
+variants["halfBreads"] = t.replace("            load_frags(G, s, c0, t0, 1);\n            mma(F);", "            load_frags(G, s, c0, t0, 1); G.bh0 = F.bh0; G.bh1 = F.bh1; G.bl0 = F.bl0; G.bl1 = F.bl1;\n            mma(F);")
+t2 = t
+for l in RA:
+    assert t2.count(l) == 1
+    t2 = t2.replace(l, "        if (ks == 0) {" + l.strip() + " }")
+variants["halfABreads"] = t2.replace("            load_frags(G, s, c0, t0, 1);\n            mma(F);", "            G = F;\n            mma(F);")
 procs = []
 for name, text in variants.items():
     if len(sys.argv) > 1 and name not in sys.argv[1:]:

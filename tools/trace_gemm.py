@@ -25,7 +25,7 @@ for (cin, cout, K) in ((512, 512, 1), (512, 1536, 1), (512, 512, 7)):
     for name, v in (("prologue", P), ("mainloop", M), ("epilogue", E), ("total", us[:, 3] - us[:, 0])):
         print("   %-9s mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f us" % (name, v.mean(), *np.percentile(v, [10, 50, 90])))
     # CU identity: XCC_ID (reg 20) + HW_ID se/sh/cu
-    hw, xcc = t[:, 4] & 0xffffffff, t[:, 6] & 0xf
+    hw, xcc = t[:, 4] & 0xffffff, t[:, 6] & 0xf
     cu = (xcc << 16) | (hw & 0xff00) | ((hw >> 13) & 7) << 20
     cus = np.unique(cu)
     e_lds = (t[:, 7] - t0) / 100.0 - us[:, 2]
@@ -35,12 +35,17 @@ for (cin, cout, K) in ((512, 512, 1), (512, 1536, 1), (512, 512, 7)):
     e_drain = us[:, 3] - tl
     print("   epilogue split: acc->LDS+barrier %.2f | param loads %.2f | row loop %.2f | store drain %.2f us (means)" %
           (e_lds.mean(), e_par.mean(), e_loop.mean(), e_drain.mean()))
+    cyc = ((t[:, 4] >> 24) & 0xffffffffff) - ((t[:, 5] >> 24) & 0xffffffffff)
+    ok = cyc > 0
+    print("   raw:", [hex(int(v)) for v in t[5]], int(ok.sum()))
+    print("   shader clock while the WG ran: %.3f GHz (median of s_memtime delta / wall delta)" %
+          np.median(cyc[ok] / ((us[ok, 3] - us[ok, 0]) * 1e3)))
     print("   distinct CUs seen: %d" % len(cus))
     # timeline of one CU
     sel = np.where(cu == cus[len(cus) // 2])[0]
     sel = sel[np.argsort(us[sel, 0])]
     for i in sel[:10]:
-        print("     wg %5d  start %7.2f  P %5.2f  M %6.2f  E %5.2f  end %7.2f" % (t[i, 5], us[i, 0], P[i], M[i], E[i], us[i, 3]))
+        print("     wg %5d  start %7.2f  P %5.2f  M %6.2f  E %5.2f  end %7.2f" % (t[i, 5] & 0xffffff, us[i, 0], P[i], M[i], E[i], us[i, 3]))
     # busy fraction: union of mainloop intervals vs span, per CU
     gaps = []
     for c in cus[:64]:

@@ -249,6 +249,45 @@ __global__ void rows_affine_kernel(const float *__restrict__ x, long R, int C, i
     }
 }
 
+// tf.nn.dropout(h, keep_prob) (models.py:70-72,92-94) with a stateless mask: element (row, col) of call `seed` is kept iff
+// the top 32 bits of splitmix64(seed ^ golden*(row*C + col + 1)) are below keep_prob*2^32; kept elements are scaled by
+// 1/keep_prob.  The same call on the gradient is the backward pass -- no mask is stored.
+__device__ __forceinline__ uint32_t dropout_bits(uint64_t seed, uint64_t idx)
+{
+    uint64_t x = seed ^ ((idx + 1) * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 32);
+}
+
+__global__ void dropout_kernel(float *__restrict__ x, long R, int C, int ld, uint64_t seed, uint32_t threshold, float inv_keep)
+{
+    const size_t n = (size_t)R * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const long row = (long)(i / C);
+        const int c = (int)(i - (size_t)row * C);
+        const size_t o = (size_t)row * ld + c;
+        x[o] = dropout_bits(seed, i) < threshold ? x[o] * inv_keep : 0.f;
+    }
+}
+
+// PReLU backward (tf_block.py:38-47: max(0,z) + alpha[c]*min(0,z)): given dr = dL/d(act output) and the pre-activation z,
+//   dz = dr * (z > 0 ? 1 : alpha[c])   (written over dr),   t = dr * min(z, 0)   (written over z; its column sums are dalpha)
+__global__ void prelu_backward_kernel(float *__restrict__ dr, float *__restrict__ z, long R, int C, int ld,
+                                      const float *__restrict__ alpha)
+{
+    const size_t n = (size_t)R * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const long row = (long)(i / C);
+        const int c = (int)(i - (size_t)row * C);
+        const size_t o = (size_t)row * ld + c;
+        const float zv = z[o], g = dr[o];
+        dr[o] = zv > 0.f ? g : alpha[c] * g;
+        z[o] = g * fminf(zv, 0.f);
+    }
+}
+
 // BN backward through the activation, closed form.  With xhat = (r-mean)*rstd, N frames:
 //   dbeta = sum dh ; dgamma = sum dh*xhat = rstd*(sum dh*r - mean*sum dh)
 //   dr = gamma*rstd*(dh - dbeta/N - xhat*dgamma/N) = A*dh + B*r + Cc
@@ -530,6 +569,29 @@ int xv_sumsq_f32(const float *x, int64_t n, float *out, void *stream)
     if (!x || !out || n <= 0) return tfail(XV_ERR_BAD_ARG, "sumsq: bad argument");
     hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (size_t)n, out);
     return tcheck("sumsq_kernel");
+}
+
+int xv_dropout_f32(float *x, int ldx, int64_t R, int c, uint64_t seed, float keep_prob, void *stream)
+{
+    if (R <= 0 || c <= 0) return 0;
+    if (!x || ldx < c) return tfail(XV_ERR_BAD_ARG, "dropout: bad argument");
+    if (!(keep_prob > 0.f) || keep_prob > 1.f) return tfail(XV_ERR_BAD_ARG, "dropout: keep_prob must be in (0, 1]");
+    if (keep_prob == 1.f) return 0;
+    const double thr = (double)keep_prob * 4294967296.0;
+    const size_t n = (size_t)R * c;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long)R, c, ldx, seed, (uint32_t)std::min(thr, 4294967295.0), 1.f / keep_prob);
+    return tcheck("dropout_kernel");
+}
+
+int xv_prelu_backward_f32(float *dr, float *z, int ld, int64_t R, int c, const float *alpha, void *stream)
+{
+    if (R <= 0 || c <= 0) return 0;
+    if (!dr || !z || !alpha || ld < c) return tfail(XV_ERR_BAD_ARG, "prelu_backward: bad argument");
+    const size_t n = (size_t)R * c;
+    hipLaunchKernelGGL(prelu_backward_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0,
+                       (hipStream_t)stream, dr, z, (long)R, c, ld, alpha);
+    return tcheck("prelu_backward_kernel");
 }
 
 int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream)

@@ -153,9 +153,8 @@ class Model(object):
         ze_utils.py:126-127,498-499)."""
         learning_rate = args.learning_rate
         print_interval = args.print_interval
-        if float(getattr(args, "dropout_proportion", 0.0) or 0.0) != 0.0:
-            raise NotImplementedError("dropout (class Model, models.py:70-72) is not implemented in this build; "
-                                      "use a *WithoutDropout class or dropout_proportion 0")
+        dropout_proportion = float(getattr(args, "dropout_proportion", 0.0) or 0.0)     # keep_prob = 1 - this, models.py:258
+        random_seed = int(getattr(args, "random_seed", 0) or 0)                          # models.py:223,233
         tr = self._trainer(args.input_dir, logger)
         minibatch_count = data_loader.count
         start_minibatch = 1
@@ -177,7 +176,7 @@ class Model(object):
             total_segments += batch_data.shape[0]
             total_segments_len += batch_data.shape[1]
             gpu_waiting = time.time()
-            loss, accuracy = tr.step(batch_data, labels, learning_rate)
+            loss, accuracy = tr.step(batch_data, labels, learning_rate, dropout_proportion, random_seed)
             total_gpu_waiting += time.time() - gpu_waiting
             objective = -loss
             total_loss += loss

@@ -21,7 +21,8 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
-           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_f32")
+           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_f32", "xv_dropout_f32",
+           "xv_prelu_backward_f32")
 
 FMT_F32, FMT_SPLIT = 0, 1
 SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 136
@@ -112,6 +113,10 @@ def load():
     lib.xv_axpy_f32.argtypes = [vp, vp, cf, i64, vp]
     lib.xv_sumsq_f32.restype = ci
     lib.xv_sumsq_f32.argtypes = [vp, i64, vp, vp]
+    lib.xv_dropout_f32.restype = ci
+    lib.xv_dropout_f32.argtypes = [vp, ci, i64, ci, ctypes.c_uint64, cf, vp]
+    lib.xv_prelu_backward_f32.restype = ci
+    lib.xv_prelu_backward_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp]
     if lib.xv_version() != ABI_VERSION:
         raise XvectorHipError("libxvector_hip.so ABI version %d != expected %d" % (lib.xv_version(), ABI_VERSION))
     _lib = lib
@@ -478,3 +483,34 @@ def sumsq(x, out):
     lib = require_gpu()
     assert x.is_contiguous()
     _check(lib.xv_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "xv_sumsq_f32")
+
+
+def dropout(x, seed, keep_prob, rows=None):
+    """In-place tf.nn.dropout on x[R, C] with the stateless mask of include/xvector_hip.h (same call = backward)."""
+    import torch
+    lib = require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "x must be a row-major cuda float32 matrix"
+    R = x.shape[0] if rows is None else int(rows)
+    _check(lib.xv_dropout_f32(_ptr(x), x.stride(0), R, x.shape[1], int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob), _stream()),
+           "xv_dropout_f32")
+
+
+def dropout_mask_reference(seed, R, C, keep_prob):
+    """NumPy restatement of the kernel's mask (bool [R, C]); used by tests and to hand the oracle the same mask."""
+    import numpy as np
+    idx = np.arange(1, R * C + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF) ^ (idx * np.uint64(0x9E3779B97F4A7C15))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    thr = min(float(np.float32(keep_prob)) * 4294967296.0, 4294967295.0)
+    return ((x >> np.uint64(32)).astype(np.int64) < int(np.uint32(thr))).reshape(R, C)
+
+
+def prelu_backward(dr, z, alpha):
+    lib = require_gpu()
+    _f32(dr, "dr"); _f32(z, "z"); _f32(alpha, "alpha")
+    assert dr.shape == z.shape and dr.stride(0) == z.stride(0) and alpha.numel() == dr.shape[1]
+    _check(lib.xv_prelu_backward_f32(_ptr(dr), _ptr(z), dr.stride(0), dr.shape[0], dr.shape[1], _ptr(alpha), _stream()),
+           "xv_prelu_backward_f32")

@@ -20,11 +20,12 @@ _BASE = dict(
     activation="relu",
     lrelu_alpha=0.2,                            # models.py:912
     l2_beta=0.0,                                # training only: loss += l2_beta*(0.1*l2(embed-0) + l2(embed-1) + l2(output))
+    dropout=False,                              # training only: tf.nn.dropout sites after BN (class Model, models.py:70-72,92-94)
 )
 
 TOPOLOGIES = {
     # class name in the reference           : constants
-    "Model":                                 dict(_BASE),                                    # models.py:20-128
+    "Model":                                 dict(_BASE, dropout=True),                      # models.py:20-128
     "ModelWithoutDropout":                   dict(_BASE),                                    # models.py:436-534
     "ModelWithoutDropoutTdnn":               dict(_BASE, kernel_sizes=[5, 3, 3, 1, 1],       # models.py:538-639
                                                   dilations=[1, 2, 3, 1, 1]),

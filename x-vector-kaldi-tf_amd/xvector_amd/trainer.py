@@ -7,9 +7,10 @@ backward, Adam, batch-norm moving-average updates.  Every arithmetic step is a k
 kernel (dgrad = same kernel, taps flipped + Cin/Cout swapped), plus wgrad, reductions, BN/pooling backward, softmax-CE,
 Adam.  PyTorch holds the device buffers and does layout shuffles (flip/permute) only.
 
-Covers the model classes without dropout (``ModelWithoutDropout`` -- the one the recipe trains, run_xvector.sh:90 --
-its Tdnn and LRelu variants).  Class ``Model`` (dropout) trains only with ``dropout_proportion == 0``; PReLU and the
-L2-loss terms of the ``ModelL2Loss*`` classes are not implemented (they raise).
+Covers every model class of topology.py: ``ModelWithoutDropout`` (the one the recipe trains, run_xvector.sh:90), its
+Tdnn / PReLU / LRelu variants, the L2-loss terms of the ``ModelL2Loss*`` classes, and class ``Model``'s dropout
+(tf.nn.dropout after BN of every frame-level / embedding layer but the last of each group, models.py:70-72,92-94) with a
+stateless counter-based mask (xv_dropout_f32) instead of TF's random stream.
 """
 import math
 
@@ -36,8 +37,8 @@ class Trainer(object):
         self.device = torch.device(device)
         self.topo = topo
         self.act = tp.ACT_CODES[topo.get("activation", "relu")]
-        if self.act == tp.ACT_PRELU:
-            raise NotImplementedError("training with PReLU is not implemented in this build")
+        self.prelu = self.act == tp.ACT_PRELU
+        self.has_dropout = bool(topo.get("dropout", False))
         self.alpha = float(topo.get("lrelu_alpha", 0.2)) if self.act == tp.ACT_LRELU else 0.0
         self.alpha_t = torch.tensor([self.alpha], dtype=torch.float32, device=self.device) if self.act == tp.ACT_LRELU else None
         self.gap = tp.max_halo(topo)
@@ -50,6 +51,8 @@ class Trainer(object):
         self.trainable = []
         for sc in self.frame_scopes + self.embed_scopes:
             self.trainable += ["%s/%s:0" % (sc, n) for n in ("w", "b", "gamma", "beta")]
+            if self.prelu:
+                self.trainable.append(sc + "/prelu/prelu:0")
         self.trainable += ["output/w:0", "output/b:0"]
         self.t = int(adam["t"]) if adam else 0
         z = lambda n: torch.zeros_like(self.P[n])
@@ -61,6 +64,19 @@ class Trainer(object):
         self._layouts = {}
         self.l2_beta = float(topo.get("l2_beta", 0.0))
         self.l2_terms = (("embed_layer-0", 0.1), ("embed_layer-1", 1.0), ("output", 1.0))       # models.py:811-832
+
+    def _alpha(self, scope):
+        """act_alpha argument of the layer kernels: per-channel vector (PReLU), 1-element tensor (LReLU) or None."""
+        return self.P[scope + "/prelu/prelu:0"] if self.prelu else self.alpha_t
+
+    @staticmethod
+    def dropout_seed(seed, step, layer):
+        """64-bit mask seed of one dropout site: (random_seed, optimizer step, site index)."""
+        return ((int(seed) & 0xFFFFFFFF) << 32) ^ ((int(step) & 0xFFFFFF) << 8) ^ (int(layer) & 0xFF)
+
+    def _dropout_sites(self):
+        """[(kind, index)] of the tf.nn.dropout sites: after every frame-level / embedding layer but the last of its group."""
+        return [("frame", i) for i in range(len(self.frame_scopes) - 1)] + [("embed", j) for j in range(len(self.embed_scopes) - 1)]
 
     def _l2_value(self):
         """beta * sum coef * tf.nn.l2_loss(t) over the penalised tensors (0 for classes without the L2 term)."""
@@ -135,7 +151,7 @@ class Trainer(object):
         return h, mean, var
 
     # -- forward ---------------------------------------------------------------------------------------------------
-    def _forward(self, x, labels, train, want_grad):
+    def _forward(self, x, labels, train, want_grad, keep_prob=1.0, seed=0):
         torch = self.torch
         x = np.asarray(x)
         B, T, F = x.shape
@@ -147,26 +163,35 @@ class Trainer(object):
         view[:, :T, :F] = x.astype(np.float32)
         X = torch.from_numpy(host).to(self.device)
         pk = self._pack()
-        S = dict(L=L, B=B, T=T, R=lay.rows, X=X, r=[], h=[X], mean=[], var=[])
+        drop = train and self.has_dropout and keep_prob < 1.0
+        sites = self._dropout_sites()
+        S = dict(L=L, B=B, T=T, R=lay.rows, X=X, r=[], z=[], h=[X], mean=[], var=[], keep=float(keep_prob) if drop else 1.0,
+                 seeds={site: self.dropout_seed(seed, self.t, n) for n, site in enumerate(sites)})
         for i, sc in enumerate(self.frame_scopes):
             K, d = self.topo["kernel_sizes"][i], self.topo["dilations"][i]
             C = self.topo["layer_sizes"][i]
             r = torch.empty((lay.rows, C), dtype=torch.float32, device=self.device)
-            hiplib.tdnn_layer(S["h"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act, self.alpha_t, K, d, L["rv"], r)
+            z = torch.empty_like(r) if (self.prelu and want_grad) else None            # PReLU backward needs the pre-activation
+            hiplib.tdnn_layer(S["h"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act, self._alpha(sc), K, d, L["rv"], r, z)
             h, mean, var = self._bn_scopes_stats(r, sc, L, T, B, train, L["rv"], True)
-            S["r"].append(r); S["h"].append(h); S["mean"].append(mean); S["var"].append(var)
+            if drop and ("frame", i) in S["seeds"]:
+                hiplib.dropout(h, S["seeds"][("frame", i)], S["keep"])
+            S["r"].append(r); S["z"].append(z); S["h"].append(h); S["mean"].append(mean); S["var"].append(var)
         Cl = self.topo["layer_sizes"][-1]
         pooled = torch.empty((B, 2 * Cl), dtype=torch.float32, device=self.device)
         hiplib.stats_pool(S["h"][-1], L["rs"], L["rl"], B, T, 512, tp.VAR2STD_EPSILON, pooled,
                           hiplib._ws(hiplib.stats_pool_workspace_bytes(Cl, B, T, 512), self.device))
         S["pooled"] = pooled
-        S["e_in"], S["e_r"], S["e_mean"], S["e_var"] = [pooled], [], [], []
+        S["e_in"], S["e_r"], S["e_z"], S["e_mean"], S["e_var"] = [pooled], [], [], [], []
         for j, sc in enumerate(self.embed_scopes):
             C = self.topo["embedding_sizes"][j]
             r = torch.empty((B, C), dtype=torch.float32, device=self.device)
-            hiplib.fc(S["e_in"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act, self.alpha_t, r, None)
+            z = torch.empty_like(r) if (self.prelu and want_grad) else None
+            hiplib.fc(S["e_in"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act, self._alpha(sc), r, z)
             a, mean, var = self._bn_scopes_stats(r, sc, L, B, 1, train, None, False)
-            S["e_r"].append(r); S["e_in"].append(a); S["e_mean"].append(mean); S["e_var"].append(var)
+            if drop and ("embed", j) in S["seeds"]:
+                hiplib.dropout(a, S["seeds"][("embed", j)], S["keep"])
+            S["e_r"].append(r); S["e_z"].append(z); S["e_in"].append(a); S["e_mean"].append(mean); S["e_var"].append(var)
         logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)
         hiplib.fc(S["e_in"][-1], pk["output"], self.P["output/b:0"], None, None, tp.ACT_NONE, None, None, logits)
         lab = torch.from_numpy(np.asarray(labels, dtype=np.int32)).to(self.device)
@@ -204,7 +229,7 @@ class Trainer(object):
         hiplib.tdnn_layer(dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid, dx)
         return dx
 
-    def _bn_backward(self, scope, dh, r, mean, var, n_frames, valid, grads):
+    def _bn_backward(self, scope, dh, r, z, mean, var, n_frames, valid, grads):
         torch = self.torch
         C = r.shape[1]
         s1 = torch.empty(C, dtype=torch.float32, device=self.device)
@@ -212,28 +237,40 @@ class Trainer(object):
         hiplib.col_sums(dh, r, s1, s2)
         dgamma, dbeta = torch.empty_like(s1), torch.empty_like(s1)
         dz = torch.empty_like(r)
-        hiplib.bn_act_backward(dh, r, s1, s2, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames, self.act, self.alpha,
-                               valid, dgamma, dbeta, dz)
+        hiplib.bn_act_backward(dh, r, s1, s2, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames,
+                               tp.ACT_NONE if self.prelu else self.act, self.alpha, valid, dgamma, dbeta, dz)
+        if self.prelu:
+            # dz holds dL/d(act output); z the pre-activation: -> dz = dL/dz, z = dr*min(z,0) whose column sums are dalpha
+            hiplib.prelu_backward(dz, z, self.P[scope + "/prelu/prelu:0"])
+            dalpha = torch.empty_like(s1)
+            hiplib.col_sums(z, None, dalpha)
+            grads[scope + "/prelu/prelu:0"] = dalpha
         grads[scope + "/gamma:0"] = dgamma
         grads[scope + "/beta:0"] = dbeta
         return dz
 
-    def gradients(self, x, labels):
-        """Forward (train phase, updates the moving statistics) + backward.  Returns (loss, acc, {name: grad tensor})."""
+    def gradients(self, x, labels, dropout_proportion=0.0, seed=0):
+        """Forward (train phase, updates the moving statistics) + backward.  Returns (loss, acc, {name: grad tensor}).
+        dropout_proportion > 0 is honoured by the classes with dropout sites (topology "dropout": True) and ignored by
+        the others, as in the reference where only class Model wires the keep-prob placeholder into the graph."""
         torch = self.torch
-        S = self._forward(x, labels, train=True, want_grad=True)
+        S = self._forward(x, labels, train=True, want_grad=True, keep_prob=1.0 - float(dropout_proportion), seed=seed)
         L, B, T = S["L"], S["B"], S["T"]
         grads = {}
         d = self._dense_backward("output", S["e_in"][-1], S["dlogits"], 1, 1, grads, True, None)
         for j in reversed(range(len(self.embed_scopes))):
             sc = self.embed_scopes[j]
-            dz = self._bn_backward(sc, d, S["e_r"][j], S["e_mean"][j], S["e_var"][j], float(B), None, grads)
+            if S["keep"] < 1.0 and ("embed", j) in S["seeds"]:
+                hiplib.dropout(d, S["seeds"][("embed", j)], S["keep"])
+            dz = self._bn_backward(sc, d, S["e_r"][j], S["e_z"][j], S["e_mean"][j], S["e_var"][j], float(B), None, grads)
             d = self._dense_backward(sc, S["e_in"][j], dz, 1, 1, grads, True, None)
         dh = torch.empty_like(S["h"][-1])
         hiplib.pool_backward(S["h"][-1], L["rs"], L["rl"], B, S["pooled"], d, dh)
         for i in reversed(range(len(self.frame_scopes))):
             sc = self.frame_scopes[i]
-            dz = self._bn_backward(sc, dh, S["r"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads)
+            if S["keep"] < 1.0 and ("frame", i) in S["seeds"]:
+                hiplib.dropout(dh, S["seeds"][("frame", i)], S["keep"])
+            dz = self._bn_backward(sc, dh, S["r"][i], S["z"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads)
             dh = self._dense_backward(sc, S["h"][i], dz, self.topo["kernel_sizes"][i], self.topo["dilations"][i], grads, i > 0,
                                       L["rv"])
         if self.l2_beta:
@@ -266,9 +303,9 @@ class Trainer(object):
             o += k
         return out
 
-    def step(self, x, labels, learning_rate):
+    def step(self, x, labels, learning_rate, dropout_proportion=0.0, seed=0):
         """One optimizer step on a minibatch x[B,T,F] (float16/32), labels[B].  Returns (loss, accuracy)."""
-        loss, acc, grads = self.gradients(x, labels)
+        loss, acc, grads = self.gradients(x, labels, dropout_proportion, seed)
         grads = self._allreduce(grads)
         self.t += 1
         lr_t = learning_rate * math.sqrt(1.0 - ADAM_B2 ** self.t) / (1.0 - ADAM_B1 ** self.t)
