@@ -210,6 +210,19 @@ int xv_prelu_backward_f32(float *dr, float *z, int ld, int64_t R, int c, const f
 /* moving = moving*decay + batch*(1-decay)   (local/tf/tf_block.py:20-21). */
 int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream);
 
+/* ---- feature front-end -------------------------------------------------------------------------------
+ * Sliding-window cepstral mean normalisation + VAD frame selection, i.e. what
+ *   apply-cmvn-sliding --norm-vars=false --center=true --cmn-window=300 ... | select-voiced-frames ...
+ * (local/tf/extract_xvectors.sh:68) do in front of extract_embedding.py, as one scatter kernel.
+ *   x[sum T, F]  raw features of n_utts utterances back to back (utt_start[u], utt_len[u] in rows; max_len = max utt_len)
+ *   dst_row[t]   per INPUT row: row of y that receives the normalised frame, or -1 to drop it (unvoiced / not in a chunk)
+ *   y[., ldy]    destination (e.g. the packed batch buffer); only columns [0, F) of the addressed rows are written
+ * Window rule and arithmetic (double-precision window sums) follow Kaldi's SlidingWindowCmn; min_window only matters
+ * when center == 0 (Kaldi default 100). */
+int xv_cmn_sliding_scatter_f32(const float *x, int ldx, int feat_dim, const int32_t *utt_start, const int32_t *utt_len,
+                               int n_utts, int max_len, int cmn_window, int center, int min_window, const int32_t *dst_row,
+                               float *y, int ldy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -253,3 +253,55 @@ def embed_utterance(mat, weights, topo=None, min_chunk_size=25, chunk_size=10000
 def rel_l2(a, ref):
     a = np.asarray(a, np.float64); ref = np.asarray(ref, np.float64)
     return float(np.linalg.norm(a - ref) / max(np.linalg.norm(ref), 1e-300))
+
+
+# ------------------------------------------------------------------------------------------------
+# feature front-end: Kaldi's apply-cmvn-sliding / select-voiced-frames, which the reference calls as
+# external binaries (local/tf/extract_xvectors.sh:68).  Kaldi is not vendored in the reference (version unpinned), so this
+# restates the published algorithm of SlidingWindowCmn (kaldi/src/feat/feature-functions.cc): PARITY UNPINNED.
+# ------------------------------------------------------------------------------------------------
+def sliding_cmn(x, cmn_window=300, center=True, min_window=100):
+    """Frame by frame as Kaldi does it: the window bounds, a running float64 window sum that adds / drops one frame at a
+    time, out[t] = float32(float64(x[t]) - sum / frames).  norm_vars = false."""
+    x64 = np.asarray(x, dtype=np.float64)
+    T = x64.shape[0]
+    out = np.empty(x64.shape, dtype=np.float32)
+    last_start = last_end = -1
+    cur = np.zeros(x64.shape[1], dtype=np.float64)
+    for t in range(T):
+        if center:
+            ws = t - cmn_window // 2
+            we = ws + cmn_window
+        else:
+            ws = t - cmn_window
+            we = t + 1
+        if ws < 0:
+            we -= ws
+            ws = 0
+        if not center and we > t:
+            we = max(t + 1, min_window)
+        if we > T:
+            ws -= we - T
+            we = T
+            if ws < 0:
+                ws = 0
+        if last_start == -1:
+            cur = x64[ws:we].sum(axis=0)
+        else:
+            if ws > last_start:
+                assert ws == last_start + 1
+                cur = cur - x64[last_start]
+            if we > last_end:
+                assert we == last_end + 1
+                cur = cur + x64[last_end]
+        last_start, last_end = ws, we
+        out[t] = (x64[t] - cur / float(we - ws)).astype(np.float32)
+    return out
+
+
+def select_voiced(feats, vad):
+    """select-voiced-frames: rows whose VAD decision is non-zero; None when the lengths differ or nothing is voiced."""
+    vad = np.asarray(vad).reshape(-1)
+    if vad.shape[0] != feats.shape[0] or not np.any(vad != 0):
+        return None
+    return feats[vad != 0]

@@ -1,0 +1,132 @@
+"""Feature front-end on the GPU vs the NumPy restatement of Kaldi's SlidingWindowCmn / select-voiced-frames
+(oracle/oracle.py).  Both sides form the window mean in float64 and round the difference to float32 once; only the order
+of the float64 additions differs, so the results agree bit for bit except where that last-place difference flips the final
+rounding: asserted as <= 1 float32 ulp everywhere and identical on > 99.9 % of the elements."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from oracle import oracle
+    from xvector_amd import frontend, hiplib
+    hiplib.require_gpu()
+    return dict(torch=torch, oracle=oracle, frontend=frontend, hiplib=hiplib)
+
+
+def _close(got, ref):
+    assert got.shape == ref.shape and got.dtype == np.float32
+    ulp = np.spacing(np.maximum(np.abs(ref), np.float32(1e-3)).astype(np.float32))
+    assert np.all(np.abs(got.astype(np.float64) - ref.astype(np.float64)) <= ulp)
+    assert np.mean(got == ref) > 0.999
+
+
+@pytest.mark.parametrize("center,window,F", [(True, 300, 23), (False, 300, 23), (True, 61, 40), (False, 600, 5)])
+def test_cmn_select_matches_oracle(env, center, window, F):
+    oracle = env["oracle"]
+    rng = np.random.default_rng(window + F)
+    lens = [1, 2, 50, 299, 300, 301, 1000, 2500, 64, 65]
+    mats = [(rng.standard_normal((t, F)) * 4 + 10 * rng.standard_normal(F)).astype(np.float32) for t in lens]
+    vads = [(rng.random(t) < 0.7).astype(np.float32) for t in lens]
+    vads[0][:] = 1.0
+    vads[2] = None                                        # no VAD for this utterance: every frame is kept
+    fe = env["frontend"].FrontEnd("cuda:0", cmn_window=window, center=center, min_window=100)
+    outs = fe.apply(mats, vads)
+    for m, v, got in zip(mats, vads, outs):
+        ref = oracle.sliding_cmn(m, window, center, 100)
+        if v is not None:
+            ref = oracle.select_voiced(ref, v)
+        if ref is None:                                   # nothing voiced in a very short utterance: dropped by both
+            assert got is None
+            continue
+        _close(got, ref)
+    # no VAD at all
+    outs = fe.apply(mats[:4])
+    for m, got in zip(mats[:4], outs):
+        _close(got, oracle.sliding_cmn(m, window, center, 100))
+
+
+def test_frontend_drops_what_select_voiced_frames_drops(env):
+    rng = np.random.default_rng(0)
+    mats = [(rng.standard_normal((t, 23))).astype(np.float32) for t in (100, 100, 100, 0)]
+    vads = [np.ones(100, np.float32), np.zeros(100, np.float32), np.ones(99, np.float32), np.zeros(0, np.float32)]
+    fe = env["frontend"].FrontEnd("cuda:0")
+    outs = fe.apply(mats, vads)
+    assert outs[0].shape == (100, 23) and outs[1] is None and outs[2] is None and outs[3] is None
+    assert env["oracle"].select_voiced(mats[1], vads[1]) is None and env["oracle"].select_voiced(mats[2], vads[2]) is None
+    assert fe.stats["dropped"] == 3 and fe.stats["frames_out"] == 100
+
+
+def test_scatter_into_a_packed_batch(env):
+    """The kernel's dst_row indirection writes straight into a packed [R, in_dim] batch: untouched rows / columns keep their
+    contents (gap rows and the 24th padding column stay zero)."""
+    torch, hiplib, oracle = env["torch"], env["hiplib"], env["oracle"]
+    rng = np.random.default_rng(3)
+    T, F = 400, 23
+    m = (rng.standard_normal((T, F)) * 3).astype(np.float32)
+    x = torch.from_numpy(m).cuda()
+    y = torch.zeros((T + 16, 24), device="cuda")
+    dst = np.full(T, -1, np.int32)
+    dst[100:300] = np.arange(8, 208)                      # one 200-frame chunk placed at row 8
+    hiplib.cmn_sliding_scatter(x, torch.zeros(1, dtype=torch.int32, device="cuda"), torch.full((1,), T, dtype=torch.int32, device="cuda"),
+                               1, T, 300, True, 100, torch.from_numpy(dst).cuda(), y)
+    got = y.cpu().numpy()
+    ref = oracle.sliding_cmn(m)
+    _close(got[8:208, :F], ref[100:300])
+    assert not got[:8].any() and not got[208:].any() and not got[:, F:].any()
+
+
+def test_cli_raw_features_plus_vad_to_speaker_xvectors(env, tmp_path):
+    """extract_xvectors.sh without Kaldi binaries: raw features (scp) + VAD (ark) -> extract_embedding.py --cmn-window 300
+    --vad-rspecifier ... -> xvector.ark/scp -> speaker_mean.py; every x-vector against the oracle pipeline
+    sliding_cmn -> select_voiced -> embed_utterance (fp64), dropped utterances as select-voiced-frames / make_embedding
+    drop them."""
+    import sys, os
+    import kaldi_io
+    import models
+    import extract_embedding as ee
+    import speaker_mean
+    from xvector_amd import synthetic
+    oracle = env["oracle"]
+    topo = synthetic.SMALL_TOPOLOGY
+    w = synthetic.trained_like(topo, 5, num_classes=8, seed=11)
+    mdir = str(tmp_path / "nnet")
+    models.Model.save_model(dict(weights=w, topology=topo, model_class="Model", num_classes=8, feat_dim=5), mdir, None)
+    rng = np.random.default_rng(1)
+    lens = [400, 60, 250, 900, 120]
+    utts = [("spkA-u%d" % i if i < 3 else "spkB-u%d" % i, (rng.standard_normal((T, 5)) * 3 + 5).astype(np.float32))
+            for i, T in enumerate(lens)]
+    vads = {k: (rng.random(m.shape[0]) < 0.8).astype(np.float32) for k, m in utts}
+    vads[utts[1][0]][:] = 0                                       # nothing voiced -> dropped
+    vads[utts[4][0]] = (np.arange(120) < 20).astype(np.float32)   # 20 voiced frames < min_chunk_size 25 -> rejected later
+    feats_ark, feats_scp = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")
+    with kaldi_io.TableWriter(feats_ark, feats_scp) as tw:
+        for k, m in utts:
+            kaldi_io.write_mat(tw, m, key=k)
+    vad_ark = str(tmp_path / "vad.ark")
+    with open(vad_ark, "wb") as f:
+        for k, _ in utts:
+            kaldi_io.write_vec_flt(f, vads[k], key=k)
+    ark, scp = str(tmp_path / "xvector.ark"), str(tmp_path / "xvector.scp")
+    ee.main(["--min-chunk-size", "25", "--chunk-size", "300", "--feature-rspecifier", "scp:" + feats_scp,
+             "--vector-wspecifier", "ark,scp:%s,%s" % (ark, scp), "--model-dir", mdir, "--cmn-window", "300",
+             "--vad-rspecifier", "ark:" + vad_ark])
+    got = dict(kaldi_io.read_vec_flt_scp(scp))
+    assert list(got) == [utts[0][0], utts[2][0], utts[3][0]]
+    for k, m in utts:
+        sel = oracle.select_voiced(oracle.sliding_cmn(m), vads[k])
+        ref = None if sel is None else oracle.embed_utterance(sel, w, topo, 25, 300, np.float64)
+        assert (ref is None) == (k not in got), k
+        if ref is not None:
+            assert oracle.rel_l2(got[k], ref) < 5e-5, k
+    spk2utt = tmp_path / "spk2utt"
+    spk2utt.write_text("spkA %s %s %s\nspkB %s %s\nspkC ghost\n" % tuple(k for k, _ in utts))
+    sark, sscp, nutt = str(tmp_path / "spk.ark"), str(tmp_path / "spk.scp"), str(tmp_path / "num_utts.ark")
+    speaker_mean.main([str(spk2utt), scp, sark, sscp, nutt])
+    spk = dict(kaldi_io.read_vec_flt_scp(sscp))
+    assert list(spk) == ["spkA", "spkB"] and open(nutt).read() == "spkA 2\nspkB 1\n"
+    np.testing.assert_allclose(spk["spkA"], (got[utts[0][0]] + got[utts[2][0]]) / np.float32(2), rtol=1e-6)
+    assert np.array_equal(spk["spkB"], got[utts[3][0]])

@@ -156,3 +156,28 @@ def test_chunk_average_is_numpy_float32_semantics(oracle_mod):
         acc = acc + n * v
     acc = acc / tot
     assert np.array_equal(oracle_mod.chunk_average(e, lens, np.float32), acc.astype(np.float32))
+
+
+def test_sliding_cmn_restatement_properties(oracle_mod):
+    oracle = oracle_mod
+    """Kaldi SlidingWindowCmn semantics (SURVEY §8f-4; parity unpinned: Kaldi is not vendored): centred window of 300 frames
+    clipped-and-shifted at the edges, whole-utterance mean when T <= window, the non-centred min_window rule."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((1000, 5)) * 3 + 7).astype(np.float32)
+    y = oracle.sliding_cmn(x)
+    x64 = x.astype(np.float64)
+    for t, (ws, we) in {0: (0, 300), 149: (0, 300), 150: (0, 300), 151: (1, 301), 500: (350, 650), 849: (699, 999),
+                        850: (700, 1000), 999: (700, 1000)}.items():
+        assert np.array_equal(y[t], (x64[t] - x64[ws:we].mean(axis=0)).astype(np.float32)) or \
+            np.allclose(y[t], x64[t] - x64[ws:we].mean(axis=0), rtol=0, atol=1e-6), t
+    short = x[:120]
+    assert np.allclose(oracle.sliding_cmn(short), short - short.astype(np.float64).mean(axis=0), atol=1e-6)
+    yn = oracle.sliding_cmn(x, 300, False, 100)
+    assert np.allclose(yn[50], x64[50] - x64[:100].mean(axis=0), atol=1e-6)          # t < min_window: first min_window frames
+    assert np.allclose(yn[500], x64[500] - x64[200:501].mean(axis=0), atol=1e-6)     # causal window of cmn_window + 1 frames
+    const = np.tile(np.float32([1.5, -2.0]), (400, 1))
+    assert not oracle.sliding_cmn(const).any()
+    vad = np.zeros(1000); vad[10:20] = 1; vad[500] = 0.5
+    sel = oracle.select_voiced(x, vad)
+    assert sel.shape == (11, 5) and np.array_equal(sel[-1], x[500])
+    assert oracle.select_voiced(x, np.zeros(1000)) is None and oracle.select_voiced(x, np.ones(999)) is None

@@ -48,6 +48,14 @@ _FLAGS = (
     ("--vector-wspecifier", "vector_wspecifier", str, None, True, None,
      "Kaldi wspecifier for the x-vectors (ark, ark pipe, or ark,scp:A,S)."),
     ("--model-dir", "model_dir", str, None, True, None, "Model directory (model.meta + weights + done)."),
+    # build-defined extension (defaults = reference behaviour): the Kaldi front-end of extract_xvectors.sh:68 on the GPU
+    ("--cmn-window", "cmn_window", int, 0, False, None,
+     "If > 0: sliding-window cepstral mean normalisation of this many frames (apply-cmvn-sliding --norm-vars=false) is "
+     "applied on the GPU, so --feature-rspecifier can name raw features."),
+    ("--cmn-center", "cmn_center", str, "yes", False, ("yes", "no"), "Centre the CMN window on the frame (--center=true)."),
+    ("--vad-rspecifier", "vad_rspecifier", str, "", False, None,
+     "If set: table of per-frame VAD decisions (same key order as the features); frames with decision 0 are dropped "
+     "(select-voiced-frames) after the CMN."),
 )
 
 
@@ -97,6 +105,26 @@ def _open_output(wspecifier, ark, scp):
     return kaldi_io.open_or_fd(wspecifier, 'wb')
 
 
+class _Null(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def _open_table(rspecifier, scp_reader, ark_reader):
+    """(key, value) iterator for 'scp:FILE' (random-access table read sequentially) or, when ``ark_reader`` is given, for
+    any ark rspecifier open_or_fd understands; None when the caller should open the rspecifier as an ark stream itself."""
+    spec = rspecifier.strip()
+    head = spec.split(':', 1)[0].replace(' ', '')
+    if head.split(',')[0] == 'scp' and not spec.endswith('|'):
+        return scp_reader(spec.split(':', 1)[1])
+    if ark_reader is None:
+        return None
+    return ark_reader(kaldi_io.open_or_fd(spec))
+
+
 def eval_dnn(args):
     use_gpu = args.use_gpu == 'yes'
     wspecifier, ark, scp = process_wspecifier(args.vector_wspecifier)
@@ -104,10 +132,13 @@ def eval_dnn(args):
         logger.info('Both output ark and scp files exist. Return from this call.')
         return
     model = Model()
-    with kaldi_io.open_or_fd(args.feature_rspecifier) as input_fid:
+    vad = _open_table(args.vad_rspecifier, kaldi_io.read_vec_flt_scp, kaldi_io.read_vec_flt_ark) if args.vad_rspecifier else None
+    feats = _open_table(args.feature_rspecifier, kaldi_io.read_mat_scp, None)
+    with (kaldi_io.open_or_fd(args.feature_rspecifier) if feats is None else _Null()) as input_fid:
         with _open_output(wspecifier, ark, scp) as output_fid:
-            model.make_embedding(input_fid, output_fid, args.model_dir, args.min_chunk_size, args.chunk_size,
-                                 use_gpu, logger)
+            model.make_embedding(input_fid if feats is None else feats, output_fid, args.model_dir, args.min_chunk_size,
+                                 args.chunk_size, use_gpu, logger, vad_stream=vad, cmn_window=args.cmn_window,
+                                 cmn_center=args.cmn_center == 'yes')
     if ark is not None:
         os.rename(ark + '.tmp.ark', ark)
     if scp is not None:

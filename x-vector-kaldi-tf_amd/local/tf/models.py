@@ -241,10 +241,19 @@ class Model(object):
                     ((time.time() - start_time) / 60.0))
 
     # -- the hot path ------------------------------------------------------------------------------
-    def make_embedding(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger):
+    def make_embedding(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger,
+                       vad_stream=None, cmn_window=0, cmn_center=True):
+        """Build-defined extension (defaults = the reference's behaviour): with ``cmn_window > 0`` and/or a
+        ``vad_stream`` (ark stream or (key, vector) iterator, same key order as the features) the sliding-window CMN and
+        the VAD frame selection that extract_xvectors.sh:68 runs as Kaldi binaries are done on the GPU first, so
+        ``input_stream`` can carry raw features.  ``input_stream`` may also be a (key, matrix) iterator."""
         start_time = time.time()
         self.load_model(None, model_dir, logger)
         ex = engine.Extractor(self.device_model, min_chunk_size, chunk_size, max_batch_rows=self.max_batch_rows)
+        front = None
+        if cmn_window > 0 or vad_stream is not None:
+            from xvector_amd import frontend
+            front = frontend.FrontEnd(self.device_model.device, cmn_window, cmn_center)     # cmn_window <= 0: selection only
 
         total_segments = 0
         num_fail = 0
@@ -279,9 +288,19 @@ class Model(object):
             host = full.cpu().numpy()
             return [host[i] if engine.plan_chunks(lens[i], min_chunk_size, chunk_size) else None for i in range(len(mats))]
 
-        def flush(keys, mats):
+        def flush(keys, mats, vads=None):
             nonlocal num_fail, num_success, compute_time
             t0 = time.time()
+            if front is not None:
+                done = front.apply(mats, vads)
+                kept = []
+                for key, m in zip(keys, done):
+                    if m is None:      # select-voiced-frames: VAD length mismatch or no voiced frame -> nothing written
+                        logger.warning("No voiced frames (or VAD / feature length mismatch) for utterance: '%s'" % key)
+                        num_fail += 1
+                    else:
+                        kept.append((key, m))
+                keys, mats = [k for k, _ in kept], [m for _, m in kept]
             vecs = extract_window(mats)
             compute_time += time.time() - t0
             if vecs is None:                      # non-root rank: nothing to write
@@ -309,16 +328,34 @@ class Model(object):
 
         def reader():
             try:
-                keys, mats, frames = [], [], 0
-                for key, mat in kaldi_io.read_mat_ark(input_stream):
+                keys, mats, vads, frames = [], [], [], 0
+                feats = kaldi_io.read_mat_ark(input_stream) if hasattr(input_stream, "read") else input_stream
+                vad_it, pending = None, {}
+                if vad_stream is not None:
+                    vad_it = kaldi_io.read_vec_flt_ark(vad_stream) if hasattr(vad_stream, "read") else vad_stream
+
+                def vad_for(key):
+                    # same key order as the features (extract_xvectors.sh reads it as scp,s,cs); out-of-order tables still
+                    # work, at the price of holding the skipped vectors
+                    if key in pending:
+                        return pending.pop(key)
+                    for k, v in vad_it:
+                        if k == key:
+                            return v
+                        pending[k] = v
+                    return np.zeros(0, np.float32)        # no VAD for this key -> length mismatch -> dropped with a warning
+
+                for key, mat in feats:
                     keys.append(key)
                     mats.append(np.ascontiguousarray(mat, dtype=np.float32))
+                    if vad_it is not None:
+                        vads.append(vad_for(key))
                     frames += mat.shape[0]
                     if frames >= self.window_frames:
-                        windows.put((keys, mats))
-                        keys, mats, frames = [], [], 0
+                        windows.put((keys, mats, vads if vad_it is not None else None))
+                        keys, mats, vads, frames = [], [], [], 0
                 if keys:
-                    windows.put((keys, mats))
+                    windows.put((keys, mats, vads if vad_it is not None else None))
                 windows.put(None)
             except BaseException as e:          # noqa: B902 -- forwarded to the consumer
                 windows.put(e)
@@ -330,9 +367,9 @@ class Model(object):
                 break
             if isinstance(item, BaseException):
                 raise item
-            keys, mats = item
+            keys, mats, vads = item
             total_segments += len(keys)
-            flush(keys, mats)
+            flush(keys, mats, vads)
 
         st = ex.stats
         logger.info("Processed %d features of average size %d frames. Done %d and failed %d" %

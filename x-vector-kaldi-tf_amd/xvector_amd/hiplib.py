@@ -22,7 +22,9 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_f32", "xv_dropout_f32",
-           "xv_prelu_backward_f32")
+           "xv_prelu_backward_f32",
+           # feature front-end
+           "xv_cmn_sliding_scatter_f32")
 
 FMT_F32, FMT_SPLIT = 0, 1
 SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 136
@@ -117,6 +119,8 @@ def load():
     lib.xv_dropout_f32.argtypes = [vp, ci, i64, ci, ctypes.c_uint64, cf, vp]
     lib.xv_prelu_backward_f32.restype = ci
     lib.xv_prelu_backward_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp]
+    lib.xv_cmn_sliding_scatter_f32.restype = ci
+    lib.xv_cmn_sliding_scatter_f32.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]
     if lib.xv_version() != ABI_VERSION:
         raise XvectorHipError("libxvector_hip.so ABI version %d != expected %d" % (lib.xv_version(), ABI_VERSION))
     _lib = lib
@@ -514,3 +518,17 @@ def prelu_backward(dr, z, alpha):
     assert dr.shape == z.shape and dr.stride(0) == z.stride(0) and alpha.numel() == dr.shape[1]
     _check(lib.xv_prelu_backward_f32(_ptr(dr), _ptr(z), dr.stride(0), dr.shape[0], dr.shape[1], _ptr(alpha), _stream()),
            "xv_prelu_backward_f32")
+
+
+def cmn_sliding_scatter(x, utt_start, utt_len, n_utts, max_len, cmn_window, center, min_window, dst_row, y):
+    """Sliding-window CMN of the utterances in x[sum T, F] scattered to rows dst_row[t] of y (see include/xvector_hip.h)."""
+    import torch
+    lib = require_gpu()
+    _f32(x, "x")
+    assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1 and y.shape[1] >= x.shape[1]
+    for t in (utt_start, utt_len, dst_row):
+        assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()
+    assert dst_row.numel() >= x.shape[0] and utt_start.numel() >= n_utts and utt_len.numel() >= n_utts
+    _check(lib.xv_cmn_sliding_scatter_f32(_ptr(x), x.stride(0), x.shape[1], _ptr(utt_start), _ptr(utt_len), int(n_utts), int(max_len),
+                                          int(cmn_window), 1 if center else 0, int(min_window), _ptr(dst_row), _ptr(y), y.stride(0),
+                                          _stream()), "xv_cmn_sliding_scatter_f32")
