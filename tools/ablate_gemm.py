@@ -90,6 +90,8 @@ for l in RA:
     assert t2.count(l) == 1
     t2 = t2.replace(l, "        if (ks == 0) {" + l.strip() + " }")
 variants["halfABreads"] = t2.replace("            load_frags(G, s, c0, t0, 1);\n            mma(F);", "            G = F;\n            mma(F);")
+variants["halfB"] = base.replace(B_LINE, "if (s & 1) for (int j = 0; j < 4; ++j) XV_GLDS16(bnext + j * 1024, dst + j * 1024);")
+variants["immB"] = base.replace(B_LINE, "for (int once = 0; once < 1; ++once) { __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bnext), (__attribute__((address_space(3))) void *)(dst), 16, 0, 0); __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bnext), (__attribute__((address_space(3))) void *)(dst), 16, 1024, 0); __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bnext), (__attribute__((address_space(3))) void *)(dst), 16, 2048, 0); __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bnext), (__attribute__((address_space(3))) void *)(dst), 16, 3072, 0); }")
 procs = []
 for name, text in variants.items():
     if len(sys.argv) > 1 and name not in sys.argv[1:]:

@@ -306,6 +306,16 @@ constexpr int T_LD = BN + 4;                      // epilogue fp32 tile row (flo
 constexpr size_t GEMM3_LDS_BYTES = (size_t)2 * A3_BYTES + 2 * B3_BYTES + BM + 4 * BN * sizeof(float);   // + row mask + epilogue params
 static_assert((size_t)BM * T_LD * 4 <= (size_t)2 * A3_BYTES + 2 * B3_BYTES, "epilogue tile must fit below the row mask");
 
+// f(integral_constant<int, T>) for T = T0 .. KT-1, unrolled at compile time
+template <int T, int KT, class F>
+__device__ __forceinline__ void for_taps(F &f)
+{
+    if constexpr (T < KT) {
+        f(std::integral_constant<int, T>{});
+        for_taps<T + 1, KT>(f);
+    }
+}
+
 struct Gemm3Params {
     const void *x;        // fp32 rows (x_split == 0) or split buffer (row 0 of it)
     int x_split;
@@ -325,15 +335,22 @@ struct Gemm3Params {
     int n_mt, n_nt, n_chunks;
 };
 
+#define XV_GLDS16_OFF(gptr, lptr, imm)                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                    \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, imm, 0)
 #define XV_GLDS16(gptr, lptr)                                                                                   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                    \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-// PW: A-halo DMA pieces (8 rows = 1 KB each) every wave issues per stage on the split-input path; the (<=17)-piece
-// halo tile of the NEXT slab is spread evenly over the stages of the current slab (K=1: 4, K=3: 3, K=5: 2, K=7: 1).
+// KT: kernel size K of the split-input path as a compile-time constant (1, 3, 5, 7; 0 = the fp32-input path, runtime K).
+// The stage loop of that path is unrolled over the K taps of a slab, so everything that depends on the tap -- fragment
+// row offsets, the A-halo DMA schedule -- is computed once, and an iteration carries ~15 integer instructions next to
+// its 24 MFMAs instead of ~85 (each one beside an MFMA costs issue slots AND clock on this power-limited loop).
+// A-halo DMA pieces (8 rows = 1 KB each): the (<=17)-piece halo tile of the NEXT slab is spread over taps 0..K-2 of
+// the current slab, PW pieces per wave per tap (K=1: 4 -- every stage loads its own slab --, K=3: 3, K=5: 2, K=7: 1).
 // POOL: the layer output is not stored; the epilogue reduces every 8-row block of the tile to per-channel (mean, M2)
 // for the statistics pooling that follows the last frame-level layer (see stats_pool_blocks_kernel).
-template <bool SPLIT_A, int PW, bool POOL>
+template <bool SPLIT_A, int KT, bool POOL>
 __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -518,62 +535,115 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
         // Straight-line iteration body (no branches): DMA is issued unconditionally (clamped at the tail, where it
         // rewrites identical bytes), so that sched_group_barrier can interleave every memory instruction with the
         // MFMAs of the same wave: the wave overlaps its own memory issue instead of relying on the co-resident block.
+        constexpr int PW = KT == 1 ? 4 : KT == 3 ? 3 : KT == 5 ? 2 : 1;
+        constexpr int NP = KT == 1 ? 16 : 17;               // pieces of a halo tile: 128 + (K-1)*dil rows, (K-1)*dil in 2..8
+        constexpr int DT = KT == 1 ? 1 : KT - 1;            // taps that carry A pieces
+        // per-tap, per-lane fragment row offset in A buffer 0 with the slot swizzle and the lane's k-half folded in:
+        // the 16-B slot T of a row sits at ((T ^ sw) << 4), T = ks*2 + kh (+4 for lo)  ->  pa ^ (ks << 5) ^ (lo << 6)
+        int pa[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int lr0 = arow0 + t * p.dil;
+            pa[t] = lr0 * SROW + (((((lr0 + goff) & 15) >> 1) ^ kh) << 4);
+        }
+        // B fragments: (col + 32) has the same swizzle, the lo plane is +B3_PLANE -> immediates; per k-step one base
+        int pb[2];
+        pb[0] = 2 * A3_BYTES + boff0 + ((kh ^ bsw0) << 4);
+        pb[1] = 2 * A3_BYTES + boff0 + (((2 + kh) ^ bsw0) << 4);
+        // A-halo DMA schedule of this wave: byte offset of piece (t, j) in the split buffer / in an LDS A buffer
+        const uint32_t rowstep = 8u * (uint32_t)xrow_bytes;
+        uint32_t ag_off[DT][PW], al_off[DT][PW];
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                int piece = (t * 4 + wave) * PW + j;
+                piece = piece < NP ? piece : NP - 1;
+                ag_off[t][j] = (uint32_t)piece * rowstep;
+                al_off[t][j] = (uint32_t)piece * 1024u;
+            }
         const uint8_t *bnext = bsrc;                         // tile of stage min(s+2, n_stages-1)
         if (n_stages <= 2) bnext = bsrc - B3_BYTES;
         const uint8_t *abase = reinterpret_cast<const uint8_t *>(p.x) + (m0 - left + (lane >> 3)) * (long)xrow_bytes + (lane & 7) * 16;
-        for (int s = 0; s < n_stages; ++s) {
-            // ---- phase 1: G <- LDS(stage s, k-step 1) interleaved with the 12 MFMAs on F ---------------------------
-            load_frags(G, s, c0, t0, 1);
-            mma(F);
+        auto load_a_frags = [&](Frags &X, int base, int ks) {       // base = pa[t] (+ buffer offset), ks compile-time
+            const char *a = lds + (base ^ (ks << 5));
+            const char *al = lds + (base ^ (ks << 5) ^ 64);
+            X.al0 = *reinterpret_cast<const bf16x8 *>(al);
+            X.al1 = *reinterpret_cast<const bf16x8 *>(al + 32 * SROW);
+            X.ah0 = *reinterpret_cast<const bf16x8 *>(a);
+            X.ah1 = *reinterpret_cast<const bf16x8 *>(a + 32 * SROW);
+        };
+        auto load_b_frags = [&](Frags &X, int base) {               // base = pb[ks] + stage buffer offset
+            const char *b = lds + base;
+            X.bh0 = *reinterpret_cast<const bf16x8 *>(b);
+            X.bh1 = *reinterpret_cast<const bf16x8 *>(b + 32 * 64);
+            X.bl0 = *reinterpret_cast<const bf16x8 *>(b + B3_PLANE);
+            X.bl1 = *reinterpret_cast<const bf16x8 *>(b + B3_PLANE + 32 * 64);
+        };
+        int s = 0;
+        for (int c = 0; c < p.n_chunks; ++c) {
+            const int abuf = (c & 1) * A3_BYTES;                     // A buffer of slab c / of slab c+1
+            const int abuf_n = A3_BYTES - abuf;
+            // slab whose halo is loaded while slab c is consumed (K > 1), clamped at the tail
+            const int cn = (c + 1 < p.n_chunks) ? c + 1 : p.n_chunks - 1;
+            const uint8_t *anext = abase + (size_t)cn * SROW;
+            char *adst_n = Abuf + (cn & 1) * A3_BYTES;
+            auto tap = [&](auto TT) {
+                constexpr int t = decltype(TT)::value;
+                const int bbuf = (s & 1) * B3_BYTES;
+                // ---- phase 1: G <- LDS(stage s, k-step 1) interleaved with the 12 MFMAs on F -----------------------
+                load_a_frags(G, pa[t] + abuf, 1);
+                load_b_frags(G, pb[1] + bbuf);
+                mma(F);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                  // B(s): stage s fully read by everybody, stage s+1 landed
-            // ---- phase 2: DMA(s+2), F <- LDS(stage s+1, k-step 0), 12 MFMAs on G ------------------------------------
-            {
-                char *dst = Bbuf + (s & 1) * B3_BYTES + wave * 4096;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) XV_GLDS16(bnext + j * 1024, dst + j * 1024);
-                bnext += (s + 3 < n_stages) ? B3_BYTES : 0;
-                // A halo of slab `ca`: K == 1 -> the slab of stage s+2 (all pieces now); K > 1 -> the next slab,
-                // pieces spread over taps 0..K-2 of the current slab (tap K-1 re-issues the last piece, harmlessly)
-                int ca = (p.K == 1) ? s + 2 : c0 + 1;
-                ca = ca < p.n_chunks ? ca : p.n_chunks - 1;
-                const int tslot = (p.K == 1) ? 0 : t0;
-                char *adst = Abuf + (ca & 1) * A3_BYTES;
-                const uint8_t *ag = abase + (size_t)ca * SROW;
-#pragma unroll
-                for (int j = 0; j < PW; ++j) {
-                    int piece = (tslot * 4 + wave) * PW + j;
-                    piece = piece < n_pieces ? piece : n_pieces - 1;
-                    XV_GLDS16(ag + (size_t)(piece * 8) * xrow_bytes, adst + piece * 1024);
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
                 }
-            }
-            {
-                const int s1 = (s + 1 < n_stages) ? s + 1 : s;           // tail: harmless re-read
-                const int cc = (s + 1 < n_stages) ? c1 : c0, tt = (s + 1 < n_stages) ? t1 : t0;
-                load_frags(F, s1, cc, tt, 0);
-            }
-            mma(G);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                  // B(s): stage s fully read by everybody, stage s+1 landed
+                // ---- phase 2: DMA(s+2), F <- LDS(stage s+1, k-step 0), 12 MFMAs on G --------------------------------
+                {
+                    char *dst = Bbuf + bbuf + wave * 4096;           // one M0; the immediate advances source AND destination
+                    XV_GLDS16_OFF(bnext, dst, 0);
+                    XV_GLDS16_OFF(bnext, dst, 1024);
+                    XV_GLDS16_OFF(bnext, dst, 2048);
+                    XV_GLDS16_OFF(bnext, dst, 3072);
+                    bnext += (s + 3 < n_stages) ? B3_BYTES : 0;
+                }
+                if constexpr (KT == 1) {
+                    // every stage is its own slab: all 16 pieces of slab min(s+2, last) now, into the buffer of slab s
+                    const int ca = (s + 2 < p.n_chunks) ? s + 2 : p.n_chunks - 1;
+                    const uint8_t *ag = abase + (size_t)ca * SROW;
+                    char *adst = Abuf + (ca & 1) * A3_BYTES;
 #pragma unroll
-            for (int i = 0; i < 4 + PW; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // 1 VMEM (LDS-DMA piece)
-            }
+                    for (int j = 0; j < PW; ++j) XV_GLDS16(ag + ag_off[0][j], adst + al_off[0][j]);
+                } else if constexpr (t < KT - 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 12 - (8 + PW) > 0 ? 12 - (8 + PW) : 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            c0 = c1; t0 = t1;
-            advance(c1, t1);
+                    for (int j = 0; j < PW; ++j) XV_GLDS16(anext + ag_off[t][j], adst_n + al_off[t][j]);
+                }
+                if constexpr (t + 1 < KT) load_a_frags(F, pa[t + 1] + abuf, 0);
+                else load_a_frags(F, pa[0] + abuf_n, 0);             // first tap of the next slab (tail: harmless read)
+                load_b_frags(F, pb[0] + (B3_BYTES - bbuf));
+                mma(G);
+                constexpr int NV = (KT == 1 || t < KT - 1) ? 4 + PW : 4;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (LDS-DMA piece)
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 12 - (4 + NV) > 0 ? 12 - (4 + NV) : 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ++s;
+            };
+            for_taps<0, KT>(tap);
         }
     } else {
         for (int s = 0; s < n_stages; ++s) {
@@ -823,32 +893,29 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
     p.n_nt = (p.cout + BN - 1) / BN;
     typedef void (*kern_t)(const Gemm3Params);
     kern_t kern;
-    int pw = 0;
+    int kt = 0;
     if (p.x_split) {
-        pw = 4;
-        if (p.K > 1) {
-            const int n_pieces = (BM + (p.K - 1) * p.dil + 7) / 8;
-            pw = (n_pieces + 4 * (p.K - 1) - 1) / (4 * (p.K - 1));
-            if (pw > 4) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: halo tile too large for the DMA schedule");
-            if (pw < 1) pw = 1;
-        }
+        kt = p.K;
+        const int span = (p.K - 1) * p.dil;
+        if ((kt != 1 && kt != 3 && kt != 5 && kt != 7) || (kt > 1 && (span < 2 || span > MAX_SPAN)))
+            return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: split-format input supports K in {1,3,5,7} with (K-1)*dilation <= 8");
     }
     if (p.blk) {
-        kern = pw == 0 ? tdnn_gemm_bf16x3_kernel<false, 0, true> : pw == 1 ? tdnn_gemm_bf16x3_kernel<true, 1, true>
-             : pw == 2 ? tdnn_gemm_bf16x3_kernel<true, 2, true> : pw == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, true>
-             : tdnn_gemm_bf16x3_kernel<true, 4, true>;
+        kern = kt == 0 ? tdnn_gemm_bf16x3_kernel<false, 0, true> : kt == 1 ? tdnn_gemm_bf16x3_kernel<true, 1, true>
+             : kt == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, true> : kt == 5 ? tdnn_gemm_bf16x3_kernel<true, 5, true>
+             : tdnn_gemm_bf16x3_kernel<true, 7, true>;
     } else {
-        kern = pw == 0 ? tdnn_gemm_bf16x3_kernel<false, 0, false> : pw == 1 ? tdnn_gemm_bf16x3_kernel<true, 1, false>
-             : pw == 2 ? tdnn_gemm_bf16x3_kernel<true, 2, false> : pw == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, false>
-             : tdnn_gemm_bf16x3_kernel<true, 4, false>;
+        kern = kt == 0 ? tdnn_gemm_bf16x3_kernel<false, 0, false> : kt == 1 ? tdnn_gemm_bf16x3_kernel<true, 1, false>
+             : kt == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, false> : kt == 5 ? tdnn_gemm_bf16x3_kernel<true, 5, false>
+             : tdnn_gemm_bf16x3_kernel<true, 7, false>;
     }
     static bool attr_done = false;
     if (!attr_done) {
         const kern_t all[] = {tdnn_gemm_bf16x3_kernel<false, 0, false>, tdnn_gemm_bf16x3_kernel<true, 1, false>,
-                              tdnn_gemm_bf16x3_kernel<true, 2, false>, tdnn_gemm_bf16x3_kernel<true, 3, false>,
-                              tdnn_gemm_bf16x3_kernel<true, 4, false>, tdnn_gemm_bf16x3_kernel<false, 0, true>,
-                              tdnn_gemm_bf16x3_kernel<true, 1, true>, tdnn_gemm_bf16x3_kernel<true, 2, true>,
-                              tdnn_gemm_bf16x3_kernel<true, 3, true>, tdnn_gemm_bf16x3_kernel<true, 4, true>};
+                              tdnn_gemm_bf16x3_kernel<true, 3, false>, tdnn_gemm_bf16x3_kernel<true, 5, false>,
+                              tdnn_gemm_bf16x3_kernel<true, 7, false>, tdnn_gemm_bf16x3_kernel<false, 0, true>,
+                              tdnn_gemm_bf16x3_kernel<true, 1, true>, tdnn_gemm_bf16x3_kernel<true, 3, true>,
+                              tdnn_gemm_bf16x3_kernel<true, 5, true>, tdnn_gemm_bf16x3_kernel<true, 7, true>};
         for (kern_t k : all) {
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
