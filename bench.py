@@ -53,6 +53,8 @@ def parse():
                          "64-chunk minibatches (SURVEY §8f-1), reported as chunks/s")
     ap.add_argument("--train-precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="--mode train: arithmetic of the forward / input-gradient GEMMs")
+    ap.add_argument("--head", choices=["am_softmax", "softmax"], default="am_softmax",
+                    help="--mode train: classification head (BASELINE configs[4] names AM-softmax; 'softmax' = the reference's head)")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = split-precision bf16 MFMA with fp32 accumulate (fp32-class accuracy, "
                          "default); fp32 = exact fp32-input MFMA")
@@ -71,6 +73,8 @@ def bench_train(args, rank, world, dev, topo, feat):
     for k in list(weights):                                   # fan-in scaled start so that activations stay O(1)
         if k.endswith("/w:0") and weights[k].ndim == 3:
             weights[k] = (weights[k] * (np.sqrt(2.0 / (weights[k].shape[0] * weights[k].shape[1])) / 0.1)).astype(np.float32)
+    if args.head == "am_softmax":
+        topo = tp.get("ModelWithoutDropoutAMSoftmax")        # same network, build-defined additive-margin head
     tr = trainer.Trainer(weights, topo, dev, precision=args.train_precision)
     rng = np.random.default_rng(1234 + rank)
     n_total = args.warmup + args.steps
@@ -104,13 +108,14 @@ def bench_train(args, rank, world, dev, topo, feat):
     flops = 3.0 * (tp.flops_per_frame(topo, feat) * frames + B * args.steps * (tp.flops_per_utt(topo, 1) + 2 * 512 * n_spk))
     if rank == 0:
         print(json.dumps({
-            "metric": "training chunks/sec (64-chunk minibatches, 200-400 frames, 64-way softmax-CE, Adam)",
+            "metric": "training chunks/sec (64-chunk minibatches, 200-400 frames, 64-way %s, Adam)" % ("AM-softmax" if args.head == "am_softmax" else "softmax-CE"),
             "value": B * world * args.steps / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.train_precision == "fp32" else "f32 (fwd/dgrad GEMMs as bf16x3 split MFMA, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: training, B=64 chunks/minibatch/GPU, T~U{%d..%d}, 64 speakers, "
-                                   "ModelWithoutDropout topology, softmax-CE (AM-softmax is not in the reference)" % (args.tmin, args.tmax),
+                                   "ModelWithoutDropout topology, head: %s%s" % (args.tmin, args.tmax, args.head,
+                                   " (scale 30, margin 0.2; build-defined, the reference has softmax-CE only)" if args.head == "am_softmax" else ""),
                        "parallelism": "data parallel x%d, one bucketed gradient all-reduce per step" % world},
             "steps_per_s": args.steps / dt, "frames_per_s": frames * world / dt,
             "approx_tflops_fwd_bwd": flops * world / dt / 1e12, "first_loss": losses[0], "last_loss": losses[-1]}))

@@ -210,6 +210,15 @@ int xv_prelu_backward_f32(float *dr, float *z, int ld, int64_t R, int c, const f
 /* moving = moving*decay + batch*(1-decay)   (local/tf/tf_block.py:20-21). */
 int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream);
 
+/* ---- additive-margin softmax head (build-defined: BASELINE configs[4] asks for it, the reference has no margin head) ----
+ * logits[b, j] = scale * (cos(x_b, w_j) - margin * [j == label_b]),  cos = <x/||x||, w_j/||w_j||>   (Wang et al. 2018).
+ * xv_l2_normalize_rows_f32: y = x / max(||x||, 1e-12) per row, norm[r] = ||x_r||;  _backward: dx = (dy - y<y,dy>) / norm;
+ * xv_am_margin_f32 applies margin and scale in place to the cosine matrix (which xv_fc_* computes from the normalised
+ * operands); the loss is xv_softmax_ce_f32 on the result. */
+int xv_l2_normalize_rows_f32(const float *x, int ldx, int nrows, int c, float *y, int ldy, float *norm, void *stream);
+int xv_l2_normalize_backward_f32(const float *dy, const float *y, const float *norm, int nrows, int c, float *dx, void *stream);
+int xv_am_margin_f32(float *cosines, const int32_t *labels, int nrows, int nclasses, float scale, float margin, void *stream);
+
 /* ---- feature front-end -------------------------------------------------------------------------------
  * Sliding-window cepstral mean normalisation + VAD frame selection, i.e. what
  *   apply-cmvn-sliding --norm-vars=false --center=true --cmn-window=300 ... | select-voiced-frames ...

@@ -90,7 +90,12 @@ def forward(params, stats, topo, x, labels, train, dropout=None):
             e0 = s
         alpha = params.get(sc + "/prelu/prelu:0")
         h = drop(bn(_act(s, topo, alpha), sc, (0,)), sc)
-    logits = h @ params["output/w:0"] + params["output/b:0"]
+    head = topo.get("head")
+    if head and head.get("type") == "am_softmax":        # build-defined head (not in the reference): Wang et al. 2018
+        cos = F.normalize(h, dim=1, eps=1e-12) @ F.normalize(params["output/w:0"], dim=0, eps=1e-12)
+        logits = head["scale"] * (cos - head["margin"] * F.one_hot(labels, cos.shape[1]).to(cos.dtype))
+    else:
+        logits = h @ params["output/w:0"] + params["output/b:0"]
     loss = F.cross_entropy(logits, labels, reduction="mean")
     beta = topo.get("l2_beta", 0.0)
     if beta:                                                           # models.py:811-842: tf.nn.l2_loss(t) = sum(t**2)/2
@@ -129,7 +134,8 @@ def train_step(weights, adam, topo, x, labels, lr, dropout=None):
         dropout = {k: (torch.tensor(np.asarray(m, np.float64)), float(keep)) for k, (m, keep) in dropout.items()}
     loss, acc, new_stats, _ = forward(p, p, topo, torch.tensor(np.asarray(x, np.float64)),
                                       torch.tensor(np.asarray(labels, np.int64)), train=True, dropout=dropout)
-    grads = torch.autograd.grad(loss, [p[n] for n in names])
+    grads = torch.autograd.grad(loss, [p[n] for n in names], allow_unused=True)      # AM-softmax head: output/b is unused
+    grads = [g if g is not None else torch.zeros_like(p[n]) for g, n in zip(grads, names)]
     t = adam["t"] + 1
     lr_t = lr * np.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
     new_w = {k: np.array(v, dtype=np.float64) for k, v in weights.items()}

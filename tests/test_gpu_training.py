@@ -125,6 +125,27 @@ def test_class_model_dropout_gradients(env):
     assert a == b
 
 
+def test_am_softmax_head_gradients(env):
+    """Build-defined additive-margin softmax head (BASELINE configs[4]; not in the reference, parity unpinned): loss,
+    accuracy and every gradient vs the float64 autograd restatement; the unused output bias gets a zero gradient."""
+    topo, w, rng = _setup(env, "ModelWithoutDropoutAMSoftmax", classes=64, seed=21)
+    assert topo["head"]["type"] == "am_softmax"
+    B, T = 16, 150
+    x = (rng.standard_normal((B, T, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 64, B)
+    tr = env["trainer"].Trainer(w, topo)
+    loss, acc, grads = tr.gradients(x, lab)
+    rl, ra, _, _, rg = env["ref"].train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3)
+    assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)) and acc == pytest.approx(ra)
+    assert not grads["output/b:0"].any() and not np.any(rg["output/b:0"])
+    bad = {n: _rel(grads[n].cpu().numpy(), rg[n]) for n in rg if n != "output/b:0" and _rel(grads[n].cpu().numpy(), rg[n]) > 2e-4}
+    assert not bad, bad
+    # a margin-free, scale-1 head on normalised operands is a plain cosine classifier: the eval path agrees too
+    l2, a2 = env["trainer"].Trainer(w, topo).eval_batch(x, lab)
+    el, ea, _ = env["ref"].eval_batch(w, topo, x, lab)
+    assert abs(l2 - el) < 1e-5 * max(1.0, abs(el)) and a2 == pytest.approx(ea)
+
+
 def test_three_adam_steps_follow_the_oracle(env):
     """Adam normalises every element by its own gradient history (update ~ lr*sign(g) on the first step), so elements
     whose gradient is at rounding-noise level are ill-conditioned in ANY implementation; they are masked out (a gradient

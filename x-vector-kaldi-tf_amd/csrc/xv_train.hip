@@ -380,6 +380,45 @@ __global__ __launch_bounds__(64) void softmax_ce_kernel(const float *__restrict_
     }
 }
 
+// ---- additive-margin softmax head (build-defined: BASELINE configs[4] names it, the reference has no margin head) ----
+// one wave64 per row: y = x / max(||x||, 1e-12), norm = ||x|| (fp64 accumulate)
+__global__ __launch_bounds__(64) void l2_normalize_rows_kernel(const float *__restrict__ x, int ldx, int C, float *__restrict__ y,
+                                                               int ldy, float *__restrict__ norm)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const float *xr = x + (size_t)r * ldx;
+    double ss = 0.0;
+    for (int j = lane; j < C; j += 64) ss += (double)xr[j] * (double)xr[j];
+    for (int off = 32; off; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const double n = sqrt(ss);
+    const float inv = (float)(1.0 / fmax(n, 1e-12));
+    for (int j = lane; j < C; j += 64) y[(size_t)r * ldy + j] = xr[j] * inv;
+    if (lane == 0) norm[r] = (float)n;
+}
+
+// dx = (dy - y * <y, dy>) / max(norm, 1e-12)    for y = x / ||x||
+__global__ __launch_bounds__(64) void l2_normalize_backward_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                   const float *__restrict__ norm, int C, float *__restrict__ dx)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const float *g = dy + (size_t)r * C, *yr = y + (size_t)r * C;
+    double dot = 0.0;
+    for (int j = lane; j < C; j += 64) dot += (double)g[j] * (double)yr[j];
+    for (int off = 32; off; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    const double inv = 1.0 / fmax((double)norm[r], 1e-12);
+    for (int j = lane; j < C; j += 64) dx[(size_t)r * C + j] = (float)(((double)g[j] - (double)yr[j] * dot) * inv);
+}
+
+// z[b, j] = scale * (cos[b, j] - margin * [j == label[b]])   in place
+__global__ void am_margin_kernel(float *__restrict__ z, const int *__restrict__ labels, int B, int N, float scale, float margin)
+{
+    const size_t n = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / N), j = (int)(i - (size_t)b * N);
+        z[i] = scale * (z[i] - (j == labels[b] ? margin : 0.f));
+    }
+}
+
 __global__ void mean2_kernel(const float *a, const float *b, int n, float *out)      // out[0]=mean(a), out[1]=mean(b), in order
 {
     if (threadIdx.x || blockIdx.x) return;
@@ -592,6 +631,32 @@ int xv_prelu_backward_f32(float *dr, float *z, int ld, int64_t R, int c, const f
     hipLaunchKernelGGL(prelu_backward_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0,
                        (hipStream_t)stream, dr, z, (long)R, c, ld, alpha);
     return tcheck("prelu_backward_kernel");
+}
+
+int xv_l2_normalize_rows_f32(const float *x, int ldx, int nrows, int c, float *y, int ldy, float *norm, void *stream)
+{
+    if (nrows <= 0) return 0;
+    if (!x || !y || !norm || c <= 0 || ldx < c || ldy < c) return tfail(XV_ERR_BAD_ARG, "l2_normalize_rows: bad argument");
+    hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3(nrows), dim3(64), 0, (hipStream_t)stream, x, ldx, c, y, ldy, norm);
+    return tcheck("l2_normalize_rows_kernel");
+}
+
+int xv_l2_normalize_backward_f32(const float *dy, const float *y, const float *norm, int nrows, int c, float *dx, void *stream)
+{
+    if (nrows <= 0) return 0;
+    if (!dy || !y || !norm || !dx || c <= 0) return tfail(XV_ERR_BAD_ARG, "l2_normalize_backward: bad argument");
+    hipLaunchKernelGGL(l2_normalize_backward_kernel, dim3(nrows), dim3(64), 0, (hipStream_t)stream, dy, y, norm, c, dx);
+    return tcheck("l2_normalize_backward_kernel");
+}
+
+int xv_am_margin_f32(float *cosines, const int32_t *labels, int nrows, int nclasses, float scale, float margin, void *stream)
+{
+    if (nrows <= 0 || nclasses <= 0) return 0;
+    if (!cosines || !labels) return tfail(XV_ERR_BAD_ARG, "am_margin: bad argument");
+    const size_t n = (size_t)nrows * nclasses;
+    hipLaunchKernelGGL(am_margin_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       cosines, labels, nrows, nclasses, scale, margin);
+    return tcheck("am_margin_kernel");
 }
 
 int xv_ema_f32(float *moving, const float *batch, int n, float decay, void *stream)

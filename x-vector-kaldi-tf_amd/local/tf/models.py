@@ -399,5 +399,9 @@ class ModelL2LossWithoutDropoutLRelu(Model):          # models.py:866
     pass
 
 
+class ModelWithoutDropoutAMSoftmax(Model):            # build-defined (BASELINE configs[4]); see xvector_amd/topology.py
+    pass
+
+
 class ModelL2LossWithoutDropoutReluHeInit(Model):     # models.py:1118
     pass

@@ -22,7 +22,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_f32", "xv_dropout_f32",
-           "xv_prelu_backward_f32",
+           "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
            "xv_cmn_sliding_scatter_f32")
 
@@ -119,6 +119,12 @@ def load():
     lib.xv_dropout_f32.argtypes = [vp, ci, i64, ci, ctypes.c_uint64, cf, vp]
     lib.xv_prelu_backward_f32.restype = ci
     lib.xv_prelu_backward_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp]
+    lib.xv_l2_normalize_rows_f32.restype = ci
+    lib.xv_l2_normalize_rows_f32.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp]
+    lib.xv_l2_normalize_backward_f32.restype = ci
+    lib.xv_l2_normalize_backward_f32.argtypes = [vp, vp, vp, ci, ci, vp, vp]
+    lib.xv_am_margin_f32.restype = ci
+    lib.xv_am_margin_f32.argtypes = [vp, vp, ci, ci, cf, cf, vp]
     lib.xv_cmn_sliding_scatter_f32.restype = ci
     lib.xv_cmn_sliding_scatter_f32.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]
     if lib.xv_version() != ABI_VERSION:
@@ -532,3 +538,35 @@ def cmn_sliding_scatter(x, utt_start, utt_len, n_utts, max_len, cmn_window, cent
     _check(lib.xv_cmn_sliding_scatter_f32(_ptr(x), x.stride(0), x.shape[1], _ptr(utt_start), _ptr(utt_len), int(n_utts), int(max_len),
                                           int(cmn_window), 1 if center else 0, int(min_window), _ptr(dst_row), _ptr(y), y.stride(0),
                                           _stream()), "xv_cmn_sliding_scatter_f32")
+
+
+def l2_normalize_rows(x):
+    """-> (y = x / ||x|| per row, norms[R])."""
+    import torch
+    lib = require_gpu()
+    _f32(x, "x")
+    y = torch.empty_like(x)
+    norm = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _check(lib.xv_l2_normalize_rows_f32(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(y), y.stride(0), _ptr(norm), _stream()),
+           "xv_l2_normalize_rows_f32")
+    return y, norm
+
+
+def l2_normalize_backward(dy, y, norm):
+    import torch
+    lib = require_gpu()
+    _f32(dy, "dy"); _f32(y, "y"); _f32(norm, "norm")
+    assert dy.shape == y.shape and norm.numel() == y.shape[0]
+    dx = torch.empty_like(y)
+    _check(lib.xv_l2_normalize_backward_f32(_ptr(dy), _ptr(y), _ptr(norm), y.shape[0], y.shape[1], _ptr(dx), _stream()),
+           "xv_l2_normalize_backward_f32")
+    return dx
+
+
+def am_margin(cosines, labels, scale, margin):
+    import torch
+    lib = require_gpu()
+    _f32(cosines, "cosines")
+    assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == cosines.shape[0]
+    _check(lib.xv_am_margin_f32(_ptr(cosines), _ptr(labels), cosines.shape[0], cosines.shape[1], float(scale), float(margin), _stream()),
+           "xv_am_margin_f32")

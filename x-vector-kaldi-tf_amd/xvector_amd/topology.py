@@ -21,6 +21,7 @@ _BASE = dict(
     lrelu_alpha=0.2,                            # models.py:912
     l2_beta=0.0,                                # training only: loss += l2_beta*(0.1*l2(embed-0) + l2(embed-1) + l2(output))
     dropout=False,                              # training only: tf.nn.dropout sites after BN (class Model, models.py:70-72,92-94)
+    head=None,                                  # training only: None = softmax-CE on output/xw_plus_b (models.py:96-113)
 )
 
 TOPOLOGIES = {
@@ -33,6 +34,9 @@ TOPOLOGIES = {
     "ModelL2LossWithoutDropoutPRelu":        dict(_BASE, activation="prelu", l2_beta=0.0002),   # models.py:746-862 (beta :756)
     "ModelL2LossWithoutDropoutLRelu":        dict(_BASE, activation="lrelu", l2_beta=0.0002),   # models.py:866-981 (beta :876)
     "ModelL2LossWithoutDropoutReluHeInit":   dict(_BASE, l2_beta=0.0002),                       # models.py:1118-1244 (beta :1128)
+    # BUILD-DEFINED (not in the reference; BASELINE configs[4] asks for an AM-softmax head): ModelWithoutDropout's network
+    # with logits = scale*(cos(x, w_j) - margin*[j == y]) on the L2-normalised embed_layer-1 output and output/w columns
+    "ModelWithoutDropoutAMSoftmax":          dict(_BASE, head=dict(type="am_softmax", scale=30.0, margin=0.2)),
 }
 
 

@@ -64,6 +64,8 @@ class Trainer(object):
         self._layouts = {}
         self.l2_beta = float(topo.get("l2_beta", 0.0))
         self.l2_terms = (("embed_layer-0", 0.1), ("embed_layer-1", 1.0), ("output", 1.0))       # models.py:811-832
+        head = topo.get("head") or {}
+        self.am = head if head.get("type") == "am_softmax" else None         # build-defined additive-margin head
 
     def _alpha(self, scope):
         """act_alpha argument of the layer kernels: per-channel vector (PReLU), 1-element tensor (LReLU) or None."""
@@ -193,8 +195,17 @@ class Trainer(object):
                 hiplib.dropout(a, S["seeds"][("embed", j)], S["keep"])
             S["e_r"].append(r); S["e_z"].append(z); S["e_in"].append(a); S["e_mean"].append(mean); S["e_var"].append(var)
         logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)
-        hiplib.fc(S["e_in"][-1], pk["output"], self.P["output/b:0"], None, None, tp.ACT_NONE, None, None, logits)
         lab = torch.from_numpy(np.asarray(labels, dtype=np.int32)).to(self.device)
+        if self.am:
+            # cosines of the L2-normalised features and class vectors (columns of output/w), then margin + scale in place
+            S["xh"], S["xnorm"] = hiplib.l2_normalize_rows(S["e_in"][-1])
+            wt = self.P["output/w:0"].t().contiguous()                                   # [classes, E]: class vectors as rows
+            S["wh_t"], S["wnorm"] = hiplib.l2_normalize_rows(wt)
+            S["wh"] = S["wh_t"].t().contiguous()                                         # [E, classes]
+            hiplib.fc(S["xh"], hiplib.pack_weights(S["wh"]), None, None, None, tp.ACT_NONE, None, None, logits)
+            hiplib.am_margin(logits, lab, self.am["scale"], self.am["margin"])
+        else:
+            hiplib.fc(S["e_in"][-1], pk["output"], self.P["output/b:0"], None, None, tp.ACT_NONE, None, None, logits)
         loss_acc = torch.empty(2, dtype=torch.float32, device=self.device)
         dlogits = torch.empty_like(logits) if want_grad else None
         hiplib.softmax_ce(logits, lab, loss_acc, dlogits)
@@ -257,7 +268,22 @@ class Trainer(object):
         S = self._forward(x, labels, train=True, want_grad=True, keep_prob=1.0 - float(dropout_proportion), seed=seed)
         L, B, T = S["L"], S["B"], S["T"]
         grads = {}
-        d = self._dense_backward("output", S["e_in"][-1], S["dlogits"], 1, 1, grads, True, None)
+        if self.am:
+            # logits = scale*(cos - margin*onehot): dL/dcos = scale*dlogits; cos = xh @ wh  ->  dxh = g wh^T, dwh = xh^T g;
+            # then back through the two L2 normalisations.  output/b is not part of this head: zero gradient.
+            g = S["dlogits"]
+            hiplib.axpy(g, g, float(self.am["scale"]) - 1.0)
+            E = S["xh"].shape[1]
+            dwh = torch.empty((1, E, self.num_classes), dtype=torch.float32, device=self.device)
+            hiplib.wgrad(S["xh"], g, 1, 1, dwh)
+            dxh = torch.empty_like(S["xh"])
+            hiplib.tdnn_layer(g, hiplib.pack_weights(S["wh_t"]), None, None, None, tp.ACT_NONE, None, 1, 1, None, dxh)
+            d = hiplib.l2_normalize_backward(dxh, S["xh"], S["xnorm"])
+            dwt = hiplib.l2_normalize_backward(dwh[0].t().contiguous(), S["wh_t"], S["wnorm"])       # [classes, E]
+            grads["output/w:0"] = dwt.t().contiguous()
+            grads["output/b:0"] = torch.zeros_like(self.P["output/b:0"])
+        else:
+            d = self._dense_backward("output", S["e_in"][-1], S["dlogits"], 1, 1, grads, True, None)
         for j in reversed(range(len(self.embed_scopes))):
             sc = self.embed_scopes[j]
             if S["keep"] < 1.0 and ("embed", j) in S["seeds"]:
