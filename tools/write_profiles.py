@@ -1,0 +1,57 @@
+"""Turn the outputs of tools/profile_round.sh (gpurun_out/) into the committed profiles/<tag>_* files + profiles/traffic.json."""
+import json, re, subprocess, sys
+tag = sys.argv[1]
+commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
+stats = open("gpurun_out/r01d_stats.txt").read()
+rd = lambda n: open("gpurun_out/%s.json" % n).read().strip()
+tot = cnt = 0
+for l in stats.splitlines():
+    if l.startswith("tdnn_gemm_bf16x3_kernel"):
+        f = l.split(); cnt += int(f[-4]); tot += float(f[-3])
+under = json.loads(rd("bench_under_prof"))
+hdr = ("# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-budget 0     (MI355X, round 1, default precision bf16x3, commit %s; tools/profile_round.sh)\n"
+       "# 6 steps (1 warm-up + 5 timed) x 24 batches.  tdnn_gemm_bf16x3_kernel<SPLIT_A, K, POOL> instantiations:\n"
+       "#   <true,7,false> = layer 2 (K=7)   <true,5,false> = layer 1 (K=5)   <true,1,false> = layer 3 (K=1)\n"
+       "#   <true,1,true>  = layer 4 (K=1) with the statistics-pooling epilogue (8-row block stats; stats_pool_blocks_kernel finishes the pooling)\n"
+       "#   <false,0,false> = layer 0 (fp32 features in) + the per-step embed FC\n"
+       "# All instantiations together: %d launches, total %.1f us, average %.2f us per launch  (bench.py roofline.avg_launch_ms %.4f under the profiler)\n"
+       "# stats_pool_kernel (12 calls) is bench.py's separate \"roofline_pool\" measurement of the standalone pooling kernel, outside the timed region.\n"
+       % (commit, cnt, tot, tot / cnt, under["roofline"]["avg_launch_ms"]))
+open("profiles/%s_kernel_stats_bf16x3.txt" % tag, "w").write(
+    hdr + stats + "\n# bench.py line printed under the profiler:\n" + rd("bench_under_prof") +
+    "\n\n# bench.py line of the same build, same box, without the profiler (default flags, incl. cpu_baseline):\n" + rd("bench_plain") +
+    "\n\n# exact-fp32 path of the same build (python bench.py --precision fp32 --cpu-budget 0):\n" + rd("bench_fp32") + "\n")
+pmc = open("gpurun_out/r01d_pmc.txt").read().splitlines()
+keep = [l for l in pmc if l.startswith("kernel ") or "tdnn_gemm" in l or "stats_pool" in l]
+vals = {}
+for l in keep:
+    m = re.match(r"(\S+<[^>]*>|\S+)\(.*?\s+(\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s*$", l)
+    if m:
+        vals.setdefault(m.group(1), {})[m.group(2)] = (int(m.group(3)), float(m.group(4)), float(m.group(5)), int(m.group(6)))
+lines = []
+for k, v in vals.items():
+    if "GRBM_GUI_ACTIVE" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v and v["SQ_VALU_MFMA_BUSY_CYCLES"][1] > 0:
+        cyc = v["GRBM_GUI_ACTIVE"][1] / 8
+        lines.append("#   %-48s MFMA busy %5.1f %% of cycles, effective clock %.2f GHz" %
+                     (k, 100 * v["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (cyc * 1024), cyc / v["GRBM_GUI_ACTIVE"][3]))
+hdr2 = ("# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --steps 1 --warmup 0 --cpu-budget 0 --utts 2000   (separate passes: FETCH_SIZE | WRITE_SIZE | SQ/GRBM set;\n"
+        "#   tools/profile_round.sh, commit %s).  5 batches per pass; last column = average kernel duration in ns.\n"
+        "# FETCH_SIZE / WRITE_SIZE in KiB per launch.  Fabric-side bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, verified on stats_pool_kernel:\n"
+        "#   its corrected reads equal its algorithmic bytes within 0.3 %%).  FETCH_SIZE counts L2-miss requests: Infinity-Cache (MALL) hits are included, so for the GEMMs it is\n"
+        "#   dominated by the 5-7 MB weight panel that every XCD streams through its 4 MB L2 once per round of workgroups, not by HBM reads.\n"
+        "# MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs); effective shader clock = (GRBM_GUI_ACTIVE/8) / duration (nominal 2.4 GHz):\n"
+        % commit + "\n".join(lines) +
+        "\n#   The split-precision MFMA loop is POWER-limited: see DESIGN.md \"What bounds the GEMM\".\n")
+open("profiles/%s_pmc_bf16x3.txt" % tag, "w").write(hdr2 + "\n".join(keep) + "\n")
+fs = sum(v["FETCH_SIZE"][2] for k, v in vals.items() if k.startswith("tdnn_gemm") and "FETCH_SIZE" in v)
+ws = sum(v["WRITE_SIZE"][2] for k, v in vals.items() if k.startswith("tdnn_gemm") and "WRITE_SIZE" in v)
+n = sum(v["FETCH_SIZE"][0] for k, v in vals.items() if k.startswith("tdnn_gemm") and "FETCH_SIZE" in v)
+json.dump({"round": 1, "kernel": "tdnn_gemm_bf16x3_kernel (all instantiations, launch-weighted mean)",
+           "source": "profiles/%s_pmc_bf16x3.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --utts 2000)" % tag,
+           "tdnn_gemm_fetch_kib_raw": round(fs / n, 1), "tdnn_gemm_write_kib": round(ws / n, 1),
+           "tdnn_gemm_hbm_bytes_per_launch": int((2 * fs / n + ws / n) * 1024),
+           "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; x2 on FETCH_SIZE per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), verified on stats_pool_kernel",
+           "note": "fabric-side traffic incl. Infinity-Cache hits; algorithmic ~0.37 GB/launch (the last layer does not store its output); the excess is the weight panel "
+                   "(5-7 MB > 4 MB L2 per XCD) re-streamed from the Infinity Cache once per round of workgroups, plus the A halo tiles re-read by the 4-12 column tiles"},
+          open("profiles/traffic.json", "w"), indent=1)
+print("\n".join(lines)); print(open("profiles/traffic.json").read())
