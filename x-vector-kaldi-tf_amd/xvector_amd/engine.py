@@ -5,8 +5,11 @@ validate the length, cut into chunks, one ``sess.run`` per chunk at batch 1, len
 is done here for MANY utterances at once: chunks are packed into one ragged ``[R, C]`` matrix with zero
 gap rows between them (see include/xvector_hip.h) and pushed through
 
-    5 x xv_tdnn_layer_f32  ->  xv_stats_pool_f32  ->  xv_fc_f32 (embed_layer-0; optional embed_layer-1)
-    ->  xv_chunk_average_f32
+    fp32 path    5 x xv_tdnn_layer_f32 -> xv_stats_pool_f32 -> xv_fc_f32 (embed_layer-0; optional embed_layer-1)
+                 -> xv_chunk_average_f32
+    bf16x3 path  4 x xv_tdnn_layer_bf16x3 (split-format activations) -> xv_tdnn_layer_pool_bf16x3 (last layer, 8-row
+    (default)    block statistics instead of the activation) -> xv_stats_pool_blocks_f32 -> xv_fc_bf16x3
+                 -> xv_chunk_average_f32
 
 PyTorch is used for device memory, streams and H2D/D2H copies only; every arithmetic step of the path
 is one of the HIP kernels behind the C ABI.
