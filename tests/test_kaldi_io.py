@@ -182,3 +182,50 @@ def test_pipe_and_large_stream_through_buffered_reader(tmp_path):
             kaldi_io.write_mat(f, m, key=k)
     got = dict(kaldi_io.read_mat_ark("ark:cat %s |" % ark))
     assert list(got) == list(mats) and all(np.array_equal(got[k], mats[k]) for k in mats)
+
+
+@pytest.mark.parametrize("no_host_lib", [False, True])
+def test_read_mat_ark_blocks_equals_the_per_record_reader(monkeypatch, no_host_lib):
+    """The block reader (native scan + one GIL-free gather per pass) returns exactly the records of read_mat_ark, in order,
+    across runs of float matrices with changing column counts, a double-precision record in the middle, empty matrices and
+    a stream delivered in small pieces; without the host library it degrades to one-record blocks."""
+    import kaldi_io
+    if no_host_lib:
+        monkeypatch.setenv("XVECTOR_NO_HOST_LIB", "1")
+    monkeypatch.setattr(kaldi_io, "_HOST_LIB", False)            # re-probe under the env setting
+    rng = np.random.default_rng(5)
+    recs = [("a%03d" % i, rng.standard_normal((int(t), 7)).astype(np.float32)) for i, t in enumerate(rng.integers(0, 40, 300))]
+    recs += [("dbl", rng.standard_normal((9, 7)))]                                               # DM record: generic path
+    recs += [("b%03d" % i, rng.standard_normal((int(t), 3)).astype(np.float32)) for i, t in enumerate(rng.integers(1, 9, 50))]
+    recs += [("c%03d" % i, rng.standard_normal((5, 7)).astype(np.float32)) for i in range(20)]
+    bio = io.BytesIO()
+    for k, m in recs:
+        kaldi_io.write_mat(bio, m, key=k)
+    raw = bio.getvalue()
+
+    class Dribble(io.RawIOBase):                       # a pipe-like stream that returns at most 777 bytes per read
+        def __init__(self, data):
+            self.data, self.p = data, 0
+
+        def readable(self):
+            return True
+
+        def readinto(self, b):
+            n = min(len(b), 777, len(self.data) - self.p)
+            b[:n] = self.data[self.p:self.p + n]
+            self.p += n
+            return n
+
+    for make in (lambda: io.BytesIO(raw), lambda: io.BufferedReader(Dribble(raw), buffer_size=512)):
+        got = []
+        nblocks = 0
+        for keys, feats, off in kaldi_io.read_mat_ark_blocks(make()):
+            nblocks += 1
+            assert feats.dtype == np.float32 and feats.flags["C_CONTIGUOUS"] and off[0] == 0 and off[-1] == feats.shape[0]
+            got += [(k, feats[off[i]:off[i + 1]]) for i, k in enumerate(keys)]
+        ref = list(kaldi_io.read_mat_ark(make()))
+        assert [k for k, _ in got] == [k for k, _ in ref] == [k for k, _ in recs]
+        for (_, a), (_, b), (_, m) in zip(got, ref, recs):
+            assert a.shape == b.shape == m.shape and np.array_equal(a, np.asarray(b, np.float32)) and np.array_equal(a, m.astype(np.float32))
+        assert nblocks == len(recs) if no_host_lib else nblocks < 20
+    monkeypatch.setattr(kaldi_io, "_HOST_LIB", False)

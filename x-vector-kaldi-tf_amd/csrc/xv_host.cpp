@@ -11,7 +11,7 @@
 
 extern "C" {
 
-int xv_host_version(void) { return 1; }
+int xv_host_version(void) { return 2; }
 
 // Scans buf[pos, len).  Fills up to max_records entries; returns the number of records found.
 // *next = offset of the first byte not consumed; *stop = 0 buffer exhausted / record incomplete (need more data),
@@ -50,6 +50,19 @@ int xv_ark_scan_fm(const uint8_t *buf, size_t pos, size_t len, int max_records, 
     if (n == max_records) *stop = 2;
     *next = pos;
     return n;
+}
+
+// Copies the payloads of n scanned records (data_off[i], rows[i] x cols float32, all with the same column count) back to
+// back into dst -- one GIL-free call instead of one NumPy copy per utterance.  Returns the number of rows copied.
+int64_t xv_ark_gather_fm(const uint8_t *buf, const int64_t *data_off, const int32_t *rows, int cols, int n, float *dst)
+{
+    int64_t r = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t nbytes = (size_t)rows[i] * (size_t)cols * 4;
+        memcpy(dst + (size_t)r * cols, buf + data_off[i], nbytes);
+        r += rows[i];
+    }
+    return r;
 }
 
 }  // extern "C"

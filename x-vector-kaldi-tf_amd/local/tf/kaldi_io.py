@@ -484,6 +484,10 @@ def _host_lib():
                 lib.xv_ark_scan_fm.restype = ctypes.c_int
                 lib.xv_ark_scan_fm.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int] + \
                     [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+                if hasattr(lib, "xv_ark_gather_fm"):
+                    lib.xv_ark_gather_fm.restype = ctypes.c_int64
+                    lib.xv_ark_gather_fm.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_void_p]
                 _HOST_LIB = lib
             except OSError:
                 _HOST_LIB = None
@@ -527,6 +531,69 @@ def _scan_fm_records(fd, lib):
             fd._fill(want)
             if len(fd.buf) - fd.pos == before:                  # nothing more to read
                 return
+
+
+def read_mat_ark_blocks(file_or_fd):
+    """Generator of (keys, feats[sum T, F] float32, offsets[n+1]) over an ark stream: utterance i of a block is
+    ``feats[offsets[i]:offsets[i+1]]``.  Runs of binary float matrices with one column count come out as ONE block per
+    scanner pass (<= 8192 records) whose payloads are gathered by a single native, GIL-free call -- the per-utterance
+    Python work of ``read_mat_ark`` (generator switch, frombuffer, copy) is what bounded the ark->ark rate.  Any other
+    record (or a stream without the host library) is returned as a one-utterance block via the generic reader."""
+    raw = open_or_fd(file_or_fd)
+    fd = raw if isinstance(raw, _BufferedStream) else _BufferedStream(raw)
+    lib = _host_lib()
+    try:
+        if lib is not None and hasattr(lib, "xv_ark_gather_fm"):
+            key_off = np.empty(_SCAN_MAX, np.int64); key_len = np.empty(_SCAN_MAX, np.int32)
+            data_off = np.empty(_SCAN_MAX, np.int64); rows = np.empty(_SCAN_MAX, np.int32); cols = np.empty(_SCAN_MAX, np.int32)
+            nxt, stop = ctypes.c_size_t(0), ctypes.c_int(0)
+        while True:
+            if lib is not None and hasattr(lib, "xv_ark_gather_fm"):
+                want = 1
+                while True:
+                    fd._fill(want)
+                    buf, pos = fd.buf, fd.pos
+                    if len(buf) == pos:
+                        break
+                    n = lib.xv_ark_scan_fm(buf, pos, len(buf), _SCAN_MAX, key_off.ctypes.data, key_len.ctypes.data,
+                                           data_off.ctypes.data, rows.ctypes.data, cols.ctypes.data, ctypes.byref(nxt),
+                                           ctypes.byref(stop))
+                    i0 = 0
+                    while i0 < n:                               # split the pass where the column count changes
+                        c = int(cols[i0])
+                        same = np.flatnonzero(cols[i0:n] != c)
+                        i1 = i0 + (int(same[0]) if len(same) else n - i0)
+                        kos, kls = key_off[i0:i1].tolist(), key_len[i0:i1].tolist()
+                        keys = [buf[ko:ko + kl].decode().strip() for ko, kl in zip(kos, kls)]
+                        bad = [k for k in keys if _KEY_OK.match(k) is None]
+                        assert not bad, "malformed key %r" % bad[0]
+                        offsets = np.zeros(i1 - i0 + 1, np.int64)
+                        np.cumsum(rows[i0:i1], out=offsets[1:])
+                        feats = np.empty((int(offsets[-1]), c), np.float32)
+                        lib.xv_ark_gather_fm(buf, data_off[i0:i1].ctypes.data, rows[i0:i1].ctypes.data, c, i1 - i0,
+                                             feats.ctypes.data)
+                        fd.pos = int(data_off[i1 - 1]) + int(rows[i1 - 1]) * c * 4
+                        yield keys, feats, offsets
+                        i0 = i1
+                    fd.pos = nxt.value
+                    if stop.value == 1:
+                        break                                   # a different record type follows
+                    if stop.value == 0:
+                        avail = len(buf) - fd.pos
+                        want = max(2 * avail, fd.BLOCK) if n == 0 else avail + 1
+                        fd._fill(want)
+                        if len(fd.buf) - fd.pos == avail:       # nothing more to read
+                            break
+            key = read_key(fd)                                  # generic path: one record of any supported type
+            if not key:
+                break
+            m = np.ascontiguousarray(read_mat(fd), dtype=np.float32)
+            yield [key], m, np.array([0, m.shape[0]], np.int64)
+    finally:
+        if raw is not file_or_fd:
+            raw.close()
+        elif fd is not raw:
+            fd.detach()
 
 
 def read_mat_ark(file_or_fd):

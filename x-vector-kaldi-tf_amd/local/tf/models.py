@@ -329,7 +329,6 @@ class Model(object):
         def reader():
             try:
                 keys, mats, vads, frames = [], [], [], 0
-                feats = kaldi_io.read_mat_ark(input_stream) if hasattr(input_stream, "read") else input_stream
                 vad_it, pending = None, {}
                 if vad_stream is not None:
                     vad_it = kaldi_io.read_vec_flt_ark(vad_stream) if hasattr(vad_stream, "read") else vad_stream
@@ -345,15 +344,27 @@ class Model(object):
                         pending[k] = v
                     return np.zeros(0, np.float32)        # no VAD for this key -> length mismatch -> dropped with a warning
 
-                for key, mat in feats:
-                    keys.append(key)
-                    mats.append(np.ascontiguousarray(mat, dtype=np.float32))
-                    if vad_it is not None:
-                        vads.append(vad_for(key))
-                    frames += mat.shape[0]
-                    if frames >= self.window_frames:
-                        windows.put((keys, mats, vads if vad_it is not None else None))
-                        keys, mats, vads, frames = [], [], [], 0
+                def blocks():
+                    # (keys, [matrices]) per block: whole scanner passes gathered natively for ark streams, one utterance
+                    # at a time for (key, matrix) iterators
+                    if hasattr(input_stream, "read"):
+                        for bkeys, bfeats, off in kaldi_io.read_mat_ark_blocks(input_stream):
+                            o = off.tolist()
+                            yield bkeys, [bfeats[o[i]:o[i + 1]] for i in range(len(bkeys))]
+                    else:
+                        for key, mat in input_stream:
+                            yield [key], [np.ascontiguousarray(mat, dtype=np.float32)]
+
+                for bkeys, bmats in blocks():
+                    for key, mat in zip(bkeys, bmats):
+                        keys.append(key)
+                        mats.append(mat)
+                        if vad_it is not None:
+                            vads.append(vad_for(key))
+                        frames += mat.shape[0]
+                        if frames >= self.window_frames:
+                            windows.put((keys, mats, vads if vad_it is not None else None))
+                            keys, mats, vads, frames = [], [], [], 0
                 if keys:
                     windows.put((keys, mats, vads if vad_it is not None else None))
                 windows.put(None)
