@@ -149,3 +149,18 @@ def test_schedules_match_reference_goldens():
     # SURVEY §8c example: '0,0@0.10,0.1@0.50,0' -> 0.05 at f = 0.3 and 0.75
     assert abs(ze_utils.get_dropout_edit_string("0,0@0.10,0.1@0.50,0", 0.3) - 0.05) < 1e-12
     assert abs(ze_utils.get_dropout_edit_string("0,0@0.10,0.1@0.50,0", 0.75) - 0.05) < 1e-12
+
+
+def test_vectorised_chunk_table_equals_the_per_utterance_plan():
+    """plan_chunk_table == plan_chunks utterance by utterance (order by length, stable), for the recipe settings, for
+    chunk_size -1, for lengths around every boundary, and for the degenerate chunk_size < min_chunk_size."""
+    rng = np.random.default_rng(0)
+    lens = np.concatenate([rng.integers(0, 700, 400), [0, 24, 25, 26, 99, 100, 101, 199, 200, 201, 224, 225, 10000, 10024, 10025, 30001]])
+    for min_chunk, chunk in ((25, 10000), (25, 100), (100, -1), (25, 200), (1, 7), (50, 20)):
+        order, c_utt, c_start, c_len, seg = engine.plan_chunk_table(lens, min_chunk, chunk)
+        plans = [engine.plan_chunks(int(t), min_chunk, chunk) for t in lens]
+        ref_order = sorted((i for i, p in enumerate(plans) if p), key=lambda i: lens[i])
+        assert order.tolist() == ref_order
+        flat = [(u, s, n) for u in ref_order for s, n in plans[u]]
+        assert list(zip(c_utt.tolist(), c_start.tolist(), c_len.tolist())) == flat
+        assert seg.tolist() == [0] + list(np.cumsum([len(plans[u]) for u in ref_order]))

@@ -53,6 +53,40 @@ def slot_rows(lengths, gap, align=1):
     return (lengths + gap + align - 1) // align * align
 
 
+def plan_chunk_table(lengths, min_chunk_size, chunk_size):
+    """``plan_chunks`` for many utterances at once, as the flat chunk table the extractor works on: utterances that yield at
+    least one chunk, ordered by length (stable), and their chunks in order.  Returns int64 arrays
+    ``(order, c_utt, c_start, c_len, seg_start)``: chunk j belongs to utterance ``c_utt[j]`` and covers frames
+    ``[c_start[j], c_start[j]+c_len[j])``; the chunks of ``order[k]`` are ``seg_start[k]:seg_start[k+1]``.
+    Vectorised (the per-utterance Python loop was the serial prefix of every window); same rules, models.py:377-407."""
+    T = np.asarray(lengths, dtype=np.int64)
+    if chunk_size != -1 and chunk_size < min_chunk_size:
+        # full-size chunks would be skipped too (models.py:406 applies to every chunk): rare enough for the plain loop
+        plans = [plan_chunks(int(t), min_chunk_size, chunk_size) for t in T]
+        order = np.array(sorted((i for i, p in enumerate(plans) if p), key=lambda i: T[i]), dtype=np.int64)
+        c_utt = np.array([u for u in order for _ in plans[u]], dtype=np.int64)
+        c_start = np.array([s for u in order for s, _ in plans[u]], dtype=np.int64)
+        c_len = np.array([n for u in order for _, n in plans[u]], dtype=np.int64)
+        seg = np.zeros(len(order) + 1, np.int64)
+        np.cumsum([len(plans[u]) for u in order], out=seg[1:])
+        return order, c_utt, c_start, c_len, seg
+    valid = np.flatnonzero((T > 0) & (T >= min_chunk_size))
+    order = valid[np.argsort(T[valid], kind="stable")]
+    To = T[order]
+    cs = To if chunk_size == -1 else np.where(To < chunk_size, To, chunk_size)          # models.py:388-394
+    nch = -(-To // np.maximum(cs, 1))                                                      # ceil, models.py:396
+    last = To - (nch - 1) * cs                                                             # tail chunk: simply shorter
+    kept = nch - (last < min_chunk_size)                                                   # models.py:405-407
+    seg = np.zeros(len(order) + 1, np.int64)
+    np.cumsum(kept, out=seg[1:])
+    c_utt = np.repeat(order, kept)
+    idx = np.arange(int(seg[-1]), dtype=np.int64) - np.repeat(seg[:-1], kept)             # chunk index within its utterance
+    csr = np.repeat(cs, kept)
+    c_start = idx * csr
+    c_len = np.where(idx == np.repeat(nch - 1, kept), np.repeat(last, kept), csr)
+    return order, c_utt, c_start, c_len, seg
+
+
 class BatchLayout(object):
     """Row layout of one ragged batch: chunk b owns rows [row_start[b], row_start[b]+row_len[b]); at least ``gap`` zero
     rows precede the first chunk and follow every chunk, and every chunk starts on a multiple of ``align`` rows
@@ -334,30 +368,24 @@ class Extractor(object):
         torch = self.model.torch
         model = self.model
         dev = model.device
-        plans = [plan_chunks(m.shape[0], self.min_chunk_size, self.chunk_size) for m in mats]
         # chunk table, utterances ordered by length so that batches are length-homogeneous
-        order = sorted((i for i, p in enumerate(plans) if p), key=lambda i: mats[i].shape[0])
-        c_utt, c_start, c_len = [], [], []
-        seg_start = [0]
-        for u in order:
-            for s, n in plans[u]:
-                c_utt.append(u); c_start.append(s); c_len.append(n)
-            seg_start.append(len(c_utt))
+        order, c_utt, c_start, c_len, seg_start = plan_chunk_table([m.shape[0] for m in mats], self.min_chunk_size,
+                                                                    self.chunk_size)
+        order, c_utt, c_start, c_len = order.tolist(), c_utt.tolist(), c_start.tolist(), c_len.tolist()
         nch = len(c_utt)
         results = [None] * len(mats)
         if nch == 0:
             return results
         gap, align = model.gap, model.align
-        slots = slot_rows(c_len, gap, align).tolist()
         lead = (gap + align - 1) // align * align
-        # batch boundaries
+        # batch boundaries: greedy fill up to max_batch_rows / max_batch_chunks (a single chunk may exceed the row budget)
+        cum = np.zeros(nch + 1, dtype=np.int64)
+        np.cumsum(slot_rows(c_len, gap, align), out=cum[1:])
         bounds, b0 = [], 0
         while b0 < nch:
-            rows, b1 = lead, b0
-            while b1 < nch and b1 - b0 < self.max_batch_chunks and (b1 == b0 or rows + slots[b1] <= self.max_batch_rows):
-                rows += slots[b1]
-                b1 += 1
-            bounds.append((b0, b1, rows))
+            b1 = int(np.searchsorted(cum, cum[b0] + self.max_batch_rows - lead, side="right")) - 1
+            b1 = min(max(b1, b0 + 1), b0 + self.max_batch_chunks, nch)
+            bounds.append((b0, b1, lead + int(cum[b1] - cum[b0])))
             b0 = b1
         stage = self._staging(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds))
         with torch.cuda.device(dev):
