@@ -55,11 +55,43 @@ class Trainer(object):
                 self.trainable.append(sc + "/prelu/prelu:0")
         self.trainable += ["output/w:0", "output/b:0"]
         self.t = int(adam["t"]) if adam else 0
-        z = lambda n: torch.zeros_like(self.P[n])
-        self.m = {n: (torch.as_tensor(np.array(adam["m"][n], np.float32)).to(self.device) if adam and n in adam["m"] else z(n))
-                  for n in self.trainable}
-        self.v = {n: (torch.as_tensor(np.array(adam["v"][n], np.float32)).to(self.device) if adam and n in adam["v"] else z(n))
-                  for n in self.trainable}
+        # every trainable tensor (and its Adam slots) is a view into ONE flat buffer, so the optimizer is one launch per step
+        # and the data-parallel all-reduce needs no staging copy; segments start on 64-element boundaries (kernel alignment)
+        offs, total = {}, 0
+        for n in self.trainable:
+            offs[n] = total
+            total += (self.P[n].numel() + 63) // 64 * 64
+        self._offs, self._flat_n = offs, total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.flat_g = torch.zeros_like(self.flat_p)                 # gradients land here directly (views in self.G)
+        # BN moving statistics and the batch statistics of a step: two flat buffers with the same layout -> one EMA launch
+        stat_names = [sc + sfx for sc in self.frame_scopes + self.embed_scopes for sfx in ("/mean:0", "/variance:0")]
+        so, stotal = {}, 0
+        for n in stat_names:
+            so[n] = stotal
+            stotal += (self.P[n].numel() + 63) // 64 * 64
+        self.flat_moving = torch.zeros(stotal, dtype=torch.float32, device=self.device)
+        self.flat_batch = torch.zeros_like(self.flat_moving)
+        self.B = {}
+        for n in stat_names:
+            k = self.P[n].numel()
+            self.flat_moving[so[n]:so[n] + k].copy_(self.P[n])
+            self.P[n] = self.flat_moving[so[n]:so[n] + k]
+            self.B[n] = self.flat_batch[so[n]:so[n] + k]
+        self.m, self.v, self.G = {}, {}, {}
+        for n in self.trainable:
+            k, shape = self.P[n].numel(), self.P[n].shape
+            seg = slice(offs[n], offs[n] + k)
+            self.flat_p[seg].copy_(self.P[n].reshape(-1))
+            self.P[n] = self.flat_p[seg].view(shape)
+            self.m[n], self.v[n] = self.flat_m[seg].view(shape), self.flat_v[seg].view(shape)
+            self.G[n] = self.flat_g[seg].view(shape)
+            if adam and n in adam["m"]:
+                self.m[n].copy_(torch.as_tensor(np.array(adam["m"][n], np.float32)).to(self.device).view(shape))
+            if adam and n in adam["v"]:
+                self.v[n].copy_(torch.as_tensor(np.array(adam["v"][n], np.float32)).to(self.device).view(shape))
         self._packed = None
         self._layouts = {}
         self.l2_beta = float(topo.get("l2_beta", 0.0))
@@ -140,11 +172,8 @@ class Trainer(object):
             cm = torch.empty((nchunks, 2 * C), dtype=torch.float32, device=self.device)
             rs, rl = (L["rs"], L["rl"]) if frame_level else (L["one_start"], L["one_len"])
             hiplib.chunk_moments(r, rs, rl, nchunks, rows_per_chunk, cm)
-            mean = torch.empty(C, dtype=torch.float32, device=self.device)
-            var = torch.empty_like(mean)
+            mean, var = self.B[scope + "/mean:0"], self.B[scope + "/variance:0"]      # moving averages: one EMA at step end
             hiplib.merge_moments(cm, rl, nchunks, mean, var)
-            hiplib.ema(self.P[scope + "/mean:0"], mean, BN_DECAY)
-            hiplib.ema(self.P[scope + "/variance:0"], var, BN_DECAY)
         else:
             mean, var = self.P[scope + "/mean:0"], self.P[scope + "/variance:0"]
         scale, shift = hiplib.fold_bn(self.P[scope + "/gamma:0"], self.P[scope + "/beta:0"], mean, var, tp.BN_EPSILON)
@@ -225,14 +254,15 @@ class Trainer(object):
         pk = self._pack()
         R, cin = x_in.shape
         cout = dz.shape[1]
-        dw = torch.empty((K, cin, cout), dtype=torch.float32, device=self.device)
-        hiplib.wgrad(x_in, dz, K, dil, dw)
-        db = torch.empty(cout, dtype=torch.float32, device=self.device)
+        gw, db = self.G[scope + "/w:0"], self.G[scope + "/b:0"]
+        if scope == self.frame_scopes[0] and self.in_dim != self.feat_dim:
+            dw = torch.empty((K, cin, cout), dtype=torch.float32, device=self.device)
+            hiplib.wgrad(x_in, dz, K, dil, dw)
+            gw.copy_(dw[:, :self.feat_dim, :])                          # drop the padding column
+        else:
+            hiplib.wgrad(x_in, dz, K, dil, gw.view(K, cin, cout))
         hiplib.col_sums(dz, None, db)
-        w = self.P[scope + "/w:0"]
-        if scope == self.frame_scopes[0]:
-            dw = dw[:, :self.feat_dim, :].contiguous()                   # drop the padding column
-        grads[scope + "/w:0"] = dw.reshape(w.shape)
+        grads[scope + "/w:0"] = gw
         grads[scope + "/b:0"] = db
         if not need_dx:
             return None
@@ -246,14 +276,14 @@ class Trainer(object):
         s1 = torch.empty(C, dtype=torch.float32, device=self.device)
         s2 = torch.empty_like(s1)
         hiplib.col_sums(dh, r, s1, s2)
-        dgamma, dbeta = torch.empty_like(s1), torch.empty_like(s1)
+        dgamma, dbeta = self.G[scope + "/gamma:0"], self.G[scope + "/beta:0"]
         dz = torch.empty_like(r)
         hiplib.bn_act_backward(dh, r, s1, s2, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames,
                                tp.ACT_NONE if self.prelu else self.act, self.alpha, valid, dgamma, dbeta, dz)
         if self.prelu:
             # dz holds dL/d(act output); z the pre-activation: -> dz = dL/dz, z = dr*min(z,0) whose column sums are dalpha
             hiplib.prelu_backward(dz, z, self.P[scope + "/prelu/prelu:0"])
-            dalpha = torch.empty_like(s1)
+            dalpha = self.G[scope + "/prelu/prelu:0"]
             hiplib.col_sums(z, None, dalpha)
             grads[scope + "/prelu/prelu:0"] = dalpha
         grads[scope + "/gamma:0"] = dgamma
@@ -261,11 +291,13 @@ class Trainer(object):
         return dz
 
     def gradients(self, x, labels, dropout_proportion=0.0, seed=0):
-        """Forward (train phase, updates the moving statistics) + backward.  Returns (loss, acc, {name: grad tensor}).
+        """Forward (train phase, updates the moving statistics) + backward.  Returns (loss, acc, {name: grad tensor});
+        the tensors are views into ``self.flat_g`` and are overwritten by the next call.
         dropout_proportion > 0 is honoured by the classes with dropout sites (topology "dropout": True) and ignored by
         the others, as in the reference where only class Model wires the keep-prob placeholder into the graph."""
         torch = self.torch
         S = self._forward(x, labels, train=True, want_grad=True, keep_prob=1.0 - float(dropout_proportion), seed=seed)
+        hiplib.ema(self.flat_moving, self.flat_batch, BN_DECAY)     # moving <- 0.95*moving + 0.05*batch, all scopes at once
         L, B, T = S["L"], S["B"], S["T"]
         grads = {}
         if self.am:
@@ -275,13 +307,14 @@ class Trainer(object):
             hiplib.axpy(g, g, float(self.am["scale"]) - 1.0)
             E = S["xh"].shape[1]
             dwh = torch.empty((1, E, self.num_classes), dtype=torch.float32, device=self.device)
+            self.G["output/b:0"].zero_()
             hiplib.wgrad(S["xh"], g, 1, 1, dwh)
             dxh = torch.empty_like(S["xh"])
             hiplib.tdnn_layer(g, hiplib.pack_weights(S["wh_t"]), None, None, None, tp.ACT_NONE, None, 1, 1, None, dxh)
             d = hiplib.l2_normalize_backward(dxh, S["xh"], S["xnorm"])
             dwt = hiplib.l2_normalize_backward(dwh[0].t().contiguous(), S["wh_t"], S["wnorm"])       # [classes, E]
-            grads["output/w:0"] = dwt.t().contiguous()
-            grads["output/b:0"] = torch.zeros_like(self.P["output/b:0"])
+            self.G["output/w:0"].copy_(dwt.t())
+            grads["output/w:0"], grads["output/b:0"] = self.G["output/w:0"], self.G["output/b:0"]
         else:
             d = self._dense_backward("output", S["e_in"][-1], S["dlogits"], 1, 1, grads, True, None)
         for j in reversed(range(len(self.embed_scopes))):
@@ -302,41 +335,30 @@ class Trainer(object):
         if self.l2_beta:
             for sc, coef in self.l2_terms:
                 for suffix in ("/w:0", "/b:0"):
-                    g = grads[sc + suffix]
-                    if not g.is_contiguous():
-                        g = grads[sc + suffix] = g.contiguous()
-                    hiplib.axpy(g, self.P[sc + suffix], self.l2_beta * coef)
+                    hiplib.axpy(grads[sc + suffix], self.P[sc + suffix], self.l2_beta * coef)
         la = S["loss_acc"].cpu().numpy()
         return float(la[0]) + self._l2_value(), float(la[1]), grads
 
-    def _allreduce(self, grads):
-        """Data parallelism (one process per GPU): ONE bucketed RCCL all-reduce of all gradients (24.5 MB fp32 for the
+    def _allreduce(self, flat):
+        """Data parallelism (one process per GPU): ONE RCCL all-reduce of the flat gradient buffer (24.5 MB fp32 for the
         default topology), averaged over ranks -- the reference's own multi-job scheme never exchanges anything (its
         model averaging is a stub, ze_utils.py:164-183), so this is build-defined.  BN statistics stay per replica."""
         import torch.distributed as dist
         if not dist.is_initialized():
-            return grads
-        torch = self.torch
+            return flat
         world = dist.get_world_size()
-        flat = torch.cat([grads[n].reshape(-1) for n in self.trainable])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if world > 1:
             hiplib.axpy(flat, flat, 1.0 / world - 1.0)              # flat /= world
-        out, o = {}, 0
-        for n in self.trainable:
-            k = grads[n].numel()
-            out[n] = flat[o:o + k].view(grads[n].shape)
-            o += k
-        return out
+        return flat
 
     def step(self, x, labels, learning_rate, dropout_proportion=0.0, seed=0):
         """One optimizer step on a minibatch x[B,T,F] (float16/32), labels[B].  Returns (loss, accuracy)."""
         loss, acc, grads = self.gradients(x, labels, dropout_proportion, seed)
-        grads = self._allreduce(grads)
+        flat = self._allreduce(self.flat_g)                     # every entry of grads is a view into flat_g
         self.t += 1
         lr_t = learning_rate * math.sqrt(1.0 - ADAM_B2 ** self.t) / (1.0 - ADAM_B1 ** self.t)
-        for n in self.trainable:
-            hiplib.adam(self.P[n], grads[n].contiguous(), self.m[n], self.v[n], lr_t, ADAM_B1, ADAM_B2, ADAM_EPS)
+        hiplib.adam(self.flat_p, flat, self.flat_m, self.flat_v, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS)
         self._packed = None
         return loss, acc
 
