@@ -181,3 +181,28 @@ def test_sliding_cmn_restatement_properties(oracle_mod):
     sel = oracle.select_voiced(x, vad)
     assert sel.shape == (11, 5) and np.array_equal(sel[-1], x[500])
     assert oracle.select_voiced(x, np.zeros(1000)) is None and oracle.select_voiced(x, np.ones(999)) is None
+
+
+def test_config1_cpu_plumbing_ark_to_ark(oracle_mod, default_weights):
+    """BASELINE configs[0]: 100 synthetic utterances, 23-dim, fixed T=200, default topology, CPU only: ark in -> the oracle's
+    restatement of the driver (chunk plan + fp32 forward + NumPy float32 average) -> ark out; output framing is the
+    reference's (key, '\\0B', 'FV ', dim 512), and the fp32 CPU path agrees with the fp64 oracle far inside the 1e-4 bar."""
+    import time
+    topo, w = default_weights
+    rng = np.random.default_rng(1234)
+    utts = [("utt%06d" % i, (rng.standard_normal((200, 23)) * 3.0).astype(np.float32)) for i in range(100)]
+    bio = io.BytesIO()
+    for k, m in utts:
+        kaldi_io.write_mat(bio, m, key=k)
+    out = io.BytesIO()
+    t0 = time.time()
+    for k, m in kaldi_io.read_mat_ark(io.BytesIO(bio.getvalue())):
+        kaldi_io.write_vec_flt(out, oracle_mod.embed_utterance(m, w, topo, 25, 10000, np.float32), key=k)
+    dt = time.time() - t0
+    got = list(kaldi_io.read_vec_flt_ark(io.BytesIO(out.getvalue())))
+    assert [k for k, _ in got] == [k for k, _ in utts] and all(v.shape == (512,) and v.dtype == np.float32 for _, v in got)
+    assert len(out.getvalue()) == 100 * (len("utt000000 ") + 2 + 3 + 1 + 4 + 512 * 4)
+    for i in (0, 37, 99):
+        ref = oracle_mod.embed_utterance(utts[i][1], w, topo, 25, 10000, np.float64)
+        assert oracle_mod.rel_l2(got[i][1], ref) < 5e-6
+    print("config 1 on the CPU oracle (fp32 C, OpenMP): %.1f utt/s" % (100 / dt))
