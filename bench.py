@@ -203,8 +203,9 @@ def main():
         step(si)
     fence()
     t0 = time.perf_counter()
+    last = None
     for si in range(args.warmup, n_steps_total):
-        step(si)
+        last = step(si)
     fence()
     dt = time.perf_counter() - t0
     if dist.is_initialized():
@@ -337,6 +338,26 @@ def main():
                                          "has %d logical cores" % (per, sweep, ncores),
                                "by_threads": {str(t): res[t][0] for t in sweep},
                                "reference_faithful_2_threads": res.get(2, (None,))[0]}
+    # ---- BASELINE configs[3] asks for the rate "incl. and excl. ark write": rank 0 writes the gathered x-vectors of ONE step
+    #      as a Kaldi ark + scp (outside the timed region; `value` excludes it, `with_ark_write` folds its time into a step)
+    if last is not None:
+        import shutil
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf"))
+        import kaldi_io
+        tmp = tempfile.mkdtemp(prefix="xv_bench_")
+        try:
+            tw0 = time.perf_counter()
+            host = torch.cat([b for b in last], dim=0).cpu().numpy()
+            keys = ["utt%07d" % i for i in range(host.shape[0])]
+            with kaldi_io.TableWriter(os.path.join(tmp, "xvector.ark"), os.path.join(tmp, "xvector.scp")) as tw:
+                kaldi_io.write_vec_flt_batch(tw, keys, list(host))
+            tw1 = time.perf_counter() - tw0
+            out["with_ark_write"] = {"ark_write_s_per_step": tw1, "ark_mb": os.path.getsize(os.path.join(tmp, "xvector.ark")) / 1e6,
+                                     "value_incl_write": n_utts * world / (dt / args.steps + tw1), "unit": "utt/s",
+                                     "note": "D2H of the gathered [N,512] block + Kaldi ark,scp write by rank 0, serial after the step"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

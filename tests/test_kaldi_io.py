@@ -229,3 +229,24 @@ def test_read_mat_ark_blocks_equals_the_per_record_reader(monkeypatch, no_host_l
             assert a.shape == b.shape == m.shape and np.array_equal(a, np.asarray(b, np.float32)) and np.array_equal(a, m.astype(np.float32))
         assert nblocks == len(recs) if no_host_lib else nblocks < 20
     monkeypatch.setattr(kaldi_io, "_HOST_LIB", False)
+
+
+def test_table_writer_batch_equals_per_record_writes(tmp_path):
+    """write_vec_flt_batch on a TableWriter (one ark write + one scp write per batch) == one write_vec_flt per key:
+    identical ark bytes, identical scp lines, and every scp offset opens on its vector."""
+    import kaldi_io
+    rng = np.random.default_rng(2)
+    keys = ["spk%d-utt%04d" % (i % 7, i) for i in range(200)]
+    vecs = [rng.standard_normal(int(d)).astype(np.float32) for d in rng.integers(1, 40, 200)]
+    a1, s1, a2, s2 = (str(tmp_path / n) for n in ("a1.ark", "s1.scp", "a2.ark", "s2.scp"))
+    with kaldi_io.TableWriter(a1, s1, scp_ark_name="X.ark") as w:
+        kaldi_io.write_vec_flt_batch(w, keys[:120], vecs[:120])
+        kaldi_io.write_vec_flt_batch(w, keys[120:], vecs[120:])
+    with kaldi_io.TableWriter(a2, s2, scp_ark_name="X.ark") as w:
+        for k, v in zip(keys, vecs):
+            kaldi_io.write_vec_flt(w, v, key=k)
+    assert open(a1, "rb").read() == open(a2, "rb").read() and open(s1).read() == open(s2).read()
+    text = open(s1).read().replace("X.ark", a1)
+    open(s1, "w").write(text)
+    got = dict(kaldi_io.read_vec_flt_scp(s1))
+    assert list(got) == keys and all(np.array_equal(got[k], v) for k, v in zip(keys, vecs))

@@ -331,6 +331,18 @@ class TableWriter(object):
     def note_key(self, key):
         self._scp.write("%s %s:%d\n" % (key, self._name, self._pos))
 
+    def write_records(self, keys, key_bytes, bodies):
+        """Many records at once: record i is ``key_bytes[i] + bodies[i]`` in the ark and its scp line points just past the
+        key (the offset Kaldi prints), one ``write`` per file."""
+        lines, pos = [], self._pos
+        for k, kb, body in zip(keys, key_bytes, bodies):
+            pos += len(kb)
+            lines.append("%s %s:%d\n" % (k, self._name, pos))
+            pos += len(body)
+        self._ark.write(b"".join(x for pair in zip(key_bytes, bodies) for x in pair))
+        self._scp.write("".join(lines))
+        self._pos = pos
+
     def close(self):
         self._ark.close()
         self._scp.close()
@@ -368,19 +380,17 @@ def write_vec_flt_batch(file_or_fd, keys, vecs):
     ``write`` call per batch; falls back to per-record writes for index-building streams (TableWriter)."""
     fd = open_or_fd(file_or_fd, mode="wb")
     try:
-        if hasattr(fd, "note_key"):
-            for k, v in zip(keys, vecs):
-                write_vec_flt(fd, v, key=k)
-            return
-        parts = []
+        key_bytes, bodies = [], []
         for k, v in zip(keys, vecs):
             v = np.asarray(v)
             if v.dtype != np.float32:
                 raise UnsupportedDataType("'%s', write_vec_flt_batch expects float32" % v.dtype)
-            parts.append((k + " ").encode() if k != "" else b"")
-            parts.append(b"\x00BFV \x04" + struct.pack("<I", v.shape[0]))
-            parts.append(np.ascontiguousarray(v).astype("<f4", copy=False).tobytes())
-        fd.write(b"".join(parts))
+            key_bytes.append((k + " ").encode() if k != "" else b"")
+            bodies.append(b"\x00BFV \x04" + struct.pack("<I", v.shape[0]) + np.ascontiguousarray(v).astype("<f4", copy=False).tobytes())
+        if hasattr(fd, "write_records"):            # TableWriter: ark + scp index
+            fd.write_records(keys, key_bytes, bodies)
+        else:
+            fd.write(b"".join(x for pair in zip(key_bytes, bodies) for x in pair))
     finally:
         if fd is not file_or_fd:
             fd.close()
