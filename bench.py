@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--utts", type=int, default=10000, help="utterances per GPU (configs[1]: 10000)")
     ap.add_argument("--tmin", type=int, default=200)
     ap.add_argument("--tmax", type=int, default=400)
-    ap.add_argument("--batch-rows", type=int, default=131072)
+    ap.add_argument("--batch-rows", type=int, default=262144)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline timing (0 = skip)")
     ap.add_argument("--parity-utts", type=int, default=6)
     ap.add_argument("--no-fused-pool", action="store_true",

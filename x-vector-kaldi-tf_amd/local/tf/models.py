@@ -51,7 +51,7 @@ class Model(object):
     statistics pooling, 2 segment-level layers (models.py:27-29)."""
 
     window_frames = 1 << 21          # utterances are read from the stream in windows of ~2M frames
-    max_batch_rows = 131072
+    max_batch_rows = 262144
 
     def __init__(self):
         self.graph = None            # kept for attribute compatibility (models.py:22-23)

@@ -338,7 +338,7 @@ class Extractor(object):
 
     NBUF = 3
 
-    def __init__(self, model, min_chunk_size, chunk_size, max_batch_rows=131072, max_batch_chunks=4096):
+    def __init__(self, model, min_chunk_size, chunk_size, max_batch_rows=262144, max_batch_chunks=8192):
         self.model = model
         self.min_chunk_size = int(min_chunk_size)
         self.chunk_size = int(chunk_size)
