@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "xvector_hip.h"
@@ -909,8 +910,11 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
              : kt == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, false> : kt == 5 ? tdnn_gemm_bf16x3_kernel<true, 5, false>
              : tdnn_gemm_bf16x3_kernel<true, 7, false>;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    // the dynamic-LDS opt-in is per device and idempotent: one bit per device id, set after the first successful pass
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         const kern_t all[] = {tdnn_gemm_bf16x3_kernel<false, 0, false>, tdnn_gemm_bf16x3_kernel<true, 1, false>,
                               tdnn_gemm_bf16x3_kernel<true, 3, false>, tdnn_gemm_bf16x3_kernel<true, 5, false>,
                               tdnn_gemm_bf16x3_kernel<true, 7, false>, tdnn_gemm_bf16x3_kernel<false, 0, true>,
@@ -920,7 +924,7 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
         }
-        attr_done = true;
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(NT), GEMM3_LDS_BYTES, st, p);
     hipError_t e = hipGetLastError();
@@ -939,13 +943,15 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
     p.n_mt = (int)((p.R + BM - 1) / BM);
     p.n_nt = (p.cout + BN - 1) / BN;
     const bool vec = (p.cin % 4 == 0) && (p.ldx % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) && (((uintptr_t)p.wp) % 16 == 0);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         hipError_t e = hipFuncSetAttribute((const void *)tdnn_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
         e = hipFuncSetAttribute((const void *)tdnn_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-        attr_done = true;
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const dim3 grid((unsigned)(p.n_mt * p.n_nt));
     if (vec)
