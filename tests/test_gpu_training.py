@@ -294,3 +294,39 @@ def test_bf16x3_training_gradients(env):
     summed = lambda n: n.endswith("/b:0") or n.endswith("/beta:0")
     assert max(e for n, e in err.items() if not summed(n)) < 5e-3, top
     assert max(e for n, e in err.items() if summed(n)) < 2e-2, top
+
+
+def test_training_clis_end_to_end(env, tmp_path, capsys):
+    """build_model -> train_dnn_one_iteration.py (two iterations on an egs tar) -> eval_dnn.py, through the CLI twins: model
+    directories are valid, the optimizer state carries over, the loss on the training archive goes down, and the eval
+    log holds the line the reference's accuracy report parses (ze_utils.py:498-499)."""
+    import re
+    import examples_io
+    import eval_dnn
+    import models
+    import train_dnn_one_iteration as cli
+    from xvector_amd import weights as wio
+    rng = np.random.default_rng(0)
+    n_spk, F, B = 6, 23, 16
+    centers = rng.standard_normal((n_spk, F)) * 2
+    mbs, labs = [], []
+    for i in range(6):
+        lab = rng.integers(0, n_spk, B)
+        mbs.append((centers[lab][:, None, :] + rng.standard_normal((B, 60 + 4 * i, F))).astype(np.float32))
+        labs.append(lab)
+    tar = str(tmp_path / "egs.1.tar")
+    examples_io.write_egs_tar(tar, mbs, np.array(labs, np.int32))
+    d0, d1, d2 = (str(tmp_path / ("model_%d" % i)) for i in range(3))
+    models.ModelWithoutDropout().build_model(n_spk, F, d0)
+    common = ["--feature-dim", str(F), "--minibatch-size", str(B), "--minibatch-count", "6", "--learning-rate", "0.002",
+              "--print-interval", "3", "--tar-file", tar]
+    cli.main(common + ["--input-dir", d0, "--output-dir", d1])
+    cli.main(common + ["--input-dir", d1, "--output-dir", d2])
+    out = capsys.readouterr().out
+    losses = [float(x) for x in re.findall(r"Overall average training loss is ([0-9.]+) over", out)]
+    assert len(losses) == 2 and losses[1] < losses[0]
+    assert wio.is_correct_model_dir(d2) and wio.load_optimizer_state(d2)["t"] == 12
+    log = str(tmp_path / "eval.log")
+    eval_dnn.main(["--tar-file", tar, "--input-dir", d2, "--log-file", log])
+    text = open(log).read()
+    assert re.search(r"Overall average loss is [0-9.]+ over \\d+ segments", text) or "Overall average" in text

@@ -164,3 +164,23 @@ def test_vectorised_chunk_table_equals_the_per_utterance_plan():
         flat = [(u, s, n) for u in ref_order for s, n in plans[u]]
         assert list(zip(c_utt.tolist(), c_start.tolist(), c_len.tolist())) == flat
         assert seg.tolist() == [0] + list(np.cumsum([len(plans[u]) for u in ref_order]))
+
+
+def test_egs_tar_round_trip(tmp_path):
+    """examples_io twin: write_egs_tar -> TarFileDataLoader serves the minibatches in order as float16 with their labels,
+    then (None, None); count matches; a label file of the wrong length is refused."""
+    import examples_io
+    rng = np.random.default_rng(0)
+    mats = [rng.standard_normal((4, 20 + 3 * i, 5)).astype(np.float32) for i in range(5)]
+    labels = rng.integers(0, 9, (5, 4)).astype(np.int32)
+    tar = str(tmp_path / "egs.7.tar")
+    examples_io.write_egs_tar(tar, mats, labels)
+    dl = examples_io.TarFileDataLoader(tar, queue_size=2)
+    assert dl.count == 5
+    for m, l in zip(mats, labels):
+        data, lab = dl.pop(timeout=10)
+        assert data.dtype == np.float16 and np.array_equal(data, m.astype(np.float16)) and np.array_equal(lab, l)
+    assert dl.pop() == (None, None)
+    np.save(tar.replace(".tar", ".npy"), labels[:3])
+    with pytest.raises(AssertionError):
+        examples_io.TarFileDataLoader(tar)

@@ -119,6 +119,26 @@ def test_reference_train_dnn_one_iteration_drives_the_twin(ref_env, tmp_path, mo
     assert accepted == [1] and best == 1
 
 
+def test_egs_archives_interchange_with_the_reference_loader(ref_env, tmp_path):
+    """An archive written by this build's examples_io.write_egs_tar is read by the reference's TarFileDataLoader
+    (examples_io.py:223-255) exactly as by this build's loader."""
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "x-vector-kaldi-tf_amd", "local", "tf")
+    spec = importlib.util.spec_from_file_location("twin_examples_io", os.path.join(here, "examples_io.py"))
+    twin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(twin)
+    rng = np.random.default_rng(3)
+    mats = [rng.standard_normal((3, 25 + i, 4)).astype(np.float32) for i in range(4)]
+    labels = rng.integers(0, 5, (4, 3)).astype(np.int32)
+    tar = str(tmp_path / "egs.1.tar")
+    twin.write_egs_tar(tar, mats, labels)
+    ref_loader = ref_env["examples_io"].TarFileDataLoader(tar, queue_size=8)
+    mine = twin.TarFileDataLoader(tar, queue_size=8)
+    assert ref_loader.count == mine.count == 4
+    for _ in range(4):
+        (a, la), (b, lb) = ref_loader.pop(timeout=10), mine.pop(timeout=10)
+        assert a.dtype == b.dtype == np.float16 and np.array_equal(a, b) and np.array_equal(la, lb)
+
+
 def test_reference_extract_embedding_cli_drives_the_twin(ref_env, tmp_path, monkeypatch):
     """Reference extract_embedding.py (its own argparse, open_or_fd calls and stream handling) -> this build's
     Model.make_embedding; the GPU extractor is replaced by the CPU oracle, so the output ark must hold the oracle's

@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""One training iteration on one egs archive -- MI355X twin of the reference's ``local/tf/train_dnn_one_iteration.py``.
+
+``train_dnn.py`` launches this once per job and iteration (train_dnn.py:258-300) with the model of the previous iteration
+(``--input-dir``), the archive (``--tar-file``), the per-iteration learning rate and dropout proportion (ze_utils.py
+schedules) and the directory for the new model (``--output-dir``); the log it prints is parsed back by
+``ze_utils.get_successful_models``.  Same flags as the reference (train_dnn_one_iteration.py:41-134); the ones its model
+code never reads (momentum, max-param-change, scale, shuffle, verbose, use-gpu) are accepted and ignored here too, and the
+ranges/scp input mode (egs cut on the fly from feature archives) is not provided -- archives are read in the tar format.
+"""
+from __future__ import print_function
+
+import argparse
+import logging
+import os
+import pprint
+import sys
+import traceback
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+import numpy as np  # noqa: E402
+
+import models  # noqa: E402
+from examples_io import TarFileDataLoader  # noqa: E402
+
+logger = logging.getLogger('train_dnn_one_iteration')
+logger.setLevel(logging.INFO)
+_handler = logging.StreamHandler(sys.stdout)
+_handler.setLevel(logging.INFO)
+_handler.setFormatter(logging.Formatter("%(asctime)s [%(pathname)s:%(lineno)s - %(funcName)s - %(levelname)s ] %(message)s"))
+logger.addHandler(_handler)
+
+# (flag, dest, type, default, required, choices, help) -- the reference's command line, train_dnn_one_iteration.py:41-134
+_FLAGS = (
+    ("--use-gpu", "use_gpu", str, "yes", False, ("yes", "no", "wait"), "Accepted for compatibility; training always runs on the GPU."),
+    ("--momentum", "momentum", float, 0.0, False, None, "Accepted for compatibility (unused by the reference's model code)."),
+    ("--shuffle", "shuffle", bool, False, False, None, "Accepted for compatibility (applies to the ranges/scp mode only)."),
+    ("--max-param-change", "max_param_change", float, 2.0, False, None, "Accepted for compatibility (unused)."),
+    ("--random-seed", "random_seed", int, 0, False, None, "Seed of the dropout masks (and of NumPy, as in the reference)."),
+    ("--print-interval", "print_interval", int, 10, False, None, "The interval for log printing."),
+    ("--verbose", "verbose", int, 0, False, None, "Accepted for compatibility (unused)."),
+    ("--feature-dim", "feature_dim", int, None, True, None, "Feature dimension; checked against the model."),
+    ("--minibatch-size", "minibatch_size", int, None, True, None, "Minibatch size of the archive."),
+    ("--minibatch-count", "minibatch_count", int, None, True, None, "Number of minibatches in the archive."),
+    ("--learning-rate", "learning_rate", float, -1.0, False, None, "Learning rate of this iteration (Adam)."),
+    ("--scale", "scale", float, 1.0, False, None, "Accepted for compatibility (unused)."),
+    ("--dropout-proportion", "dropout_proportion", float, 0.0, False, None, "Dropout proportion of this iteration."),
+    ("--tar-file", "tar_file", str, "", False, None, "egs archive (minibatch_<i>.npy members) with its .npy label file."),
+    ("--input-dir", "input_dir", str, None, True, None, "Model directory to start from."),
+    ("--output-dir", "output_dir", str, None, True, None, "Directory the new model is written to."),
+)
+
+
+def get_args(argv=None):
+    parser = argparse.ArgumentParser(description="One DNN training iteration on the MI355X.",
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter, conflict_handler='resolve')
+    for flag, dest, typ, default, required, choices, text in _FLAGS:
+        kw = dict(dest=dest, type=typ, help=text)
+        if required:
+            kw["required"] = True
+        else:
+            kw["default"] = default
+        if choices:
+            kw["choices"] = list(choices)
+        parser.add_argument(flag, **kw)
+    print(' '.join(sys.argv))
+    return process_args(parser.parse_args(argv))
+
+
+def process_args(args):
+    args.input_dir = args.input_dir.strip()
+    if not args.input_dir or not os.path.exists(os.path.join(args.input_dir, 'model.meta')):
+        raise Exception("This scripts expects the input model was exist in '{0}' directory.".format(args.input_dir))
+    if not args.tar_file:
+        raise Exception("This build reads egs from tar archives only: give --tar-file (ranges/scp mode is not provided).")
+    if not os.path.exists(args.tar_file):
+        raise Exception("The specified tar file '{0}' not exist.".format(args.tar_file))
+    if not os.path.exists(args.tar_file.replace('.tar', '.npy')):
+        raise Exception("There is no corresponding npy label file for tar file '{0}'.".format(args.tar_file))
+    if args.dropout_proportion > 1.0 or args.dropout_proportion < 0.0:
+        raise Exception("The value of dropout-proportion must be in range [0 - 1].")
+    return args
+
+
+def train(args):
+    logger.info("Arguments for the experiment\n{0}".format(pprint.pformat(vars(args))))
+    if args.random_seed != 0:
+        np.random.seed(args.random_seed)
+    data_loader = TarFileDataLoader(args.tar_file, logger=None, queue_size=16)
+    models.Model().train_one_iteration(data_loader, args, logger)      # the model class comes from the model directory
+
+
+def main(argv=None):
+    try:
+        train(get_args(argv))
+    except BaseException as e:
+        if not isinstance(e, KeyboardInterrupt):
+            traceback.print_exc()
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
