@@ -30,7 +30,8 @@ logger = logging.getLogger('train_dnn_one_iteration')
 logger.setLevel(logging.INFO)
 _handler = logging.StreamHandler(sys.stdout)
 _handler.setLevel(logging.INFO)
-_handler.setFormatter(logging.Formatter("%(asctime)s [%(pathname)s:%(lineno)s - %(funcName)s - %(levelname)s ] %(message)s"))
+LOG_FORMAT = logging.Formatter("%(asctime)s [%(pathname)s:%(lineno)s - %(funcName)s - %(levelname)s ] %(message)s")
+_handler.setFormatter(LOG_FORMAT)
 logger.addHandler(_handler)
 
 # (flag, dest, type, default, required, choices, help) -- the reference's command line, train_dnn_one_iteration.py:41-134
@@ -54,10 +55,12 @@ _FLAGS = (
 )
 
 
-def get_args(argv=None):
-    parser = argparse.ArgumentParser(description="One DNN training iteration on the MI355X.",
-                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter, conflict_handler='resolve')
-    for flag, dest, typ, default, required, choices, text in _FLAGS:
+def parse_flags(table, description, argv=None):
+    """argparse from a (flag, dest, type, default, required, choices, help) table; echoes the command line like the
+    reference's scripts do."""
+    parser = argparse.ArgumentParser(description=description, formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                                     conflict_handler='resolve')
+    for flag, dest, typ, default, required, choices, text in table:
         kw = dict(dest=dest, type=typ, help=text)
         if required:
             kw["required"] = True
@@ -67,21 +70,31 @@ def get_args(argv=None):
             kw["choices"] = list(choices)
         parser.add_argument(flag, **kw)
     print(' '.join(sys.argv))
-    return process_args(parser.parse_args(argv))
+    return parser.parse_args(argv)
 
 
-def process_args(args):
+def check_model_dir(path):
+    path = (path or "").strip()
+    if not path or not os.path.exists(os.path.join(path, 'model.meta')):
+        raise Exception("no model found in '%s' (model.meta is missing)" % path)
+
+
+def check_archive(tar_file):
+    if not tar_file or not os.path.exists(tar_file):
+        raise Exception("egs archive '%s' does not exist" % tar_file)
+    if not os.path.exists(tar_file.replace('.tar', '.npy')):
+        raise Exception("egs archive '%s' has no label file next to it (.npy)" % tar_file)
+
+
+def get_args(argv=None):
+    args = parse_flags(_FLAGS, "One DNN training iteration on the MI355X.", argv)
+    check_model_dir(args.input_dir)
     args.input_dir = args.input_dir.strip()
-    if not args.input_dir or not os.path.exists(os.path.join(args.input_dir, 'model.meta')):
-        raise Exception("This scripts expects the input model was exist in '{0}' directory.".format(args.input_dir))
     if not args.tar_file:
-        raise Exception("This build reads egs from tar archives only: give --tar-file (ranges/scp mode is not provided).")
-    if not os.path.exists(args.tar_file):
-        raise Exception("The specified tar file '{0}' not exist.".format(args.tar_file))
-    if not os.path.exists(args.tar_file.replace('.tar', '.npy')):
-        raise Exception("There is no corresponding npy label file for tar file '{0}'.".format(args.tar_file))
-    if args.dropout_proportion > 1.0 or args.dropout_proportion < 0.0:
-        raise Exception("The value of dropout-proportion must be in range [0 - 1].")
+        raise Exception("this build reads egs from tar archives only: give --tar-file (the ranges/scp mode is not provided)")
+    check_archive(args.tar_file)
+    if not 0.0 <= args.dropout_proportion <= 1.0:
+        raise Exception("--dropout-proportion must lie in [0, 1]")
     return args
 
 
