@@ -486,9 +486,25 @@ inline unsigned gs_blocks(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ?
 
 extern "C" {
 
+// Row splits of a wgrad launch: at least ceil(R/4096), then as many more as still fit into the same number of rounds of
+// 512 resident workgroups (256 CUs x 2) -- a 19 k-row minibatch with 112 (tap, tile) pairs ran 560 workgroups = 1.09
+// rounds before, i.e. the chip half empty for the second round; 9 splits make it 1008 = 1.97 rounds.  Splits never get
+// shorter than 512 rows, and the merge order stays fixed (deterministic).
+static long wgrad_splits(int64_t R, int cin, int cout, int K)
+{
+    if (R <= 4096) return 1;
+    const long tiles = (long)K * ((cin + WT - 1) / WT) * ((cout + WT - 1) / WT);
+    const long s0 = (R + 4095) / 4096;
+    const long rounds = (tiles * s0 + 511) / 512;
+    long s = (512 * rounds) / tiles;
+    const long smax = (R + 511) / 512;
+    if (s > smax) s = smax;
+    return s < s0 ? s0 : s;
+}
+
 size_t xv_wgrad_workspace_bytes(int64_t R, int cin, int cout, int K)
 {
-    const long splits = R <= 4096 ? 1 : (R + 4095) / 4096;
+    const long splits = wgrad_splits(R, cin, cout, K);
     return splits <= 1 ? 0 : (size_t)splits * K * cin * (size_t)cout * sizeof(float);
 }
 
@@ -500,7 +516,7 @@ int xv_wgrad_f32(const float *x, int ldx, const float *dz, int lddz, int64_t R, 
     WgradParams p{};
     p.x = x; p.dz = dz; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.cout = cout; p.lddz = lddz; p.K = K; p.dil = dilation;
     p.n_ct = (cin + WT - 1) / WT; p.n_ot = (cout + WT - 1) / WT;
-    const long splits = R <= 4096 ? 1 : (R + 4095) / 4096;
+    const long splits = wgrad_splits(R, cin, cout, K);
     p.rows_per_split = ((R + splits - 1) / splits + WR - 1) / WR * WR;
     if (splits > 1 && !workspace) return tfail(XV_ERR_BAD_ARG, "wgrad: workspace required");
     p.out = splits > 1 ? (float *)workspace : dw;
