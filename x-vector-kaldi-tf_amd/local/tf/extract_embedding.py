@@ -105,6 +105,20 @@ def _open_output(wspecifier, ark, scp):
     return kaldi_io.open_or_fd(wspecifier, 'wb')
 
 
+class _Discard(object):
+    """Output sink of the non-root ranks (they write nothing: make_embedding gathers on rank 0)."""
+    mode = "wb"
+
+    def write(self, data):
+        return len(data)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class _Null(object):
     def __enter__(self):
         return None
@@ -131,14 +145,18 @@ def eval_dnn(args):
     if ark is not None and os.path.exists(ark) and scp is not None and os.path.exists(scp):
         logger.info('Both output ark and scp files exist. Return from this call.')
         return
+    # under torchrun (one process per GPU) every rank reads the features, but only rank 0 owns the output table
+    root = int(os.environ.get("RANK", "0")) == 0
     model = Model()
     vad = _open_table(args.vad_rspecifier, kaldi_io.read_vec_flt_scp, kaldi_io.read_vec_flt_ark) if args.vad_rspecifier else None
     feats = _open_table(args.feature_rspecifier, kaldi_io.read_mat_scp, None)
     with (kaldi_io.open_or_fd(args.feature_rspecifier) if feats is None else _Null()) as input_fid:
-        with _open_output(wspecifier, ark, scp) as output_fid:
+        with (_open_output(wspecifier, ark, scp) if root else _Discard()) as output_fid:
             model.make_embedding(input_fid if feats is None else feats, output_fid, args.model_dir, args.min_chunk_size,
                                  args.chunk_size, use_gpu, logger, vad_stream=vad, cmn_window=args.cmn_window,
                                  cmn_center=args.cmn_center == 'yes')
+    if not root:
+        return
     if ark is not None:
         os.rename(ark + '.tmp.ark', ark)
     if scp is not None:
