@@ -33,7 +33,23 @@ def init_process_group(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # RCCL prints a five-line version banner through C stdio's stdout when its first communicator is created;
+            # callers of this package promise machine-readable stdout (bench.py: ONE JSON line), so fd 1 points at
+            # stderr while the communicator is brought up (a barrier forces it) and the C buffers are flushed
+            import ctypes
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+                dist.barrier()
+                ctypes.CDLL(None).fflush(None)
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 
 
