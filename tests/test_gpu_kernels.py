@@ -100,6 +100,28 @@ def test_tdnn_layer_matches_oracle(env, cin, cout, K, dil, act):
     assert (yh[~valid] == 0).all()
 
 
+def test_fp32_gemm_both_tile_heights(env):
+    """The exact-fp32 GEMM picks 64-row workgroup tiles when 128-row tiles would not fill 1.5 rounds of the chip and 128-row
+    tiles otherwise: the same layer on a small batch (64-row form) and on a 26 k-row batch (128-row form) against the oracle,
+    and the chunks common to both batches must come out bit-identical (tile height must not change the arithmetic)."""
+    oracle = env["oracle"]
+    rng = np.random.default_rng(9)
+    cin, cout, K = 64, 512, 5
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    small = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in (130, 25, 257)]
+    big = small + [(rng.standard_normal((300, cin)) * 2).astype(np.float32) for _ in range(85)]
+    outs_s, _, lay_s, _ = _run_layer(env, small, w, b, bn, "relu", None, K, 1)
+    outs_b, _, lay_b, _ = _run_layer(env, big, w, b, bn, "relu", None, K, 1)
+    assert (lay_s.rows + 127) // 128 * 4 < 768 <= (lay_b.rows + 127) // 128 * 4
+    for m, a, c in zip(small, outs_s, outs_b):
+        assert oracle.rel_l2(a, oracle.tdnn_layer(m, w, b, bn, "relu", None, 1, np.float64)) < TOL_GEMM
+        assert np.array_equal(a, c)
+    for i in (3, 40, 87):
+        assert oracle.rel_l2(outs_b[i], oracle.tdnn_layer(big[i], w, b, bn, "relu", None, 1, np.float64)) < TOL_GEMM
+
+
 @pytest.mark.parametrize("fmt", ["f32", "split"])
 @pytest.mark.parametrize("cin,cout,K,dil,act", [
     (24, 512, 5, 1, "relu"),        # layer 0 with the 23 MFCC dims padded to 24 columns

@@ -81,12 +81,13 @@ __device__ __forceinline__ float apply_act(float z, int act, float a)
 
 // Fused epilogue shared by the fp32 and the bf16x3 GEMM kernels.
 // D layout of a 32x32 MFMA tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <int WROWS>      // rows of the tile one wave owns: 64 (two 32-row MFMA blocks) or 32 (one)
 __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, const uint8_t *Ms, long m0, int n0, int wr, int wc,
                                               int lane, const f32x16 &acc00, const f32x16 &acc01, const f32x16 &acc10,
                                               const f32x16 &acc11)
 {
     const int colb = n0 + wc * 64 + (lane & 31);
-    const int rowb = wr * 64 + 4 * (lane >> 5);
+    const int rowb = wr * WROWS + 4 * (lane >> 5);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         const int gc = colb + cb * 32;
@@ -96,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, const uint8_t
         const float sh = p.shift ? p.shift[gc] : 0.f;
         const float al = (p.act == XV_ACT_LRELU) ? p.alpha[0] : (p.act == XV_ACT_PRELU ? p.alpha[gc] : 0.f);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < WROWS / 32; ++rb) {
             const f32x16 &a = (rb == 0) ? (cb == 0 ? acc00 : acc01) : (cb == 0 ? acc10 : acc11);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -117,9 +118,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, const uint8_t
 
 // VEC: Cin % 4 == 0 and 16-B aligned rows -> dwordx4 staging loads; otherwise dword loads (the
 // 23-dim MFCC input layer).
-template <bool VEC>
+// BMT: rows per workgroup tile, 128 or 64.  The 64-row form (each wave one 32-row MFMA block x two column blocks) exists
+// for small problems -- a training minibatch of 19 k rows makes 608 128-row tiles on Cout = 512, i.e. 1.19 rounds of the
+// 512 resident workgroups; 1216 half-size tiles are 2.4 rounds of half the length.
+template <bool VEC, int BMT>
 __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
 {
+    constexpr int WROWS = BMT / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                                 // [2][A_ROWS][LDS_LD]
     float *Bs = smem + 2 * A_ROWS * LDS_LD;           // [2][BN][LDS_LD]
@@ -138,22 +143,22 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
     const int q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
-    const long m0 = (long)mt * BM;
+    const long m0 = (long)mt * BMT;
     const int n0 = nt * BN;
 
     const int span = (p.K - 1) * p.dil;
     const int left = span >> 1;
-    const int rowsA = BM + span;
+    const int rowsA = BMT + span;
     const int n_chunks = (p.cin + BK - 1) / BK;
     const int n_stages = n_chunks * p.K;
 
-    if (tid < BM) {
+    if (tid < BMT) {
         const long gr = m0 + tid;
         Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
     }
 
     constexpr int B_REGS = VEC ? 4 : 16;
-    constexpr int A_REGS = VEC ? 5 : 17;
+    constexpr int A_REGS = VEC ? ((BMT + MAX_SPAN) * 8 + NT - 1) / NT : ((BMT + MAX_SPAN) * 32 + NT - 1) / NT;
     typedef typename std::conditional<VEC, f32x4, float>::type stage_t;
     stage_t breg[B_REGS];
     stage_t areg[A_REGS];
@@ -220,10 +225,10 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
             const int f = tid + NT * j;
             if constexpr (VEC) {
                 const int lr = f >> 3;
-                if (lr < A_ROWS) *reinterpret_cast<f32x4 *>(dst + lr * LDS_LD + (f & 7) * 4) = areg[j];
+                if (lr < BMT + MAX_SPAN) *reinterpret_cast<f32x4 *>(dst + lr * LDS_LD + (f & 7) * 4) = areg[j];
             } else {
                 const int lr = f >> 5;
-                if (lr < A_ROWS) dst[lr * LDS_LD + (f & 31)] = areg[j];
+                if (lr < BMT + MAX_SPAN) dst[lr * LDS_LD + (f & 31)] = areg[j];
             }
         }
     };
@@ -249,20 +254,23 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
         }
 
         const float *Ab = As + (chunk & 1) * (A_ROWS * LDS_LD) +
-                          (wr * 64 + (lane & 31) + tap * p.dil) * LDS_LD + (lane >> 5) * 4;
+                          (wr * WROWS + (lane & 31) + tap * p.dil) * LDS_LD + (lane >> 5) * 4;
         const float *Bb = Bs + (s & 1) * (BN * LDS_LD) + (wc * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Ab + kk * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(Ab + 32 * LDS_LD + kk * 8);
+            f32x4 a1 = a0;
+            if constexpr (BMT == 128) a1 = *reinterpret_cast<const f32x4 *>(Ab + 32 * LDS_LD + kk * 8);
             const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Bb + kk * 8);
             const f32x4 b1 = *reinterpret_cast<const f32x4 *>(Bb + 32 * LDS_LD + kk * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc00, 0, 0, 0);
                 acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
+                if constexpr (BMT == 128) {
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
+                }
             }
         }
 
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
         tap = ntap;
     }
 
-    gemm_epilogue(p, Ms, m0, n0, wr, wc, lane, acc00, acc01, acc10, acc11);
+    gemm_epilogue<WROWS>(p, Ms, m0, n0, wr, wc, lane, acc00, acc01, acc10, acc11);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -940,24 +948,27 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
     if (p.ldx < p.cin || p.ldy < p.cout) return fail(XV_ERR_BAD_ARG, "tdnn: leading dimension too small");
     if ((p.act == XV_ACT_LRELU || p.act == XV_ACT_PRELU) && !p.alpha) return fail(XV_ERR_BAD_ARG, "tdnn: act_alpha is NULL");
     p.kred = p.K * p.cin;
-    p.n_mt = (int)((p.R + BM - 1) / BM);
     p.n_nt = (p.cout + BN - 1) / BN;
+    // 64-row tiles when 128-row tiles would leave the chip with fewer than 1.5 rounds of resident workgroups
+    const bool small = ((p.R + BM - 1) / BM) * p.n_nt < 768;
+    const int bmt = small ? 64 : BM;
+    p.n_mt = (int)((p.R + bmt - 1) / bmt);
     const bool vec = (p.cin % 4 == 0) && (p.ldx % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) && (((uintptr_t)p.wp) % 16 == 0);
+    typedef void (*kern_t)(const GemmParams);
+    const kern_t all[] = {tdnn_gemm_kernel<true, 128>, tdnn_gemm_kernel<false, 128>, tdnn_gemm_kernel<true, 64>,
+                          tdnn_gemm_kernel<false, 64>};
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t e = hipFuncSetAttribute((const void *)tdnn_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-        e = hipFuncSetAttribute((const void *)tdnn_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        for (kern_t k : all) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        }
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const dim3 grid((unsigned)(p.n_mt * p.n_nt));
-    if (vec)
-        hipLaunchKernelGGL(tdnn_gemm_kernel<true>, grid, dim3(NT), GEMM_LDS_BYTES, st, p);
-    else
-        hipLaunchKernelGGL(tdnn_gemm_kernel<false>, grid, dim3(NT), GEMM_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(all[(small ? 2 : 0) + (vec ? 0 : 1)], grid, dim3(NT), GEMM_LDS_BYTES, st, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_kernel launch");
 }
