@@ -30,6 +30,46 @@ variants = {
     "nowait": base.replace(W, "                __syncthreads();"),
     "nobarrier": base.replace(W, '                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");'),
 }
+# per-workgroup timeline: p.ypre is re-used as a trace buffer [n_wg][8] of int64 (wall clock 100 MHz, HW_ID)
+def traced(text):
+    i0 = text.index("void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)")
+    i1 = text.index("int launch_gemm3") + len("int launch_gemm3")
+    return text[:i0] + _traced(text[i0:i1]) + text[i1:]
+
+
+def _traced(text):
+    t = text.replace("if (p.ypre) {", "if (false) {")
+    assert t.count("if (p.y && p.y_split && !p.ypre && n0 + BN <= p.cout) {") == 1
+    t = t.replace("if (p.y && p.y_split && !p.ypre && n0 + BN <= p.cout) {", "if (p.y && p.y_split && n0 + BN <= p.cout) {")
+    a0 = "    if (tid < BM) {\n        const long gr = m0 + tid;\n        Ms[tid] ="
+    assert t.count(a0) == 1
+    t = t.replace(a0, "    long long *trc = reinterpret_cast<long long *>(p.ypre) + (size_t)blockIdx.x * 8;  /*clk*/\n"
+                      "    if (tid == 0) { trc[0] = wall_clock64(); trc[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); trc[5] = (long long)wg | ((long long)(__builtin_readcyclecounter() & 0xffffffffffll) << 24); trc[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)); }\n" + a0)
+    a1 = "    Frags F = {}, G = {};\n    load_frags(F, 0, 0, 0, 0);"
+    assert t.count(a1) == 1
+    t = t.replace(a1, "    if (tid == 0) trc[1] = wall_clock64();\n" + a1)
+    a2 = "    float *T = reinterpret_cast<float *>(lds);\n    {\n        const int col = wc * 64 + (lane & 31);"
+    assert t.count(a2) == 1
+    t = t.replace(a2, "    if (tid == 0) trc[2] = wall_clock64();\n" + a2)
+    # end of kernel: the non-POOL epilogue loop closes with "        }\n    }\n}\n\nint launch_gemm3"
+    a3 = "        }\n    }\n}\n\nint launch_gemm3"
+    assert t.count(a3) == 1
+    t = t.replace(a3, "        }\n    }\n    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();\n}\n\nint launch_gemm3")
+    b1 = "    const int cg = tid & 15;                            // 8-channel group of the 128-column tile"
+    assert t.count(b1) == 1
+    t = t.replace(b1, "    if (tid == 0) trc[7] = wall_clock64();\n" + b1)
+    f1 = "        else rows(std::false_type{});\n        return;"
+    assert t.count(f1) == 1
+    t = t.replace(f1, "        else rows(std::false_type{});\n        if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n"
+                      "        __builtin_amdgcn_s_waitcnt(0);\n        if (tid == 0) { trc[3] = wall_clock64(); trc[4] = (trc[4] & 0xffffff) | ((long long)(__builtin_readcyclecounter() & 0xffffffffffll) << 24); }\n        return;")
+    t = t.replace("    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();", "    if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();")
+    return t
+variants["trace"] = traced(base)
+EPI = "    float *T = reinterpret_cast<float *>(lds);\n    {\n        const int col = wc * 64 + (lane & 31);"
+assert base.count(EPI) == 1
+variants["epiprio"] = base.replace(EPI, "    __builtin_amdgcn_s_setprio(3);\n" + EPI)
+variants["trace_epiprio"] = traced(variants["epiprio"])
+
 procs = []
 for name, text in variants.items():
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
