@@ -58,9 +58,9 @@ def _traced(text):
     b1 = "    const int cg = tid & 15;                            // 8-channel group of the 128-column tile"
     assert t.count(b1) == 1
     t = t.replace(b1, "    if (tid == 0) trc[7] = wall_clock64();\n" + b1)
-    f1 = "        else rows(std::false_type{});\n        return;"
+    f1 = "        else run(std::integral_constant<int, 0>{});\n        return;"
     assert t.count(f1) == 1
-    t = t.replace(f1, "        else rows(std::false_type{});\n        if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n"
+    t = t.replace(f1, "        else run(std::integral_constant<int, 0>{});\n        if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n"
                       "        __builtin_amdgcn_s_waitcnt(0);\n        if (tid == 0) { trc[3] = wall_clock64(); trc[4] = (trc[4] & 0xffffff) | ((long long)(__builtin_readcyclecounter() & 0xffffffffffll) << 24); }\n        return;")
     t = t.replace("    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();", "    if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();")
     return t

@@ -734,14 +734,15 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
             keep[j] = Ms[lr] ? 1.f : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
-        auto rows = [&](auto LRELU) {
+        auto rows = [&](auto MODE) {                   // 0: max(z,0) + alpha*min(z,0)   1: leaky max(alpha*z, z)   2: plain ReLU
+            constexpr int mode = decltype(MODE)::value;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 n += keep[j];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
-                    const float a = decltype(LRELU)::value ? fmaxf(al[i] * z, z) : fmaxf(z, 0.f) + al[i] * fminf(z, 0.f);
+                    const float a = mode == 1 ? fmaxf(al[i] * z, z) : mode == 2 ? fmaxf(z, 0.f) : fmaxf(z, 0.f) + al[i] * fminf(z, 0.f);
                     const float v = a * sc[i] + sh[i];
                     if (j == 0) { v0[i] = v; s1[i] = 0.f; s2[i] = 0.f; }
                     else {
@@ -752,8 +753,9 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
                 }
             }
         };
-        if (lrelu) rows(std::true_type{});
-        else rows(std::false_type{});
+        if (lrelu) rows(std::integral_constant<int, 1>{});
+        else if (p.act == XV_ACT_RELU) rows(std::integral_constant<int, 2>{});
+        else rows(std::integral_constant<int, 0>{});
         // row 0 of a block is valid whenever any row is (chunks start on block boundaries, gaps follow the frames)
         const float rn = n > 0.f ? 1.f / n : 0.f;
         float mean[8], m2[8];
@@ -793,7 +795,11 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
             keep[j] = Ms[lr] ? 1.f : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
-        auto rows = [&](auto LRELU) {
+        // every instruction here competes with the co-resident workgroup's MFMA stream for issue slots (an epilogue takes
+        // 5-15 us of wall time for ~500 VALU instructions), so the common cases are specialised at compile time: plain ReLU
+        // (no alpha term) and threads none of whose 8 rows is a gap row (no mask multiply; ~99 % of threads)
+        auto rows = [&](auto MODE, auto MASKED) {
+            constexpr int mode = decltype(MODE)::value;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const long gr = m0 + (tid >> 4) + 16 * j;
@@ -801,8 +807,9 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
-                    const float a = decltype(LRELU)::value ? fmaxf(al[i] * z, z) : fmaxf(z, 0.f) + al[i] * fminf(z, 0.f);
-                    const float v = (a * sc[i] + sh[i]) * keep[j];
+                    const float a = mode == 1 ? fmaxf(al[i] * z, z) : mode == 2 ? fmaxf(z, 0.f) : fmaxf(z, 0.f) + al[i] * fminf(z, 0.f);
+                    float v = a * sc[i] + sh[i];
+                    if constexpr (decltype(MASKED)::value) v *= keep[j];
                     hi[i] = (__bf16)v;
                     lo[i] = (__bf16)(v - (float)hi[i]);
                 }
@@ -812,8 +819,14 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
                 __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8 *>(row + (((4 + slot) ^ sw) << 4)));
             }
         };
-        if (lrelu) rows(std::true_type{});
-        else rows(std::false_type{});
+        const bool masked = keep[0] * keep[1] * keep[2] * keep[3] * keep[4] * keep[5] * keep[6] * keep[7] == 0.f;
+        auto run = [&](auto MODE) {
+            if (masked) rows(MODE, std::true_type{});
+            else rows(MODE, std::false_type{});
+        };
+        if (lrelu) run(std::integral_constant<int, 1>{});
+        else if (p.act == XV_ACT_RELU) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 0>{});
         return;
     }
 #pragma unroll
