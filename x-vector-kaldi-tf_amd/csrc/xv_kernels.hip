@@ -1283,7 +1283,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 6; }
+int xv_version(void) { return 7; }
 
 const char *xv_last_error(void) { return g_err; }
 
