@@ -14,6 +14,7 @@ Fixtures
                         key was run with, and the exact output ark bytes of the reference driver
   schedules.npz         reference ze_utils.get_learning_rate / get_dropout_edit_string (ze_utils.py:111-120, 310-443)
                         evaluated on grids of arguments (SURVEY §8c golden 4)
+  egs_ranges.npz        what the reference's ranges/scp loader (examples_io.py:12-75,188-221) serves for a toy table
   forward_default.npz   fp64-oracle x-vectors (default + dilated topology, trained-like weights from
                         seed) for T in {25,200,400,1000}; sub-sampled per-layer tensors for T=25
 Usage:  python tests/golden/make_golden.py
@@ -223,11 +224,74 @@ def golden_schedules(out):
           (len(lr_vals), table.shape[0], table.shape[1], bad_raises))
 
 
+def golden_egs_ranges(out):
+    """Reference examples_io.process_range_file + load_ranges_data + DataLoader (the ranges/scp input mode of
+    train_dnn_one_iteration.py:177-200): the minibatches it serves, in the order it serves them, for a toy feature
+    table and ranges file, with --shuffle and a seed as train() applies them."""
+    import tempfile
+    h5 = types.ModuleType("h5py")
+    sys.modules.setdefault("h5py", h5)
+    sys.path.insert(0, REF)
+    sys.modules["kaldi_io"] = sys.modules["ref_kaldi_io"]
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_examples_io", os.path.join(REF, "examples_io.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    sys.path.remove(REF)
+    del sys.modules["kaldi_io"]
+    ref_io = sys.modules["ref_kaldi_io"]
+    rng = np.random.default_rng(42)
+    F, B, count = 6, 4, 5
+    utts = [("utt%02d" % i, (rng.standard_normal((int(t), F)) * 2).astype(np.float32)) for i, t in enumerate(rng.integers(90, 160, 9))]
+    lens = [20, 35, 27, 20, 31]                                  # one chunk length per minibatch (create_egs.py:508-513)
+    lines = []
+    slots = [(mb, k) for mb in range(count) for k in range(B)]
+    rng.shuffle(slots)
+    for n, (mb, k) in enumerate(slots):
+        u = int(rng.integers(0, len(utts)))
+        off = int(rng.integers(0, utts[u][1].shape[0] - lens[mb]))
+        lines.append("%s %d %d %d %d %d" % (utts[u][0], mb, 100 + mb, off, lens[mb], int(rng.integers(0, 7))))
+    lines.sort(key=lambda l: l.split()[0])                       # ranges files are grouped by utterance
+    tmp = tempfile.mkdtemp()
+    ark, scp, rng_file = os.path.join(tmp, "feats.ark"), os.path.join(tmp, "feats.scp"), os.path.join(tmp, "ranges.1")
+    used = set(l.split()[0] for l in lines)      # the recipe filters the scp to the archive's utterances (train_dnn.py:259)
+    utts = [(k, m) for k, m in utts if k in used]
+    with open(ark, "wb") as f, open(scp, "wt") as g:
+        for k, m in utts:
+            f.write((k + " ").encode())
+            g.write("%s %s:%d\n" % (k, ark, f.tell()))
+            ref_io.write_mat(f, m)
+    open(rng_file, "wt").write("\n".join(lines) + "\n")
+    res = {}
+    for tag, shuffle, seed in (("plain", False, 0), ("shuffled", True, 11)):
+        u2c, info = ex.process_range_file(rng_file, count, B)
+        data, labels = ex.load_ranges_data(u2c, info, B, scp, F)
+        if seed:
+            np.random.seed(seed)
+        if shuffle:
+            perm = np.random.permutation(np.arange(count))
+            data, labels = data[perm], labels[perm]
+        dl = ex.DataLoader(data, labels, False)
+        assert dl.count == count
+        for i in range(count):
+            d, l = dl.pop()
+            res["%s_data_%d" % (tag, i)] = d
+            res["%s_labels_%d" % (tag, i)] = l
+        assert dl.pop() == (None, None)
+    np.savez_compressed(out, ranges="\n".join(lines) + "\n", keys=np.array([k for k, _ in utts]),
+                        **{"feat_%d" % i: m for i, (_, m) in enumerate(utts)}, count=count, minibatch_size=B, feat_dim=F, **res)
+    print("egs_ranges: %d lines, %d minibatches x %d, served orders recorded (plain, shuffled seed 11)" % (len(lines), count, B))
+
+
 def main():
     ref_io, ref_models, Session = import_reference()
     if sys.argv[1:] == ["schedules"]:            # leaves the other (byte-stable) fixtures untouched
         golden_schedules(os.path.join(HERE, "schedules.npz"))
         return
+    if sys.argv[1:] == ["egs_ranges"]:
+        golden_egs_ranges(os.path.join(HERE, "egs_ranges.npz"))
+        return
+    golden_egs_ranges(os.path.join(HERE, "egs_ranges.npz"))
     golden_schedules(os.path.join(HERE, "schedules.npz"))
     golden_ark_io(ref_io, os.path.join(HERE, "ark_io.npz"))
     golden_make_embedding(ref_io, ref_models, Session, os.path.join(HERE, "make_embedding.npz"))

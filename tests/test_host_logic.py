@@ -184,3 +184,52 @@ def test_egs_tar_round_trip(tmp_path):
     np.save(tar.replace(".tar", ".npy"), labels[:3])
     with pytest.raises(AssertionError):
         examples_io.TarFileDataLoader(tar)
+
+
+def test_ranges_loader_serves_what_the_reference_loader_serves(tmp_path):
+    """examples_io.RangesDataLoader == reference process_range_file + load_ranges_data + [shuffle] + DataLoader on the toy
+    table of tests/golden/egs_ranges.npz: same minibatches, same order (plain and with --shuffle under seed 11)."""
+    import examples_io
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "egs_ranges.npz"))
+    keys = [str(k) for k in g["keys"]]
+    ark, scp, ranges = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp"), str(tmp_path / "ranges.1")
+    with kaldi_io.TableWriter(ark, scp) as tw:
+        for i, k in enumerate(keys):
+            kaldi_io.write_mat(tw, g["feat_%d" % i], key=k)
+    open(ranges, "wt").write(str(g["ranges"]))
+    count, B, F = int(g["count"]), int(g["minibatch_size"]), int(g["feat_dim"])
+    for tag, shuffle, seed in (("plain", False, 0), ("shuffled", True, 11)):
+        if seed:
+            np.random.seed(seed)
+        dl = examples_io.RangesDataLoader(ranges, scp, count, B, F, shuffle=shuffle)
+        assert dl.count == count
+        for i in range(count):
+            d, l = dl.pop()
+            assert d.dtype == np.float32 and np.array_equal(d, g["%s_data_%d" % (tag, i)]), (tag, i)
+            assert np.array_equal(l, g["%s_labels_%d" % (tag, i)]), (tag, i)
+        assert dl.pop() == (None, None)
+    with pytest.raises(AssertionError):
+        examples_io.RangesDataLoader(ranges, scp, count, B + 1, F)
+
+
+def test_trainer_cli_accepts_the_command_line_train_dnn_builds(tmp_path):
+    """The flag set train_dnn.py:269-301 puts on every trainer job (incl. the ones the model code never reads) parses, with
+    the tar archive taking precedence over ranges/scp when both are given (train_dnn.py:264-267)."""
+    import examples_io
+    import train_dnn_one_iteration as cli
+    from xvector_amd import synthetic, topology, weights as wio
+    mdir = str(tmp_path / "model_3")
+    topo = topology.get("ModelWithoutDropout")
+    wio.save_model_dir(mdir, synthetic.reference_init(topo, 23, 8, seed=0), topo, "ModelWithoutDropout", 8, 23)
+    tar = str(tmp_path / "egs.7.tar")
+    examples_io.write_egs_tar(tar, [np.zeros((2, 30, 23), np.float32)], np.zeros((1, 2), np.int32))
+    argv = ["--use-gpu=yes", "--verbose=0", "--print-interval=10", "--momentum=0.0", "--max-param-change=2.0",
+            "--l2-regularize-factor=0.3333333333333333", "--random-seed=8", "--learning-rate=0.0015", "--scale=1.0",
+            "--minibatch-count=1", "--feature-dim=23", "--dropout-proportion=0.05", "--tar-file=" + tar,
+            "--ranges-file=" + str(tmp_path / "temp" / "ranges.7"), "--scp-file=" + str(tmp_path / "temp" / "feats.scp.7"), "--shuffle=True",
+            "--minibatch-size=2", "--input-dir=" + mdir, "--output-dir=" + str(tmp_path / "model_4.1")]
+    args = cli.get_args(argv)
+    assert args.tar_file == tar and args.learning_rate == 0.0015 and args.dropout_proportion == 0.05 and args.random_seed == 8
+    assert args.shuffle is True and args.minibatch_size == 2 and args.print_interval == 10
+    with pytest.raises(Exception):
+        cli.get_args([a for a in argv if not a.startswith("--tar-file")])          # no tar and the ranges file does not exist

@@ -8,6 +8,14 @@ filled by a background thread; the model pops ``(data, labels)`` with a timeout 
 exhausted.  This module keeps that protocol (class name, ``count``, ``pop(timeout)``) and adds the matching writer, so
 training runs end to end without the rest of the reference's example-generation tooling (ranges files, h5 export: control
 plane, out of scope).
+
+``RangesDataLoader`` is the other input mode of the reference's trainer (train_dnn_one_iteration.py:177-200; always on the
+command line ``train_dnn.py:258-262`` builds, used when no tar exists): minibatches are cut on the fly from a feature
+table according to a Kaldi ranges file, one line per chunk
+
+    <utt-id> <minibatch-index> <ignored> <first-frame> <num-frames> <label>
+
+(examples_io.py:20-23).  Pinned against what the reference's own loader serves: tests/golden/egs_ranges.npz.
 """
 import io
 import queue
@@ -16,7 +24,7 @@ import threading
 
 import numpy as np
 
-__all__ = ["TarFileDataLoader", "write_egs_tar"]
+__all__ = ["TarFileDataLoader", "RangesDataLoader", "write_egs_tar"]
 
 
 def write_egs_tar(tar_path, minibatches, labels):
@@ -65,3 +73,54 @@ class TarFileDataLoader(object):
         item = self.queue.get(block=True, timeout=timeout)
         self._left -= 1
         return item
+
+
+class RangesDataLoader(object):
+    """Minibatches cut from ``scp_file`` as listed in ``ranges_file`` (float32 [B, T, F], int32 labels [B]).
+
+    Semantics of the reference pipeline process_range_file -> load_ranges_data -> [shuffle] -> DataLoader
+    (examples_io.py:12-75,188-221; train_dnn_one_iteration.py:177-200): every chunk of a minibatch has the same length;
+    a minibatch must hold exactly ``minibatch_size`` chunks, filled in the order the utterances come out of the scp and,
+    within an utterance, in ranges-file order; ``shuffle`` permutes the minibatches with ``np.random.permutation`` (seed it
+    with ``np.random.seed`` beforehand, as the trainer does); the loader then serves them LAST FIRST, because the
+    reference pops from the end of its list.  An utterance of the scp without a ranges entry is an error there too."""
+
+    def __init__(self, ranges_file, scp_file, minibatch_count, minibatch_size, feature_dim, shuffle=False, logger=None):
+        import kaldi_io
+        chunks, length, filled = {}, [None] * minibatch_count, [0] * minibatch_count
+        total = [0] * minibatch_count
+        with open(ranges_file, "rt") as fid:
+            for line in fid:
+                f = line.split()
+                if not f:
+                    continue
+                mb, first, n, label = int(f[1]), int(f[3]), int(f[4]), int(f[5])
+                chunks.setdefault(f[0], []).append((mb, first, n, label))
+                if length[mb] is None:
+                    length[mb] = n
+                assert length[mb] == n, "minibatch %d mixes chunk lengths %d and %d" % (mb, length[mb], n)
+                total[mb] += 1
+        for mb in range(minibatch_count):
+            assert length[mb] is not None and total[mb] == minibatch_size, \
+                "minibatch %d holds %d chunks, expected %d" % (mb, total[mb], minibatch_size)
+        data = [np.zeros((minibatch_size, length[mb], feature_dim), np.float32) for mb in range(minibatch_count)]
+        labels = [np.zeros(minibatch_size, np.int32) for _ in range(minibatch_count)]
+        for key, mat in kaldi_io.read_mat_scp(scp_file):
+            for mb, first, n, label in chunks[key]:
+                piece = mat[first:first + n]
+                assert piece.shape == (length[mb], feature_dim), "chunk of %s does not fit its utterance / feature dim" % key
+                data[mb][filled[mb]] = piece
+                labels[mb][filled[mb]] = label
+                filled[mb] += 1
+        order = np.arange(minibatch_count)
+        if shuffle:
+            order = np.random.permutation(order)
+        self._queue = [(data[i], labels[i]) for i in order]
+        self.count = minibatch_count
+        if logger is not None:
+            logger.info("Loaded %d minibatches from %d utterances." % (minibatch_count, len(chunks)))
+
+    def pop(self, timeout=30):
+        if not self._queue:
+            return None, None
+        return self._queue.pop()

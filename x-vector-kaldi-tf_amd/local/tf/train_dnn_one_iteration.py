@@ -5,8 +5,9 @@
 (``--input-dir``), the archive (``--tar-file``), the per-iteration learning rate and dropout proportion (ze_utils.py
 schedules) and the directory for the new model (``--output-dir``); the log it prints is parsed back by
 ``ze_utils.get_successful_models``.  Same flags as the reference (train_dnn_one_iteration.py:41-134); the ones its model
-code never reads (momentum, max-param-change, scale, shuffle, verbose, use-gpu) are accepted and ignored here too, and the
-ranges/scp input mode (egs cut on the fly from feature archives) is not provided -- archives are read in the tar format.
+code never reads (momentum, max-param-change, l2-regularize-factor, scale, verbose, use-gpu, sequential-loading) are
+accepted and ignored here too.  Both input modes are provided: the egs tar (``--tar-file``, preferred when it exists,
+train_dnn.py:264-267) and the ranges/scp mode (``--ranges-file`` + ``--scp-file`` [+ ``--shuffle``]).
 """
 from __future__ import print_function
 
@@ -24,7 +25,7 @@ if _HERE not in sys.path:
 import numpy as np  # noqa: E402
 
 import models  # noqa: E402
-from examples_io import TarFileDataLoader  # noqa: E402
+from examples_io import RangesDataLoader, TarFileDataLoader  # noqa: E402
 
 logger = logging.getLogger('train_dnn_one_iteration')
 logger.setLevel(logging.INFO)
@@ -38,8 +39,12 @@ logger.addHandler(_handler)
 _FLAGS = (
     ("--use-gpu", "use_gpu", str, "yes", False, ("yes", "no", "wait"), "Accepted for compatibility; training always runs on the GPU."),
     ("--momentum", "momentum", float, 0.0, False, None, "Accepted for compatibility (unused by the reference's model code)."),
-    ("--shuffle", "shuffle", bool, False, False, None, "Accepted for compatibility (applies to the ranges/scp mode only)."),
+    ("--shuffle", "shuffle", bool, False, False, None, "Permute the minibatches of the ranges/scp mode (any non-empty value = true, as in the reference)."),
     ("--max-param-change", "max_param_change", float, 2.0, False, None, "Accepted for compatibility (unused)."),
+    ("--l2-regularize-factor", "l2_regularize_factor", float, 1.0, False, None, "Accepted for compatibility (unused)."),
+    ("--ranges-file", "ranges_file", str, "", False, None, "Kaldi ranges file of this archive (used when no --tar-file is given)."),
+    ("--scp-file", "scp_file", str, "", False, None, "Feature scp restricted to the utterances of the ranges file."),
+    ("--sequential-loading", "sequential_loading", str, "true", False, ("true", "false"), "Accepted for compatibility."),
     ("--random-seed", "random_seed", int, 0, False, None, "Seed of the dropout masks (and of NumPy, as in the reference)."),
     ("--print-interval", "print_interval", int, 10, False, None, "The interval for log printing."),
     ("--verbose", "verbose", int, 0, False, None, "Accepted for compatibility (unused)."),
@@ -90,9 +95,12 @@ def get_args(argv=None):
     args = parse_flags(_FLAGS, "One DNN training iteration on the MI355X.", argv)
     check_model_dir(args.input_dir)
     args.input_dir = args.input_dir.strip()
-    if not args.tar_file:
-        raise Exception("this build reads egs from tar archives only: give --tar-file (the ranges/scp mode is not provided)")
-    check_archive(args.tar_file)
+    if args.tar_file:
+        check_archive(args.tar_file)
+    else:
+        for what, path in (("ranges", args.ranges_file), ("scp", args.scp_file)):
+            if not path or not os.path.exists(path):
+                raise Exception("the %s file '%s' does not exist (and no --tar-file was given)" % (what, path))
     if not 0.0 <= args.dropout_proportion <= 1.0:
         raise Exception("--dropout-proportion must lie in [0, 1]")
     return args
@@ -102,7 +110,11 @@ def train(args):
     logger.info("Arguments for the experiment\n{0}".format(pprint.pformat(vars(args))))
     if args.random_seed != 0:
         np.random.seed(args.random_seed)
-    data_loader = TarFileDataLoader(args.tar_file, logger=None, queue_size=16)
+    if args.tar_file:
+        data_loader = TarFileDataLoader(args.tar_file, logger=None, queue_size=16)
+    else:
+        data_loader = RangesDataLoader(args.ranges_file, args.scp_file, args.minibatch_count, args.minibatch_size,
+                                       args.feature_dim, shuffle=args.shuffle)
     models.Model().train_one_iteration(data_loader, args, logger)      # the model class comes from the model directory
 
 
