@@ -65,6 +65,9 @@ def _traced(text):
     t = t.replace("    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();", "    if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();")
     return t
 variants["trace"] = traced(base)
+# K=1 only: half the A pieces (odd stages keep stale data) / half the B pieces -- what a two-tile workgroup would save
+variants["k1halfA"] = base.replace(A_LINES[0], "if (s & 1) " + A_LINES[0])
+variants["k1halfB"] = base.replace(B_LINES[2], ";").replace(B_LINES[3], ";")
 EPI = "    float *T = reinterpret_cast<float *>(lds);\n    {\n        const int col = wc * 64 + (lane & 31);"
 assert base.count(EPI) == 1
 variants["epiprio"] = base.replace(EPI, "    __builtin_amdgcn_s_setprio(3);\n" + EPI)
