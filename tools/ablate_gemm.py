@@ -65,6 +65,13 @@ def _traced(text):
     t = t.replace("    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();", "    if (tid == 0) trc[6] = (trc[6] & 0xf) | (wall_clock64() << 8);\n    __builtin_amdgcn_s_waitcnt(0);\n    if (tid == 0) trc[3] = wall_clock64();")
     return t
 variants["trace"] = traced(base)
+MMA_OLD = base[base.index("    auto mma = [&](const Frags &F) {"):base.index("    // Register-level software pipeline at k-step granularity")]
+def _m(a, b, acc):
+    return "        %s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.%s, F.%s, %s, 0, 0, 0);\n" % (acc, a, b, acc)
+snake = [("al0", "bh0", "acc00"), ("al0", "bh1", "acc01"), ("al1", "bh1", "acc11"), ("al1", "bh0", "acc10"),
+         ("ah0", "bh0", "acc00"), ("ah0", "bh1", "acc01"), ("ah1", "bh1", "acc11"), ("ah1", "bh0", "acc10"),
+         ("ah0", "bl0", "acc00"), ("ah0", "bl1", "acc01"), ("ah1", "bl1", "acc11"), ("ah1", "bl0", "acc10")]
+variants["snake"] = base.replace(MMA_OLD, "    auto mma = [&](const Frags &F) {\n" + "".join(_m(*t) for t in snake) + "    };\n\n")
 # K=1 only: half the A pieces (odd stages keep stale data) / half the B pieces -- what a two-tile workgroup would save
 variants["k1halfA"] = base.replace(A_LINES[0], "if (s & 1) " + A_LINES[0])
 variants["k1halfB"] = base.replace(B_LINES[2], ";").replace(B_LINES[3], ";")
