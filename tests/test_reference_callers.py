@@ -119,6 +119,49 @@ def test_reference_train_dnn_one_iteration_drives_the_twin(ref_env, tmp_path, mo
     assert accepted == [1] and best == 1
 
 
+def test_eval_logs_parse_with_the_reference_accuracy_report(ref_env, tmp_path, monkeypatch):
+    """Model.eval's log (written the way eval_dnn.py does, one file per iteration) is read back by the reference's own
+    ze_utils.parse_prob_logs (ze_utils.py:490-528, the source of accuracy.report)."""
+    models = ref_env["models"]
+
+    class FakeEval(object):
+        def __init__(self, loss, acc):
+            self.v = (loss, acc)
+
+        def eval_batch(self, x, labels):
+            return self.v
+
+    class OneBatch(object):
+        count = 2
+
+        def __init__(self):
+            self.left = 2
+
+        def pop(self, timeout=30):
+            self.left -= 1
+            return (np.zeros((3, 20, 5), np.float16), np.zeros(3, np.int32)) if self.left >= 0 else (None, None)
+
+    (tmp_path / "log").mkdir()
+    want = {}
+    for it, (tl, ta, vl, va) in {3: (0.6923, 0.8548, 0.9011, 0.7712), 7: (0.4102, 0.9017, 0.8125, 0.8003)}.items():
+        for kind, loss, acc in (("train_subset", tl, ta), ("valid", vl, va)):
+            path = tmp_path / "log" / ("compute_prob_%s.%d.log" % (kind, it))
+            logger = logging.getLogger("eval_%s_%d" % (kind, it))
+            logger.setLevel(logging.INFO)
+            h = logging.FileHandler(str(path), mode="w")
+            h.setFormatter(logging.Formatter("%(asctime)s [%(pathname)s:%(lineno)s - %(funcName)s - %(levelname)s ] %(message)s"))
+            logger.addHandler(h)
+            monkeypatch.setattr(models.Model, "_trainer", lambda self, d, lg, _l=loss, _a=acc: FakeEval(_l, _a))
+            models.Model().eval(OneBatch(), "unused", True, logger)
+            h.close()
+            logger.removeHandler(h)
+        want[it] = (tl, ta, vl, va)
+    rows = ref_env["ze_utils"].parse_prob_logs(str(tmp_path), key="accuracy")
+    assert [r[0] for r in rows] == [3, 7]
+    for it, tl, ta, vl, va in rows:
+        assert (tl, ta, vl, va) == pytest.approx(want[it], abs=1e-4)
+
+
 def test_egs_archives_interchange_with_the_reference_loader(ref_env, tmp_path):
     """An archive written by this build's examples_io.write_egs_tar is read by the reference's TarFileDataLoader
     (examples_io.py:223-255) exactly as by this build's loader."""
