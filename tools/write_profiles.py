@@ -51,7 +51,7 @@ json.dump({"round": 1, "kernel": "tdnn_gemm_bf16x3_kernel (all instantiations, l
            "tdnn_gemm_fetch_kib_raw": round(fs / n, 1), "tdnn_gemm_write_kib": round(ws / n, 1),
            "tdnn_gemm_hbm_bytes_per_launch": int((2 * fs / n + ws / n) * 1024),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; x2 on FETCH_SIZE per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), verified on stats_pool_kernel",
-           "note": "fabric-side traffic incl. Infinity-Cache hits; algorithmic ~0.37 GB/launch (the last layer does not store its output); the excess is the weight panel "
+           "note": "fabric-side traffic incl. Infinity-Cache hits; algorithmic ~0.74 GB/launch at the default 262144-row batches (the last layer does not store its output); the excess is the weight panel "
                    "(5-7 MB > 4 MB L2 per XCD) re-streamed from the Infinity Cache once per round of workgroups, plus the A halo tiles re-read by the 4-12 column tiles"},
           open("profiles/traffic.json", "w"), indent=1)
 print("\n".join(lines)); print(open("profiles/traffic.json").read())
