@@ -219,6 +219,24 @@ int xv_l2_normalize_rows_f32(const float *x, int ldx, int nrows, int c, float *y
 int xv_l2_normalize_backward_f32(const float *dy, const float *y, const float *norm, int nrows, int c, float *dx, void *stream);
 int xv_am_margin_f32(float *cosines, const int32_t *labels, int nrows, int nclasses, float scale, float margin, void *stream);
 
+/* ---- self-attentive statistics pooling (ModelL2LossWithoutDropoutLReluAttention, local/tf/models.py:1036-1052) -------
+ * The last frame-level layer has 2*C channels, h = [h1 | h2].  With u = h1.W + b (one more K=1 xv_tdnn_layer_* call):
+ *   xv_attention_scores_f32   scores[r] = sum_c v[c]*tanh(u[r,c])            (models.py:1045-1046; fp64 row sums);
+ *                             nonlin (optional, [R, ldn]) receives tanh(u) for the training backward
+ *   xv_attention_softmax_f32  att[rows of chunk b] = softmax(scores[rows of chunk b])   (models.py:1046)
+ *   xv_attention_pool_f32     out[b] = [ m | sqrt(max(q,0) + eps) ],  m = sum_t att[t] h2[t,:],  q = sum_t att[t] h2[t,:]^2 - m^2
+ *                             (models.py:1048-1050; products and sums in fp64).  Chunks longer than split_rows rows are
+ *                             reduced by several workgroups through `workspace`
+ *                             (xv_attention_pool_workspace_bytes bytes, 8-byte aligned; may be NULL when that is 0).
+ * Gap rows of scores / att are never read or written. */
+int xv_attention_scores_f32(const float *u, int64_t ldu, int64_t R, int c, const float *v, float *scores, float *nonlin,
+                            int64_t ldn, void *stream);
+int xv_attention_softmax_f32(const float *scores, const int32_t *row_start, const int32_t *row_len, int nchunks, float *att,
+                             void *stream);
+size_t xv_attention_pool_workspace_bytes(int c, int nchunks, int max_len, int split_rows);
+int xv_attention_pool_f32(const float *h, int64_t ldh, int c, const float *att, const int32_t *row_start, const int32_t *row_len,
+                          int nchunks, int max_len, int split_rows, float eps, float *out, void *workspace, void *stream);
+
 /* ---- feature front-end -------------------------------------------------------------------------------
  * Sliding-window cepstral mean normalisation + VAD frame selection, i.e. what
  *   apply-cmvn-sliding --norm-vars=false --center=true --cmn-window=300 ... | select-voiced-frames ...

@@ -8,7 +8,7 @@ It restates, on the CPU, what the reference (BUTSpeechFIT/x-vector-kaldi-tf) com
 extraction path; file:line citations are relative to the reference root:
 
 * forward graph            local/tf/models.py:50-94 (== 466-500 ModelWithoutDropout,
-                           569-605 ModelWithoutDropoutTdnn)
+                           569-605 ModelWithoutDropoutTdnn; attention pooling 1036-1050)
 * batch-norm eval          local/tf/tf_block.py:9-16,25-28
 * which tensor is the xvec local/tf/models.py:159,414 (``embed_layer-0/scores:0``)
 * chunk / average driver   local/tf/models.py:373-423
@@ -43,6 +43,9 @@ DEFAULT_TOPOLOGY = dict(          # models.py:27-29
 )
 DILATED_TOPOLOGY = dict(DEFAULT_TOPOLOGY, kernel_sizes=[5, 3, 3, 1, 1],    # models.py:545-548
                         dilations=[1, 2, 3, 1, 1])
+
+ATTENTION_TOPOLOGY = dict(DEFAULT_TOPOLOGY, layer_sizes=[512, 512, 512, 512, 3072], activation="lrelu",   # models.py:992-994
+                          pooling="attention")
 
 _ACT = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}
 
@@ -145,6 +148,23 @@ def _bn(weights, scope):
     return tuple(weights["%s/%s:0" % (scope, n)] for n in ("gamma", "beta", "mean", "variance"))
 
 
+def attention_pool(h, weights, eps=VAR2STD_EPSILON, dtype=np.float64, return_attention=False):
+    """Self-attentive statistics pooling of ModelL2LossWithoutDropoutLReluAttention (models.py:1036-1050), NumPy in ``dtype``:
+    h[T, 2A] = [h1 | h2] (tf.split :1044); n = tanh(h1 W + b) (:1045); a = softmax_t(n v) (:1046);
+    m = sum_t a h2 (:1048); q = sum_t a h2^2 - m^2 (:1049); pooled = [m | sqrt(q + 1e-5)] (:1050)."""
+    h = np.asarray(h, dtype)
+    A = h.shape[1] // 2
+    h1, h2 = h[:, :A], h[:, A:]
+    n = np.tanh(h1 @ np.asarray(weights["attention/w:0"], dtype) + np.asarray(weights["attention/b:0"], dtype))
+    s = n @ np.asarray(weights["attention/v:0"], dtype)
+    e = np.exp(s - s.max())
+    a = (e / e.sum()).astype(dtype)
+    m = a @ h2
+    q = a @ (h2 * h2) - m * m
+    pooled = np.concatenate([m, np.sqrt(q + dtype(eps))]).astype(dtype)
+    return (pooled, a) if return_attention else pooled
+
+
 def forward(x, weights, topo=None, dtype=np.float64, embedding_index=0, return_intermediates=False):
     """x[T,F] -> x-vector.  ``weights`` is keyed by the TF variable names (models.py:199-213)."""
     topo = topo or DEFAULT_TOPOLOGY
@@ -156,7 +176,10 @@ def forward(x, weights, topo=None, dtype=np.float64, embedding_index=0, return_i
         h = tdnn_layer(h, weights[sc + "/w:0"], weights[sc + "/b:0"], _bn(weights, sc), act,
                        _layer_alpha(weights, sc, topo), d, dtype)
         inter.append(h)
-    pooled = stats_pool(h, VAR2STD_EPSILON, dtype)
+    if topo.get("pooling", "stats") == "attention":
+        pooled = attention_pool(h, weights, VAR2STD_EPSILON, dtype)
+    else:
+        pooled = stats_pool(h, VAR2STD_EPSILON, dtype)
     inter.append(pooled)
     e0 = fc(pooled[None, :], weights["embed_layer-0/w:0"], weights["embed_layer-0/b:0"], dtype)[0]
     inter.append(e0)
@@ -201,8 +224,16 @@ def forward_numpy(x, weights, topo=None, embedding_index=0):
         for k in range(K):
             z += hp[k * d:k * d + T] @ w[k]
         h = bn(activation(z, sc), sc)
-    mu = h.mean(axis=0)
-    var = ((h - mu) ** 2).mean(axis=0)
+    if topo.get("pooling", "stats") == "attention":          # models.py:1036-1050, written out once more, independently
+        A = h.shape[1] // 2
+        u = h[:, :A] @ np.asarray(weights["attention/w:0"], np.float64) + np.asarray(weights["attention/b:0"], np.float64)
+        s = np.tanh(u) @ np.asarray(weights["attention/v:0"], np.float64)
+        a = np.exp(s - np.logaddexp.reduce(s))
+        mu = np.einsum("tc,t->c", h[:, A:], a)
+        var = np.einsum("tc,t->c", h[:, A:] ** 2, a) - mu ** 2
+    else:
+        mu = h.mean(axis=0)
+        var = ((h - mu) ** 2).mean(axis=0)
     pooled = np.concatenate([mu, np.sqrt(var + VAR2STD_EPSILON)])
     e0 = pooled @ np.asarray(weights["embed_layer-0/w:0"], np.float64) + weights["embed_layer-0/b:0"]
     if embedding_index == 0:

@@ -175,10 +175,11 @@ def golden_forward(out):
     for tname, topo in (("default", topology.get("ModelWithoutDropout")),
                         ("dilated", topology.get("ModelWithoutDropoutTdnn")),
                         ("prelu", topology.get("ModelWithoutDropoutPRelu")),
-                        ("lrelu", topology.get("ModelL2LossWithoutDropoutLRelu"))):
+                        ("lrelu", topology.get("ModelL2LossWithoutDropoutLRelu")),
+                        ("attention", topology.get("ModelL2LossWithoutDropoutLReluAttention"))):
         weights = synthetic.trained_like(topo, 23, seed=FWD_SEED)
         rng = np.random.default_rng(FWD_SEED + 1)
-        for T in (FWD_T if tname in ("default", "dilated") else [25, 200]):
+        for T in (FWD_T if tname in ("default", "dilated") else [25, 200, 1000] if tname == "attention" else [25, 200]):
             x = (rng.standard_normal((T, 23)) * 3.0).astype(np.float32)
             e1, inter = oracle.forward(x, weights, topo, np.float64, embedding_index=1, return_intermediates=True)
             e0 = inter[6]
@@ -287,6 +288,9 @@ def main():
     ref_io, ref_models, Session = import_reference()
     if sys.argv[1:] == ["schedules"]:            # leaves the other (byte-stable) fixtures untouched
         golden_schedules(os.path.join(HERE, "schedules.npz"))
+        return
+    if sys.argv[1:] == ["forward"]:
+        golden_forward(os.path.join(HERE, "forward_default.npz"))
         return
     if sys.argv[1:] == ["egs_ranges"]:
         golden_egs_ranges(os.path.join(HERE, "egs_ranges.npz"))

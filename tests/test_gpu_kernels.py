@@ -381,3 +381,71 @@ def test_bad_arguments_fail_loudly(env):
     y = torch.zeros((10, 8), dtype=torch.float32, device=dev)
     with pytest.raises(hiplib.XvectorHipError):
         hiplib.tdnn_layer(x, wp, None, None, None, 1, None, 9, 2, None, y)      # (K-1)*dil = 16 > 8
+
+
+# ---- self-attentive pooling kernels (models.py:1036-1050) ----------------------------------------------------------------
+@pytest.mark.parametrize("A,lens,split,strided", [
+    (1536, [25, 200, 400, 1, 7, 33, 512], 512, True),      # direct path; h2 = right half of a [R, 2A] buffer
+    (1536, [25, 2000, 513, 10000, 100], 512, False),       # split path + merge kernel
+    (48, [5, 64, 300], 512, True),                         # A < 64: partially filled wave
+    (256, [1000, 999], 128, False),
+])
+def test_attention_scores_softmax_pool_match_oracle(env, A, lens, split, strided):
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(A + sum(lens))
+    layout = engine.BatchLayout(lens, 3)
+    R = layout.rows
+    u_host = (1.5 * rng.standard_normal((R, A))).astype(np.float32)
+    v_host = (rng.standard_normal(A) * (2.0 / np.sqrt(A))).astype(np.float32)
+    full = (rng.standard_normal((R, 2 * A)) * 1.7 + 3.0 * rng.standard_normal(2 * A)).astype(np.float32)
+    full[: layout.lead] = 1e6                                   # garbage in the gaps must not matter
+    u, v = torch.from_numpy(u_host).to(dev), torch.from_numpy(v_host).to(dev)
+    hbuf = torch.from_numpy(full).to(dev)
+    h2 = hbuf[:, A:] if strided else hbuf[:, A:].contiguous()
+    rs, rl = torch.from_numpy(layout.row_start).to(dev), torch.from_numpy(layout.row_len).to(dev)
+    scores = torch.empty(R, dtype=torch.float32, device=dev)
+    nl = torch.empty((R, A), dtype=torch.float32, device=dev)
+    att = torch.full((R,), float("nan"), dtype=torch.float32, device=dev)
+    out = torch.full((len(lens), 2 * A), float("nan"), dtype=torch.float32, device=dev)
+    need = hiplib.attention_pool_workspace_bytes(A, len(lens), max(lens), split)
+    assert (need > 0) == (max(lens) > split)
+    ws = torch.empty(max(need // 8, 1), dtype=torch.float64, device=dev)
+    hiplib.attention_scores(u, v, scores, nl)
+    hiplib.attention_softmax(scores, rs, rl, len(lens), att)
+    hiplib.attention_pool(h2, att, rs, rl, len(lens), max(lens), split, 1e-5, out, ws)
+    torch.cuda.synchronize()
+    s_ref = np.tanh(u_host.astype(np.float64)) @ v_host.astype(np.float64)
+    assert np.abs(scores.cpu().numpy() - s_ref).max() < 2e-6 * max(1.0, np.abs(s_ref).max())
+    assert np.abs(nl.cpu().numpy() - np.tanh(u_host.astype(np.float64))).max() < 5e-7
+    got, a_got = out.cpu().numpy(), att.cpu().numpy()
+    for i, (s, n) in enumerate(zip(layout.row_start, layout.row_len)):
+        sl = slice(int(s), int(s) + int(n))
+        e = np.exp(s_ref[sl] - s_ref[sl].max())
+        a = e / e.sum()
+        assert np.abs(a_got[sl] - a).max() < 1e-5 * a.max()
+        x = full[sl, A:].astype(np.float64)
+        m = a @ x
+        sd = np.sqrt(a @ (x * x) - m * m + 1e-5)
+        assert oracle.rel_l2(got[i, :A], m) < 1e-5 and oracle.rel_l2(got[i, A:], sd) < 1e-5, (i, n)
+    assert np.isnan(a_got[: layout.lead]).all()                 # gap rows are never written
+
+
+def test_attention_pool_uniform_weights_equal_plain_statistics(env):
+    """With constant scores the attention is 1/T and the weighted moments are tf.nn.moments: the two pooling kernels agree."""
+    torch, hiplib, engine, dev = env["torch"], env["hiplib"], env["engine"], env["dev"]
+    rng = np.random.default_rng(3)
+    lens, A = [300, 25, 1111], 192
+    layout = engine.BatchLayout(lens, 3)
+    h = torch.from_numpy((rng.standard_normal((layout.rows, A)) + 2.0).astype(np.float32)).to(dev)
+    rs, rl = torch.from_numpy(layout.row_start).to(dev), torch.from_numpy(layout.row_len).to(dev)
+    scores = torch.full((layout.rows,), 0.7, dtype=torch.float32, device=dev)
+    att = torch.zeros(layout.rows, dtype=torch.float32, device=dev)
+    a_out = torch.empty((3, 2 * A), dtype=torch.float32, device=dev)
+    p_out = torch.empty((3, 2 * A), dtype=torch.float32, device=dev)
+    ws = torch.empty(hiplib.attention_pool_workspace_bytes(A, 3, max(lens), 512) // 8 + 1, dtype=torch.float64, device=dev)
+    ws2 = torch.empty(hiplib.stats_pool_workspace_bytes(A, 3, max(lens), 512) // 4 + 1, dtype=torch.float32, device=dev)
+    hiplib.attention_softmax(scores, rs, rl, 3, att)
+    hiplib.attention_pool(h, att, rs, rl, 3, max(lens), 512, 1e-5, a_out, ws)
+    hiplib.stats_pool(h, rs, rl, 3, max(lens), 512, 1e-5, p_out, ws2)
+    torch.cuda.synchronize()
+    assert torch.allclose(a_out, p_out, rtol=2e-6, atol=2e-6)

@@ -17,8 +17,12 @@ def test_topology_flop_constants_match_survey():
     assert topology.flops_per_utt(topo) == 3145728                # 3,145,728 FLOP/utt
     assert topology.flops_per_frame(topology.get("ModelWithoutDropoutTdnn"), 23) == 5360640
     assert topology.max_halo(topo) == 3 and topology.max_halo(topology.get("ModelWithoutDropoutTdnn")) == 3
+    att = topology.get("ModelL2LossWithoutDropoutLReluAttention")        # models.py:992: last layer 6*512, split in two
+    assert topology.pooled_dim(att) == 3072 == topology.pooled_dim(topo)
+    assert topology.flops_per_frame(att, 23) == 8506368 + 2 * 512 * 1536 + 2 * 1536 * 1536
+    assert topology.flops_per_utt(att) == 3145728
     with pytest.raises(KeyError):
-        topology.get("ModelL2LossWithoutDropoutLReluAttention")  # attention pooling: out of scope
+        topology.get("NoSuchModel")
 
 
 def test_plan_chunks_semantics():

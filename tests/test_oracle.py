@@ -40,8 +40,16 @@ def _torch_forward(x, w, topo, embedding_index=0):
         r = activation(z, sc)
         h = F.batch_norm(r, t(w[sc + "/mean:0"]), t(w[sc + "/variance:0"]), t(w[sc + "/gamma:0"]), t(w[sc + "/beta:0"]),
                          training=False, eps=topology.BN_EPSILON)
-    mu = h.mean(dim=2)
-    var = h.var(dim=2, unbiased=False)
+    if topo.get("pooling") == "attention":                  # models.py:1036-1050 with torch ops (softmax / einsum as written there)
+        hh = h.permute(0, 2, 1)                             # [1, T, 2A]
+        h1, h2 = torch.chunk(hh, 2, dim=2)
+        nl = torch.tanh(torch.einsum("ijk,kl->ijl", h1, t(w["attention/w:0"])) + t(w["attention/b:0"]))
+        att = torch.softmax(torch.einsum("ijk,k->ij", nl, t(w["attention/v:0"])), dim=-1)
+        mu = torch.einsum("ijk,ij->ik", h2, att)
+        var = torch.einsum("ijk,ij->ik", h2 * h2, att) - mu * mu
+    else:
+        mu = h.mean(dim=2)
+        var = h.var(dim=2, unbiased=False)
     pooled = torch.cat([mu, torch.sqrt(var + topology.VAR2STD_EPSILON)], dim=1)
     e0 = pooled @ t(w["embed_layer-0/w:0"]) + t(w["embed_layer-0/b:0"])
     if embedding_index == 0:
@@ -53,7 +61,7 @@ def _torch_forward(x, w, topo, embedding_index=0):
 
 
 @pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelWithoutDropoutPRelu",
-                                 "ModelL2LossWithoutDropoutLRelu"])
+                                 "ModelL2LossWithoutDropoutLRelu", "ModelL2LossWithoutDropoutLReluAttention"])
 def test_c_oracle_vs_numpy_vs_torch(oracle_mod, cls):
     topo = topology.get(cls)
     # narrower layers keep the test fast; kernel sizes / dilations / activation are the class's own
@@ -100,6 +108,11 @@ def test_golden_forward_vectors_reproduce(oracle_mod, golden):
         assert oracle_mod.rel_l2(e0, g["default_T%d_e0" % T]) < 1e-9
         e32 = oracle_mod.forward(x, w, topo, np.float32)
         assert oracle_mod.rel_l2(e32, g["default_T%d_e0" % T]) < 5e-6
+    topo = topology.get("ModelL2LossWithoutDropoutLReluAttention")
+    w = synthetic.trained_like(topo, 23, seed=FWD_SEED)
+    rng = np.random.default_rng(FWD_SEED + 1)
+    x = (rng.standard_normal((25, 23)) * 3.0).astype(np.float32)
+    assert oracle_mod.rel_l2(oracle_mod.forward(x, w, topo, np.float64), g["attention_T25_e0"]) < 1e-9
 
 
 def test_chunk_plan_matches_reference_driver(oracle_mod, golden):

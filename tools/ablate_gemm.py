@@ -88,6 +88,6 @@ for name, text in variants.items():
     open(f, "w").write(text)
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                    "-I" + os.path.join(ROOT, "include"), "-I" + SRC, "-Wno-unused-function",
-                                   "-o", os.path.join(OUT, "lib_%s.so" % name), f, os.path.join(SRC, "xv_train.hip"), os.path.join(SRC, "xv_frontend.hip")]))
+                                   "-o", os.path.join(OUT, "lib_%s.so" % name), f, os.path.join(SRC, "xv_train.hip"), os.path.join(SRC, "xv_frontend.hip"), os.path.join(SRC, "xv_attention.hip")]))
 assert all(p.wait() == 0 for p in procs)
 print("built:", sorted(os.listdir(OUT)))

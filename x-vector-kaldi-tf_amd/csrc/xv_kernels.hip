@@ -1283,7 +1283,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 7; }
+int xv_version(void) { return 8; }
 
 const char *xv_last_error(void) { return g_err; }
 

@@ -410,6 +410,10 @@ class ModelL2LossWithoutDropoutLRelu(Model):          # models.py:866
     pass
 
 
+class ModelL2LossWithoutDropoutLReluAttention(Model):    # models.py:985  (self-attentive pooling, attention/{w,b,v})
+    pass
+
+
 class ModelWithoutDropoutAMSoftmax(Model):            # build-defined (BASELINE configs[4]); see xvector_amd/topology.py
     pass
 

@@ -145,6 +145,16 @@ class BatchLayout(object):
 # ------------------------------------------------------------------------------------------------
 # device model
 # ------------------------------------------------------------------------------------------------
+class _ColumnView(object):
+    """weights[name][cols] for the per-channel vectors of a layer."""
+
+    def __init__(self, weights, cols):
+        self.weights, self.cols = weights, cols
+
+    def __getitem__(self, name):
+        return self.weights[name][self.cols]
+
+
 class DeviceModel(object):
     """Weights of one model directory resident in HBM in kernel layout, plus reusable activation
     buffers.  ``weights`` is keyed by the TF variable names (weights.py)."""
@@ -160,8 +170,10 @@ class DeviceModel(object):
         hiplib.require_gpu()
         assert precision in ("fp32", "bf16x3")
         self.precision = precision
-        self.fused_pool = (precision == "bf16x3") if fused_pool is None else bool(fused_pool)
+        self.attention = tp.is_attention(topo)
+        self.fused_pool = (precision == "bf16x3" and not self.attention) if fused_pool is None else bool(fused_pool)
         assert not (self.fused_pool and precision != "bf16x3"), "fused pooling exists on the bf16x3 path only"
+        assert not (self.fused_pool and self.attention), "the fused epilogue computes plain statistics, not attention-weighted ones"
         self.align = hiplib.POOL_BLOCK_ROWS if self.fused_pool else 1
         self.torch = torch
         self.device = torch.device(device)
@@ -184,12 +196,29 @@ class DeviceModel(object):
                     wpad[:, :self.feat_dim] = w
                     w = wpad
                 self.layers.append(self._prep(weights, sc, w, k, d))
+            if self.attention:
+                # models.py:1036-1046: h = [h1 | h2]; u = h1 . attention/w + attention/b is one more K=1 layer.  On the
+                # bf16x3 path the last frame-level layer runs as two launches over the two column halves of its weights so
+                # that h1 comes out in the split format (input of the attention GEMM) and h2 as fp32 rows (pooling input)
+                A = self.layers[-1]["cout"] // 2
+                self.att_dim = A
+                aw = weights["attention/w:0"]
+                assert aw.shape == (A, A), "attention/w:0 must be [%d, %d]" % (A, A)
+                self.att = dict(K=1, dil=1, cin=A, cout=A, bias=self._dev(weights["attention/b:0"]),
+                                v=self._dev(weights["attention/v:0"]))
+                if precision == "bf16x3":
+                    self.att["wp"] = hiplib.pack_weights_bf16x3(self._dev(aw[None, :, :]))
+                    sc = "frame_level_info_layer-%d" % (len(self.layers) - 1)
+                    k, d = topo["kernel_sizes"][-1], topo["dilations"][-1]
+                    self.last_halves = [self._prep(weights, sc, weights[sc + "/w:0"], k, d, cols=slice(a, a + A)) for a in (0, A)]
+                else:
+                    self.att["wp"] = hiplib.pack_weights(self._dev(aw))
             self.embed = []
             for j in range(len(topo["embedding_sizes"])):
                 sc = "embed_layer-%d" % j
                 self.embed.append(self._prep(weights, sc, weights[sc + "/w:0"][None, :, :], 1, 1))
             torch.cuda.synchronize()
-        self.pooled_dim = 2 * self.layers[-1]["cout"]
+        self.pooled_dim = tp.pooled_dim(topo)
         self.embed_dim = self.embed[self.embedding_index]["cout"]
         self._cap_rows = 0
         self._cap_chunks = 0
@@ -199,7 +228,10 @@ class DeviceModel(object):
     def _dev(self, a):
         return self.torch.as_tensor(np.array(a, dtype=np.float32, order="C")).to(self.device)     # copy: sources may be read-only
 
-    def _prep(self, weights, scope, w3d, k, d):
+    def _prep(self, weights, scope, w3d, k, d, cols=slice(None)):
+        """Kernel-layout parameters of one layer (``cols``: only these output channels)."""
+        w3d = w3d[:, :, cols]
+        weights = _ColumnView(weights, cols)
         layer = dict(K=k, dil=d, cin=w3d.shape[1], cout=w3d.shape[2])
         if self.precision == "bf16x3":
             layer["wp"] = hiplib.pack_weights_bf16x3(self._dev(w3d))                  # tiled hi/lo bf16
@@ -234,6 +266,16 @@ class DeviceModel(object):
             if self.fused_pool:
                 self._last = torch.empty(hiplib.block_stats_floats(self._cap_rows, self.layers[-1]["cout"]), dtype=torch.float32,
                                          device=self.device)
+            elif self.attention:
+                A = self.att_dim
+                if self.precision == "bf16x3":
+                    self._h1 = hiplib.SplitBuf(self._cap_rows, A, self.device)
+                    self._last = torch.empty((self._cap_rows, A), dtype=torch.float32, device=self.device)          # h2
+                else:
+                    self._last = torch.empty((self._cap_rows, 2 * A), dtype=torch.float32, device=self.device)      # [h1 | h2]
+                self._u = torch.empty((self._cap_rows, A), dtype=torch.float32, device=self.device)
+                self._scores = torch.empty(self._cap_rows, dtype=torch.float32, device=self.device)
+                self._att = torch.zeros(self._cap_rows, dtype=torch.float32, device=self.device)
             else:
                 self._last = torch.empty((self._cap_rows, self.layers[-1]["cout"]), dtype=torch.float32, device=self.device)
         if nchunks > self._cap_chunks:
@@ -241,7 +283,10 @@ class DeviceModel(object):
             self._pooled = torch.empty((self._cap_chunks, self.pooled_dim), dtype=torch.float32, device=self.device)
             self._pool_ws = None
         if max_len is not None and not self.fused_pool:
-            need = hiplib.stats_pool_workspace_bytes(self.layers[-1]["cout"], self._cap_chunks, max_len, self.POOL_SPLIT_ROWS)
+            if self.attention:
+                need = hiplib.attention_pool_workspace_bytes(self.att_dim, self._cap_chunks, max_len, self.POOL_SPLIT_ROWS)
+            else:
+                need = hiplib.stats_pool_workspace_bytes(self.layers[-1]["cout"], self._cap_chunks, max_len, self.POOL_SPLIT_ROWS)
             if need and (self._pool_ws is None or self._pool_ws.numel() * 4 < need):
                 self._pool_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
 
@@ -269,6 +314,9 @@ class DeviceModel(object):
                 hiplib.tdnn_layer_pool(h, R, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"],
                                        row_valid, self._last)
                 break
+            if last and self.attention:
+                h = self._attention_scores(h, R, L, row_valid)
+                break
             y = self._view(self._last if last else bufs[i & 1], R, L["cout"])
             hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
                               row_valid, y, rows=R)
@@ -277,12 +325,38 @@ class DeviceModel(object):
             events[1].record()
         if self.fused_pool:
             hiplib.stats_pool_blocks(self._last, self.layers[-1]["cout"], row_start, row_len, nchunks, tp.VAR2STD_EPSILON, pooled)
+        elif self.attention:
+            hiplib.attention_softmax(self._scores, row_start, row_len, nchunks, self._att)
+            hiplib.attention_pool(h, self._att, row_start, row_len, nchunks, max_len, self.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON,
+                                  pooled, self._pool_ws)
         else:
             hiplib.stats_pool(h, row_start, row_len, nchunks, max_len, self.POOL_SPLIT_ROWS, tp.VAR2STD_EPSILON, pooled,
                               self._pool_ws)
         if events is not None:
             events[2].record()
         return pooled
+
+    def _attention_scores(self, h, R, L, row_valid):
+        """Last frame-level layer + attention scores (models.py:1022-1046) for one batch: leaves the per-row scores in
+        ``self._scores`` and returns h2[R, A], the half of the layer output that is pooled."""
+        A, T = self.att_dim, self.att
+        u = self._u[:R]
+        if self.precision == "bf16x3":
+            L1, L2 = self.last_halves
+            hiplib.tdnn_layer(h, L1["wp"], L1["bias"], L1["scale"], L1["shift"], self.act, L1["alpha"], L1["K"], L1["dil"],
+                              row_valid, self._h1, rows=R)
+            h2 = self._last[:R]
+            hiplib.tdnn_layer(h, L2["wp"], L2["bias"], L2["scale"], L2["shift"], self.act, L2["alpha"], L2["K"], L2["dil"],
+                              row_valid, h2, rows=R)
+            h1 = self._h1
+        else:
+            y = self._last[:R]
+            hiplib.tdnn_layer(h, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"],
+                              row_valid, y, rows=R)
+            h1, h2 = y[:, :A], y[:, A:]
+        hiplib.tdnn_layer(h1, T["wp"], T["bias"], None, None, tp.ACT_NONE, None, 1, 1, None, u, rows=R)
+        hiplib.attention_scores(u, T["v"], self._scores, rows=R)
+        return h2
 
     def segment_level(self, pooled, out):
         """Segment-level part for ANY number of chunks at once (run once per window so the GEMM has enough rows to

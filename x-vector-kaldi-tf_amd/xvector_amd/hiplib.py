@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -24,7 +24,9 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_f32", "xv_dropout_f32",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
-           "xv_cmn_sliding_scatter_f32")
+           "xv_cmn_sliding_scatter_f32",
+           # self-attentive pooling
+           "xv_attention_scores_f32", "xv_attention_softmax_f32", "xv_attention_pool_workspace_bytes", "xv_attention_pool_f32")
 
 FMT_F32, FMT_SPLIT = 0, 1
 SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 136
@@ -127,6 +129,14 @@ def load():
     lib.xv_am_margin_f32.argtypes = [vp, vp, ci, ci, cf, cf, vp]
     lib.xv_cmn_sliding_scatter_f32.restype = ci
     lib.xv_cmn_sliding_scatter_f32.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]
+    lib.xv_attention_scores_f32.restype = ci
+    lib.xv_attention_scores_f32.argtypes = [vp, i64, i64, ci, vp, vp, vp, i64, vp]
+    lib.xv_attention_softmax_f32.restype = ci
+    lib.xv_attention_softmax_f32.argtypes = [vp, vp, vp, ci, vp, vp]
+    lib.xv_attention_pool_workspace_bytes.restype = sz
+    lib.xv_attention_pool_workspace_bytes.argtypes = [ci, ci, ci, ci]
+    lib.xv_attention_pool_f32.restype = ci
+    lib.xv_attention_pool_f32.argtypes = [vp, i64, ci, vp, vp, vp, ci, ci, ci, cf, vp, vp, vp]
     if lib.xv_version() != ABI_VERSION:
         raise XvectorHipError("libxvector_hip.so ABI version %d != expected %d" % (lib.xv_version(), ABI_VERSION))
     _lib = lib
@@ -323,7 +333,7 @@ def tdnn_layer(x, wp, bias, scale, shift, act, alpha, K, dilation, row_valid, y,
         assert wp.K == K
         R = int(rows) if rows is not None else (x.rows if isinstance(x, SplitBuf) else x.shape[0])
         return tdnn_layer3(x, R, wp, bias, scale, shift, act, alpha, dilation, row_valid, y, y_preact)
-    _f32(x, "x")
+    _rows2d(x, "x")
     _f32(wp, "wp")
     R = x.shape[0] if rows is None else int(rows)
     cin = x.shape[1]
@@ -570,3 +580,57 @@ def am_margin(cosines, labels, scale, margin):
     assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == cosines.shape[0]
     _check(lib.xv_am_margin_f32(_ptr(cosines), _ptr(labels), cosines.shape[0], cosines.shape[1], float(scale), float(margin), _stream()),
            "xv_am_margin_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# self-attentive statistics pooling (local/tf/models.py:1036-1052)
+# ------------------------------------------------------------------------------------------------
+def _rows2d(t, name):
+    """2-D cuda float32 tensor whose rows are contiguous (a column slice of a wider buffer is fine)."""
+    import torch
+    assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1, "%s must be cuda float32 rows" % name
+    return t
+
+
+def attention_scores(u, v, scores, nonlin=None, rows=None):
+    """scores[r] = sum_c v[c]*tanh(u[r,c]); nonlin (optional, same shape as u) receives tanh(u)."""
+    lib = require_gpu()
+    _rows2d(u, "u"); _f32(v, "v"); _f32(scores, "scores")
+    R = u.shape[0] if rows is None else int(rows)
+    assert v.numel() == u.shape[1] and scores.numel() >= R
+    ldn = 0
+    if nonlin is not None:
+        _rows2d(nonlin, "nonlin"); assert nonlin.shape[1] == u.shape[1] and nonlin.shape[0] >= R
+        ldn = nonlin.stride(0)
+    _check(lib.xv_attention_scores_f32(_ptr(u), u.stride(0), R, u.shape[1], _ptr(v), _ptr(scores), _ptr(nonlin), ldn, _stream()),
+           "xv_attention_scores_f32")
+
+
+def attention_softmax(scores, row_start, row_len, nchunks, att):
+    import torch
+    lib = require_gpu()
+    _f32(scores, "scores"); _f32(att, "att")
+    assert row_start.dtype == torch.int32 and row_len.dtype == torch.int32 and row_start.is_cuda and row_len.is_cuda
+    assert att.numel() >= scores.numel()
+    _check(lib.xv_attention_softmax_f32(_ptr(scores), _ptr(row_start), _ptr(row_len), int(nchunks), _ptr(att), _stream()),
+           "xv_attention_softmax_f32")
+
+
+def attention_pool_workspace_bytes(c, nchunks, max_len, split_rows):
+    return int(load().xv_attention_pool_workspace_bytes(int(c), int(nchunks), int(max_len), int(split_rows)))
+
+
+def attention_pool(h, att, row_start, row_len, nchunks, max_len, split_rows, eps, out, workspace=None):
+    """out[b] = [sum_t att h | sqrt(sum_t att h^2 - (sum_t att h)^2 + eps)] over the rows of chunk b; h: [R, C] rows (may be a
+    column slice of a wider buffer)."""
+    import torch
+    lib = require_gpu()
+    _rows2d(h, "h"); _f32(att, "att"); _f32(out, "out")
+    assert row_start.dtype == torch.int32 and row_len.dtype == torch.int32 and row_start.is_cuda and row_len.is_cuda
+    c = h.shape[1]
+    assert out.shape[1] == 2 * c and out.shape[0] >= nchunks and att.numel() >= h.shape[0]
+    need = attention_pool_workspace_bytes(c, nchunks, max_len, split_rows)
+    if need:
+        assert workspace is not None and workspace.numel() * workspace.element_size() >= need, "attention pool workspace too small"
+    _check(lib.xv_attention_pool_f32(_ptr(h), h.stride(0), c, _ptr(att), _ptr(row_start), _ptr(row_len), int(nchunks), int(max_len),
+                                     int(split_rows), float(eps), _ptr(out), _ptr(workspace), _stream()), "xv_attention_pool_f32")

@@ -29,7 +29,7 @@ def _shapes(topo, feat_dim):
     for i, (k, c) in enumerate(zip(topo["kernel_sizes"], topo["layer_sizes"])):
         yield "frame_level_info_layer-%d" % i, (k, prev, c)
         prev = c
-    prev *= 2
+    prev = tp.pooled_dim(topo)
     for j, c in enumerate(topo["embedding_sizes"]):
         yield "embed_layer-%d" % j, (prev, c)
         prev = c
@@ -50,6 +50,11 @@ def reference_init(topo, feat_dim, num_classes, seed=0):
         if topo.get("activation") == "prelu":
             w[scope + "/prelu/prelu:0"] = np.full(c, 0.1, np.float32)     # tf_block.py:45-46
         last = c
+    if tp.is_attention(topo):                                             # models.py:1040-1043
+        a = topo["layer_sizes"][-1] // 2
+        w["attention/b:0"] = np.full(a, 0.1, np.float32)
+        w["attention/v:0"] = np.full(a, 0.1, np.float32)
+        w["attention/w:0"] = _truncated_normal(rng, (a, a), 0.1)
     lim = np.sqrt(6.0 / (last + num_classes))                             # xavier_initializer (uniform)
     w["output/w:0"] = rng.uniform(-lim, lim, size=(last, num_classes)).astype(np.float32)
     w["output/b:0"] = np.full(num_classes, 0.1, np.float32)
@@ -102,7 +107,13 @@ def trained_like(topo, feat_dim, num_classes=64, seed=0, calib_frames=2000, inpu
         if topo.get("activation") == "prelu":
             w[sc + "/prelu/prelu:0"] = alpha
         prev = c
-    prev *= 2
+    if tp.is_attention(topo):
+        # scores with a standard deviation of ~1.5 over the frames: attention neither uniform nor one-hot
+        a = prev // 2
+        w["attention/w:0"] = _truncated_normal(rng, (a, a), np.sqrt(1.0 / a))
+        w["attention/b:0"] = (0.1 * rng.standard_normal(a)).astype(np.float32)
+        w["attention/v:0"] = (rng.standard_normal(a) * (1.5 / (0.6 * np.sqrt(a)))).astype(np.float32)
+    prev = tp.pooled_dim(topo)
     for j, c in enumerate(topo["embedding_sizes"]):
         sc = "embed_layer-%d" % j
         w[sc + "/w:0"] = _truncated_normal(rng, (prev, c), np.sqrt(1.0 / prev))

@@ -32,6 +32,8 @@ class Trainer(object):
         import torch
         hiplib.require_gpu()
         assert precision in ("fp32", "bf16x3")
+        if tp.is_attention(topo):
+            raise NotImplementedError("training of the self-attentive pooling class is not implemented (extraction is)")
         self.precision = precision
         self.torch = torch
         self.device = torch.device(device)

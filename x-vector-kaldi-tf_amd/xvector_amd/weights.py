@@ -10,7 +10,7 @@ are non-empty (``local/tf/ze_utils.py:561-567``, ``local/tf/extract_embedding.py
                              enumerates (``local/tf/models.py:199-213``):
                              ``frame_level_info_layer-{i}/{w,b,gamma,beta,mean,variance}:0``,
                              ``embed_layer-{j}/{w,b,gamma,beta,mean,variance}:0``, ``output/{w,b}:0``,
-                             optional ``.../prelu/prelu:0``
+                             optional ``.../prelu/prelu:0``, ``attention/{w,b,v}:0``
 * ``done``                -- the marker the drivers look for.
 
 A directory written by the reference itself (TF1 ``Saver``: ``model.meta`` protobuf + ``model.index`` +
@@ -39,6 +39,8 @@ def expected_names(topo):
         names += ["%s/%s:0" % (sc, n) for n in ("w", "b", "gamma", "beta", "mean", "variance")]
         if topo.get("activation") == "prelu":
             names.append("%s/prelu/prelu:0" % sc)
+    if topo.get("pooling", "stats") == "attention":
+        names += ["attention/w:0", "attention/b:0", "attention/v:0"]          # models.py:1040-1043
     names += ["output/w:0", "output/b:0"]
     return names
 
