@@ -53,6 +53,9 @@ def parse():
                          "64-chunk minibatches (SURVEY §8f-1), reported as chunks/s")
     ap.add_argument("--train-precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="--mode train: arithmetic of the forward / input-gradient GEMMs")
+    ap.add_argument("--train-class", default=None,
+                    help="--mode train only: a model class of local/tf/models.py (e.g. ModelL2LossWithoutDropoutLReluAttention) "
+                         "instead of the default ModelWithoutDropout network; implies its own head (softmax-CE)")
     ap.add_argument("--head", choices=["am_softmax", "softmax"], default="am_softmax",
                     help="--mode train: classification head (BASELINE configs[4] names AM-softmax; 'softmax' = the reference's head)")
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
@@ -69,11 +72,16 @@ def bench_train(args, rank, world, dev, topo, feat):
     import torch.distributed as dist
     from xvector_amd import synthetic, topology as tp, trainer
     B, n_spk = 64, 64
+    if args.train_class:
+        topo = tp.get(args.train_class)
+        args.head = "am_softmax" if (topo.get("head") or {}).get("type") == "am_softmax" else "softmax"
     weights = synthetic.reference_init(topo, feat, n_spk, seed=1)
     for k in list(weights):                                   # fan-in scaled start so that activations stay O(1)
         if k.endswith("/w:0") and weights[k].ndim == 3:
             weights[k] = (weights[k] * (np.sqrt(2.0 / (weights[k].shape[0] * weights[k].shape[1])) / 0.1)).astype(np.float32)
-    if args.head == "am_softmax":
+    if "attention/w:0" in weights:
+        weights["attention/w:0"] = (weights["attention/w:0"] * (np.sqrt(1.0 / weights["attention/w:0"].shape[0]) / 0.1)).astype(np.float32)
+    if args.head == "am_softmax" and not args.train_class:
         topo = tp.get("ModelWithoutDropoutAMSoftmax")        # same network, build-defined additive-margin head
     tr = trainer.Trainer(weights, topo, dev, precision=args.train_precision)
     rng = np.random.default_rng(1234 + rank)
@@ -114,7 +122,7 @@ def bench_train(args, rank, world, dev, topo, feat):
             "dtype": "f32" if args.train_precision == "fp32" else "f32 (fwd/dgrad GEMMs as bf16x3 split MFMA, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: training, B=64 chunks/minibatch/GPU, T~U{%d..%d}, 64 speakers, "
-                                   "ModelWithoutDropout topology, head: %s%s" % (args.tmin, args.tmax, args.head,
+                                   "%s topology, head: %s%s" % (args.tmin, args.tmax, args.train_class or "ModelWithoutDropout", args.head,
                                    " (scale 30, margin 0.2; build-defined, the reference has softmax-CE only)" if args.head == "am_softmax" else ""),
                        "parallelism": "data parallel x%d, one bucketed gradient all-reduce per step" % world},
             "steps_per_s": args.steps / dt, "frames_per_s": frames * world / dt,

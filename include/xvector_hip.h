@@ -236,6 +236,20 @@ int xv_attention_softmax_f32(const float *scores, const int32_t *row_start, cons
 size_t xv_attention_pool_workspace_bytes(int c, int nchunks, int max_len, int split_rows);
 int xv_attention_pool_f32(const float *h, int64_t ldh, int c, const float *att, const int32_t *row_start, const int32_t *row_len,
                           int nchunks, int max_len, int split_rows, float eps, float *out, void *workspace, void *stream);
+/* Backward of the three steps above (training step of the attention class):
+ *   xv_attention_pool_backward_f32     dh[t,c] = att[t] (g1[c] + 2 h[t,c] g2[c]),  datt[t] = sum_c h[t,c] g1[c] + h[t,c]^2 g2[c]
+ *                                      with g2 = dsd/(2 sd), g1 = dm - 2 m g2, [m | sd] = pooled, [dm | dsd] = dpooled
+ *   xv_attention_softmax_backward_f32  dscores[t] = att[t] (datt[t] - sum_tau att[tau] datt[tau])   per chunk
+ *   xv_attention_scores_backward_f32   du[r,c] = dscores[r] v[c] (1 - n[r,c]^2);  nonlin (= n = tanh(u)) is OVERWRITTEN with
+ *                                      dscores[r] n[r,c], whose column sums are dv (xv_col_sums_f32); rows outside every
+ *                                      chunk must carry dscores = 0. */
+int xv_attention_pool_backward_f32(const float *h, int64_t ldh, int c, const float *att, const int32_t *row_start,
+                                   const int32_t *row_len, int nchunks, int max_len, const float *pooled, const float *dpooled,
+                                   float *dh, int64_t lddh, float *datt, void *stream);
+int xv_attention_softmax_backward_f32(const float *att, const float *datt, const int32_t *row_start, const int32_t *row_len,
+                                      int nchunks, float *dscores, void *stream);
+int xv_attention_scores_backward_f32(float *nonlin, int64_t ldn, const float *dscores, const float *v, int64_t R, int c, float *du,
+                                     int64_t lddu, void *stream);
 
 /* ---- feature front-end -------------------------------------------------------------------------------
  * Sliding-window cepstral mean normalisation + VAD frame selection, i.e. what

@@ -3,7 +3,7 @@
 Restates the training graph of the reference (BUTSpeechFIT/x-vector-kaldi-tf) for the model classes without
 dropout, following the TF op definitions at its call sites:
 
-* forward, train phase          local/tf/models.py:466-500 (ModelWithoutDropout), 569-605 (Tdnn), 895-960 (LRelu)
+* forward, train phase          local/tf/models.py:466-500 (ModelWithoutDropout), 569-605 (Tdnn), 895-960 (LRelu), 1022-1083 (LReluAttention)
 * batch-norm train branch       local/tf/tf_block.py:18-23: moments over every axis but the last (biased variance),
                                 normalise with the BATCH statistics, moving <- moving*decay + batch*(1-decay), decay 0.95
                                 (models.py:65,482)
@@ -33,6 +33,8 @@ def trainable_names(topo):
         names += ["%s/%s:0" % (sc, n) for n in ("w", "b", "gamma", "beta")]
         if topo.get("activation") == "prelu":
             names.append("%s/prelu/prelu:0" % sc)
+    if topo.get("pooling", "stats") == "attention":
+        names += ["attention/w:0", "attention/b:0", "attention/v:0"]     # models.py:1040-1043
     return names + ["output/w:0", "output/b:0"]
 
 
@@ -79,8 +81,15 @@ def forward(params, stats, topo, x, labels, train, dropout=None):
         r = _act(z, topo, alpha.view(1, -1, 1) if alpha is not None else None)
         h = drop(bn(r.transpose(1, 2), sc, (0, 1)), sc).transpose(1, 2)
     ht = h.transpose(1, 2)                                           # [B, T, C]
-    mu = ht.mean(dim=1)
-    var = ((ht - mu.unsqueeze(1)) ** 2).mean(dim=1)
+    if topo.get("pooling", "stats") == "attention":                  # models.py:1036-1050, op for op
+        h1, h2 = torch.chunk(ht, 2, dim=2)
+        nl = torch.tanh(torch.einsum("ijk,kl->ijl", h1, params["attention/w:0"]) + params["attention/b:0"])
+        att = torch.softmax(torch.einsum("ijk,k->ij", nl, params["attention/v:0"]), dim=-1)
+        mu = torch.einsum("ijk,ij->ik", h2, att)
+        var = torch.einsum("ijk,ij->ik", h2 * h2, att) - mu * mu
+    else:
+        mu = ht.mean(dim=1)
+        var = ((ht - mu.unsqueeze(1)) ** 2).mean(dim=1)
     h = torch.cat([mu, torch.sqrt(var + VAR2STD_EPSILON)], dim=1)
     e0 = None
     for j in range(len(topo["embedding_sizes"])):

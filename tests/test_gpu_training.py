@@ -30,7 +30,8 @@ def _setup(env, cls, widths=(64, 64, 64, 64, 96), emb=(32, 32), classes=10, feat
     return topo, w, rng
 
 
-@pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelL2LossWithoutDropoutLRelu"])
+@pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelL2LossWithoutDropoutLRelu",
+                                 "ModelL2LossWithoutDropoutLReluAttention"])
 def test_eval_batch_matches_oracle(env, cls):
     topo, w, rng = _setup(env, cls)
     x = (rng.standard_normal((6, 57, 23)) * 3).astype(np.float32)
@@ -42,7 +43,8 @@ def test_eval_batch_matches_oracle(env, cls):
 
 
 @pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelL2LossWithoutDropoutLRelu",
-                                 "ModelWithoutDropoutPRelu", "ModelL2LossWithoutDropoutPRelu"])
+                                 "ModelWithoutDropoutPRelu", "ModelL2LossWithoutDropoutPRelu",
+                                 "ModelL2LossWithoutDropoutLReluAttention"])
 def test_gradients_match_autograd(env, cls):
     topo, w, rng = _setup(env, cls, seed=3)
     B, T = 8, 211
@@ -330,3 +332,76 @@ def test_training_clis_end_to_end(env, tmp_path, capsys):
     eval_dnn.main(["--tar-file", tar, "--input-dir", d2, "--log-file", log])
     text = open(log).read()
     assert re.search(r"Overall average loss is [0-9.]+ over \\d+ segments", text) or "Overall average" in text
+
+
+def test_attention_backward_kernels_unit(env):
+    """xv_attention_{pool,softmax,scores}_backward_f32 against torch-CPU float64 autograd of the same three steps
+    (models.py:1045-1050), on a ragged layout with column-sliced h2 / dh2 buffers."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    from xvector_amd.engine import BatchLayout
+    rng = np.random.default_rng(4)
+    lens, A = [37, 5, 260], 96
+    lay = BatchLayout(lens, 3)
+    R = lay.rows
+    u_h = rng.standard_normal((R, A)).astype(np.float32)
+    v_h = (rng.standard_normal(A) * 0.3).astype(np.float32)
+    h_h = (rng.standard_normal((R, 2 * A)) + 1.0).astype(np.float32)
+    dp_h = rng.standard_normal((len(lens), 2 * A)).astype(np.float32)
+    dev = "cuda"
+    u, v, hbuf, dpool = (torch.from_numpy(a).to(dev) for a in (u_h, v_h, h_h, dp_h))
+    rs, rl = torch.from_numpy(lay.row_start).to(dev), torch.from_numpy(lay.row_len).to(dev)
+    scores = torch.empty(R, device=dev); nl = torch.empty((R, A), device=dev); att = torch.zeros(R, device=dev)
+    pooled = torch.empty((len(lens), 2 * A), device=dev)
+    hiplib.attention_scores(u, v, scores, nl)
+    hiplib.attention_softmax(scores, rs, rl, len(lens), att)
+    hiplib.attention_pool(hbuf[:, A:], att, rs, rl, len(lens), max(lens), 512, 1e-5, pooled)
+    dh = torch.zeros((R, 2 * A), device=dev); datt = torch.zeros(R, device=dev); dsc = torch.zeros(R, device=dev)
+    du = torch.empty((R, A), device=dev); dv = torch.empty(A, device=dev)
+    hiplib.attention_pool_backward(hbuf[:, A:], att, rs, rl, len(lens), max(lens), pooled, dpool, dh[:, A:], datt)
+    hiplib.attention_softmax_backward(att, datt, rs, rl, len(lens), dsc)
+    hiplib.attention_scores_backward(nl, dsc, v, du)
+    hiplib.col_sums(nl, None, dv)
+    torch.cuda.synchronize()
+    # float64 autograd of the same graph, chunk by chunk
+    ut = torch.tensor(u_h, dtype=torch.float64, requires_grad=True)
+    vt = torch.tensor(v_h, dtype=torch.float64, requires_grad=True)
+    ht = torch.tensor(h_h[:, A:], dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    for b, (s, n) in enumerate(zip(lay.row_start, lay.row_len)):
+        sl = slice(int(s), int(s) + int(n))
+        a = torch.softmax(torch.tanh(ut[sl]) @ vt, dim=0)
+        m = a @ ht[sl]
+        sd = torch.sqrt(a @ (ht[sl] ** 2) - m * m + 1e-5)
+        total = total + (torch.cat([m, sd]) * torch.tensor(dp_h[b], dtype=torch.float64)).sum()
+    gu, gv, gh = torch.autograd.grad(total, [ut, vt, ht])
+    assert _rel(du.cpu().numpy(), gu.numpy()) < 2e-5
+    assert _rel(dv.cpu().numpy(), gv.numpy()) < 2e-5
+    assert _rel(dh[:, A:].cpu().numpy(), gh.numpy()) < 2e-5
+    assert float(dh[:, :A].abs().max()) == 0.0                       # the h1 half was not touched
+
+
+def test_attention_class_bf16x3_gradients_and_adam_steps(env):
+    """The attention class on the split-precision GEMMs, and two optimizer steps in fp32 against the oracle."""
+    topo, w, rng = _setup(env, "ModelL2LossWithoutDropoutLReluAttention", seed=9)
+    B, T = 8, 205
+    x = (rng.standard_normal((B, T, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, B)
+    tr = env["trainer"].Trainer(w, topo, precision="bf16x3")
+    loss, acc, grads = tr.gradients(x, lab)
+    rl, ra, _, _, rg = env["ref"].train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3)
+    assert abs(loss - rl) < 1e-4 * max(1.0, abs(rl))
+    err = {n: _rel(grads[n].cpu().numpy(), rg[n]) for n in rg}
+    summed = lambda n: n.endswith("/b:0") or n.endswith("/beta:0")
+    top = sorted(err.items(), key=lambda kv: -kv[1])[:6]
+    assert max(e for n, e in err.items() if not summed(n)) < 5e-3, top
+    assert max(e for n, e in err.items() if summed(n)) < 2e-2, top
+    tr = env["trainer"].Trainer(w, topo)
+    ref_w, ref_adam = {k: np.array(v, np.float64) for k, v in w.items()}, {"t": 0, "m": {}, "v": {}}
+    for step in range(2):
+        loss, acc = tr.step(x, lab, 1e-3)
+        rl, ra, ref_w, ref_adam, _ = env["ref"].train_step(ref_w, ref_adam, topo, x.astype(np.float64), lab, 1e-3)
+        assert abs(loss - rl) < 2e-4 * max(1.0, abs(rl)), (step, loss, rl)
+    got, adam = tr.export()
+    assert adam["t"] == 2 and set(n for n in adam["m"] if n.startswith("attention/")) == {"attention/w:0", "attention/b:0", "attention/v:0"}
+    for n in ("attention/w:0", "attention/v:0", "frame_level_info_layer-4/w:0"):
+        assert _rel(got[n] - w[n], ref_w[n] - w[n]) < 0.05, n

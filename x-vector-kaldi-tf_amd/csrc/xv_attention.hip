@@ -204,6 +204,92 @@ __global__ void attention_pool_merge_kernel(const double *__restrict__ partial, 
     out[(size_t)b * 2 * C + C + c] = sqrtf((float)fmax(s2 - s1 * s1, 0.0) + eps);
 }
 
+
+// ---- backward (training step) -----------------------------------------------------------------------------------------
+// pooled = [m | sd], sd = sqrt(S2 - m^2 + eps), m = sum_t a_t x_t, S2 = sum_t a_t x_t^2.  With g2 = dsd/(2 sd) and
+// g1 = dm - 2 m g2:   dx[t,c] = a_t (g1[c] + 2 x[t,c] g2[c]),   da_t = sum_c x[t,c] g1[c] + x[t,c]^2 g2[c].
+// One wave64 per row of a chunk.
+__global__ __launch_bounds__(256) void attention_pool_backward_kernel(const float *__restrict__ h, long ldh, int C,
+                                                                      const float *__restrict__ att,
+                                                                      const int *__restrict__ row_start,
+                                                                      const int *__restrict__ row_len,
+                                                                      const float *__restrict__ pooled,
+                                                                      const float *__restrict__ dpooled,
+                                                                      float *__restrict__ dh, long lddh, float *__restrict__ datt)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= row_len[b]) return;
+    const size_t r = (size_t)row_start[b] + t;
+    const int lane = threadIdx.x & 63;
+    const float a = att[r];
+    const float *pm = pooled + (size_t)b * 2 * C, *pd = dpooled + (size_t)b * 2 * C;
+    double acc = 0.0;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(h + r * ldh + c);
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(pm + c), sd = *reinterpret_cast<const f32x4 *>(pm + C + c);
+        const f32x4 dm = *reinterpret_cast<const f32x4 *>(pd + c), dsd = *reinterpret_cast<const f32x4 *>(pd + C + c);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float g2 = dsd[i] / (2.0f * sd[i]);
+            const float g1 = dm[i] - 2.0f * m[i] * g2;
+            o[i] = a * (g1 + 2.0f * x[i] * g2);
+            acc += (double)x[i] * ((double)g1 + (double)x[i] * (double)g2);
+        }
+        *reinterpret_cast<f32x4 *>(dh + r * lddh + c) = o;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) datt[r] = (float)acc;
+}
+
+// a = softmax(s) over the rows of a chunk:  ds_t = a_t (da_t - sum_tau a_tau da_tau).  One workgroup per chunk.
+__global__ __launch_bounds__(256) void attention_softmax_backward_kernel(const float *__restrict__ att,
+                                                                         const float *__restrict__ datt,
+                                                                         const int *__restrict__ row_start,
+                                                                         const int *__restrict__ row_len,
+                                                                         float *__restrict__ dscores)
+{
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const int len = row_len[b];
+    if (len <= 0) return;
+    const size_t r0 = row_start[b];
+    const int tid = threadIdx.x;
+    double dot = 0.0;
+    for (int t = tid; t < len; t += 256) dot += (double)att[r0 + t] * (double)datt[r0 + t];
+    dot = wave_sum(dot);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    dot = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int t = tid; t < len; t += 256) dscores[r0 + t] = (float)((double)att[r0 + t] * ((double)datt[r0 + t] - dot));
+}
+
+// s_r = sum_c v_c n_rc, n = tanh(u):  du_rc = ds_r v_c (1 - n_rc^2);  nonlin is overwritten with ds_r n_rc, whose column sums
+// are dv (xv_col_sums_f32).  One wave64 per row.
+__global__ __launch_bounds__(256) void attention_scores_backward_kernel(float *__restrict__ nl, long ldn,
+                                                                        const float *__restrict__ dscores,
+                                                                        const float *__restrict__ v, long R, int C,
+                                                                        float *__restrict__ du, long lddu)
+{
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float ds = dscores[r];
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 n = *reinterpret_cast<const f32x4 *>(nl + r * ldn + c);
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(v + c);
+        f32x4 o, g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = ds * w[i] * (1.0f - n[i] * n[i]);
+            g[i] = ds * n[i];
+        }
+        *reinterpret_cast<f32x4 *>(du + r * lddu + c) = o;
+        *reinterpret_cast<f32x4 *>(nl + r * ldn + c) = g;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -265,6 +351,50 @@ int xv_attention_pool_f32(const float *h, int64_t ldh, int c, const float *att, 
         }
     }
     return 0;
+}
+
+int xv_attention_pool_backward_f32(const float *h, int64_t ldh, int c, const float *att, const int32_t *row_start,
+                                   const int32_t *row_len, int nchunks, int max_len, const float *pooled, const float *dpooled,
+                                   float *dh, int64_t lddh, float *datt, void *stream)
+{
+    if (nchunks <= 0 || max_len <= 0) return 0;
+    if (!h || !att || !row_start || !row_len || !pooled || !dpooled || !dh || !datt)
+        return att_fail(XV_ERR_BAD_ARG, "attention_pool_backward: NULL pointer");
+    if (c <= 0 || (c & 3) || (ldh & 3) || (lddh & 3) || ldh < c || lddh < c || (((uintptr_t)h) & 15) || (((uintptr_t)dh) & 15) ||
+        (((uintptr_t)pooled) & 15) || (((uintptr_t)dpooled) & 15))
+        return att_fail(XV_ERR_BAD_ARG, "attention_pool_backward: C, ld must be multiples of 4 and buffers 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    for (int b0 = 0; b0 < nchunks; b0 += 65535) {
+        const int nb = nchunks - b0 < 65535 ? nchunks - b0 : 65535;
+        hipLaunchKernelGGL(attention_pool_backward_kernel, dim3((max_len + 3) / 4, nb), dim3(256), 0, st, h, (long)ldh, c, att,
+                           row_start + b0, row_len + b0, pooled + (size_t)b0 * 2 * c, dpooled + (size_t)b0 * 2 * c, dh, (long)lddh,
+                           datt);
+        int rc = att_check("attention_pool_backward_kernel");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int xv_attention_softmax_backward_f32(const float *att, const float *datt, const int32_t *row_start, const int32_t *row_len,
+                                      int nchunks, float *dscores, void *stream)
+{
+    if (nchunks <= 0) return 0;
+    if (!att || !datt || !row_start || !row_len || !dscores) return att_fail(XV_ERR_BAD_ARG, "attention_softmax_backward: NULL pointer");
+    hipLaunchKernelGGL(attention_softmax_backward_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, att, datt, row_start,
+                       row_len, dscores);
+    return att_check("attention_softmax_backward_kernel");
+}
+
+int xv_attention_scores_backward_f32(float *nonlin, int64_t ldn, const float *dscores, const float *v, int64_t R, int c, float *du,
+                                     int64_t lddu, void *stream)
+{
+    if (R <= 0) return 0;
+    if (!nonlin || !dscores || !v || !du || c <= 0 || (c & 3) || (ldn & 3) || (lddu & 3) || ldn < c || lddu < c ||
+        (((uintptr_t)nonlin) & 15) || (((uintptr_t)du) & 15) || (((uintptr_t)v) & 15))
+        return att_fail(XV_ERR_BAD_ARG, "attention_scores_backward: C, ld must be multiples of 4 and buffers 16-byte aligned");
+    hipLaunchKernelGGL(attention_scores_backward_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, nonlin,
+                       (long)ldn, dscores, v, (long)R, c, du, (long)lddu);
+    return att_check("attention_scores_backward_kernel");
 }
 
 }  // extern "C"

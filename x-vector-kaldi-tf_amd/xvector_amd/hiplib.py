@@ -26,7 +26,8 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32
            # feature front-end
            "xv_cmn_sliding_scatter_f32",
            # self-attentive pooling
-           "xv_attention_scores_f32", "xv_attention_softmax_f32", "xv_attention_pool_workspace_bytes", "xv_attention_pool_f32")
+           "xv_attention_scores_f32", "xv_attention_softmax_f32", "xv_attention_pool_workspace_bytes", "xv_attention_pool_f32",
+           "xv_attention_pool_backward_f32", "xv_attention_softmax_backward_f32", "xv_attention_scores_backward_f32")
 
 FMT_F32, FMT_SPLIT = 0, 1
 SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 136
@@ -137,6 +138,12 @@ def load():
     lib.xv_attention_pool_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.xv_attention_pool_f32.restype = ci
     lib.xv_attention_pool_f32.argtypes = [vp, i64, ci, vp, vp, vp, ci, ci, ci, cf, vp, vp, vp]
+    lib.xv_attention_pool_backward_f32.restype = ci
+    lib.xv_attention_pool_backward_f32.argtypes = [vp, i64, ci, vp, vp, vp, ci, ci, vp, vp, vp, i64, vp, vp]
+    lib.xv_attention_softmax_backward_f32.restype = ci
+    lib.xv_attention_softmax_backward_f32.argtypes = [vp, vp, vp, vp, ci, vp, vp]
+    lib.xv_attention_scores_backward_f32.restype = ci
+    lib.xv_attention_scores_backward_f32.argtypes = [vp, i64, vp, vp, i64, ci, vp, i64, vp]
     if lib.xv_version() != ABI_VERSION:
         raise XvectorHipError("libxvector_hip.so ABI version %d != expected %d" % (lib.xv_version(), ABI_VERSION))
     _lib = lib
@@ -256,7 +263,7 @@ def tdnn_layer3(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y,
         assert x.channels == w.cin and x.rows >= R
         xp, ldx = ctypes.c_void_p(x.ptr), 0
     else:
-        _f32(x, "x"); assert x.shape[1] == w.cin and x.shape[0] >= R
+        _rows2d(x, "x"); assert x.shape[1] == w.cin and x.shape[0] >= R
         xp, ldx = _ptr(x), x.stride(0)
     if y is None:
         yp, ldy = None, 0
@@ -264,7 +271,7 @@ def tdnn_layer3(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y,
         assert y.channels == w.cout and y.rows >= R
         yp, ldy = ctypes.c_void_p(y.ptr), 0
     else:
-        _f32(y, "y"); assert y.shape[1] == w.cout and y.shape[0] >= R
+        _rows2d(y, "y"); assert y.shape[1] == w.cout and y.shape[0] >= R
         yp, ldy = _ptr(y), y.stride(0)
     ldpre = 0
     if y_preact is not None:
@@ -434,7 +441,7 @@ def rows_affine(x, scale, shift, row_valid, y, rows=None):
 def wgrad(x, dz, K, dilation, dw):
     """dw[K, Cin, Cout] (contiguous) = sum_r x[r + tap shift] (x) dz[r]."""
     lib = require_gpu()
-    _f32(x, "x"); _f32(dz, "dz"); _f32(dw, "dw")
+    _rows2d(x, "x"); _f32(dz, "dz"); _f32(dw, "dw")
     R, cin = x.shape
     cout = dz.shape[1]
     assert dz.shape[0] == R and tuple(dw.shape) == (K, cin, cout)
@@ -634,3 +641,31 @@ def attention_pool(h, att, row_start, row_len, nchunks, max_len, split_rows, eps
         assert workspace is not None and workspace.numel() * workspace.element_size() >= need, "attention pool workspace too small"
     _check(lib.xv_attention_pool_f32(_ptr(h), h.stride(0), c, _ptr(att), _ptr(row_start), _ptr(row_len), int(nchunks), int(max_len),
                                      int(split_rows), float(eps), _ptr(out), _ptr(workspace), _stream()), "xv_attention_pool_f32")
+
+
+def attention_pool_backward(h, att, row_start, row_len, nchunks, max_len, pooled, dpooled, dh, datt):
+    """h, dh: [R, C] rows (column slices allowed); pooled, dpooled: [nchunks, 2C]; datt: [R] (only chunk rows are written)."""
+    lib = require_gpu()
+    _rows2d(h, "h"); _rows2d(dh, "dh"); _f32(att, "att"); _f32(pooled, "pooled"); _f32(dpooled, "dpooled"); _f32(datt, "datt")
+    c = h.shape[1]
+    assert dh.shape == h.shape and pooled.shape[1] == 2 * c and dpooled.shape == pooled.shape and datt.numel() >= h.shape[0]
+    _check(lib.xv_attention_pool_backward_f32(_ptr(h), h.stride(0), c, _ptr(att), _ptr(row_start), _ptr(row_len), int(nchunks),
+                                              int(max_len), _ptr(pooled), _ptr(dpooled), _ptr(dh), dh.stride(0), _ptr(datt),
+                                              _stream()), "xv_attention_pool_backward_f32")
+
+
+def attention_softmax_backward(att, datt, row_start, row_len, nchunks, dscores):
+    lib = require_gpu()
+    _f32(att, "att"); _f32(datt, "datt"); _f32(dscores, "dscores")
+    _check(lib.xv_attention_softmax_backward_f32(_ptr(att), _ptr(datt), _ptr(row_start), _ptr(row_len), int(nchunks), _ptr(dscores),
+                                                 _stream()), "xv_attention_softmax_backward_f32")
+
+
+def attention_scores_backward(nonlin, dscores, v, du):
+    """du = dscores v (1 - nonlin^2); nonlin <- dscores * nonlin (column sums = dv)."""
+    lib = require_gpu()
+    _rows2d(nonlin, "nonlin"); _rows2d(du, "du"); _f32(dscores, "dscores"); _f32(v, "v")
+    R, c = nonlin.shape
+    assert du.shape == nonlin.shape and dscores.numel() >= R and v.numel() == c
+    _check(lib.xv_attention_scores_backward_f32(_ptr(nonlin), nonlin.stride(0), _ptr(dscores), _ptr(v), R, c, _ptr(du), du.stride(0),
+                                                _stream()), "xv_attention_scores_backward_f32")

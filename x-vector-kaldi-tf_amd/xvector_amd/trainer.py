@@ -32,8 +32,7 @@ class Trainer(object):
         import torch
         hiplib.require_gpu()
         assert precision in ("fp32", "bf16x3")
-        if tp.is_attention(topo):
-            raise NotImplementedError("training of the self-attentive pooling class is not implemented (extraction is)")
+        self.attention = tp.is_attention(topo)              # self-attentive pooling (models.py:1036-1050)
         self.precision = precision
         self.torch = torch
         self.device = torch.device(device)
@@ -55,6 +54,8 @@ class Trainer(object):
             self.trainable += ["%s/%s:0" % (sc, n) for n in ("w", "b", "gamma", "beta")]
             if self.prelu:
                 self.trainable.append(sc + "/prelu/prelu:0")
+        if self.attention:
+            self.trainable += ["attention/w:0", "attention/b:0", "attention/v:0"]
         self.trainable += ["output/w:0", "output/b:0"]
         self.t = int(adam["t"]) if adam else 0
         # every trainable tensor (and its Adam slots) is a view into ONE flat buffer, so the optimizer is one launch per step
@@ -140,7 +141,7 @@ class Trainer(object):
         if self._packed is not None:
             return self._packed
         pk = {}
-        for sc in self.frame_scopes + self.embed_scopes + ["output"]:
+        for sc in self.frame_scopes + self.embed_scopes + ["output"] + (["attention"] if self.attention else []):
             w = self._w3(sc, None)                                           # [K, Cin, Cout]
             K, cin, cout = w.shape
             # dgrad: dx[r,c] = sum_{k,o} dz[r - (k-(K-1)/2)d, o] w[k,c,o]  == the forward kernel on w'[k',o,c] = w[K-1-k',c,o]
@@ -211,9 +212,25 @@ class Trainer(object):
                 hiplib.dropout(h, S["seeds"][("frame", i)], S["keep"])
             S["r"].append(r); S["z"].append(z); S["h"].append(h); S["mean"].append(mean); S["var"].append(var)
         Cl = self.topo["layer_sizes"][-1]
-        pooled = torch.empty((B, 2 * Cl), dtype=torch.float32, device=self.device)
-        hiplib.stats_pool(S["h"][-1], L["rs"], L["rl"], B, T, 512, tp.VAR2STD_EPSILON, pooled,
-                          hiplib._ws(hiplib.stats_pool_workspace_bytes(Cl, B, T, 512), self.device))
+        if self.attention:
+            # h = [h1 | h2]: u = h1.W + b (one more K=1 GEMM), scores = v.tanh(u), softmax over the frames of each chunk,
+            # weighted mean / std of h2
+            A = Cl // 2
+            hl = S["h"][-1]
+            u = torch.empty((lay.rows, A), dtype=torch.float32, device=self.device)
+            hiplib.tdnn_layer(hl[:, :A], pk["attention"], self.P["attention/b:0"], None, None, tp.ACT_NONE, None, 1, 1, None, u)
+            scores = torch.empty(lay.rows, dtype=torch.float32, device=self.device)
+            S["nl"] = torch.empty_like(u) if want_grad else None
+            hiplib.attention_scores(u, self.P["attention/v:0"], scores, S["nl"])
+            S["att"] = torch.zeros(lay.rows, dtype=torch.float32, device=self.device)
+            hiplib.attention_softmax(scores, L["rs"], L["rl"], B, S["att"])
+            pooled = torch.empty((B, 2 * A), dtype=torch.float32, device=self.device)
+            hiplib.attention_pool(hl[:, A:], S["att"], L["rs"], L["rl"], B, T, 512, tp.VAR2STD_EPSILON, pooled,
+                                  hiplib._ws(hiplib.attention_pool_workspace_bytes(A, B, T, 512), self.device))
+        else:
+            pooled = torch.empty((B, 2 * Cl), dtype=torch.float32, device=self.device)
+            hiplib.stats_pool(S["h"][-1], L["rs"], L["rl"], B, T, 512, tp.VAR2STD_EPSILON, pooled,
+                              hiplib._ws(hiplib.stats_pool_workspace_bytes(Cl, B, T, 512), self.device))
         S["pooled"] = pooled
         S["e_in"], S["e_r"], S["e_z"], S["e_mean"], S["e_var"] = [pooled], [], [], [], []
         for j, sc in enumerate(self.embed_scopes):
@@ -250,8 +267,8 @@ class Trainer(object):
         return float(la[0]) + self._l2_value(), float(la[1])
 
     # -- backward + Adam -------------------------------------------------------------------------------------------
-    def _dense_backward(self, scope, x_in, dz, K, dil, grads, need_dx, valid):
-        """dW, db (and dx) of  z = conv(x_in, W) + b  given dz."""
+    def _dense_backward(self, scope, x_in, dz, K, dil, grads, need_dx, valid, dx_out=None):
+        """dW, db (and dx) of  z = conv(x_in, W) + b  given dz.  dx_out: optional [R, Cin] rows that receive dx."""
         torch = self.torch
         pk = self._pack()
         R, cin = x_in.shape
@@ -268,7 +285,7 @@ class Trainer(object):
         grads[scope + "/b:0"] = db
         if not need_dx:
             return None
-        dx = torch.empty((R, cin), dtype=torch.float32, device=self.device)
+        dx = dx_out if dx_out is not None else torch.empty((R, cin), dtype=torch.float32, device=self.device)
         hiplib.tdnn_layer(dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid, dx)
         return dx
 
@@ -325,8 +342,22 @@ class Trainer(object):
                 hiplib.dropout(d, S["seeds"][("embed", j)], S["keep"])
             dz = self._bn_backward(sc, d, S["e_r"][j], S["e_z"][j], S["e_mean"][j], S["e_var"][j], float(B), None, grads)
             d = self._dense_backward(sc, S["e_in"][j], dz, 1, 1, grads, True, None)
-        dh = torch.empty_like(S["h"][-1])
-        hiplib.pool_backward(S["h"][-1], L["rs"], L["rl"], B, S["pooled"], d, dh)
+        if self.attention:
+            hl = S["h"][-1]
+            A = hl.shape[1] // 2
+            dh = torch.zeros_like(hl)                                   # [dh1 | dh2]; gap rows stay zero
+            datt = torch.zeros(hl.shape[0], dtype=torch.float32, device=self.device)
+            dscores = torch.zeros_like(datt)
+            hiplib.attention_pool_backward(hl[:, A:], S["att"], L["rs"], L["rl"], B, T, S["pooled"], d, dh[:, A:], datt)
+            hiplib.attention_softmax_backward(S["att"], datt, L["rs"], L["rl"], B, dscores)
+            du = torch.empty_like(S["nl"])
+            hiplib.attention_scores_backward(S["nl"], dscores, self.P["attention/v:0"], du)     # S["nl"] <- dscores * tanh(u)
+            hiplib.col_sums(S["nl"], None, self.G["attention/v:0"])
+            grads["attention/v:0"] = self.G["attention/v:0"]
+            self._dense_backward("attention", hl[:, :A], du, 1, 1, grads, True, None, dx_out=dh[:, :A])
+        else:
+            dh = torch.empty_like(S["h"][-1])
+            hiplib.pool_backward(S["h"][-1], L["rs"], L["rl"], B, S["pooled"], d, dh)
         for i in reversed(range(len(self.frame_scopes))):
             sc = self.frame_scopes[i]
             if S["keep"] < 1.0 and ("frame", i) in S["seeds"]:
