@@ -237,3 +237,25 @@ def test_trainer_cli_accepts_the_command_line_train_dnn_builds(tmp_path):
     assert args.shuffle is True and args.minibatch_size == 2 and args.print_interval == 10
     with pytest.raises(Exception):
         cli.get_args([a for a in argv if not a.startswith("--tar-file")])          # no tar and the ranges file does not exist
+
+
+def test_build_model_initialisers_per_class():
+    """reference_init restates each class's initialisers: truncated_normal(0.1) / b = 0.1 / Xavier-uniform output
+    (models.py:56-58,98-100); He-normal / He-uniform / Glorot for ModelL2LossWithoutDropoutReluHeInit (models.py:1158-1210);
+    attention/{b,v} = 0.1, attention/w truncated_normal(0.1) (models.py:1040-1043)."""
+    from xvector_amd import synthetic, topology
+    w = synthetic.reference_init(topology.get("ModelWithoutDropout"), 23, 64, seed=3)
+    k = w["frame_level_info_layer-1/w:0"]
+    assert k.shape == (5, 512, 512) and abs(k.std() - 0.1 * 0.8796) < 2e-3 and np.abs(k).max() <= 0.2     # 2-sigma truncation
+    assert np.all(w["frame_level_info_layer-1/b:0"] == np.float32(0.1)) and np.all(w["output/b:0"] == np.float32(0.1))
+    assert np.abs(w["output/w:0"]).max() <= np.sqrt(6.0 / (512 + 64))
+    he = synthetic.reference_init(topology.get("ModelL2LossWithoutDropoutReluHeInit"), 23, 64, seed=3)
+    for name, fan_in in (("frame_level_info_layer-0", 5 * 23), ("frame_level_info_layer-2", 7 * 512), ("embed_layer-0", 3072)):
+        k, b = he[name + "/w:0"], he[name + "/b:0"]
+        sd = np.sqrt(2.0 / fan_in)
+        assert abs(k.std() / (sd * 0.8796) - 1) < 0.03 and np.abs(k).max() <= 2 * sd * 1.0001
+        assert np.abs(b).max() <= np.sqrt(6.0 / fan_in) and b.std() > 0.4 * np.sqrt(6.0 / fan_in)
+    assert abs(he["output/w:0"].std() / (np.sqrt(2.0 / 576) * 0.8796) - 1) < 0.03
+    att = synthetic.reference_init(topology.get("ModelL2LossWithoutDropoutLReluAttention"), 23, 64, seed=3)
+    assert att["attention/w:0"].shape == (1536, 1536) and np.all(att["attention/v:0"] == np.float32(0.1))
+    assert att["frame_level_info_layer-4/w:0"].shape == (1, 512, 3072) and att["embed_layer-0/w:0"].shape == (3072, 512)

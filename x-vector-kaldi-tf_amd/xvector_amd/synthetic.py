@@ -4,7 +4,8 @@ used once to manufacture "trained-like" running statistics; the extractor never 
 
 * ``reference_init``      -- the reference's initialisers: ``truncated_normal(stddev=0.1)`` weights,
                              ``b = 0.1``, BN gamma=1 beta=0 mean=0 variance=1, Xavier output layer
-                             (local/tf/models.py:56-58,82-84,98-100; local/tf/tf_block.py:10-14).
+                             (local/tf/models.py:56-58,82-84,98-100; local/tf/tf_block.py:10-14); He / Glorot
+                             initialisers for ModelL2LossWithoutDropoutReluHeInit (models.py:1158-1210).
 * ``trained_like``        -- the same shapes with fan-in-scaled weights, non-trivial gamma/beta and BN
                              running statistics calibrated on a random 2000-frame input, so that BN is
                              exercised and activations stay O(1) through the stack.
@@ -39,10 +40,17 @@ def reference_init(topo, feat_dim, num_classes, seed=0):
     rng = np.random.default_rng(seed)
     w = {}
     last = feat_dim
+    he = topo.get("init", "default") == "he"
     for scope, shape in _shapes(topo, feat_dim):
         c = shape[-1]
-        w[scope + "/w:0"] = _truncated_normal(rng, shape, 0.1)
-        w[scope + "/b:0"] = np.full(c, 0.1, np.float32)
+        if he:          # he_normal weights, he_uniform biases (models.py:1158-1163 frame level, 1181-1185 embedding layers)
+            fan_in = int(np.prod(shape[:-1]))
+            w[scope + "/w:0"] = _truncated_normal(rng, shape, np.sqrt(2.0 / fan_in))
+            lim = np.sqrt(6.0 / fan_in)
+            w[scope + "/b:0"] = rng.uniform(-lim, lim, size=c).astype(np.float32)
+        else:
+            w[scope + "/w:0"] = _truncated_normal(rng, shape, 0.1)
+            w[scope + "/b:0"] = np.full(c, 0.1, np.float32)
         w[scope + "/gamma:0"] = np.ones(c, np.float32)
         w[scope + "/beta:0"] = np.zeros(c, np.float32)
         w[scope + "/mean:0"] = np.zeros(c, np.float32)
@@ -56,6 +64,10 @@ def reference_init(topo, feat_dim, num_classes, seed=0):
         w["attention/v:0"] = np.full(a, 0.1, np.float32)
         w["attention/w:0"] = _truncated_normal(rng, (a, a), 0.1)
     lim = np.sqrt(6.0 / (last + num_classes))                             # xavier_initializer (uniform)
+    if he:              # glorot_normal weights, glorot_uniform bias (models.py:1205-1210)
+        w["output/w:0"] = _truncated_normal(rng, (last, num_classes), np.sqrt(2.0 / (last + num_classes)))
+        w["output/b:0"] = rng.uniform(-lim, lim, size=num_classes).astype(np.float32)
+        return w
     w["output/w:0"] = rng.uniform(-lim, lim, size=(last, num_classes)).astype(np.float32)
     w["output/b:0"] = np.full(num_classes, 0.1, np.float32)
     return w

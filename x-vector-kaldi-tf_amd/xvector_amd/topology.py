@@ -22,6 +22,8 @@ _BASE = dict(
     l2_beta=0.0,                                # training only: loss += l2_beta*(0.1*l2(embed-0) + l2(embed-1) + l2(output))
     dropout=False,                              # training only: tf.nn.dropout sites after BN (class Model, models.py:70-72,92-94)
     head=None,                                  # training only: None = softmax-CE on output/xw_plus_b (models.py:96-113)
+    init="default",                             # build_model only: "default" = truncated_normal(0.1) / b = 0.1 / Xavier output
+                                                # (models.py:56-58,98-100); "he" = models.py:1158-1163,1181-1185,1205-1210
     pooling="stats",                            # "stats": tf.nn.moments over time (models.py:75-76); "attention": see below
 )
 
@@ -34,7 +36,7 @@ TOPOLOGIES = {
     "ModelWithoutDropoutPRelu":              dict(_BASE, activation="prelu"),                # models.py:643-742
     "ModelL2LossWithoutDropoutPRelu":        dict(_BASE, activation="prelu", l2_beta=0.0002),   # models.py:746-862 (beta :756)
     "ModelL2LossWithoutDropoutLRelu":        dict(_BASE, activation="lrelu", l2_beta=0.0002),   # models.py:866-981 (beta :876)
-    "ModelL2LossWithoutDropoutReluHeInit":   dict(_BASE, l2_beta=0.0002),                       # models.py:1118-1244 (beta :1128)
+    "ModelL2LossWithoutDropoutReluHeInit":   dict(_BASE, l2_beta=0.0002, init="he"),            # models.py:1118-1244 (beta :1128)
     # self-attentive pooling: the last layer is 6*512 wide and split into h1 | h2; weights softmax_t(v . tanh(h1 W + b)) pool h2
     # (models.py:985-1114: sizes :992, split/attention :1036-1050, beta :995); variables attention/{w,b,v}:0
     "ModelL2LossWithoutDropoutLReluAttention": dict(_BASE, layer_sizes=[512, 512, 512, 512, 3072], activation="lrelu",
