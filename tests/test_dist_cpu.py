@@ -57,3 +57,83 @@ def test_two_rank_gloo_sharded_gather(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK 2" in outs[0]
+
+
+DRIVER_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    import train_dnn
+
+    class FakeModel(object):            # stands in for the GPU trainer: one collective per step, like Trainer._allreduce
+        def build_model(self, num_classes, feat_dim, out, logger=None):
+            os.makedirs(out); open(os.path.join(out, "model.meta"), "wt").write("init"); open(os.path.join(out, "done"), "wt").write("done")
+        def train_one_iteration(self, loader, args, logger):
+            steps = 0
+            for _ in range(loader.count):
+                data, lab = loader.pop()
+                assert data is not None
+                t = torch.tensor([1.0]); dist.all_reduce(t); assert t.item() == dist.get_world_size()
+                steps += 1
+            logger.info("Overall average objective function is %%.4f over %%d segments." %% (-1.0, steps))
+            assert args.save_model == (dist.get_rank() == 0)
+            if args.save_model:
+                os.makedirs(args.output_dir)
+                open(os.path.join(args.output_dir, "model.meta"), "wt").write("from %%s steps=%%d lr=%%.6f seed=%%d" %% (
+                    os.path.basename(args.input_dir), steps, args.learning_rate, args.random_seed))
+                open(os.path.join(args.output_dir, "done"), "wt").write("done")
+        def eval(self, loader, input_dir, use_gpu, logger):
+            logger.info("Overall average loss is 0.5000 over 8 segments. Also, the overall average accuracy is 0.7500.")
+
+    train_dnn.models.Model = FakeModel
+    train_dnn.models.ModelWithoutDropout = FakeModel
+    train_dnn.main(sys.argv[1:])
+    print("DRIVER_OK")
+""")
+
+
+def test_two_rank_gloo_training_driver(tmp_path):
+    """train_dnn.py under a 2-rank gloo group with a stand-in model: archive assignment per rank (train_dnn.py:246-249), the
+    step count capped to the shortest archive of the iteration, a collective per step on both ranks, rank 0 alone writes the
+    models, per-job logs, diagnostics spread over the ranks, model_final + accuracy.report."""
+    import examples_io
+    from conftest import TWIN
+    egs, exp = str(tmp_path / "egs"), str(tmp_path / "exp")
+    os.makedirs(os.path.join(egs, "info")); os.makedirs(os.path.join(egs, "temp"))
+    open(os.path.join(egs, "info", "feat_dim"), "wt").write("5\n")
+    open(os.path.join(egs, "info", "num_archives"), "wt").write("4\n")
+    rng = np.random.default_rng(0)
+    counts = {1: 3, 2: 2, 3: 3, 4: 4}
+    with open(os.path.join(egs, "temp", "archive_minibatch_count"), "wt") as fid:
+        for a, c in counts.items():
+            examples_io.write_egs_tar(os.path.join(egs, "egs.%d.tar" % a), [rng.standard_normal((4, 10 + a, 5)) for _ in range(c)],
+                                      rng.integers(0, 3, (c, 4)))
+            fid.write("%d %d\n" % (a, c))
+    for name in ("valid_egs.1.tar", "train_subset_egs.1.tar"):
+        examples_io.write_egs_tar(os.path.join(egs, name), [rng.standard_normal((4, 9, 5))], rng.integers(0, 3, (1, 4)))
+    script = tmp_path / "driver_worker.py"
+    script.write_text(DRIVER_WORKER % (PKG, TWIN))
+    port = 31000 + (os.getpid() % 2000)
+    flags = ["--tf-model-class", "ModelWithoutDropout", "--dir", exp, "--egs-dir", egs, "--num-targets", "3", "--minibatch-size", "4",
+             "--num-epochs", "1", "--cleanup", "false", "--random-seed", "7"]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)] + flags, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("DRIVER_OK" in o for o in outs)
+    # 4 archives / 2 ranks = 2 iterations; iteration 0: archives 1,2 -> min(3,2) steps; iteration 1: archives 3,4 -> min(3,4)
+    m1 = open(os.path.join(exp, "model_1", "model.meta")).read()
+    m2 = open(os.path.join(exp, "model_2", "model.meta")).read()
+    assert m1.startswith("from model_0 steps=2 ") and m1.endswith("seed=7"), m1
+    assert m2.startswith("from model_1 steps=3 ") and m2.endswith("seed=8"), m2
+    lr1, lr2 = float(m1.split("lr=")[1].split()[0]), float(m2.split("lr=")[1].split()[0])
+    assert abs(lr1 - 2 * 0.0003) < 1e-9 and abs(lr2 - 2 * 0.00003) < 1e-9              # ze_utils.py:111-120 with num_jobs = 2
+    logs = sorted(os.listdir(os.path.join(exp, "log")))
+    assert [l for l in logs if l.startswith("train.")] == ["train.0.1.log", "train.0.2.log", "train.1.1.log", "train.1.2.log"]
+    assert "over 2 segments" in open(os.path.join(exp, "log", "train.0.2.log")).read()
+    assert "compute_prob_valid.1.log" in logs and "compute_prob_train_subset.1.log" in logs
+    assert os.readlink(os.path.join(exp, "model_final")) == "model_2"
+    rep = open(os.path.join(exp, "accuracy.report")).read().splitlines()
+    assert len(rep) == 4 and rep[1].split("\t")[0] == "0" and rep[1].split("\t")[2:] == ["0.5", "0.5", "0", "0.75", "0.75", "0"]

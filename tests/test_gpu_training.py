@@ -405,3 +405,77 @@ def test_attention_class_bf16x3_gradients_and_adam_steps(env):
     assert adam["t"] == 2 and set(n for n in adam["m"] if n.startswith("attention/")) == {"attention/w:0", "attention/b:0", "attention/v:0"}
     for n in ("attention/w:0", "attention/v:0", "frame_level_info_layer-4/w:0"):
         assert _rel(got[n] - w[n], ref_w[n] - w[n]) < 0.05, n
+
+
+def _make_egs_dir(root, n_archives, n_spk=6, F=23, B=16, mb_per_archive=4, seed=0):
+    """A miniature egs directory as get_egs.sh leaves it: info/, temp/archive_minibatch_count, egs.<n>.tar (+ labels),
+    valid_egs.1.tar, train_subset_egs.1.tar."""
+    import os
+    import examples_io
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((n_spk, F)) * 2
+    os.makedirs(os.path.join(root, "info")); os.makedirs(os.path.join(root, "temp"))
+    open(os.path.join(root, "info", "feat_dim"), "wt").write("%d\n" % F)
+    open(os.path.join(root, "info", "num_archives"), "wt").write("%d\n" % n_archives)
+
+    def archive(path, count):
+        mbs, labs = [], []
+        for i in range(count):
+            lab = rng.integers(0, n_spk, B)
+            mbs.append((centers[lab][:, None, :] + rng.standard_normal((B, 50 + 3 * i, F))).astype(np.float32))
+            labs.append(lab)
+        examples_io.write_egs_tar(path, mbs, np.array(labs, np.int32))
+
+    with open(os.path.join(root, "temp", "archive_minibatch_count"), "wt") as fid:
+        for a in range(1, n_archives + 1):
+            count = mb_per_archive + (a % 2)                  # unequal archives
+            archive(os.path.join(root, "egs.%d.tar" % a), count)
+            fid.write("%d %d\n" % (a, count))
+    archive(os.path.join(root, "valid_egs.1.tar"), 2)
+    archive(os.path.join(root, "train_subset_egs.1.tar"), 2)
+
+
+def test_train_dnn_driver_end_to_end(env, tmp_path, monkeypatch):
+    """train_dnn.py (the in-process driver): model_0 + model_name.txt, one model per iteration, schedules, diagnostics and
+    per-job logs in the reference's format, clean-up rule, model_final link, accuracy.report; --stage resumes; the final
+    model extracts.  The process-group path runs as a forced 1-rank RCCL group (multi-rank: world_size-2 gloo test on CPU)."""
+    import os
+    import re
+    import train_dnn
+    from xvector_amd import weights as wio
+    egs = str(tmp_path / "egs"); exp = str(tmp_path / "exp")
+    _make_egs_dir(egs, 3)
+    flags = ["--tf-model-class", "ModelWithoutDropout", "--dir", exp, "--egs-dir", egs, "--num-targets", "6", "--minibatch-size", "16",
+             "--num-epochs", "2", "--initial-effective-lrate", "0.002", "--final-effective-lrate", "0.0005", "--print-interval", "2",
+             "--preserve-model-interval", "4", "--dropout-schedule", "0,0@0.20,0.1@0.50,0"]
+    train_dnn.main(flags)
+    assert open(os.path.join(exp, "model_name.txt")).read() == "ModelWithoutDropout"
+    # 2 epochs x 3 archives, 1 job -> 6 iterations; clean-up keeps multiples of 4 and the final model
+    kept = sorted(d for d in os.listdir(exp) if d.startswith("model_") and d != "model_name.txt")
+    assert kept == ["model_0", "model_4", "model_6", "model_final"], kept
+    assert os.path.islink(os.path.join(exp, "model_final")) and os.readlink(os.path.join(exp, "model_final")) == "model_6"
+    assert wio.is_correct_model_dir(os.path.join(exp, "model_final"))
+    # archive 1, 2, 3, 1, ... with 5, 4, 5 minibatches: Adam took 5+4+5+5+4+5 steps
+    assert wio.load_optimizer_state(os.path.join(exp, "model_6"))["t"] == 28
+    logs = sorted(os.listdir(os.path.join(exp, "log")))
+    assert [l for l in logs if l.startswith("train.")] == ["train.%d.1.log" % i for i in range(6)]
+    assert len([l for l in logs if l.startswith("compute_prob_valid.")]) == 6
+    text = open(os.path.join(exp, "log", "train.3.1.log")).read()
+    assert re.search(r"INFO .* Overall average objective function is -?[0-9.]+ over \d+ segments", text)     # ze_utils.py:126-127
+    assert "# Accounting: time=" in text
+    losses = [float(re.search(r"Overall average training loss is ([0-9.]+)", open(os.path.join(exp, "log", "train.%d.1.log" % i)).read()).group(1))
+              for i in range(6)]
+    assert losses[-1] < losses[0]
+    rep = open(os.path.join(exp, "accuracy.report")).read().splitlines()
+    assert rep[0].startswith("%Iter\tduration\ttrain_loss\tvalid_loss") and len(rep) >= 8 and rep[1].split("\t")[0] == "0"
+    # resume: nothing below --stage is touched, existing models are not retrained
+    before = os.path.getmtime(os.path.join(exp, "model_6", "model.meta"))
+    train_dnn.main(flags + ["--stage", "5"])
+    assert os.path.getmtime(os.path.join(exp, "model_6", "model.meta")) == before
+    # the same driver inside a (1-rank) RCCL process group
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"),
+                 ("XV_FORCE_DIST", "1")):
+        monkeypatch.setenv(k, v)
+    exp2 = str(tmp_path / "exp2")
+    train_dnn.main([f if f != exp else exp2 for f in flags] + ["--num-epochs", "1"])
+    assert wio.is_correct_model_dir(os.path.join(exp2, "model_final"))

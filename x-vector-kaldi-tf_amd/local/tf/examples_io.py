@@ -57,6 +57,7 @@ class TarFileDataLoader(object):
         self._left = self.count
         self._logger = logger
         self.queue = queue.Queue(queue_size)
+        self._stop = threading.Event()
         self._thread = threading.Thread(target=self._fill, daemon=True)
         self._thread.start()
 
@@ -65,7 +66,20 @@ class TarFileDataLoader(object):
             index = int(name[:-4].split("_")[1])              # minibatch_<index>.npy
             # read the member fully first: numpy cannot memory-map a tar member and (numpy 2.x) probes fileno()
             data = np.load(io.BytesIO(self._tar.extractfile(name).read()))
-            self.queue.put((data, self._labels[index]))
+            while not self._stop.is_set():
+                try:
+                    self.queue.put((data, self._labels[index]), timeout=0.2)
+                    break
+                except queue.Full:
+                    continue
+            if self._stop.is_set():
+                return
+
+    def close(self):
+        """Stop the reader thread and release the archive (a consumer that pops fewer than ``count`` minibatches)."""
+        self._stop.set()
+        self._thread.join()
+        self._tar.close()
 
     def pop(self, timeout=30):
         if self._left == 0:

@@ -208,10 +208,13 @@ class Model(object):
                                                             total_accuracy / minibatch_count))
         logger.info("Overall average objective function is %.4f over %d segments." %
                     (total_objective / minibatch_count, total_segments))
-        w, adam = tr.export()
-        self.save_model(dict(weights=w, topology=self.meta["topology"], model_class=self.meta["model_class"],
-                             num_classes=self.meta["num_classes"], feat_dim=self.meta["feat_dim"]), args.output_dir, logger)
-        wio.save_optimizer_state(args.output_dir, adam)
+        if getattr(args, "save_model", True):          # data-parallel driver (train_dnn.py): only one rank of the group writes
+            w, adam = tr.export()
+            # optimizer slots first, the model (whose 'done' marker completes the directory) last
+            os.makedirs(args.output_dir, exist_ok=True)
+            wio.save_optimizer_state(args.output_dir, adam)
+            self.save_model(dict(weights=w, topology=self.meta["topology"], model_class=self.meta["model_class"],
+                                 num_classes=self.meta["num_classes"], feat_dim=self.meta["feat_dim"]), args.output_dir, logger)
         logger.info("Elapsed time for processing whole training minibatches is %.2f minutes." %
                     ((time.time() - start_time) / 60.0))
 
