@@ -160,6 +160,21 @@ def test_eval_logs_parse_with_the_reference_accuracy_report(ref_env, tmp_path, m
     assert [r[0] for r in rows] == [3, 7]
     for it, tl, ta, vl, va in rows:
         assert (tl, ta, vl, va) == pytest.approx(want[it], abs=1e-4)
+    # the driver's per-job logs end with the trailer queue.pl/run.pl leave ("# Accounting: time=<s> threads=1"): the
+    # reference's generate_report (ze_utils.py:467-558) and the twin's produce the same accuracy.report from this directory
+    for it, job, sec in ((3, 1, 41), (3, 2, 57), (7, 1, 12)):
+        (tmp_path / "log" / ("train.%d.%d.log" % (it, job))).write_text(
+            "2026-01-01 00:00:00,000 [x.py:1 - f - INFO ] Overall average objective function is -0.5 over 9 segments.\n"
+            "# Accounting: time=%d threads=1\n" % sec)
+    from conftest import TWIN                   # sys.modules["ze_utils"] is the reference's here: load the twin by path
+    spec = importlib.util.spec_from_file_location("ze_utils_twin", os.path.join(TWIN, "ze_utils.py"))
+    twin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(twin)
+    assert twin.__file__ != ref_env["ze_utils"].__file__
+    ref_report, ref_times, ref_data = ref_env["ze_utils"].generate_report(str(tmp_path))
+    report, times, data = twin.generate_report(str(tmp_path))
+    assert times == ref_times == {3: 57.0, 7: 12.0}
+    assert data == ref_data and report == ref_report
 
 
 def test_egs_archives_interchange_with_the_reference_loader(ref_env, tmp_path):
