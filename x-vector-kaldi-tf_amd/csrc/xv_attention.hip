@@ -48,7 +48,17 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
-// One wave64 per row: scores[r] = sum_c v[c] * tanh(u[r,c]); a lane takes float4 number lane, lane+64, ... of the row.
+// tanh(x) = 1 - 2/(e^{2x} + 1) on the hardware exp / rcp: ~1e-7 ABSOLUTE error (the rounding level of an fp32 result near
+// 1; what matters for sum_c v_c tanh(u_c) and for 1 - n^2 in the backward), exact limits (e -> inf gives 1, e -> 0 gives
+// -1), 5 instructions.  The library tanhf (branches, IEEE division, relative accuracy for tiny arguments) made the scores
+// kernel compute-bound at 47 % of the HBM peak.
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
+
+// One wave64 per row: scores[r] = sum_c v[c] * tanh(u[r,c]); a lane takes float4 number lane, lane+64, ... of the row
+// (<= 24 fp32 terms per lane for C = 1536), the 64 lane sums are added in fp64.
 __global__ __launch_bounds__(256) void attention_scores_kernel(const float *__restrict__ u, long ldu, long R, int C,
                                                                const float *__restrict__ v, float *__restrict__ scores,
                                                                float *__restrict__ nl, long ldn)
@@ -57,19 +67,37 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(const float *__re
     if (r >= R) return;
     const int lane = threadIdx.x & 63;
     const float *row = u + r * ldu;
-    double acc = 0.0;
-    for (int c = lane * 4; c < C; c += 256) {
+    float part = 0.0f;
+    int c = lane * 4;
+    for (; c + 256 < C; c += 512) {                 // two independent 16-byte loads in flight per lane
+        const f32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(row + c));
+        const f32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(row + c + 256));
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(v + c), w1 = *reinterpret_cast<const f32x4 *>(v + c + 256);
+        f32x4 t0, t1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            t0[i] = tanh_fast(x0[i]);
+            t1[i] = tanh_fast(x1[i]);
+            part = fmaf(w0[i], t0[i], part);
+            part = fmaf(w1[i], t1[i], part);
+        }
+        if (nl) {                                   // training keeps tanh(u) for the backward
+            *reinterpret_cast<f32x4 *>(nl + r * ldn + c) = t0;
+            *reinterpret_cast<f32x4 *>(nl + r * ldn + c + 256) = t1;
+        }
+    }
+    if (c < C) {
         const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(row + c));
         const f32x4 w = *reinterpret_cast<const f32x4 *>(v + c);
         f32x4 t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            t[i] = tanhf(x[i]);
-            acc += (double)w[i] * (double)t[i];
+            t[i] = tanh_fast(x[i]);
+            part = fmaf(w[i], t[i], part);
         }
-        if (nl) *reinterpret_cast<f32x4 *>(nl + r * ldn + c) = t;       // training keeps tanh(u) for the backward
+        if (nl) *reinterpret_cast<f32x4 *>(nl + r * ldn + c) = t;
     }
-    acc = wave_sum(acc);
+    const double acc = wave_sum((double)part);
     if (lane == 0) scores[r] = (float)acc;
 }
 
@@ -208,7 +236,10 @@ __global__ void attention_pool_merge_kernel(const double *__restrict__ partial, 
 // ---- backward (training step) -----------------------------------------------------------------------------------------
 // pooled = [m | sd], sd = sqrt(S2 - m^2 + eps), m = sum_t a_t x_t, S2 = sum_t a_t x_t^2.  With g2 = dsd/(2 sd) and
 // g1 = dm - 2 m g2:   dx[t,c] = a_t (g1[c] + 2 x[t,c] g2[c]),   da_t = sum_c x[t,c] g1[c] + x[t,c]^2 g2[c].
-// One wave64 per row of a chunk.
+// One workgroup per (chunk, block of APB_ROWS rows): g1, g2 of the chunk are formed once per workgroup in LDS (2*C floats,
+// one division per channel instead of one per element), then each of the 4 waves takes every 4th row of the block.
+constexpr int APB_ROWS = 32;
+
 __global__ __launch_bounds__(256) void attention_pool_backward_kernel(const float *__restrict__ h, long ldh, int C,
                                                                       const float *__restrict__ att,
                                                                       const int *__restrict__ row_start,
@@ -217,30 +248,38 @@ __global__ __launch_bounds__(256) void attention_pool_backward_kernel(const floa
                                                                       const float *__restrict__ dpooled,
                                                                       float *__restrict__ dh, long lddh, float *__restrict__ datt)
 {
+    extern __shared__ float g[];                     // g1[C] | g2[C]
     const int b = blockIdx.y;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= row_len[b]) return;
-    const size_t r = (size_t)row_start[b] + t;
-    const int lane = threadIdx.x & 63;
-    const float a = att[r];
+    const int len = row_len[b];
+    const int t0 = blockIdx.x * APB_ROWS;
+    if (t0 >= len) return;
     const float *pm = pooled + (size_t)b * 2 * C, *pd = dpooled + (size_t)b * 2 * C;
-    double acc = 0.0;
-    for (int c = lane * 4; c < C; c += 256) {
-        const f32x4 x = *reinterpret_cast<const f32x4 *>(h + r * ldh + c);
-        const f32x4 m = *reinterpret_cast<const f32x4 *>(pm + c), sd = *reinterpret_cast<const f32x4 *>(pm + C + c);
-        const f32x4 dm = *reinterpret_cast<const f32x4 *>(pd + c), dsd = *reinterpret_cast<const f32x4 *>(pd + C + c);
-        f32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float g2 = dsd[i] / (2.0f * sd[i]);
-            const float g1 = dm[i] - 2.0f * m[i] * g2;
-            o[i] = a * (g1 + 2.0f * x[i] * g2);
-            acc += (double)x[i] * ((double)g1 + (double)x[i] * (double)g2);
-        }
-        *reinterpret_cast<f32x4 *>(dh + r * lddh + c) = o;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float g2 = pd[C + c] / (2.0f * pm[C + c]);
+        g[C + c] = g2;
+        g[c] = pd[c] - 2.0f * pm[c] * g2;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) datt[r] = (float)acc;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int t1 = min(t0 + APB_ROWS, len);
+    for (int t = t0 + (threadIdx.x >> 6); t < t1; t += 4) {
+        const size_t r = (size_t)row_start[b] + t;
+        const float a = att[r];
+        double acc = 0.0;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(h + r * ldh + c));
+            const f32x4 g1 = *reinterpret_cast<const f32x4 *>(g + c), g2 = *reinterpret_cast<const f32x4 *>(g + C + c);
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i] = a * (g1[i] + 2.0f * x[i] * g2[i]);
+                acc += (double)x[i] * ((double)g1[i] + (double)x[i] * (double)g2[i]);
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(dh + r * lddh + c));
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) datt[r] = (float)acc;
+    }
 }
 
 // a = softmax(s) over the rows of a chunk:  ds_t = a_t (da_t - sum_tau a_tau da_tau).  One workgroup per chunk.
@@ -363,10 +402,12 @@ int xv_attention_pool_backward_f32(const float *h, int64_t ldh, int c, const flo
     if (c <= 0 || (c & 3) || (ldh & 3) || (lddh & 3) || ldh < c || lddh < c || (((uintptr_t)h) & 15) || (((uintptr_t)dh) & 15) ||
         (((uintptr_t)pooled) & 15) || (((uintptr_t)dpooled) & 15))
         return att_fail(XV_ERR_BAD_ARG, "attention_pool_backward: C, ld must be multiples of 4 and buffers 16-byte aligned");
+    if (c > 8192) return att_fail(XV_ERR_UNSUPPORTED, "attention_pool_backward: more than 8192 channels");      // 64 KB of LDS
     hipStream_t st = (hipStream_t)stream;
     for (int b0 = 0; b0 < nchunks; b0 += 65535) {
         const int nb = nchunks - b0 < 65535 ? nchunks - b0 : 65535;
-        hipLaunchKernelGGL(attention_pool_backward_kernel, dim3((max_len + 3) / 4, nb), dim3(256), 0, st, h, (long)ldh, c, att,
+        hipLaunchKernelGGL(attention_pool_backward_kernel, dim3((max_len + APB_ROWS - 1) / APB_ROWS, nb), dim3(256),
+                           2 * (size_t)c * sizeof(float), st, h, (long)ldh, c, att,
                            row_start + b0, row_len + b0, pooled + (size_t)b0 * 2 * c, dpooled + (size_t)b0 * 2 * c, dh, (long)lddh,
                            datt);
         int rc = att_check("attention_pool_backward_kernel");
