@@ -1,5 +1,6 @@
 """Development aid: extraction rate of every model class (SURVEY §8f-3 + the attention class) on BASELINE configs[1]-shaped
-input resident in HBM, with a parity spot check against the fp64 oracle.  bench.py stays the headline (default class)."""
+input resident in HBM (timing only; parity of every class is asserted by tests/test_gpu_forward.py).  bench.py stays the
+headline (default class)."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd"))
@@ -17,7 +18,6 @@ ap.add_argument("--classes", nargs="*", default=["ModelWithoutDropout", "ModelWi
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 feat = 23
-from oracle import oracle          # checker only
 for cls in args.classes:
     topo = tp.get(cls)
     weights = synthetic.trained_like(topo, feat, seed=1)
@@ -57,14 +57,9 @@ for cls in args.classes:
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    got = xvec.cpu().numpy()
-    worst = 0.0
-    for j in (0, batches[0]["n"] // 2, batches[0]["n"] - 1):
-        lay = batches[0]["lay"]; s, m = int(lay.row_start[j]), int(lay.row_len[j])
-        ref = oracle.embed_utterance(batches[0]["x"][s:s + m, :feat].cpu().numpy(), weights, topo, 25, 10000, np.float64)
-        worst = max(worst, oracle.rel_l2(got[j], ref))
+    assert bool(torch.isfinite(xvec).all())
     fl = tp.flops_per_frame(topo, feat) * frames + tp.flops_per_utt(topo) * n
     print(json.dumps({"class": cls, "precision": args.precision, "utt_per_s": n / dt, "ms_per_step": dt * 1e3,
-                      "algorithmic_tflops": fl / dt / 1e12, "gflop_per_utt": fl / n / 1e9, "parity_rel_l2_max": worst}))
+                      "algorithmic_tflops": fl / dt / 1e12, "gflop_per_utt": fl / n / 1e9}))
     del model, batches, E, P, xvec
     torch.cuda.empty_cache()
