@@ -259,3 +259,31 @@ def test_build_model_initialisers_per_class():
     att = synthetic.reference_init(topology.get("ModelL2LossWithoutDropoutLReluAttention"), 23, 64, seed=3)
     assert att["attention/w:0"].shape == (1536, 1536) and np.all(att["attention/v:0"] == np.float32(0.1))
     assert att["frame_level_info_layer-4/w:0"].shape == (1, 512, 3072) and att["embed_layer-0/w:0"].shape == (3072, 512)
+
+
+def test_native_batch_packer_equals_numpy_pack():
+    """xv_pack_rows_f32 (libxvector_host.so) writes exactly what BatchLayout.pack + row_valid write: chunk rows copied, every
+    other row zeroed, padding columns untouched, on 1..5 threads; inconsistent layouts are refused."""
+    from xvector_amd import engine
+    lib = engine._host_lib()
+    assert lib is not None
+    rng = np.random.default_rng(0)
+    for F, ld, align, lens in ((23, 24, 8, [25, 1, 300, 7, 64] * 9), (23, 24, 1, [5]), (16, 16, 1, [40, 3, 3, 900]), (23, 24, 8, [])):
+        mats = [rng.standard_normal((t, F)).astype(np.float32) for t in lens]
+        lay = engine.BatchLayout(lens, 3, align)
+        want = np.full((lay.rows + 5, ld), 7.0, np.float32); want[:, F:] = 0
+        want_rv = np.full(lay.rows + 5, 9, np.uint8)
+        lay.pack(mats, want); lay.row_valid(want_rv)
+        src = np.array([m.__array_interface__["data"][0] for m in mats], np.uint64)
+        ln = np.array(lens, np.int32)
+        for nt in (1, 2, 5):
+            got = np.full((lay.rows + 5, ld), 7.0, np.float32); got[:, F:] = 0
+            got_rv = np.full(lay.rows + 5, 9, np.uint8)
+            rc = lib.xv_pack_rows_f32(src.ctypes.data, ln.ctypes.data, lay.row_start.ctypes.data, len(lens), F, got.ctypes.data, ld,
+                                      lay.rows, got_rv.ctypes.data, nt)
+            assert rc == 0 and np.array_equal(got, want) and np.array_equal(got_rv, want_rv), (F, ld, align, nt)
+    bad = np.array([10, 5], np.int32)                                   # not ascending
+    two = np.array([3, 3], np.int32)
+    buf = np.zeros((32, 24), np.float32)
+    assert lib.xv_pack_rows_f32(src.ctypes.data if len(src) else 0, two.ctypes.data, bad.ctypes.data, 2, 23, buf.ctypes.data, 24, 32, None, 1) == -1
+    assert lib.xv_pack_rows_f32(0, two.ctypes.data, np.array([0, 30], np.int32).ctypes.data, 2, 23, buf.ctypes.data, 24, 32, None, 1) == -1   # overruns dst_rows

@@ -250,3 +250,35 @@ def test_table_writer_batch_equals_per_record_writes(tmp_path):
     open(s1, "w").write(text)
     got = dict(kaldi_io.read_vec_flt_scp(s1))
     assert list(got) == keys and all(np.array_equal(got[k], v) for k, v in zip(keys, vecs))
+
+
+def test_batch_vector_writer_equals_per_record_writer(tmp_path):
+    """write_vec_flt_batch == a loop of write_vec_flt, byte for byte: [n, D] array or list input, keys of one or several
+    lengths, ragged dimensions, plain stream and ark+scp table (scp offsets included), empty batch."""
+    rng = np.random.default_rng(5)
+    mat = rng.standard_normal((7, 12)).astype(np.float32)
+    cases = [
+        (["utt%03d" % i for i in range(7)], mat),                                        # uniform keys, 2-D array
+        (["utt%03d" % i for i in range(7)], [mat[i] for i in range(7)]),                 # uniform keys, list of rows
+        (["a", "bb", "ccc-1", "d", "ee", "f_f", "g.7"], mat),                            # keys of several lengths
+        (["k1", "k22", "k333"], [mat[0], mat[1][:5], mat[2][:9]]),                       # ragged dimensions
+        ([], np.zeros((0, 12), np.float32)),
+    ]
+    for n, (keys, vecs) in enumerate(cases):
+        one, many = io.BytesIO(), io.BytesIO()
+        for k, v in zip(keys, vecs):
+            kaldi_io.write_vec_flt(one, np.asarray(v), key=k)
+        kaldi_io.write_vec_flt_batch(many, keys, vecs)
+        assert one.getvalue() == many.getvalue(), n
+        a1, s1, a2, s2 = (str(tmp_path / ("%s%d" % (x, n))) for x in ("a1_", "s1_", "a2_", "s2_"))
+        with kaldi_io.TableWriter(a1, s1, "X.ark") as t1:
+            for k, v in zip(keys, vecs):
+                kaldi_io.write_vec_flt(t1, np.asarray(v), key=k)
+        with kaldi_io.TableWriter(a2, s2, "X.ark") as t2:
+            kaldi_io.write_vec_flt_batch(t2, keys, vecs)
+            kaldi_io.write_vec_flt_batch(t2, keys, vecs)                                  # offsets keep counting across batches
+        assert open(a2, "rb").read() == 2 * open(a1, "rb").read()
+        lines1, lines2 = open(s1).read().splitlines(), open(s2).read().splitlines()
+        assert lines2[:len(lines1)] == lines1 and len(lines2) == 2 * len(lines1)
+    with pytest.raises(kaldi_io.UnsupportedDataType):
+        kaldi_io.write_vec_flt_batch(io.BytesIO(), ["a"], np.zeros((1, 3), np.float64))

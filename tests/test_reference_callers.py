@@ -224,9 +224,23 @@ def test_reference_extract_embedding_cli_drives_the_twin(ref_env, tmp_path, monk
             self.stats["frames"] += sum(m.shape[0] for m in mats)
             return [oracle.embed_utterance(m, w, topo, self.a[0], self.a[1], np.float32) for m in mats]
 
+        def submit(self, mats, addrs=None):        # the extractor's two-phase interface (launch now, collect later)
+            assert addrs is None or len(addrs) == len(mats)
+            return self.extract(mats)
+
+        def finish(self, handle, as_array=False):
+            if not as_array:
+                return handle
+            valid = np.array([v is not None for v in handle], dtype=bool)
+            full = np.zeros((len(handle), topo["embedding_sizes"][0]), np.float32)
+            for i, v in enumerate(handle):
+                if v is not None:
+                    full[i] = v
+            return full, valid
+
     def fake_load(self, sess, input_dir, logger):
         self.meta = dict(topology=topo)
-        self.device_model = types.SimpleNamespace(device="cpu", embed_dim=topo["embedding_sizes"][0])
+        self.device_model = types.SimpleNamespace(device="cpu", embed_dim=topo["embedding_sizes"][0], feat_dim=23)
     monkeypatch.setattr(engine, "Extractor", FakeExtractor)
     monkeypatch.setattr(models.Model, "load_model", fake_load)
     out = str(tmp_path / "xvector.ark")

@@ -1,44 +1,84 @@
-"""Where the ark->ark wall time goes (development aid): reader-thread busy time, main-thread queue wait, extract, write."""
-import io, logging, os, sys, tempfile, threading, time, queue
+"""Where the ark->ark wall time goes (development aid): Model.make_embedding on an in-memory ark of n utterances with the
+phases of the reader thread and of the main thread timed (monkeypatched wrappers; a few % of overhead)."""
+import io, logging, os, sys, threading, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "x-vector-kaldi-tf_amd"), os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf")):
     sys.path.insert(0, p)
 import kaldi_io, models
-from xvector_amd import engine, synthetic, topology as tp
+from xvector_amd import engine, synthetic, topology as tp, weights as wio
+import tempfile
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
-if len(sys.argv) > 2: sys.setswitchinterval(float(sys.argv[2]))
-print('switch interval', sys.getswitchinterval())
+if len(sys.argv) > 2:
+    sys.setswitchinterval(float(sys.argv[2]))
 topo = tp.get("ModelWithoutDropout"); w = synthetic.trained_like(topo, 23, seed=1)
+mdir = tempfile.mkdtemp(); wio.save_model_dir(mdir, w, topo, "ModelWithoutDropout", 64, 23)
 utts = synthetic.make_utterances(n, 200, 400, 23, 1234)
 bio = io.BytesIO()
-for k, m in utts: kaldi_io.write_mat(bio, m, key=k)
+cut = 0
+for i, (k, m) in enumerate(utts):
+    kaldi_io.write_mat(bio, m, key=k)
+    if i == n // 10:
+        cut = bio.tell()
 raw = bio.getvalue(); del utts
-model = engine.DeviceModel(w, topo, "cuda:0"); ex = engine.Extractor(model, 25, 10000)
-win = models.Model.window_frames
-stat = dict(parse=0.0, wait=0.0, extract=0.0, write=0.0)
-q = queue.Queue(maxsize=2)
-def reader():
-    keys, mats, frames = [], [], 0
-    t0 = time.time()
-    for key, mat in kaldi_io.read_mat_ark(io.BytesIO(raw)):
-        keys.append(key); mats.append(np.ascontiguousarray(mat, dtype=np.float32)); frames += mat.shape[0]
-        if frames >= win:
-            stat["parse"] += time.time() - t0
-            q.put((keys, mats)); keys, mats, frames = [], [], 0
-            t0 = time.time()
-    stat["parse"] += time.time() - t0
-    if keys: q.put((keys, mats))
-    q.put(None)
-T0 = time.time()
-threading.Thread(target=reader, daemon=True).start()
+T = {}
+main_id = threading.get_ident()
+
+
+def timed(obj, name, label):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return f(*a, **k)
+        finally:
+            key = label + (" [reader]" if threading.get_ident() != main_id else "")
+            T[key] = T.get(key, 0.0) + time.perf_counter() - t0
+    setattr(obj, name, g)
+
+
+timed(engine.BatchLayout, "pack", "pack")
+timed(engine.BatchLayout, "row_valid", "row_valid")
+timed(engine.DeviceModel, "frame_level", "frame_level (launches)")
+timed(engine.DeviceModel, "segment_level", "segment_level")
+timed(engine, "plan_chunk_table", "plan_chunk_table")
+timed(engine.Extractor, "submit", "submit (total)")
+timed(engine.Extractor, "finish", "finish (wait for the GPU + D2H)")
+timed(engine, "matrix_addresses", "matrix_addresses")
+timed(engine.Extractor, "_staging", "_staging")
+class _Lib(object):
+    def __init__(self, lib): self.lib = lib
+    def xv_pack_rows_f32(self, *a):
+        t0 = time.perf_counter(); rc = self.lib.xv_pack_rows_f32(*a); T["native pack"] = T.get("native pack", 0.0) + time.perf_counter() - t0
+        return rc
+engine._host_lib(); engine._HOST[0] = _Lib(engine._HOST[0])
+timed(kaldi_io, "write_vec_flt_batch", "write")
+import torch
+_sync = torch.cuda.Event.synchronize
+def sync(self):
+    t0 = time.perf_counter(); _sync(self); T["event wait (staging set busy)"] = T.get("event wait (staging set busy)", 0.0) + time.perf_counter() - t0
+torch.cuda.Event.synchronize = sync
+_blocks = kaldi_io.read_mat_ark_blocks
+def blocks(fd):
+    it = _blocks(fd)
+    while True:
+        t0 = time.perf_counter()
+        try:
+            item = next(it)
+        except StopIteration:
+            return
+        finally:
+            T["ark scan + gather [reader]"] = T.get("ark scan + gather [reader]", 0.0) + time.perf_counter() - t0
+        yield item
+kaldi_io.read_mat_ark_blocks = blocks
+log = logging.getLogger("p"); log.addHandler(logging.NullHandler())
+m = models.Model()
+m.make_embedding(io.BytesIO(raw[:cut]), io.BytesIO(), mdir, 25, 10000, True, log)       # warm-up
+T.clear()
+t0 = time.perf_counter()
 out = io.BytesIO()
-while True:
-    t0 = time.time(); item = q.get(); stat["wait"] += time.time() - t0
-    if item is None: break
-    keys, mats = item
-    t0 = time.time(); v = ex.extract(mats); stat["extract"] += time.time() - t0
-    t0 = time.time(); kaldi_io.write_vec_flt_batch(out, keys, v); stat["write"] += time.time() - t0
-tot = time.time() - T0
-print("n=%d total %.3f s (%.0f utt/s): reader busy %.3f | main: wait %.3f extract %.3f write %.3f" %
-      (n, tot, n / tot, stat["parse"], stat["wait"], stat["extract"], stat["write"]))
+m.make_embedding(io.BytesIO(raw), out, mdir, 25, 10000, True, log)
+tot = time.perf_counter() - t0
+print("n=%d total %.3f s (%.0f utt/s)" % (n, tot, n / tot))
+for k, v in sorted(T.items(), key=lambda kv: -kv[1]):
+    print("  %-36s %.3f s" % (k, v))

@@ -5,13 +5,20 @@
 // per-byte / per-field Python parsing of the reference's reader (local/tf/kaldi_io.py:120-133, 395-437) for the
 // record type the feature pipeline emits; anything else (DM, CM, text) stops the scan and is left to the generic
 // Python reader.
+//
+// xv_pack_rows_f32: the batch packer of the extractor (xvector_amd/engine.py BatchLayout): chunk i = len[i] rows of
+// feat_dim floats at address src[i] -> rows [dst_row[i], dst_row[i]+len[i]) of the (pinned) staging matrix, every other
+// row zeroed, row_valid filled.  One GIL-free call on a few threads instead of one np.concatenate per batch.
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
 
+#include <thread>
+#include <vector>
+
 extern "C" {
 
-int xv_host_version(void) { return 2; }
+int xv_host_version(void) { return 3; }
 
 // Scans buf[pos, len).  Fills up to max_records entries; returns the number of records found.
 // *next = offset of the first byte not consumed; *stop = 0 buffer exhausted / record incomplete (need more data),
@@ -63,6 +70,57 @@ int64_t xv_ark_gather_fm(const uint8_t *buf, const int64_t *data_off, const int3
         r += rows[i];
     }
     return r;
+}
+
+// Chunks must be given in ascending, non-overlapping dst_row order.  Columns [feat_dim, dst_ld) of dst are not touched (the
+// caller keeps them zero).  Returns 0, or -1 on inconsistent arguments (nothing is written then).
+int xv_pack_rows_f32(const uint64_t *src, const int32_t *len, const int32_t *dst_row, int n, int feat_dim, float *dst,
+                     int64_t dst_ld, int64_t dst_rows, uint8_t *row_valid, int n_threads)
+{
+    if (n < 0 || feat_dim <= 0 || dst_ld < feat_dim || dst_rows < 0 || !dst) return -1;
+    int64_t prev = 0;
+    for (int i = 0; i < n; ++i) {
+        if (len[i] < 0 || dst_row[i] < prev) return -1;
+        prev = (int64_t)dst_row[i] + len[i];
+    }
+    if (prev > dst_rows) return -1;
+    const size_t row_bytes = (size_t)feat_dim * 4;
+    auto zero_rows = [&](int64_t a, int64_t b) {            // rows [a, b): feature columns and validity flags
+        if (row_valid && b > a) memset(row_valid + a, 0, (size_t)(b - a));
+        if (dst_ld == feat_dim) {
+            if (b > a) memset(dst + a * dst_ld, 0, (size_t)(b - a) * row_bytes);
+        } else {
+            for (int64_t r = a; r < b; ++r) memset(dst + r * dst_ld, 0, row_bytes);
+        }
+    };
+    auto work = [&](int i0, int i1, bool last) {            // chunks [i0, i1) and the gap in front of each of them
+        for (int i = i0; i < i1; ++i) {
+            const int64_t start = dst_row[i];
+            zero_rows(i == 0 ? 0 : (int64_t)dst_row[i - 1] + len[i - 1], start);
+            const float *s = reinterpret_cast<const float *>(src[i]);
+            if (dst_ld == feat_dim) {
+                memcpy(dst + start * dst_ld, s, (size_t)len[i] * row_bytes);
+            } else {
+                float *d = dst + start * dst_ld;
+                for (int32_t r = 0; r < len[i]; ++r) memcpy(d + (size_t)r * dst_ld, s + (size_t)r * feat_dim, row_bytes);
+            }
+            if (row_valid) memset(row_valid + start, 1, (size_t)len[i]);
+        }
+        if (last) zero_rows(n == 0 ? 0 : (int64_t)dst_row[n - 1] + len[n - 1], dst_rows);
+    };
+    int nt = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+    if (n < 4 * nt) nt = 1;
+    if (nt == 1) {
+        work(0, n, true);
+        return 0;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) {
+        const int i0 = (int)((int64_t)n * t / nt), i1 = (int)((int64_t)n * (t + 1) / nt);
+        pool.emplace_back(work, i0, i1, t == nt - 1);
+    }
+    for (auto &th : pool) th.join();
+    return 0;
 }
 
 }  // extern "C"

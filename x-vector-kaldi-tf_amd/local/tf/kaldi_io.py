@@ -343,6 +343,19 @@ class TableWriter(object):
         self._scp.write("".join(lines))
         self._pos = pos
 
+    def write_uniform_records(self, keys, key_len, blob):
+        """``len(keys)`` records of equal size already serialised in ``blob``; every key takes ``key_len`` bytes (incl. the
+        separating space)."""
+        size = len(blob) // max(len(keys), 1)
+        pos = self._pos + key_len
+        lines = []
+        for k in keys:
+            lines.append("%s %s:%d\n" % (k, self._name, pos))
+            pos += size
+        self._ark.write(blob)
+        self._scp.write("".join(lines))
+        self._pos += len(blob)
+
     def close(self):
         self._ark.close()
         self._scp.close()
@@ -376,21 +389,56 @@ def write_vec_flt(file_or_fd, v, key=""):
 
 
 def write_vec_flt_batch(file_or_fd, keys, vecs):
-    """Write many float32 vectors as consecutive binary records (same bytes as write_vec_flt per key) with one
-    ``write`` call per batch; falls back to per-record writes for index-building streams (TableWriter)."""
+    """Write many float32 vectors as consecutive binary records (same bytes as write_vec_flt per key) with one ``write``
+    call per batch.  ``vecs``: a float32 ``[n, D]`` array or a sequence of float32 vectors.  Equal-length vectors are
+    serialised without per-record NumPy calls (and without any per-record Python when the keys have one length too)."""
     fd = open_or_fd(file_or_fd, mode="wb")
     try:
-        key_bytes, bodies = [], []
-        for k, v in zip(keys, vecs):
-            v = np.asarray(v)
-            if v.dtype != np.float32:
-                raise UnsupportedDataType("'%s', write_vec_flt_batch expects float32" % v.dtype)
-            key_bytes.append((k + " ").encode() if k != "" else b"")
-            bodies.append(b"\x00BFV \x04" + struct.pack("<I", v.shape[0]) + np.ascontiguousarray(v).astype("<f4", copy=False).tobytes())
-        if hasattr(fd, "write_records"):            # TableWriter: ark + scp index
-            fd.write_records(keys, key_bytes, bodies)
+        n = len(keys)
+        if n == 0:
+            return
+        mat = None
+        if isinstance(vecs, np.ndarray) and vecs.ndim == 2:
+            mat = vecs
+        elif len({np.shape(v) for v in vecs}) == 1 and np.ndim(vecs[0]) == 1:
+            mat = np.stack(vecs)
+        if mat is not None and mat.dtype != np.float32:
+            raise UnsupportedDataType("'%s', write_vec_flt_batch expects float32" % mat.dtype)
+        if mat is None:                                      # ragged dimensions: one record at a time
+            key_bytes, bodies = [], []
+            for k, v in zip(keys, vecs):
+                v = np.asarray(v)
+                if v.dtype != np.float32:
+                    raise UnsupportedDataType("'%s', write_vec_flt_batch expects float32" % v.dtype)
+                key_bytes.append((k + " ").encode() if k != "" else b"")
+                bodies.append(b"\x00BFV \x04" + struct.pack("<I", v.shape[0]) + np.ascontiguousarray(v).astype("<f4", copy=False).tobytes())
+            blob = None
         else:
-            fd.write(b"".join(x for pair in zip(key_bytes, bodies) for x in pair))
+            assert mat.shape[0] == n
+            head = b"\x00BFV \x04" + struct.pack("<I", mat.shape[1])
+            payload = np.ascontiguousarray(mat).astype("<f4", copy=False)
+            key_bytes = [(k + " ").encode() if k != "" else b"" for k in keys]
+            klen = len(key_bytes[0])
+            if all(len(kb) == klen for kb in key_bytes):
+                # every record has the same size: assemble them as the rows of one uint8 matrix
+                rec = np.empty((n, klen + len(head) + 4 * mat.shape[1]), dtype=np.uint8)
+                if klen:
+                    rec[:, :klen] = np.frombuffer(b"".join(key_bytes), dtype=np.uint8).reshape(n, klen)
+                rec[:, klen:klen + len(head)] = np.frombuffer(head, dtype=np.uint8)
+                rec[:, klen + len(head):] = payload.view(np.uint8).reshape(n, 4 * mat.shape[1])
+                blob = rec.tobytes()
+                bodies = None
+            else:
+                raw, step = payload.tobytes(), 4 * mat.shape[1]
+                bodies = [head + raw[i * step:(i + 1) * step] for i in range(n)]
+                blob = None
+        if hasattr(fd, "write_records"):                     # TableWriter: ark + scp index
+            if bodies is None:
+                fd.write_uniform_records(keys, klen, blob)
+            else:
+                fd.write_records(keys, key_bytes, bodies)
+        else:
+            fd.write(blob if blob is not None else b"".join(x for pair in zip(key_bytes, bodies) for x in pair))
     finally:
         if fd is not file_or_fd:
             fd.close()

@@ -269,9 +269,11 @@ class Model(object):
         from xvector_amd import dist as xdist
         rank, world = xdist.init_process_group()
 
-        def extract_window(mats):
+        def submit_window(mats, addrs):
+            """-> a zero-argument function returning the vectors of the window (None on non-root ranks)."""
             if world == 1:
-                return ex.extract(mats)
+                handle = ex.submit(mats, addrs)                   # packed, copied and launched; results are collected later
+                return lambda: ex.finish(handle, as_array=True)
             import torch
             dev = self.device_model.device
             lens = [m.shape[0] for m in mats]
@@ -287,12 +289,14 @@ class Model(object):
 
             full = xdist.sharded_extract(lens, shard_fn, dim, dev)
             if rank != 0:
-                return None
+                return lambda: None
             host = full.cpu().numpy()
-            return [host[i] if engine.plan_chunks(lens[i], min_chunk_size, chunk_size) else None for i in range(len(mats))]
+            valid = np.array([bool(engine.plan_chunks(t, min_chunk_size, chunk_size)) for t in lens], dtype=bool)
+            return lambda: (host, valid)
 
-        def flush(keys, mats, vads=None):
-            nonlocal num_fail, num_success, compute_time
+        def submit(keys, mats, vads=None, addrs=None):
+            """Front-end (optional) + everything up to the kernel launches of one window; returns what ``collect`` needs."""
+            nonlocal num_fail, compute_time
             t0 = time.time()
             if front is not None:
                 done = front.apply(mats, vads)
@@ -303,25 +307,32 @@ class Model(object):
                         num_fail += 1
                     else:
                         kept.append((key, m))
-                keys, mats = [k for k, _ in kept], [m for _, m in kept]
-            vecs = extract_window(mats)
+                keys, mats, addrs = [k for k, _ in kept], [m for _, m in kept], None
+            result = submit_window(mats, addrs)
             compute_time += time.time() - t0
-            if vecs is None:                      # non-root rank: nothing to write
+            return keys, mats, result
+
+        def collect(keys, mats, result):
+            """Wait for a submitted window and write its vectors (input order)."""
+            nonlocal num_fail, num_success, compute_time
+            t0 = time.time()
+            out = result()
+            compute_time += time.time() - t0
+            if out is None:                       # non-root rank: nothing to write
                 return
-            ok_keys, ok_vecs = [], []
-            for key, mat, vec in zip(keys, mats, vecs):
-                if vec is None:
-                    if mat.shape[0] == 0:
-                        logger.warning("Zero-length utterance: '%s'" % key)
+            vecs, valid = out
+            if not valid.all():
+                for i in np.flatnonzero(~valid).tolist():
+                    if mats[i].shape[0] == 0:
+                        logger.warning("Zero-length utterance: '%s'" % keys[i])
                     else:
                         logger.warning("Minimum chunk size of %d is greater than the number of rows in utterance: %s" %
-                                       (min_chunk_size, key))
-                    num_fail += 1
-                    continue
-                ok_keys.append(key)
-                ok_vecs.append(vec)
-            kaldi_io.write_vec_flt_batch(output_stream, ok_keys, ok_vecs)      # same bytes as write_vec_flt per key
-            num_success += len(ok_keys)
+                                       (min_chunk_size, keys[i]))
+                num_fail += int((~valid).sum())
+                keys = [k for k, ok in zip(keys, valid.tolist()) if ok]
+                vecs = vecs[valid]
+            out_q.put((keys, vecs))                 # written by the writer thread, in order
+            num_success += len(keys)
 
         # A reader thread parses the next window of the ark stream while the GPU works on the current one
         # (bounded queue: at most 2 parsed windows in memory).  Order is preserved; a parse error is re-raised here.
@@ -331,7 +342,7 @@ class Model(object):
 
         def reader():
             try:
-                keys, mats, vads, frames = [], [], [], 0
+                keys, mats, vads, addrs, frames = [], [], [], [], 0
                 vad_it, pending = None, {}
                 if vad_stream is not None:
                     vad_it = kaldi_io.read_vec_flt_ark(vad_stream) if hasattr(vad_stream, "read") else vad_stream
@@ -348,42 +359,85 @@ class Model(object):
                     return np.zeros(0, np.float32)        # no VAD for this key -> length mismatch -> dropped with a warning
 
                 def blocks():
-                    # (keys, [matrices]) per block: whole scanner passes gathered natively for ark streams, one utterance
-                    # at a time for (key, matrix) iterators
+                    # (keys, [matrices], [address of row 0]) per block: whole scanner passes gathered natively for ark
+                    # streams, one utterance at a time for (key, matrix) iterators
                     if hasattr(input_stream, "read"):
                         for bkeys, bfeats, off in kaldi_io.read_mat_ark_blocks(input_stream):
                             o = off.tolist()
-                            yield bkeys, [bfeats[o[i]:o[i + 1]] for i in range(len(bkeys))]
+                            base, row_bytes = bfeats.ctypes.data, bfeats.shape[1] * bfeats.itemsize if bfeats.ndim == 2 else 0
+                            yield bkeys, [bfeats[o[i]:o[i + 1]] for i in range(len(bkeys))], [base + r * row_bytes for r in o[:-1]]
                     else:
                         for key, mat in input_stream:
-                            yield [key], [np.ascontiguousarray(mat, dtype=np.float32)]
+                            mat = np.ascontiguousarray(mat, dtype=np.float32)
+                            yield [key], [mat], [mat.__array_interface__["data"][0]]
 
-                for bkeys, bmats in blocks():
-                    for key, mat in zip(bkeys, bmats):
-                        keys.append(key)
-                        mats.append(mat)
-                        if vad_it is not None:
-                            vads.append(vad_for(key))
-                        frames += mat.shape[0]
-                        if frames >= self.window_frames:
-                            windows.put((keys, mats, vads if vad_it is not None else None))
-                            keys, mats, vads, frames = [], [], [], 0
+                def put():
+                    F = self.device_model.feat_dim          # anything else goes down the checked NumPy packing path and raises there
+                    ok = all(m.ndim == 2 and m.shape[1] == F and m.dtype == np.float32 for m in mats)
+                    windows.put((keys, mats, vads if vad_it is not None else None, np.array(addrs, dtype=np.uint64) if ok else None))
+
+                for bkeys, bmats, baddrs in blocks():
+                    # whole blocks are appended (a window closes at the first block boundary past window_frames)
+                    keys.extend(bkeys)
+                    mats.extend(bmats)
+                    addrs.extend(baddrs)
+                    if vad_it is not None:
+                        vads.extend(vad_for(key) for key in bkeys)
+                    frames += sum(m.shape[0] for m in bmats) if len(bmats) < 64 else int(np.sum([m.shape[0] for m in bmats]))
+                    if frames >= self.window_frames:
+                        put()
+                        keys, mats, vads, addrs, frames = [], [], [], [], 0
                 if keys:
-                    windows.put((keys, mats, vads if vad_it is not None else None))
+                    put()
                 windows.put(None)
             except BaseException as e:          # noqa: B902 -- forwarded to the consumer
                 windows.put(e)
 
+        # ... and a writer thread serialises the records of finished windows (same bytes as write_vec_flt per key), so that
+        # formatting ~50 k records per window does not sit between two kernel launches.  Its error, if any, is re-raised below.
+        out_q = queue.Queue(maxsize=4)
+        writer_error = []
+
+        def writer():
+            while True:
+                item = out_q.get()
+                if item is None:
+                    return
+                if writer_error:
+                    continue                        # keep draining so that the producer never blocks
+                try:
+                    kaldi_io.write_vec_flt_batch(output_stream, item[0], item[1])
+                except BaseException as e:          # noqa: B902 -- forwarded to the caller
+                    writer_error.append(e)
+
+        writer_thread = threading.Thread(target=writer, daemon=True)
+        writer_thread.start()
         threading.Thread(target=reader, daemon=True).start()
-        while True:
-            item = windows.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            keys, mats, vads = item
-            total_segments += len(keys)
-            flush(keys, mats, vads)
+        # software pipeline of depth 2 over the windows: the host work of window i+1 (packing, H2D, launches) is issued
+        # before the vectors of window i are awaited and written, so the GPU never waits for the writer
+        in_flight = None
+        try:
+            while True:
+                item = windows.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                if writer_error:
+                    raise writer_error[0]
+                keys, mats, vads, addrs = item
+                total_segments += len(keys)
+                nxt = submit(keys, mats, vads, addrs)
+                if in_flight is not None:
+                    collect(*in_flight)
+                in_flight = nxt
+            if in_flight is not None:
+                collect(*in_flight)
+        finally:
+            out_q.put(None)
+            writer_thread.join()                    # the caller closes output_stream right after we return
+        if writer_error:
+            raise writer_error[0]
 
         st = ex.stats
         logger.info("Processed %d features of average size %d frames. Done %d and failed %d" %

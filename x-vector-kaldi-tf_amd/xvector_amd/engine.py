@@ -14,12 +14,44 @@ gap rows between them (see include/xvector_hip.h) and pushed through
 PyTorch is used for device memory, streams and H2D/D2H copies only; every arithmetic step of the path
 is one of the HIP kernels behind the C ABI.
 """
+import ctypes
 import math
+import os
 
 import numpy as np
 
 from . import hiplib
 from . import topology as tp
+
+_HOST = []
+
+
+def _host_lib():
+    """libxvector_host.so (csrc/xv_host.cpp, built next to local/tf/kaldi_io.py): the native batch packer.  Optional -- without
+    it (or with an older build) batches are packed with NumPy."""
+    if not _HOST:
+        lib = None
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "local", "tf", "libxvector_host.so")
+        try:
+            lib = ctypes.CDLL(path)
+            lib.xv_pack_rows_f32.restype = ctypes.c_int
+            lib.xv_pack_rows_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+        except (OSError, AttributeError):
+            lib = None
+        _HOST.append(lib)
+    return _HOST[0]
+
+
+def matrix_addresses(mats, feat_dim):
+    """uint64 address of row 0 of every utterance matrix, or None when one of them is not a C-contiguous float32
+    ``[T, feat_dim]`` array (the native packer reads them in place)."""
+    out = np.empty(len(mats), dtype=np.uint64)
+    for i, m in enumerate(mats):
+        if m.dtype != np.float32 or m.ndim != 2 or m.shape[1] != feat_dim or not m.flags.c_contiguous:
+            return None
+        out[i] = m.__array_interface__["data"][0]
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -421,13 +453,16 @@ class Extractor(object):
         self.stats = dict(batches=0, chunks=0, frames=0, rows=0)
         self._stage = None
         self._copy_stream = None
+        self._turn = 0
 
     def _staging(self, rows, nchunks):
         """NBUF pinned sets: features [rows, in_dim] (padding columns zeroed once), row_valid[rows], meta int32[2, chunks]."""
         torch = self.model.torch
         if self._stage is None or self._stage[0]["x"].shape[0] < rows or self._stage[0]["meta"].shape[1] < nchunks:
-            rows = max(rows, 1024)
-            nchunks = max(nchunks, 64)
+            # sized for the largest regular batch up front: re-pinning 3 x 25 MB whenever a window brings a slightly larger
+            # batch costs more than the kernels of that batch
+            rows = max(rows, 1024) if rows <= 4096 else max(rows, self.max_batch_rows)
+            nchunks = max(nchunks, 64) if nchunks <= 64 else max(nchunks, min(self.max_batch_chunks, 8192))
             self._stage = []
             for _ in range(self.NBUF):
                 self._stage.append(dict(x=torch.zeros((rows, self.model.in_dim), dtype=torch.float32).pin_memory(),
@@ -437,19 +472,38 @@ class Extractor(object):
             self._copy_stream = torch.cuda.Stream(device=self.model.device)
         return self._stage
 
-    def extract(self, mats):
+    PACK_THREADS = int(os.environ.get("XVECTOR_PACK_THREADS", "4"))
+
+    def extract(self, mats, addrs=None):
         """mats: list of float32 [T, F] arrays.  Returns a list of float32[E] (or None) per input."""
+        return self.finish(self.submit(mats, addrs))
+
+    def submit(self, mats, addrs=None):
+        """Plan, pack, copy and launch everything for ``mats`` and start the asynchronous D2H copy of the x-vectors; returns a
+        handle for ``finish``.  The caller may submit the next window before finishing this one (the host work of window
+        i+1 then overlaps the kernels of window i).  ``addrs``: optional ``matrix_addresses(mats, F)`` computed elsewhere
+        (e.g. by the reader thread)."""
         torch = self.model.torch
         model = self.model
         dev = model.device
         # chunk table, utterances ordered by length so that batches are length-homogeneous
         order, c_utt, c_start, c_len, seg_start = plan_chunk_table([m.shape[0] for m in mats], self.min_chunk_size,
                                                                     self.chunk_size)
-        order, c_utt, c_start, c_len = order.tolist(), c_utt.tolist(), c_start.tolist(), c_len.tolist()
         nch = len(c_utt)
-        results = [None] * len(mats)
+        handle = dict(n=len(mats), order=order, nch=nch)
         if nch == 0:
-            return results
+            return handle
+        F = model.feat_dim
+        lib = _host_lib()
+        if lib is not None and addrs is None:
+            addrs = matrix_addresses(mats, F)
+        native = lib is not None and addrs is not None
+        if native:
+            c_src = np.asarray(addrs, dtype=np.uint64)[c_utt] + (c_start * (F * 4)).astype(np.uint64)
+            c_len32 = c_len.astype(np.int32)
+        else:
+            assert mats[int(c_utt[0])].shape[1] == F, "feature dimension does not match the model"
+            l_utt, l_start, l_len = c_utt.tolist(), c_start.tolist(), c_len.tolist()
         gap, align = model.gap, model.align
         lead = (gap + align - 1) // align * align
         # batch boundaries: greedy fill up to max_batch_rows / max_batch_chunks (a single chunk may exceed the row budget)
@@ -466,16 +520,23 @@ class Extractor(object):
             compute = torch.cuda.current_stream()
             E_all = torch.empty((nch, model.embed_dim), dtype=torch.float32, device=dev)
             P_all = torch.empty((nch, model.pooled_dim), dtype=torch.float32, device=dev)
-            model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), max(c_len))
+            model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), int(c_len.max()))
             keep = []                                   # device inputs stay referenced until the window is done
             for bi, (b0, b1, _) in enumerate(bounds):
                 layout = BatchLayout(c_len[b0:b1], gap, align)
-                assert mats[c_utt[b0]].shape[1] == model.feat_dim, "feature dimension does not match the model"
-                st = stage[bi % self.NBUF]
+                st = stage[self._turn % self.NBUF]
+                self._turn += 1
                 if st["event"] is not None:
                     st["event"].synchronize()            # the copy that last read this pinned set has finished
-                layout.pack([mats[c_utt[i]][c_start[i]:c_start[i] + c_len[i]] for i in range(b0, b1)], st["x"].numpy())
-                layout.row_valid(st["rv"].numpy())
+                if native:
+                    xs = st["x"].numpy()
+                    rc = lib.xv_pack_rows_f32(c_src[b0:b1].ctypes.data, c_len32[b0:b1].ctypes.data, layout.row_start.ctypes.data,
+                                              layout.nchunks, F, xs.ctypes.data, xs.shape[1], layout.rows,
+                                              st["rv"].numpy().ctypes.data, self.PACK_THREADS)
+                    assert rc == 0, "xv_pack_rows_f32 rejected the batch layout"
+                else:
+                    layout.pack([mats[l_utt[i]][l_start[i]:l_start[i] + l_len[i]] for i in range(b0, b1)], st["x"].numpy())
+                    layout.row_valid(st["rv"].numpy())
                 meta = st["meta"].numpy()
                 meta[0, :layout.nchunks] = layout.row_start
                 meta[1, :layout.nchunks] = layout.row_len
@@ -494,12 +555,41 @@ class Extractor(object):
                 self.stats["frames"] += int(layout.row_len.sum())
                 self.stats["rows"] += layout.rows
             model.segment_level(P_all, E_all)
-            seg = torch.from_numpy(np.asarray(seg_start, dtype=np.int32)).to(dev)
-            cl = torch.from_numpy(np.asarray(c_len, dtype=np.int32)).to(dev)
+            # (pinned + copy stream: a pageable H2D copy here would block the host until every kernel of the window is done)
+            tail = torch.from_numpy(np.concatenate([np.asarray(seg_start, dtype=np.int32), c_len.astype(np.int32)])).pin_memory()
+            with torch.cuda.stream(self._copy_stream):
+                tail_d = tail.to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+            compute.wait_event(ev)
+            seg, cl = tail_d[:len(order) + 1], tail_d[len(order) + 1:]
             out = torch.empty((len(order), model.embed_dim), dtype=torch.float32, device=dev)
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
-            host_out = out.cpu().numpy()
-            del keep
-        for j, u in enumerate(order):
-            results[u] = host_out[j]
+            host = torch.empty((len(order), model.embed_dim), dtype=torch.float32).pin_memory()
+            host.copy_(out, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(compute)
+        # mats (the native packer read them in place) and the device buffers stay referenced until finish()
+        handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats))
+        return handle
+
+    def finish(self, handle, as_array=False):
+        """Wait for a submitted window and return its x-vectors in input order: a list with None for rejected utterances,
+        or with ``as_array`` the pair (float32 [n, E] array, bool [n] mask of the utterances that produced a vector)."""
+        n = handle["n"]
+        if handle["nch"]:
+            handle["done"].synchronize()
+            host_out = handle["host"].numpy()
+            handle["keep"] = None
+        if as_array:
+            full = np.zeros((n, self.model.embed_dim), dtype=np.float32)
+            valid = np.zeros(n, dtype=bool)
+            if handle["nch"]:
+                full[handle["order"]] = host_out
+                valid[handle["order"]] = True
+            return full, valid
+        results = [None] * n
+        if handle["nch"]:
+            for j, u in enumerate(handle["order"].tolist()):
+                results[u] = host_out[j]
         return results
