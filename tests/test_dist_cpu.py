@@ -137,3 +137,75 @@ def test_two_rank_gloo_training_driver(tmp_path):
     assert os.readlink(os.path.join(exp, "model_final")) == "model_2"
     rep = open(os.path.join(exp, "accuracy.report")).read().splitlines()
     assert len(rep) == 4 and rep[1].split("\t")[0] == "0" and rep[1].split("\t")[2:] == ["0.5", "0.5", "0", "0.75", "0.75", "0"]
+
+
+EMBED_WORKER = textwrap.dedent("""
+    import io, logging, os, sys, types
+    sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import numpy as np, torch.distributed as dist
+    import kaldi_io, models
+    from xvector_amd import engine
+
+    class FakeExtractor(object):          # stand-in for the GPU extractor: vector = f(utterance), None below min_chunk_size
+        def __init__(self, model, min_chunk_size, chunk_size, **kw):
+            self.min = min_chunk_size
+            self.stats = dict(batches=0, chunks=0, frames=0, rows=0)
+        def extract(self, mats):
+            self.stats["frames"] += sum(m.shape[0] for m in mats)
+            return [None if m.shape[0] < self.min else np.concatenate([m.mean(0), [m.shape[0]]]).astype(np.float32) for m in mats]
+        def submit(self, mats, addrs=None):
+            return self.extract(mats)
+        def finish(self, h, as_array=False):
+            valid = np.array([v is not None for v in h], bool)
+            full = np.zeros((len(h), 6), np.float32)
+            for i, v in enumerate(h):
+                if v is not None:
+                    full[i] = v
+            return (full, valid) if as_array else h
+
+    def fake_load(self, sess, input_dir, logger):
+        self.device_model = types.SimpleNamespace(device="cpu", embed_dim=6, feat_dim=5)
+    engine.Extractor = FakeExtractor
+    models.Model.load_model = fake_load
+    models.Model.window_frames = 400          # several windows -> several gathers
+    log = logging.getLogger("w"); log.addHandler(logging.NullHandler())
+    out = io.BytesIO()
+    with open(sys.argv[1], "rb") as fin:
+        models.Model().make_embedding(fin, out, "unused", 10, -1, True, log)
+    rank = int(os.environ.get("RANK", "0"))
+    open(sys.argv[2] + ".%%d" %% rank, "wb").write(out.getvalue())
+    print("EMBED_OK")
+""")
+
+
+def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path):
+    """Model.make_embedding under a 2-rank gloo group (stand-in extractor): every rank reads the stream, extracts its
+    frame-balanced shard of each window, ONE gather per window, rank 0 alone writes -- and writes exactly the bytes a single
+    process writes (input order restored, rejected utterances dropped)."""
+    import kaldi_io
+    from conftest import TWIN
+    rng = np.random.default_rng(2)
+    lens = [30, 5, 80, 12, 0, 200, 45, 9, 60, 33, 150, 10, 71]
+    ark = tmp_path / "feats.ark"
+    with open(ark, "wb") as f:
+        for i, t in enumerate(lens):
+            kaldi_io.write_mat(f, rng.standard_normal((t, 5)).astype(np.float32), key="utt%02d" % i)
+    script = tmp_path / "embed_worker.py"
+    script.write_text(EMBED_WORKER % (PKG, TWIN, os.path.dirname(PKG)))
+    single = subprocess.run([sys.executable, str(script), str(ark), str(tmp_path / "single")], stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}, timeout=240)
+    assert single.returncode == 0, single.stdout.decode()
+    port = 33000 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(ark), str(tmp_path / "dist")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    want = open(str(tmp_path / "single.0"), "rb").read()
+    got = {k: v for k, v in kaldi_io.read_vec_flt_ark(str(tmp_path / "dist.0"))}
+    assert open(str(tmp_path / "dist.0"), "rb").read() == want
+    assert open(str(tmp_path / "dist.1"), "rb").read() == b""                      # the non-root rank writes nothing
+    assert list(got) == ["utt%02d" % i for i, t in enumerate(lens) if t >= 10]
+    assert got["utt05"][-1] == 200.0
