@@ -195,9 +195,11 @@ int xv_softmax_ce_f32(const float *logits, const int32_t *labels, int nrows, int
 int xv_adam_f32(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1, float beta2, float eps,
                 void *stream);
 /* y += a*x and out[0] = sum x^2: the L2 penalty of the ModelL2Loss* classes, beta*(0.1|1)*tf.nn.l2_loss(w)
- * (local/tf/models.py:811-842): gradient g += beta*coef*w, loss += beta*coef*sumsq/2. */
+ * (local/tf/models.py:811-842): gradient g += beta*coef*w, loss += beta*coef*sumsq/2.  xv_sumsq_f32 reduces in two
+ * stages (fp64 partials in `workspace`, xv_sumsq_workspace_bytes(n) bytes, 8-byte aligned, added in a fixed order). */
 int xv_axpy_f32(float *y, const float *x, float a, int64_t n, void *stream);
-int xv_sumsq_f32(const float *x, int64_t n, float *out, void *stream);
+size_t xv_sumsq_workspace_bytes(int64_t n);
+int xv_sumsq_f32(const float *x, int64_t n, float *out, void *workspace, void *stream);
 /* tf.nn.dropout(x, keep_prob) in place on x[R, C] (models.py:70-72, 92-94): element (r, c) is kept (and scaled by
  * 1/keep_prob) iff the top 32 bits of splitmix64(seed ^ 0x9E3779B97F4A7C15*(r*C + c + 1)) < keep_prob*2^32, else zeroed.
  * Stateless: the same call on the gradient buffer is the backward pass.  keep_prob == 1 is a no-op. */

@@ -1283,7 +1283,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 8; }
+int xv_version(void) { return 9; }
 
 const char *xv_last_error(void) { return g_err; }
 

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -21,7 +21,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
-           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_f32", "xv_dropout_f32",
+           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
            "xv_cmn_sliding_scatter_f32",
@@ -116,8 +116,10 @@ def load():
     lib.xv_ema_f32.argtypes = [vp, vp, ci, cf, vp]
     lib.xv_axpy_f32.restype = ci
     lib.xv_axpy_f32.argtypes = [vp, vp, cf, i64, vp]
+    lib.xv_sumsq_workspace_bytes.restype = sz
+    lib.xv_sumsq_workspace_bytes.argtypes = [i64]
     lib.xv_sumsq_f32.restype = ci
-    lib.xv_sumsq_f32.argtypes = [vp, i64, vp, vp]
+    lib.xv_sumsq_f32.argtypes = [vp, i64, vp, vp, vp]
     lib.xv_dropout_f32.restype = ci
     lib.xv_dropout_f32.argtypes = [vp, ci, i64, ci, ctypes.c_uint64, cf, vp]
     lib.xv_prelu_backward_f32.restype = ci
@@ -509,7 +511,8 @@ def axpy(y, x, a):
 def sumsq(x, out):
     lib = require_gpu()
     assert x.is_contiguous()
-    _check(lib.xv_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "xv_sumsq_f32")
+    ws = _ws(lib.xv_sumsq_workspace_bytes(x.numel()), x.device)
+    _check(lib.xv_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _ptr(ws), _stream()), "xv_sumsq_f32")
 
 
 def dropout(x, seed, keep_prob, rows=None):
