@@ -1,0 +1,41 @@
+"""Randomised parity sweep (fixed seeds): random layer widths / kernel sizes / dilations / activations / pooling kind /
+feature dims / utterance lengths / chunking / batch sizes through DeviceModel + Extractor, both precisions, against the fp64
+oracle.  Widths are multiples of 4 (the pooling and FC kernels require 16-byte rows and say so loudly otherwise)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_topologies_match_the_oracle(oracle_mod, seed):
+    from xvector_amd import engine, hiplib, synthetic
+    hiplib.require_gpu()
+    rng = np.random.default_rng(seed)
+    worst = {"fp32": 0.0, "bf16x3": 0.0}
+    for case in range(14):
+        step = int(rng.choice([4, 8, 32]))
+        width = lambda lo, hi: max(step, int(rng.integers(lo, hi)) // step * step)      # noqa: E731
+        attention = rng.random() < 0.3
+        ks = [int(rng.choice([1, 3, 5, 7])) for _ in range(5)]
+        ds = [int(rng.choice([1, 1, 2, 3])) if k > 1 else 1 for k in ks]
+        ds = [d if (k - 1) * d <= 8 else 1 for k, d in zip(ks, ds)]
+        last = width(8, 260)
+        topo = dict(layer_sizes=[width(8, 200), width(8, 200), width(8, 200), width(8, 200), max(8, last // 8 * 8) if attention else last],
+                    kernel_sizes=ks, dilations=ds, embedding_sizes=[width(4, 70), width(4, 70)],
+                    activation=str(rng.choice(["relu", "lrelu", "prelu"])), lrelu_alpha=0.2, pooling="attention" if attention else "stats")
+        F = int(rng.choice([23, 24, 30, 13, 40]))
+        w = synthetic.trained_like(topo, F, 8, seed=int(rng.integers(1 << 30)))
+        lens = [int(x) for x in rng.integers(1, 700, size=int(rng.integers(1, 9)))]
+        mn, cs = int(rng.choice([1, 10, 25])), int(rng.choice([-1, 100, 333]))
+        mats = [(rng.standard_normal((t, F)) * 3).astype(np.float32) for t in lens]
+        refs = [oracle_mod.embed_utterance(m, w, topo, mn, cs, np.float64) for m in mats]
+        for prec in ("fp32", "bf16x3"):
+            model = engine.DeviceModel(w, topo, "cuda:0", precision=prec)
+            got = engine.Extractor(model, mn, cs, max_batch_rows=int(rng.choice([64, 700, 262144]))).extract(mats)
+            for g, r in zip(got, refs):
+                assert (g is None) == (r is None), (case, prec, topo, lens, mn, cs)
+                if g is not None:
+                    worst[prec] = max(worst[prec], oracle_mod.rel_l2(g, r))
+    # the north-star bar is 1e-4; exact-fp32 sits two orders below it on every topology
+    assert worst["fp32"] < 1e-5 and worst["bf16x3"] < 1e-4, worst
