@@ -39,3 +39,35 @@ def test_random_topologies_match_the_oracle(oracle_mod, seed):
                     worst[prec] = max(worst[prec], oracle_mod.rel_l2(g, r))
     # the north-star bar is 1e-4; exact-fp32 sits two orders below it on every topology
     assert worst["fp32"] < 1e-5 and worst["bf16x3"] < 1e-4, worst
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_topologies_gradients_match_autograd(seed):
+    """The training step (fp32 kernels) on random topologies -- widths, kernel sizes, dilations, activation, pooling kind,
+    L2 term, dropout-free -- against the float64 autograd oracle: loss 1e-5, every gradient tensor 5e-4 relative L2."""
+    from oracle import train_ref
+    from xvector_amd import hiplib, synthetic, trainer
+    hiplib.require_gpu()
+    rng = np.random.default_rng(seed)
+    for case in range(5):
+        width = lambda lo, hi: int(rng.integers(lo, hi)) // 4 * 4                        # noqa: E731
+        attention = rng.random() < 0.4
+        ks = [int(rng.choice([1, 3, 5, 7])) for _ in range(5)]
+        ds = [int(rng.choice([1, 2])) if 1 < k < 7 else 1 for k in ks]
+        topo = dict(layer_sizes=[width(16, 100), width(16, 100), width(16, 100), width(16, 100), width(16, 120) // 8 * 8],
+                    kernel_sizes=ks, dilations=ds, embedding_sizes=[width(8, 48), width(8, 48)],
+                    activation=str(rng.choice(["relu", "lrelu", "prelu"])), lrelu_alpha=0.2, l2_beta=float(rng.choice([0.0, 0.0002])),
+                    dropout=False, head=None, pooling="attention" if attention else "stats")
+        F, classes, B, T = int(rng.choice([23, 24, 13])), 7, int(rng.integers(3, 9)), int(rng.integers(40, 230))
+        w = synthetic.trained_like(topo, F, classes, seed=int(rng.integers(1 << 30)))
+        x = (rng.standard_normal((B, T, F)) * 3).astype(np.float32)
+        lab = rng.integers(0, classes, B)
+        loss, acc, grads = trainer.Trainer(w, topo).gradients(x, lab)
+        rl, ra, _, _, rg = train_ref.train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3)
+        assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)), (case, topo)
+        bad = {}
+        for n, ref in rg.items():
+            e = float(np.linalg.norm(grads[n].cpu().numpy().astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30))
+            if e > 5e-4:
+                bad[n] = e
+        assert not bad, (case, topo, bad)
