@@ -339,7 +339,12 @@ def main():
         per = max(2.0, args.cpu_budget / (len(sweep) + 1))
         res = {t: torch_ref.time_baseline(weights, topo, mats, t, per) for t in sweep}
         best = max(res, key=lambda t: res[t][0])
+        # the port itself against the fp64 oracle ("CPU(fp32)-vs-fp64 oracle"), on two utterances of the sample
+        port = torch_ref.TorchCpuModel(weights, topo)
+        port_err = max(oracle.rel_l2(port.forward(m), oracle.forward(m, weights, topo, np.float64)) for m in mats[:2])
+        gflop_per_utt = (tp.flops_per_frame(topo, feat) * float(np.mean(sample_lens)) + tp.flops_per_utt(topo)) / 1e9
         out["cpu_baseline"] = {"value": res[best][0], "unit": "utt/s", "cores": best, "kind": "port",
+                               "gflops": res[best][0] * gflop_per_utt, "port_rel_l2_vs_fp64_oracle": port_err,
                                "sample": "torch-CPU fp32 (oneDNN) port of the reference forward, batch 1 per utterance as "
                                          "local/tf/models.py:401-414 runs it; a 32-utterance slice of the same length "
                                          "distribution cycled for %.0f s per thread count; best of threads=%s reported; host "
