@@ -49,7 +49,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 7). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 9). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
