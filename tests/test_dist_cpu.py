@@ -65,7 +65,7 @@ DRIVER_WORKER = textwrap.dedent("""
     import torch, torch.distributed as dist
     import train_dnn
 
-    class FakeModel(object):            # stands in for the GPU trainer: one collective per step, like Trainer._allreduce
+    class FakeModel(object):            # stands in for the GPU trainer: collectives in every step, like Trainer.step
         def build_model(self, num_classes, feat_dim, out, logger=None):
             os.makedirs(out); open(os.path.join(out, "model.meta"), "wt").write("init"); open(os.path.join(out, "done"), "wt").write("done")
         def train_one_iteration(self, loader, args, logger):

@@ -479,3 +479,42 @@ def test_train_dnn_driver_end_to_end(env, tmp_path, monkeypatch):
     exp2 = str(tmp_path / "exp2")
     train_dnn.main([f if f != exp else exp2 for f in flags] + ["--num-epochs", "1"])
     assert wio.is_correct_model_dir(os.path.join(exp2, "model_final"))
+
+
+def test_bucketed_allreduce_ranges_and_single_rank_group(env, monkeypatch):
+    """The data-parallel buckets tile the flat gradient buffer exactly once, in backward order (tail, frame layers 4+3, 2,
+    1+0), for the default and the attention class and for a 2-layer toy topology; a step inside a (1-rank) RCCL group --
+    four asynchronous all-reduces issued during the backward pass -- leaves bit-identical weights to a step without one."""
+    torch = env["torch"]
+    for cls in ("ModelWithoutDropout", "ModelL2LossWithoutDropoutLReluAttention"):
+        topo, w, rng = _setup(env, cls, seed=2)
+        tr = env["trainer"].Trainer(w, topo)
+        rr = tr._ready_ranges()
+        assert [after for _, _, after in rr] == [None, 3, 2, 0]
+        cover = np.zeros(tr._flat_n, np.int32)
+        for a, b, _ in rr:
+            cover[a:b] += 1
+        assert (cover == 1).all()
+        assert rr[0][1] == tr._flat_n and rr[-1][0] == 0
+    topo, w, rng = _setup(env, "ModelWithoutDropout", seed=2)
+    x = (rng.standard_normal((6, 90, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, 6)
+    plain = env["trainer"].Trainer(w, topo)
+    plain.step(x, lab, 1e-3)
+    import torch.distributed as dist
+    from xvector_amd import dist as xdist
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"),
+                 ("XV_FORCE_DIST", "1")):
+        monkeypatch.setenv(k, v)
+    xdist.init_process_group()
+    try:
+        assert dist.is_initialized()
+        grouped = env["trainer"].Trainer(w, topo)
+        fired = []
+        orig = dist.all_reduce
+        monkeypatch.setattr(dist, "all_reduce", lambda t, **kw: (fired.append(t.numel()), orig(t, **kw))[1])
+        grouped.step(x, lab, 1e-3)
+        assert len(fired) == 4 and sum(fired) == grouped._flat_n
+        assert torch.equal(grouped.flat_p, plain.flat_p)
+    finally:
+        dist.destroy_process_group()

@@ -12,7 +12,7 @@ own egs archive, keeping the model of the best job (its model averaging is a stu
 
 * rank j plays job j+1 of the iteration: it reads archive ``((num_archives_processed + j) % num_archives) + 1``
   (train_dnn.py:246-249; ``egs.<n>.tar`` when it exists, else the ranges/scp pair, train_dnn.py:258-267);
-* the ranks train SYNCHRONOUSLY: every optimizer step all-reduces the flat gradient buffer (Trainer._allreduce), so all
+* the ranks train SYNCHRONOUSLY: every optimizer step all-reduces the flat gradient buffer (bucketed, overlapped with the backward pass: Trainer.step), so all
   ranks hold the same weights and rank 0 writes ``model_<iter+1>`` -- no job selection, no averaging pass.  An iteration
   takes as many steps as its shortest archive has minibatches;
 * learning-rate and dropout schedules, iteration count, ``model_0`` creation, ``model_name.txt``, clean-up rule,
