@@ -73,3 +73,10 @@ def test_host_library_loads_and_scans():
     assert [k for k, _ in got] == [k for k, _ in mats]
     assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(got, mats))
     assert got[17][1].dtype == np.float64 and got[16][1].dtype == np.float32
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md maps each C-ABI symbol to the reference interface it replaces: none may be missing."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in _declared_symbols() if s not in doc]
+    assert not missing, missing
