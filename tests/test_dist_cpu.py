@@ -209,3 +209,72 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path):
     assert open(str(tmp_path / "dist.1"), "rb").read() == b""                      # the non-root rank writes nothing
     assert list(got) == ["utt%02d" % i for i, t in enumerate(lens) if t >= 10]
     assert got["utt05"][-1] == 200.0
+
+
+CLI_WORKER = textwrap.dedent("""
+    import os, sys, types
+    sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import numpy as np
+    import models, extract_embedding
+    from xvector_amd import engine
+
+    class FakeExtractor(object):          # stand-in for the GPU extractor (see test_two_rank_gloo_make_embedding...)
+        def __init__(self, model, min_chunk_size, chunk_size, **kw):
+            self.min = min_chunk_size
+            self.stats = dict(batches=0, chunks=0, frames=0, rows=0)
+        def extract(self, mats):
+            self.stats["frames"] += sum(m.shape[0] for m in mats)
+            return [None if m.shape[0] < self.min else np.concatenate([m.mean(0), [m.shape[0]]]).astype(np.float32) for m in mats]
+        def submit(self, mats, addrs=None):
+            return self.extract(mats)
+        def finish(self, h, as_array=False):
+            valid = np.array([v is not None for v in h], bool)
+            full = np.zeros((len(h), 6), np.float32)
+            for i, v in enumerate(h):
+                if v is not None:
+                    full[i] = v
+            return (full, valid) if as_array else h
+
+    def fake_load(self, sess, input_dir, logger):
+        self.device_model = types.SimpleNamespace(device="cpu", embed_dim=6, feat_dim=5)
+    engine.Extractor = FakeExtractor
+    models.Model.load_model = fake_load
+    models.Model.window_frames = 300
+    extract_embedding.main(sys.argv[1:])
+    print("CLI_OK")
+""")
+
+
+def test_two_rank_gloo_cli_shards_an_scp_table(tmp_path):
+    """extract_embedding.py under a 2-rank group with an 'scp:' feature table: every rank reads only its line range, one
+    gather at the end, rank 0 writes ark + scp -- identical files to the single-process run (order, rejected keys, offsets)."""
+    import kaldi_io
+    from conftest import TWIN
+    rng = np.random.default_rng(4)
+    lens = [30, 5, 80, 12, 0, 200, 45, 9, 60, 33, 150, 10, 71, 8, 90]
+    ark, scp = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")
+    with kaldi_io.TableWriter(ark, scp) as w:
+        for i, t in enumerate(lens):
+            kaldi_io.write_mat(w, rng.standard_normal((t, 5)).astype(np.float32), key="utt%02d" % i)
+    mdir = tmp_path / "model"; mdir.mkdir(); (mdir / "model.meta").write_text("x"); (mdir / "done").write_text("done")
+    script = tmp_path / "cli_worker.py"
+    script.write_text(CLI_WORKER % (PKG, TWIN, os.path.dirname(PKG)))
+
+    def flags(tag):
+        return ["--min-chunk-size", "10", "--feature-rspecifier", "scp:" + scp, "--model-dir", str(mdir),
+                "--vector-wspecifier", "ark,scp:%s,%s" % (tmp_path / (tag + ".ark"), tmp_path / (tag + ".scp"))]
+    base_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, str(script)] + flags("one"), env=base_env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert one.returncode == 0, one.stdout.decode()
+    port = 35000 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(base_env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)] + flags("two"), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert open(str(tmp_path / "two.ark"), "rb").read() == open(str(tmp_path / "one.ark"), "rb").read()
+    s1 = open(str(tmp_path / "one.scp")).read().replace("one.ark", "X")
+    s2 = open(str(tmp_path / "two.scp")).read().replace("two.ark", "X")
+    assert s1 == s2 and len(s1.splitlines()) == sum(t >= 10 for t in lens)
+    assert not os.path.exists(str(tmp_path / "two.ark.tmp.ark"))

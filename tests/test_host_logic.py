@@ -287,3 +287,28 @@ def test_native_batch_packer_equals_numpy_pack():
     buf = np.zeros((32, 24), np.float32)
     assert lib.xv_pack_rows_f32(src.ctypes.data if len(src) else 0, two.ctypes.data, bad.ctypes.data, 2, 23, buf.ctypes.data, 24, 32, None, 1) == -1
     assert lib.xv_pack_rows_f32(0, two.ctypes.data, np.array([0, 30], np.int32).ctypes.data, 2, 23, buf.ctypes.data, 24, 32, None, 1) == -1   # overruns dst_rows
+
+
+def test_cli_scp_sharding_helpers(tmp_path):
+    """extract_embedding._scp_shard: contiguous line ranges that tile the table in order; the VAD scp follows the keys of the
+    feature shard (missing VAD entries are simply absent -> the extractor warns and drops those keys)."""
+    import extract_embedding as cli
+    feats, vad = tmp_path / "feats.scp", tmp_path / "vad.scp"
+    keys = ["utt%02d" % i for i in range(11)]
+    feats.write_text("".join("%s feats.ark:%d\n" % (k, 100 * i) for i, k in enumerate(keys)) + "\n")
+    vad.write_text("".join("%s vad.ark:%d\n" % (k, 7 * i) for i, k in reversed(list(enumerate(keys))) if k != "utt04"))
+    assert cli._is_scp_table("scp:x.scp") and cli._is_scp_table("scp,s,cs: x.scp") and not cli._is_scp_table("ark:x.ark")
+    assert not cli._is_scp_table("scp:cat x.scp |")
+    seen = []
+    for world in (1, 3, 4):
+        got = []
+        for r in range(world):
+            f, v = cli._scp_shard("scp:%s" % feats, r, world, "scp:%s" % vad)
+            fk = [ln.split()[0] for ln in f.read().splitlines()]
+            vk = [ln.split()[0] for ln in v.read().splitlines()]
+            assert vk == [k for k in fk if k != "utt04"]                  # same order as the feature shard
+            got += fk
+        assert got == keys
+        seen.append(got)
+    f, v = cli._scp_shard("scp:%s" % feats, 0, 2)
+    assert v is None and len(f.read().splitlines()) == 5

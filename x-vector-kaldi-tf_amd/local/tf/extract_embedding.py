@@ -139,22 +139,86 @@ def _open_table(rspecifier, scp_reader, ark_reader):
     return ark_reader(kaldi_io.open_or_fd(spec))
 
 
+class _Collector(object):
+    """In-memory sink of one rank's x-vectors (kaldi_io.write_vec_flt_batch hands over (keys, vectors) as they are)."""
+    mode = "wb"
+
+    def __init__(self):
+        self.keys, self.blocks = [], []
+
+    def write_vectors(self, keys, vecs):
+        import numpy as np
+        if len(keys):
+            self.keys.extend(keys)
+            self.blocks.append(np.asarray(vecs, dtype=np.float32).reshape(len(keys), -1))
+
+    def write(self, data):
+        raise IOError("the sharded extractor writes vectors, not bytes")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _scp_lines(spec):
+    with kaldi_io.open_or_fd(spec.split(':', 1)[1].strip(), 'rb') as fid:
+        return [ln for ln in fid.read().decode().splitlines(True) if ln.strip()]
+
+
+def _scp_shard(spec, rank, world, vad_spec=None):
+    """Lines [n*rank/world, n*(rank+1)/world) of the scp behind 'scp:FILE' as a text stream: contiguous, so concatenating the
+    ranks' outputs in rank order restores the input order (the role of utils/split_data.sh + split_scp.pl in
+    extract_xvectors.sh:63-65).  With ``vad_spec`` (also an scp table) the second value is the VAD scp restricted to the same
+    keys, in the same order."""
+    import io
+    lines = _scp_lines(spec)
+    lo, hi = len(lines) * rank // world, len(lines) * (rank + 1) // world
+    mine = lines[lo:hi]
+    if vad_spec is None:
+        return io.StringIO("".join(mine)), None
+    table = {}
+    for ln in _scp_lines(vad_spec):
+        table[ln.split(None, 1)[0]] = ln if ln.endswith("\n") else ln + "\n"
+    keys = [ln.split(None, 1)[0] for ln in mine]
+    return io.StringIO("".join(mine)), io.StringIO("".join(table[k] for k in keys if k in table))
+
+
+def _is_scp_table(rspecifier):
+    spec = rspecifier.strip()
+    return spec.split(':', 1)[0].replace(' ', '').split(',')[0] == 'scp' and not spec.endswith('|')
+
+
 def eval_dnn(args):
     use_gpu = args.use_gpu == 'yes'
     wspecifier, ark, scp = process_wspecifier(args.vector_wspecifier)
     if ark is not None and os.path.exists(ark) and scp is not None and os.path.exists(scp):
         logger.info('Both output ark and scp files exist. Return from this call.')
         return
-    # under torchrun (one process per GPU) every rank reads the features, but only rank 0 owns the output table
-    root = int(os.environ.get("RANK", "0")) == 0
+    # under torchrun (one process per GPU) only rank 0 owns the output table.  An scp feature table is sharded by line
+    # range -- every rank reads ONLY its utterances, extracts them as a single process would, and one RCCL gather at the
+    # end brings the x-vectors to rank 0; any other rspecifier (ark stream, pipe) is read by every rank and sharded per window
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    root = rank == 0
+    presharded = world > 1 and _is_scp_table(args.feature_rspecifier) and \
+        (not args.vad_rspecifier or _is_scp_table(args.vad_rspecifier))
     model = Model()
-    vad = _open_table(args.vad_rspecifier, kaldi_io.read_vec_flt_scp, kaldi_io.read_vec_flt_ark) if args.vad_rspecifier else None
-    feats = _open_table(args.feature_rspecifier, kaldi_io.read_mat_scp, None)
+    if presharded:
+        feat_scp, vad_scp = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
+        feats = kaldi_io.read_mat_scp(feat_scp)
+        vad = kaldi_io.read_vec_flt_scp(vad_scp) if vad_scp is not None else None
+    else:
+        vad = _open_table(args.vad_rspecifier, kaldi_io.read_vec_flt_scp, kaldi_io.read_vec_flt_ark) if args.vad_rspecifier else None
+        feats = _open_table(args.feature_rspecifier, kaldi_io.read_mat_scp, None)
+    collector = _Collector() if presharded else None
     with (kaldi_io.open_or_fd(args.feature_rspecifier) if feats is None else _Null()) as input_fid:
-        with (_open_output(wspecifier, ark, scp) if root else _Discard()) as output_fid:
+        with (collector if presharded else _open_output(wspecifier, ark, scp) if root else _Discard()) as output_fid:
             model.make_embedding(input_fid if feats is None else feats, output_fid, args.model_dir, args.min_chunk_size,
                                  args.chunk_size, use_gpu, logger, vad_stream=vad, cmn_window=args.cmn_window,
-                                 cmn_center=args.cmn_center == 'yes')
+                                 cmn_center=args.cmn_center == 'yes', distributed=not presharded)
+    if presharded:
+        _gather_and_write(model, collector, wspecifier, ark, scp, rank, world)
     if not root:
         return
     if ark is not None:
@@ -168,6 +232,27 @@ def eval_dnn(args):
             fid_out.write(text)
         os.rename(scp + '.tmp', scp)
         os.remove(scp + '.tmp.scp')
+
+
+def _gather_and_write(model, collector, wspecifier, ark, scp, rank, world):
+    """The single exchange of the sharded mode: keys as objects, vectors as ONE padded gather (xvector_amd.dist), then
+    rank 0 writes the shards in rank order = input order."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from xvector_amd import dist as xdist
+    dim, dev = model.device_model.embed_dim, model.device_model.device
+    local = np.concatenate(collector.blocks) if collector.blocks else np.zeros((0, dim), np.float32)
+    counts = [None] * world
+    dist.all_gather_object(counts, len(collector.keys))
+    keys = [None] * world if rank == 0 else None
+    dist.gather_object(collector.keys, keys, dst=0)
+    blocks = xdist.gather_blocks(torch.from_numpy(local).to(dev), counts, 0)
+    if rank == 0:
+        with _open_output(wspecifier, ark, scp) as output_fid:
+            for r in range(world):
+                kaldi_io.write_vec_flt_batch(output_fid, keys[r], blocks[r].cpu().numpy())
+    dist.barrier()
 
 
 def main(argv=None):

@@ -2,8 +2,8 @@
 # x-vector extraction of one Kaldi data directory on the MI355X(s) of one node -- what local/tf/extract_xvectors.sh of the
 # reference does with `nj` CPU jobs + Kaldi binaries, as ONE launch:
 #   * raw features + VAD are read directly (sliding-window CMN and voiced-frame selection run on the GPU),
-#   * with --ngpu N > 1 every rank extracts a frame-balanced shard of each window and ONE RCCL gather brings the vectors
-#     to rank 0, which writes xvector.ark/.scp in input order (no split_data.sh, no per-job arks to concatenate),
+#   * with --ngpu N > 1 every rank reads and extracts its own line range of feats.scp / vad.scp and ONE RCCL gather brings
+#     the vectors to rank 0, which writes xvector.ark/.scp in input order (no split_data.sh, no per-job arks to concatenate),
 #   * speaker-level means as in stage 2 of the reference script.
 # Usage: extract_xvectors_mi355x.sh [--ngpu N] [--chunk-size 10000] [--min-chunk-size 25] [--cmn-window 300] <nnet-dir> <data> <xvector-dir>
 set -euo pipefail

@@ -392,6 +392,9 @@ def write_vec_flt_batch(file_or_fd, keys, vecs):
     """Write many float32 vectors as consecutive binary records (same bytes as write_vec_flt per key) with one ``write``
     call per batch.  ``vecs``: a float32 ``[n, D]`` array or a sequence of float32 vectors.  Equal-length vectors are
     serialised without per-record NumPy calls (and without any per-record Python when the keys have one length too)."""
+    if hasattr(file_or_fd, "write_vectors"):                 # an in-memory sink (extract_embedding.py, sharded mode)
+        file_or_fd.write_vectors(keys, vecs)
+        return
     fd = open_or_fd(file_or_fd, mode="wb")
     try:
         n = len(keys)

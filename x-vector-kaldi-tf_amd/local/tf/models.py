@@ -245,11 +245,13 @@ class Model(object):
 
     # -- the hot path ------------------------------------------------------------------------------
     def make_embedding(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger,
-                       vad_stream=None, cmn_window=0, cmn_center=True):
+                       vad_stream=None, cmn_window=0, cmn_center=True, distributed=True):
         """Build-defined extension (defaults = the reference's behaviour): with ``cmn_window > 0`` and/or a
         ``vad_stream`` (ark stream or (key, vector) iterator, same key order as the features) the sliding-window CMN and
         the VAD frame selection that extract_xvectors.sh:68 runs as Kaldi binaries are done on the GPU first, so
-        ``input_stream`` can carry raw features.  ``input_stream`` may also be a (key, matrix) iterator."""
+        ``input_stream`` can carry raw features.  ``input_stream`` may also be a (key, matrix) iterator.  Under torchrun every
+        rank reads the same stream and extracts its share of each window (one gather per window to rank 0) unless
+        ``distributed=False`` says that the caller sharded the input itself."""
         start_time = time.time()
         self.load_model(None, model_dir, logger)
         ex = engine.Extractor(self.device_model, min_chunk_size, chunk_size, max_batch_rows=self.max_batch_rows)
@@ -268,6 +270,10 @@ class Model(object):
         # alone writes (the role of split_data.sh + nj jobs + `cat xvector.*.scp`, extract_xvectors.sh:63-95).
         from xvector_amd import dist as xdist
         rank, world = xdist.init_process_group()
+        if not distributed:
+            # the caller already gave every rank its own part of the input (extract_embedding.py shards scp tables by line
+            # range): behave as a single process and leave the exchange to the caller
+            rank, world = 0, 1
 
         def submit_window(mats, addrs):
             """-> a zero-argument function returning the vectors of the window (None on non-root ranks)."""
