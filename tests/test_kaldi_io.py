@@ -282,3 +282,42 @@ def test_batch_vector_writer_equals_per_record_writer(tmp_path):
         assert lines2[:len(lines1)] == lines1 and len(lines2) == 2 * len(lines1)
     with pytest.raises(kaldi_io.UnsupportedDataType):
         kaldi_io.write_vec_flt_batch(io.BytesIO(), ["a"], np.zeros((1, 3), np.float64))
+
+
+def test_scp_table_block_reader_equals_entry_reads(tmp_path):
+    """kaldi_io.MatScp.blocks(): an scp that follows its arks is read as streams (few large blocks), a subset / shuffled /
+    multi-ark / compressed-record table falls back where needed -- always the same (key, matrix) sequence as read_mat_scp."""
+    rng = np.random.default_rng(7)
+    arks = []
+    lines = []
+    for a in range(2):
+        ark, scp = str(tmp_path / ("f%d.ark" % a)), str(tmp_path / ("f%d.scp" % a))
+        with kaldi_io.TableWriter(ark, scp) as w:
+            for i in range(40):
+                m = rng.standard_normal((int(rng.integers(0, 30)), 6)).astype(np.float32 if i % 7 else np.float64)
+                kaldi_io.write_mat(w, m, key="a%d-utt%03d" % (a, i))
+        lines += open(scp).read().splitlines(True)
+    tables = {
+        "in order": lines,
+        "subset": [ln for i, ln in enumerate(lines) if i % 3 != 1],
+        "shuffled": [lines[i] for i in rng.permutation(len(lines))],
+        "tail then head": lines[50:] + lines[:50],
+        "one": lines[17:18],
+        "empty": [],
+    }
+    for name, tl in tables.items():
+        path = str(tmp_path / "t.scp")
+        open(path, "wt").write("".join(tl))
+        want = list(kaldi_io.read_mat_scp(path))
+        table = kaldi_io.MatScp(path)
+        assert len(table) == len(tl)
+        got, nblocks = [], 0
+        for keys, feats, off in table.blocks():
+            nblocks += 1
+            assert feats.dtype == np.float32 and off[0] == 0 and len(off) == len(keys) + 1
+            got += [(k, feats[off[i]:off[i + 1]]) for i, k in enumerate(keys)]
+        assert [k for k, _ in got] == [k for k, _ in want], name
+        assert all(np.array_equal(g, np.asarray(w, np.float32)) for (_, g), (_, w) in zip(got, want)), name
+        assert [k for k, _ in table] == [k for k, _ in want]
+        if name == "in order":
+            assert nblocks <= 30          # float64 records split the runs; still far fewer blocks than utterances

@@ -693,6 +693,74 @@ def read_mat_scp(file_or_fd):
             fd.close()
 
 
+_RX_OFFSET = re.compile(r"^(.*):(\d+)$")
+
+
+class MatScp(object):
+    """A feature scp as a table: iterate it for ``(key, matrix)`` pairs (= ``read_mat_scp``) or call ``blocks()`` for the
+    ``(keys, feats, offsets)`` blocks of ``read_mat_ark_blocks``.  An scp written next to its ark (copy-feats,
+    compute-mfcc-feats, TableWriter) lists the records of each ark file in file order, back to back: ``blocks()`` then reads
+    such a run as ONE stream -- seek to the first record, let the native scanner/gatherer take whole passes -- instead of one
+    open + seek + read per utterance, and checks every key against the scp.  Where the table departs from the ark order (a
+    subset, a shuffled list, a piped rxfile) it falls back to entry-by-entry reads, so any scp gives the same result."""
+
+    def __init__(self, file_or_fd):
+        fd = open_or_fd(file_or_fd)
+        try:
+            lines = [ln.decode() if isinstance(ln, bytes) else ln for ln in fd]
+        finally:
+            if fd is not file_or_fd:
+                fd.close()
+        self.entries = []
+        for ln in lines:
+            if ln.strip():
+                key, rx = ln.strip("\n").split(" ", 1)
+                self.entries.append((key, rx.strip()))
+
+    def __len__(self):
+        return len(self.entries)
+
+    def __iter__(self):
+        for key, rx in self.entries:
+            yield key, read_mat(rx)
+
+    def blocks(self):
+        ents, n, i = self.entries, len(self.entries), 0
+        misses = 0
+        while i < n:
+            key, rx = ents[i]
+            m = _RX_OFFSET.match(rx)
+            if m is None or rx.endswith("|") or misses >= 2 or _host_lib() is None:
+                mat = np.ascontiguousarray(read_mat(rx), dtype=np.float32)            # entry-by-entry
+                yield [key], mat, np.array([0, mat.shape[0]], np.int64)
+                i += 1
+                continue
+            path, start = m.group(1), int(m.group(2)) - len(key) - 1                  # the record starts at its key
+            run = i
+            while run < n and ents[run][1].startswith(path + ":"):
+                run += 1
+            got = 0
+            with open(path, "rb") as f:
+                f.seek(start)
+                for bkeys, feats, off in read_mat_ark_blocks(f):
+                    want = [k for k, _ in ents[i:min(i + len(bkeys), run)]]
+                    same = 0
+                    while same < len(want) and bkeys[same] == want[same]:
+                        same += 1
+                    if same:
+                        yield bkeys[:same], feats[:int(off[same])], off[:same + 1]
+                        i += same
+                        got += same
+                    if same < len(bkeys) or i >= run:
+                        break
+            # a run that ended after a handful of records means the table does not follow the ark: stop re-seeking for it
+            misses = misses + 1 if got < 4 and i < run else 0
+            if got == 0:                                                               # not even the first key matched
+                mat = np.ascontiguousarray(read_mat(rx), dtype=np.float32)
+                yield [key], mat, np.array([0, mat.shape[0]], np.int64)
+                i += 1
+
+
 def write_mat(file_or_fd, m, key=""):
     """Write a binary Kaldi matrix ('FM '/'DM ', row-major)."""
     fd = open_or_fd(file_or_fd, mode="wb")

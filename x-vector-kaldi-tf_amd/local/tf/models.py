@@ -249,7 +249,8 @@ class Model(object):
         """Build-defined extension (defaults = the reference's behaviour): with ``cmn_window > 0`` and/or a
         ``vad_stream`` (ark stream or (key, vector) iterator, same key order as the features) the sliding-window CMN and
         the VAD frame selection that extract_xvectors.sh:68 runs as Kaldi binaries are done on the GPU first, so
-        ``input_stream`` can carry raw features.  ``input_stream`` may also be a (key, matrix) iterator.  Under torchrun every
+        ``input_stream`` can carry raw features.  ``input_stream`` may also be a (key, matrix) iterator or a table with a
+        ``blocks()`` method (kaldi_io.MatScp).  Under torchrun every
         rank reads the same stream and extracts its share of each window (one gather per window to rank 0) unless
         ``distributed=False`` says that the caller sharded the input itself."""
         start_time = time.time()
@@ -367,8 +368,9 @@ class Model(object):
                 def blocks():
                     # (keys, [matrices], [address of row 0]) per block: whole scanner passes gathered natively for ark
                     # streams, one utterance at a time for (key, matrix) iterators
-                    if hasattr(input_stream, "read"):
-                        for bkeys, bfeats, off in kaldi_io.read_mat_ark_blocks(input_stream):
+                    if hasattr(input_stream, "read") or hasattr(input_stream, "blocks"):
+                        source = kaldi_io.read_mat_ark_blocks(input_stream) if hasattr(input_stream, "read") else input_stream.blocks()
+                        for bkeys, bfeats, off in source:
                             o = off.tolist()
                             base, row_bytes = bfeats.ctypes.data, bfeats.shape[1] * bfeats.itemsize if bfeats.ndim == 2 else 0
                             yield bkeys, [bfeats[o[i]:o[i + 1]] for i in range(len(bkeys))], [base + r * row_bytes for r in o[:-1]]
