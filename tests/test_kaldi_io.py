@@ -321,3 +321,27 @@ def test_scp_table_block_reader_equals_entry_reads(tmp_path):
         assert [k for k, _ in table] == [k for k, _ in want]
         if name == "in order":
             assert nblocks <= 30          # float64 records split the runs; still far fewer blocks than utterances
+
+
+def test_vector_block_reader_and_vector_scp_table(tmp_path):
+    """read_vec_flt_ark_blocks / VecScp.blocks(): a VAD-like ark (float vectors of various lengths, one double-precision
+    record, one empty vector) comes out in scanner passes with the same keys and values as read_vec_flt_ark / _scp."""
+    rng = np.random.default_rng(9)
+    ark, scp = str(tmp_path / "vad.ark"), str(tmp_path / "vad.scp")
+    with kaldi_io.TableWriter(ark, scp) as w:
+        for i in range(60):
+            v = (rng.random(int(rng.integers(0, 50))) > 0.3).astype(np.float64 if i == 31 else np.float32)
+            kaldi_io.write_vec_flt(w, v, key="utt%02d" % i)
+    want = list(kaldi_io.read_vec_flt_ark(ark))
+    got, nblocks = [], 0
+    for keys, vals, off in kaldi_io.read_vec_flt_ark_blocks(ark):
+        nblocks += 1
+        assert vals.ndim == 1 and vals.dtype == np.float32
+        got += [(k, vals[off[i]:off[i + 1]]) for i, k in enumerate(keys)]
+    assert [k for k, _ in got] == [k for k, _ in want] and nblocks <= 4
+    assert all(np.array_equal(g, np.asarray(w_, np.float32)) for (_, g), (_, w_) in zip(got, want))
+    table = kaldi_io.VecScp(scp)
+    got2 = [(k, vals[off[i]:off[i + 1]]) for keys, vals, off in table.blocks() for i, k in enumerate(keys)]
+    assert [k for k, _ in got2] == [k for k, _ in want]
+    assert all(np.array_equal(g, np.asarray(w_, np.float32)) for (_, g), (_, w_) in zip(got2, want))
+    assert [(k, v.tolist()) for k, v in table] == [(k, np.asarray(v, np.float32).tolist()) for k, v in kaldi_io.read_vec_flt_scp(scp)]

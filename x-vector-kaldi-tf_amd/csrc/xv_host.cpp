@@ -18,7 +18,7 @@
 
 extern "C" {
 
-int xv_host_version(void) { return 3; }
+int xv_host_version(void) { return 4; }
 
 // Scans buf[pos, len).  Fills up to max_records entries; returns the number of records found.
 // *next = offset of the first byte not consumed; *stop = 0 buffer exhausted / record incomplete (need more data),
@@ -51,6 +51,42 @@ int xv_ark_scan_fm(const uint8_t *buf, size_t pos, size_t len, int max_records, 
         data_off[n] = (int64_t)d;
         rows[n] = r;
         cols[n] = c;
+        ++n;
+        pos = d + nbytes;
+    }
+    if (n == max_records) *stop = 2;
+    *next = pos;
+    return n;
+}
+
+// The same scan for binary float VECTOR records ("<key> \0BFV \4<int32 dim><dim float32>", e.g. a vad.ark): reported as
+// dim x 1 matrices (rows = dim, cols = 1), so that xv_ark_gather_fm gathers them too.
+int xv_ark_scan_fv(const uint8_t *buf, size_t pos, size_t len, int max_records, int64_t *key_off, int32_t *key_len,
+                   int64_t *data_off, int32_t *rows, int32_t *cols, size_t *next, int *stop)
+{
+    int n = 0;
+    *stop = 0;
+    while (n < max_records) {
+        const uint8_t *sp = (const uint8_t *)memchr(buf + pos, ' ', len - pos);
+        if (!sp) break;
+        const size_t kend = (size_t)(sp - buf);
+        const size_t h = kend + 1;                                 // "\0B" "FV " \4 dim = 2 + 3 + 5 bytes
+        if (h + 10 > len) break;
+        if (buf[h] != 0 || buf[h + 1] != 'B' || buf[h + 2] != 'F' || buf[h + 3] != 'V' || buf[h + 4] != ' ' || buf[h + 5] != 4) {
+            *stop = 1;
+            break;
+        }
+        int32_t dim;
+        memcpy(&dim, buf + h + 6, 4);
+        if (dim < 0) { *stop = 1; break; }
+        const size_t d = h + 10;
+        const size_t nbytes = (size_t)dim * 4;
+        if (d + nbytes > len) break;
+        key_off[n] = (int64_t)pos;
+        key_len[n] = (int32_t)(kend - pos);
+        data_off[n] = (int64_t)d;
+        rows[n] = dim;
+        cols[n] = 1;
         ++n;
         pos = d + nbytes;
     }

@@ -207,9 +207,9 @@ def eval_dnn(args):
     if presharded:
         feat_scp, vad_scp = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
         feats = kaldi_io.MatScp(feat_scp)
-        vad = kaldi_io.read_vec_flt_scp(vad_scp) if vad_scp is not None else None
+        vad = kaldi_io.VecScp(vad_scp) if vad_scp is not None else None
     else:
-        vad = _open_table(args.vad_rspecifier, kaldi_io.read_vec_flt_scp, kaldi_io.read_vec_flt_ark) if args.vad_rspecifier else None
+        vad = _open_table(args.vad_rspecifier, kaldi_io.VecScp, lambda stream: stream) if args.vad_rspecifier else None
         feats = _open_table(args.feature_rspecifier, kaldi_io.MatScp, None)
     collector = _Collector() if presharded else None
     with (kaldi_io.open_or_fd(args.feature_rspecifier) if feats is None else _Null()) as input_fid:

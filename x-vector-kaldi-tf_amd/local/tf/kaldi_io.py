@@ -545,6 +545,9 @@ def _host_lib():
                 lib.xv_ark_scan_fm.restype = ctypes.c_int
                 lib.xv_ark_scan_fm.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int] + \
                     [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+                if hasattr(lib, "xv_ark_scan_fv"):
+                    lib.xv_ark_scan_fv.restype = ctypes.c_int
+                    lib.xv_ark_scan_fv.argtypes = lib.xv_ark_scan_fm.argtypes
                 if hasattr(lib, "xv_ark_gather_fm"):
                     lib.xv_ark_gather_fm.restype = ctypes.c_int64
                     lib.xv_ark_gather_fm.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
@@ -600,9 +603,23 @@ def read_mat_ark_blocks(file_or_fd):
     scanner pass (<= 8192 records) whose payloads are gathered by a single native, GIL-free call -- the per-utterance
     Python work of ``read_mat_ark`` (generator switch, frombuffer, copy) is what bounded the ark->ark rate.  Any other
     record (or a stream without the host library) is returned as a one-utterance block via the generic reader."""
+    return _read_ark_blocks(file_or_fd, "xv_ark_scan_fm", lambda fd: np.ascontiguousarray(read_mat(fd), dtype=np.float32))
+
+
+def read_vec_flt_ark_blocks(file_or_fd):
+    """The same for float vectors (e.g. a VAD table): generator of (keys, values[sum dim] float32, offsets[n+1])."""
+    for keys, vals, offsets in _read_ark_blocks(file_or_fd, "xv_ark_scan_fv",
+                                                lambda fd: np.ascontiguousarray(read_vec_flt(fd), dtype=np.float32).reshape(-1, 1)):
+        yield keys, vals.reshape(-1), offsets
+
+
+def _read_ark_blocks(file_or_fd, scan_name, read_one):
     raw = open_or_fd(file_or_fd)
     fd = raw if isinstance(raw, _BufferedStream) else _BufferedStream(raw)
     lib = _host_lib()
+    if lib is not None and not (hasattr(lib, "xv_ark_gather_fm") and hasattr(lib, scan_name)):
+        lib = None
+    scan = getattr(lib, scan_name) if lib is not None else None
     try:
         if lib is not None and hasattr(lib, "xv_ark_gather_fm"):
             key_off = np.empty(_SCAN_MAX, np.int64); key_len = np.empty(_SCAN_MAX, np.int32)
@@ -616,9 +633,9 @@ def read_mat_ark_blocks(file_or_fd):
                     buf, pos = fd.buf, fd.pos
                     if len(buf) == pos:
                         break
-                    n = lib.xv_ark_scan_fm(buf, pos, len(buf), _SCAN_MAX, key_off.ctypes.data, key_len.ctypes.data,
-                                           data_off.ctypes.data, rows.ctypes.data, cols.ctypes.data, ctypes.byref(nxt),
-                                           ctypes.byref(stop))
+                    n = scan(buf, pos, len(buf), _SCAN_MAX, key_off.ctypes.data, key_len.ctypes.data,
+                             data_off.ctypes.data, rows.ctypes.data, cols.ctypes.data, ctypes.byref(nxt),
+                             ctypes.byref(stop))
                     i0 = 0
                     while i0 < n:                               # split the pass where the column count changes
                         c = int(cols[i0])
@@ -648,7 +665,7 @@ def read_mat_ark_blocks(file_or_fd):
             key = read_key(fd)                                  # generic path: one record of any supported type
             if not key:
                 break
-            m = np.ascontiguousarray(read_mat(fd), dtype=np.float32)
+            m = read_one(fd)
             yield [key], m, np.array([0, m.shape[0]], np.int64)
     finally:
         if raw is not file_or_fd:
@@ -696,8 +713,8 @@ def read_mat_scp(file_or_fd):
 _RX_OFFSET = re.compile(r"^(.*):(\d+)$")
 
 
-class MatScp(object):
-    """A feature scp as a table: iterate it for ``(key, matrix)`` pairs (= ``read_mat_scp``) or call ``blocks()`` for the
+class _ScpTable(object):
+    """An scp as a table: iterate it for ``(key, matrix)`` pairs (= ``read_mat_scp``) or call ``blocks()`` for the
     ``(keys, feats, offsets)`` blocks of ``read_mat_ark_blocks``.  An scp written next to its ark (copy-feats,
     compute-mfcc-feats, TableWriter) lists the records of each ark file in file order, back to back: ``blocks()`` then reads
     such a run as ONE stream -- seek to the first record, let the native scanner/gatherer take whole passes -- instead of one
@@ -720,9 +737,12 @@ class MatScp(object):
     def __len__(self):
         return len(self.entries)
 
+    # subclasses provide _one(rxfile) -> float32 array of one record and _ark_blocks = the ark block reader of the record type
+    _ark_blocks = None
+
     def __iter__(self):
         for key, rx in self.entries:
-            yield key, read_mat(rx)
+            yield key, self._one(rx)
 
     def blocks(self):
         ents, n, i = self.entries, len(self.entries), 0
@@ -731,7 +751,7 @@ class MatScp(object):
             key, rx = ents[i]
             m = _RX_OFFSET.match(rx)
             if m is None or rx.endswith("|") or misses >= 2 or _host_lib() is None:
-                mat = np.ascontiguousarray(read_mat(rx), dtype=np.float32)            # entry-by-entry
+                mat = self._one(rx)                                                    # entry-by-entry
                 yield [key], mat, np.array([0, mat.shape[0]], np.int64)
                 i += 1
                 continue
@@ -742,7 +762,7 @@ class MatScp(object):
             got = 0
             with open(path, "rb") as f:
                 f.seek(start)
-                for bkeys, feats, off in read_mat_ark_blocks(f):
+                for bkeys, feats, off in type(self)._ark_blocks(f):
                     want = [k for k, _ in ents[i:min(i + len(bkeys), run)]]
                     same = 0
                     while same < len(want) and bkeys[same] == want[same]:
@@ -756,9 +776,27 @@ class MatScp(object):
             # a run that ended after a handful of records means the table does not follow the ark: stop re-seeking for it
             misses = misses + 1 if got < 4 and i < run else 0
             if got == 0:                                                               # not even the first key matched
-                mat = np.ascontiguousarray(read_mat(rx), dtype=np.float32)
+                mat = self._one(rx)
                 yield [key], mat, np.array([0, mat.shape[0]], np.int64)
                 i += 1
+
+
+class MatScp(_ScpTable):
+    """Feature table: ``(key, float32 [T, F])`` / blocks ``(keys, feats[sum T, F], offsets)``."""
+    _ark_blocks = staticmethod(read_mat_ark_blocks)
+
+    @staticmethod
+    def _one(rx):
+        return np.ascontiguousarray(read_mat(rx), dtype=np.float32)
+
+
+class VecScp(_ScpTable):
+    """Vector table (e.g. vad.scp): ``(key, float32 [dim])`` / blocks ``(keys, values[sum dim], offsets)``."""
+    _ark_blocks = staticmethod(read_vec_flt_ark_blocks)
+
+    @staticmethod
+    def _one(rx):
+        return np.ascontiguousarray(read_vec_flt(rx), dtype=np.float32)
 
 
 def write_mat(file_or_fd, m, key=""):

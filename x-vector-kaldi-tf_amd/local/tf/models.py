@@ -352,7 +352,17 @@ class Model(object):
                 keys, mats, vads, addrs, frames = [], [], [], [], 0
                 vad_it, pending = None, {}
                 if vad_stream is not None:
-                    vad_it = kaldi_io.read_vec_flt_ark(vad_stream) if hasattr(vad_stream, "read") else vad_stream
+                    # an ark stream or a table with blocks() (kaldi_io.VecScp) is read in scanner passes, one view per key
+                    if hasattr(vad_stream, "read") or hasattr(vad_stream, "blocks"):
+                        def vad_records():
+                            src = kaldi_io.read_vec_flt_ark_blocks(vad_stream) if hasattr(vad_stream, "read") else vad_stream.blocks()
+                            for vkeys, vals, voff in src:
+                                vo = voff.tolist()
+                                for n_, k_ in enumerate(vkeys):
+                                    yield k_, vals[vo[n_]:vo[n_ + 1]]
+                        vad_it = vad_records()
+                    else:
+                        vad_it = iter(vad_stream)
 
                 def vad_for(key):
                     # same key order as the features (extract_xvectors.sh reads it as scp,s,cs); out-of-order tables still

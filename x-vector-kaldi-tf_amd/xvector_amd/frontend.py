@@ -27,6 +27,10 @@ class FrontEnd(object):
         self.center = bool(center)
         self.min_window = int(min_window)
         self.stats = dict(utterances=0, frames_in=0, frames_out=0, dropped=0)
+        # own stream: the result goes back to the host, so nothing on the compute stream depends on it -- and on the compute
+        # stream the D2H copy would queue behind the extraction kernels of the previous window (measured: the whole pipeline
+        # serialised)
+        self._stream = torch.cuda.Stream(device=self.device)
 
     def apply(self, mats, vads=None):
         """mats: list of float32 [T, F]; vads: None (every frame voiced) or a list of 1-D arrays (non-zero = voiced).
@@ -34,53 +38,60 @@ class FrontEnd(object):
         torch = self.torch
         n = len(mats)
         out = [None] * n
-        keep, sel = [], []
-        for i, m in enumerate(mats):
-            T = m.shape[0]
-            if vads is None or vads[i] is None:
-                idx = np.arange(T, dtype=np.int64)
-            else:
-                v = np.asarray(vads[i]).reshape(-1)
-                if v.shape[0] != T or not np.any(v != 0):          # select-voiced-frames: mismatch / nothing voiced
-                    self.stats["dropped"] += 1
-                    continue
-                idx = np.flatnonzero(v != 0)
-            if T == 0:
-                out[i] = np.zeros((0, m.shape[1]), np.float32)
-                continue
-            keep.append(i)
-            sel.append(idx)
-        if not keep:
+        if n == 0:
             return out
-        if self.cmn_window <= 0:                               # selection only: no arithmetic, no device round trip
-            for i, idx in zip(keep, sel):
-                out[i] = np.ascontiguousarray(mats[i][idx], dtype=np.float32)
-                self.stats["frames_in"] += mats[i].shape[0]
-                self.stats["frames_out"] += len(idx)
-            self.stats["utterances"] += len(keep)
+        # everything per frame is done on concatenated arrays (one NumPy call per window, not per utterance)
+        T = np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=n)
+        if vads is None:
+            for i in np.flatnonzero(T == 0).tolist():
+                out[i] = np.zeros((0, mats[i].shape[1]), np.float32)
+            cand = np.flatnonzero(T > 0)
+            voiced = None
+        else:
+            flat = [None if v is None else np.asarray(v).reshape(-1) for v in vads]
+            vl = np.fromiter((-1 if v is None else v.shape[0] for v in flat), dtype=np.int64, count=n)
+            for i in np.flatnonzero((vl < 0) & (T == 0)).tolist():      # no VAD for this key and no frames: an empty matrix
+                out[i] = np.zeros((0, mats[i].shape[1]), np.float32)
+            cand = np.flatnonzero(((vl == T) | (vl < 0)) & (T > 0))      # select-voiced-frames: a length mismatch drops the key
+            voiced = np.concatenate([np.ones(int(T[i]), bool) if flat[i] is None else flat[i] != 0 for i in cand.tolist()]) \
+                if len(cand) else np.zeros(0, bool)
+            starts_c = np.zeros(len(cand), dtype=np.int64)
+            np.cumsum(T[cand][:-1], out=starts_c[1:])
+            counts_c = np.add.reduceat(voiced, starts_c) if len(cand) else np.zeros(0, np.int64)
+            has = counts_c > 0                                           # ... and so does a VAD without a voiced frame
+            voiced = voiced[np.repeat(has, T[cand])]
+            cand = cand[has]
+            self.stats["dropped"] += int(np.count_nonzero(vl >= 0)) - int(np.count_nonzero(vl[cand] >= 0))
+        if len(cand) == 0:
             return out
+        keep = cand.tolist()
         F = mats[keep[0]].shape[1]
-        lens = np.array([mats[i].shape[0] for i in keep], dtype=np.int64)
+        lens = T[cand]
         starts = np.zeros(len(keep), dtype=np.int64)
         np.cumsum(lens[:-1], out=starts[1:])
         total_in = int(lens.sum())
         assert total_in < 2 ** 31
-        counts = np.array([len(s) for s in sel], dtype=np.int64)
+        if voiced is None:
+            counts = lens
+            dst = np.arange(total_in, dtype=np.int32)
+        else:
+            counts = np.add.reduceat(voiced, starts).astype(np.int64)
+            dst = np.where(voiced, np.cumsum(voiced, dtype=np.int64) - 1, -1).astype(np.int32)
         ostarts = np.zeros(len(keep), dtype=np.int64)
         np.cumsum(counts[:-1], out=ostarts[1:])
         total_out = int(counts.sum())
-        dst = np.full(total_in, -1, dtype=np.int32)
-        for s0, o0, idx in zip(starts, ostarts, sel):
-            dst[s0 + idx] = np.arange(o0, o0 + len(idx), dtype=np.int32)
-        raw = np.concatenate([np.ascontiguousarray(mats[i], dtype=np.float32) for i in keep], axis=0)
-        with torch.cuda.device(self.device):
-            x = torch.from_numpy(raw).to(self.device)
-            y = torch.empty((max(total_out, 1), F), dtype=torch.float32, device=self.device)
-            hiplib.cmn_sliding_scatter(x, torch.from_numpy(starts.astype(np.int32)).to(self.device),
-                                       torch.from_numpy(lens.astype(np.int32)).to(self.device), len(keep), int(lens.max()),
-                                       self.cmn_window, self.center, self.min_window, torch.from_numpy(dst).to(self.device), y)
-            host = y[:total_out].cpu().numpy()
-        for i, o0, c in zip(keep, ostarts, counts):
+        raw = np.concatenate([np.asarray(mats[i], dtype=np.float32) for i in keep], axis=0)
+        if self.cmn_window <= 0:                               # selection only: no arithmetic, no device round trip
+            host = raw if voiced is None else raw[voiced]
+        else:
+            with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+                x = torch.from_numpy(raw).to(self.device)
+                y = torch.empty((max(total_out, 1), F), dtype=torch.float32, device=self.device)
+                hiplib.cmn_sliding_scatter(x, torch.from_numpy(starts.astype(np.int32)).to(self.device),
+                                           torch.from_numpy(lens.astype(np.int32)).to(self.device), len(keep), int(lens.max()),
+                                           self.cmn_window, self.center, self.min_window, torch.from_numpy(dst).to(self.device), y)
+                host = y[:total_out].cpu().numpy()
+        for i, o0, c in zip(keep, ostarts.tolist(), counts.tolist()):
             out[i] = host[o0:o0 + c]
         self.stats["utterances"] += len(keep)
         self.stats["frames_in"] += total_in
