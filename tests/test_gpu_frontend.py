@@ -130,3 +130,38 @@ def test_cli_raw_features_plus_vad_to_speaker_xvectors(env, tmp_path):
     assert list(spk) == ["spkA", "spkB"] and open(nutt).read() == "spkA 2\nspkB 1\n"
     np.testing.assert_allclose(spk["spkA"], (got[utts[0][0]] + got[utts[2][0]]) / np.float32(2), rtol=1e-6)
     assert np.array_equal(spk["spkB"], got[utts[3][0]])
+
+
+def test_device_front_end_path_equals_host_round_trip(tmp_path):
+    """Extractor.submit_raw (CMN + voiced-frame selection scattered straight into the packed batches on the device) gives
+    bit-identical x-vectors to FrontEnd.apply + Extractor.extract (selected features through the host), across chunking,
+    small batches that split utterances, VADs that drop utterances, missing VADs and an all-voiced window."""
+    from xvector_amd import engine, frontend, synthetic, topology
+    topo = topology.get("ModelWithoutDropout")
+    w = synthetic.trained_like(topo, 23, seed=3)
+    model = engine.DeviceModel(w, topo, "cuda:0")
+    rng = np.random.default_rng(12)
+    Ts = [300, 40, 1, 0, 777, 25, 1300, 90, 260, 33]
+    mats = [(rng.standard_normal((t, 23)) * 3 + 1.5).astype(np.float32) for t in Ts]
+    vads = [(rng.random(t) < 0.7).astype(np.float32) for t in Ts]
+    vads[1] = np.zeros(40, np.float32)              # nothing voiced -> dropped
+    vads[4] = vads[4][:-1]                          # length mismatch -> dropped
+    vads[7] = None                                  # no VAD for this key: every frame voiced
+    for vv, (mn, cs, rows) in ((vads, (25, 200, 262144)), (vads, (10, -1, 512)), (None, (25, 300, 700)), (vads, (25, 10000, 262144))):
+        fe = frontend.FrontEnd("cuda:0", 300, True)
+        sel = fe.apply(mats, vv)
+        ex = engine.Extractor(model, mn, cs, max_batch_rows=rows)
+        keep = [i for i, m in enumerate(sel) if m is not None]
+        want = ex.extract([sel[i] for i in keep])
+        ex2 = engine.Extractor(model, mn, cs, max_batch_rows=rows)
+        handle, lens, dropped = ex2.submit_raw(mats, vv, 300, True)
+        got = ex2.finish(handle)
+        assert [i for i in range(len(mats)) if not dropped[i]] == keep or vv is None
+        assert [int(lens[i]) for i in keep] == [sel[i].shape[0] for i in keep]
+        for j, i in enumerate(keep):
+            assert (want[j] is None) == (got[i] is None), (i, mn, cs)
+            if want[j] is not None:
+                assert np.array_equal(want[j], got[i]), (i, mn, cs, rows)
+        for i in range(len(mats)):
+            if i not in keep:
+                assert got[i] is None

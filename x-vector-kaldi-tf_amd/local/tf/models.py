@@ -302,9 +302,29 @@ class Model(object):
             return lambda: (host, valid)
 
         def submit(keys, mats, vads=None, addrs=None):
-            """Front-end (optional) + everything up to the kernel launches of one window; returns what ``collect`` needs."""
+            """Front-end (optional) + everything up to the kernel launches of one window; returns what ``collect`` needs:
+            the keys that go on, their (selected) lengths and a function that yields the vectors."""
             nonlocal num_fail, compute_time
             t0 = time.time()
+            lens = None
+            if front is not None and front.cmn_window > 0 and world == 1 and hasattr(ex, "submit_raw") and engine.can_submit_raw(mats, self.device_model.feat_dim):
+                # CMN + voiced-frame selection on the device, scattered straight into the packed batches
+                handle, lens, dropped = ex.submit_raw(mats, vads, front.cmn_window, front.center, front.min_window)
+                for i in np.flatnonzero(dropped).tolist():
+                    logger.warning("No voiced frames (or VAD / feature length mismatch) for utterance: '%s'" % keys[i])
+                num_fail += int(dropped.sum())
+                if dropped.any():
+                    keep_idx = np.flatnonzero(~dropped)
+                    keys, lens = [keys[i] for i in keep_idx.tolist()], lens[keep_idx]
+
+                    def result(h=handle, sel=keep_idx):
+                        full, valid = ex.finish(h, as_array=True)
+                        return full[sel], valid[sel]
+                else:
+                    def result(h=handle):
+                        return ex.finish(h, as_array=True)
+                compute_time += time.time() - t0
+                return keys, lens, result
             if front is not None:
                 done = front.apply(mats, vads)
                 kept = []
@@ -316,10 +336,11 @@ class Model(object):
                         kept.append((key, m))
                 keys, mats, addrs = [k for k, _ in kept], [m for _, m in kept], None
             result = submit_window(mats, addrs)
+            lens = np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=len(mats))
             compute_time += time.time() - t0
-            return keys, mats, result
+            return keys, lens, result
 
-        def collect(keys, mats, result):
+        def collect(keys, lens, result):
             """Wait for a submitted window and write its vectors (input order)."""
             nonlocal num_fail, num_success, compute_time
             t0 = time.time()
@@ -330,7 +351,7 @@ class Model(object):
             vecs, valid = out
             if not valid.all():
                 for i in np.flatnonzero(~valid).tolist():
-                    if mats[i].shape[0] == 0:
+                    if lens[i] == 0:
                         logger.warning("Zero-length utterance: '%s'" % keys[i])
                     else:
                         logger.warning("Minimum chunk size of %d is greater than the number of rows in utterance: %s" %

@@ -43,6 +43,13 @@ def _host_lib():
     return _HOST[0]
 
 
+def can_submit_raw(mats, feat_dim):
+    """Extractor.submit_raw reads the raw matrices in place through the native packer: host library present and every matrix a
+    C-contiguous float32 [T, feat_dim] array."""
+    return _host_lib() is not None and all(m.dtype == np.float32 and m.ndim == 2 and m.shape[1] == feat_dim and m.flags.c_contiguous
+                                           for m in mats)
+
+
 def matrix_addresses(mats, feat_dim):
     """uint64 address of row 0 of every utterance matrix, or None when one of them is not a C-contiguous float32
     ``[T, feat_dim]`` array (the native packer reads them in place)."""
@@ -572,6 +579,155 @@ class Extractor(object):
         # mats (the native packer read them in place) and the device buffers stay referenced until finish()
         handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats))
         return handle
+
+    def submit_raw(self, mats, vads, cmn_window, center=True, min_window=100):
+        """``submit`` for RAW features: sliding-window CMN + VAD frame selection (xv_cmn_sliding_scatter_f32) run on the
+        device and write every voiced, normalised frame straight into its row of the packed batch -- the selected features
+        never exist on the host.  mats: float32 [T, F] arrays; vads: None or one 1-D array (non-zero = voiced) / None per
+        utterance.  Returns ``(handle, lengths, vad_dropped)``: the handle for ``finish``; the number of selected frames per
+        utterance; a bool mask of the utterances select-voiced-frames drops (VAD length mismatch / no voiced frame)."""
+        from .frontend import select_voiced
+        torch = self.model.torch
+        model = self.model
+        dev = model.device
+        n = len(mats)
+        F = model.feat_dim
+        lib = _host_lib()
+        addrs = matrix_addresses(mats, F) if lib is not None else None
+        assert lib is not None and addrs is not None, "submit_raw needs libxvector_host.so and C-contiguous float32 [T, %d] matrices" % F
+        T, cand, voiced, _, _ = select_voiced(mats, vads)
+        V = np.zeros(n, dtype=np.int64)                       # selected frames per utterance
+        vstart = np.zeros(n, dtype=np.int64)                  # offset of the utterance's flags in `voiced`
+        if voiced is None:
+            V[cand] = T[cand]
+        else:
+            cs = np.zeros(len(cand), dtype=np.int64)
+            np.cumsum(T[cand][:-1], out=cs[1:])
+            vstart[cand] = cs
+            V[cand] = np.add.reduceat(voiced, cs) if len(cand) else 0
+        vad_dropped = np.ones(n, dtype=bool)
+        vad_dropped[cand] = False
+        if vads is None:
+            vad_dropped[:] = False
+        else:
+            vad_dropped &= np.fromiter((v is not None for v in vads), dtype=bool, count=n)
+        order, c_utt, c_start, c_len, seg_start = plan_chunk_table(V, self.min_chunk_size, self.chunk_size)
+        nch = len(c_utt)
+        handle = dict(n=n, order=order, nch=nch)
+        if nch == 0:
+            return handle, V, vad_dropped
+        gap, align = model.gap, model.align
+        lead = (gap + align - 1) // align * align
+        cum = np.zeros(nch + 1, dtype=np.int64)
+        np.cumsum(slot_rows(c_len, gap, align), out=cum[1:])
+        bounds, b0 = [], 0
+        while b0 < nch:
+            b1 = int(np.searchsorted(cum, cum[b0] + self.max_batch_rows - lead, side="right")) - 1
+            b1 = min(max(b1, b0 + 1), b0 + self.max_batch_chunks, nch)
+            bounds.append((b0, b1, lead + int(cum[b1] - cum[b0])))
+            b0 = b1
+        kept = np.diff(seg_start)                             # chunks per utterance of `order`
+        first_len = c_len[seg_start[:-1]]                     # = the chunk size the plan used for the utterance
+        # utterances (positions in `order`) touched by each batch, and the raw rows they bring
+        spans = [(int(np.searchsorted(seg_start, b0, side="right")) - 1, int(np.searchsorted(seg_start, b1, side="left")))
+                 for b0, b1, _ in bounds]
+        raw_rows = max(int(T[order[lo:hi]].sum()) for lo, hi in spans)
+        self._raw_staging(raw_rows, max(hi - lo for lo, hi in spans), F)
+        self._staging(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds))
+        with torch.cuda.device(dev):
+            compute = torch.cuda.current_stream()
+            E_all = torch.empty((nch, model.embed_dim), dtype=torch.float32, device=dev)
+            P_all = torch.empty((nch, model.pooled_dim), dtype=torch.float32, device=dev)
+            model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), int(c_len.max()))
+            keep = []
+            for (b0, b1, _), (lo, hi) in zip(bounds, spans):
+                layout = BatchLayout(c_len[b0:b1], gap, align)
+                U = order[lo:hi]
+                Tb = T[U]
+                nU, rows_in = len(U), int(Tb.sum())
+                ustart = np.zeros(nU, dtype=np.int64)
+                np.cumsum(Tb[:-1], out=ustart[1:])
+                # destination row of every raw frame of the batch's utterances (-1: unvoiced / chunk of another batch / dropped tail)
+                p = np.repeat(np.arange(nU), Tb)
+                if voiced is None:
+                    vm = np.ones(rows_in, dtype=bool)
+                    vidx = np.arange(rows_in, dtype=np.int64) - np.repeat(ustart, Tb)
+                else:
+                    vm = np.concatenate([voiced[vstart[u]:vstart[u] + T[u]] for u in U.tolist()])
+                    cv = np.cumsum(vm, dtype=np.int64)
+                    before = cv[ustart + Tb - 1] - V[U]                       # voiced frames of the batch before each utterance
+                    vidx = cv - 1 - np.repeat(before, Tb)
+                size = first_len[lo:hi][p]
+                k = vidx // size
+                cid = seg_start[lo:hi][p] + k
+                ok = vm & (k < kept[lo:hi][p]) & (cid >= b0) & (cid < b1)
+                dst = np.where(ok, layout.row_start[np.clip(cid - b0, 0, layout.nchunks - 1)] + (vidx - k * size), -1).astype(np.int32)
+                st = self._raw_stage[self._turn % self.NBUF]
+                sx = self._stage[self._turn % self.NBUF]
+                self._turn += 1
+                for s_ in (st, sx):
+                    if s_["event"] is not None:
+                        s_["event"].synchronize()
+                src_b, len_b, start_b = addrs[U], Tb.astype(np.int32), ustart.astype(np.int32)      # (kept alive across the call)
+                rc = lib.xv_pack_rows_f32(src_b.ctypes.data, len_b.ctypes.data, start_b.ctypes.data, nU, F,
+                                          st["raw"].numpy().ctypes.data, F, rows_in, None, self.PACK_THREADS)
+                assert rc == 0, "xv_pack_rows_f32 rejected the raw layout"
+                st["dst"].numpy()[:rows_in] = dst
+                um = st["utt"].numpy()
+                um[0, :nU] = ustart
+                um[1, :nU] = Tb
+                layout.row_valid(sx["rv"].numpy())
+                meta = sx["meta"].numpy()
+                meta[0, :layout.nchunks] = layout.row_start
+                meta[1, :layout.nchunks] = layout.row_len
+                with torch.cuda.stream(self._copy_stream):
+                    raw_d = st["raw"][:rows_in].to(dev, non_blocking=True)
+                    dst_d = st["dst"][:rows_in].to(dev, non_blocking=True)
+                    utt_d = st["utt"][:, :nU].to(dev, non_blocking=True)
+                    rv = sx["rv"][:layout.rows].to(dev, non_blocking=True)
+                    md = sx["meta"][:, :layout.nchunks].to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                st["event"] = sx["event"] = ev
+                compute.wait_event(ev)
+                x = torch.zeros((layout.rows, model.in_dim), dtype=torch.float32, device=dev)      # gap rows and padding columns
+                hiplib.cmn_sliding_scatter(raw_d, utt_d[0], utt_d[1], nU, int(Tb.max()), cmn_window, center, min_window, dst_d, x)
+                model.frame_level(x, md[0], md[1], rv, layout.nchunks, layout.max_len, P_all[b0:b1])
+                keep.append((x, rv, md, raw_d, dst_d, utt_d))
+                self.stats["batches"] += 1
+                self.stats["chunks"] += layout.nchunks
+                self.stats["frames"] += int(layout.row_len.sum())
+                self.stats["rows"] += layout.rows
+            model.segment_level(P_all, E_all)
+            tail = torch.from_numpy(np.concatenate([np.asarray(seg_start, dtype=np.int32), c_len.astype(np.int32)])).pin_memory()
+            with torch.cuda.stream(self._copy_stream):
+                tail_d = tail.to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+            compute.wait_event(ev)
+            seg, cl = tail_d[:len(order) + 1], tail_d[len(order) + 1:]
+            out = torch.empty((len(order), model.embed_dim), dtype=torch.float32, device=dev)
+            hiplib.chunk_average(E_all, seg, cl, len(order), out)
+            host = torch.empty((len(order), model.embed_dim), dtype=torch.float32).pin_memory()
+            host.copy_(out, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(compute)
+        handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats))
+        return handle, V, vad_dropped
+
+    def _raw_staging(self, rows, nutts, feat_dim):
+        """NBUF pinned sets for submit_raw: raw features [rows, F], destination rows int32[rows], (start, length) int32[2, utts]."""
+        torch = self.model.torch
+        cur = getattr(self, "_raw_stage", None)
+        if cur is None or cur[0]["raw"].shape[0] < rows or cur[0]["utt"].shape[1] < nutts or cur[0]["raw"].shape[1] != feat_dim:
+            rows = max(rows, 2 * self.max_batch_rows) if rows > 4096 else max(rows, 1024)
+            nutts = max(nutts, min(self.max_batch_chunks, 8192)) if nutts > 64 else max(nutts, 64)
+            self._raw_stage = [dict(raw=torch.zeros((rows, feat_dim), dtype=torch.float32).pin_memory(),
+                                    dst=torch.zeros(rows, dtype=torch.int32).pin_memory(),
+                                    utt=torch.zeros((2, nutts), dtype=torch.int32).pin_memory(), event=None) for _ in range(self.NBUF)]
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.model.device)
+        return self._raw_stage
 
     def finish(self, handle, as_array=False):
         """Wait for a submitted window and return its x-vectors in input order: a list with None for rejected utterances,

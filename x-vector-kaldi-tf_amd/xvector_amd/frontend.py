@@ -17,6 +17,32 @@ import numpy as np
 from . import hiplib
 
 
+def select_voiced(mats, vads):
+    """The utterance-level rules of select-voiced-frames for a window, vectorised.  Returns
+    ``(T, cand, voiced, empty, dropped)``: frame counts of all utterances; indices of the utterances that go on (T > 0, VAD of
+    the right length with at least one voiced frame, or no VAD at all); the voiced flags of their frames concatenated in that
+    order (None = every frame voiced); indices of utterances that have neither frames nor a VAD (they stay empty matrices);
+    the number of utterances dropped because of their VAD (length mismatch / nothing voiced)."""
+    n = len(mats)
+    T = np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=n)
+    if vads is None:
+        return T, np.flatnonzero(T > 0), None, np.flatnonzero(T == 0).tolist(), 0
+    flat = [None if v is None else np.asarray(v).reshape(-1) for v in vads]
+    vl = np.fromiter((-1 if v is None else v.shape[0] for v in flat), dtype=np.int64, count=n)
+    empty = np.flatnonzero((vl < 0) & (T == 0)).tolist()
+    cand = np.flatnonzero(((vl == T) | (vl < 0)) & (T > 0))                  # a length mismatch drops the key
+    voiced = np.concatenate([np.ones(int(T[i]), bool) if flat[i] is None else flat[i] != 0 for i in cand.tolist()]) \
+        if len(cand) else np.zeros(0, bool)
+    starts = np.zeros(len(cand), dtype=np.int64)
+    np.cumsum(T[cand][:-1], out=starts[1:])
+    counts = np.add.reduceat(voiced, starts) if len(cand) else np.zeros(0, np.int64)
+    has = counts > 0                                                          # ... and so does a VAD without a voiced frame
+    voiced = voiced[np.repeat(has, T[cand])]
+    cand = cand[has]
+    dropped = int(np.count_nonzero(vl >= 0)) - int(np.count_nonzero(vl[cand] >= 0))
+    return T, cand, voiced, empty, dropped
+
+
 class FrontEnd(object):
     def __init__(self, device="cuda:0", cmn_window=300, center=True, min_window=100):
         import torch
@@ -41,27 +67,10 @@ class FrontEnd(object):
         if n == 0:
             return out
         # everything per frame is done on concatenated arrays (one NumPy call per window, not per utterance)
-        T = np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=n)
-        if vads is None:
-            for i in np.flatnonzero(T == 0).tolist():
-                out[i] = np.zeros((0, mats[i].shape[1]), np.float32)
-            cand = np.flatnonzero(T > 0)
-            voiced = None
-        else:
-            flat = [None if v is None else np.asarray(v).reshape(-1) for v in vads]
-            vl = np.fromiter((-1 if v is None else v.shape[0] for v in flat), dtype=np.int64, count=n)
-            for i in np.flatnonzero((vl < 0) & (T == 0)).tolist():      # no VAD for this key and no frames: an empty matrix
-                out[i] = np.zeros((0, mats[i].shape[1]), np.float32)
-            cand = np.flatnonzero(((vl == T) | (vl < 0)) & (T > 0))      # select-voiced-frames: a length mismatch drops the key
-            voiced = np.concatenate([np.ones(int(T[i]), bool) if flat[i] is None else flat[i] != 0 for i in cand.tolist()]) \
-                if len(cand) else np.zeros(0, bool)
-            starts_c = np.zeros(len(cand), dtype=np.int64)
-            np.cumsum(T[cand][:-1], out=starts_c[1:])
-            counts_c = np.add.reduceat(voiced, starts_c) if len(cand) else np.zeros(0, np.int64)
-            has = counts_c > 0                                           # ... and so does a VAD without a voiced frame
-            voiced = voiced[np.repeat(has, T[cand])]
-            cand = cand[has]
-            self.stats["dropped"] += int(np.count_nonzero(vl >= 0)) - int(np.count_nonzero(vl[cand] >= 0))
+        T, cand, voiced, empty, dropped = select_voiced(mats, vads)
+        for i in empty:
+            out[i] = np.zeros((0, mats[i].shape[1]), np.float32)
+        self.stats["dropped"] += dropped
         if len(cand) == 0:
             return out
         keep = cand.tolist()
