@@ -307,9 +307,10 @@ class Model(object):
             nonlocal num_fail, compute_time
             t0 = time.time()
             lens = None
-            if front is not None and front.cmn_window > 0 and world == 1 and hasattr(ex, "submit_raw") and engine.can_submit_raw(mats, self.device_model.feat_dim):
+            if front is not None and front.cmn_window > 0 and world == 1 and hasattr(ex, "submit_raw") and \
+                    engine._host_lib() is not None and (addrs is not None or engine.can_submit_raw(mats, self.device_model.feat_dim)):
                 # CMN + voiced-frame selection on the device, scattered straight into the packed batches
-                handle, lens, dropped = ex.submit_raw(mats, vads, front.cmn_window, front.center, front.min_window)
+                handle, lens, dropped = ex.submit_raw(mats, vads, front.cmn_window, front.center, front.min_window, addrs)
                 for i in np.flatnonzero(dropped).tolist():
                     logger.warning("No voiced frames (or VAD / feature length mismatch) for utterance: '%s'" % keys[i])
                 num_fail += int(dropped.sum())

@@ -580,11 +580,11 @@ class Extractor(object):
         handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats))
         return handle
 
-    def submit_raw(self, mats, vads, cmn_window, center=True, min_window=100):
+    def submit_raw(self, mats, vads, cmn_window, center=True, min_window=100, addrs=None):
         """``submit`` for RAW features: sliding-window CMN + VAD frame selection (xv_cmn_sliding_scatter_f32) run on the
         device and write every voiced, normalised frame straight into its row of the packed batch -- the selected features
         never exist on the host.  mats: float32 [T, F] arrays; vads: None or one 1-D array (non-zero = voiced) / None per
-        utterance.  Returns ``(handle, lengths, vad_dropped)``: the handle for ``finish``; the number of selected frames per
+        utterance; addrs: optional ``matrix_addresses(mats, F)``.  Returns ``(handle, lengths, vad_dropped)``: the handle for ``finish``; the number of selected frames per
         utterance; a bool mask of the utterances select-voiced-frames drops (VAD length mismatch / no voiced frame)."""
         from .frontend import select_voiced
         torch = self.model.torch
@@ -593,7 +593,8 @@ class Extractor(object):
         n = len(mats)
         F = model.feat_dim
         lib = _host_lib()
-        addrs = matrix_addresses(mats, F) if lib is not None else None
+        if addrs is None and lib is not None:
+            addrs = matrix_addresses(mats, F)
         assert lib is not None and addrs is not None, "submit_raw needs libxvector_host.so and C-contiguous float32 [T, %d] matrices" % F
         T, cand, voiced, _, _ = select_voiced(mats, vads)
         V = np.zeros(n, dtype=np.int64)                       # selected frames per utterance
