@@ -18,7 +18,7 @@
 
 extern "C" {
 
-int xv_host_version(void) { return 4; }
+int xv_host_version(void) { return 5; }
 
 // Scans buf[pos, len).  Fills up to max_records entries; returns the number of records found.
 // *next = offset of the first byte not consumed; *stop = 0 buffer exhausted / record incomplete (need more data),
@@ -99,13 +99,22 @@ int xv_ark_scan_fv(const uint8_t *buf, size_t pos, size_t len, int max_records, 
 // back into dst -- one GIL-free call instead of one NumPy copy per utterance.  Returns the number of rows copied.
 int64_t xv_ark_gather_fm(const uint8_t *buf, const int64_t *data_off, const int32_t *rows, int cols, int n, float *dst)
 {
-    int64_t r = 0;
-    for (int i = 0; i < n; ++i) {
-        const size_t nbytes = (size_t)rows[i] * (size_t)cols * 4;
-        memcpy(dst + (size_t)r * cols, buf + data_off[i], nbytes);
-        r += rows[i];
+    std::vector<int64_t> first(n + 1, 0);                          // destination row of every record
+    for (int i = 0; i < n; ++i) first[i + 1] = first[i] + rows[i];
+    auto work = [&](int i0, int i1) {
+        for (int i = i0; i < i1; ++i)
+            memcpy(dst + (size_t)first[i] * cols, buf + data_off[i], (size_t)rows[i] * (size_t)cols * 4);
+    };
+    const size_t total = (size_t)first[n] * (size_t)cols * 4;
+    const int nt = total >= ((size_t)8 << 20) && n >= 64 ? 4 : 1;   // a scanner pass of 8192 utterances is ~230 MB
+    if (nt == 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
+        for (auto &th : pool) th.join();
     }
-    return r;
+    return first[n];
 }
 
 // Chunks must be given in ascending, non-overlapping dst_row order.  Columns [feat_dim, dst_ld) of dst are not touched (the
