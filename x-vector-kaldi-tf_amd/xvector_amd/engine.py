@@ -33,6 +33,8 @@ def _host_lib():
         lib = None
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "local", "tf", "libxvector_host.so")
         try:
+            if os.environ.get("XVECTOR_NO_HOST_LIB") == "1":
+                raise OSError("disabled")
             lib = ctypes.CDLL(path)
             lib.xv_pack_rows_f32.restype = ctypes.c_int
             lib.xv_pack_rows_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
