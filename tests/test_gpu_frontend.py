@@ -137,6 +137,8 @@ def test_device_front_end_path_equals_host_round_trip(tmp_path):
     bit-identical x-vectors to FrontEnd.apply + Extractor.extract (selected features through the host), across chunking,
     small batches that split utterances, VADs that drop utterances, missing VADs and an all-voiced window."""
     from xvector_amd import engine, frontend, synthetic, topology
+    if engine._host_lib() is None:
+        pytest.skip("libxvector_host.so disabled: make_embedding then takes the host round trip")
     topo = topology.get("ModelWithoutDropout")
     w = synthetic.trained_like(topo, 23, seed=3)
     model = engine.DeviceModel(w, topo, "cuda:0")
