@@ -49,10 +49,16 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 9). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 10). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
+/* Process-wide launch tuning (no TF counterpart; the analogue of the session's ConfigProto knobs,
+ * local/tf/models.py:361-363).  Results do not depend on any of these.
+ *   XV_TUNE_TILE_ROWS  rows per workgroup tile of the bf16x3 GEMM with split-format input: 128 (4 waves, two
+ *                      workgroups per CU), 256 (8 waves, one per CU), 0 = built-in choice. */
+#define XV_TUNE_TILE_ROWS 1
+int xv_set_tuning(int key, int value);
 
 /* One-off weight re-layout.  TF stores a conv kernel as w[K, Cin, Cout] == row-major [K*Cin, Cout]
  * (local/tf/models.py:56-57) and an FC weight as w[In, Out] (local/tf/models.py:83); the GEMM kernel
@@ -97,7 +103,7 @@ int xv_tdnn_layer_f32(const float *x, int64_t R, int cin, int ldx, const float *
 #define XV_FMT_F32 0
 #define XV_FMT_SPLIT 1
 #define XV_SPLIT_PAD_BEFORE 8
-#define XV_SPLIT_PAD_AFTER 136
+#define XV_SPLIT_PAD_AFTER 264
 size_t xv_packed_weights_bf16x3_bytes(int K, int cin, int cout);
 int xv_pack_weights_bf16x3(const float *w, int K, int cin, int cout, void *wt, void *stream);
 size_t xv_split_row_bytes(int channels);

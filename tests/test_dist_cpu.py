@@ -59,6 +59,66 @@ def test_two_rank_gloo_sharded_gather(tmp_path):
     assert "GATHER_OK 2" in outs[0]
 
 
+SKIP_WORKER = textwrap.dedent("""
+    import os, sys, logging, types
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from xvector_amd import dist as xdist
+    import models
+    rank, world = xdist.init_process_group("gloo")
+
+    class Stepper(object):            # stands in for trainer.Trainer: one collective per step, like the gradient all-reduce
+        device = "cpu"
+        def __init__(self): self.steps = []
+        def step(self, x, labels, lr, dp, seed):
+            t = torch.tensor([float(x[0, 0, 0])]); dist.all_reduce(t)
+            self.steps.append(t.item())
+            return 1.0, 0.5
+        def export(self): raise AssertionError("save_model is off")
+
+    class Loader(object):             # rank 1 has no batch at index 1 (None) and times out at index 3
+        count = 5
+        def __init__(self): self.i = -1
+        def pop(self, timeout=30):
+            import queue
+            self.i += 1
+            if rank == 1 and self.i == 1: return None, None
+            if rank == 1 and self.i == 3: raise queue.Empty()
+            return np.full((2, 7, 3), float(self.i + 1), np.float32), np.zeros(2, np.int32)
+
+    tr = Stepper()
+    models.Model._trainer = lambda self, d, lg: tr
+    logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%%(levelname)s %%(message)s")
+    args = types.SimpleNamespace(learning_rate=1e-3, print_interval=2, dropout_proportion=0.0, random_seed=0, input_dir="unused",
+                                 output_dir="unused", save_model=False)
+    models.Model().train_one_iteration(Loader(), args, logging.getLogger("skip"))
+    # both ranks stepped on indices 0, 2, 4 only, and every step paired batches of the SAME index (sum = 2 * (index + 1))
+    assert tr.steps == [2.0, 6.0, 10.0], tr.steps
+    dist.barrier()
+    print("SKIP_OK", rank)
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_gloo_training_skips_minibatches_together(tmp_path):
+    """A rank whose loader times out or yields None must not skip a step on its own: the gradient all-reduce of the other
+    rank would pair with a later step (or hang).  Model.train_one_iteration agrees on the skip with one MIN all-reduce."""
+    from conftest import TWIN
+    script = tmp_path / "skip_worker.py"
+    script.write_text(SKIP_WORKER % (PKG, TWIN))
+    port = 33000 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "SKIP_OK 0" in outs[0] and "SKIP_OK 1" in outs[1]
+    assert "skipped: another rank of the group has no batch" in outs[0]
+    assert "batch_data is None for the minibatch index 1" in outs[1] and "Timeout reach when reading the minibatch index 3" in outs[1]
+    assert "Overall average objective function is -0.6000 over 6 segments." in outs[0]      # 3 steps of loss 1.0 over 5 planned
+
+
 DRIVER_WORKER = textwrap.dedent("""
     import os, sys
     sys.path.insert(0, %r); sys.path.insert(0, %r)

@@ -156,6 +156,59 @@ def test_tdnn_layer_bf16x3_matches_oracle(env, cin, cout, K, dil, act, fmt):
     assert np.array_equal(alone[0], outs[2])
 
 
+@pytest.mark.parametrize("cin,cout,K,dil,act", [
+    (512, 512, 1, 1, "relu"),
+    (512, 1536, 1, 1, "relu"),
+    (512, 512, 3, 3, "relu"),
+    (512, 512, 5, 1, "prelu"),
+    (512, 512, 7, 1, "relu"),
+    (64, 200, 3, 1, "lrelu"),       # ragged Cout
+])
+def test_bf16x3_256_row_tiles_equal_128_row_tiles_bitwise(env, cin, cout, K, dil, act):
+    """XV_TUNE_TILE_ROWS: the 8-wave / 256-row workgroup tile accumulates every output element in the same order as the
+    4-wave / 128-row tile, so layer outputs and pooling block statistics must be bit-identical (and the 128-row form is
+    the one checked against the oracle above).  Row counts straddle tile boundaries (R % 256 in 1..255)."""
+    torch, hiplib, engine, dev = env["torch"], env["hiplib"], env["engine"], env["dev"]
+    rng = np.random.default_rng(cin + cout * 3 + K)
+    lens = [25, 1, 130, 257, 64, 3, 300, 511, 77]
+    mats = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in lens]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = None
+    if act == "lrelu":
+        alpha = np.array([0.2], np.float32)
+    elif act == "prelu":
+        alpha = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    layout = engine.BatchLayout(lens, max(1, (K - 1) * dil // 2), hiplib.POOL_BLOCK_ROWS)
+    host = np.zeros((layout.rows, cin), np.float32)
+    layout.pack(mats, host)
+    x = torch.from_numpy(host).to(dev)
+    rv = torch.from_numpy(layout.row_valid()).to(dev)
+    wp = hiplib.pack_weights_bf16x3(torch.from_numpy(w).to(dev))
+    scale, shift = hiplib.fold_bn(*(torch.from_numpy(a).to(dev) for a in bn), 1e-3)
+    al = None if alpha is None else torch.from_numpy(alpha).to(dev)
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+    bias = torch.from_numpy(b).to(dev)
+    xin = hiplib.SplitBuf(layout.rows, cin, dev)
+    hiplib.split_encode(x, xin)
+    got = {}
+    try:
+        for rows in (128, 256):
+            hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, rows)
+            yout = hiplib.SplitBuf(layout.rows, cout, dev)
+            hiplib.tdnn_layer(xin, wp, bias, scale, shift, code, al, K, dil, rv, yout, None, rows=layout.rows)
+            blk = torch.full((hiplib.block_stats_floats(layout.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
+            hiplib.tdnn_layer_pool(xin, layout.rows, wp, bias, scale, shift, code, al, dil, rv, blk)
+            torch.cuda.synchronize()
+            got[rows] = (hiplib.split_decode(yout, layout.rows).cpu().numpy(), blk.cpu().numpy())
+    finally:
+        hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
+    assert np.isfinite(got[256][0]).all() and np.abs(got[256][0]).max() > 0
+    assert np.array_equal(got[128][0], got[256][0])
+    assert np.array_equal(got[128][1], got[256][1], equal_nan=True)
+
+
 def test_split_format_roundtrip_and_layout(env):
     """xv_split_encode_f32 / xv_split_decode_f32 against a NumPy statement of the documented layout
     (include/xvector_hip.h): slot t = plane*4 + (k>>3) stored at t ^ ((r>>1)&7), value = hi + lo."""

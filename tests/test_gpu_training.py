@@ -42,6 +42,20 @@ def test_eval_batch_matches_oracle(env, cls):
     assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)) and acc == pytest.approx(ra)
 
 
+def test_out_of_range_labels_raise(env):
+    """The reference's create_one_hot_output_matrix raises IndexError for a label >= num_classes (models.py:164-169); the
+    twin must not hand such a label to the loss kernel (out-of-bounds device read, silently wrong loss)."""
+    topo, w, rng = _setup(env, "ModelWithoutDropout")
+    x = (rng.standard_normal((4, 30, 23)) * 3).astype(np.float32)
+    tr = env["trainer"].Trainer(w, topo)
+    for bad in ([0, 1, 10, 2], [0, -1, 3, 2], [0, 1, 2]):
+        with pytest.raises(IndexError):
+            tr.eval_batch(x, np.array(bad))
+        with pytest.raises(IndexError):
+            tr.step(x, np.array(bad), 1e-3)
+    assert tr.t == 0
+
+
 @pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelL2LossWithoutDropoutLRelu",
                                  "ModelWithoutDropoutPRelu", "ModelL2LossWithoutDropoutPRelu",
                                  "ModelL2LossWithoutDropoutLReluAttention"])

@@ -161,3 +161,87 @@ def test_bad_files_are_rejected(tmp_path):
     os.remove(str(p))
     with pytest.raises(IOError):
         wio.load_model_dir(str(tmp_path))
+
+
+def _tf_dir(tmp_path, class_written, meta_bytes, name_file=None, seed=5):
+    """A directory as the reference's Saver leaves it for a model of class ``class_written`` (default widths)."""
+    topo = topology.get(class_written)
+    w = synthetic.reference_init(topo, 23, 10, seed=seed)
+    nnet = tmp_path / ("nnet_%s_%d" % (class_written, len(list(tmp_path.iterdir()))))
+    mdir = nnet / "model_7"
+    mdir.mkdir(parents=True)
+    if name_file:
+        (nnet / "model_name.txt").write_text(name_file + "\n")
+    (mdir / "model.meta").write_bytes(meta_bytes)
+    (mdir / "done").write_text("done")
+    write_bundle(str(mdir / "model"), _tf_style_arrays(w))
+    return str(mdir), w
+
+
+GRAPH_RELU = b"\x0a\x10frame_level_info_layer-0/conv1d\x12\x06Conv2D\x0a\x04Relu"
+GRAPH_LRELU = GRAPH_RELU + b"\x0a\x09LeakyRelu"
+
+
+def test_wrong_or_missing_model_class_is_refused(tmp_path, monkeypatch, caplog):
+    """A PReLU / LeakyReLU / attention checkpoint has the conv shapes of the default class: loading it as ReLU would give
+    wrong x-vectors silently.  Stray variables are refused, the graph decides ReLU vs LeakyReLU, and without any stated
+    class and without a graph nothing is guessed."""
+    monkeypatch.delenv("XVECTOR_MODEL_CLASS", raising=False)
+    # PReLU checkpoint, directory claims the default class -> stray prelu variables
+    d, _ = _tf_dir(tmp_path, "ModelWithoutDropoutPRelu", GRAPH_RELU, name_file="ModelWithoutDropout")
+    with pytest.raises(ValueError, match="does not define"):
+        wio.load_model_dir(d)
+    # same checkpoint, class stated by the environment -> fine
+    monkeypatch.setenv("XVECTOR_MODEL_CLASS", "ModelWithoutDropoutPRelu")
+    got, meta = wio.load_model_dir(d)
+    assert meta["topology"]["activation"] == "prelu" and "frame_level_info_layer-3/prelu/prelu:0" in got
+    monkeypatch.delenv("XVECTOR_MODEL_CLASS")
+    # LeakyReLU checkpoint claimed to be ReLU: only the graph shows it
+    d, _ = _tf_dir(tmp_path, "ModelL2LossWithoutDropoutLRelu", GRAPH_LRELU, name_file="ModelWithoutDropout")
+    with pytest.raises(ValueError, match="LeakyRelu"):
+        wio.load_model_dir(d)
+    d, _ = _tf_dir(tmp_path, "ModelWithoutDropout", GRAPH_RELU, name_file="ModelL2LossWithoutDropoutLRelu")
+    with pytest.raises(ValueError, match="LeakyRelu"):
+        wio.load_model_dir(d)
+    # no class stated: the checkpoint's own evidence picks it (and says so) ...
+    d, _ = _tf_dir(tmp_path, "ModelL2LossWithoutDropoutLRelu", GRAPH_LRELU)
+    with caplog.at_level("WARNING"):
+        _, meta = wio.load_model_dir(d)
+    assert meta["topology"]["activation"] == "lrelu" and "inferred from the checkpoint" in caplog.text
+    d, _ = _tf_dir(tmp_path, "ModelWithoutDropoutTdnn", GRAPH_RELU)
+    assert wio.load_model_dir(d)[1]["topology"]["dilations"] == [1, 2, 3, 1, 1]
+    d, _ = _tf_dir(tmp_path, "ModelL2LossWithoutDropoutLReluAttention", GRAPH_LRELU)
+    assert wio.load_model_dir(d)[1]["topology"]["pooling"] == "attention"
+    # ... unless there is no graph to tell ReLU from LeakyReLU
+    d, _ = _tf_dir(tmp_path, "ModelWithoutDropout", b"\x0a\x03abc")
+    with pytest.raises(ValueError, match="refusing to guess"):
+        wio.load_model_dir(d)
+
+
+def test_adam_slots_of_a_tf_checkpoint_resume(tmp_path):
+    """<var>/Adam, <var>/Adam_1 and beta1_power of a reference-written checkpoint become the optimizer state the trainer
+    resumes from (the reference's Saver.restore does the same, models.py:232-236)."""
+    topo = topology.get("ModelWithoutDropout")
+    w = synthetic.reference_init(topo, 23, 10, seed=2)
+    arrays = {k[:-2]: v for k, v in w.items()}
+    rng = np.random.default_rng(0)
+    for k in list(arrays):
+        if k.rsplit("/", 1)[-1] in ("w", "b", "gamma", "beta"):
+            arrays[k + "/Adam"] = rng.standard_normal(arrays[k].shape).astype(np.float32)
+            arrays[k + "/Adam_1"] = rng.random(arrays[k].shape).astype(np.float32)
+    arrays["beta1_power"] = np.array(0.9 ** 37, np.float32)
+    arrays["beta2_power"] = np.array(0.999 ** 37, np.float32)
+    mdir = tmp_path / "model_3"
+    mdir.mkdir()
+    (mdir / "model.meta").write_bytes(GRAPH_RELU)
+    (mdir / "done").write_text("done")
+    (mdir / "model_name.txt").write_text("ModelWithoutDropout")
+    write_bundle(str(mdir / "model"), arrays)
+    adam = wio.load_optimizer_state(str(mdir))
+    assert adam["t"] == 37
+    assert np.array_equal(adam["m"]["embed_layer-0/w:0"], arrays["embed_layer-0/w/Adam"])
+    assert np.array_equal(adam["v"]["frame_level_info_layer-2/gamma:0"], arrays["frame_level_info_layer-2/gamma/Adam_1"])
+    assert set(adam["m"]) == set(adam["v"]) == {k + ":0" for k in arrays if k + "/Adam" in arrays}
+    # a model written before the first step has no slots: fresh optimizer
+    write_bundle(str(mdir / "model"), {k[:-2]: v for k, v in w.items()})
+    assert wio.load_optimizer_state(str(mdir)) is None

@@ -308,12 +308,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SROW = 128;                         // bytes per (row, 32-channel slab): LDS A row and HBM split row-slab
-constexpr int A3_BYTES = A_ROWS * SROW;           // 17408
 constexpr int B3_PLANE = BN * 64;                 // 8192
 constexpr int B3_BYTES = 2 * B3_PLANE;            // 16384: [hi tile][lo tile]
 constexpr int T_LD = BN + 4;                      // epilogue fp32 tile row (floats)
-constexpr size_t GEMM3_LDS_BYTES = (size_t)2 * A3_BYTES + 2 * B3_BYTES + BM + 4 * BN * sizeof(float);   // + row mask + epilogue params
-static_assert((size_t)BM * T_LD * 4 <= (size_t)2 * A3_BYTES + 2 * B3_BYTES, "epilogue tile must fit below the row mask");
+// Workgroup geometry of the bf16x3 kernel: WM x 2 waves, each wave a 64 x 64 sub-tile (2 x 2 MFMA tiles) -> tile of
+// WM*64 rows x 128 columns.  WM = 2: 4 waves, 128-row tile, 69.7 KB of LDS, two workgroups per CU.  WM = 4: 8 waves,
+// 256-row tile, one workgroup per CU (same waves per SIMD): a weight tile feeds twice the MFMAs, i.e. half the
+// global->LDS weight bytes per FLOP.  LDS: [operand buffers | epilogue fp32 tile (aliased)] [row mask] [epilogue params].
+constexpr int gemm3_oper_bytes(int wm) { return 2 * (wm * 64 + MAX_SPAN) * SROW + 2 * B3_BYTES; }
+constexpr int gemm3_tile_bytes(int wm) { return wm * 64 * T_LD * 4; }
+constexpr int gemm3_mask_off(int wm) { return gemm3_oper_bytes(wm) > gemm3_tile_bytes(wm) ? gemm3_oper_bytes(wm) : gemm3_tile_bytes(wm); }
+constexpr size_t gemm3_lds_bytes(int wm) { return (size_t)gemm3_mask_off(wm) + wm * 64 + 4 * BN * sizeof(float); }
 
 // f(integral_constant<int, T>) for T = T0 .. KT-1, unrolled at compile time
 template <int T, int KT, class F>
@@ -359,14 +364,20 @@ struct Gemm3Params {
 // the current slab, PW pieces per wave per tap (K=1: 4 -- every stage loads its own slab --, K=3: 3, K=5: 2, K=7: 1).
 // POOL: the layer output is not stored; the epilogue reduces every 8-row block of the tile to per-channel (mean, M2)
 // for the statistics pooling that follows the last frame-level layer (see stats_pool_blocks_kernel).
-template <bool SPLIT_A, int KT, bool POOL>
-__global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)
+template <bool SPLIT_A, int KT, bool POOL, int WM>
+__global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)
 {
+    constexpr int NW = 2 * WM;                         // waves per workgroup
+    constexpr int NT = NW * 64;                        // threads (shadows the file-scope constant of the fp32 kernel)
+    constexpr int BM = WM * 64;                        // rows per workgroup tile
+    constexpr int A_ROWS = BM + MAX_SPAN;
+    constexpr int A3_BYTES = A_ROWS * SROW;
+    constexpr int BP = 16 / NW;                        // 1 KB pieces of a 16 KB weight tile per wave
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *Abuf = lds;                                  // [2][A_ROWS][128 B]
     char *Bbuf = lds + 2 * A3_BYTES;                   // [2][hi 8 KB | lo 8 KB]
-    uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + 2 * A3_BYTES + 2 * B3_BYTES);
-    float *Ps = reinterpret_cast<float *>(lds + 2 * A3_BYTES + 2 * B3_BYTES + BM);
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + gemm3_mask_off(WM));
+    float *Ps = reinterpret_cast<float *>(lds + gemm3_mask_off(WM) + BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -410,11 +421,11 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     }
 
     // ---- B: one 16 KB tile per stage, 4 x 1 KB DMA pieces per wave ---------------------------------------
-    const uint8_t *bsrc = p.wt + (size_t)nt * n_stages * B3_BYTES + wave * 4096 + lane * 16;
+    const uint8_t *bsrc = p.wt + (size_t)nt * n_stages * B3_BYTES + wave * (BP * 1024) + lane * 16;
     auto dma_b = [&](int buf) {
-        char *dst = Bbuf + buf * B3_BYTES + wave * 4096;
+        char *dst = Bbuf + buf * B3_BYTES + wave * (BP * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) XV_GLDS16(bsrc + j * 1024, dst + j * 1024);
+        for (int j = 0; j < BP; ++j) XV_GLDS16(bsrc + j * 1024, dst + j * 1024);
         bsrc += B3_BYTES;
     };
 
@@ -423,13 +434,13 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     const uint8_t *asrc = nullptr;
     if constexpr (SPLIT_A)
         asrc = reinterpret_cast<const uint8_t *>(p.x) + (m0 - left + wave * 8 + (lane >> 3)) * (long)xrow_bytes + (lane & 7) * 16;
-    const int n_pieces = (rowsA + 7) >> 3;             // <= 17
+    const int n_pieces = (rowsA + 7) >> 3;             // <= BM/8 + 1
     auto dma_a = [&](int buf) {
         char *dst = Abuf + buf * A3_BYTES + wave * 1024;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int piece = wave + 4 * j;
-            if (piece < n_pieces) XV_GLDS16(asrc + (size_t)(32 * j) * xrow_bytes, dst + j * 4096);
+            const int piece = wave + NW * j;
+            if (piece < n_pieces) XV_GLDS16(asrc + (size_t)(8 * NW * j) * xrow_bytes, dst + j * (NW * 1024));
         }
         asrc += SROW;                                   // next 32-channel slab
     };
@@ -544,9 +555,15 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
         // Straight-line iteration body (no branches): DMA is issued unconditionally (clamped at the tail, where it
         // rewrites identical bytes), so that sched_group_barrier can interleave every memory instruction with the
         // MFMAs of the same wave: the wave overlaps its own memory issue instead of relying on the co-resident block.
-        constexpr int PW = KT == 1 ? 4 : KT == 3 ? 3 : KT == 5 ? 2 : 1;
-        constexpr int NP = KT == 1 ? 16 : 17;               // pieces of a halo tile: 128 + (K-1)*dil rows, (K-1)*dil in 2..8
+        constexpr int NP = KT == 1 ? BM / 8 : BM / 8 + 1;   // pieces of a halo tile: BM + (K-1)*dil rows, (K-1)*dil in 2..8
         constexpr int DT = KT == 1 ? 1 : KT - 1;            // taps that carry A pieces
+        // a "slot" = one piece per wave; the NS slots a halo tile needs are dealt to the taps as evenly as possible,
+        // early taps first (K=7: 1,1,1,1,1,0  K=5: 2,1,1,1  K=3: 3,2  K=1: 4), so that at most NW-1 pieces per slab are
+        // clamped duplicates
+        constexpr int NS = (NP + NW - 1) / NW;
+        constexpr int PW = (NS + DT - 1) / DT;              // most slots any tap carries
+        auto slots_of = [](int t) constexpr { return t < DT ? (NS + DT - 1 - t) / DT : 0; };
+        auto slot_base = [](int t) constexpr { int b = 0; for (int u = 0; u < t; ++u) b += (NS + DT - 1 - u) / DT; return b; };
         // per-tap, per-lane fragment row offset in A buffer 0 with the slot swizzle and the lane's k-half folded in:
         // the 16-B slot T of a row sits at ((T ^ sw) << 4), T = ks*2 + kh (+4 for lo)  ->  pa ^ (ks << 5) ^ (lo << 6)
         int pa[KT];
@@ -566,7 +583,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
         for (int t = 0; t < DT; ++t)
 #pragma unroll
             for (int j = 0; j < PW; ++j) {
-                int piece = (t * 4 + wave) * PW + j;
+                int piece = (slot_base(t) + j) * NW + wave;      // slots beyond slots_of(t) are never issued
                 piece = piece < NP ? piece : NP - 1;
                 ag_off[t][j] = (uint32_t)piece * rowstep;
                 al_off[t][j] = (uint32_t)piece * 1024u;
@@ -615,11 +632,13 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
                 __syncthreads();                  // B(s): stage s fully read by everybody, stage s+1 landed
                 // ---- phase 2: DMA(s+2), F <- LDS(stage s+1, k-step 0), 12 MFMAs on G --------------------------------
                 {
-                    char *dst = Bbuf + bbuf + wave * 4096;           // one M0; the immediate advances source AND destination
+                    char *dst = Bbuf + bbuf + wave * (BP * 1024);    // one M0; the immediate advances source AND destination
                     XV_GLDS16_OFF(bnext, dst, 0);
                     XV_GLDS16_OFF(bnext, dst, 1024);
-                    XV_GLDS16_OFF(bnext, dst, 2048);
-                    XV_GLDS16_OFF(bnext, dst, 3072);
+                    if constexpr (BP == 4) {
+                        XV_GLDS16_OFF(bnext, dst, 2048);
+                        XV_GLDS16_OFF(bnext, dst, 3072);
+                    }
                     bnext += (s + 3 < n_stages) ? B3_BYTES : 0;
                 }
                 if constexpr (KT == 1) {
@@ -631,13 +650,13 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
                     for (int j = 0; j < PW; ++j) XV_GLDS16(ag + ag_off[0][j], adst + al_off[0][j]);
                 } else if constexpr (t < KT - 1) {
 #pragma unroll
-                    for (int j = 0; j < PW; ++j) XV_GLDS16(anext + ag_off[t][j], adst_n + al_off[t][j]);
+                    for (int j = 0; j < slots_of(t); ++j) XV_GLDS16(anext + ag_off[t][j], adst_n + al_off[t][j]);
                 }
                 if constexpr (t + 1 < KT) load_a_frags(F, pa[t + 1] + abuf, 0);
                 else load_a_frags(F, pa[0] + abuf_n, 0);             // first tap of the next slab (tail: harmless read)
                 load_b_frags(F, pb[0] + (B3_BYTES - bbuf));
                 mma(G);
-                constexpr int NV = (KT == 1 || t < KT - 1) ? 4 + PW : 4;
+                constexpr int NV = BP + (KT == 1 ? PW : slots_of(t));
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
@@ -789,7 +808,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
         float keep[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int lr = (tid >> 4) + 16 * j;
+            const int lr = (tid >> 4) + (NT / 16) * j;
             tv[j][0] = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8);
             tv[j][1] = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8 + 4);
             keep[j] = Ms[lr] ? 1.f : 0.f;
@@ -802,7 +821,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
             constexpr int mode = decltype(MODE)::value;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const long gr = m0 + (tid >> 4) + 16 * j;
+                const long gr = m0 + (tid >> 4) + (NT / 16) * j;
                 bf16x8 hi, lo;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -831,7 +850,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int lr = (tid >> 4) + 16 * j;
+        const int lr = (tid >> 4) + (NT / 16) * j;
         const long gr = m0 + lr;
         if (gr >= p.R) continue;
         const f32x4 t0 = *reinterpret_cast<const f32x4 *>(T + lr * T_LD + cg * 8);
@@ -885,6 +904,32 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Para
     }
 }
 
+typedef void (*gemm3_fn)(const Gemm3Params);
+struct Gemm3Kernel {
+    int kt;       // 0: fp32-row input (runtime K), else the compile-time kernel size of the split-input path
+    bool pool;
+    int wm;
+    gemm3_fn fn;
+};
+#define XV_G3(SPLIT, KT, POOL, WM) {KT, POOL, WM, tdnn_gemm_bf16x3_kernel<SPLIT, KT, POOL, WM>}
+const Gemm3Kernel GEMM3_KERNELS[] = {
+    XV_G3(false, 0, false, 2), XV_G3(false, 0, true, 2),
+    XV_G3(true, 1, false, 2), XV_G3(true, 3, false, 2), XV_G3(true, 5, false, 2), XV_G3(true, 7, false, 2),
+    XV_G3(true, 1, true, 2),  XV_G3(true, 3, true, 2),  XV_G3(true, 5, true, 2),  XV_G3(true, 7, true, 2),
+    XV_G3(true, 1, false, 4), XV_G3(true, 3, false, 4), XV_G3(true, 5, false, 4), XV_G3(true, 7, false, 4),
+    XV_G3(true, 1, true, 4),  XV_G3(true, 3, true, 4),  XV_G3(true, 5, true, 4),  XV_G3(true, 7, true, 4),
+};
+#undef XV_G3
+const Gemm3Kernel *find_gemm3(int kt, bool pool, int wm)
+{
+    for (const Gemm3Kernel &e : GEMM3_KERNELS)
+        if (e.kt == kt && e.pool == pool && e.wm == wm) return &e;
+    return nullptr;
+}
+
+// tuning knobs (xv_set_tuning); 0 = built-in choice
+std::atomic<int> g_tile_rows{0};
+
 int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
 {
     Gemm3Params p = p0;
@@ -911,10 +956,7 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
     }
     if (p.ypre && (p.ldpre < p.cout || (((uintptr_t)p.ypre) & 15))) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: bad y_preact");
     if (((uintptr_t)p.wt) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3: packed weights must be 16-byte aligned");
-    p.n_mt = (int)((p.R + BM - 1) / BM);
     p.n_nt = (p.cout + BN - 1) / BN;
-    typedef void (*kern_t)(const Gemm3Params);
-    kern_t kern;
     int kt = 0;
     if (p.x_split) {
         kt = p.K;
@@ -922,32 +964,32 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
         if ((kt != 1 && kt != 3 && kt != 5 && kt != 7) || (kt > 1 && (span < 2 || span > MAX_SPAN)))
             return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: split-format input supports K in {1,3,5,7} with (K-1)*dilation <= 8");
     }
-    if (p.blk) {
-        kern = kt == 0 ? tdnn_gemm_bf16x3_kernel<false, 0, true> : kt == 1 ? tdnn_gemm_bf16x3_kernel<true, 1, true>
-             : kt == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, true> : kt == 5 ? tdnn_gemm_bf16x3_kernel<true, 5, true>
-             : tdnn_gemm_bf16x3_kernel<true, 7, true>;
-    } else {
-        kern = kt == 0 ? tdnn_gemm_bf16x3_kernel<false, 0, false> : kt == 1 ? tdnn_gemm_bf16x3_kernel<true, 1, false>
-             : kt == 3 ? tdnn_gemm_bf16x3_kernel<true, 3, false> : kt == 5 ? tdnn_gemm_bf16x3_kernel<true, 5, false>
-             : tdnn_gemm_bf16x3_kernel<true, 7, false>;
+    // workgroup tile: 256 rows (8 waves, one workgroup per CU) for the wide-context layers when the input is in the split
+    // format and there are enough rows to fill the chip with such tiles, else 128 rows (4 waves, two per CU);
+    // xv_set_tuning(XV_TUNE_TILE_ROWS) overrides
+    int wm = 2;
+    if (p.x_split) {
+        const int want = g_tile_rows.load(std::memory_order_relaxed);
+        // measured on 262144-row batches (tools/layer_bench.py, profiles/r02a_layer_tile.txt): K = 7 +2.7 %, K = 5 +1.2 %,
+        // K = 1 -1.5 ... -3.5 % (with one workgroup per CU the prologue and epilogue of a 16-stage tile are exposed)
+        const bool big_enough = ((p.R + 255) / 256) * p.n_nt >= 512;          // two rounds of 256 CUs
+        if (want == 256 || (want == 0 && p.K >= 5 && big_enough)) wm = 4;
     }
+    p.n_mt = (int)((p.R + wm * 64 - 1) / (wm * 64));
+    const Gemm3Kernel *k = find_gemm3(kt, p.blk != nullptr, wm);
+    if (!k) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: no kernel for this configuration");
     // the dynamic-LDS opt-in is per device and idempotent: one bit per device id, set after the first successful pass
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        const kern_t all[] = {tdnn_gemm_bf16x3_kernel<false, 0, false>, tdnn_gemm_bf16x3_kernel<true, 1, false>,
-                              tdnn_gemm_bf16x3_kernel<true, 3, false>, tdnn_gemm_bf16x3_kernel<true, 5, false>,
-                              tdnn_gemm_bf16x3_kernel<true, 7, false>, tdnn_gemm_bf16x3_kernel<false, 0, true>,
-                              tdnn_gemm_bf16x3_kernel<true, 1, true>, tdnn_gemm_bf16x3_kernel<true, 3, true>,
-                              tdnn_gemm_bf16x3_kernel<true, 5, true>, tdnn_gemm_bf16x3_kernel<true, 7, true>};
-        for (kern_t k : all) {
-            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM3_LDS_BYTES);
-            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        for (const Gemm3Kernel &e : GEMM3_KERNELS) {
+            hipError_t err = hipFuncSetAttribute((const void *)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm3_lds_bytes(e.wm));
+            if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute");
         }
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(NT), GEMM3_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(k->fn, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(wm * 128), gemm3_lds_bytes(wm), st, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_bf16x3_kernel launch");
 }
@@ -1283,7 +1325,19 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 9; }
+int xv_version(void) { return 10; }
+
+int xv_set_tuning(int key, int value)
+{
+    switch (key) {
+    case XV_TUNE_TILE_ROWS:
+        if (value != 0 && value != 128 && value != 256) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: tile rows must be 0, 128 or 256");
+        g_tile_rows.store(value, std::memory_order_relaxed);
+        return 0;
+    default:
+        return fail(XV_ERR_BAD_ARG, "xv_set_tuning: unknown key");
+    }
+}
 
 const char *xv_last_error(void) { return g_err; }
 

@@ -51,8 +51,9 @@ def eval_dnn(args):
 
 
 def main(argv=None):
+    args = get_args(argv)          # outside the try, as in the reference: --help / usage errors exit through argparse
     try:
-        eval_dnn(get_args(argv))
+        eval_dnn(args)
     except KeyboardInterrupt:
         sys.exit(1)
     except BaseException:

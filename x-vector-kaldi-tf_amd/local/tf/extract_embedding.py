@@ -256,8 +256,9 @@ def _gather_and_write(model, collector, wspecifier, ark, scp, rank, world):
 
 
 def main(argv=None):
+    args = get_args(argv)          # outside the try, as in the reference: --help / usage errors exit through argparse
     try:
-        eval_dnn(get_args(argv))
+        eval_dnn(args)
     except BaseException as e:
         if not isinstance(e, KeyboardInterrupt):
             traceback.print_exc()

@@ -134,80 +134,64 @@ class Model(object):
         return tr
 
     @staticmethod
-    def _pop(data_loader, minibatch_idx, logger, what):
+    def _next_batch(data_loader, index, logger, what, meter):
+        """One ``data_loader.pop()`` (examples_io.py:213-221,252-255) with the reference's two tolerated failures -- a
+        ``queue.Empty`` timeout and a ``None`` batch (models.py:244-253): both are logged and reported as "no batch"."""
         import queue
+        t0 = time.time()
         try:
-            batch_data, labels = data_loader.pop()
-        except queue.Empty:                                        # models.py:248-250
-            logger.warning('Timeout reach when reading %s %d' % (what, minibatch_idx))
-            return None, None
-        if batch_data is None:                                     # models.py:251-253
-            logger.warning('batch_data is None for %s %d' % (what, minibatch_idx))
-        return batch_data, labels
+            batch, labels = data_loader.pop()
+        except queue.Empty:
+            logger.warning('Timeout reach when reading %s %d' % (what, index))
+            batch, labels = None, None
+        else:
+            if batch is None:
+                logger.warning('batch_data is None for %s %d' % (what, index))
+        meter.waited("disk", time.time() - t0)
+        return batch, labels
+
+    @staticmethod
+    def _everyone_has(batch, device):
+        """Data-parallel runs only: every optimizer step is a collective (Trainer.step all-reduces the gradient), so a
+        rank may not skip a minibatch on its own.  The decision is made together -- one MIN all-reduce of a "have a
+        batch" flag -- and either every rank steps or every rank skips (its batch, if it had one, is dropped)."""
+        import torch.distributed as dist
+        have = batch is not None
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return have
+        import torch
+        on_gpu = dist.get_backend() == "nccl"
+        flag = torch.tensor([1 if have else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
     def train_one_iteration(self, data_loader, args, logger):
         """Twin of models.py:216-305: one pass over ``data_loader`` (``.count`` minibatches of ``[B,T,F]`` float16/32 +
         int labels), Adam with ``args.learning_rate``, then the model (and the optimizer slots) are saved to
         ``args.output_dir``.  Reads the same ``args`` fields as the reference (learning_rate, print_interval,
         dropout_proportion, input_dir, output_dir, random_seed) and prints the same log lines (they are regex-parsed by
-        ze_utils.py:126-127,498-499)."""
-        learning_rate = args.learning_rate
-        print_interval = args.print_interval
-        dropout_proportion = float(getattr(args, "dropout_proportion", 0.0) or 0.0)     # keep_prob = 1 - this, models.py:258
-        random_seed = int(getattr(args, "random_seed", 0) or 0)                          # models.py:223,233
+        ze_utils.py:126-127,498-499); the running averages behind those lines live in ``runstats.Meter``."""
+        from xvector_amd import runstats
+        keep_out = float(getattr(args, "dropout_proportion", 0.0) or 0.0)      # keep_prob = 1 - this, models.py:258
+        seed = int(getattr(args, "random_seed", 0) or 0)                       # models.py:223,233
         tr = self._trainer(args.input_dir, logger)
-        minibatch_count = data_loader.count
-        start_minibatch = 1
-        total_segments, minibatch_segments = 0, 0
-        total_loss, minibatch_loss = 0, 0
-        total_objective, minibatch_objective = 0, 0
-        total_accuracy, minibatch_accuracy = 0, 0
-        total_segments_len = 0
-        total_gpu_waiting = 0.0
-        total_disk_waiting = 0.0
-        start_time = time.time()
-        for minibatch_idx in range(minibatch_count):
-            disk_waiting = time.time()
-            batch_data, labels = self._pop(data_loader, minibatch_idx, logger, 'the minibatch index')
-            total_disk_waiting += time.time() - disk_waiting
-            if batch_data is None:
-                continue
-            minibatch_segments += batch_data.shape[0]
-            total_segments += batch_data.shape[0]
-            total_segments_len += batch_data.shape[1]
-            gpu_waiting = time.time()
-            loss, accuracy = tr.step(batch_data, labels, learning_rate, dropout_proportion, random_seed)
-            total_gpu_waiting += time.time() - gpu_waiting
-            objective = -loss
-            total_loss += loss
-            minibatch_loss += loss
-            total_objective += objective
-            minibatch_objective += objective
-            total_accuracy += accuracy
-            minibatch_accuracy += accuracy
-            end_minibatch = minibatch_idx + 1
-            if end_minibatch % print_interval == 0:
-                cnt = end_minibatch - start_minibatch + 1
-                logger.info("Average training loss for minibatches %d-%d is %.4f over %d segments. Also, the "
-                            "average training accuracy for these minibatches is %.4f and the average "
-                            "objective function for these minibatches is %.4f. Average DISK waiting: %.1f "
-                            "secs and average GPU waiting: %.1f secs for each minibatch." %
-                            (start_minibatch, end_minibatch, minibatch_loss / cnt, minibatch_segments, minibatch_accuracy / cnt,
-                             minibatch_objective / cnt, total_disk_waiting / cnt, total_gpu_waiting / cnt))
-                start_minibatch = end_minibatch + 1
-                minibatch_segments = 0
-                minibatch_loss = 0
-                minibatch_accuracy = 0
-                minibatch_objective = 0
-                total_gpu_waiting = 0.0
-                total_disk_waiting = 0.0
-        logger.info("Processed %d segments of average size %d into %d minibatches. Avg minibatch size was %d." %
-                    (total_segments, total_segments_len / minibatch_count, minibatch_count, total_segments / minibatch_count))
-        logger.info("Overall average training loss is %.4f over %d segments. Also, the overall "
-                    "average training accuracy is %.4f." % (total_loss / minibatch_count, total_segments,
-                                                            total_accuracy / minibatch_count))
-        logger.info("Overall average objective function is %.4f over %d segments." %
-                    (total_objective / minibatch_count, total_segments))
+        meter = runstats.Meter(planned=data_loader.count, report_every=args.print_interval)
+        for index in range(data_loader.count):
+            batch, labels = self._next_batch(data_loader, index, logger, 'the minibatch index', meter)
+            if not self._everyone_has(batch, getattr(tr, 'device', 'cpu')):
+                if batch is not None:
+                    logger.warning('minibatch index %d skipped: another rank of the group has no batch' % index)
+                meter.skipped(index)
+            else:
+                t0 = time.time()
+                loss, accuracy = tr.step(batch, labels, args.learning_rate, keep_out, seed)
+                meter.waited("gpu", time.time() - t0)
+                meter.stepped(index, batch.shape[0], batch.shape[1], loss, accuracy)
+            line = meter.interval_line(index)
+            if line:
+                logger.info(line)
+        for line in meter.training_summary():
+            logger.info(line)
         if getattr(args, "save_model", True):          # data-parallel driver (train_dnn.py): only one rank of the group writes
             w, adam = tr.export()
             # optimizer slots first, the model (whose 'done' marker completes the directory) last
@@ -215,33 +199,22 @@ class Model(object):
             wio.save_optimizer_state(args.output_dir, adam)
             self.save_model(dict(weights=w, topology=self.meta["topology"], model_class=self.meta["model_class"],
                                  num_classes=self.meta["num_classes"], feat_dim=self.meta["feat_dim"]), args.output_dir, logger)
-        logger.info("Elapsed time for processing whole training minibatches is %.2f minutes." %
-                    ((time.time() - start_time) / 60.0))
+        logger.info(meter.elapsed_line())
 
     def eval(self, data_loader, input_dir, use_gpu, logger):
         """Twin of models.py:307-354: loss / accuracy over ``data_loader`` in the eval phase (moving BN statistics)."""
+        from xvector_amd import runstats
         tr = self._trainer(input_dir, logger)
-        minibatch_count = data_loader.count
-        total_segments = 0
-        total_loss = 0
-        total_accuracy = 0
-        total_segments_len = 0
-        start_time = time.time()
-        for minibatch_idx in range(minibatch_count):
-            batch_data, labels = self._pop(data_loader, minibatch_idx, logger, 'minibatch index')
-            if batch_data is None:
+        meter = runstats.Meter(planned=data_loader.count)
+        for index in range(data_loader.count):
+            batch, labels = self._next_batch(data_loader, index, logger, 'minibatch index', meter)
+            if batch is None:
                 continue
-            total_segments += batch_data.shape[0]
-            total_segments_len += batch_data.shape[1]
-            loss, accuracy = tr.eval_batch(batch_data, labels)
-            total_loss += loss
-            total_accuracy += accuracy
-        logger.info("Processed %d segments of average size %d into %d minibatches. Avg minibatch size was %d." %
-                    (total_segments, total_segments_len / minibatch_count, minibatch_count, total_segments / minibatch_count))
-        logger.info("Overall average loss is %.4f over %d segments. Also, the overall "
-                    "average accuracy is %.4f." % (total_loss / minibatch_count, total_segments, total_accuracy / minibatch_count))
-        logger.info("Elapsed time for processing whole training minibatches is %.2f minutes." %
-                    ((time.time() - start_time) / 60.0))
+            loss, accuracy = tr.eval_batch(batch, labels)
+            meter.stepped(index, batch.shape[0], batch.shape[1], loss, accuracy)
+        for line in meter.eval_summary():
+            logger.info(line)
+        logger.info(meter.elapsed_line())
 
     # -- the hot path ------------------------------------------------------------------------------
     def make_embedding(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger,

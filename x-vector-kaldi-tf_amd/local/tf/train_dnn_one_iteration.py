@@ -119,8 +119,9 @@ def train(args):
 
 
 def main(argv=None):
+    args = get_args(argv)          # outside the try, as in the reference: --help / usage errors exit through argparse
     try:
-        train(get_args(argv))
+        train(args)
     except BaseException as e:
         if not isinstance(e, KeyboardInterrupt):
             traceback.print_exc()

@@ -10,10 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
-SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
+SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
            "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32",
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_split_row_bytes", "xv_split_encode_f32",
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
@@ -30,7 +30,8 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_pack_weights_f32", "xv_fold_bn_f32
            "xv_attention_pool_backward_f32", "xv_attention_softmax_backward_f32", "xv_attention_scores_backward_f32")
 
 FMT_F32, FMT_SPLIT = 0, 1
-SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 136
+SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 264
+TUNE_TILE_ROWS = 1
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
@@ -56,6 +57,8 @@ def load():
     lib.xv_version.argtypes = []
     lib.xv_last_error.restype = ctypes.c_char_p
     lib.xv_last_error.argtypes = []
+    lib.xv_set_tuning.restype = ci
+    lib.xv_set_tuning.argtypes = [ci, ci]
     lib.xv_pack_weights_f32.restype = ci
     lib.xv_pack_weights_f32.argtypes = [vp, ci, ci, vp, vp]
     lib.xv_fold_bn_f32.restype = ci
@@ -160,6 +163,12 @@ def require_gpu():
         raise XvectorHipError("no MI355X visible (torch.cuda.is_available() is False): the x-vector hot path "
                               "has no CPU fallback")
     return lib
+
+
+def set_tuning(key, value):
+    """Process-wide launch tuning (``TUNE_*`` keys of the header); never changes results."""
+    lib = load()
+    _check(lib.xv_set_tuning(int(key), int(value)), "xv_set_tuning")
 
 
 def _check(rc, what):

@@ -193,8 +193,8 @@ def read_bundle(prefix):
 
 
 def guess_class_name(model_dir):
-    """The driver writes the class name to <nnet_dir>/model_name.txt (train_dnn.py:495); model dirs are its
-    children (model_0, model_final, ...).  XVECTOR_MODEL_CLASS overrides."""
+    """The class name a deployment states: XVECTOR_MODEL_CLASS, else <nnet_dir>/model_name.txt, which the driver writes
+    (train_dnn.py:495; model dirs are its children model_0, model_final, ...).  None when neither exists."""
     env = os.environ.get("XVECTOR_MODEL_CLASS")
     if env:
         return env
@@ -204,17 +204,65 @@ def guess_class_name(model_dir):
             name = open(p).read().strip()
             if name:
                 return name
-    return "ModelWithoutDropout"                        # the class the reference recipe trains (run_xvector.sh:90)
+    return None
+
+
+def _is_slot(name):
+    """Adam slots / power accumulators tf.train.AdamOptimizer adds to the checkpoint (models.py:112,134-137)."""
+    return name.endswith("/Adam") or name.endswith("/Adam_1") or name in ("beta1_power", "beta2_power")
+
+
+def extraction_signature(topo):
+    """What of a topology changes the x-vector: everything else (dropout, L2 penalty, initialiser, head) is training-only."""
+    return (tuple(topo["kernel_sizes"]), tuple(topo["layer_sizes"]), tuple(topo["embedding_sizes"]),
+            topo.get("activation", "relu"), topo.get("pooling", "stats"))
+
+
+def infer_signature(arrays, metagraph=b""):
+    """The same tuple read off a checkpoint: kernel sizes / widths from the variable shapes, PReLU and attention from their
+    variables, LeakyReLU from the op / name-scope token ``LeakyRelu`` that ``tf.nn.leaky_relu`` (models.py:912) leaves in
+    the MetaGraphDef ``model.meta`` -- the bundle alone cannot tell LeakyReLU from ReLU."""
+    kernels, widths, embeds = [], [], []
+    i = 0
+    while "frame_level_info_layer-%d/w" % i in arrays:
+        k, _, cout = arrays["frame_level_info_layer-%d/w" % i].shape
+        kernels.append(int(k)); widths.append(int(cout))
+        i += 1
+    j = 0
+    while "embed_layer-%d/w" % j in arrays:
+        embeds.append(int(arrays["embed_layer-%d/w" % j].shape[1]))
+        j += 1
+    if any(n.endswith("/prelu/prelu") for n in arrays):
+        act = "prelu"
+    elif b"LeakyRelu" in metagraph:
+        act = "lrelu"
+    elif b"frame_level_info_layer-0" in metagraph:
+        act = "relu"                 # a real graph (it names the model's nodes) without a LeakyRelu anywhere
+    else:
+        act = None                   # no usable graph: ReLU and LeakyReLU checkpoints look the same
+    pooling = "attention" if any(n.startswith("attention/") for n in arrays) else "stats"
+    return (tuple(kernels), tuple(widths), tuple(embeds), act, pooling)
+
+
+def class_for_signature(sig):
+    """First class of the topology table with this extraction signature (classes that differ only in training-time
+    settings share their x-vectors), or None."""
+    for name, topo in tp.TOPOLOGIES.items():
+        if extraction_signature(topo) == sig:
+            return name
+    return None
 
 
 def weights_from_bundle(arrays, class_name):
-    """Map bundle variables to (weights keyed by TF names with ':0', topology, num_classes, feat_dim); the
-    topology's kernel sizes / widths are cross-checked against the variable shapes."""
+    """Map bundle variables to (weights keyed by TF names with ':0', topology, num_classes, feat_dim).  The variable SET
+    must be the one the class defines -- PReLU slopes or attention parameters the class would silently ignore are refused --
+    and kernel sizes / widths are cross-checked against the variable shapes."""
+    from . import weights as wio
     topo = tp.get(class_name)
     w = {}
     for name, arr in arrays.items():
-        if "/Adam" in name or name in ("beta1_power", "beta2_power"):
-            continue                                    # optimizer slots (models.py:112)
+        if _is_slot(name):
+            continue
         w[name + ":0"] = np.ascontiguousarray(arr, dtype=np.float32)
     n_layers = len(topo["layer_sizes"])
     for i in range(n_layers):
@@ -228,16 +276,58 @@ def weights_from_bundle(arrays, class_name):
                                                                            topo["kernel_sizes"][i], topo["layer_sizes"][i]))
     if topo["activation"] == "prelu" and "frame_level_info_layer-0/prelu/prelu:0" not in w:
         raise ValueError("class %s expects PReLU variables, the checkpoint has none" % class_name)
+    expected = set(wio.expected_names(topo))
+    scopes = ("frame_level_info_layer-", "embed_layer-", "attention/", "output/")
+    stray = sorted(n for n in w if n.startswith(scopes) and n not in expected)
+    if stray:
+        raise ValueError("the checkpoint holds variables class %s does not define (%s): it was written by another model "
+                         "class -- set XVECTOR_MODEL_CLASS or model_name.txt" % (class_name, ", ".join(stray[:4])))
     feat_dim = int(w["frame_level_info_layer-0/w:0"].shape[1])
     num_classes = int(w["output/w:0"].shape[1]) if "output/w:0" in w else 0
     return w, topo, num_classes, feat_dim
 
 
+def optimizer_state_from_bundle(arrays):
+    """Adam state of a reference-written checkpoint in the form weights.load_optimizer_state returns: ``<var>/Adam`` is the
+    first moment, ``<var>/Adam_1`` the second, and the step count follows from ``beta1_power = 0.9**t`` (TF keeps the power,
+    not the count).  None when the bundle has no slots (a model written before any training step)."""
+    m = {n[:-len("/Adam")] + ":0": np.asarray(a, np.float32) for n, a in arrays.items() if n.endswith("/Adam")}
+    v = {n[:-len("/Adam_1")] + ":0": np.asarray(a, np.float32) for n, a in arrays.items() if n.endswith("/Adam_1")}
+    if not m or "beta1_power" not in arrays:
+        return None
+    p = float(np.asarray(arrays["beta1_power"]).reshape(-1)[0])
+    t = int(round(np.log(p) / np.log(0.9))) if 0.0 < p < 1.0 else 0
+    return dict(t=t, m=m, v=v)
+
+
 def load_tf_model_dir(model_dir, class_name=None):
-    """-> (weights, meta) like weights.load_model_dir, straight from a TF checkpoint directory."""
+    """-> (weights, meta) like weights.load_model_dir, straight from a TF checkpoint directory.  The class comes from the
+    caller / XVECTOR_MODEL_CLASS / model_name.txt and must agree with what the checkpoint itself shows (variables +
+    MetaGraphDef); without a stated class the checkpoint's own evidence picks it, and that is logged."""
+    import logging
     prefix = os.path.join(model_dir, "model")
+    arrays = read_bundle(prefix)
+    meta_path = os.path.join(model_dir, "model.meta")
+    metagraph = open(meta_path, "rb").read() if os.path.exists(meta_path) else b""
+    seen = infer_signature(arrays, metagraph)
     class_name = class_name or guess_class_name(model_dir)
-    w, topo, num_classes, feat_dim = weights_from_bundle(read_bundle(prefix), class_name)
+    if class_name is None:
+        if seen[3] is None:
+            raise ValueError("'%s': no model class stated (XVECTOR_MODEL_CLASS / model_name.txt) and model.meta holds no graph "
+                             "to tell a ReLU from a LeakyReLU checkpoint -- refusing to guess" % model_dir)
+        class_name = class_for_signature(seen)
+        if class_name is None:
+            raise ValueError("'%s': no model class stated (XVECTOR_MODEL_CLASS / model_name.txt) and the checkpoint matches "
+                             "none of the known classes: kernels %s, widths %s, embeddings %s, %s, %s pooling" % ((model_dir,) + seen))
+        logging.getLogger(__name__).warning("no model class stated for '%s' (XVECTOR_MODEL_CLASS / model_name.txt): using %s, "
+                                            "inferred from the checkpoint's variables and graph", model_dir, class_name)
+    else:
+        stated = extraction_signature(tp.get(class_name))[3]
+        # the variable set is checked in weights_from_bundle; the one thing only the graph shows is LeakyReLU vs ReLU
+        if seen[3] in ("relu", "lrelu") and stated in ("relu", "lrelu") and stated != seen[3]:
+            raise ValueError("'%s': class %s uses %s but the checkpoint's graph (model.meta) %s LeakyRelu ops -- wrong model class"
+                             % (model_dir, class_name, stated, "contains" if seen[3] == "lrelu" else "has no"))
+    w, topo, num_classes, feat_dim = weights_from_bundle(arrays, class_name)
     meta = dict(format="tensorflow-checkpoint", model_class=class_name, topology=topo, num_classes=num_classes,
                 feat_dim=feat_dim)
     return w, meta

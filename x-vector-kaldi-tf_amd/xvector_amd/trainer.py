@@ -190,6 +190,13 @@ class Trainer(object):
         x = np.asarray(x)
         B, T, F = x.shape
         assert F == self.feat_dim, "feature dimension %d does not match the model (%d)" % (F, self.feat_dim)
+        labels = np.asarray(labels)
+        # the reference one-hot encodes on the host and raises IndexError for a label outside the output layer
+        # (create_one_hot_output_matrix, models.py:164-169); the loss kernel indexes logits[b, label] and must never see one
+        if labels.shape != (B,) or (B and (labels.min() < 0 or labels.max() >= self.num_classes)):
+            raise IndexError("labels must be %d integers in [0, %d): got shape %s, range [%s, %s] (egs built with another "
+                             "--num-targets?)" % (B, self.num_classes, labels.shape, labels.min() if labels.size else "-",
+                                                  labels.max() if labels.size else "-"))
         L = self._layout(B, T)
         lay = L["lay"]
         host = np.zeros((lay.rows, self.in_dim), np.float32)

@@ -83,6 +83,10 @@ def load_optimizer_state(input_dir):
     """-> adam dict or None (fresh optimizer) when the directory has no optimizer state."""
     p = os.path.join(input_dir, OPTIMIZER)
     if not os.path.exists(p):
+        # a checkpoint the reference's Saver wrote carries the slots inside the bundle (models.py:134-137)
+        if os.path.exists(os.path.join(input_dir, "model.index")):
+            from . import tf_checkpoint
+            return tf_checkpoint.optimizer_state_from_bundle(tf_checkpoint.read_bundle(os.path.join(input_dir, "model")))
         return None
     adam = {"t": 0, "m": {}, "v": {}}
     with np.load(p) as z:
