@@ -130,6 +130,24 @@ int xv_tdnn_layer_pool_bf16x3(const void *x, int x_format, int64_t R, int cin, i
 int xv_stats_pool_blocks_f32(const float *block_stats, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
                              float eps, float *out, void *stream);
 
+/* The last TWO frame-level layers and the first half of statistics pooling in one launch, for topologies whose last two
+ * layers have no temporal context (kernel size 1: models.py:28 [5,5,7,1,1], :545 [5,3,3,1,1]):
+ *     h = bn1(act(x . w1 + b1))          frame_level_info_layer-(n-2)   models.py:54-67
+ *     y = bn2(act(h . w2 + b2))          frame_level_info_layer-(n-1)
+ *     block_stats = per-8-row (mean, M2) of y, as xv_tdnn_layer_pool_bf16x3 writes them (merge: xv_stats_pool_blocks_f32)
+ * h never exists in memory: a wave keeps its 16 frames x Cmid of h in registers, produced by the first GEMM directly in
+ * the operand layout of the second (v_mfma_f32_16x16x32_bf16, bf16x3 arithmetic).  x: XV_FMT_SPLIT rows (same padding
+ * contract as xv_tdnn_layer_bf16x3).  wt = xv_pack_pair_bf16x3(w1[Cin,Cmid], w2[Cmid,Cout]) (TF's [in, out] order;
+ * xv_packed_pair_bf16x3_bytes bytes, 0 = unsupported shape).  Supported: Cmid == 512, Cin % 32 == 0, Cout % 64 == 0,
+ * Cout <= 2048 (else XV_ERR_UNSUPPORTED: run the two layers separately).  Chunks must start on rows that are multiples of
+ * 8, as for xv_tdnn_layer_pool_bf16x3.  act_alpha1 / act_alpha2: [1] for LRELU, [Cmid] / [Cout] for PRELU. */
+size_t xv_packed_pair_bf16x3_bytes(int cin, int cmid, int cout);
+int xv_pack_pair_bf16x3(const float *w1, const float *w2, int cin, int cmid, int cout, void *wt, void *stream);
+int xv_tdnn_pair_pool_bf16x3(const void *x, int64_t R, int cin, int cmid, int cout, const void *wt, const float *bias1,
+                             const float *bn_scale1, const float *bn_shift1, const float *act_alpha1, const float *bias2,
+                             const float *bn_scale2, const float *bn_shift2, const float *act_alpha2, int act_kind,
+                             const uint8_t *row_valid, float *block_stats, void *stream);
+
 /* xv_fc_f32 twin: fp32 rows in, fp32 rows out; wt = xv_pack_weights_bf16x3(w, 1, In, Out). */
 int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const void *wt, const float *bias, const float *bn_scale,
                  const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y, float *y_preact, void *stream);

@@ -360,6 +360,88 @@ def test_tdnn_layer_pool_blocks_match_oracle(env, fmt, cin, cout, K, dil, act, l
     assert np.isnan(bad[1]).all() and np.array_equal(bad[0], got[0]) and np.array_equal(bad[2:], got[2:])
 
 
+@pytest.mark.parametrize("cin,cout,act,lens", [
+    (512, 1536, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),      # layers 3 + 4 of the default topology
+    (64, 64, "prelu", [300, 25, 64, 3]),                         # two k-steps, one column group
+    (96, 192, "lrelu", [1200, 33]),                              # long chunk: many blocks per chunk
+    (512, 1536, "none", [40, 129]),
+])
+def test_tdnn_pair_pool_matches_oracle(env, cin, cout, act, lens):
+    """xv_tdnn_pair_pool_bf16x3 (two K = 1 layers chained in registers + pooling block statistics) +
+    xv_stats_pool_blocks_f32 == statistics pooling of layer(layer(x)) in the fp64 oracle; and the same block statistics
+    as the two-launch path (xv_tdnn_layer_bf16x3 -> xv_tdnn_layer_pool_bf16x3) up to fp32 summation order."""
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    cmid = 512
+    assert hiplib.pair_supported(cin, cmid, cout) and not hiplib.pair_supported(cin, 256, cout) and not hiplib.pair_supported(40, cmid, cout)
+    rng = np.random.default_rng(cin + cout + len(lens))
+    mats = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in lens]
+    w1 = (rng.standard_normal((1, cin, cmid)) / np.sqrt(cin)).astype(np.float32)
+    w2 = (rng.standard_normal((1, cmid, cout)) / np.sqrt(cmid)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(cmid)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn1, bn2 = _rand_bn(rng, cmid), _rand_bn(rng, cout)
+    a1 = a2 = None
+    if act == "lrelu":
+        a1 = a2 = np.array([0.2], np.float32)
+    elif act == "prelu":
+        a1 = (0.1 + 0.05 * rng.standard_normal(cmid)).astype(np.float32)
+        a2 = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    layout = engine.BatchLayout(lens, 1, hiplib.POOL_BLOCK_ROWS)
+    host = np.zeros((layout.rows, cin), np.float32)
+    layout.pack(mats, host)
+    x = torch.from_numpy(host).to(dev)
+    rv = torch.from_numpy(layout.row_valid()).to(dev)
+    xin = hiplib.SplitBuf(layout.rows, cin, dev)
+    hiplib.split_encode(x, xin)
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    s1, o1 = hiplib.fold_bn(*(t(a) for a in bn1), 1e-3)
+    s2, o2 = hiplib.fold_bn(*(t(a) for a in bn2), 1e-3)
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+    pair = hiplib.pack_pair_bf16x3(t(w1[0]), t(w2[0]))
+    blk = torch.full((hiplib.block_stats_floats(layout.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
+    hiplib.tdnn_pair_pool(xin, layout.rows, pair, (t(b1), s1, o1, t(a1)), (t(b2), s2, o2, t(a2)), code, rv, blk)
+    out = torch.full((len(lens), 2 * cout), float("nan"), dtype=torch.float32, device=dev)
+    rs, rl = torch.from_numpy(layout.row_start).to(dev), torch.from_numpy(layout.row_len).to(dev)
+    hiplib.stats_pool_blocks(blk, cout, rs, rl, len(lens), 1e-5, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    for i, m in enumerate(mats):
+        h = oracle.tdnn_layer(m, w1, b1, bn1, act, a1, 1, np.float64)
+        ref = oracle.stats_pool(oracle.tdnn_layer(h, w2, b2, bn2, act, a2, 1, np.float64), 1e-5, np.float64)
+        assert oracle.rel_l2(got[i, :cout], ref[:cout]) < 2 * TOL_GEMM3, (i, lens[i])
+        assert oracle.rel_l2(got[i, cout:], ref[cout:]) < 2 * TOL_GEMM3, (i, lens[i])
+    # the two-launch path on the same input: same quantity, different fp32 summation order
+    hmid = hiplib.SplitBuf(layout.rows, cmid, dev)
+    hiplib.tdnn_layer(xin, hiplib.pack_weights_bf16x3(t(w1)), t(b1), s1, o1, code, t(a1), 1, 1, rv, hmid, None, rows=layout.rows)
+    blk2 = torch.full_like(blk, float("nan"))
+    hiplib.tdnn_layer_pool(hmid, layout.rows, hiplib.pack_weights_bf16x3(t(w2)), t(b2), s2, o2, code, t(a2), 1, rv, blk2)
+    out2 = torch.empty_like(out)
+    hiplib.stats_pool_blocks(blk2, cout, rs, rl, len(lens), 1e-5, out2)
+    torch.cuda.synchronize()
+    two = out2.cpu().numpy()
+    for i in range(len(lens)):
+        assert oracle.rel_l2(got[i], two[i]) < 1e-5, (i, lens[i])
+    # blocks beyond the last row are never written; every block that holds frames is
+    b1_, b2_ = blk.cpu().numpy().reshape(-1, 2, cout), blk2.cpu().numpy().reshape(-1, 2, cout)
+    has_frames = layout.row_valid().astype(bool)
+    has_frames = np.pad(has_frames, (0, (-len(has_frames)) % 8)).reshape(-1, 8).any(axis=1)
+    assert np.isfinite(b1_[has_frames]).all() and np.allclose(b1_[has_frames], b2_[has_frames], rtol=2e-3, atol=2e-4)
+    # batch composition does not change a chunk's bits: chunk 0 alone
+    lay1 = engine.BatchLayout(lens[:1], 1, hiplib.POOL_BLOCK_ROWS)
+    host1 = np.zeros((lay1.rows, cin), np.float32)
+    lay1.pack(mats[:1], host1)
+    x1 = hiplib.SplitBuf(lay1.rows, cin, dev)
+    hiplib.split_encode(torch.from_numpy(host1).to(dev), x1)
+    blk1 = torch.full((hiplib.block_stats_floats(lay1.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
+    hiplib.tdnn_pair_pool(x1, lay1.rows, pair, (t(b1), s1, o1, t(a1)), (t(b2), s2, o2, t(a2)), code,
+                          torch.from_numpy(lay1.row_valid()).to(dev), blk1)
+    out1 = torch.empty((1, 2 * cout), dtype=torch.float32, device=dev)
+    hiplib.stats_pool_blocks(blk1, cout, torch.from_numpy(lay1.row_start).to(dev), torch.from_numpy(lay1.row_len).to(dev), 1, 1e-5, out1)
+    torch.cuda.synchronize()
+    assert np.array_equal(out1.cpu().numpy()[0], got[0])
+
+
 def test_stats_pool_constant_channel_is_exact(env):
     """A dead-ReLU channel is constant over time: mean exact, std == sqrt(eps) exactly."""
     torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]

@@ -35,3 +35,30 @@ for (cin, cout, K) in ((512, 512, 1), (512, 1536, 1), (512, 512, 5), (512, 512, 
         ex = 6.0 * R * cin * cout * K / 1e9
         print("cin %d cout %4d K %d out=%s tile %3d: median %.3f ms (min %.3f)  %.0f TF executed (%.1f%% of 2.5 PF)" %
               (cin, cout, K, name, rows, med, mn, ex / med, ex / med / 25))
+
+# the two K = 1 layers + pooling epilogue: two launches (layer 3 -> split buffer -> layer 4 with POOL epilogue) vs the
+# register-chained pair kernel, interleaved rounds
+cin, cmid, cout = 512, 512, 1536
+w1 = torch.randn((1, cin, cmid), device=dev) / cin ** 0.5; w2 = torch.randn((1, cmid, cout), device=dev) / cmid ** 0.5
+wp1, wp2 = hiplib.pack_weights_bf16x3(w1), hiplib.pack_weights_bf16x3(w2)
+pair = hiplib.pack_pair_bf16x3(w1[0], w2[0])
+x = torch.relu(torch.randn((R, cin), device=dev)); xs = hiplib.SplitBuf(R, cin, dev); hiplib.split_encode(x, xs)
+b1 = torch.zeros(cmid, device=dev); b2 = torch.zeros(cout, device=dev); rv = torch.ones(R, dtype=torch.uint8, device=dev)
+hs = hiplib.SplitBuf(R, cmid, dev); blk = torch.empty(hiplib.block_stats_floats(R, cout), device=dev)
+def two():
+    hiplib.tdnn_layer3(xs, R, wp1, b1, None, None, 1, None, 1, rv, hs)
+    hiplib.tdnn_layer_pool(hs, R, wp2, b2, None, None, 1, None, 1, rv, blk)
+def one():
+    hiplib.tdnn_pair_pool(xs, R, pair, (b1, None, None, None), (b2, None, None, None), 1, rv, blk)
+times = {"two launches": [], "pair kernel": []}
+for rnd in range(ROUNDS + 1):
+    for name, fn in (("two launches", two), ("pair kernel", one)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(REPS): fn()
+        b.record(); torch.cuda.synchronize()
+        if rnd: times[name].append(a.elapsed_time(b) / REPS)
+for name, t in times.items():
+    t = sorted(t); med = t[len(t) // 2]
+    ex = 6.0 * R * cin * (cmid + cout) / 1e9
+    print("layers 3+4+pool %s: median %.3f ms (min %.3f)  %.0f TF executed (%.1f%% of 2.5 PF)" % (name, med, t[0], ex / med, ex / med / 25))

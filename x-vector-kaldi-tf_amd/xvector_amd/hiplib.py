@@ -18,6 +18,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_split_row_bytes", "xv_split_encode_f32",
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32",
+           "xv_packed_pair_bf16x3_bytes", "xv_pack_pair_bf16x3", "xv_tdnn_pair_pool_bf16x3",
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
@@ -89,6 +90,12 @@ def load():
     lib.xv_block_stats_bytes.argtypes = [i64, ci]
     lib.xv_tdnn_layer_pool_bf16x3.restype = ci
     lib.xv_tdnn_layer_pool_bf16x3.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
+    lib.xv_packed_pair_bf16x3_bytes.restype = sz
+    lib.xv_packed_pair_bf16x3_bytes.argtypes = [ci, ci, ci]
+    lib.xv_pack_pair_bf16x3.restype = ci
+    lib.xv_pack_pair_bf16x3.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+    lib.xv_tdnn_pair_pool_bf16x3.restype = ci
+    lib.xv_tdnn_pair_pool_bf16x3.argtypes = [vp, i64, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]
     lib.xv_stats_pool_blocks_f32.restype = ci
     lib.xv_stats_pool_blocks_f32.argtypes = [vp, ci, vp, vp, ci, cf, vp, vp]
     lib.xv_chunk_average_f32.restype = ci
@@ -320,6 +327,47 @@ def tdnn_layer_pool(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid
     _check(lib.xv_tdnn_layer_pool_bf16x3(xp, fmt, int(R), w.cin, ldx, _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
                                          _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), _ptr(block_stats), _stream()),
            "xv_tdnn_layer_pool_bf16x3")
+
+
+class PackedPair(object):
+    """Weights of two consecutive K = 1 layers in the stage order of xv_tdnn_pair_pool_bf16x3."""
+
+    def __init__(self, wt, cin, cmid, cout):
+        self.wt, self.cin, self.cmid, self.cout = wt, cin, cmid, cout
+
+
+def pair_supported(cin, cmid, cout):
+    return int(load().xv_packed_pair_bf16x3_bytes(int(cin), int(cmid), int(cout))) > 0
+
+
+def pack_pair_bf16x3(w1, w2):
+    """w1[Cin, Cmid], w2[Cmid, Cout] (device fp32, TF's [in, out] order) -> PackedPair."""
+    import torch
+    lib = require_gpu()
+    _f32(w1, "w1"); _f32(w2, "w2")
+    assert w1.dim() == 2 and w2.dim() == 2 and w1.shape[1] == w2.shape[0]
+    cin, cmid, cout = int(w1.shape[0]), int(w1.shape[1]), int(w2.shape[1])
+    nbytes = int(lib.xv_packed_pair_bf16x3_bytes(cin, cmid, cout))
+    if nbytes == 0:
+        raise XvectorHipError("xv_pack_pair_bf16x3: unsupported shape %d -> %d -> %d" % (cin, cmid, cout))
+    wt = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    _check(lib.xv_pack_pair_bf16x3(_ptr(w1.contiguous()), _ptr(w2.contiguous()), cin, cmid, cout, _ptr(wt), _stream()),
+           "xv_pack_pair_bf16x3")
+    return PackedPair(wt, cin, cmid, cout)
+
+
+def tdnn_pair_pool(x, R, w, p1, p2, act, row_valid, block_stats):
+    """Two K = 1 layers + pooling block statistics in one launch.  x: SplitBuf; w: PackedPair; p1 / p2: (bias, bn_scale,
+    bn_shift, act_alpha) device tensors (None allowed) of the first / second layer."""
+    lib = require_gpu()
+    assert isinstance(x, SplitBuf) and isinstance(w, PackedPair)
+    assert x.channels == w.cin and x.rows >= R
+    _f32(block_stats, "block_stats"); assert block_stats.numel() >= block_stats_floats(R, w.cout)
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_pair_pool_bf16x3(ctypes.c_void_p(x.ptr), int(R), w.cin, w.cmid, w.cout, _ptr(w.wt), _ptr(p1[0]), _ptr(p1[1]),
+                                        _ptr(p1[2]), _ptr(p1[3]), _ptr(p2[0]), _ptr(p2[1]), _ptr(p2[2]), _ptr(p2[3]), int(act),
+                                        _ptr(row_valid), _ptr(block_stats), _stream()), "xv_tdnn_pair_pool_bf16x3")
 
 
 def stats_pool_blocks(block_stats, c, row_start, row_len, nchunks, eps, out):
