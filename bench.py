@@ -13,10 +13,14 @@ for every ragged batch 5x TDNN GEMM -> statistics pooling -> segment FC, then th
 average, then (N > 1) the single RCCL gather of the [10000, 512] blocks to rank 0.  Inputs (packed
 feature batches) are resident in HBM before the timed region starts; nothing is skipped or cached.
 
-Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (tdnn_gemm_kernel<true>, fp32-input
-MFMA, peak 157.3 TFLOP/s) from algorithmic FLOPs / HIP-event time measured inside the timed region;
-``roofline_pool`` is the same for the HBM-bound pooling kernel; ``cpu_baseline`` is a torch-CPU fp32 port
-of the reference forward (batch 1, like the reference) timed on this box's host cores on a bounded sample.
+Rank 0 prints ONE JSON line.  ``roofline`` is for the GEMM kernels of the step (bf16x3 split-precision MFMA by default:
+tdnn_gemm_bf16x3_kernel for layers 0-2, tdnn_pair_pool_kernel for layers 3+4 + pooling statistics, the FC) from
+algorithmic FLOPs / HIP-event time measured inside the timed region; ``roofline_pool`` is the same for the HBM-bound
+pooling kernel; ``cpu_baseline`` is a torch-CPU fp32 port of the reference forward (batch 1, like the reference) timed on
+this box's host cores on a bounded sample: the faithful 2-thread figure, a thread sweep, and ``all_cores`` = the
+reference's deployment shape (nj processes x 2 threads).  At N = 1 the line also carries ``fp32_exact`` (the same step on
+the exact-fp32 MFMA path) and ``e2e_ark_to_ark`` (ark bytes -> Model.make_embedding -> ark bytes, PCIe and Kaldi parsing
+included; never ``value``).
 """
 import argparse
 import json
@@ -44,7 +48,10 @@ def parse():
     ap.add_argument("--tmin", type=int, default=200)
     ap.add_argument("--tmax", type=int, default=400)
     ap.add_argument("--batch-rows", type=int, default=262144)
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline timing (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=18.0, help="seconds of CPU-baseline timing (0 = skip)")
+    ap.add_argument("--e2e-utts", type=int, default=50000,
+                    help="N = 1 only: utterances of the ark -> ark sub-measurement through Model.make_embedding (0 = skip)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the exact-fp32 sub-measurement (fp32_exact)")
     ap.add_argument("--parity-utts", type=int, default=6)
     ap.add_argument("--no-fused-pool", action="store_true",
                     help="bf16x3: store the last layer and run the standalone pooling kernel (A/B against the fused epilogue)")
@@ -131,6 +138,138 @@ def bench_train(args, rank, world, dev, topo, feat):
         dist.destroy_process_group()
 
 
+def _kernel_source_sha():
+    """Hash of the kernel sources: profiles/traffic.json is only quoted when it was measured on these very kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "x-vector-kaldi-tf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _traffic(batch_rows):
+    """(bytes per launch or None, provenance) from profiles/traffic.json -- PMC counters come from separate rocprofv3 passes
+    (tools/profile_round.sh), so the number is stamped with the kernel sources and batch size it was measured at and dropped
+    when either differs from this run."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no profiles/traffic.json"
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        return None, "unreadable profiles/traffic.json"
+    if t.get("kernel_sha") != _kernel_source_sha():
+        return None, "profiles/traffic.json is stale: measured on other kernel sources (%s)" % t.get("kernel_sha")
+    if t.get("batch_rows") != batch_rows:
+        return None, "profiles/traffic.json was measured at batch_rows=%s" % t.get("batch_rows")
+    return t.get("gemm_hbm_bytes_per_launch"), "%s; batch_rows %d; kernel sources %s" % (t.get("source"), t["batch_rows"], t["kernel_sha"])
+
+
+def _resident_batches(args, model, lens, dev, feat, seed):
+    """The workload in kernel layout, resident in HBM: length-bucketed ragged batches of <= batch_rows rows."""
+    import torch
+    from xvector_amd import engine
+    gap, align = model.gap, model.align
+    lead = (gap + align - 1) // align * align
+    order = np.argsort(lens, kind="stable")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    batches = []
+    b0 = 0
+    while b0 < len(order):
+        rows, b1 = lead, b0
+        while b1 < len(order) and (b1 == b0 or rows + int(engine.slot_rows(lens[order[b1]], gap, align)) <= args.batch_rows):
+            rows += int(engine.slot_rows(lens[order[b1]], gap, align))
+            b1 += 1
+        lay = engine.BatchLayout(lens[order[b0:b1]], gap, align)
+        rv = torch.from_numpy(lay.row_valid()).to(dev)
+        x = torch.randn((lay.rows, model.in_dim), generator=gen, device=dev, dtype=torch.float32) * 3.0
+        x *= rv[:, None].to(torch.float32)                        # gap rows are zero by contract
+        x[:, feat:] = 0                                           # 23 MFCC dims live in a 24-column (16-B aligned) row
+        batches.append(dict(x=x, rs=torch.from_numpy(lay.row_start).to(dev), rl=torch.from_numpy(lay.row_len).to(dev),
+                            rv=rv, n=lay.nchunks, max_len=lay.max_len, lo=b0, hi=b1, rows=lay.rows,
+                            frames=int(lay.row_len.sum()), lay=lay))
+        b0 = b1
+    return order, batches
+
+
+def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
+    """The same step on the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulate), 1 warm-up + 2
+    timed passes over the resident batches -- what the bf16x3 default is traded against."""
+    import torch
+    from xvector_amd import engine, hiplib, topology as tp
+    model = engine.DeviceModel(weights, topo, dev, precision="fp32", fused_pool=False)
+    model.reserve(max(b["rows"] for b in batches), max(b["n"] for b in batches), max(b["max_len"] for b in batches))
+    P = torch.empty((n_utts, model.pooled_dim), dtype=torch.float32, device=dev)
+    E = torch.empty((n_utts, model.embed_dim), dtype=torch.float32, device=dev)
+    steps = 2
+    ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in batches] for _ in range(steps + 1)]
+
+    def one(si):
+        for bi, b in enumerate(batches):
+            # the batches were laid out with the 8-row chunk alignment of the fused path: a valid layout for this path too
+            model.frame_level(b["x"], b["rs"], b["rl"], b["rv"], b["n"], b["max_len"], P[b["lo"]:b["hi"]], events=ev[si][bi])
+        model.segment_level(P, E)
+    one(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for si in range(1, steps + 1):
+        one(si)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    t_g = sum(e[0].elapsed_time(e[1]) for si in range(1, steps + 1) for e in ev[si]) * 1e-3
+    fl = tp.flops_per_frame(topo, feat) * frames
+    return {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n_utts) / dt / 1e12,
+            "tdnn_gemm_tflops": fl * steps / t_g / 1e12, "frac_of_fp32_mfma_peak_157.3": fl * steps / t_g / MFMA_F32_PEAK,
+            "kernel": "tdnn_gemm_kernel (v_mfma_f32_32x32x2_f32), standalone stats_pool_kernel"}
+
+
+def _e2e_leg(args, weights, topo, feat):
+    """ark bytes in RAM -> Model.make_embedding (reader thread, native packer, H2D, kernels, D2H, writer thread) -> ark bytes:
+    the PCIe- and parsing-inclusive rate of the drop-in entry point, model load included."""
+    import io
+    import logging
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf"))
+    import kaldi_io
+    import models
+    from xvector_amd import synthetic
+    n = args.e2e_utts
+    lens = synthetic.utterance_lengths(n, args.tmin, args.tmax, 4321)
+    rng = np.random.default_rng(4321)
+    pool = [(rng.standard_normal((args.tmax, feat)) * 3.0).astype(np.float32) for _ in range(257)]
+    src = io.BytesIO()
+    for i in range(n):
+        kaldi_io.write_mat(src, pool[i % 257][:lens[i]], key="utt%07d" % i)
+    data = src.getvalue()
+    del src
+    tmp = tempfile.mkdtemp(prefix="xv_bench_e2e_")
+    log = logging.getLogger("bench_e2e")
+    log.addHandler(logging.NullHandler())
+    log.propagate = False
+    try:
+        models.Model.save_model(dict(weights=weights, topology=topo, model_class="ModelWithoutDropout", num_classes=64, feat_dim=feat),
+                                tmp, None)
+        best = None
+        for _ in range(2):                                         # first pass also pins the staging buffers
+            out = io.BytesIO()
+            t0 = time.perf_counter()
+            models.Model().make_embedding(io.BytesIO(data), out, tmp, 25, 10000, True, log)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        nvec = out.getbuffer().nbytes // (len("utt0000000") + 1 + 2 + 3 + 1 + 4 + 512 * 4)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": n / best, "unit": "utt/s", "utterances": n, "vectors_written": int(nvec), "seconds": best,
+            "ark_gb_in": len(data) / 1e9, "ark_gb_per_s": len(data) / 1e9 / best,
+            "path": "ark bytes in host RAM -> Model.make_embedding(min_chunk 25, chunk 10000) -> ark bytes in host RAM, incl. model "
+                    "load, Kaldi parsing, packing, H2D, D2H and FV serialisation; best of 2 passes"}
+
+
 def main():
     args = parse()
     import torch
@@ -152,30 +291,10 @@ def main():
     weights = synthetic.trained_like(topo, feat, seed=1)
     model = engine.DeviceModel(weights, topo, dev, precision=args.precision,
                                fused_pool=(args.precision == "bf16x3" and not args.no_fused_pool))
-    gap, align = model.gap, model.align
-    lead = (gap + align - 1) // align * align
 
     # ---- synthetic workload resident in HBM: ragged batches in kernel layout -------------------
     lens = synthetic.utterance_lengths(args.utts, args.tmin, args.tmax, 1234 + rank)
-    order = np.argsort(lens, kind="stable")                       # length-bucketed batches
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    batches = []
-    b0 = 0
-    while b0 < len(order):
-        rows, b1 = lead, b0
-        while b1 < len(order) and (b1 == b0 or rows + int(engine.slot_rows(lens[order[b1]], gap, align)) <= args.batch_rows):
-            rows += int(engine.slot_rows(lens[order[b1]], gap, align))
-            b1 += 1
-        lay = engine.BatchLayout(lens[order[b0:b1]], gap, align)
-        rv = torch.from_numpy(lay.row_valid()).to(dev)
-        x = torch.randn((lay.rows, model.in_dim), generator=gen, device=dev, dtype=torch.float32) * 3.0
-        x *= rv[:, None].to(torch.float32)                        # gap rows are zero by contract
-        x[:, feat:] = 0                                           # 23 MFCC dims live in a 24-column (16-B aligned) row
-        batches.append(dict(x=x, rs=torch.from_numpy(lay.row_start).to(dev), rl=torch.from_numpy(lay.row_len).to(dev),
-                            rv=rv, n=lay.nchunks, max_len=lay.max_len, lo=b0, hi=b1, rows=lay.rows,
-                            frames=int(lay.row_len.sum()), lay=lay))
-        b0 = b1
+    order, batches = _resident_batches(args, model, lens, dev, feat, 1234 + rank)
     n_utts = len(order)
     frames = int(lens.sum())
     model.reserve(max(b["rows"] for b in batches), max(b["n"] for b in batches), max(b["max_len"] for b in batches))
@@ -231,15 +350,17 @@ def main():
         t_gemm += ev_fc[si][0].elapsed_time(ev_fc[si][1])
     t_gemm, t_pool = t_gemm * 1e-3, t_pool * 1e-3
     fl_gemm = (tp.flops_per_frame(topo, feat) * frames + tp.flops_per_utt(topo) * n_utts) * args.steps
-    n_gemm_launch = (5 * len(batches) + 1) * args.steps
+    paired = getattr(model, "pair", None) is not None
+    launches_per_batch = len(model.layers) - (1 if paired else 0)
+    n_gemm_launch = (launches_per_batch * len(batches) + 1) * args.steps
     C = topo["layer_sizes"][-1]
     by_pool = (4 * C * frames + 4 * 2 * C * n_utts) * args.steps
     pool_kernel = "stats_pool_kernel"
     if model.fused_pool:
         # the timed path reduces the last layer inside the GEMM epilogue; the standalone pooling kernel (fp32 path, training)
         # is timed here, outside the timed region, on a materialised [rows, 1536] fp32 activation of the largest batch
-        pool_kernel = "stats_pool_kernel (standalone, measured outside the timed region: the bf16x3 path fuses pooling " \
-                      "into the last GEMM's epilogue + stats_pool_blocks_kernel)"
+        pool_kernel = "stats_pool_kernel (standalone, measured outside the timed region: the bf16x3 path reduces the last layer " \
+                      "to 8-row block statistics in the GEMM epilogue + stats_pool_blocks_kernel)"
         big = max(batches, key=lambda b: b["rows"])
         hbuf = torch.randn((big["rows"], C), device=dev, dtype=torch.float32)
         pout = torch.empty((big["n"], 2 * C), device=dev, dtype=torch.float32)
@@ -267,14 +388,19 @@ def main():
             dist.destroy_process_group()
         return
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("tdnn_gemm_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
+    traffic, traffic_src = _traffic(args.batch_rows)
+    if args.precision == "fp32":
+        kern = {"kernel": "tdnn_gemm_kernel<true> (5 TDNN layers per batch + embed FC per step)",
+                "peak": MFMA_F32_PEAK / 1e12, "frac": fl_gemm / t_gemm / MFMA_F32_PEAK,
+                "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"}
+    else:
+        kern = {"kernel": ("tdnn_gemm_bf16x3_kernel (layers 0-2) + tdnn_pair_pool_kernel (layers 3+4 chained in registers, pooling "
+                           "statistics in its epilogue) per batch, embed FC per step" if paired else
+                           "tdnn_gemm_bf16x3_kernel (5 TDNN layers per batch + embed FC per step)"),
+                "peak": MFMA_BF16_PEAK / 3 / 1e12, "frac": 3 * fl_gemm / t_gemm / MFMA_BF16_PEAK,
+                "executed_bf16_tflops": 3 * fl_gemm / t_gemm / 1e12,
+                "peak_note": "achieved = ALGORITHMIC (fp32-contraction) FLOPs; every product costs 3 bf16 MFMAs, so "
+                             "peak = 2.5 PFLOP/s dense bf16 MFMA / 3 and frac = executed bf16 FLOPs / 2.5 PF"}
     out = {
         "metric": "utterances/sec (= x-vectors/sec, 512-d) on synthetic 23-dim MFCC, T~U[200,400]",
         "value": n_utts * world * args.steps / dt,
@@ -287,23 +413,16 @@ def main():
         "config": {"workload": "BASELINE configs[1]: %d utts/GPU, 23-dim MFCC, T~U{%d..%d}, default x-vector topology "
                                "[512,512,512,512,1536] k=[5,5,7,1,1], 512-d embed_layer-0" % (n_utts, args.tmin, args.tmax),
                    "utts_per_gpu": n_utts, "frames_per_gpu": frames, "batches_per_step": len(batches),
-                   "batch_rows": args.batch_rows, "precision": args.precision, "fused_pool": bool(model.fused_pool), "dist_initialized": bool(dist.is_initialized()),
+                   "batch_rows": args.batch_rows, "precision": args.precision, "fused_pool": bool(model.fused_pool),
+                   "pair_kernel": paired, "dist_initialized": bool(dist.is_initialized()),
                    "parallelism": "utterance-sharded x%d, one RCCL gather" % world},
         "frames_per_s": frames * world * args.steps / dt,
         "algorithmic_tflops": fl_total * world * args.steps / dt / 1e12,
         "roofline": dict({"bound": "mfma", "achieved": fl_gemm / t_gemm / 1e12, "unit": "TFLOP/s", "traffic": traffic,
+                          "traffic_source": traffic_src,
                           "avg_launch_ms": t_gemm / n_gemm_launch * 1e3, "launches": n_gemm_launch,
                           "algorithmic_gflop_per_launch": fl_gemm / n_gemm_launch / 1e9,
-                          "frac_of_fp32_mfma_peak_157.3": fl_gemm / t_gemm / MFMA_F32_PEAK},
-                         **({"kernel": "tdnn_gemm_kernel<true> (5 TDNN layers per batch + embed FC per step)",
-                             "peak": MFMA_F32_PEAK / 1e12, "frac": fl_gemm / t_gemm / MFMA_F32_PEAK,
-                             "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"}
-                            if args.precision == "fp32" else
-                            {"kernel": "tdnn_gemm_bf16x3_kernel (5 TDNN layers per batch + embed FC per step)",
-                             "peak": MFMA_BF16_PEAK / 3 / 1e12, "frac": 3 * fl_gemm / t_gemm / MFMA_BF16_PEAK,
-                             "executed_bf16_tflops": 3 * fl_gemm / t_gemm / 1e12,
-                             "peak_note": "achieved = ALGORITHMIC (fp32-contraction) FLOPs; every product costs 3 bf16 MFMAs, so "
-                                          "peak = 2.5 PFLOP/s dense bf16 MFMA / 3 and frac = executed bf16 FLOPs / 2.5 PF"})),
+                          "frac_of_fp32_mfma_peak_157.3": fl_gemm / t_gemm / MFMA_F32_PEAK}, **kern),
         "roofline_pool": {"kernel": pool_kernel, "bound": "hbm", "achieved": by_pool / t_pool / 1e9,
                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": by_pool / t_pool / HBM_PEAK,
                           "avg_launch_ms": t_pool / pool_launches * 1e3,
@@ -317,7 +436,7 @@ def main():
                               "avg_launch_ms": t_blocks / (len(batches) * args.steps) * 1e3}
 
     if args.cpu_budget > 0:
-        from oracle import oracle, torch_ref
+        from oracle import oracle
         # parity spot check (oracle as the checker): a few utterances of the resident workload
         worst = 0.0
         got = xvec.cpu().numpy()
@@ -328,29 +447,40 @@ def main():
             worst = max(worst, oracle.rel_l2(got[j], oracle.embed_utterance(m, weights, topo, 25, 10000, np.float64)))
         out["parity_rel_l2_max_vs_fp64_oracle"] = worst
     if args.cpu_budget > 0 and world == 1:
-        from oracle import torch_ref
+        from oracle import oracle, torch_ref
         sample_lens = synthetic.utterance_lengths(32, args.tmin, args.tmax, 1234)
         rng = np.random.default_rng(99)
         mats = [(rng.standard_normal((int(T), feat)) * 3.0).astype(np.float32) for T in sample_lens]
-        ncores = os.cpu_count() or 1
-        # batch-1 forwards do not scale to hundreds of threads: sweep a few thread counts (2 = the reference's TF
-        # session config, local/tf/models.py:361-363) and report the best one as the baseline
-        sweep = sorted(set(t for t in (2, 8, 32) if t <= ncores))
-        per = max(2.0, args.cpu_budget / (len(sweep) + 1))
-        res = {t: torch_ref.time_baseline(weights, topo, mats, t, per) for t in sweep}
+        logical, granted = os.cpu_count() or 1, torch_ref.effective_cores()
+        # (i) one process, a few thread counts (2 = the reference's TF session config, local/tf/models.py:361-363): batch-1
+        #     forwards do not scale to hundreds of threads;  (ii) the reference's deployment: nj processes x 2 threads
+        #     (run.sh:229-247 -> extract_xvectors.sh:83-88) on every core this container is granted
+        sweep = sorted(set(t for t in (2, 8, 32) if t <= max(2, granted)))
+        share = args.cpu_budget / (len(sweep) + 2.0)
+        res = {t: torch_ref.time_baseline(weights, topo, mats, t, max(1.5, share)) for t in sweep}
         best = max(res, key=lambda t: res[t][0])
+        nproc = max(1, min(granted // 2, 64))
+        dep_rate, dep_each = torch_ref.time_baseline_processes(weights, topo, mats, nproc, 2, max(2.0, 2 * share))
         # the port itself against the fp64 oracle ("CPU(fp32)-vs-fp64 oracle"), on two utterances of the sample
         port = torch_ref.TorchCpuModel(weights, topo)
         port_err = max(oracle.rel_l2(port.forward(m), oracle.forward(m, weights, topo, np.float64)) for m in mats[:2])
         gflop_per_utt = (tp.flops_per_frame(topo, feat) * float(np.mean(sample_lens)) + tp.flops_per_utt(topo)) / 1e9
-        out["cpu_baseline"] = {"value": res[best][0], "unit": "utt/s", "cores": best, "kind": "port",
-                               "gflops": res[best][0] * gflop_per_utt, "port_rel_l2_vs_fp64_oracle": port_err,
+        top_rate, top_cores = (dep_rate, 2 * nproc) if dep_rate > res[best][0] else (res[best][0], best)
+        out["cpu_baseline"] = {"value": top_rate, "unit": "utt/s", "cores": top_cores, "kind": "port",
+                               "gflops": top_rate * gflop_per_utt, "port_rel_l2_vs_fp64_oracle": port_err,
                                "sample": "torch-CPU fp32 (oneDNN) port of the reference forward, batch 1 per utterance as "
                                          "local/tf/models.py:401-414 runs it; a 32-utterance slice of the same length "
-                                         "distribution cycled for %.0f s per thread count; best of threads=%s reported; host "
-                                         "has %d logical cores" % (per, sweep, ncores),
+                                         "distribution cycled for %.1f s per single-process thread count %s and %.1f s for the "
+                                         "all-cores deployment shape; value = the better of the two; host shows %d logical cores, "
+                                         "the container is granted %d" % (max(1.5, share), sweep, max(2.0, 2 * share), logical, granted),
                                "by_threads": {str(t): res[t][0] for t in sweep},
-                               "reference_faithful_2_threads": res.get(2, (None,))[0]}
+                               "reference_faithful_2_threads": res.get(2, (None,))[0],
+                               "all_cores": {"value": dep_rate, "unit": "utt/s", "processes": nproc, "threads_per_process": 2,
+                                             "cores": 2 * nproc, "host_logical_cores": logical, "container_granted_cores": granted,
+                                             "shape": "nj independent extractor processes x 2 intra-op threads, as run.sh:229-247 / "
+                                                      "extract_xvectors.sh:83-88 deploy the reference (models.py:361-363)"}}
+    if world == 1 and args.precision == "bf16x3" and not args.no_fp32_leg:
+        out["fp32_exact"] = _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat)
     # ---- BASELINE configs[3] asks for the rate "incl. and excl. ark write": rank 0 writes the gathered x-vectors of ONE step
     #      as a Kaldi ark + scp (outside the timed region; `value` excludes it, `with_ark_write` folds its time into a step)
     if last is not None:
@@ -371,6 +501,11 @@ def main():
                                      "note": "D2H of the gathered [N,512] block + Kaldi ark,scp write by rank 0, serial after the step"}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+    if world == 1 and args.e2e_utts > 0 and args.precision == "bf16x3":
+        del batches, E_all, P_all
+        e2e = _e2e_leg(args, weights, topo, feat)
+        e2e["fraction_of_resident_rate"] = e2e["value"] / out["value"]
+        out["e2e_ark_to_ark"] = e2e
     print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

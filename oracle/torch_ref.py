@@ -63,3 +63,68 @@ def time_baseline(weights, topo, mats, threads, budget_s=12.0):
         return n / dt, n, frames
     finally:
         torch.set_num_threads(prev)
+
+
+def effective_cores():
+    """Host cores this process may actually use: the scheduler affinity mask capped by the cgroup CPU quota (a container can
+    show 256 logical cores and be granted 16)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(math.ceil(int(txt[0]) / float(txt[1])))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(math.ceil(quota / float(period)))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def time_baseline_processes(weights, topo, mats, processes, threads, budget_s):
+    """The reference's DEPLOYMENT shape (run.sh:229-247 -> extract_xvectors.sh:83-88): ``processes`` independent extractor
+    jobs, each a batch-1 forward loop with ``threads`` intra-op threads (models.py:361-363), all running at once on this
+    host.  Returns (aggregate utterances/s, per-process rates)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="xv_cpu_base_")
+    try:
+        np.savez(os.path.join(tmp, "w.npz"), **{k: np.asarray(v) for k, v in weights.items()})
+        np.savez(os.path.join(tmp, "m.npz"), *mats)
+        json.dump(topo, open(os.path.join(tmp, "topo.json"), "wt"))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        cmd = [sys.executable, os.path.abspath(__file__), "--worker", tmp, str(threads), str(budget_s)]
+        procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(processes)]
+        rates = []
+        for p in procs:
+            out = p.communicate(timeout=budget_s * 4 + 180)[0].decode().split()
+            if p.returncode == 0 and out:
+                rates.append(float(out[-1]))
+        return sum(rates), rates
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    import json
+    import os
+    import sys
+    if len(sys.argv) == 5 and sys.argv[1] == "--worker":
+        d, threads, budget = sys.argv[2], int(sys.argv[3]), float(sys.argv[4])
+        with np.load(os.path.join(d, "w.npz")) as z:
+            weights = {k: z[k] for k in z.files}
+        with np.load(os.path.join(d, "m.npz")) as z:
+            mats = [z[k] for k in z.files]
+        topo = json.load(open(os.path.join(d, "topo.json")))
+        print(time_baseline(weights, topo, mats, threads, budget)[0])

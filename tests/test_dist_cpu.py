@@ -227,21 +227,33 @@ EMBED_WORKER = textwrap.dedent("""
         self.device_model = types.SimpleNamespace(device="cpu", embed_dim=6, feat_dim=5)
     engine.Extractor = FakeExtractor
     models.Model.load_model = fake_load
-    models.Model.window_frames = 400          # several windows -> several gathers
+    models.Model.window_frames = 400          # several windows, still ONE gather
+
+    import torch.distributed as _d
+    _calls = []
+    def _count(name):
+        real = getattr(_d, name)
+        def wrapped(*a, **k):
+            _calls.append(name)
+            return real(*a, **k)
+        setattr(_d, name, wrapped)
+    for _n in ("gather", "all_gather", "all_gather_object", "gather_object", "broadcast", "broadcast_object_list", "all_reduce",
+               "scatter", "all_to_all", "send", "recv", "reduce"):
+        _count(_n)
     log = logging.getLogger("w"); log.addHandler(logging.NullHandler())
     out = io.BytesIO()
     with open(sys.argv[1], "rb") as fin:
         models.Model().make_embedding(fin, out, "unused", 10, -1, True, log)
     rank = int(os.environ.get("RANK", "0"))
     open(sys.argv[2] + ".%%d" %% rank, "wb").write(out.getvalue())
-    print("EMBED_OK")
+    print("EMBED_OK collectives=%%s" %% ",".join(_calls))
 """)
 
 
 def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path):
     """Model.make_embedding under a 2-rank gloo group (stand-in extractor): every rank reads the stream, extracts its
-    frame-balanced shard of each window, ONE gather per window, rank 0 alone writes -- and writes exactly the bytes a single
-    process writes (input order restored, rejected utterances dropped)."""
+    frame-balanced shard of each window, ONE gather at the very end (however many windows), rank 0 alone writes -- and writes
+    exactly the bytes a single process writes (input order restored, rejected utterances dropped)."""
     import kaldi_io
     from conftest import TWIN
     rng = np.random.default_rng(2)
@@ -267,6 +279,7 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path):
     got = {k: v for k, v in kaldi_io.read_vec_flt_ark(str(tmp_path / "dist.0"))}
     assert open(str(tmp_path / "dist.0"), "rb").read() == want
     assert open(str(tmp_path / "dist.1"), "rb").read() == b""                      # the non-root rank writes nothing
+    assert all("EMBED_OK collectives=gather\n" in o for o in outs), outs         # the whole job: exactly one data-path collective
     assert list(got) == ["utt%02d" % i for i, t in enumerate(lens) if t >= 10]
     assert got["utt05"][-1] == 200.0
 
@@ -300,8 +313,20 @@ CLI_WORKER = textwrap.dedent("""
     engine.Extractor = FakeExtractor
     models.Model.load_model = fake_load
     models.Model.window_frames = 300
+
+    import torch.distributed as _d
+    _calls = []
+    def _count(name):
+        real = getattr(_d, name)
+        def wrapped(*a, **k):
+            _calls.append(name)
+            return real(*a, **k)
+        setattr(_d, name, wrapped)
+    for _n in ("gather", "all_gather", "all_gather_object", "gather_object", "broadcast", "broadcast_object_list", "all_reduce",
+               "scatter", "all_to_all", "send", "recv", "reduce"):
+        _count(_n)
     extract_embedding.main(sys.argv[1:])
-    print("CLI_OK")
+    print("CLI_OK collectives=%%s" %% ",".join(_calls))
 """)
 
 
@@ -338,3 +363,5 @@ def test_two_rank_gloo_cli_shards_an_scp_table(tmp_path):
     s2 = open(str(tmp_path / "two.scp")).read().replace("two.ark", "X")
     assert s1 == s2 and len(s1.splitlines()) == sum(t >= 10 for t in lens)
     assert not os.path.exists(str(tmp_path / "two.ark.tmp.ark"))
+    # north star: "a single RCCL gather at the end" -- no object collectives for counts or keys (the line ranges are deterministic)
+    assert all("CLI_OK collectives=gather\n" in o for o in outs), outs

@@ -18,7 +18,7 @@ def _run(*flags):
 
 
 def test_extraction_bench_line():
-    d = _run("--utts", "600", "--steps", "2", "--warmup", "1", "--cpu-budget", "2", "--parity-utts", "2")
+    d = _run("--utts", "600", "--steps", "2", "--warmup", "1", "--cpu-budget", "6", "--parity-utts", "2", "--e2e-utts", "700")
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
         assert isinstance(d[k], t), k
@@ -32,6 +32,26 @@ def test_extraction_bench_line():
     assert c["kind"] == "port" and c["unit"] == "utt/s" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
     assert d["parity_rel_l2_max_vs_fp64_oracle"] < 1e-4
     assert d["roofline_pool"]["bound"] == "hbm" and 0 < d["roofline_pool"]["frac"] < 1.2
+    assert isinstance(r["traffic_source"], str) and d["config"]["pair_kernel"] is True
+    # the deployment-shaped CPU baseline (nj processes x 2 threads on the cores the container is granted) next to the faithful figure
+    a = c["all_cores"]
+    assert a["value"] > 0 and a["threads_per_process"] == 2 and a["cores"] == 2 * a["processes"] <= max(2, a["container_granted_cores"])
+    assert c["reference_faithful_2_threads"] > 0 and c["value"] >= max(a["value"], c["reference_faithful_2_threads"]) * 0.999
+    # exact-fp32 sub-record and the PCIe / parsing-inclusive ark -> ark rate ride on the same line; neither is `value`
+    f = d["fp32_exact"]
+    assert f["unit"] == "utt/s" and 0 < f["value"] < d["value"] and 0 < f["frac_of_fp32_mfma_peak_157.3"] < 1
+    e = d["e2e_ark_to_ark"]
+    assert e["utterances"] == 700 and e["vectors_written"] == 700 and e["value"] > 0
+    assert e["fraction_of_resident_rate"] == pytest.approx(e["value"] / d["value"])
+
+
+def test_bench_at_the_per_rank_size_of_the_million_utterance_job():
+    """BASELINE configs[3] gives every one of 8 ranks 125 k utterances: the resident-input step at that size (37.5 M frames,
+    ~145 batches) on one GPU."""
+    d = _run("--utts", "125000", "--steps", "1", "--warmup", "0", "--cpu-budget", "0", "--e2e-utts", "0", "--no-fp32-leg")
+    assert d["config"]["utts_per_gpu"] == 125000 and d["config"]["batches_per_step"] > 100
+    assert 36e6 < d["config"]["frames_per_gpu"] < 39e6 and d["value"] > 20000 and "fp32_exact" not in d and "e2e_ark_to_ark" not in d
+    assert d["with_ark_write"]["ark_mb"] > 250
 
 
 def test_fp32_and_training_bench_lines():

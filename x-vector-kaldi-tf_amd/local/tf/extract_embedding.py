@@ -171,18 +171,19 @@ def _scp_shard(spec, rank, world, vad_spec=None):
     """Lines [n*rank/world, n*(rank+1)/world) of the scp behind 'scp:FILE' as a text stream: contiguous, so concatenating the
     ranks' outputs in rank order restores the input order (the role of utils/split_data.sh + split_scp.pl in
     extract_xvectors.sh:63-65).  With ``vad_spec`` (also an scp table) the second value is the VAD scp restricted to the same
-    keys, in the same order."""
+    keys, in the same order.  Third value: the key lists of ALL shards (every rank can tell which utterances its peers hold,
+    so the final exchange carries no keys)."""
     import io
     lines = _scp_lines(spec)
-    lo, hi = len(lines) * rank // world, len(lines) * (rank + 1) // world
-    mine = lines[lo:hi]
+    cuts = [len(lines) * r // world for r in range(world + 1)]
+    shard_keys = [[ln.split(None, 1)[0] for ln in lines[cuts[r]:cuts[r + 1]]] for r in range(world)]
+    mine = lines[cuts[rank]:cuts[rank + 1]]
     if vad_spec is None:
-        return io.StringIO("".join(mine)), None
+        return io.StringIO("".join(mine)), None, shard_keys
     table = {}
     for ln in _scp_lines(vad_spec):
         table[ln.split(None, 1)[0]] = ln if ln.endswith("\n") else ln + "\n"
-    keys = [ln.split(None, 1)[0] for ln in mine]
-    return io.StringIO("".join(mine)), io.StringIO("".join(table[k] for k in keys if k in table))
+    return io.StringIO("".join(mine)), io.StringIO("".join(table[k] for k in shard_keys[rank] if k in table)), shard_keys
 
 
 def _is_scp_table(rspecifier):
@@ -201,11 +202,12 @@ def eval_dnn(args):
     # end brings the x-vectors to rank 0; any other rspecifier (ark stream, pipe) is read by every rank and sharded per window
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     root = rank == 0
-    presharded = world > 1 and _is_scp_table(args.feature_rspecifier) and \
+    grouped = world > 1 or (os.environ.get("XV_FORCE_DIST") == "1" and "RANK" in os.environ)     # the latter: 1-rank group (tests)
+    presharded = grouped and _is_scp_table(args.feature_rspecifier) and \
         (not args.vad_rspecifier or _is_scp_table(args.vad_rspecifier))
     model = Model()
     if presharded:
-        feat_scp, vad_scp = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
+        feat_scp, vad_scp, shard_keys = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
         feats = kaldi_io.MatScp(feat_scp)
         vad = kaldi_io.VecScp(vad_scp) if vad_scp is not None else None
     else:
@@ -218,7 +220,7 @@ def eval_dnn(args):
                                  args.chunk_size, use_gpu, logger, vad_stream=vad, cmn_window=args.cmn_window,
                                  cmn_center=args.cmn_center == 'yes', distributed=not presharded)
     if presharded:
-        _gather_and_write(model, collector, wspecifier, ark, scp, rank, world)
+        _gather_and_write(model, collector, shard_keys, wspecifier, ark, scp, rank, world)
     if not root:
         return
     if ark is not None:
@@ -234,25 +236,38 @@ def eval_dnn(args):
         os.remove(scp + '.tmp.scp')
 
 
-def _gather_and_write(model, collector, wspecifier, ark, scp, rank, world):
-    """The single exchange of the sharded mode: keys as objects, vectors as ONE padded gather (xvector_amd.dist), then
-    rank 0 writes the shards in rank order = input order."""
+def _gather_and_write(model, collector, shard_keys, wspecifier, ark, scp, rank, world):
+    """The single exchange of the sharded mode (extract_xvectors.sh:92-95 concatenates the jobs' outputs; here ONE RCCL
+    gather does).  Every rank knows every shard's key list -- the line ranges of the scp are deterministic -- so only
+    numbers travel: rank r sends one row per utterance of ITS shard, in scp order, ``[emitted? | x-vector]``; the blocks
+    are padded to the largest shard so that a single fixed-shape ``dist.gather`` moves everything (xvector_amd.dist).
+    Rank 0 reads the flags (utterances rejected for their length or by the VAD emitted nothing), pairs the rest with the
+    keys it already has and writes the shards in rank order = input order."""
     import numpy as np
     import torch
-    import torch.distributed as dist
     from xvector_amd import dist as xdist
     dim, dev = model.device_model.embed_dim, model.device_model.device
-    local = np.concatenate(collector.blocks) if collector.blocks else np.zeros((0, dim), np.float32)
-    counts = [None] * world
-    dist.all_gather_object(counts, len(collector.keys))
-    keys = [None] * world if rank == 0 else None
-    dist.gather_object(collector.keys, keys, dst=0)
-    blocks = xdist.gather_blocks(torch.from_numpy(local).to(dev), counts, 0)
+    mine = shard_keys[rank]
+    block = np.zeros((len(mine), dim + 1), np.float32)
+    if collector.keys:
+        # the emitted keys are a subsequence of the shard's keys (make_embedding keeps input order)
+        rows, j = np.empty(len(collector.keys), np.int64), 0
+        for i, k in enumerate(mine):
+            if j < len(rows) and collector.keys[j] == k:
+                rows[j] = i
+                j += 1
+        if j != len(rows):
+            raise RuntimeError("sharded extraction: emitted keys are not a subsequence of the shard's scp keys")
+        block[rows, 0] = 1.0
+        block[rows, 1:] = np.concatenate(collector.blocks)
+    blocks = xdist.gather_blocks(torch.from_numpy(block).to(dev), [len(k) for k in shard_keys], 0)
     if rank == 0:
         with _open_output(wspecifier, ark, scp) as output_fid:
             for r in range(world):
-                kaldi_io.write_vec_flt_batch(output_fid, keys[r], blocks[r].cpu().numpy())
-    dist.barrier()
+                got = blocks[r].cpu().numpy()
+                emitted = got[:, 0] > 0.5
+                kaldi_io.write_vec_flt_batch(output_fid, [k for k, ok in zip(shard_keys[r], emitted.tolist()) if ok],
+                                             np.ascontiguousarray(got[emitted, 1:]))
 
 
 def main(argv=None):

@@ -216,6 +216,29 @@ class Model(object):
             logger.info(line)
         logger.info(meter.elapsed_line())
 
+    def _exchange_shards(self, stash, rank, world, min_chunk_size, chunk_size, emit):
+        """The one collective of the multi-GPU stream mode: every rank contributes the x-vectors of its shares of all
+        windows as one block (counts follow from the deterministic partitions, so nothing but vectors travels); rank 0 cuts
+        the blocks back into windows, restores the input order and emits them."""
+        import torch
+        from xvector_amd import dist as xdist
+        dim, dev = self.device_model.embed_dim, self.device_model.device
+        counts = [int(sum(len(sh[r]) for _, _, sh, _ in stash)) for r in range(world)]
+        local = np.concatenate([v for _, _, _, v in stash]) if stash and counts[rank] else np.zeros((0, dim), np.float32)
+        blocks = xdist.gather_blocks(torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32)).to(dev), counts, 0)
+        if rank != 0:
+            return
+        blocks = [b.cpu().numpy() for b in blocks]
+        at = [0] * world
+        for keys, lens, shards, _ in stash:
+            full = np.zeros((len(keys), dim), np.float32)
+            for r in range(world):
+                n = len(shards[r])
+                full[shards[r]] = blocks[r][at[r]:at[r] + n]
+                at[r] += n
+            valid = np.array([bool(engine.plan_chunks(int(t), min_chunk_size, chunk_size)) for t in lens], dtype=bool)
+            emit(keys, lens, full, valid)
+
     # -- the hot path ------------------------------------------------------------------------------
     def make_embedding(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger,
                        vad_stream=None, cmn_window=0, cmn_center=True, distributed=True):
@@ -239,9 +262,12 @@ class Model(object):
         num_success = 0
         compute_time = 0.0
 
-        # Multi-GPU (one process per GPU, torchrun): every rank reads the same stream, extracts only its
-        # frame-balanced shard of each window and ONE gather per window brings the x-vectors to rank 0, which
-        # alone writes (the role of split_data.sh + nj jobs + `cat xvector.*.scp`, extract_xvectors.sh:63-95).
+        # Multi-GPU (one process per GPU, torchrun) on a stream nobody can split (ark file, pipe): every rank reads the same
+        # stream and extracts only its frame-balanced share of each window -- the partition follows from the lengths, so it
+        # needs no communication -- keeps its x-vectors, and ONE gather at the very end brings them to rank 0, which restores
+        # the input order and alone writes (the role of split_data.sh + nj jobs + `cat xvector.*.scp`,
+        # extract_xvectors.sh:63-95).  An scp table is better served by extract_embedding.py's line-range sharding, where
+        # the ranks do not even parse each other's utterances.
         from xvector_amd import dist as xdist
         rank, world = xdist.init_process_group()
         if not distributed:
@@ -254,25 +280,11 @@ class Model(object):
             if world == 1:
                 handle = ex.submit(mats, addrs)                   # packed, copied and launched; results are collected later
                 return lambda: ex.finish(handle, as_array=True)
-            import torch
-            dev = self.device_model.device
             lens = [m.shape[0] for m in mats]
-            dim = self.device_model.embed_dim
-
-            def shard_fn(idx):
-                vecs = ex.extract([mats[i] for i in idx])
-                out = torch.zeros((len(idx), dim), dtype=torch.float32)
-                for j, v in enumerate(vecs):
-                    if v is not None:
-                        out[j] = torch.from_numpy(v)
-                return out.to(dev)
-
-            full = xdist.sharded_extract(lens, shard_fn, dim, dev)
-            if rank != 0:
-                return lambda: None
-            host = full.cpu().numpy()
-            valid = np.array([bool(engine.plan_chunks(t, min_chunk_size, chunk_size)) for t in lens], dtype=bool)
-            return lambda: (host, valid)
+            shards = xdist.partition_lpt(lens, world)
+            idx = shards[rank].tolist()
+            handle = ex.submit([mats[i] for i in idx], None if addrs is None else addrs[shards[rank]])
+            return lambda: ("shard", shards, ex.finish(handle, as_array=True)[0])
 
         def submit(keys, mats, vads=None, addrs=None):
             """Front-end (optional) + everything up to the kernel launches of one window; returns what ``collect`` needs:
@@ -320,9 +332,14 @@ class Model(object):
             t0 = time.time()
             out = result()
             compute_time += time.time() - t0
-            if out is None:                       # non-root rank: nothing to write
+            if len(out) == 3:                     # multi-GPU: this rank's share of the window; exchanged once, at the end
+                stash.append((keys, lens, out[1], out[2]))
                 return
-            vecs, valid = out
+            emit(keys, lens, *out)
+
+        def emit(keys, lens, vecs, valid):
+            """Warn about rejected utterances, hand the rest to the writer thread."""
+            nonlocal num_fail, num_success
             if not valid.all():
                 for i in np.flatnonzero(~valid).tolist():
                     if lens[i] == 0:
@@ -429,6 +446,7 @@ class Model(object):
         # software pipeline of depth 2 over the windows: the host work of window i+1 (packing, H2D, launches) is issued
         # before the vectors of window i are awaited and written, so the GPU never waits for the writer
         in_flight = None
+        stash = []                                  # multi-GPU: (keys, lens, shards, local vectors) per window
         try:
             while True:
                 item = windows.get()
@@ -446,6 +464,8 @@ class Model(object):
                 in_flight = nxt
             if in_flight is not None:
                 collect(*in_flight)
+            if world > 1:
+                self._exchange_shards(stash, rank, world, min_chunk_size, chunk_size, emit)
         finally:
             out_q.put(None)
             writer_thread.join()                    # the caller closes output_stream right after we return

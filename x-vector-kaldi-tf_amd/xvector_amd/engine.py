@@ -202,11 +202,14 @@ class DeviceModel(object):
 
     POOL_SPLIT_ROWS = 512
 
-    def __init__(self, weights, topo, device="cuda:0", embedding_index=0, precision="bf16x3", fused_pool=None):
+    def __init__(self, weights, topo, device="cuda:0", embedding_index=0, precision="bf16x3", fused_pool=None, pair_kernel=None):
         """precision: "fp32" = exact fp32 MFMA GEMMs; "bf16x3" = split-precision bf16 MFMA GEMMs (fp32-class
         accuracy, ~3e-6 rel-L2 on the x-vector; see include/xvector_hip.h).  fused_pool (default: on for bf16x3): the
         last frame-level layer reduces its output to 8-row block statistics in the GEMM epilogue instead of storing it
-        (xv_tdnn_layer_pool_bf16x3); batches must then be laid out with ``align`` = 8."""
+        (xv_tdnn_layer_pool_bf16x3); batches must then be laid out with ``align`` = 8.  pair_kernel (default: on with
+        fused_pool when the last two layers have kernel size 1 and a shape xv_tdnn_pair_pool_bf16x3 supports;
+        XVECTOR_PAIR_KERNEL=0 turns it off): those two layers and the block statistics run as one launch whose
+        intermediate activation stays in registers."""
         import torch
         hiplib.require_gpu()
         assert precision in ("fp32", "bf16x3")
@@ -254,6 +257,16 @@ class DeviceModel(object):
                     self.last_halves = [self._prep(weights, sc, weights[sc + "/w:0"], k, d, cols=slice(a, a + A)) for a in (0, A)]
                 else:
                     self.att["wp"] = hiplib.pack_weights(self._dev(aw))
+            self.pair = None
+            want_pair = (os.environ.get("XVECTOR_PAIR_KERNEL", "1") != "0") if pair_kernel is None else bool(pair_kernel)
+            if want_pair and self.fused_pool and len(self.layers) >= 3:
+                La, Lb = self.layers[-2], self.layers[-1]
+                if La["K"] == 1 and Lb["K"] == 1 and hiplib.pair_supported(La["cin"], La["cout"], Lb["cout"]):
+                    n = len(self.layers)
+                    wa = weights["frame_level_info_layer-%d/w:0" % (n - 2)][0]
+                    wb = weights["frame_level_info_layer-%d/w:0" % (n - 1)][0]
+                    self.pair = hiplib.pack_pair_bf16x3(self._dev(wa), self._dev(wb))
+            assert not (pair_kernel and self.pair is None), "pair_kernel=True but the topology / precision does not allow it"
             self.embed = []
             for j in range(len(topo["embedding_sizes"])):
                 sc = "embed_layer-%d" % j
@@ -351,6 +364,11 @@ class DeviceModel(object):
             events[0].record()
         for i, L in enumerate(self.layers):
             last = i == len(self.layers) - 1
+            if self.pair is not None and i == len(self.layers) - 2:
+                Lb = self.layers[-1]
+                hiplib.tdnn_pair_pool(h, R, self.pair, (L["bias"], L["scale"], L["shift"], L["alpha"]),
+                                      (Lb["bias"], Lb["scale"], Lb["shift"], Lb["alpha"]), self.act, row_valid, self._last)
+                break
             if last and self.fused_pool:
                 hiplib.tdnn_layer_pool(h, R, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"],
                                        row_valid, self._last)
