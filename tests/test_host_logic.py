@@ -303,12 +303,13 @@ def test_cli_scp_sharding_helpers(tmp_path):
     for world in (1, 3, 4):
         got = []
         for r in range(world):
-            f, v = cli._scp_shard("scp:%s" % feats, r, world, "scp:%s" % vad)
+            f, v, all_keys = cli._scp_shard("scp:%s" % feats, r, world, "scp:%s" % vad)
             fk = [ln.split()[0] for ln in f.read().splitlines()]
+            assert all_keys[r] == fk and sum(all_keys, []) == keys       # every rank knows every shard's keys: no key exchange
             vk = [ln.split()[0] for ln in v.read().splitlines()]
             assert vk == [k for k in fk if k != "utt04"]                  # same order as the feature shard
             got += fk
         assert got == keys
         seen.append(got)
-    f, v = cli._scp_shard("scp:%s" % feats, 0, 2)
-    assert v is None and len(f.read().splitlines()) == 5
+    f, v, all_keys = cli._scp_shard("scp:%s" % feats, 0, 2)
+    assert v is None and len(f.read().splitlines()) == 5 and [len(k) for k in all_keys] == [5, 6]

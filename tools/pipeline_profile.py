@@ -37,6 +37,7 @@ def timed(obj, name, label):
     setattr(obj, name, g)
 
 
+timed(models.Model, "load_model", "load_model")
 timed(engine.BatchLayout, "pack", "pack")
 timed(engine.BatchLayout, "row_valid", "row_valid")
 timed(engine.DeviceModel, "frame_level", "frame_level (launches)")
@@ -59,8 +60,8 @@ def sync(self):
     t0 = time.perf_counter(); _sync(self); T["event wait (staging set busy)"] = T.get("event wait (staging set busy)", 0.0) + time.perf_counter() - t0
 torch.cuda.Event.synchronize = sync
 _blocks = kaldi_io.read_mat_ark_blocks
-def blocks(fd):
-    it = _blocks(fd)
+def blocks(fd, alloc=None):
+    it = _blocks(fd, alloc)
     while True:
         t0 = time.perf_counter()
         try:
@@ -72,6 +73,8 @@ def blocks(fd):
         yield item
 kaldi_io.read_mat_ark_blocks = blocks
 log = logging.getLogger("p"); log.addHandler(logging.NullHandler())
+if os.environ.get("XV_FIRST_WINDOW"):
+    models.Model.first_window_frames = int(os.environ["XV_FIRST_WINDOW"])
 m = models.Model()
 m.make_embedding(io.BytesIO(raw[:cut]), io.BytesIO(), mdir, 25, 10000, True, log)       # warm-up
 T.clear()

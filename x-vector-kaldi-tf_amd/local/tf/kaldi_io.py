@@ -202,6 +202,97 @@ class _BufferedStream(object):
         self.fd.close()
 
 
+class _ArenaStream(_BufferedStream):
+    """The read-ahead of the BLOCK readers: ONE recycled byte arena filled with ``readinto`` in 64 MiB reads.  The plain
+    ``_BufferedStream`` builds a fresh ``bytes`` object per refill (``read`` + ``join``): at ark rates of GB/s the page faults
+    of those ever-new buffers and the extra copy cost more than the parsing itself.  Valid bytes are ``arena[pos:end]``;
+    ``addr`` is the arena's address for the native scanner / gatherer."""
+
+    BLOCK = 1 << 26
+
+    def __init__(self, fd):
+        self.fd = fd
+        self.buf = b""                                   # (unused: the arena replaces it)
+        self.pos = self.end = 0
+        self._alloc(self.BLOCK + (1 << 20))
+
+    def _alloc(self, cap):
+        self.arena = bytearray(cap)
+        self._pin = (ctypes.c_char * cap).from_buffer(self.arena)          # also keeps the bytearray from being resized
+        self.addr = ctypes.addressof(self._pin)
+        self.view = memoryview(self.arena)
+
+    def _fill(self, need):
+        avail = self.end - self.pos
+        if avail >= need:
+            return
+        if need > len(self.arena):                       # one record larger than the arena: grow, keep the unread bytes
+            old = self.view[self.pos:self.end]
+            keep = bytes(old)
+            del old
+            self.view.release()
+            del self._pin
+            self._alloc(max(need + (1 << 20), 2 * len(self.arena)))
+            self.arena[:avail] = keep
+            self.pos, self.end = 0, avail
+        elif self.pos:
+            self.arena[:avail] = self.arena[self.pos:self.end]              # unread tail to the front (usually < one record)
+            self.pos, self.end = 0, avail
+        readinto = getattr(self.fd, "readinto", None)
+        while self.end - self.pos < need or self.end == avail:
+            if readinto is not None:
+                got = readinto(self.view[self.end:])
+            else:
+                blk = self.fd.read(len(self.arena) - self.end)
+                got = len(blk) if blk else 0
+                if got:
+                    self.arena[self.end:self.end + got] = blk
+            if not got:
+                break
+            self.end += got
+            if self.end == len(self.arena):
+                break
+
+    def read(self, n=-1):
+        if n is None or n < 0:
+            rest = bytes(self.view[self.pos:self.end]) + self.fd.read()
+            self.pos = self.end = 0
+            return rest
+        self._fill(n)
+        out = bytes(self.view[self.pos:min(self.pos + n, self.end)])
+        self.pos += len(out)
+        return out
+
+    def _until(self, sep, keep_sep):
+        while True:
+            i = self.arena.find(sep, self.pos, self.end)
+            if i >= 0:
+                out = bytes(self.view[self.pos:i + (1 if keep_sep else 0)])
+                self.pos = i + 1
+                return out
+            before = self.end - self.pos
+            self._fill(before + 1)
+            if self.end - self.pos == before:            # end of stream
+                out = bytes(self.view[self.pos:self.end])
+                self.pos = self.end
+                return out
+
+    def readline(self):
+        return self._until(b"\n", True)
+
+    def read_token(self):
+        return self._until(b" ", False)
+
+    def detach(self):
+        unread = self.end - self.pos
+        if unread:
+            try:
+                self.fd.seek(-unread, 1)
+            except Exception:
+                pass                                          # pipes: the read-ahead is simply dropped with the generator
+        self.pos = self.end = 0
+
+
 def _read_exact(fd, n):
     """fd.read(n) that tolerates short reads from pipes; returns fewer bytes only at EOF."""
     buf = fd.read(n)
@@ -543,14 +634,14 @@ def _host_lib():
             try:
                 lib = ctypes.CDLL(path)
                 lib.xv_ark_scan_fm.restype = ctypes.c_int
-                lib.xv_ark_scan_fm.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int] + \
+                lib.xv_ark_scan_fm.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int] + \
                     [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
                 if hasattr(lib, "xv_ark_scan_fv"):
                     lib.xv_ark_scan_fv.restype = ctypes.c_int
                     lib.xv_ark_scan_fv.argtypes = lib.xv_ark_scan_fm.argtypes
                 if hasattr(lib, "xv_ark_gather_fm"):
                     lib.xv_ark_gather_fm.restype = ctypes.c_int64
-                    lib.xv_ark_gather_fm.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                    lib.xv_ark_gather_fm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                      ctypes.c_void_p]
                 _HOST_LIB = lib
             except OSError:
@@ -597,58 +688,68 @@ def _scan_fm_records(fd, lib):
                 return
 
 
-def read_mat_ark_blocks(file_or_fd):
+def read_mat_ark_blocks(file_or_fd, alloc=None):
     """Generator of (keys, feats[sum T, F] float32, offsets[n+1]) over an ark stream: utterance i of a block is
     ``feats[offsets[i]:offsets[i+1]]``.  Runs of binary float matrices with one column count come out as ONE block per
-    scanner pass (<= 8192 records) whose payloads are gathered by a single native, GIL-free call -- the per-utterance
-    Python work of ``read_mat_ark`` (generator switch, frombuffer, copy) is what bounded the ark->ark rate.  Any other
-    record (or a stream without the host library) is returned as a one-utterance block via the generic reader."""
-    return _read_ark_blocks(file_or_fd, "xv_ark_scan_fm", lambda fd: np.ascontiguousarray(read_mat(fd), dtype=np.float32))
+    scanner pass (<= 8192 records or one 64 MiB arena) whose payloads are gathered by a single native, GIL-free call -- the
+    per-utterance Python work of ``read_mat_ark`` (generator switch, frombuffer, copy) is what bounded the ark->ark rate.
+    ``alloc(rows, cols)`` may supply the float32 storage of a block (callers that recycle their buffers; default: a fresh
+    array).  Any other record (or a stream without the host library) is returned as a one-utterance block via the generic
+    reader."""
+    return _read_ark_blocks(file_or_fd, "xv_ark_scan_fm", lambda fd: np.ascontiguousarray(read_mat(fd), dtype=np.float32), alloc)
 
 
-def read_vec_flt_ark_blocks(file_or_fd):
+def read_vec_flt_ark_blocks(file_or_fd, alloc=None):
     """The same for float vectors (e.g. a VAD table): generator of (keys, values[sum dim] float32, offsets[n+1])."""
     for keys, vals, offsets in _read_ark_blocks(file_or_fd, "xv_ark_scan_fv",
-                                                lambda fd: np.ascontiguousarray(read_vec_flt(fd), dtype=np.float32).reshape(-1, 1)):
+                                                lambda fd: np.ascontiguousarray(read_vec_flt(fd), dtype=np.float32).reshape(-1, 1),
+                                                alloc):
         yield keys, vals.reshape(-1), offsets
 
 
-def _read_ark_blocks(file_or_fd, scan_name, read_one):
+def _read_ark_blocks(file_or_fd, scan_name, read_one, alloc=None):
     raw = open_or_fd(file_or_fd)
-    fd = raw if isinstance(raw, _BufferedStream) else _BufferedStream(raw)
     lib = _host_lib()
     if lib is not None and not (hasattr(lib, "xv_ark_gather_fm") and hasattr(lib, scan_name)):
         lib = None
-    scan = getattr(lib, scan_name) if lib is not None else None
+    if isinstance(raw, _BufferedStream):
+        fd = raw
+    else:
+        fd = _ArenaStream(raw) if lib is not None else _BufferedStream(raw)
+    fast = lib is not None and isinstance(fd, _ArenaStream)
+    if alloc is None:
+        alloc = lambda r, c: np.empty((r, c), np.float32)
     try:
-        if lib is not None and hasattr(lib, "xv_ark_gather_fm"):
+        if fast:
+            scan = getattr(lib, scan_name)
             key_off = np.empty(_SCAN_MAX, np.int64); key_len = np.empty(_SCAN_MAX, np.int32)
             data_off = np.empty(_SCAN_MAX, np.int64); rows = np.empty(_SCAN_MAX, np.int32); cols = np.empty(_SCAN_MAX, np.int32)
             nxt, stop = ctypes.c_size_t(0), ctypes.c_int(0)
         while True:
-            if lib is not None and hasattr(lib, "xv_ark_gather_fm"):
+            if fast:
                 want = 1
                 while True:
                     fd._fill(want)
-                    buf, pos = fd.buf, fd.pos
-                    if len(buf) == pos:
+                    if fd.end == fd.pos:
                         break
-                    n = scan(buf, pos, len(buf), _SCAN_MAX, key_off.ctypes.data, key_len.ctypes.data,
+                    n = scan(fd.addr, fd.pos, fd.end, _SCAN_MAX, key_off.ctypes.data, key_len.ctypes.data,
                              data_off.ctypes.data, rows.ctypes.data, cols.ctypes.data, ctypes.byref(nxt),
                              ctypes.byref(stop))
+                    arena = fd.arena
                     i0 = 0
                     while i0 < n:                               # split the pass where the column count changes
                         c = int(cols[i0])
                         same = np.flatnonzero(cols[i0:n] != c)
                         i1 = i0 + (int(same[0]) if len(same) else n - i0)
                         kos, kls = key_off[i0:i1].tolist(), key_len[i0:i1].tolist()
-                        keys = [buf[ko:ko + kl].decode().strip() for ko, kl in zip(kos, kls)]
+                        keys = [arena[ko:ko + kl].decode().strip() for ko, kl in zip(kos, kls)]
                         bad = [k for k in keys if _KEY_OK.match(k) is None]
                         assert not bad, "malformed key %r" % bad[0]
                         offsets = np.zeros(i1 - i0 + 1, np.int64)
                         np.cumsum(rows[i0:i1], out=offsets[1:])
-                        feats = np.empty((int(offsets[-1]), c), np.float32)
-                        lib.xv_ark_gather_fm(buf, data_off[i0:i1].ctypes.data, rows[i0:i1].ctypes.data, c, i1 - i0,
+                        feats = alloc(int(offsets[-1]), c)
+                        assert feats.dtype == np.float32 and feats.shape == (int(offsets[-1]), c) and feats.flags.c_contiguous
+                        lib.xv_ark_gather_fm(fd.addr, data_off[i0:i1].ctypes.data, rows[i0:i1].ctypes.data, c, i1 - i0,
                                              feats.ctypes.data)
                         fd.pos = int(data_off[i1 - 1]) + int(rows[i1 - 1]) * c * 4
                         yield keys, feats, offsets
@@ -657,10 +758,10 @@ def _read_ark_blocks(file_or_fd, scan_name, read_one):
                     if stop.value == 1:
                         break                                   # a different record type follows
                     if stop.value == 0:
-                        avail = len(buf) - fd.pos
-                        want = max(2 * avail, fd.BLOCK) if n == 0 else avail + 1
+                        avail = fd.end - fd.pos
+                        want = max(2 * avail, 1 << 22) if n == 0 else avail + 1
                         fd._fill(want)
-                        if len(fd.buf) - fd.pos == avail:       # nothing more to read
+                        if fd.end - fd.pos == avail:            # nothing more to read
                             break
             key = read_key(fd)                                  # generic path: one record of any supported type
             if not key:
@@ -744,7 +845,7 @@ class _ScpTable(object):
         for key, rx in self.entries:
             yield key, self._one(rx)
 
-    def blocks(self):
+    def blocks(self, alloc=None):
         ents, n, i = self.entries, len(self.entries), 0
         misses = 0
         while i < n:
@@ -762,7 +863,7 @@ class _ScpTable(object):
             got = 0
             with open(path, "rb") as f:
                 f.seek(start)
-                for bkeys, feats, off in type(self)._ark_blocks(f):
+                for bkeys, feats, off in type(self)._ark_blocks(f, alloc):
                     want = [k for k, _ in ents[i:min(i + len(bkeys), run)]]
                     same = 0
                     while same < len(want) and bkeys[same] == want[same]:

@@ -50,7 +50,8 @@ class Model(object):
     """Default topology: 5 frame-level layers [512,512,512,512,1536], kernels [5,5,7,1,1],
     statistics pooling, 2 segment-level layers (models.py:27-29)."""
 
-    window_frames = 1 << 21          # utterances are read from the stream in windows of ~2M frames
+    window_frames = 1 << 21          # utterances are read from the stream in windows of up to ~2M frames ...
+    first_window_frames = 1 << 18    # ... starting with one batch's worth and doubling (pipeline fill)
     max_batch_rows = 262144
 
     def __init__(self):
@@ -358,6 +359,26 @@ class Model(object):
         import queue
         import threading
         windows = queue.Queue(maxsize=2)
+        # Feature storage of the windows is recycled: a window's utterances are gathered by the scanner straight into one of
+        # a few long-lived [rows, F] buffers (no fresh pages per scanner pass -- at GB/s the page faults of ever-new arrays cost
+        # as much as the parsing); the main thread hands a buffer back once the window's batches are packed into the staging sets.
+        F_dim = self.device_model.feat_dim
+        pool_rows = int(self.window_frames) + (kaldi_io._ArenaStream.BLOCK // (4 * F_dim)) + 4096
+        pool = queue.Queue()
+        for _ in range(4):
+            pool.put(np.empty((pool_rows, F_dim), np.float32))
+        slab = {"buf": None, "used": 0}
+
+        def alloc(nrows, ncols):
+            if ncols != F_dim or nrows > pool_rows:
+                return np.empty((nrows, ncols), np.float32)            # (wrong width: rejected later with a clear error)
+            if slab["buf"] is None:
+                slab["buf"], slab["used"] = pool.get(), 0
+            if slab["used"] + nrows > pool_rows:
+                return np.empty((nrows, ncols), np.float32)            # rare: an oversized last block of a window
+            out = slab["buf"][slab["used"]:slab["used"] + nrows]
+            slab["used"] += nrows
+            return out
 
         def reader():
             try:
@@ -391,7 +412,8 @@ class Model(object):
                     # (keys, [matrices], [address of row 0]) per block: whole scanner passes gathered natively for ark
                     # streams, one utterance at a time for (key, matrix) iterators
                     if hasattr(input_stream, "read") or hasattr(input_stream, "blocks"):
-                        source = kaldi_io.read_mat_ark_blocks(input_stream) if hasattr(input_stream, "read") else input_stream.blocks()
+                        source = kaldi_io.read_mat_ark_blocks(input_stream, alloc) if hasattr(input_stream, "read") else \
+                            input_stream.blocks(alloc)
                         for bkeys, bfeats, off in source:
                             o = off.tolist()
                             base, row_bytes = bfeats.ctypes.data, bfeats.shape[1] * bfeats.itemsize if bfeats.ndim == 2 else 0
@@ -404,19 +426,25 @@ class Model(object):
                 def put():
                     F = self.device_model.feat_dim          # anything else goes down the checked NumPy packing path and raises there
                     ok = all(m.ndim == 2 and m.shape[1] == F and m.dtype == np.float32 for m in mats)
-                    windows.put((keys, mats, vads if vad_it is not None else None, np.array(addrs, dtype=np.uint64) if ok else None))
+                    windows.put((keys, mats, vads if vad_it is not None else None, np.array(addrs, dtype=np.uint64) if ok else None,
+                                 slab["buf"]))
+                    slab["buf"] = None                      # the next window gathers into another buffer of the pool
 
+                # the first window is one batch's worth of frames so that the GPU starts after the first scanner pass instead
+                # of after ~2 M frames of parsing; windows then double up to window_frames (fewer, larger host round trips)
+                limit = min(self.window_frames, self.first_window_frames)
                 for bkeys, bmats, baddrs in blocks():
-                    # whole blocks are appended (a window closes at the first block boundary past window_frames)
+                    # whole blocks are appended (a window closes at the first block boundary past its frame limit)
                     keys.extend(bkeys)
                     mats.extend(bmats)
                     addrs.extend(baddrs)
                     if vad_it is not None:
                         vads.extend(vad_for(key) for key in bkeys)
                     frames += sum(m.shape[0] for m in bmats) if len(bmats) < 64 else int(np.sum([m.shape[0] for m in bmats]))
-                    if frames >= self.window_frames:
+                    if frames >= limit:
                         put()
                         keys, mats, vads, addrs, frames = [], [], [], [], 0
+                        limit = min(self.window_frames, 2 * limit)
                 if keys:
                     put()
                 windows.put(None)
@@ -456,9 +484,12 @@ class Model(object):
                     raise item
                 if writer_error:
                     raise writer_error[0]
-                keys, mats, vads, addrs = item
+                keys, mats, vads, addrs, held = item
                 total_segments += len(keys)
                 nxt = submit(keys, mats, vads, addrs)
+                del mats, item
+                if held is not None:
+                    pool.put(held)                          # every batch of the window is packed: the reader may refill it
                 if in_flight is not None:
                     collect(*in_flight)
                 in_flight = nxt
