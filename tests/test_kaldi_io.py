@@ -345,3 +345,63 @@ def test_vector_block_reader_and_vector_scp_table(tmp_path):
     assert [k for k, _ in got2] == [k for k, _ in want]
     assert all(np.array_equal(g, np.asarray(w_, np.float32)) for (_, g), (_, w_) in zip(got2, want))
     assert [(k, v.tolist()) for k, v in table] == [(k, np.asarray(v, np.float32).tolist()) for k, v in kaldi_io.read_vec_flt_scp(scp)]
+
+
+def test_in_place_windows_equal_the_record_reader(tmp_path):
+    """scan_mat_ark_windows / MatScp.windows: the matrices are used where the stream was read to (ArkArena), nothing is
+    gathered -- every arena size (records cut by the arena's end are carried over, a record larger than an arena and a
+    double-precision record go through the generic reader, a column-count change inside an arena splits the item), the short
+    first fill, a truncated stream, early close handing the unread bytes back, and an scp table with a gap in it."""
+    import io
+    if kaldi_io._host_lib() is None:
+        pytest.skip("host library not built")
+    rng = np.random.default_rng(0)
+    bio = io.BytesIO()
+    mats = []
+    for i in range(300):
+        T, F = int(rng.integers(0, 60)), (23 if i < 250 else 5)
+        m = rng.standard_normal((T, F)).astype(np.float32)
+        kaldi_io.write_mat(bio, m.astype(np.float64) if i == 100 else m, key="k%d" % i)
+        mats.append(m)
+    data = bio.getvalue()
+    for cap, first in ((1 << 20, None), (20000, None), (9000, 3000), (700, None), (6000, 100)):
+        arenas = []
+
+        def take():
+            arenas.append(kaldi_io.ArkArena(cap))
+            return arenas[-1]
+        got, holders = [], []
+        for keys, addr, rows, cols, holder in kaldi_io.scan_mat_ark_windows(io.BytesIO(data), take, first):
+            am = kaldi_io.ArkMats()
+            am.add(addr, rows, cols, holder)
+            assert len(am) == len(keys) and am.uniform_cols() == cols and am.frames() == int(np.sum(rows))
+            got += [(k, np.array(am[j])) for j, k in enumerate(keys)]
+            if isinstance(holder, kaldi_io.ArkArena):
+                assert all(holder is not h for h in holders)       # an arena is handed out with exactly one item
+                holders.append(holder)
+        assert [k for k, _ in got] == ["k%d" % i for i in range(300)], cap
+        assert all(a.shape == b.shape and np.array_equal(a.astype(np.float32), b) for (_, a), b in zip(got, mats))
+    with pytest.raises(Exception):
+        list(kaldi_io.scan_mat_ark_windows(io.BytesIO(data[:-7]), lambda: kaldi_io.ArkArena(1 << 20)))
+    f = io.BytesIO(data)
+    g = kaldi_io.scan_mat_ark_windows(f, lambda: kaldi_io.ArkArena(20000))
+    first_keys = next(g)[0]
+    g.close()
+    rest = list(kaldi_io.read_mat_ark(f))
+    assert rest[0][0] == "k%d" % len(first_keys) and len(first_keys) + len(rest) == 300
+    # scp table: in-order run, one entry skipped (the run ends there and restarts), everything verified against the keys
+    ark, scp = str(tmp_path / "f.ark"), str(tmp_path / "f.scp")
+    with kaldi_io.TableWriter(ark, scp) as tw:
+        for i in range(120):
+            kaldi_io.write_mat(tw, mats[i] if i != 100 else mats[i].astype(np.float64), key="k%d" % i)
+    lines = open(scp).read().splitlines()
+    sub = str(tmp_path / "sub.scp")
+    open(sub, "wt").write("\n".join(l for i, l in enumerate(lines) if i != 57) + "\n")
+    got = []
+    for keys, addr, rows, cols, holder in kaldi_io.MatScp(sub).windows(lambda: kaldi_io.ArkArena(30000)):
+        am = kaldi_io.ArkMats()
+        am.add(addr, rows, cols, holder)
+        got += [(k, np.array(am[j])) for j, k in enumerate(keys)]
+    want = [i for i in range(120) if i != 57]
+    assert [k for k, _ in got] == ["k%d" % i for i in want]
+    assert all(np.array_equal(a.astype(np.float32), mats[i]) for (_, a), i in zip(got, want))

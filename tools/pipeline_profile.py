@@ -59,9 +59,9 @@ _sync = torch.cuda.Event.synchronize
 def sync(self):
     t0 = time.perf_counter(); _sync(self); T["event wait (staging set busy)"] = T.get("event wait (staging set busy)", 0.0) + time.perf_counter() - t0
 torch.cuda.Event.synchronize = sync
-_blocks = kaldi_io.read_mat_ark_blocks
-def blocks(fd, alloc=None):
-    it = _blocks(fd, alloc)
+_blocks = kaldi_io.scan_mat_ark_windows
+def blocks(fd, take_arena, first_fill=None):
+    it = _blocks(fd, take_arena, first_fill)
     while True:
         t0 = time.perf_counter()
         try:
@@ -69,19 +69,51 @@ def blocks(fd, alloc=None):
         except StopIteration:
             return
         finally:
-            T["ark scan + gather [reader]"] = T.get("ark scan + gather [reader]", 0.0) + time.perf_counter() - t0
+            T["ark read + scan [reader]"] = T.get("ark read + scan [reader]", 0.0) + time.perf_counter() - t0
         yield item
-kaldi_io.read_mat_ark_blocks = blocks
+kaldi_io.scan_mat_ark_windows = blocks
+# GPU-side span: first frame_level launch .. last chunk_average, and wall-clock marks of the main thread
+_fl = engine.DeviceModel.frame_level
+marks = {}
+def fl(self, *a, **k):
+    if "gpu_first" not in marks:
+        marks["gpu_first"] = torch.cuda.Event(enable_timing=True); marks["gpu_first"].record(); marks["t_first_launch"] = time.perf_counter()
+    return _fl(self, *a, **k)
+engine.DeviceModel.frame_level = fl
+_fin = engine.Extractor.finish
+def fin(self, h, as_array=False):
+    r = _fin(self, h, as_array)
+    marks["gpu_last"] = torch.cuda.Event(enable_timing=True); marks["gpu_last"].record(); marks["t_last_finish"] = time.perf_counter()
+    return r
+engine.Extractor.finish = fin
+def stamp(obj, name, label):
+    f = getattr(obj, name)
+    def g(*a, **k):
+        marks.setdefault(label + " start", time.perf_counter())
+        try:
+            return f(*a, **k)
+        finally:
+            marks.setdefault(label + " end", time.perf_counter())
+    setattr(obj, name, g)
+stamp(models.Model, "load_model", "load_model")
+stamp(engine.Extractor, "submit", "first submit")
+stamp(engine.Extractor, "_staging", "first _staging")
+stamp(engine.DeviceModel, "reserve", "first reserve")
+stamp(kaldi_io, "arena_acquire", "first arena_acquire")
 log = logging.getLogger("p"); log.addHandler(logging.NullHandler())
 if os.environ.get("XV_FIRST_WINDOW"):
     models.Model.first_window_frames = int(os.environ["XV_FIRST_WINDOW"])
 m = models.Model()
 m.make_embedding(io.BytesIO(raw[:cut]), io.BytesIO(), mdir, 25, 10000, True, log)       # warm-up
-T.clear()
+T.clear(); marks.clear()
 t0 = time.perf_counter()
 out = io.BytesIO()
 m.make_embedding(io.BytesIO(raw), out, mdir, 25, 10000, True, log)
 tot = time.perf_counter() - t0
 print("n=%d total %.3f s (%.0f utt/s)" % (n, tot, n / tot))
+torch.cuda.synchronize()
+print("  marks (s after start): " + ", ".join("%s %.3f" % (k, v - t0) for k, v in sorted(marks.items(), key=lambda kv: kv[1] if isinstance(kv[1], float) else 1e9) if isinstance(v, float)))
+print("  first launch at %.3f s, last finish returned at %.3f s, GPU span first launch -> after last finish %.3f s" %
+      (marks["t_first_launch"] - t0, marks["t_last_finish"] - t0, marks["gpu_first"].elapsed_time(marks["gpu_last"]) * 1e-3))
 for k, v in sorted(T.items(), key=lambda kv: -kv[1]):
     print("  %-36s %.3f s" % (k, v))

@@ -18,7 +18,7 @@
 
 extern "C" {
 
-int xv_host_version(void) { return 5; }
+int xv_host_version(void) { return 6; }
 
 // Scans buf[pos, len).  Fills up to max_records entries; returns the number of records found.
 // *next = offset of the first byte not consumed; *stop = 0 buffer exhausted / record incomplete (need more data),
@@ -93,6 +93,33 @@ int xv_ark_scan_fv(const uint8_t *buf, size_t pos, size_t len, int max_records, 
     if (n == max_records) *stop = 2;
     *next = pos;
     return n;
+}
+
+// The keys of n scanned records, whitespace-stripped, validated against Kaldi's key alphabet [./a-zA-Z0-9_-]+ and written
+// back to back with '\n' separators (no trailing separator): ONE decode + split in Python instead of a slice, a decode, a
+// strip and a regular-expression match per utterance (that loop held the interpreter lock for milliseconds per window).
+// Returns the number of bytes written, or -(i+1) when key i is empty / malformed / does not fit (the caller then takes the
+// per-key path, which reports it).
+int64_t xv_ark_keys(const uint8_t *buf, const int64_t *key_off, const int32_t *key_len, int n, uint8_t *out, int64_t cap)
+{
+    int64_t w = 0;
+    for (int i = 0; i < n; ++i) {
+        const uint8_t *k = buf + key_off[i];
+        int32_t len = key_len[i];
+        while (len > 0 && (*k == ' ' || *k == '\n' || *k == '\r' || *k == '\t')) { ++k; --len; }
+        while (len > 0 && (k[len - 1] == ' ' || k[len - 1] == '\n' || k[len - 1] == '\r' || k[len - 1] == '\t')) --len;
+        if (len <= 0 || w + len + 1 > cap) return -(int64_t)(i + 1);
+        for (int32_t j = 0; j < len; ++j) {
+            const uint8_t c = k[j];
+            const bool ok = (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '.' || c == '/' ||
+                            c == '_' || c == '-';
+            if (!ok) return -(int64_t)(i + 1);
+            out[w + j] = c;
+        }
+        w += len;
+        if (i + 1 < n) out[w++] = '\n';
+    }
+    return w;
 }
 
 // Copies the payloads of n scanned records (data_off[i], rows[i] x cols float32, all with the same column count) back to

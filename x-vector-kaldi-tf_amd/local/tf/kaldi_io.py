@@ -639,6 +639,10 @@ def _host_lib():
                 if hasattr(lib, "xv_ark_scan_fv"):
                     lib.xv_ark_scan_fv.restype = ctypes.c_int
                     lib.xv_ark_scan_fv.argtypes = lib.xv_ark_scan_fm.argtypes
+                if hasattr(lib, "xv_ark_keys"):
+                    lib.xv_ark_keys.restype = ctypes.c_int64
+                    lib.xv_ark_keys.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_int64]
                 if hasattr(lib, "xv_ark_gather_fm"):
                     lib.xv_ark_gather_fm.restype = ctypes.c_int64
                     lib.xv_ark_gather_fm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
@@ -650,6 +654,23 @@ def _host_lib():
 
 
 _SCAN_MAX = 8192
+
+
+def _decode_keys(lib, addr, buf, key_off, key_len):
+    """Keys of the scanned records ``key_off`` / ``key_len`` (arrays) inside the block at ``addr`` (``buf`` = the same bytes as
+    an indexable object): one native pass + one decode/split when the host library has ``xv_ark_keys``, per key otherwise or
+    when a key is malformed (so that the assertion names it)."""
+    n = len(key_off)
+    if n and hasattr(lib, "xv_ark_keys"):
+        out = np.empty(int(key_len.sum()) + n, np.uint8)
+        ko, kl = np.ascontiguousarray(key_off, np.int64), np.ascontiguousarray(key_len, np.int32)
+        w = lib.xv_ark_keys(addr, ko.ctypes.data, kl.ctypes.data, n, out.ctypes.data, len(out))
+        if w >= 0:
+            return out[:w].tobytes().decode().split("\n")
+    keys = [bytes(buf[ko:ko + kl]).decode().strip() for ko, kl in zip(key_off.tolist(), key_len.tolist())]
+    bad = [k for k in keys if _KEY_OK.match(k) is None]
+    assert not bad, "malformed key %r" % bad[0]
+    return keys
 
 
 def _scan_fm_records(fd, lib):
@@ -741,10 +762,7 @@ def _read_ark_blocks(file_or_fd, scan_name, read_one, alloc=None):
                         c = int(cols[i0])
                         same = np.flatnonzero(cols[i0:n] != c)
                         i1 = i0 + (int(same[0]) if len(same) else n - i0)
-                        kos, kls = key_off[i0:i1].tolist(), key_len[i0:i1].tolist()
-                        keys = [arena[ko:ko + kl].decode().strip() for ko, kl in zip(kos, kls)]
-                        bad = [k for k in keys if _KEY_OK.match(k) is None]
-                        assert not bad, "malformed key %r" % bad[0]
+                        keys = _decode_keys(lib, fd.addr, arena, key_off[i0:i1], key_len[i0:i1])
                         offsets = np.zeros(i1 - i0 + 1, np.int64)
                         np.cumsum(rows[i0:i1], out=offsets[1:])
                         feats = alloc(int(offsets[-1]), c)
@@ -773,6 +791,212 @@ def _read_ark_blocks(file_or_fd, scan_name, read_one, alloc=None):
             raw.close()
         elif fd is not raw:
             fd.detach()
+
+
+# ------------------------------------------------------------------------------------------------
+# in-place windows: the utterances stay where the stream was read to
+# ------------------------------------------------------------------------------------------------
+class ArkArena(object):
+    """A long-lived read buffer of the in-place reader (``scan_mat_ark_windows``): the stream is read straight into it
+    (``readinto``) and the matrices of the records found there are used where they lie.  Anonymous mmap with transparent huge
+    pages where the kernel offers them: the first touch of a fresh arena is a page-fault storm otherwise (47 k faults per
+    192 MB), and arenas are recycled process-wide (``arena_acquire`` / ``arena_release``) so that it is paid once."""
+
+    def __init__(self, nbytes):
+        import mmap
+        self.buf = mmap.mmap(-1, int(nbytes))
+        if hasattr(self.buf, "madvise") and hasattr(mmap, "MADV_HUGEPAGE"):
+            try:
+                self.buf.madvise(mmap.MADV_HUGEPAGE)
+            except OSError:
+                pass
+        self._pin = (ctypes.c_char * len(self.buf)).from_buffer(self.buf)
+        self.addr = ctypes.addressof(self._pin)
+        self.view = memoryview(self.buf)
+
+    def __len__(self):
+        return len(self.buf)
+
+
+_ARENA_FREE = {}          # size -> idle arenas of this process (at most _ARENA_KEEP per size)
+_ARENA_KEEP = 6
+_ARENA_LOCK = threading.Lock()
+
+
+def arena_acquire(nbytes):
+    with _ARENA_LOCK:
+        free = _ARENA_FREE.get(int(nbytes))
+        if free:
+            return free.pop()
+    return ArkArena(nbytes)
+
+
+def arena_release(arena):
+    with _ARENA_LOCK:
+        free = _ARENA_FREE.setdefault(len(arena), [])
+        if len(free) < _ARENA_KEEP and all(a is not arena for a in free):
+            free.append(arena)
+
+
+class ArkMats(object):
+    """The float32 matrices of a window as a sequence that is NOT materialised: row counts (``lengths``) and row-0
+    addresses (``addrs``) are arrays, element ``i`` becomes a NumPy view only when somebody indexes it.  ``holders`` are the
+    objects (arenas / arrays) that own the memory: whoever keeps the window keeps them."""
+
+    def __init__(self):
+        self._addr, self._rows, self._cols, self.holders, self._count = [], [], [], [], [0]
+        self.lengths = np.zeros(0, np.int64)
+        self.addrs = np.zeros(0, np.uint64)
+
+    def add(self, addr, rows, cols, holder):
+        self._addr.append(np.asarray(addr, np.uint64)); self._rows.append(np.asarray(rows, np.int64))
+        self._cols.append(int(cols)); self.holders.append(holder)
+        self._count.append(self._count[-1] + len(self._rows[-1]))
+        self.lengths = self._rows[0] if len(self._rows) == 1 else np.concatenate(self._rows)
+        self.addrs = self._addr[0] if len(self._addr) == 1 else np.concatenate(self._addr)
+
+    def uniform_cols(self):
+        """The common column count, or None when the pieces disagree (or there is nothing)."""
+        return self._cols[0] if self._cols and all(c == self._cols[0] for c in self._cols) else None
+
+    def frames(self):
+        return int(self.lengths.sum())
+
+    def __len__(self):
+        return self._count[-1]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        p = int(np.searchsorted(self._count, i, side="right")) - 1
+        j = i - self._count[p]
+        holder, r, c = self.holders[p], int(self._rows[p][j]), self._cols[p]
+        if isinstance(holder, np.ndarray):
+            return holder
+        if isinstance(holder, list):
+            return holder[j]
+        return np.frombuffer(holder.buf, dtype="<f4", count=r * c, offset=int(self._addr[p][j]) - holder.addr).reshape(r, c)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None):
+    """The in-place form of ``read_mat_ark_blocks``: generator of ``(keys, addr[n] uint64, rows[n] int32, cols, holder)``.
+    The stream is read (``readinto``) into arenas that ``take_arena()`` hands out (``ArkArena``; the caller recycles them once it
+    is done with the window), the native scanner locates the binary float-matrix records, and NOTHING is copied: ``addr[i]``
+    is where row 0 of utterance i lies inside ``holder`` (the arena).  One item per arena and column count; the bytes of a
+    record cut off by the arena's end are carried to the front of the next arena.  ``first_fill``: bytes to read into the first
+    arena (then doubling): a consumer pipeline starts sooner on a short first window.  Records of any other type are decoded
+    by the generic reader and come out one at a time with ``holder`` = their own float32 array.  Needs the host library."""
+    lib = _host_lib()
+    assert lib is not None and hasattr(lib, "xv_ark_scan_fm"), "scan_mat_ark_windows needs libxvector_host.so"
+    raw = open_or_fd(file_or_fd)
+    readinto = getattr(raw, "readinto", None)
+    key_off = np.empty(_SCAN_MAX, np.int64); key_len = np.empty(_SCAN_MAX, np.int32)
+    data_off = np.empty(_SCAN_MAX, np.int64); rows = np.empty(_SCAN_MAX, np.int32); cols = np.empty(_SCAN_MAX, np.int32)
+    nxt, stop = ctypes.c_size_t(0), ctypes.c_int(0)
+    carry, eof, unread, fill = b"", False, 0, first_fill
+    try:
+        while carry or not eof:
+            arena = take_arena()
+            cap = len(arena)
+            end = min(len(carry), cap)
+            arena.buf[:end] = carry[:end]
+            spill = carry[end:]                                  # (only when one record is larger than a whole arena)
+            carry = b""
+            limit = cap if not fill else min(cap, max(int(fill), end + 64))
+            fill = None if not fill or limit == cap else 2 * limit
+            while end < limit and not eof and not spill:
+                if readinto is not None:
+                    # in slices: an in-memory stream copies under the interpreter lock, and 72 MB in one call would stall
+                    # every other thread of the pipeline for ~15 ms
+                    got = readinto(arena.view[end:min(limit, end + (4 << 20))])
+                else:
+                    blk = raw.read(limit - end)
+                    got = len(blk) if blk else 0
+                    arena.buf[end:end + got] = blk or b""
+                if not got:
+                    eof = True
+                else:
+                    end += got
+            unread = end
+            pos = 0
+            keys, a_parts, r_parts, c_now = [], [], [], None
+
+            handed = [False]
+
+            def flush():
+                """The records collected so far as one item.  An arena is the holder of exactly ONE item (its consumer recycles
+                it); the records of a further item of the same arena -- the column count changed inside it -- are copied out."""
+                if not keys:
+                    return None
+                addr = np.concatenate(a_parts) if len(a_parts) > 1 else a_parts[0]
+                nrow = np.concatenate(r_parts) if len(r_parts) > 1 else r_parts[0]
+                holder = arena
+                if handed[0]:
+                    holder = [np.frombuffer(arena.buf, dtype="<f4", count=int(r) * c_now, offset=int(a) - arena.addr)
+                              .reshape(int(r), c_now).copy() for a, r in zip(addr.tolist(), nrow.tolist())]
+                    addr = np.array([m.__array_interface__["data"][0] for m in holder], np.uint64)
+                handed[0] = True
+                out = (list(keys), addr, nrow, c_now, holder)
+                del keys[:], a_parts[:], r_parts[:]
+                return out
+            while pos < end:
+                n = lib.xv_ark_scan_fm(arena.addr, pos, end, _SCAN_MAX, key_off.ctypes.data, key_len.ctypes.data,
+                                       data_off.ctypes.data, rows.ctypes.data, cols.ctypes.data, ctypes.byref(nxt), ctypes.byref(stop))
+                i0 = 0
+                while i0 < n:                                   # a change of the column count closes the item
+                    c = int(cols[i0])
+                    diff = np.flatnonzero(cols[i0:n] != c)
+                    i1 = i0 + (int(diff[0]) if len(diff) else n - i0)
+                    if c_now is not None and c != c_now:
+                        item = flush()
+                        if item:
+                            yield item
+                    c_now = c
+                    keys.extend(_decode_keys(lib, arena.addr, arena.buf, key_off[i0:i1], key_len[i0:i1]))
+                    a_parts.append(data_off[i0:i1].astype(np.uint64) + np.uint64(arena.addr))
+                    r_parts.append(rows[i0:i1].copy())
+                    i0 = i1
+                pos = nxt.value
+                unread = end - pos
+                if stop.value != 2:
+                    break                                       # 2 = scanner table full: scan on in the same arena
+            item = flush()
+            if item:
+                yield item
+            rest = bytes(arena.view[pos:end]) + spill
+            if rest:
+                if stop.value == 1 or (eof and not spill) or (pos == 0 and end == cap):
+                    # a record of another type, a truncated tail, or a record larger than a whole arena: ONE record through
+                    # the generic reader, whose read-ahead then becomes the carry of the next arena
+                    bs = _BufferedStream(raw)
+                    bs.buf, bs.pos = rest, 0
+                    key = read_key(bs)
+                    if key:
+                        m = np.ascontiguousarray(read_mat(bs), dtype=np.float32)
+                        carry = bs.buf[bs.pos:]
+                        unread = len(carry)
+                        yield [key], np.array([m.__array_interface__["data"][0]], np.uint64), np.array([m.shape[0]], np.int32), \
+                            (m.shape[1] if m.ndim == 2 else 0), m
+                    else:
+                        carry, unread = b"", 0
+                else:
+                    carry = rest                                 # an incomplete record: goes to the front of the next arena
+                    unread = len(carry)
+            del arena
+    finally:
+        if raw is not file_or_fd:
+            raw.close()
+        elif unread:
+            try:
+                raw.seek(-unread, 1)
+            except Exception:
+                pass
 
 
 def read_mat_ark(file_or_fd):
@@ -883,8 +1107,47 @@ class _ScpTable(object):
 
 
 class MatScp(_ScpTable):
-    """Feature table: ``(key, float32 [T, F])`` / blocks ``(keys, feats[sum T, F], offsets)``."""
+    """Feature table: ``(key, float32 [T, F])`` / blocks ``(keys, feats[sum T, F], offsets)`` / in-place windows."""
     _ark_blocks = staticmethod(read_mat_ark_blocks)
+
+    def windows(self, take_arena, first_fill=None):
+        """``scan_mat_ark_windows`` over the table: runs of entries that follow their ark are read in place, every key is
+        checked against the table; entries that do not (subsets, shuffled lists, pipes) are read one by one."""
+        ents, n, i = self.entries, len(self.entries), 0
+        misses = 0
+        while i < n:
+            key, rx = ents[i]
+            m = _RX_OFFSET.match(rx)
+            if m is None or rx.endswith("|") or misses >= 2 or _host_lib() is None:
+                mat = self._one(rx)
+                yield [key], np.array([mat.__array_interface__["data"][0]], np.uint64), np.array([mat.shape[0]], np.int32), \
+                    mat.shape[1], mat
+                i += 1
+                continue
+            path, start = m.group(1), int(m.group(2)) - len(key) - 1                  # the record starts at its key
+            run = i
+            while run < n and ents[run][1].startswith(path + ":"):
+                run += 1
+            got = 0
+            with open(path, "rb") as f:
+                f.seek(start)
+                for bkeys, addr, rows, cols, holder in scan_mat_ark_windows(f, take_arena, first_fill if i == 0 else None):
+                    want = [k for k, _ in ents[i:min(i + len(bkeys), run)]]
+                    same = 0
+                    while same < len(want) and bkeys[same] == want[same]:
+                        same += 1
+                    if same:
+                        yield bkeys[:same], addr[:same], rows[:same], cols, holder
+                        i += same
+                        got += same
+                    if same < len(bkeys) or i >= run:
+                        break
+            misses = misses + 1 if got < 4 and i < run else 0
+            if got == 0:                                                               # not even the first key matched
+                mat = self._one(rx)
+                yield [key], np.array([mat.__array_interface__["data"][0]], np.uint64), np.array([mat.shape[0]], np.int32), \
+                    mat.shape[1], mat
+                i += 1
 
     @staticmethod
     def _one(rx):

@@ -46,12 +46,46 @@ def _device():
     return "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
 
 
+class _Subset(object):
+    """Utterances ``idx`` of a window: a sequence with the ``lengths`` / ``addrs`` arrays the extractor plans and packs from;
+    a matrix is only materialised when somebody indexes it."""
+
+    def __init__(self, mats, idx, lens, addrs):
+        self.mats, self.idx = mats, np.asarray(idx, np.int64)
+        self.lengths = np.asarray(lens, np.int64)[self.idx]
+        self.addrs = None if addrs is None else np.asarray(addrs, np.uint64)[self.idx]
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, i):
+        return self.mats[int(self.idx[i])]
+
+    def __iter__(self):
+        for i in self.idx.tolist():
+            yield self.mats[i]
+
+
+class _Cancelled(Exception):
+    pass
+
+
+class _Held(object):
+    """Keeps a gathered block alive as the holder of an ``ArkMats`` piece and hands out its utterances as views."""
+
+    def __init__(self, feats, offsets):
+        self.buf, self.addr, self._feats, self._off = feats, feats.ctypes.data, feats, offsets
+
+
 class Model(object):
     """Default topology: 5 frame-level layers [512,512,512,512,1536], kernels [5,5,7,1,1],
     statistics pooling, 2 segment-level layers (models.py:27-29)."""
 
     window_frames = 1 << 21          # utterances are read from the stream in windows of up to ~2M frames ...
     first_window_frames = 1 << 18    # ... starting with one batch's worth and doubling (pipeline fill)
+    arena_bytes = 72 << 20           # in-place reading: one arena (= one window) holds ~786 k 23-dim frames, three batches' worth
+    first_arena_bytes = 48 << 20     # ... the first one is filled to two batches' worth only, so that the GPU starts sooner
+    arena_count = 4                  # read arenas in rotation (one being filled, two queued, one being packed)
     max_batch_rows = 262144
 
     def __init__(self):
@@ -118,7 +152,7 @@ class Model(object):
 
     def get_models_weights(self, input_dir, logger=None):
         w, _ = wio.load_model_dir(input_dir)
-        return w
+        return {k: np.array(v) for k, v in w.items()}          # own, writable arrays (the loader hands out views of the file)
 
     # -- training / diagnostics ---------------------------------------------------------
     def _trainer(self, input_dir, logger):
@@ -250,8 +284,121 @@ class Model(object):
         ``blocks()`` method (kaldi_io.MatScp).  Under torchrun every
         rank reads the same stream and extracts its share of each window (one gather per window to rank 0) unless
         ``distributed=False`` says that the caller sharded the input itself."""
+        import queue
+        import threading
         start_time = time.time()
-        self.load_model(None, model_dir, logger)
+        # A reader thread parses the next window of the ark stream while the GPU works on the current one
+        # (bounded queue: at most 2 parsed windows in memory).  Order is preserved; a parse error is re-raised here.
+        windows = queue.Queue(maxsize=2)
+        # The utterances are used IN PLACE: the stream is read (readinto) into a few long-lived arenas, the native scanner
+        # locates the matrices there, and the native packer copies them from the arena straight into the pinned staging sets
+        # -- one host copy between the ark bytes and the H2D DMA, no fresh pages per window (at GB/s the page faults of
+        # ever-new arrays and the extra gather copy cost more than the parsing).  An arena goes back to the pool once the
+        # window's batches are packed.  Without libxvector_host.so the generic (gathering) block reader is used.
+        in_place = kaldi_io._host_lib() is not None and (hasattr(input_stream, "read") or hasattr(input_stream, "windows"))
+        arena_bytes = int(self.arena_bytes)
+        cancel = threading.Event()                    # set when the consumer gives up (e.g. the model failed to load)
+        pool = queue.Queue()
+        mine = []                                     # arenas this call took from the process-wide free list
+
+        def take_arena():
+            if len(mine) < self.arena_count and pool.empty():
+                mine.append(kaldi_io.arena_acquire(arena_bytes))
+                return mine[-1]
+            return pool.get()
+
+        def reader():
+            try:
+                keys, vads = [], []
+                vad_it, pending = None, {}
+                if vad_stream is not None:
+                    # an ark stream or a table with blocks() (kaldi_io.VecScp) is read in scanner passes, one view per key
+                    if hasattr(vad_stream, "read") or hasattr(vad_stream, "blocks"):
+                        def vad_records():
+                            src = kaldi_io.read_vec_flt_ark_blocks(vad_stream) if hasattr(vad_stream, "read") else vad_stream.blocks()
+                            for vkeys, vals, voff in src:
+                                vo = voff.tolist()
+                                for n_, k_ in enumerate(vkeys):
+                                    yield k_, vals[vo[n_]:vo[n_ + 1]]
+                        vad_it = vad_records()
+                    else:
+                        vad_it = iter(vad_stream)
+
+                def vad_for(key):
+                    # same key order as the features (extract_xvectors.sh reads it as scp,s,cs); out-of-order tables still
+                    # work, at the price of holding the skipped vectors
+                    if key in pending:
+                        return pending.pop(key)
+                    for k, v in vad_it:
+                        if k == key:
+                            return v
+                        pending[k] = v
+                    return np.zeros(0, np.float32)        # no VAD for this key -> length mismatch -> dropped with a warning
+
+                def pieces():
+                    """(keys, addr[n], rows[n], cols, holder) -- utterances where they lie: whole arenas for ark streams and scp
+                    tables (first arena short, then doubling: the GPU starts after a fraction of a window), gathered blocks
+                    without the host library, one matrix at a time for (key, matrix) iterators."""
+                    first = int(self.first_arena_bytes)
+                    if in_place:
+                        source = kaldi_io.scan_mat_ark_windows(input_stream, take_arena, first) if hasattr(input_stream, "read") \
+                            else input_stream.windows(take_arena, first)
+                        for item in source:
+                            yield item
+                    elif hasattr(input_stream, "read") or hasattr(input_stream, "blocks"):
+                        source = kaldi_io.read_mat_ark_blocks(input_stream) if hasattr(input_stream, "read") else input_stream.blocks()
+                        for bkeys, bfeats, off in source:
+                            row_bytes = bfeats.shape[1] * bfeats.itemsize if bfeats.ndim == 2 else 0
+                            yield bkeys, (bfeats.ctypes.data + off[:-1] * row_bytes).astype(np.uint64), np.diff(off).astype(np.int32), \
+                                (bfeats.shape[1] if bfeats.ndim == 2 else 0), _Held(bfeats, off)
+                    else:
+                        for key, mat in input_stream:
+                            mat = np.ascontiguousarray(mat, dtype=np.float32)
+                            yield [key], np.array([mat.__array_interface__["data"][0]], np.uint64), \
+                                np.array([mat.shape[0]], np.int32), (mat.shape[1] if mat.ndim == 2 else 0), mat
+
+                mats, frames = kaldi_io.ArkMats(), 0
+
+                def put():
+                    item = (keys, mats, vads if vad_it is not None else None)
+                    while not cancel.is_set():
+                        try:
+                            windows.put(item, timeout=0.2)
+                            return
+                        except queue.Full:
+                            pass
+                    raise _Cancelled()
+
+                # a window closes at the first piece boundary past its frame limit (in place: one arena = one window)
+                limit = min(self.window_frames, self.first_window_frames)
+                for bkeys, addr, rows, cols, holder in pieces():
+                    keys.extend(bkeys)
+                    mats.add(addr, rows, cols, holder)
+                    if vad_it is not None:
+                        vads.extend(vad_for(key) for key in bkeys)
+                    frames += int(np.sum(rows))
+                    if frames >= limit or in_place:
+                        put()
+                        keys, vads, mats, frames = [], [], kaldi_io.ArkMats(), 0
+                        limit = min(self.window_frames, 2 * limit)
+                if keys:
+                    put()
+                windows.put(None)
+            except _Cancelled:
+                pass
+            except BaseException as e:          # noqa: B902 -- forwarded to the consumer
+                windows.put(e)
+
+        # the reader starts BEFORE the model is loaded: the first arena is read and scanned while the weights are packed
+        reader_thread = threading.Thread(target=reader, daemon=True)
+        reader_thread.start()
+
+        try:
+            self.load_model(None, model_dir, logger)
+        except BaseException:
+            cancel.set()
+            raise
+        F_dim = self.device_model.feat_dim
         ex = engine.Extractor(self.device_model, min_chunk_size, chunk_size, max_batch_rows=self.max_batch_rows)
         front = None
         if cmn_window > 0 or vad_stream is not None:
@@ -281,10 +428,11 @@ class Model(object):
             if world == 1:
                 handle = ex.submit(mats, addrs)                   # packed, copied and launched; results are collected later
                 return lambda: ex.finish(handle, as_array=True)
-            lens = [m.shape[0] for m in mats]
+            lens = mats.lengths if hasattr(mats, "lengths") else np.array([m.shape[0] for m in mats], np.int64)
             shards = xdist.partition_lpt(lens, world)
             idx = shards[rank].tolist()
-            handle = ex.submit([mats[i] for i in idx], None if addrs is None else addrs[shards[rank]])
+            mine = _Subset(mats, shards[rank], lens, addrs)
+            handle = ex.submit(mine, mine.addrs)
             return lambda: ("shard", shards, ex.finish(handle, as_array=True)[0])
 
         def submit(keys, mats, vads=None, addrs=None):
@@ -323,7 +471,7 @@ class Model(object):
                         kept.append((key, m))
                 keys, mats, addrs = [k for k, _ in kept], [m for _, m in kept], None
             result = submit_window(mats, addrs)
-            lens = np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=len(mats))
+            lens = mats.lengths if hasattr(mats, "lengths") else np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=len(mats))
             compute_time += time.time() - t0
             return keys, lens, result
 
@@ -354,103 +502,6 @@ class Model(object):
             out_q.put((keys, vecs))                 # written by the writer thread, in order
             num_success += len(keys)
 
-        # A reader thread parses the next window of the ark stream while the GPU works on the current one
-        # (bounded queue: at most 2 parsed windows in memory).  Order is preserved; a parse error is re-raised here.
-        import queue
-        import threading
-        windows = queue.Queue(maxsize=2)
-        # Feature storage of the windows is recycled: a window's utterances are gathered by the scanner straight into one of
-        # a few long-lived [rows, F] buffers (no fresh pages per scanner pass -- at GB/s the page faults of ever-new arrays cost
-        # as much as the parsing); the main thread hands a buffer back once the window's batches are packed into the staging sets.
-        F_dim = self.device_model.feat_dim
-        pool_rows = int(self.window_frames) + (kaldi_io._ArenaStream.BLOCK // (4 * F_dim)) + 4096
-        pool = queue.Queue()
-        for _ in range(4):
-            pool.put(np.empty((pool_rows, F_dim), np.float32))
-        slab = {"buf": None, "used": 0}
-
-        def alloc(nrows, ncols):
-            if ncols != F_dim or nrows > pool_rows:
-                return np.empty((nrows, ncols), np.float32)            # (wrong width: rejected later with a clear error)
-            if slab["buf"] is None:
-                slab["buf"], slab["used"] = pool.get(), 0
-            if slab["used"] + nrows > pool_rows:
-                return np.empty((nrows, ncols), np.float32)            # rare: an oversized last block of a window
-            out = slab["buf"][slab["used"]:slab["used"] + nrows]
-            slab["used"] += nrows
-            return out
-
-        def reader():
-            try:
-                keys, mats, vads, addrs, frames = [], [], [], [], 0
-                vad_it, pending = None, {}
-                if vad_stream is not None:
-                    # an ark stream or a table with blocks() (kaldi_io.VecScp) is read in scanner passes, one view per key
-                    if hasattr(vad_stream, "read") or hasattr(vad_stream, "blocks"):
-                        def vad_records():
-                            src = kaldi_io.read_vec_flt_ark_blocks(vad_stream) if hasattr(vad_stream, "read") else vad_stream.blocks()
-                            for vkeys, vals, voff in src:
-                                vo = voff.tolist()
-                                for n_, k_ in enumerate(vkeys):
-                                    yield k_, vals[vo[n_]:vo[n_ + 1]]
-                        vad_it = vad_records()
-                    else:
-                        vad_it = iter(vad_stream)
-
-                def vad_for(key):
-                    # same key order as the features (extract_xvectors.sh reads it as scp,s,cs); out-of-order tables still
-                    # work, at the price of holding the skipped vectors
-                    if key in pending:
-                        return pending.pop(key)
-                    for k, v in vad_it:
-                        if k == key:
-                            return v
-                        pending[k] = v
-                    return np.zeros(0, np.float32)        # no VAD for this key -> length mismatch -> dropped with a warning
-
-                def blocks():
-                    # (keys, [matrices], [address of row 0]) per block: whole scanner passes gathered natively for ark
-                    # streams, one utterance at a time for (key, matrix) iterators
-                    if hasattr(input_stream, "read") or hasattr(input_stream, "blocks"):
-                        source = kaldi_io.read_mat_ark_blocks(input_stream, alloc) if hasattr(input_stream, "read") else \
-                            input_stream.blocks(alloc)
-                        for bkeys, bfeats, off in source:
-                            o = off.tolist()
-                            base, row_bytes = bfeats.ctypes.data, bfeats.shape[1] * bfeats.itemsize if bfeats.ndim == 2 else 0
-                            yield bkeys, [bfeats[o[i]:o[i + 1]] for i in range(len(bkeys))], [base + r * row_bytes for r in o[:-1]]
-                    else:
-                        for key, mat in input_stream:
-                            mat = np.ascontiguousarray(mat, dtype=np.float32)
-                            yield [key], [mat], [mat.__array_interface__["data"][0]]
-
-                def put():
-                    F = self.device_model.feat_dim          # anything else goes down the checked NumPy packing path and raises there
-                    ok = all(m.ndim == 2 and m.shape[1] == F and m.dtype == np.float32 for m in mats)
-                    windows.put((keys, mats, vads if vad_it is not None else None, np.array(addrs, dtype=np.uint64) if ok else None,
-                                 slab["buf"]))
-                    slab["buf"] = None                      # the next window gathers into another buffer of the pool
-
-                # the first window is one batch's worth of frames so that the GPU starts after the first scanner pass instead
-                # of after ~2 M frames of parsing; windows then double up to window_frames (fewer, larger host round trips)
-                limit = min(self.window_frames, self.first_window_frames)
-                for bkeys, bmats, baddrs in blocks():
-                    # whole blocks are appended (a window closes at the first block boundary past its frame limit)
-                    keys.extend(bkeys)
-                    mats.extend(bmats)
-                    addrs.extend(baddrs)
-                    if vad_it is not None:
-                        vads.extend(vad_for(key) for key in bkeys)
-                    frames += sum(m.shape[0] for m in bmats) if len(bmats) < 64 else int(np.sum([m.shape[0] for m in bmats]))
-                    if frames >= limit:
-                        put()
-                        keys, mats, vads, addrs, frames = [], [], [], [], 0
-                        limit = min(self.window_frames, 2 * limit)
-                if keys:
-                    put()
-                windows.put(None)
-            except BaseException as e:          # noqa: B902 -- forwarded to the consumer
-                windows.put(e)
-
         # ... and a writer thread serialises the records of finished windows (same bytes as write_vec_flt per key), so that
         # formatting ~50 k records per window does not sit between two kernel launches.  Its error, if any, is re-raised below.
         out_q = queue.Queue(maxsize=4)
@@ -470,7 +521,6 @@ class Model(object):
 
         writer_thread = threading.Thread(target=writer, daemon=True)
         writer_thread.start()
-        threading.Thread(target=reader, daemon=True).start()
         # software pipeline of depth 2 over the windows: the host work of window i+1 (packing, H2D, launches) is issued
         # before the vectors of window i are awaited and written, so the GPU never waits for the writer
         in_flight = None
@@ -484,12 +534,15 @@ class Model(object):
                     raise item
                 if writer_error:
                     raise writer_error[0]
-                keys, mats, vads, addrs, held = item
+                keys, mats, vads = item
+                # a column count other than the model's goes down the checked NumPy packing path and raises there
+                addrs = mats.addrs if mats.uniform_cols() == F_dim else None
                 total_segments += len(keys)
                 nxt = submit(keys, mats, vads, addrs)
+                for held in mats.holders:
+                    if isinstance(held, kaldi_io.ArkArena):
+                        pool.put(held)                      # every batch of the window is packed: the reader may refill it
                 del mats, item
-                if held is not None:
-                    pool.put(held)                          # every batch of the window is packed: the reader may refill it
                 if in_flight is not None:
                     collect(*in_flight)
                 in_flight = nxt
@@ -498,8 +551,12 @@ class Model(object):
             if world > 1:
                 self._exchange_shards(stash, rank, world, min_chunk_size, chunk_size, emit)
         finally:
+            cancel.set()                            # (no-op after a complete pass: the reader has already returned)
             out_q.put(None)
             writer_thread.join()                    # the caller closes output_stream right after we return
+            if not reader_thread.is_alive():        # (a reader still inside an arena keeps it; the others are recycled)
+                for a in mine:
+                    kaldi_io.arena_release(a)
         if writer_error:
             raise writer_error[0]
 

@@ -48,13 +48,18 @@ def _host_lib():
 def can_submit_raw(mats, feat_dim):
     """Extractor.submit_raw reads the raw matrices in place through the native packer: host library present and every matrix a
     C-contiguous float32 [T, feat_dim] array."""
-    return _host_lib() is not None and all(m.dtype == np.float32 and m.ndim == 2 and m.shape[1] == feat_dim and m.flags.c_contiguous
-                                           for m in mats)
+    if _host_lib() is None:
+        return False
+    if hasattr(mats, "uniform_cols"):                     # kaldi_io.ArkMats: float32 matrices where the stream was read to
+        return mats.uniform_cols() == feat_dim
+    return all(m.dtype == np.float32 and m.ndim == 2 and m.shape[1] == feat_dim and m.flags.c_contiguous for m in mats)
 
 
 def matrix_addresses(mats, feat_dim):
     """uint64 address of row 0 of every utterance matrix, or None when one of them is not a C-contiguous float32
     ``[T, feat_dim]`` array (the native packer reads them in place)."""
+    if hasattr(mats, "uniform_cols"):
+        return mats.addrs if mats.uniform_cols() == feat_dim else None
     out = np.empty(len(mats), dtype=np.uint64)
     for i, m in enumerate(mats):
         if m.dtype != np.float32 or m.ndim != 2 or m.shape[1] != feat_dim or not m.flags.c_contiguous:
@@ -462,6 +467,24 @@ class DeviceModel(object):
 # ------------------------------------------------------------------------------------------------
 # extractor: utterances in, x-vectors out
 # ------------------------------------------------------------------------------------------------
+_STAGE_CACHE = {}          # (in_dim, NBUF) -> parked pinned staging sets of finished extractors (at most 2 per key)
+_STAGE_LOCK = __import__("threading").Lock()
+
+
+def _park_stage(holder):
+    if len(holder) == 2 and holder[1] is not None:
+        key, stage = holder
+        for st in stage:
+            if st.get("event") is not None:
+                st["event"].synchronize()
+                st["event"] = None
+        with _STAGE_LOCK:
+            parked = _STAGE_CACHE.setdefault(key, [])
+            if len(parked) < 2 and all(p is not stage for p in parked):
+                parked.append(stage)
+        holder[:] = []
+
+
 class Extractor(object):
     """Batches the chunk plans of many utterances (length-bucketed), runs them and averages per
     utterance.  Output order == input order, rejected utterances yield ``None`` vectors.
@@ -481,23 +504,54 @@ class Extractor(object):
         self._stage = None
         self._copy_stream = None
         self._turn = 0
+        self._finalizer = None
+        self._holder = []                              # [cache key, staging sets]: what the finalizer parks
+        self._pin_free = {}
 
     def _staging(self, rows, nchunks):
-        """NBUF pinned sets: features [rows, in_dim] (padding columns zeroed once), row_valid[rows], meta int32[2, chunks]."""
+        """NBUF pinned sets: features [rows, in_dim] (padding columns zeroed once), row_valid[rows], meta int32[2, chunks].
+        Pinning 3 x 25 MB costs tens of milliseconds, so the sets of a finished extractor are parked process-wide
+        (``_STAGE_CACHE``) and the next one -- every ``make_embedding`` call builds its own -- picks them up."""
         torch = self.model.torch
         if self._stage is None or self._stage[0]["x"].shape[0] < rows or self._stage[0]["meta"].shape[1] < nchunks:
             # sized for the largest regular batch up front: re-pinning 3 x 25 MB whenever a window brings a slightly larger
             # batch costs more than the kernels of that batch
             rows = max(rows, 1024) if rows <= 4096 else max(rows, self.max_batch_rows)
             nchunks = max(nchunks, 64) if nchunks <= 64 else max(nchunks, min(self.max_batch_chunks, 8192))
-            self._stage = []
-            for _ in range(self.NBUF):
-                self._stage.append(dict(x=torch.zeros((rows, self.model.in_dim), dtype=torch.float32).pin_memory(),
-                                        rv=torch.zeros(rows, dtype=torch.uint8).pin_memory(),
-                                        meta=torch.zeros((2, nchunks), dtype=torch.int32).pin_memory(), event=None))
+            if self._stage is not None:
+                _park_stage(self._holder)
+            with _STAGE_LOCK:
+                parked = _STAGE_CACHE.get((self.model.in_dim, self.NBUF), [])
+                hit = next((i for i, st in enumerate(parked) if st[0]["x"].shape[0] >= rows and st[0]["meta"].shape[1] >= nchunks), None)
+                self._stage = parked.pop(hit) if hit is not None else None
+            if self._stage is None:
+                self._stage = []
+                for _ in range(self.NBUF):
+                    self._stage.append(dict(x=torch.zeros((rows, self.model.in_dim), dtype=torch.float32).pin_memory(),
+                                            rv=torch.zeros(rows, dtype=torch.uint8).pin_memory(),
+                                            meta=torch.zeros((2, nchunks), dtype=torch.int32).pin_memory(), event=None))
+            if self._finalizer is None:
+                import weakref
+                self._finalizer = weakref.finalize(self, _park_stage, self._holder)
+            self._holder[:] = [(self.model.in_dim, self.NBUF), self._stage]
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.model.device)
         return self._stage
+
+    def _pinned(self, kind, shape, dtype):
+        """A pinned host tensor of ``shape`` from this extractor's free list (per-window buffers: the chunk table that goes up,
+        the x-vectors that come down): one hipHostMalloc per window is a millisecond the pipeline has no use for."""
+        torch = self.model.torch
+        need = int(np.prod(shape))
+        free = self._pin_free.setdefault((kind, dtype), [])
+        best = next((i for i, t in enumerate(free) if t.numel() >= need), None)
+        flat = free.pop(best) if best is not None else torch.empty(max(need, 1) * 5 // 4 + 64, dtype=dtype).pin_memory()
+        return flat, flat[:need].view(shape)
+
+    def _unpin(self, kind, flat):
+        free = self._pin_free.setdefault((kind, flat.dtype), [])
+        if len(free) < 4:
+            free.append(flat)
 
     PACK_THREADS = int(os.environ.get("XVECTOR_PACK_THREADS", "4"))
 
@@ -509,15 +563,16 @@ class Extractor(object):
         """Plan, pack, copy and launch everything for ``mats`` and start the asynchronous D2H copy of the x-vectors; returns a
         handle for ``finish``.  The caller may submit the next window before finishing this one (the host work of window
         i+1 then overlaps the kernels of window i).  ``addrs``: optional ``matrix_addresses(mats, F)`` computed elsewhere
-        (e.g. by the reader thread)."""
+        (e.g. by the reader thread).  ``mats`` may be a lazy sequence with a ``lengths`` array (kaldi_io.ArkMats): with ``addrs``
+        the native packer reads the rows in place and no matrix object is ever built."""
         torch = self.model.torch
         model = self.model
         dev = model.device
+        lens = mats.lengths if hasattr(mats, "lengths") else [m.shape[0] for m in mats]
         # chunk table, utterances ordered by length so that batches are length-homogeneous
-        order, c_utt, c_start, c_len, seg_start = plan_chunk_table([m.shape[0] for m in mats], self.min_chunk_size,
-                                                                    self.chunk_size)
+        order, c_utt, c_start, c_len, seg_start = plan_chunk_table(lens, self.min_chunk_size, self.chunk_size)
         nch = len(c_utt)
-        handle = dict(n=len(mats), order=order, nch=nch)
+        handle = dict(n=len(lens), order=order, nch=nch)
         if nch == 0:
             return handle
         F = model.feat_dim
@@ -583,7 +638,9 @@ class Extractor(object):
                 self.stats["rows"] += layout.rows
             model.segment_level(P_all, E_all)
             # (pinned + copy stream: a pageable H2D copy here would block the host until every kernel of the window is done)
-            tail = torch.from_numpy(np.concatenate([np.asarray(seg_start, dtype=np.int32), c_len.astype(np.int32)])).pin_memory()
+            tail_np = np.concatenate([np.asarray(seg_start, dtype=np.int32), c_len.astype(np.int32)])
+            tail_flat, tail = self._pinned("tail", tail_np.shape, torch.int32)
+            tail.numpy()[:] = tail_np
             with torch.cuda.stream(self._copy_stream):
                 tail_d = tail.to(dev, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -592,12 +649,12 @@ class Extractor(object):
             seg, cl = tail_d[:len(order) + 1], tail_d[len(order) + 1:]
             out = torch.empty((len(order), model.embed_dim), dtype=torch.float32, device=dev)
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
-            host = torch.empty((len(order), model.embed_dim), dtype=torch.float32).pin_memory()
+            host_flat, host = self._pinned("xvec", (len(order), model.embed_dim), torch.float32)
             host.copy_(out, non_blocking=True)
             done = torch.cuda.Event()
             done.record(compute)
         # mats (the native packer read them in place) and the device buffers stay referenced until finish()
-        handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats))
+        handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats), pinned=(tail_flat, host_flat))
         return handle
 
     def submit_raw(self, mats, vads, cmn_window, center=True, min_window=100, addrs=None):
@@ -720,7 +777,9 @@ class Extractor(object):
                 self.stats["frames"] += int(layout.row_len.sum())
                 self.stats["rows"] += layout.rows
             model.segment_level(P_all, E_all)
-            tail = torch.from_numpy(np.concatenate([np.asarray(seg_start, dtype=np.int32), c_len.astype(np.int32)])).pin_memory()
+            tail_np = np.concatenate([np.asarray(seg_start, dtype=np.int32), c_len.astype(np.int32)])
+            tail_flat, tail = self._pinned("tail", tail_np.shape, torch.int32)
+            tail.numpy()[:] = tail_np
             with torch.cuda.stream(self._copy_stream):
                 tail_d = tail.to(dev, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -729,11 +788,11 @@ class Extractor(object):
             seg, cl = tail_d[:len(order) + 1], tail_d[len(order) + 1:]
             out = torch.empty((len(order), model.embed_dim), dtype=torch.float32, device=dev)
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
-            host = torch.empty((len(order), model.embed_dim), dtype=torch.float32).pin_memory()
+            host_flat, host = self._pinned("xvec", (len(order), model.embed_dim), torch.float32)
             host.copy_(out, non_blocking=True)
             done = torch.cuda.Event()
             done.record(compute)
-        handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats))
+        handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats), pinned=(tail_flat, host_flat))
         return handle, V, vad_dropped
 
     def _raw_staging(self, rows, nutts, feat_dim):
@@ -764,6 +823,10 @@ class Extractor(object):
             if handle["nch"]:
                 full[handle["order"]] = host_out
                 valid[handle["order"]] = True
+                pinned = handle.pop("pinned", None)          # the vectors were copied out: the pinned buffers go round again
+                if pinned is not None:
+                    self._unpin("tail", pinned[0])
+                    self._unpin("xvec", pinned[1])
             return full, valid
         results = [None] * n
         if handle["nch"]:

@@ -24,7 +24,7 @@ def select_voiced(mats, vads):
     order (None = every frame voiced); indices of utterances that have neither frames nor a VAD (they stay empty matrices);
     the number of utterances dropped because of their VAD (length mismatch / nothing voiced)."""
     n = len(mats)
-    T = np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=n)
+    T = np.asarray(mats.lengths, np.int64) if hasattr(mats, "lengths") else np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=n)
     if vads is None:
         return T, np.flatnonzero(T > 0), None, np.flatnonzero(T == 0).tolist(), 0
     flat = [None if v is None else np.asarray(v).reshape(-1) for v in vads]

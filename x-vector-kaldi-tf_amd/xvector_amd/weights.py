@@ -107,6 +107,48 @@ def is_correct_model_dir(model_dir):
     return True
 
 
+def _read_stored_npz(path):
+    """{name: float32 array} of an UNCOMPRESSED ``.npz`` (what ``np.savez`` writes) as read-only views of the memory-mapped
+    file: ``np.load`` runs every member through zipfile's CRC check and a copy (30 ms for this model's 25 MB -- a tenth of a
+    50 k-utterance extraction), here the member payloads are located through the zip directory and used where they are.
+    None when the file is not a plain stored archive of C-order arrays (the caller falls back to ``np.load``)."""
+    import ast
+    import mmap
+    import struct
+    import zipfile
+    try:
+        out = {}
+        with open(path, "rb") as f:
+            infos = zipfile.ZipFile(f).infolist()
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        for info in infos:
+            if info.compress_type != zipfile.ZIP_STORED or not info.filename.endswith(".npy"):
+                return None
+            h = info.header_offset
+            if mm[h:h + 4] != b"PK\x03\x04":
+                return None
+            nlen, elen = struct.unpack("<HH", mm[h + 26:h + 30])
+            start = h + 30 + nlen + elen
+            if mm[start:start + 6] != b"\x93NUMPY":
+                return None
+            if mm[start + 6] == 1:
+                hlen, off = struct.unpack("<H", mm[start + 8:start + 10])[0], 10
+            else:
+                hlen, off = struct.unpack("<I", mm[start + 8:start + 12])[0], 12
+            header = ast.literal_eval(mm[start + off:start + off + hlen].decode("latin1"))
+            if header.get("fortran_order"):
+                return None
+            dtype, shape = np.dtype(header["descr"]), tuple(header["shape"])
+            if dtype.hasobject:
+                return None
+            count = int(np.prod(shape)) if shape else 1
+            arr = np.frombuffer(mm, dtype=dtype, count=count, offset=start + off + hlen).reshape(shape)
+            out[info.filename[:-4]] = arr if arr.dtype == np.float32 else arr.astype(np.float32)
+        return out
+    except Exception:
+        return None
+
+
 def load_model_dir(input_dir):
     """-> (weights dict, meta dict).  Raises with a clear message on a TF checkpoint directory."""
     meta_path = os.path.join(input_dir, META)
@@ -129,8 +171,10 @@ def load_model_dir(input_dir):
             return weights, meta
         raise IOError("'%s' is neither an %s model directory nor a TensorFlow checkpoint directory (no model.index)"
                       % (input_dir, FORMAT_TAG))
-    with np.load(os.path.join(input_dir, WEIGHTS)) as z:
-        weights = {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
+    weights = _read_stored_npz(os.path.join(input_dir, WEIGHTS))
+    if weights is None:
+        with np.load(os.path.join(input_dir, WEIGHTS)) as z:
+            weights = {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
     missing = [n for n in expected_names(meta["topology"]) if n not in weights]
     if missing:
         raise KeyError("model dir '%s' lacks variables: %s" % (input_dir, ", ".join(missing)))
