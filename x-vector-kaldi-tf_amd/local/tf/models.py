@@ -83,7 +83,7 @@ class Model(object):
 
     window_frames = 1 << 21          # utterances are read from the stream in windows of up to ~2M frames ...
     first_window_frames = 1 << 18    # ... starting with one batch's worth and doubling (pipeline fill)
-    arena_bytes = 72 << 20           # in-place reading: one arena (= one window) holds ~786 k 23-dim frames, three batches' worth
+    arena_bytes = 144 << 20          # in-place reading: one arena (= one window) holds ~1.6 M 23-dim frames, six batches' worth
     first_arena_bytes = 48 << 20     # ... the first one is filled to two batches' worth only, so that the GPU starts sooner
     arena_count = 4                  # read arenas in rotation (one being filled, two queued, one being packed)
     max_batch_rows = 262144

@@ -555,6 +555,36 @@ class Extractor(object):
 
     PACK_THREADS = int(os.environ.get("XVECTOR_PACK_THREADS", "4"))
 
+    def _batch_bounds(self, cum, lead):
+        """Chunk ranges of the batches of a window: ``cum[j]`` = rows the chunks before j occupy.  The window's rows are dealt
+        EVENLY to the fewest batches that respect ``max_batch_rows`` (3.2 batches' worth of rows become 4 batches of 0.8, not
+        3 + a 0.2 remnant that fills a fraction of the chip); a single chunk may still exceed the row budget."""
+        nch = len(cum) - 1
+        budget = max(self.max_batch_rows - lead, 1)
+        total = int(cum[-1])
+        n_b = max(1, -(-total // budget))
+        cuts = None
+        for extra in (0, 1):
+            # batch k ends at the first chunk boundary at or past k/n_b of the rows
+            c = sorted(set([0] + [int(np.searchsorted(cum, total * k / float(n_b + extra), side="left")) for k in range(1, n_b + extra)] + [nch]))
+            if all(int(cum[b1] - cum[b0]) <= budget or b1 - b0 == 1 for b0, b1 in zip(c[:-1], c[1:])):
+                cuts = c
+                break
+        if cuts is None:
+            # chunks that are large next to the row budget (tests, tiny budgets): greedy fill
+            cuts, b0 = [0], 0
+            while b0 < nch:
+                b1 = int(np.searchsorted(cum, cum[b0] + budget, side="right")) - 1
+                b0 = min(max(b1, b0 + 1), nch)
+                cuts.append(b0)
+        bounds = []
+        for b0, b1 in zip(cuts[:-1], cuts[1:]):
+            while b1 - b0 > self.max_batch_chunks:   # (only with thousands of very short chunks)
+                bounds.append((b0, b0 + self.max_batch_chunks, lead + int(cum[b0 + self.max_batch_chunks] - cum[b0])))
+                b0 += self.max_batch_chunks
+            bounds.append((b0, b1, lead + int(cum[b1] - cum[b0])))
+        return bounds
+
     def extract(self, mats, addrs=None):
         """mats: list of float32 [T, F] arrays.  Returns a list of float32[E] (or None) per input."""
         return self.finish(self.submit(mats, addrs))
@@ -591,12 +621,7 @@ class Extractor(object):
         # batch boundaries: greedy fill up to max_batch_rows / max_batch_chunks (a single chunk may exceed the row budget)
         cum = np.zeros(nch + 1, dtype=np.int64)
         np.cumsum(slot_rows(c_len, gap, align), out=cum[1:])
-        bounds, b0 = [], 0
-        while b0 < nch:
-            b1 = int(np.searchsorted(cum, cum[b0] + self.max_batch_rows - lead, side="right")) - 1
-            b1 = min(max(b1, b0 + 1), b0 + self.max_batch_chunks, nch)
-            bounds.append((b0, b1, lead + int(cum[b1] - cum[b0])))
-            b0 = b1
+        bounds = self._batch_bounds(cum, lead)
         stage = self._staging(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds))
         with torch.cuda.device(dev):
             compute = torch.cuda.current_stream()
@@ -698,12 +723,7 @@ class Extractor(object):
         lead = (gap + align - 1) // align * align
         cum = np.zeros(nch + 1, dtype=np.int64)
         np.cumsum(slot_rows(c_len, gap, align), out=cum[1:])
-        bounds, b0 = [], 0
-        while b0 < nch:
-            b1 = int(np.searchsorted(cum, cum[b0] + self.max_batch_rows - lead, side="right")) - 1
-            b1 = min(max(b1, b0 + 1), b0 + self.max_batch_chunks, nch)
-            bounds.append((b0, b1, lead + int(cum[b1] - cum[b0])))
-            b0 = b1
+        bounds = self._batch_bounds(cum, lead)
         kept = np.diff(seg_start)                             # chunks per utterance of `order`
         first_len = c_len[seg_start[:-1]]                     # = the chunk size the plan used for the utterance
         # utterances (positions in `order`) touched by each batch, and the raw rows they bring
