@@ -49,7 +49,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 10). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 11). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -129,6 +129,19 @@ int xv_tdnn_layer_pool_bf16x3(const void *x, int x_format, int64_t R, int cin, i
                               int dilation, int cout, const uint8_t *row_valid, float *block_stats, void *stream);
 int xv_stats_pool_blocks_f32(const float *block_stats, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
                              float eps, float *out, void *stream);
+
+/* The FIRST frame-level layer (frame_level_info_layer-0: conv1d over the MFCC rows, models.py:54-67) as a kernel built around
+ * its output stream: the im2col operand of a wave's 16 frames is formed in registers straight from the fp32 feature rows, the
+ * weights of 128 output channels stay in LDS for a strip of 512 frames, and the epilogue writes XV_FMT_SPLIT rows directly from
+ * the accumulators.  Same contraction and epilogue as xv_tdnn_layer_bf16x3 with x in XV_FMT_F32 and y in XV_FMT_SPLIT.
+ * x[R, ldx]: rows of ceil8(Cin) floats (columns >= Cin zero), ldx % 8 == 0, 32-byte aligned; wt = xv_pack_first_bf16x3(w[K,Cin,Cout]).
+ * Supported: K odd, K*ceil8(Cin) <= 128, (K-1)*dilation <= 8, Cout % 32 == 0, Cout <= 512 (xv_packed_first_bf16x3_bytes
+ * returns 0 otherwise; the general kernel takes those shapes). */
+size_t xv_packed_first_bf16x3_bytes(int K, int cin, int cout);
+int xv_pack_first_bf16x3(const float *w, int K, int cin, int cout, void *wt, void *stream);
+int xv_tdnn_first_bf16x3(const float *x, int64_t R, int cin, int ldx, const void *wt, const float *bias, const float *bn_scale,
+                         const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                         const uint8_t *row_valid, void *y, void *stream);
 
 /* The last TWO frame-level layers and the first half of statistics pooling in one launch, for topologies whose last two
  * layers have no temporal context (kernel size 1: models.py:28 [5,5,7,1,1], :545 [5,3,3,1,1]):

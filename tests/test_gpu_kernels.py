@@ -360,6 +360,65 @@ def test_tdnn_layer_pool_blocks_match_oracle(env, fmt, cin, cout, K, dil, act, l
     assert np.isnan(bad[1]).all() and np.array_equal(bad[0], got[0]) and np.array_equal(bad[2:], got[2:])
 
 
+@pytest.mark.parametrize("feat,cout,K,dil,act,lens", [
+    (23, 512, 5, 1, "relu", [25, 1, 7, 130, 257, 600, 64, 3]),      # layer 0 of the default topology (23 MFCCs in 24 columns)
+    (5, 64, 3, 2, "prelu", [300, 25, 2]),                            # narrow features, dilation, one pass of 64 channels
+    (30, 288, 3, 1, "lrelu", [1200, 33]),                            # two passes (256 + 32 channels), 3 taps x 32 columns
+    (23, 512, 5, 1, "none", [513]),
+])
+def test_tdnn_first_layer_kernel_matches_oracle_and_the_general_kernel(env, feat, cout, K, dil, act, lens):
+    """xv_tdnn_first_bf16x3 (im2col operand built in registers from the fp32 rows, split-format output straight from the
+    accumulators) against the fp64 oracle, and against xv_tdnn_layer_bf16x3 on the same input: same products, another
+    fp32 summation order.  Gap rows come out as exact zeros; rows past R are not written."""
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    in_dim = (feat + 7) // 8 * 8
+    assert hiplib.first_supported(K, in_dim, cout) and not hiplib.first_supported(7, 24, 512) and not hiplib.first_supported(5, 24, 520)
+    rng = np.random.default_rng(feat + cout + K)
+    mats = [(rng.standard_normal((t, feat)) * 3).astype(np.float32) for t in lens]
+    w = (rng.standard_normal((K, feat, cout)) / np.sqrt(K * feat)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = None
+    if act == "lrelu":
+        alpha = np.array([0.2], np.float32)
+    elif act == "prelu":
+        alpha = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    gap = max(1, (K - 1) * dil // 2)
+    layout = engine.BatchLayout(lens, gap, 8)
+    host = np.zeros((layout.rows, in_dim), np.float32)
+    layout.pack(mats, host[:, :feat] if False else host)           # pack writes the first `feat` columns of each row
+    x = torch.from_numpy(host).to(dev)
+    rv = torch.from_numpy(layout.row_valid()).to(dev)
+    wpad = np.zeros((K, in_dim, cout), np.float32)
+    wpad[:, :feat] = w
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    scale, shift = hiplib.fold_bn(*(t(a) for a in bn), 1e-3)
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+    first = hiplib.pack_first_bf16x3(t(wpad))
+    y = hiplib.SplitBuf(layout.rows, cout, dev)
+    y.base.fill_(0x7f)                                             # poison (bf16 0x7f7f = 3.4e38): unwritten slots would show
+    hiplib.tdnn_first(x, layout.rows, first, t(b), scale, shift, code, t(alpha), dil, rv, y)
+    got = hiplib.split_decode(y, layout.rows).cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got).max() < 1e6
+    valid = layout.row_valid().astype(bool)
+    assert (got[~valid] == 0).all()
+    for i, m in enumerate(mats):
+        ref = oracle.tdnn_layer(m, w, b, bn, act, alpha, dil, np.float64)
+        s = int(layout.row_start[i])
+        assert oracle.rel_l2(got[s:s + lens[i]], ref) < TOL_GEMM3, (i, lens[i])
+    y2 = hiplib.SplitBuf(layout.rows, cout, dev)
+    hiplib.tdnn_layer(x, hiplib.pack_weights_bf16x3(t(wpad)), t(b), scale, shift, code, t(alpha), K, dil, rv, y2, None, rows=layout.rows)
+    two = hiplib.split_decode(y2, layout.rows).cpu().numpy()
+    assert oracle.rel_l2(got, two) < 5e-6
+    # rows past R stay untouched: run on a prefix of the rows and look at the poison behind it
+    R2 = int(layout.row_start[-1])                                 # everything before the last chunk
+    y3 = hiplib.SplitBuf(layout.rows, cout, dev)
+    y3.base.fill_(0x7f)
+    hiplib.tdnn_first(x, R2, first, t(b), scale, shift, code, t(alpha), dil, rv, y3)
+    tail = hiplib.split_decode(y3, layout.rows).cpu().numpy()[R2:]
+    assert (np.abs(tail) > 1e30).all()
+
+
 @pytest.mark.parametrize("cin,cout,act,lens", [
     (512, 1536, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),      # layers 3 + 4 of the default topology
     (64, 64, "prelu", [300, 25, 64, 3]),                         # two k-steps, one column group

@@ -62,3 +62,24 @@ for name, t in times.items():
     t = sorted(t); med = t[len(t) // 2]
     ex = 6.0 * R * cin * (cmid + cout) / 1e9
     print("layers 3+4+pool %s: median %.3f ms (min %.3f)  %.0f TF executed (%.1f%% of 2.5 PF)" % (name, med, t[0], ex / med, ex / med / 25))
+
+# layer 0 (23 MFCC dims in 24 columns -> 512): the general kernel vs the kernel built for it
+feat, cout0 = 24, 512
+w0 = torch.randn((5, feat, cout0), device=dev) / (5 * 23) ** 0.5; w0[:, 23] = 0
+x0 = torch.randn((R, feat), device=dev) * 3; x0[:, 23] = 0
+wp0, first = hiplib.pack_weights_bf16x3(w0), hiplib.pack_first_bf16x3(w0)
+b0 = torch.zeros(cout0, device=dev); y0 = hiplib.SplitBuf(R, cout0, dev)
+variants = {"general kernel": lambda: hiplib.tdnn_layer3(x0, R, wp0, b0, None, None, 1, None, 1, rv, y0),
+            "first-layer kernel": lambda: hiplib.tdnn_first(x0, R, first, b0, None, None, 1, None, 1, rv, y0)}
+times = {k: [] for k in variants}
+for rnd in range(ROUNDS + 1):
+    for name, fn in variants.items():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(REPS): fn()
+        b.record(); torch.cuda.synchronize()
+        if rnd: times[name].append(a.elapsed_time(b) / REPS)
+for name, t in times.items():
+    t = sorted(t); med = t[len(t) // 2]
+    print("layer 0 %s: median %.3f ms (min %.3f)  output stream %.0f GB/s (%.1f%% of 8 TB/s)" %
+          (name, med, t[0], R * cout0 * 4 / med / 1e6, R * cout0 * 4 / med / 1e6 / 80))

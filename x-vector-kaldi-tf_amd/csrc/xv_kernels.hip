@@ -1325,7 +1325,7 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 10; }
+int xv_version(void) { return 11; }
 
 int xv_set_tuning(int key, int value)
 {

@@ -262,6 +262,15 @@ class DeviceModel(object):
                     self.last_halves = [self._prep(weights, sc, weights[sc + "/w:0"], k, d, cols=slice(a, a + A)) for a in (0, A)]
                 else:
                     self.att["wp"] = hiplib.pack_weights(self._dev(aw))
+            # layer 0 on the kernel built for it (output-stream bound; see csrc/xv_first.hip) when its shape allows
+            self.first = None
+            L0 = self.layers[0]
+            if precision == "bf16x3" and os.environ.get("XVECTOR_FIRST_KERNEL", "1") != "0" and len(self.layers) > 1 and \
+                    self.in_dim % 8 == 0 and hiplib.first_supported(L0["K"], self.in_dim, L0["cout"]) and (L0["K"] - 1) * L0["dil"] <= 8:
+                w0 = weights["frame_level_info_layer-0/w:0"]
+                wpad = np.zeros((L0["K"], self.in_dim, w0.shape[2]), np.float32)
+                wpad[:, :self.feat_dim] = w0
+                self.first = hiplib.pack_first_bf16x3(self._dev(wpad))
             self.pair = None
             want_pair = (os.environ.get("XVECTOR_PAIR_KERNEL", "1") != "0") if pair_kernel is None else bool(pair_kernel)
             if want_pair and self.fused_pool and len(self.layers) >= 3:
@@ -369,6 +378,11 @@ class DeviceModel(object):
             events[0].record()
         for i, L in enumerate(self.layers):
             last = i == len(self.layers) - 1
+            if i == 0 and self.first is not None and isinstance(bufs[0], hiplib.SplitBuf):
+                y = self._view(bufs[0], R, L["cout"])
+                hiplib.tdnn_first(h, R, self.first, L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, y)
+                h = y
+                continue
             if self.pair is not None and i == len(self.layers) - 2:
                 Lb = self.layers[-1]
                 hiplib.tdnn_pair_pool(h, R, self.pair, (L["bias"], L["scale"], L["shift"], L["alpha"]),

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -19,6 +19,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32",
            "xv_packed_pair_bf16x3_bytes", "xv_pack_pair_bf16x3", "xv_tdnn_pair_pool_bf16x3",
+           "xv_packed_first_bf16x3_bytes", "xv_pack_first_bf16x3", "xv_tdnn_first_bf16x3",
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
@@ -90,6 +91,12 @@ def load():
     lib.xv_block_stats_bytes.argtypes = [i64, ci]
     lib.xv_tdnn_layer_pool_bf16x3.restype = ci
     lib.xv_tdnn_layer_pool_bf16x3.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
+    lib.xv_packed_first_bf16x3_bytes.restype = sz
+    lib.xv_packed_first_bf16x3_bytes.argtypes = [ci, ci, ci]
+    lib.xv_pack_first_bf16x3.restype = ci
+    lib.xv_pack_first_bf16x3.argtypes = [vp, ci, ci, ci, vp, vp]
+    lib.xv_tdnn_first_bf16x3.restype = ci
+    lib.xv_tdnn_first_bf16x3.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
     lib.xv_packed_pair_bf16x3_bytes.restype = sz
     lib.xv_packed_pair_bf16x3_bytes.argtypes = [ci, ci, ci]
     lib.xv_pack_pair_bf16x3.restype = ci
@@ -327,6 +334,44 @@ def tdnn_layer_pool(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid
     _check(lib.xv_tdnn_layer_pool_bf16x3(xp, fmt, int(R), w.cin, ldx, _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
                                          _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), _ptr(block_stats), _stream()),
            "xv_tdnn_layer_pool_bf16x3")
+
+
+class PackedFirst(object):
+    """Weights of the first frame-level layer in the fragment order of xv_tdnn_first_bf16x3."""
+
+    def __init__(self, wt, K, cin, cout):
+        self.wt, self.K, self.cin, self.cout = wt, K, cin, cout
+
+
+def first_supported(K, cin, cout):
+    return int(load().xv_packed_first_bf16x3_bytes(int(K), int(cin), int(cout))) > 0
+
+
+def pack_first_bf16x3(w3d):
+    """w[K, Cin, Cout] (device fp32, TF order) -> PackedFirst."""
+    import torch
+    lib = require_gpu()
+    _f32(w3d, "w"); assert w3d.dim() == 3
+    K, cin, cout = (int(v) for v in w3d.shape)
+    nbytes = int(lib.xv_packed_first_bf16x3_bytes(K, cin, cout))
+    if nbytes == 0:
+        raise XvectorHipError("xv_pack_first_bf16x3: unsupported shape K=%d, %d -> %d" % (K, cin, cout))
+    wt = torch.empty(nbytes, dtype=torch.uint8, device=w3d.device)
+    _check(lib.xv_pack_first_bf16x3(_ptr(w3d.contiguous()), K, cin, cout, _ptr(wt), _stream()), "xv_pack_first_bf16x3")
+    return PackedFirst(wt, K, cin, cout)
+
+
+def tdnn_first(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y):
+    """First frame-level layer: x fp32 rows [>=R, ld] (ld % 8 == 0, columns >= Cin zero) -> y (SplitBuf).  w: PackedFirst."""
+    lib = require_gpu()
+    assert isinstance(w, PackedFirst) and isinstance(y, SplitBuf)
+    _rows2d(x, "x"); assert x.shape[0] >= R and x.shape[1] >= w.cin
+    assert y.channels == w.cout and y.rows >= R
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_first_bf16x3(_ptr(x), int(R), w.cin, x.stride(0), _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+                                    _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), ctypes.c_void_p(y.ptr), _stream()),
+           "xv_tdnn_first_bf16x3")
 
 
 class PackedPair(object):
