@@ -255,7 +255,7 @@ def _e2e_leg(args, weights, topo, feat):
         models.Model.save_model(dict(weights=weights, topology=topo, model_class="ModelWithoutDropout", num_classes=64, feat_dim=feat),
                                 tmp, None)
         best = None
-        for _ in range(2):                                         # first pass also pins the staging buffers
+        for _ in range(3):                                         # the first pass also pins the staging buffers and faults the read arenas in
             out = io.BytesIO()
             t0 = time.perf_counter()
             models.Model().make_embedding(io.BytesIO(data), out, tmp, 25, 10000, True, log)
@@ -267,7 +267,7 @@ def _e2e_leg(args, weights, topo, feat):
     return {"value": n / best, "unit": "utt/s", "utterances": n, "vectors_written": int(nvec), "seconds": best,
             "ark_gb_in": len(data) / 1e9, "ark_gb_per_s": len(data) / 1e9 / best,
             "path": "ark bytes in host RAM -> Model.make_embedding(min_chunk 25, chunk 10000) -> ark bytes in host RAM, incl. model "
-                    "load, Kaldi parsing, packing, H2D, D2H and FV serialisation; best of 2 passes"}
+                    "load, Kaldi parsing, packing, H2D, D2H and FV serialisation; best of 3 passes"}
 
 
 def main():
