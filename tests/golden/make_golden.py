@@ -285,21 +285,23 @@ def golden_egs_ranges(out):
 
 
 def main():
+    # XV_GOLDEN_OUT: write somewhere else (tests/test_golden_reproducible.py regenerates into a scratch directory and compares)
+    out_dir = os.environ.get("XV_GOLDEN_OUT", HERE)
     ref_io, ref_models, Session = import_reference()
     if sys.argv[1:] == ["schedules"]:            # leaves the other (byte-stable) fixtures untouched
-        golden_schedules(os.path.join(HERE, "schedules.npz"))
+        golden_schedules(os.path.join(out_dir, "schedules.npz"))
         return
     if sys.argv[1:] == ["forward"]:
-        golden_forward(os.path.join(HERE, "forward_default.npz"))
+        golden_forward(os.path.join(out_dir, "forward_default.npz"))
         return
     if sys.argv[1:] == ["egs_ranges"]:
-        golden_egs_ranges(os.path.join(HERE, "egs_ranges.npz"))
+        golden_egs_ranges(os.path.join(out_dir, "egs_ranges.npz"))
         return
-    golden_egs_ranges(os.path.join(HERE, "egs_ranges.npz"))
-    golden_schedules(os.path.join(HERE, "schedules.npz"))
-    golden_ark_io(ref_io, os.path.join(HERE, "ark_io.npz"))
-    golden_make_embedding(ref_io, ref_models, Session, os.path.join(HERE, "make_embedding.npz"))
-    golden_forward(os.path.join(HERE, "forward_default.npz"))
+    golden_egs_ranges(os.path.join(out_dir, "egs_ranges.npz"))
+    golden_schedules(os.path.join(out_dir, "schedules.npz"))
+    golden_ark_io(ref_io, os.path.join(out_dir, "ark_io.npz"))
+    golden_make_embedding(ref_io, ref_models, Session, os.path.join(out_dir, "make_embedding.npz"))
+    golden_forward(os.path.join(out_dir, "forward_default.npz"))
 
 
 if __name__ == "__main__":
