@@ -63,6 +63,41 @@ def test_model_dir_contract_roundtrip(tmp_path):
     assert np.all(w["frame_level_info_layer-0/b:0"] == np.float32(0.1))
     assert np.all(w["frame_level_info_layer-3/variance:0"] == 1) and np.all(w["embed_layer-1/gamma:0"] == 1)
     assert sorted(w) == sorted(wio.expected_names(meta["topology"]))
+    assert w["output/w:0"].flags.writeable                                  # own arrays, not views of the weight file
+    # model.h5 (models.py:180-214): written and then served from when h5py exists -- exercised with a minimal stand-in here
+    assert not os.path.exists(os.path.join(mdir, "model.h5"))               # no h5py in this image: nothing written
+    import sys, types
+
+    class _Group(object):
+        pass
+
+    class _Data(object):
+        def __init__(self, a): self.a = a
+        def __getitem__(self, k): return self.a
+
+    class _File(object):
+        store = {}
+        def __init__(self, path, mode):
+            self.path, self.mode = path, mode
+            if mode == "w":
+                open(path, "wb").write(b"h5-stand-in")
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def create_dataset(self, name, data): _File.store.setdefault(self.path, {})[name] = np.array(data)
+        def visititems(self, fn):
+            for k, v in _File.store[self.path].items():
+                fn(k, _Data(v))
+    fake = types.ModuleType("h5py")
+    fake.Group, fake.File = _Group, _File
+    sys.modules["h5py"] = fake
+    try:
+        first = m.get_models_weights(mdir)
+        assert os.path.exists(os.path.join(mdir, "model.h5")) and sorted(_File.store[os.path.join(mdir, "model.h5")]) == sorted(w)
+        os.remove(os.path.join(mdir, "model.weights.npz"))                  # second call must come from the h5 alone
+        again = m.get_models_weights(mdir)
+        assert sorted(again) == sorted(first) and all(np.array_equal(again[k], w[k]) and again[k].dtype == np.float32 for k in w)
+    finally:
+        del sys.modules["h5py"]
     # incomplete dirs are rejected
     os.remove(os.path.join(mdir, "done"))
     assert not wio.is_correct_model_dir(mdir)

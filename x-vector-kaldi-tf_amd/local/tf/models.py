@@ -151,8 +151,41 @@ class Model(object):
         print('\n')
 
     def get_models_weights(self, input_dir, logger=None):
-        w, _ = wio.load_model_dir(input_dir)
-        return {k: np.array(v) for k, v in w.items()}          # own, writable arrays (the loader hands out views of the file)
+        """Twin of models.py:180-214: ``{tf variable name: float32 ndarray}`` of the trainable variables plus the BN moving
+        statistics, printed one per line, cached in / served from ``<input_dir>/model.h5`` when ``h5py`` is installed (one
+        dataset per variable, named like the variable -- the layout the reference writes).  Without ``h5py`` the dictionary
+        is returned all the same and no file is written."""
+        h5file = os.path.join(input_dir, 'model.h5')
+        try:
+            import h5py
+        except ImportError:
+            h5py = None
+        if h5py is not None and os.path.exists(h5file):
+            name2weights = {}
+
+            def collect(name, node):
+                if not isinstance(node, h5py.Group):
+                    name2weights[name] = np.array(node[()])
+            with h5py.File(h5file, 'r') as hf:
+                hf.visititems(collect)
+            return name2weights
+        w, meta = wio.load_model_dir(input_dir)
+        name2weights = {}
+        for name in wio.expected_names(meta["topology"]):     # trainables first, then mean / variance: the reference's order
+            if name.rsplit('/', 1)[-1] not in ("mean:0", "variance:0"):
+                name2weights[name] = np.array(w[name], dtype=np.float32)      # own, writable arrays (the loader hands out views)
+        for name in wio.expected_names(meta["topology"]):
+            if name not in name2weights:
+                name2weights[name] = np.array(w[name], dtype=np.float32)
+        for name, mat in name2weights.items():
+            print('%s  shape: %s' % (name, str(mat.shape)))
+        if h5py is not None:
+            with h5py.File(h5file, 'w') as hf:
+                for name, mat in name2weights.items():
+                    hf.create_dataset(name, data=mat.astype(np.float32))
+        elif logger is not None:
+            logger.info("h5py is not installed: %s not written" % h5file)
+        return name2weights
 
     # -- training / diagnostics (SURVEY §8f-1) ---------------------------------------------------------
     def _trainer(self, input_dir, logger):
