@@ -41,6 +41,49 @@ def test_random_topologies_match_the_oracle(oracle_mod, seed):
     assert worst["fp32"] < 1e-5 and worst["bf16x3"] < 1e-4, worst
 
 
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_topologies_through_the_first_layer_and_pair_kernels(oracle_mod, seed):
+    """Random topologies of the shape the specialised kernels take -- layer 0 with K*ceil8(F) <= 128 and a width that is a
+    multiple of 32; last two layers K = 1 around a 512-wide intermediate -- through DeviceModel + Extractor (bf16x3) against
+    the fp64 oracle, with the kernels asserted to be the ones that ran; the same model with both switched off must agree to
+    fp32 summation order."""
+    import os
+    from xvector_amd import engine, hiplib, synthetic
+    hiplib.require_gpu()
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for case in range(6):
+        F = int(rng.choice([23, 13, 24, 8]))
+        k0 = int(rng.choice([3, 5])) if F > 16 else int(rng.choice([3, 5, 7]))
+        ks = [k0, int(rng.choice([1, 3, 5])), int(rng.choice([3, 5, 7])), 1, 1]
+        ds = [int(rng.choice([1, 2])) if k == 3 else 1 for k in ks]
+        topo = dict(layer_sizes=[int(rng.choice([32, 64, 160, 512])), int(rng.choice([32, 96])), int(rng.choice([32, 64, 160])), 512,
+                                 int(rng.choice([64, 192, 320, 1536]))],
+                    kernel_sizes=ks, dilations=ds, embedding_sizes=[int(rng.choice([16, 40])), 16],
+                    activation=str(rng.choice(["relu", "lrelu", "prelu"])), lrelu_alpha=0.2, pooling="stats")
+        w = synthetic.trained_like(topo, F, 8, seed=int(rng.integers(1 << 30)))
+        lens = [int(x) for x in rng.integers(1, 900, size=int(rng.integers(2, 10)))]
+        mn, cs = int(rng.choice([1, 25])), int(rng.choice([-1, 200]))
+        mats = [(rng.standard_normal((t, F)) * 3).astype(np.float32) for t in lens]
+        refs = [oracle_mod.embed_utterance(m, w, topo, mn, cs, np.float64) for m in mats]
+        model = engine.DeviceModel(w, topo, "cuda:0")
+        assert model.pair is not None and model.first is not None, topo
+        got = engine.Extractor(model, mn, cs, max_batch_rows=int(rng.choice([700, 262144]))).extract(mats)
+        os.environ["XVECTOR_PAIR_KERNEL"] = os.environ["XVECTOR_FIRST_KERNEL"] = "0"
+        try:
+            plain = engine.DeviceModel(w, topo, "cuda:0")
+        finally:
+            del os.environ["XVECTOR_PAIR_KERNEL"], os.environ["XVECTOR_FIRST_KERNEL"]
+        assert plain.pair is None and plain.first is None
+        base = engine.Extractor(plain, mn, cs).extract(mats)
+        for g, b, r in zip(got, base, refs):
+            assert (g is None) == (r is None) == (b is None), (case, topo, lens, mn, cs)
+            if g is not None:
+                worst = max(worst, oracle_mod.rel_l2(g, r))
+                assert oracle_mod.rel_l2(g, b) < 2e-5, (case, topo)
+    assert worst < 1e-4, worst
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_topologies_gradients_match_autograd(seed):
     """The training step (fp32 kernels) on random topologies -- widths, kernel sizes, dilations, activation, pooling kind,
