@@ -49,13 +49,13 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 11). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 12). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
 /* Process-wide launch tuning (no TF counterpart; the analogue of the session's ConfigProto knobs,
  * local/tf/models.py:361-363).  Results do not depend on any of these.
- *   XV_TUNE_TILE_ROWS  rows per workgroup tile of the bf16x3 GEMM with split-format input: 128 (4 waves, two
+ *   XV_TUNE_TILE_ROWS  rows per workgroup tile of the bf16x3 / f16bf8 GEMMs with split-format input: 128 (4 waves, two
  *                      workgroups per CU), 256 (8 waves, one per CU), 0 = built-in choice. */
 #define XV_TUNE_TILE_ROWS 1
 int xv_set_tuning(int key, int value);
@@ -160,6 +160,41 @@ int xv_tdnn_pair_pool_bf16x3(const void *x, int64_t R, int cin, int cmid, int co
                              const float *bn_scale1, const float *bn_shift1, const float *act_alpha1, const float *bias2,
                              const float *bn_scale2, const float *bn_shift2, const float *act_alpha2, int act_kind,
                              const uint8_t *row_valid, float *block_stats, void *stream);
+
+/* ---- f16bf8 split-precision twins of the hidden frame-level layers --------------------------------------------------
+ *
+ * The same layer (models.py:54-76) with every product formed as
+ *     x*w = xh*wh + 2^-11 (xl8*wh8 + xh8*wl8)      xh = fp16(x), xl8 = bf8(2^11 (x - xh)), xh8 = bf8(x)   (bf8 = e5m2)
+ * i.e. one v_mfma_f32_32x32x16_f16 and one block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 holds both cross terms
+ * of a 32-channel slab; the 2^-11 is its E8M0 scale operand) per three bf16 MFMAs of the bf16x3 arithmetic; fp32
+ * accumulation, fp32 epilogue.  Accuracy on the full network: 1.1e-5 relative L2 against fp64 (bf16x3: 5e-6).
+ *   XV_FMT_SPLIT8  the XV_FMT_SPLIT geometry (128 bytes per row and 32-channel slab, same padding contract, same
+ *                  xv_split_row_bytes, physical slot = logical slot ^ ((r>>1)&7)) with logical slot g (0..3) = fp16 hi of
+ *                  channels 8g..8g+7 and slot 4+g = [8 x xl8 | 8 x xh8] of the same channels.
+ * Range: values are clamped to +-57344 (largest finite e5m2; fp16 ends at 65504) when a layer WRITES this format; every
+ * writer takes `status` (device int32, may be NULL) and ORs bit 0 into it when it had to clamp -- the caller then repeats
+ * the batch in the bf16x3 arithmetic (fp32 range).  Activations of a BN-normalised network are O(1..100).
+ * Weights: xv_pack_weights_f16bf8 -> xv_packed_weights_f16bf8_bytes(K,Cin,Cout) bytes of 16 KB tiles in the order of
+ *   xv_pack_weights_bf16x3, each [fp16 plane 128x64 B][8-bit plane 128x64 B, slot g = 8 x wh8 | 8 x wl8]; |w| > 57344 clamps.
+ * xv_tdnn_layer_f16bf8: x in XV_FMT_SPLIT8; y in XV_FMT_F32 (row stride ldy), XV_FMT_SPLIT (to feed a bf16x3 consumer such
+ *   as xv_tdnn_pair_pool_bf16x3) or XV_FMT_SPLIT8; K in {1,3,5,7}, 2 <= (K-1)*dilation <= 8 for K > 1.
+ * xv_tdnn_layer_pool_f16bf8: the xv_tdnn_layer_pool_bf16x3 contract (block statistics instead of y).
+ * xv_tdnn_first_f16bf8: xv_tdnn_first_bf16x3 (bf16x3 arithmetic on the fp32 feature rows, same packed weights) writing
+ *   XV_FMT_SPLIT8 rows.  xv_split8_encode_f32 / xv_split8_decode_f32: tooling and tests (decode returns hi + xl8 / 2^11). */
+#define XV_FMT_SPLIT8 2
+size_t xv_packed_weights_f16bf8_bytes(int K, int cin, int cout);
+int xv_pack_weights_f16bf8(const float *w, int K, int cin, int cout, void *wt, void *stream);
+int xv_split8_encode_f32(const float *x, int64_t R, int c, int ldx, void *xs, int32_t *status, void *stream);
+int xv_split8_decode_f32(const void *xs, int64_t R, int c, float *x, int ldx, void *stream);
+int xv_tdnn_layer_f16bf8(const void *x, int64_t R, int cin, const void *wt, const float *bias, const float *bn_scale,
+                         const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                         const uint8_t *row_valid, void *y, int y_format, int ldy, int32_t *status, void *stream);
+int xv_tdnn_layer_pool_f16bf8(const void *x, int64_t R, int cin, const void *wt, const float *bias, const float *bn_scale,
+                              const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                              const uint8_t *row_valid, float *block_stats, void *stream);
+int xv_tdnn_first_f16bf8(const float *x, int64_t R, int cin, int ldx, const void *wt, const float *bias, const float *bn_scale,
+                         const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                         const uint8_t *row_valid, void *y, int32_t *status, void *stream);
 
 /* xv_fc_f32 twin: fp32 rows in, fp32 rows out; wt = xv_pack_weights_bf16x3(w, 1, In, Out). */
 int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const void *wt, const float *bias, const float *bn_scale,

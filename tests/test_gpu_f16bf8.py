@@ -1,0 +1,262 @@
+"""GPU parity tests of the f16bf8 arithmetic (xv_gemm8.hip, xv_split8.h) through the C ABI against the fp64 oracle.
+
+A product is xh*wh + 2^-11 (xl8*wh8 + xh8*wl8): one fp16 MFMA + one block-scaled bf8 MFMA instead of three bf16 MFMAs.
+Per layer the result is good to ~1e-5 relative L2 (bf16x3: ~3e-6); the tolerance here is 4e-5, the north star's bar for
+the whole network is 1e-4 (checked in test_gpu_forward.py for this precision as for the others).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_GEMM8 = 4e-5
+CODE = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}
+
+
+@pytest.fixture(scope="module")
+def env(oracle_mod):
+    import torch
+    from xvector_amd import engine, hiplib
+    hiplib.require_gpu()
+    return dict(torch=torch, hiplib=hiplib, engine=engine, oracle=oracle_mod, dev=torch.device("cuda:0"))
+
+
+def _rand_bn(rng, c):
+    return ((1 + 0.1 * rng.standard_normal(c)).astype(np.float32), (0.1 * rng.standard_normal(c)).astype(np.float32),
+            (0.2 * rng.standard_normal(c)).astype(np.float32), np.exp(0.2 * rng.standard_normal(c)).astype(np.float32))
+
+
+def _alpha(rng, act, cout):
+    if act == "lrelu":
+        return np.array([0.2], np.float32)
+    if act == "prelu":
+        return (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    return None
+
+
+def test_split8_roundtrip_layout_and_overflow_flag(env):
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    rng = np.random.default_rng(0)
+    R, C = 77, 80                                   # ragged last slab
+    x = (rng.standard_normal((R, C)) * np.exp(1.5 * rng.standard_normal((R, C)))).astype(np.float32)   # |x| up to ~1e3
+    x[3, 5] = 0.0
+    x[4, 6] = 1e-7                                  # below fp16's normal range: kept to an absolute 2^-25
+    xd = torch.from_numpy(x).to(dev)
+    buf = hiplib.SplitBuf(R, C, dev, hiplib.FMT_SPLIT8)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    hiplib.split_encode(xd, buf, status=status)
+    back = hiplib.split_decode(buf, R).cpu().numpy()
+    assert int(status.item()) == 0
+    err = np.abs(back - x)
+    assert (err <= np.maximum(np.abs(x) * 2.0 ** -13, 2.0 ** -24)).all()
+    # bytes: slot g of a row-slab = fp16 hi of channels 8g..8g+7, physical slot = logical ^ ((row >> 1) & 7)
+    raw = buf.base.cpu().numpy()[hiplib.SPLIT_PAD_BEFORE * buf.row_bytes:].reshape(-1, buf.row_bytes)
+    r, c = 10, 37
+    slab, g, e = c // 32, (c % 32) // 8, c % 8
+    sw = (r >> 1) & 7
+    hi = raw[r, slab * 128 + ((g ^ sw) << 4):][:16].view(np.float16)[e]
+    assert hi == np.float16(x[r, c])
+    cross = raw[r, slab * 128 + (((4 + g) ^ sw) << 4):][:16]
+    h8 = (cross[8 + e:9 + e].astype(np.uint16) << 8).view(np.float16)[0]              # e5m2 = the upper byte of an fp16
+    assert abs(float(h8) - x[r, c]) <= abs(x[r, c]) * 0.125
+    l8 = (cross[e:e + 1].astype(np.uint16) << 8).view(np.float16)[0]
+    assert abs(float(hi) + float(l8) / 2048 - x[r, c]) <= abs(x[r, c]) * 2.0 ** -13
+    # the padding channels of the last slab (80..95: groups 2 and 3 of slab 2) are zeros
+    for r in range(R):
+        sw = (r >> 1) & 7
+        for slot in (2, 3, 6, 7):
+            assert not raw[r, 2 * 128 + ((slot ^ sw) << 4):][:16].any()
+    # range: |v| > 57344 clamps and raises the flag
+    x[7, 7] = 1e6
+    x[8, 1] = -7e4
+    hiplib.split_encode(torch.from_numpy(x).to(dev), buf, status=status)
+    back = hiplib.split_decode(buf, R).cpu().numpy()
+    assert int(status.item()) == 1 and back[7, 7] == 57344.0 and back[8, 1] == -57344.0
+
+
+@pytest.mark.parametrize("tile_rows", [128, 256])
+@pytest.mark.parametrize("cin,cout,K,dil,act,yfmt", [
+    (512, 512, 5, 1, "relu", "split8"),       # layer 1 of the default topology
+    (512, 512, 7, 1, "relu", "split"),        # layer 2, feeding the bf16x3 pair kernel
+    (512, 512, 1, 1, "relu", "split8"),
+    (512, 1536, 1, 1, "lrelu", "f32"),
+    (512, 512, 3, 3, "relu", "split8"),       # dilated
+    (512, 512, 3, 2, "prelu", "split"),
+    (64, 48, 5, 1, "prelu", "split8"),        # ragged Cout: the general epilogue
+    (40, 200, 3, 2, "lrelu", "f32"),          # Cin not a multiple of 32
+    (96, 128, 7, 1, "none", "split8"),
+])
+def test_tdnn_layer_f16bf8_matches_oracle(env, cin, cout, K, dil, act, yfmt, tile_rows):
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(cin * 1000 + cout + K * 7 + dil + 2)
+    lens = [25, 1, 130, 257, 64, 3, 700]
+    mats = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in lens]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = _alpha(rng, act, cout)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    gap = max(1, (K - 1) * dil // 2)
+    scale, shift = hiplib.fold_bn(*(t(a) for a in bn), 1e-3)
+    wp = hiplib.pack_weights_f16bf8(t(w))
+    assert wp.wt.numel() == hiplib.pack_weights_bf16x3(t(w)).wt.numel()
+
+    def run(ms):
+        layout = engine.BatchLayout([m.shape[0] for m in ms], gap)
+        host = np.zeros((layout.rows, cin), np.float32)
+        layout.pack(ms, host)
+        xin = hiplib.SplitBuf(layout.rows, cin, dev, hiplib.FMT_SPLIT8)
+        hiplib.split_encode(t(host), xin)
+        rv = t(layout.row_valid())
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        if yfmt == "f32":
+            y = torch.full((layout.rows, cout), float("nan"), dtype=torch.float32, device=dev)
+        else:
+            y = hiplib.SplitBuf(layout.rows, cout, dev, hiplib.FMT_SPLIT8 if yfmt == "split8" else hiplib.FMT_SPLIT)
+            y.base.fill_(0x7b)                     # poison: fp16 0x7b7b = 61280, bf16 0x7b7b = 1.3e36
+        hiplib.tdnn_layer8(xin, layout.rows, wp, t(b), scale, shift, CODE[act], t(alpha), dil, rv, y, status)
+        yh = (y if yfmt == "f32" else hiplib.split_decode(y, layout.rows)).cpu().numpy()
+        assert int(status.item()) == 0
+        return [yh[s:s + n] for s, n in zip(layout.row_start, layout.row_len)], yh, layout
+
+    hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, tile_rows)
+    try:
+        outs, yh, layout = run(mats)
+        alone, _, _ = run([mats[3]])
+    finally:
+        hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
+    for m, got in zip(mats, outs):
+        ref = oracle.tdnn_layer(m, w, b, bn, act, alpha, dil, np.float64)
+        assert np.isfinite(got).all()
+        assert oracle.rel_l2(got, ref) < TOL_GEMM8, (m.shape[0], oracle.rel_l2(got, ref))
+    assert (yh[~layout.row_valid().astype(bool)] == 0).all()          # gap rows: exact zeros
+    assert np.array_equal(alone[0], outs[3])                            # batch composition does not change a result
+
+
+def test_f16bf8_tile_heights_agree_bitwise(env):
+    """256-row and 128-row workgroup tiles accumulate every output element in the same order."""
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    rng = np.random.default_rng(5)
+    R, cin, cout, K = 3000, 512, 512, 5
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = hiplib.SplitBuf(R, cin, dev, hiplib.FMT_SPLIT8)
+    hiplib.split_encode(t(rng.standard_normal((R, cin)).astype(np.float32)), x)
+    wp = hiplib.pack_weights_f16bf8(t((rng.standard_normal((K, cin, cout)) / 50).astype(np.float32)))
+    outs = []
+    for rows in (128, 256):
+        hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, rows)
+        try:
+            y = hiplib.SplitBuf(R, cout, dev, hiplib.FMT_SPLIT8)
+            hiplib.tdnn_layer8(x, R, wp, None, None, None, 1, None, 1, None, y)
+            outs.append(y.base.cpu().numpy().copy())
+        finally:
+            hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_f16bf8_overflow_sets_the_status_word(env):
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    R, cin, cout = 300, 64, 128
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = hiplib.SplitBuf(R, cin, dev, hiplib.FMT_SPLIT8)
+    hiplib.split_encode(t(np.full((R, cin), 100.0, np.float32)), x)
+    w = np.zeros((1, cin, cout), np.float32)
+    w[0, :, 0] = 1.0                                 # column 0: 6400 -- fine; with bn scale 10: 64000 > 57344
+    wp = hiplib.pack_weights_f16bf8(t(w))
+    scale = t(np.full(cout, 10.0, np.float32))
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    y = hiplib.SplitBuf(R, cout, dev, hiplib.FMT_SPLIT8)
+    hiplib.tdnn_layer8(x, R, wp, None, scale, None, 1, None, 1, None, y, status)
+    got = hiplib.split_decode(y, R).cpu().numpy()
+    assert int(status.item()) == 1 and (got[:, 0] == 57344.0).all() and (got[:, 1:] == 0).all()
+    # the same values into fp32 rows or the bf16 split format: no clamp, no flag
+    status.zero_()
+    y32 = torch.empty((R, cout), dtype=torch.float32, device=dev)
+    hiplib.tdnn_layer8(x, R, wp, None, scale, None, 1, None, 1, None, y32, status)
+    assert int(status.item()) == 0 and (y32[:, 0] == 64000.0).all()
+
+
+@pytest.mark.parametrize("cin,cout,K,dil,act,lens", [
+    (512, 1536, 1, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),
+    (64, 200, 3, 1, "prelu", [300, 25, 64]),
+    (40, 48, 5, 2, "lrelu", [1200, 33]),
+])
+def test_tdnn_layer_pool_f16bf8_blocks_match_oracle(env, cin, cout, K, dil, act, lens):
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(cin + cout + K + len(lens) + 1)
+    mats = [(rng.standard_normal((n, cin)) * 2).astype(np.float32) for n in lens]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = _alpha(rng, act, cout)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    layout = engine.BatchLayout(lens, max(1, (K - 1) * dil // 2), hiplib.POOL_BLOCK_ROWS)
+    host = np.zeros((layout.rows, cin), np.float32)
+    layout.pack(mats, host)
+    xin = hiplib.SplitBuf(layout.rows, cin, dev, hiplib.FMT_SPLIT8)
+    hiplib.split_encode(t(host), xin)
+    scale, shift = hiplib.fold_bn(*(t(a) for a in bn), 1e-3)
+    blk = torch.full((hiplib.block_stats_floats(layout.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
+    hiplib.tdnn_layer_pool8(xin, layout.rows, hiplib.pack_weights_f16bf8(t(w)), t(b), scale, shift, CODE[act], t(alpha), dil,
+                            t(layout.row_valid()), blk)
+    out = torch.full((len(lens), 2 * cout), float("nan"), dtype=torch.float32, device=dev)
+    hiplib.stats_pool_blocks(blk, cout, t(layout.row_start), t(layout.row_len), len(lens), 1e-5, out)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    for i, m in enumerate(mats):
+        ref = oracle.stats_pool(oracle.tdnn_layer(m, w, b, bn, act, alpha, dil, np.float64), 1e-5, np.float64)
+        assert oracle.rel_l2(got[i, :cout], ref[:cout]) < TOL_GEMM8, (i, lens[i])
+        assert oracle.rel_l2(got[i, cout:], ref[cout:]) < TOL_GEMM8, (i, lens[i])
+
+
+def test_first_layer_kernel_writes_split8(env):
+    """xv_tdnn_first_f16bf8 = xv_tdnn_first_bf16x3 with the other output encoding: same values to the encoding's precision."""
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(11)
+    feat, in_dim, cout, K = 23, 24, 512, 5
+    lens = [25, 1, 130, 600, 3]
+    mats = [(rng.standard_normal((n, feat)) * 3).astype(np.float32) for n in lens]
+    w = np.zeros((K, in_dim, cout), np.float32)
+    w[:, :feat] = rng.standard_normal((K, feat, cout)) / np.sqrt(K * feat)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    layout = engine.BatchLayout(lens, 2, 8)
+    host = np.zeros((layout.rows, in_dim), np.float32)
+    layout.pack(mats, host)
+    scale, shift = hiplib.fold_bn(*(t(a) for a in bn), 1e-3)
+    first = hiplib.pack_first_bf16x3(t(w))
+    rv = t(layout.row_valid())
+    y3 = hiplib.SplitBuf(layout.rows, cout, dev)
+    hiplib.tdnn_first(t(host), layout.rows, first, t(b), scale, shift, 1, None, 1, rv, y3)
+    y8 = hiplib.SplitBuf(layout.rows, cout, dev, hiplib.FMT_SPLIT8)
+    y8.base.fill_(0x7b)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    hiplib.tdnn_first(t(host), layout.rows, first, t(b), scale, shift, 1, None, 1, rv, y8, status)
+    a, c = hiplib.split_decode(y3, layout.rows).cpu().numpy(), hiplib.split_decode(y8, layout.rows).cpu().numpy()
+    assert int(status.item()) == 0 and np.isfinite(c).all()
+    assert (np.abs(a - c) <= np.maximum(np.abs(a) * 2.0 ** -13, 2.0 ** -24)).all()
+    assert (c[~layout.row_valid().astype(bool)] == 0).all()
+    for i, m in enumerate(mats):
+        s = int(layout.row_start[i])
+        assert oracle.rel_l2(c[s:s + lens[i]], oracle.tdnn_layer(m, w[:, :feat], b, bn, "relu", None, 1, np.float64)) < TOL_GEMM8
+
+
+def test_f16bf8_bad_arguments_fail_loudly(env):
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x8 = hiplib.SplitBuf(64, 64, dev, hiplib.FMT_SPLIT8)
+    x3 = hiplib.SplitBuf(64, 64, dev)
+    y = torch.empty((64, 32), dtype=torch.float32, device=dev)
+    w9 = hiplib.pack_weights_f16bf8(t(np.zeros((9, 64, 32), np.float32)))
+    with pytest.raises(hiplib.XvectorHipError, match="K in"):
+        hiplib.tdnn_layer8(x8, 64, w9, None, None, None, 1, None, 1, None, y)
+    w5 = hiplib.pack_weights_f16bf8(t(np.zeros((5, 64, 32), np.float32)))
+    with pytest.raises(hiplib.XvectorHipError, match="dilation"):
+        hiplib.tdnn_layer8(x8, 64, w5, None, None, None, 1, None, 3, None, y)
+    with pytest.raises(AssertionError):
+        hiplib.tdnn_layer8(x3, 64, w5, None, None, None, 1, None, 1, None, y)          # bf16 split input
+    with pytest.raises(hiplib.XvectorHipError, match="act_alpha"):
+        hiplib.tdnn_layer8(x8, 64, w5, None, None, None, 3, None, 1, None, y)
+    assert hiplib.f16bf8_supported(5, 1) and hiplib.f16bf8_supported(3, 3) and hiplib.f16bf8_supported(1, 1)
+    assert not hiplib.f16bf8_supported(9, 1) and not hiplib.f16bf8_supported(5, 3) and not hiplib.f16bf8_supported(4, 1)

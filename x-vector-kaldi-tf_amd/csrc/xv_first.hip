@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "xvector_hip.h"
+#include "xv_split8.h"
 
 extern "C" void xv_internal_set_error(const char *msg);
 
@@ -59,6 +60,7 @@ struct FirstParams {
     const uint8_t *valid;
     uint8_t *y;                // split-format output, row 0
     int ychunks;
+    int *status;               // Y8: bit 0 set when a value had to be clamped (may be NULL)
 };
 
 #define XV_GLDS16_OFF(gptr, lptr, imm)                                                                          \
@@ -71,7 +73,8 @@ __device__ __forceinline__ float act_fn(float z, float a)
     return MODE == 1 ? fmaxf(a * z, z) : MODE == 2 ? fmaxf(z, 0.f) : fmaxf(z, 0.f) + a * fminf(z, 0.f);
 }
 
-template <int MODE>
+// Y8: write XV_FMT_SPLIT8 rows (fp16 hi + bf8 cross bytes, xv_split8.h) instead of the bf16 hi/lo planes
+template <int MODE, bool Y8>
 __global__ __launch_bounds__(FR_WAVES * 64, 4) void tdnn_first_kernel(const FirstParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(FR_WAVES * 64, 4) void tdnn_first_kernel(const Firs
         c0[u] = k - tap * p.kc;
     }
     const size_t yrow = (size_t)p.ychunks * SROW;
+    float amax = 0.f;
     const int n_pass = (p.cout + FR_PASS_COLS - 1) / FR_PASS_COLS;
 
     for (int pass = 0; pass < n_pass; ++pass) {
@@ -176,24 +180,40 @@ __global__ __launch_bounds__(FR_WAVES * 64, 4) void tdnn_first_kernel(const Firs
                 const f32x4 b0 = P4[c4], b1 = P4[c4 + 1], s0 = P4[FR_MAX_COUT / 4 + c4], s1 = P4[FR_MAX_COUT / 4 + c4 + 1],
                             o0 = P4[2 * FR_MAX_COUT / 4 + c4], o1 = P4[2 * FR_MAX_COUT / 4 + c4 + 1],
                             a0 = P4[3 * FR_MAX_COUT / 4 + c4], a1 = P4[3 * FR_MAX_COUT / 4 + c4 + 1];
-                bf16x8 vh, vl;
+                float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v0 = (act_fn<MODE>(lo4[e] + b0[e], a0[e]) * s0[e] + o0[e]) * keep;
-                    const float v1 = (act_fn<MODE>(hi4[e] + b1[e], a1[e]) * s1[e] + o1[e]) * keep;
-                    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
-                    vh[e] = h0; vh[4 + e] = h1;
-                    vl[e] = (__bf16)(v0 - (float)h0); vl[4 + e] = (__bf16)(v1 - (float)h1);
+                    v[e] = (act_fn<MODE>(lo4[e] + b0[e], a0[e]) * s0[e] + o0[e]) * keep;
+                    v[4 + e] = (act_fn<MODE>(hi4[e] + b1[e], a1[e]) * s1[e] + o1[e]) * keep;
                 }
-                if (row < p.R) {
-                    const int slab = cb >> 5, t = (cb & 31) >> 3;
-                    uint8_t *slabp = yr + (size_t)slab * SROW;
-                    __builtin_nontemporal_store(vh, reinterpret_cast<bf16x8 *>(slabp + ((t ^ sw) << 4)));
-                    __builtin_nontemporal_store(vl, reinterpret_cast<bf16x8 *>(slabp + (((4 + t) ^ sw) << 4)));
+                const int slab = cb >> 5, t = (cb & 31) >> 3;
+                uint8_t *slabp = yr + (size_t)slab * SROW;
+                if constexpr (Y8) {
+                    xv_f16x8 vh;
+                    xv_i32x4 vx;
+                    xv_split8_encode8<true>(v, vh, vx, amax);
+                    if (row < p.R) {
+                        __builtin_nontemporal_store(vh, reinterpret_cast<xv_f16x8 *>(slabp + ((t ^ sw) << 4)));
+                        __builtin_nontemporal_store(vx, reinterpret_cast<xv_i32x4 *>(slabp + (((4 + t) ^ sw) << 4)));
+                    }
+                } else {
+                    bf16x8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const __bf16 h = (__bf16)v[e];
+                        vh[e] = h;
+                        vl[e] = (__bf16)(v[e] - (float)h);
+                    }
+                    if (row < p.R) {
+                        __builtin_nontemporal_store(vh, reinterpret_cast<bf16x8 *>(slabp + ((t ^ sw) << 4)));
+                        __builtin_nontemporal_store(vl, reinterpret_cast<bf16x8 *>(slabp + (((4 + t) ^ sw) << 4)));
+                    }
                 }
             }
         }
     }
+    if constexpr (Y8)
+        if (amax > XV_SPLIT8_MAX && p.status) atomicOr(p.status, 1);
 }
 
 // w[K][cin][cout] (TF order) -> per pass of FR_PASS_COLS output channels: [tile][k-step 0..3][hi 1 KB | lo 1 KB], fragment
@@ -248,26 +268,27 @@ int xv_pack_first_bf16x3(const float *w, int K, int cin, int cout, void *wt, voi
     return 0;
 }
 
-int xv_tdnn_first_bf16x3(const float *x, int64_t R, int cin, int ldx, const void *wt, const float *bias, const float *bn_scale,
-                         const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
-                         const uint8_t *row_valid, void *y, void *stream)
+static int first_launch(const float *x, int64_t R, int cin, int ldx, const void *wt, const float *bias, const float *bn_scale,
+                        const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                        const uint8_t *row_valid, void *y, bool y8, int32_t *status, void *stream)
 {
     if (R <= 0) return 0;
-    if (!x || !wt || !y) return fail(XV_ERR_BAD_ARG, "tdnn_first_bf16x3: NULL pointer");
-    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_first_bf16x3: unknown act_kind");
-    if ((act_kind == XV_ACT_LRELU || act_kind == XV_ACT_PRELU) && !act_alpha) return fail(XV_ERR_BAD_ARG, "tdnn_first_bf16x3: act_alpha is NULL");
+    if (!x || !wt || !y) return fail(XV_ERR_BAD_ARG, "tdnn_first: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_first: unknown act_kind");
+    if ((act_kind == XV_ACT_LRELU || act_kind == XV_ACT_PRELU) && !act_alpha) return fail(XV_ERR_BAD_ARG, "tdnn_first: act_alpha is NULL");
     const int kc = (cin + 7) / 8 * 8;
     if (!first_shape_ok(K, cin, cout) || dilation <= 0 || (K - 1) * dilation > 8)
-        return fail(XV_ERR_UNSUPPORTED, "tdnn_first_bf16x3: needs K odd, K*ceil8(cin) <= 128, (K-1)*dilation <= 8, cout % 32 == 0, cout <= 512");
+        return fail(XV_ERR_UNSUPPORTED, "tdnn_first: needs K odd, K*ceil8(cin) <= 128, (K-1)*dilation <= 8, cout % 32 == 0, cout <= 512");
     if (ldx < kc || (ldx & 7) || (((uintptr_t)x) & 31))
-        return fail(XV_ERR_UNSUPPORTED, "tdnn_first_bf16x3: rows must hold ceil8(cin) floats (padding columns zero), ldx % 8 == 0, x 32-byte aligned");
-    if ((((uintptr_t)wt) | ((uintptr_t)y)) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_first_bf16x3: wt and y must be 16-byte aligned");
+        return fail(XV_ERR_UNSUPPORTED, "tdnn_first: rows must hold ceil8(cin) floats (padding columns zero), ldx % 8 == 0, x 32-byte aligned");
+    if ((((uintptr_t)wt) | ((uintptr_t)y)) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_first: wt and y must be 16-byte aligned");
     FirstParams p{};
     p.x = x; p.R = (long)R; p.ldx = ldx; p.kc = kc; p.K = K; p.dil = dilation; p.cout = cout; p.wt = (const uint8_t *)wt;
     p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.alpha = act_alpha; p.act = act_kind; p.valid = row_valid;
-    p.y = (uint8_t *)y; p.ychunks = cout / 32;
+    p.y = (uint8_t *)y; p.ychunks = cout / 32; p.status = (int *)status;
     typedef void (*kern_t)(const FirstParams);
-    const kern_t kerns[3] = {tdnn_first_kernel<0>, tdnn_first_kernel<1>, tdnn_first_kernel<2>};
+    const kern_t kerns[6] = {tdnn_first_kernel<0, false>, tdnn_first_kernel<1, false>, tdnn_first_kernel<2, false>,
+                             tdnn_first_kernel<0, true>,  tdnn_first_kernel<1, true>,  tdnn_first_kernel<2, true>};
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -280,10 +301,27 @@ int xv_tdnn_first_bf16x3(const float *x, int64_t R, int cin, int ldx, const void
     }
     const int mode = act_kind == XV_ACT_LRELU ? 1 : act_kind == XV_ACT_RELU ? 2 : 0;
     const long strip = (long)FR_STRIP * FR_ROWS;
-    hipLaunchKernelGGL(kerns[mode], dim3((unsigned)((R + strip - 1) / strip)), dim3(FR_WAVES * 64), FR_LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kerns[mode + (y8 ? 3 : 0)], dim3((unsigned)((R + strip - 1) / strip)), dim3(FR_WAVES * 64), FR_LDS_BYTES,
+                       (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;
+}
+
+int xv_tdnn_first_bf16x3(const float *x, int64_t R, int cin, int ldx, const void *wt, const float *bias, const float *bn_scale,
+                         const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                         const uint8_t *row_valid, void *y, void *stream)
+{
+    return first_launch(x, R, cin, ldx, wt, bias, bn_scale, bn_shift, act_kind, act_alpha, K, dilation, cout, row_valid, y, false,
+                        nullptr, stream);
+}
+
+int xv_tdnn_first_f16bf8(const float *x, int64_t R, int cin, int ldx, const void *wt, const float *bias, const float *bn_scale,
+                         const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                         const uint8_t *row_valid, void *y, int32_t *status, void *stream)
+{
+    return first_launch(x, R, cin, ldx, wt, bias, bn_scale, bn_shift, act_kind, act_alpha, K, dilation, cout, row_valid, y, true,
+                        status, stream);
 }
 
 }  // extern "C"

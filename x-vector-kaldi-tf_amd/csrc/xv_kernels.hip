@@ -1325,7 +1325,9 @@ int check_launch(const char *what)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int xv_version(void) { return 11; }
+void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
+
+int xv_version(void) { return 12; }
 
 int xv_set_tuning(int key, int value)
 {
@@ -1333,6 +1335,7 @@ int xv_set_tuning(int key, int value)
     case XV_TUNE_TILE_ROWS:
         if (value != 0 && value != 128 && value != 256) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: tile rows must be 0, 128 or 256");
         g_tile_rows.store(value, std::memory_order_relaxed);
+        xv_internal_gemm8_tile_rows(value);
         return 0;
     default:
         return fail(XV_ERR_BAD_ARG, "xv_set_tuning: unknown key");

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -20,6 +20,8 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32",
            "xv_packed_pair_bf16x3_bytes", "xv_pack_pair_bf16x3", "xv_tdnn_pair_pool_bf16x3",
            "xv_packed_first_bf16x3_bytes", "xv_pack_first_bf16x3", "xv_tdnn_first_bf16x3",
+           "xv_packed_weights_f16bf8_bytes", "xv_pack_weights_f16bf8", "xv_split8_encode_f32", "xv_split8_decode_f32",
+           "xv_tdnn_layer_f16bf8", "xv_tdnn_layer_pool_f16bf8", "xv_tdnn_first_f16bf8",
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
@@ -31,7 +33,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_attention_scores_f32", "xv_attention_softmax_f32", "xv_attention_pool_workspace_bytes", "xv_attention_pool_f32",
            "xv_attention_pool_backward_f32", "xv_attention_softmax_backward_f32", "xv_attention_scores_backward_f32")
 
-FMT_F32, FMT_SPLIT = 0, 1
+FMT_F32, FMT_SPLIT, FMT_SPLIT8 = 0, 1, 2
 SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 264
 TUNE_TILE_ROWS = 1
 
@@ -97,6 +99,20 @@ def load():
     lib.xv_pack_first_bf16x3.argtypes = [vp, ci, ci, ci, vp, vp]
     lib.xv_tdnn_first_bf16x3.restype = ci
     lib.xv_tdnn_first_bf16x3.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
+    lib.xv_packed_weights_f16bf8_bytes.restype = sz
+    lib.xv_packed_weights_f16bf8_bytes.argtypes = [ci, ci, ci]
+    lib.xv_pack_weights_f16bf8.restype = ci
+    lib.xv_pack_weights_f16bf8.argtypes = [vp, ci, ci, ci, vp, vp]
+    lib.xv_split8_encode_f32.restype = ci
+    lib.xv_split8_encode_f32.argtypes = [vp, i64, ci, ci, vp, vp, vp]
+    lib.xv_split8_decode_f32.restype = ci
+    lib.xv_split8_decode_f32.argtypes = [vp, i64, ci, vp, ci, vp]
+    lib.xv_tdnn_layer_f16bf8.restype = ci
+    lib.xv_tdnn_layer_f16bf8.argtypes = [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp]
+    lib.xv_tdnn_layer_pool_f16bf8.restype = ci
+    lib.xv_tdnn_layer_pool_f16bf8.argtypes = [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
+    lib.xv_tdnn_first_f16bf8.restype = ci
+    lib.xv_tdnn_first_f16bf8.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp, vp]
     lib.xv_packed_pair_bf16x3_bytes.restype = sz
     lib.xv_packed_pair_bf16x3_bytes.argtypes = [ci, ci, ci]
     lib.xv_pack_pair_bf16x3.restype = ci
@@ -239,32 +255,39 @@ def pack_weights_bf16x3(w3d):
 
 
 class SplitBuf(object):
-    """Device buffer in the split activation format with the zero padding rows the layer kernels may read
+    """Device buffer in a split activation format (``fmt``: FMT_SPLIT = bf16 hi/lo planes, FMT_SPLIT8 = fp16 hi + bf8
+    cross bytes; same geometry) with the zero padding rows the layer kernels may read
     (rows [-SPLIT_PAD_BEFORE, rows + SPLIT_PAD_AFTER))."""
 
-    def __init__(self, rows, channels, device):
+    def __init__(self, rows, channels, device, fmt=FMT_SPLIT):
         import torch
-        self.rows, self.channels = int(rows), int(channels)
+        self.rows, self.channels, self.fmt = int(rows), int(channels), int(fmt)
         self.row_bytes = int(load().xv_split_row_bytes(self.channels))
         self.base = torch.zeros((SPLIT_PAD_BEFORE + self.rows + SPLIT_PAD_AFTER) * self.row_bytes, dtype=torch.uint8, device=device)
         self.ptr = self.base.data_ptr() + SPLIT_PAD_BEFORE * self.row_bytes      # row 0
 
-    def view(self, channels):
-        """Same storage seen as a buffer of ``channels`` channels per row (<= allocated width)."""
+    def view(self, channels, fmt=None):
+        """Same storage seen as a buffer of ``channels`` channels per row (<= allocated width), optionally in the other
+        split format (all-zero bytes are zeros in both)."""
         v = object.__new__(SplitBuf)
         v.rows, v.channels, v.base = self.rows, int(channels), self.base
+        v.fmt = self.fmt if fmt is None else int(fmt)
         v.row_bytes = int(load().xv_split_row_bytes(v.channels))
         assert v.row_bytes <= self.row_bytes
         v.ptr = self.base.data_ptr() + SPLIT_PAD_BEFORE * v.row_bytes
         return v
 
 
-def split_encode(x, buf, rows=None):
-    """fp32 rows x[R, C] -> buf (SplitBuf)."""
+def split_encode(x, buf, rows=None, status=None):
+    """fp32 rows x[R, C] -> buf (SplitBuf, either format; ``status``: int32 device tensor, FMT_SPLIT8 only)."""
     lib = require_gpu()
     _f32(x, "x")
     R = x.shape[0] if rows is None else int(rows)
     assert R <= buf.rows and x.shape[1] == buf.channels
+    if buf.fmt == FMT_SPLIT8:
+        _check(lib.xv_split8_encode_f32(_ptr(x), R, x.shape[1], x.stride(0), ctypes.c_void_p(buf.ptr), _ptr(status), _stream()),
+               "xv_split8_encode_f32")
+        return
     _check(lib.xv_split_encode_f32(_ptr(x), R, x.shape[1], x.stride(0), ctypes.c_void_p(buf.ptr), _stream()), "xv_split_encode_f32")
 
 
@@ -274,8 +297,8 @@ def split_decode(buf, rows, out=None):
     lib = require_gpu()
     if out is None:
         out = torch.empty((rows, buf.channels), dtype=torch.float32, device=buf.base.device)
-    _check(lib.xv_split_decode_f32(ctypes.c_void_p(buf.ptr), int(rows), buf.channels, _ptr(out), out.stride(0), _stream()),
-           "xv_split_decode_f32")
+    fn = lib.xv_split8_decode_f32 if buf.fmt == FMT_SPLIT8 else lib.xv_split_decode_f32
+    _check(fn(ctypes.c_void_p(buf.ptr), int(rows), buf.channels, _ptr(out), out.stride(0), _stream()), "xv_split_decode_f32")
     return out
 
 
@@ -284,6 +307,7 @@ def tdnn_layer3(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y,
     lib = require_gpu()
     assert isinstance(w, Packed3)
     xs, ys = isinstance(x, SplitBuf), isinstance(y, SplitBuf)
+    assert not (xs and x.fmt != FMT_SPLIT) and not (ys and y.fmt != FMT_SPLIT), "bf16x3 layers take the bf16 split format"
     if xs:
         assert x.channels == w.cin and x.rows >= R
         xp, ldx = ctypes.c_void_p(x.ptr), 0
@@ -322,7 +346,7 @@ def tdnn_layer_pool(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid
     lib = require_gpu()
     assert isinstance(w, Packed3)
     if isinstance(x, SplitBuf):
-        assert x.channels == w.cin and x.rows >= R
+        assert x.channels == w.cin and x.rows >= R and x.fmt == FMT_SPLIT
         xp, ldx, fmt = ctypes.c_void_p(x.ptr), 0, FMT_SPLIT
     else:
         _f32(x, "x"); assert x.shape[1] == w.cin and x.shape[0] >= R
@@ -361,17 +385,81 @@ def pack_first_bf16x3(w3d):
     return PackedFirst(wt, K, cin, cout)
 
 
-def tdnn_first(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y):
-    """First frame-level layer: x fp32 rows [>=R, ld] (ld % 8 == 0, columns >= Cin zero) -> y (SplitBuf).  w: PackedFirst."""
+def tdnn_first(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y, status=None):
+    """First frame-level layer: x fp32 rows [>=R, ld] (ld % 8 == 0, columns >= Cin zero) -> y (SplitBuf; its format selects
+    the entry point, ``status`` as for tdnn_layer8).  w: PackedFirst."""
     lib = require_gpu()
     assert isinstance(w, PackedFirst) and isinstance(y, SplitBuf)
     _rows2d(x, "x"); assert x.shape[0] >= R and x.shape[1] >= w.cin
     assert y.channels == w.cout and y.rows >= R
     if row_valid is not None:
         assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    if y.fmt == FMT_SPLIT8:
+        _check(lib.xv_tdnn_first_f16bf8(_ptr(x), int(R), w.cin, x.stride(0), _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+                                        _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), ctypes.c_void_p(y.ptr), _ptr(status),
+                                        _stream()), "xv_tdnn_first_f16bf8")
+        return
     _check(lib.xv_tdnn_first_bf16x3(_ptr(x), int(R), w.cin, x.stride(0), _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
                                     _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), ctypes.c_void_p(y.ptr), _stream()),
            "xv_tdnn_first_bf16x3")
+
+
+class Packed8(object):
+    """Tiled f16bf8 weights of one layer (xv_pack_weights_f16bf8) + the shape they were packed for."""
+
+    def __init__(self, wt, K, cin, cout):
+        self.wt, self.K, self.cin, self.cout = wt, K, cin, cout
+
+
+def f16bf8_supported(K, dilation):
+    """Shapes xv_tdnn_layer_f16bf8 takes (the split-input shapes of the bf16x3 kernel)."""
+    span = (int(K) - 1) * int(dilation)
+    return int(K) in (1, 3, 5, 7) and (int(K) == 1 or 2 <= span <= 8)
+
+
+def pack_weights_f16bf8(w3d):
+    """w3d: [K, Cin, Cout] fp32 (TF layout) -> Packed8."""
+    import torch
+    lib = require_gpu()
+    _f32(w3d, "w")
+    K, cin, cout = w3d.shape
+    nbytes = int(lib.xv_packed_weights_f16bf8_bytes(K, cin, cout))
+    wt = torch.empty(nbytes, dtype=torch.uint8, device=w3d.device)
+    _check(lib.xv_pack_weights_f16bf8(_ptr(w3d), K, cin, cout, _ptr(wt), _stream()), "xv_pack_weights_f16bf8")
+    return Packed8(wt, K, cin, cout)
+
+
+def tdnn_layer8(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y, status=None):
+    """f16bf8 layer.  x: SplitBuf in FMT_SPLIT8; y: contiguous fp32 tensor [>=R, C] or SplitBuf of either format; w: Packed8;
+    status: int32 device tensor whose bit 0 is set when a FMT_SPLIT8 output had to be clamped (None: not reported)."""
+    lib = require_gpu()
+    assert isinstance(w, Packed8) and isinstance(x, SplitBuf) and x.fmt == FMT_SPLIT8
+    assert x.channels == w.cin and x.rows >= R
+    if isinstance(y, SplitBuf):
+        assert y.channels == w.cout and y.rows >= R
+        yp, ldy, yfmt = ctypes.c_void_p(y.ptr), 0, y.fmt
+    else:
+        _rows2d(y, "y"); assert y.shape[1] == w.cout and y.shape[0] >= R
+        yp, ldy, yfmt = _ptr(y), y.stride(0), FMT_F32
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_layer_f16bf8(ctypes.c_void_p(x.ptr), int(R), w.cin, _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+                                    _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), yp, yfmt, ldy, _ptr(status), _stream()),
+           "xv_tdnn_layer_f16bf8")
+
+
+def tdnn_layer_pool8(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, block_stats):
+    """tdnn_layer_pool in the f16bf8 arithmetic (x: SplitBuf in FMT_SPLIT8, w: Packed8)."""
+    lib = require_gpu()
+    assert isinstance(w, Packed8) and isinstance(x, SplitBuf) and x.fmt == FMT_SPLIT8
+    assert x.channels == w.cin and x.rows >= R
+    _f32(block_stats, "block_stats")
+    assert block_stats.numel() >= block_stats_floats(R, w.cout), "block_stats too small"
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_layer_pool_f16bf8(ctypes.c_void_p(x.ptr), int(R), w.cin, _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift),
+                                         int(act), _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), _ptr(block_stats),
+                                         _stream()), "xv_tdnn_layer_pool_f16bf8")
 
 
 class PackedPair(object):
@@ -406,7 +494,7 @@ def tdnn_pair_pool(x, R, w, p1, p2, act, row_valid, block_stats):
     bn_shift, act_alpha) device tensors (None allowed) of the first / second layer."""
     lib = require_gpu()
     assert isinstance(x, SplitBuf) and isinstance(w, PackedPair)
-    assert x.channels == w.cin and x.rows >= R
+    assert x.channels == w.cin and x.rows >= R and x.fmt == FMT_SPLIT
     _f32(block_stats, "block_stats"); assert block_stats.numel() >= block_stats_floats(R, w.cout)
     if row_valid is not None:
         assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
