@@ -65,7 +65,7 @@ def parse():
                          "instead of the default ModelWithoutDropout network; implies its own head (softmax-CE)")
     ap.add_argument("--head", choices=["am_softmax", "softmax"], default="am_softmax",
                     help="--mode train: classification head (BASELINE configs[4] names AM-softmax; 'softmax' = the reference's head)")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+    ap.add_argument("--precision", choices=["bf16x3", "f16bf8", "fp32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = split-precision bf16 MFMA with fp32 accumulate (fp32-class accuracy, "
                          "default); fp32 = exact fp32-input MFMA")
     return ap.parse_args()
@@ -290,7 +290,7 @@ def main():
         return bench_train(args, rank, world, dev, topo, feat)
     weights = synthetic.trained_like(topo, feat, seed=1)
     model = engine.DeviceModel(weights, topo, dev, precision=args.precision,
-                               fused_pool=(args.precision == "bf16x3" and not args.no_fused_pool))
+                               fused_pool=(args.precision in ("bf16x3", "f16bf8") and not args.no_fused_pool))
 
     # ---- synthetic workload resident in HBM: ragged batches in kernel layout -------------------
     lens = synthetic.utterance_lengths(args.utts, args.tmin, args.tmax, 1234 + rank)

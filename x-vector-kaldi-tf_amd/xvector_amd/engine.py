@@ -217,8 +217,24 @@ class DeviceModel(object):
         intermediate activation stays in registers."""
         import torch
         hiplib.require_gpu()
-        assert precision in ("fp32", "bf16x3")
+        assert precision in ("fp32", "bf16x3", "f16bf8")
+        # "f16bf8": the hidden frame-level layers form a product as one fp16 MFMA + one block-scaled bf8 MFMA instead of
+        # three bf16 MFMAs (xv_tdnn_layer_f16bf8; ~1e-5 rel-L2 on the x-vector).  Everything else (first layer, segment FCs,
+        # the pair kernel, pooling) is the bf16x3 path.  A topology the f16bf8 kernels do not cover runs as plain bf16x3;
+        # a batch whose activations leave the fp16 range raises ``status`` and is repeated by ``fallback()``.
+        self.requested_precision = precision
+        self.f16bf8 = False
+        if precision == "f16bf8":
+            precision = "bf16x3"
+            ks, ds = list(topo["kernel_sizes"]), list(topo["dilations"])
+            w0 = weights["frame_level_info_layer-0/w:0"]
+            self.f16bf8 = (not tp.is_attention(topo) and fused_pool in (None, True) and len(ks) >= 3 and
+                           os.environ.get("XVECTOR_FIRST_KERNEL", "1") != "0" and
+                           hiplib.first_supported(ks[0], (w0.shape[1] + 7) // 8 * 8, w0.shape[2]) and (ks[0] - 1) * ds[0] <= 8 and
+                           all(hiplib.f16bf8_supported(k, d) for k, d in zip(ks[1:], ds[1:])))
         self.precision = precision
+        self._weights = weights if self.f16bf8 else None
+        self._fallback = None
         self.attention = tp.is_attention(topo)
         self.fused_pool = (precision == "bf16x3" and not self.attention) if fused_pool is None else bool(fused_pool)
         assert not (self.fused_pool and precision != "bf16x3"), "fused pooling exists on the bf16x3 path only"
@@ -281,6 +297,13 @@ class DeviceModel(object):
                     wb = weights["frame_level_info_layer-%d/w:0" % (n - 1)][0]
                     self.pair = hiplib.pack_pair_bf16x3(self._dev(wa), self._dev(wb))
             assert not (pair_kernel and self.pair is None), "pair_kernel=True but the topology / precision does not allow it"
+            if self.f16bf8:
+                assert self.first is not None
+                n = len(self.layers)
+                for i in range(1, n - 2 if self.pair is not None else n):
+                    sc = "frame_level_info_layer-%d" % i
+                    self.layers[i]["wp8"] = hiplib.pack_weights_f16bf8(self._dev(weights[sc + "/w:0"]))
+                self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.embed = []
             for j in range(len(topo["embedding_sizes"])):
                 sc = "embed_layer-%d" % j
@@ -292,6 +315,13 @@ class DeviceModel(object):
         self._cap_chunks = 0
         self._pool_ws = None
         self._a0 = None
+
+    def fallback(self):
+        """The bf16x3 twin of an f16bf8 model (built on first use): repeats a batch whose activations left the fp16 range."""
+        if self._fallback is None:
+            assert self.f16bf8
+            self._fallback = DeviceModel(self._weights, self.topo, self.device, self.embedding_index, "bf16x3")
+        return self._fallback
 
     def _dev(self, a):
         return self.torch.as_tensor(np.array(a, dtype=np.float32, order="C")).to(self.device)     # copy: sources may be read-only
@@ -365,17 +395,26 @@ class DeviceModel(object):
         return buf.view(-1)[: rows * width].view(rows, width)
 
     # -- the kernel sequence ----------------------------------------------------------------------
-    def frame_level(self, x, row_start, row_len, row_valid, nchunks, max_len, pooled, events=None):
+    def frame_level(self, x, row_start, row_len, row_valid, nchunks, max_len, pooled, events=None, status=None):
         """Frame-level part for ONE ragged batch: x[R,in_dim] (gap rows zero) -> 5 TDNN layers -> statistics
         pooling, written to pooled[nchunks, 2*C_last].  Device tensors only; no allocation when ``reserve`` was
         called with sufficient capacity.  ``events``: optional 3 torch.cuda.Event recorded before the first layer,
-        after the last layer and after pooling (bench.py's per-kernel timing)."""
+        after the last layer and after pooling (bench.py's per-kernel timing).  ``status`` (f16bf8 models): int32 device
+        tensor that collects the out-of-range flag of this batch (default: the model's own ``status`` word)."""
         R = x.shape[0]
         self.reserve(R, nchunks, max_len)
         h = x
         bufs = (self._ping, self._pong)
         if events is not None:
             events[0].record()
+        if self.f16bf8:
+            self._frame_level_f16bf8(x, R, row_valid, self.status if status is None else status)
+            if events is not None:
+                events[1].record()
+            hiplib.stats_pool_blocks(self._last, self.layers[-1]["cout"], row_start, row_len, nchunks, tp.VAR2STD_EPSILON, pooled)
+            if events is not None:
+                events[2].record()
+            return pooled
         for i, L in enumerate(self.layers):
             last = i == len(self.layers) - 1
             if i == 0 and self.first is not None and isinstance(bufs[0], hiplib.SplitBuf):
@@ -413,6 +452,30 @@ class DeviceModel(object):
         if events is not None:
             events[2].record()
         return pooled
+
+    def _frame_level_f16bf8(self, x, R, row_valid, status):
+        """first-layer kernel -> split8; hidden layers in the f16bf8 arithmetic; the layer in front of the pair kernel writes
+        the bf16 split format that kernel reads; block statistics end up in ``self._last``."""
+        n = len(self.layers)
+        bufs = (self._ping, self._pong)
+        S8, S3 = hiplib.FMT_SPLIT8, hiplib.FMT_SPLIT
+        L = self.layers[0]
+        stop = n - 2 if self.pair is not None else n - 1        # layers [1, stop) run on xv_tdnn_layer_f16bf8
+        h = bufs[0].view(L["cout"], S3 if (self.pair is not None and stop == 1) else S8)
+        hiplib.tdnn_first(x, R, self.first, L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, h, status)
+        for i in range(1, stop):
+            L = self.layers[i]
+            y = bufs[i & 1].view(L["cout"], S3 if (self.pair is not None and i == stop - 1) else S8)
+            hiplib.tdnn_layer8(h, R, L["wp8"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, y, status)
+            h = y
+        if self.pair is not None:
+            La, Lb = self.layers[-2], self.layers[-1]
+            hiplib.tdnn_pair_pool(h, R, self.pair, (La["bias"], La["scale"], La["shift"], La["alpha"]),
+                                  (Lb["bias"], Lb["scale"], Lb["shift"], Lb["alpha"]), self.act, row_valid, self._last)
+        else:
+            L = self.layers[-1]
+            hiplib.tdnn_layer_pool8(h, R, L["wp8"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid,
+                                    self._last)
 
     def _attention_scores(self, h, R, L, row_valid):
         """Last frame-level layer + attention scores (models.py:1022-1046) for one batch: leaves the per-row scores in
@@ -521,6 +584,7 @@ class Extractor(object):
         self._finalizer = None
         self._holder = []                              # [cache key, staging sets]: what the finalizer parks
         self._pin_free = {}
+        self._fallback_ex = None                       # bf16x3 twin of an f16bf8 extractor (out-of-range windows)
 
     def _staging(self, rows, nchunks):
         """NBUF pinned sets: features [rows, in_dim] (padding columns zeroed once), row_valid[rows], meta int32[2, chunks].
@@ -643,6 +707,7 @@ class Extractor(object):
             P_all = torch.empty((nch, model.pooled_dim), dtype=torch.float32, device=dev)
             model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), int(c_len.max()))
             keep = []                                   # device inputs stay referenced until the window is done
+            status = torch.zeros(1, dtype=torch.int32, device=dev) if model.f16bf8 else None
             for bi, (b0, b1, _) in enumerate(bounds):
                 layout = BatchLayout(c_len[b0:b1], gap, align)
                 st = stage[self._turn % self.NBUF]
@@ -669,7 +734,7 @@ class Extractor(object):
                     ev.record(self._copy_stream)
                 st["event"] = ev
                 compute.wait_event(ev)
-                model.frame_level(x, md[0], md[1], rv, layout.nchunks, layout.max_len, P_all[b0:b1])
+                model.frame_level(x, md[0], md[1], rv, layout.nchunks, layout.max_len, P_all[b0:b1], status=status)
                 keep.append((x, rv, md))
                 self.stats["batches"] += 1
                 self.stats["chunks"] += layout.nchunks
@@ -690,11 +755,21 @@ class Extractor(object):
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
             host_flat, host = self._pinned("xvec", (len(order), model.embed_dim), torch.float32)
             host.copy_(out, non_blocking=True)
+            self._watch(handle, status, lambda ex: ex.submit(mats, addrs))
             done = torch.cuda.Event()
             done.record(compute)
         # mats (the native packer read them in place) and the device buffers stay referenced until finish()
         handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats), pinned=(tail_flat, host_flat))
         return handle
+
+    def _watch(self, handle, status, redo):
+        """f16bf8 models: bring the window's out-of-range flag down with its x-vectors; ``finish`` repeats the window on the
+        bf16x3 twin of the model (``redo``) when it is set."""
+        if status is None:
+            return
+        flat, flag = self._pinned("flag", (1,), self.model.torch.int32)
+        flag.copy_(status, non_blocking=True)
+        handle.update(flag=flag, flag_flat=flat, redo=redo, status=status)
 
     def submit_raw(self, mats, vads, cmn_window, center=True, min_window=100, addrs=None):
         """``submit`` for RAW features: sliding-window CMN + VAD frame selection (xv_cmn_sliding_scatter_f32) run on the
@@ -752,6 +827,7 @@ class Extractor(object):
             P_all = torch.empty((nch, model.pooled_dim), dtype=torch.float32, device=dev)
             model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), int(c_len.max()))
             keep = []
+            status = torch.zeros(1, dtype=torch.int32, device=dev) if model.f16bf8 else None
             for (b0, b1, _), (lo, hi) in zip(bounds, spans):
                 layout = BatchLayout(c_len[b0:b1], gap, align)
                 U = order[lo:hi]
@@ -804,7 +880,7 @@ class Extractor(object):
                 compute.wait_event(ev)
                 x = torch.zeros((layout.rows, model.in_dim), dtype=torch.float32, device=dev)      # gap rows and padding columns
                 hiplib.cmn_sliding_scatter(raw_d, utt_d[0], utt_d[1], nU, int(Tb.max()), cmn_window, center, min_window, dst_d, x)
-                model.frame_level(x, md[0], md[1], rv, layout.nchunks, layout.max_len, P_all[b0:b1])
+                model.frame_level(x, md[0], md[1], rv, layout.nchunks, layout.max_len, P_all[b0:b1], status=status)
                 keep.append((x, rv, md, raw_d, dst_d, utt_d))
                 self.stats["batches"] += 1
                 self.stats["chunks"] += layout.nchunks
@@ -824,6 +900,7 @@ class Extractor(object):
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
             host_flat, host = self._pinned("xvec", (len(order), model.embed_dim), torch.float32)
             host.copy_(out, non_blocking=True)
+            self._watch(handle, status, lambda ex: ex.submit_raw(mats, vads, cmn_window, center, min_window, addrs)[0])
             done = torch.cuda.Event()
             done.record(compute)
         handle.update(host=host, done=done, keep=(keep, E_all, P_all, tail, tail_d, out, mats), pinned=(tail_flat, host_flat))
@@ -849,6 +926,25 @@ class Extractor(object):
         n = handle["n"]
         if handle["nch"]:
             handle["done"].synchronize()
+            if handle.get("flag") is not None:
+                clamped = int(handle["flag"][0]) != 0
+                self._unpin("flag", handle.pop("flag_flat"))
+                handle["flag"] = None
+                if clamped:
+                    # some activation of the window left the fp16 range of the f16bf8 arithmetic: the whole window again on
+                    # the bf16x3 twin (fp32 range) -- its results replace the clamped ones
+                    redo = handle.pop("redo")
+                    pinned = handle.pop("pinned", None)
+                    if pinned is not None:
+                        self._unpin("tail", pinned[0])
+                        self._unpin("xvec", pinned[1])
+                    handle["keep"] = None
+                    self.stats["fallback_windows"] = self.stats.get("fallback_windows", 0) + 1
+                    if self._fallback_ex is None:
+                        self._fallback_ex = Extractor(self.model.fallback(), self.min_chunk_size, self.chunk_size,
+                                                      self.max_batch_rows, self.max_batch_chunks)
+                    return self._fallback_ex.finish(redo(self._fallback_ex), as_array)
+                handle.pop("redo", None)
             host_out = handle["host"].numpy()
             handle["keep"] = None
         if as_array:
