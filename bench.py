@@ -65,7 +65,7 @@ def parse():
                          "instead of the default ModelWithoutDropout network; implies its own head (softmax-CE)")
     ap.add_argument("--head", choices=["am_softmax", "softmax"], default="am_softmax",
                     help="--mode train: classification head (BASELINE configs[4] names AM-softmax; 'softmax' = the reference's head)")
-    ap.add_argument("--precision", choices=["bf16x3", "f16bf8", "fp32"], default="bf16x3",
+    ap.add_argument("--precision", choices=["f16bf8", "bf16x3", "fp32"], default="f16bf8",
                     help="GEMM arithmetic: bf16x3 = split-precision bf16 MFMA with fp32 accumulate (fp32-class accuracy, "
                          "default); fp32 = exact fp32-input MFMA")
     return ap.parse_args()
@@ -393,6 +393,24 @@ def main():
         kern = {"kernel": "tdnn_gemm_kernel<true> (5 TDNN layers per batch + embed FC per step)",
                 "peak": MFMA_F32_PEAK / 1e12, "frac": fl_gemm / t_gemm / MFMA_F32_PEAK,
                 "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"}
+    elif getattr(model, "f16bf8", False):
+        # MFMA time a product costs, in bf16-MFMA units: 3 in the bf16x3 arithmetic (first layer, pair kernel, embed FC);
+        # 2 in the f16bf8 arithmetic (one fp16 MFMA at the bf16 rate + one scaled 8-bit MFMA that executes 2 products at
+        # twice that rate).  frac = MFMA-pipe time at nominal rates / measured kernel time.
+        prev, units = feat, 0.0
+        for i, (k, c) in enumerate(zip(topo["kernel_sizes"], topo["layer_sizes"])):
+            units += 2.0 * k * prev * c * frames * (2 if "wp8" in model.layers[i] else 3)
+            prev = c
+        units = (units + 3.0 * tp.flops_per_utt(topo) * n_utts) * args.steps
+        kern = {"kernel": "tdnn_first_kernel (layer 0, bf16x3) + tdnn_gemm_f16bf8_wide_kernel (layers 1-2: fp16 MFMA + scaled bf8 MFMA "
+                          "per product) + tdnn_pair_pool_kernel (layers 3+4 chained in registers, bf16x3, pooling statistics in its "
+                          "epilogue) per batch, embed FC per step",
+                "peak": fl_gemm / (units / MFMA_BF16_PEAK) / 1e12, "frac": units / t_gemm / MFMA_BF16_PEAK,
+                "executed_bf16_equivalent_tflops": units / t_gemm / 1e12,
+                "peak_note": "achieved = ALGORITHMIC (fp32-contraction) FLOPs.  A product costs 3 bf16 MFMAs in the bf16x3 kernels "
+                             "and 1 fp16 MFMA + 2 products of a scaled 8-bit MFMA at twice the rate (= 2 bf16-MFMA times) in the "
+                             "f16bf8 kernels; peak = algorithmic FLOPs / (MFMA-pipe time at 2.5 PF bf16 / 5 PF fp8 dense), "
+                             "frac = that pipe time / measured kernel time"}
     else:
         kern = {"kernel": ("tdnn_gemm_bf16x3_kernel (layers 0-2) + tdnn_pair_pool_kernel (layers 3+4 chained in registers, pooling "
                            "statistics in its epilogue) per batch, embed FC per step" if paired else
@@ -408,7 +426,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "f32 in/out, GEMMs as bf16x3 split MFMA (hi*hi+hi*lo+lo*hi) with f32 accumulate",
+        "dtype": ("f32" if args.precision == "fp32" else
+                  "f32 in/out, f32 accumulate; GEMM products as fp16 MFMA + 2^-11 x scaled bf8 MFMA of the cross terms (layers 1-2) "
+                  "and bf16x3 split MFMA (layer 0, layers 3-4, FC)" if getattr(model, "f16bf8", False) else
+                  "f32 in/out, GEMMs as bf16x3 split MFMA (hi*hi+hi*lo+lo*hi) with f32 accumulate"),
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %d utts/GPU, 23-dim MFCC, T~U{%d..%d}, default x-vector topology "
                                "[512,512,512,512,1536] k=[5,5,7,1,1], 512-d embed_layer-0" % (n_utts, args.tmin, args.tmax),
@@ -479,7 +500,7 @@ def main():
                                              "cores": 2 * nproc, "host_logical_cores": logical, "container_granted_cores": granted,
                                              "shape": "nj independent extractor processes x 2 intra-op threads, as run.sh:229-247 / "
                                                       "extract_xvectors.sh:83-88 deploy the reference (models.py:361-363)"}}
-    if world == 1 and args.precision == "bf16x3" and not args.no_fp32_leg:
+    if world == 1 and args.precision != "fp32" and not args.no_fp32_leg:
         out["fp32_exact"] = _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat)
     # ---- BASELINE configs[3] asks for the rate "incl. and excl. ark write": rank 0 writes the gathered x-vectors of ONE step
     #      as a Kaldi ark + scp (outside the timed region; `value` excludes it, `with_ark_write` folds its time into a step)
@@ -501,8 +522,9 @@ def main():
                                      "note": "D2H of the gathered [N,512] block + Kaldi ark,scp write by rank 0, serial after the step"}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    if world == 1 and args.e2e_utts > 0 and args.precision == "bf16x3":
+    if world == 1 and args.e2e_utts > 0 and args.precision != "fp32":
         del batches, E_all, P_all
+        os.environ["XVECTOR_PRECISION"] = args.precision          # Model.load_model reads it
         e2e = _e2e_leg(args, weights, topo, feat)
         e2e["fraction_of_resident_rate"] = e2e["value"] / out["value"]
         out["e2e_ark_to_ark"] = e2e

@@ -74,7 +74,7 @@ def test_split8_roundtrip_layout_and_overflow_flag(env):
     assert int(status.item()) == 1 and back[7, 7] == 57344.0 and back[8, 1] == -57344.0
 
 
-@pytest.mark.parametrize("tile_rows", [128, 256])
+@pytest.mark.parametrize("tile_rows", [128, 256, 512])      # 512 = the 256 x 256 tile where the shape allows it, else the built-in choice
 @pytest.mark.parametrize("cin,cout,K,dil,act,yfmt", [
     (512, 512, 5, 1, "relu", "split8"),       # layer 1 of the default topology
     (512, 512, 7, 1, "relu", "split"),        # layer 2, feeding the bf16x3 pair kernel
@@ -134,7 +134,7 @@ def test_tdnn_layer_f16bf8_matches_oracle(env, cin, cout, K, dil, act, yfmt, til
 
 
 def test_f16bf8_tile_heights_agree_bitwise(env):
-    """256-row and 128-row workgroup tiles accumulate every output element in the same order."""
+    """128 x 128, 256 x 128 and 256 x 256 workgroup tiles accumulate every output element in the same order."""
     torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
     rng = np.random.default_rng(5)
     R, cin, cout, K = 3000, 512, 512, 5
@@ -143,7 +143,7 @@ def test_f16bf8_tile_heights_agree_bitwise(env):
     hiplib.split_encode(t(rng.standard_normal((R, cin)).astype(np.float32)), x)
     wp = hiplib.pack_weights_f16bf8(t((rng.standard_normal((K, cin, cout)) / 50).astype(np.float32)))
     outs = []
-    for rows in (128, 256):
+    for rows in (128, 256, 512):
         hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, rows)
         try:
             y = hiplib.SplitBuf(R, cout, dev, hiplib.FMT_SPLIT8)
@@ -151,7 +151,7 @@ def test_f16bf8_tile_heights_agree_bitwise(env):
             outs.append(y.base.cpu().numpy().copy())
         finally:
             hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 def test_f16bf8_overflow_sets_the_status_word(env):
@@ -176,12 +176,14 @@ def test_f16bf8_overflow_sets_the_status_word(env):
     assert int(status.item()) == 0 and (y32[:, 0] == 64000.0).all()
 
 
-@pytest.mark.parametrize("cin,cout,K,dil,act,lens", [
-    (512, 1536, 1, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),
-    (64, 200, 3, 1, "prelu", [300, 25, 64]),
-    (40, 48, 5, 2, "lrelu", [1200, 33]),
+@pytest.mark.parametrize("cin,cout,K,dil,act,lens,tile_rows", [
+    (512, 1536, 1, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000], 0),
+    (64, 200, 3, 1, "prelu", [300, 25, 64], 0),
+    (40, 48, 5, 2, "lrelu", [1200, 33], 0),
+    (96, 512, 3, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000], 512),      # the 256 x 256 tile with the POOL epilogue
+    (64, 256, 5, 1, "prelu", [300, 25, 64], 512),
 ])
-def test_tdnn_layer_pool_f16bf8_blocks_match_oracle(env, cin, cout, K, dil, act, lens):
+def test_tdnn_layer_pool_f16bf8_blocks_match_oracle(env, cin, cout, K, dil, act, lens, tile_rows):
     torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
     rng = np.random.default_rng(cin + cout + K + len(lens) + 1)
     mats = [(rng.standard_normal((n, cin)) * 2).astype(np.float32) for n in lens]
@@ -197,8 +199,12 @@ def test_tdnn_layer_pool_f16bf8_blocks_match_oracle(env, cin, cout, K, dil, act,
     hiplib.split_encode(t(host), xin)
     scale, shift = hiplib.fold_bn(*(t(a) for a in bn), 1e-3)
     blk = torch.full((hiplib.block_stats_floats(layout.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
-    hiplib.tdnn_layer_pool8(xin, layout.rows, hiplib.pack_weights_f16bf8(t(w)), t(b), scale, shift, CODE[act], t(alpha), dil,
-                            t(layout.row_valid()), blk)
+    hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, tile_rows)
+    try:
+        hiplib.tdnn_layer_pool8(xin, layout.rows, hiplib.pack_weights_f16bf8(t(w)), t(b), scale, shift, CODE[act], t(alpha), dil,
+                                t(layout.row_valid()), blk)
+    finally:
+        hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
     out = torch.full((len(lens), 2 * cout), float("nan"), dtype=torch.float32, device=dev)
     hiplib.stats_pool_blocks(blk, cout, t(layout.row_start), t(layout.row_len), len(lens), 1e-5, out)
     got = out.cpu().numpy()

@@ -25,9 +25,9 @@ for (cin, cout, K) in ((512, 512, 5), (512, 512, 7), (512, 512, 1), (512, 1536, 
         fns = {"bf16x3": lambda: hiplib.tdnn_layer3(x3, R, w3, bias, None, None, 1, None, 1, rv, y3),
                "f16bf8": lambda: hiplib.tdnn_layer8(x8, R, w8, bias, None, None, 1, None, 1, rv, y8, status),
                "f16bf8 -> bf16 split": lambda: hiplib.tdnn_layer8(x8, R, w8, bias, None, None, 1, None, 1, rv, y3, status)}
-    times = {(n, rows): [] for n in fns for rows in (128, 256)}
+    times = {(n, rows): [] for n in fns for rows in (128, 256, 512)}
     for rnd in range(ROUNDS + 1):
-        for rows in (128, 256):
+        for rows in (128, 256, 512):
             hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, rows)
             for n, fn in fns.items():
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -53,10 +53,13 @@ constexpr int B_PLANE = BN * 64;        // 8192: fp16 plane / 8-bit plane of a w
 constexpr int B_BYTES = 2 * B_PLANE;    // 16384
 constexpr int T_LD = BN + 4;            // epilogue fp32 tile row (floats)
 
-constexpr int g8_oper_bytes(int wm) { return 2 * (wm * 64 + MAX_SPAN) * SROW + 2 * B_BYTES; }
+// (A ring of THREE weight tiles with the DMA issued three stages ahead and a counted s_waitcnt vmcnt was measured on the
+// 256-row form: no gain -- DMA latency is not what parks the waves -- so two buffers and vmcnt(0) it is.)
+constexpr int g8_ring(int, int) { return 2; }           // weight tiles in LDS
+constexpr int g8_oper_bytes(int kt, int wm) { return 2 * (wm * 64 + MAX_SPAN) * SROW + g8_ring(kt, wm) * B_BYTES; }
 constexpr int g8_tile_bytes(int wm) { return wm * 64 * T_LD * 4; }
-constexpr int g8_mask_off(int wm) { return g8_oper_bytes(wm) > g8_tile_bytes(wm) ? g8_oper_bytes(wm) : g8_tile_bytes(wm); }
-constexpr size_t g8_lds_bytes(int wm) { return (size_t)g8_mask_off(wm) + wm * 64 + 4 * BN * sizeof(float); }
+constexpr int g8_mask_off(int kt, int wm) { return g8_oper_bytes(kt, wm) > g8_tile_bytes(wm) ? g8_oper_bytes(kt, wm) : g8_tile_bytes(wm); }
+constexpr size_t g8_lds_bytes(int kt, int wm) { return (size_t)g8_mask_off(kt, wm) + wm * 64 + 4 * BN * sizeof(float); }
 
 template <int T, int KT, class F>
 __device__ __forceinline__ void for_taps(F &f)
@@ -98,11 +101,12 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
     constexpr int A_ROWS = BM + MAX_SPAN;
     constexpr int A_BYTES = A_ROWS * SROW;
     constexpr int BP = 16 / NW;                        // 1 KB pieces of a weight tile per wave
+    constexpr int RING = g8_ring(KT, WM);              // weight tiles in LDS
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *Abuf = lds;                                  // [2][A_ROWS][128 B]
-    char *Bbuf = lds + 2 * A_BYTES;                    // [2][fp16 plane 8 KB | 8-bit plane 8 KB]
-    uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + g8_mask_off(WM));
-    float *Ps = reinterpret_cast<float *>(lds + g8_mask_off(WM) + BM);
+    char *Bbuf = lds + 2 * A_BYTES;                    // [RING][fp16 plane 8 KB | 8-bit plane 8 KB]
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + g8_mask_off(KT, WM));
+    float *Ps = reinterpret_cast<float *>(lds + g8_mask_off(KT, WM) + BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -145,13 +149,13 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
     const int boff0 = brow * 64;
     const int bsw0 = (brow >> 2) & 3;                  // (brow + 32) has the same swizzle
 
-    // ---- prologue: stages 0 and 1 ---------------------------------------------------------------------------
-    const uint8_t *bsrc = p.wt + (size_t)nt * n_stages * B_BYTES + wave * (BP * 1024) + lane * 16;
-    auto dma_b = [&](int buf) {
+    // ---- prologue: the first RING weight tiles and the first halo tile(s) ------------------------------------------
+    const uint8_t *bbase = p.wt + (size_t)nt * n_stages * B_BYTES + wave * (BP * 1024) + lane * 16;
+    auto dma_b = [&](int stage, int buf) {
+        const uint8_t *src = bbase + (size_t)(stage < n_stages ? stage : n_stages - 1) * B_BYTES;
         char *dst = Bbuf + buf * B_BYTES + wave * (BP * 1024);
 #pragma unroll
-        for (int j = 0; j < BP; ++j) XV_GLDS16(bsrc + j * 1024, dst + j * 1024);
-        bsrc += B_BYTES;
+        for (int j = 0; j < BP; ++j) XV_GLDS16(src + j * 1024, dst + j * 1024);
     };
     const uint8_t *abase = p.x + (m0 - left + (lane >> 3)) * (long)xrow_bytes + (lane & 7) * 16;
     constexpr int NP = KT == 1 ? BM / 8 : BM / 8 + 1;   // 8-row (1 KB) pieces of a halo tile
@@ -160,12 +164,10 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
         for (int piece = wave; piece < NP; piece += NW)
             XV_GLDS16(abase + (size_t)chunk * SROW + (size_t)piece * 8 * xrow_bytes, dst + piece * 1024);
     };
-    dma_b(0);
+#pragma unroll
+    for (int j = 0; j < RING; ++j) dma_b(j, j);
     dma_a_slab(0);
-    if (n_stages > 1) {
-        dma_b(1);
-        if (KT == 1) dma_a_slab(1);
-    }
+    if (KT == 1 && n_stages > 1) dma_a_slab(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
             ag_off[t][j] = (uint32_t)piece * rowstep;
             al_off[t][j] = (uint32_t)piece * 1024u;
         }
-    const uint8_t *bnext = bsrc;                         // tile of stage min(s+2, n_stages-1)
-    if (n_stages <= 2) bnext = bsrc - B_BYTES;
+    const uint8_t *bnext = bbase + (size_t)(RING < n_stages ? RING : n_stages - 1) * B_BYTES;     // tile of stage min(s+RING, last)
+    int bcur = 0, bnxt = B_BYTES;                        // ring offsets of the weight tiles of stages s and s+1
 
     FragsH F;
     FragsX G;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
         char *adst_n = Abuf + (cn & 1) * A_BYTES;
         auto tap = [&](auto TT) {
             constexpr int t = decltype(TT)::value;
-            const int bbuf = (s & 1) * B_BYTES;
+            const int bbuf = bcur;
             // ---- phase 1: G <- 8-bit fragments of stage s, interleaved with the 8 fp16 MFMAs on F -------------------
             load_x(G, px[t] + abuf, bbuf);
             mma_h(F);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
                     XV_GLDS16_OFF(bnext, dst, 2048);
                     XV_GLDS16_OFF(bnext, dst, 3072);
                 }
-                bnext += (s + 3 < n_stages) ? B_BYTES : 0;
+                bnext += (s + RING + 1 < n_stages) ? B_BYTES : 0;
             }
             if constexpr (KT == 1) {
                 const int ca = (s + 2 < p.n_chunks) ? s + 2 : p.n_chunks - 1;
@@ -294,12 +296,12 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
                 char *adst = Abuf + (ca & 1) * A_BYTES;
 #pragma unroll
                 for (int j = 0; j < PW; ++j) XV_GLDS16(ag + ag_off[0][j], adst + al_off[0][j]);
-            } else if constexpr (t < KT - 1) {
+            } else if constexpr (t < DT) {
 #pragma unroll
                 for (int j = 0; j < slots_of(t); ++j) XV_GLDS16(anext + ag_off[t][j], adst_n + al_off[t][j]);
             }
-            if constexpr (t + 1 < KT) load_h(F, pa[t + 1] + abuf, B_BYTES - bbuf);
-            else load_h(F, pa[0] + abuf_n, B_BYTES - bbuf);       // first tap of the next slab (tail: harmless read)
+            if constexpr (t + 1 < KT) load_h(F, pa[t + 1] + abuf, bnxt);
+            else load_h(F, pa[0] + abuf_n, bnxt);                 // first tap of the next slab (tail: harmless read)
             mma_x(G);
             constexpr int NV = BP + (KT == 1 ? PW : slots_of(t));
             // per scaled MFMA (64 cycles): its share of the LDS-DMA pieces and 2 DS reads
@@ -311,6 +313,8 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
 #undef XV_G8_GROUP
             __builtin_amdgcn_sched_barrier(0);
             ++s;
+            bcur = bnxt;
+            bnxt = bnxt + B_BYTES == RING * B_BYTES ? 0 : bnxt + B_BYTES;
         };
         for_taps<0, KT>(tap);
     }
@@ -518,6 +522,399 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same layer on a 256 x 256 workgroup tile: 8 waves as 2 x 4, each a 128 x 64 sub-tile (4 x 2 MFMA tiles, 128
+// accumulator registers).  With 64 x 64 sub-tiles this arithmetic needs 147 LDS bytes per MFMA cycle -- more than the 128
+// the LDS delivers (halving the fragment reads made the kernel 14 % faster); 4 x 2 sub-tiles need 24 fragment reads per
+// 1024 MFMA cycles instead of 16 per 512, and a 32 KB weight stage feeds twice the MFMAs: 113 bytes per cycle.
+// The fragment sets are pipelined in four steps per stage so that at most four 16-register sets are live next to the
+// accumulators (t / b = row tiles 0,1 / 2,3 of the wave; H = fp16 fragments of both k-steps, X = 8-bit fragments):
+//     step 1   8 fp16 MFMAs (top,    BH)   | read AHb(s), BX(s)
+//     step 2   8 fp16 MFMAs (bottom, BH)   | read AXt(s)
+//     barrier  [every B fragment of stage s is in registers; stage s+1 has landed]
+//     step 3   4 scaled MFMAs (top,    BX) | DMA of stage s+2 | read AXb(s), BH(s+1)
+//     step 4   4 scaled MFMAs (bottom, BX) | read AHt(s+1)
+// A fragments may be read after the barrier because a halo buffer is only rewritten one slab later (K > 1 only; the K = 1
+// layers keep the narrow kernel).  Cout % 256 == 0, split-format or POOL output (the launcher falls back otherwise).
+// The epilogue goes through the LDS in two halves of 128 rows (the fp32 tile of a half is exactly the operand area).
+// ------------------------------------------------------------------------------------------------
+constexpr int W_BM = 256, W_BN = 256, W_TLD = W_BN + 4;
+constexpr int W_A_BYTES = (W_BM + MAX_SPAN) * SROW;        // 33792
+constexpr int W_B_BYTES = 2 * B_BYTES;                     // 32768: two 128-column weight tiles
+constexpr int W_OPER = 2 * W_A_BYTES + 2 * W_B_BYTES;      // 133120
+constexpr int W_TILE = 128 * W_TLD * 4;                    // 133120
+constexpr int W_MASK_OFF = W_OPER > W_TILE ? W_OPER : W_TILE;
+constexpr size_t W_LDS_BYTES = (size_t)W_MASK_OFF + W_BM + 4 * W_BN * sizeof(float);
+
+template <int KT, bool POOL>
+__global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gemm8Params p)
+{
+    static_assert(KT > 1, "the wide kernel reads A fragments after the stage barrier: K > 1 only");
+    constexpr int NW = 8;
+    constexpr int BP = 4;                              // 1 KB pieces of a 32 KB weight stage per wave
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *Abuf = lds;
+    char *Bbuf = lds + 2 * W_A_BYTES;
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + W_MASK_OFF);
+    float *Ps = reinterpret_cast<float *>(lds + W_MASK_OFF + W_BM);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = p.n_mt * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const long m0 = (long)mt * W_BM;
+    const int n0 = nt * W_BN;
+
+    const int span = (KT - 1) * p.dil;
+    const int left = span >> 1;
+    const int n_stages = p.n_chunks * KT;
+    const int goff = (int)((m0 - left) & 15);
+
+    if (tid < W_BM) {
+        const long gr = m0 + tid;
+        Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
+    } else {
+        const int c = tid - W_BM, gc = n0 + c;           // Cout % 256 == 0: every column exists
+        Ps[c] = p.bias ? p.bias[gc] : 0.f;
+        Ps[W_BN + c] = p.scale ? p.scale[gc] : 1.f;
+        Ps[2 * W_BN + c] = p.shift ? p.shift[gc] : 0.f;
+        Ps[3 * W_BN + c] = p.act == XV_ACT_NONE ? 1.f : p.act == XV_ACT_LRELU ? p.alpha[0] : p.act == XV_ACT_PRELU ? p.alpha[gc] : 0.f;
+    }
+
+    const size_t xrow_bytes = (size_t)p.xchunks * SROW;
+    const int arow0 = wr * 128 + (lane & 31);
+    const int bcol = wc * 64 + (lane & 31);            // column of the 256-column stage; + 32 stays inside its 128-column tile
+    const int kh = lane >> 5;
+    const int boff0 = (bcol >> 7) * B_BYTES + (bcol & 127) * 64;
+    const int bsw0 = ((bcol & 127) >> 2) & 3;
+
+    // weight stage = the tiles of column tiles 2 nt and 2 nt + 1; wave w moves pieces 4w .. 4w+3 of its 32 KB
+    const uint8_t *bbase = p.wt + ((size_t)(2 * nt + (wave >> 2)) * n_stages) * B_BYTES + (wave & 3) * 4096 + lane * 16;
+    const int bdst = (wave >> 2) * B_BYTES + (wave & 3) * 4096;
+    const uint8_t *abase = p.x + (m0 - left + (lane >> 3)) * (long)xrow_bytes + (lane & 7) * 16;
+    constexpr int NP = W_BM / 8 + 1;
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint8_t *src = bbase + (size_t)(j < n_stages ? j : n_stages - 1) * B_BYTES;
+            char *dst = Bbuf + j * W_B_BYTES + bdst;
+#pragma unroll
+            for (int i = 0; i < BP; ++i) XV_GLDS16(src + i * 1024, dst + i * 1024);
+        }
+        for (int piece = wave; piece < NP; piece += NW) XV_GLDS16(abase + (size_t)piece * 8 * xrow_bytes, Abuf + piece * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+    struct SetH { xv_f16x8 f0[2], f1[2]; };            // two MFMA tiles x two k-steps
+    struct SetX { xv_i32x8 f0, f1; };
+    int scale_a = XV_SPLIT8_E8M0, scale_b = 127;
+    asm volatile("" : "+v"(scale_a), "+v"(scale_b));
+
+    int pa[KT], px[KT];                                // row tile 0 of the wave; tile i is + i * 32 rows (same swizzle)
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int lr0 = arow0 + t * p.dil;
+        const int sw = ((lr0 + goff) & 15) >> 1;
+        pa[t] = lr0 * SROW + ((sw ^ kh) << 4);
+        px[t] = lr0 * SROW + ((sw ^ (4 + 2 * kh)) << 4);
+    }
+    const int pb0 = 2 * W_A_BYTES + boff0 + ((kh ^ bsw0) << 4);
+    const int pb1 = 2 * W_A_BYTES + boff0 + (((2 + kh) ^ bsw0) << 4);
+    const int pbx = 2 * W_A_BYTES + B_PLANE + boff0 + (((2 * kh) ^ bsw0) << 4);
+
+    auto load_ah = [&](SetH &X, int base) {             // base = pa[t] + A buffer offset + (0 | 64 rows)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const char *a = lds + (base ^ (ks << 5));
+            X.f0[ks] = *reinterpret_cast<const xv_f16x8 *>(a);
+            X.f1[ks] = *reinterpret_cast<const xv_f16x8 *>(a + 32 * SROW);
+        }
+    };
+    auto load_bh = [&](SetH &X, int bbase_) {
+        X.f0[0] = *reinterpret_cast<const xv_f16x8 *>(lds + pb0 + bbase_);
+        X.f1[0] = *reinterpret_cast<const xv_f16x8 *>(lds + pb0 + bbase_ + 32 * 64);
+        X.f0[1] = *reinterpret_cast<const xv_f16x8 *>(lds + pb1 + bbase_);
+        X.f1[1] = *reinterpret_cast<const xv_f16x8 *>(lds + pb1 + bbase_ + 32 * 64);
+    };
+    auto cat = [](xv_i32x4 u, xv_i32x4 v) { return __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7); };
+    auto load_ax = [&](SetX &X, int base) {             // base = px[t] + A buffer offset + (0 | 64 rows)
+        const char *a = lds + base, *a2 = lds + (base ^ 16);
+        X.f0 = cat(*reinterpret_cast<const xv_i32x4 *>(a), *reinterpret_cast<const xv_i32x4 *>(a2));
+        X.f1 = cat(*reinterpret_cast<const xv_i32x4 *>(a + 32 * SROW), *reinterpret_cast<const xv_i32x4 *>(a2 + 32 * SROW));
+    };
+    auto load_bx = [&](SetX &X, int bbase_) {
+        const char *b = lds + pbx + bbase_, *b2 = lds + ((pbx + bbase_) ^ 16);
+        X.f0 = cat(*reinterpret_cast<const xv_i32x4 *>(b), *reinterpret_cast<const xv_i32x4 *>(b2));
+        X.f1 = cat(*reinterpret_cast<const xv_i32x4 *>(b + 32 * 64), *reinterpret_cast<const xv_i32x4 *>(b2 + 32 * 64));
+    };
+    auto mma_h = [&](const SetH &A, const SetH &B, int i0) {      // row tiles i0, i0+1
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            acc[i0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.f0[ks], B.f0[ks], acc[i0][0], 0, 0, 0);
+            acc[i0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.f0[ks], B.f1[ks], acc[i0][1], 0, 0, 0);
+            acc[i0 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.f1[ks], B.f0[ks], acc[i0 + 1][0], 0, 0, 0);
+            acc[i0 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.f1[ks], B.f1[ks], acc[i0 + 1][1], 0, 0, 0);
+        }
+    };
+    auto mma_x = [&](const SetX &A, const SetX &B, int i0) {
+        acc[i0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A.f0, B.f0, acc[i0][0], 1, 1, 0, scale_a, 0, scale_b);
+        acc[i0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A.f0, B.f1, acc[i0][1], 1, 1, 0, scale_a, 0, scale_b);
+        acc[i0 + 1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A.f1, B.f0, acc[i0 + 1][0], 1, 1, 0, scale_a, 0, scale_b);
+        acc[i0 + 1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A.f1, B.f1, acc[i0 + 1][1], 1, 1, 0, scale_a, 0, scale_b);
+    };
+
+    constexpr int DT = KT - 1;
+    constexpr int NS = (NP + NW - 1) / NW;
+    constexpr int PW = (NS + DT - 1) / DT;
+    auto slots_of = [](int t) constexpr { return t < DT ? (NS + DT - 1 - t) / DT : 0; };
+    auto slot_base = [](int t) constexpr { int b = 0; for (int u = 0; u < t; ++u) b += (NS + DT - 1 - u) / DT; return b; };
+    const uint32_t rowstep = 8u * (uint32_t)xrow_bytes;
+    uint32_t ag_off[DT][PW], al_off[DT][PW];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            int piece = (slot_base(t) + j) * NW + wave;
+            piece = piece < NP ? piece : NP - 1;
+            ag_off[t][j] = (uint32_t)piece * rowstep;
+            al_off[t][j] = (uint32_t)piece * 1024u;
+        }
+    const uint8_t *bnext = bbase + (size_t)(2 < n_stages ? 2 : n_stages - 1) * B_BYTES;
+
+    constexpr int HALF = 64 * SROW;                    // row tiles 2,3 of the wave
+    SetH AHt, AHb, BH;
+    SetX AXt, AXb, BX;
+    load_ah(AHt, pa[0]);
+    load_bh(BH, 0);
+
+    int s = 0;
+    for (int c = 0; c < p.n_chunks; ++c) {
+        const int abuf = (c & 1) * W_A_BYTES;
+        const int abuf_n = W_A_BYTES - abuf;
+        const int cn = (c + 1 < p.n_chunks) ? c + 1 : p.n_chunks - 1;
+        const uint8_t *anext = abase + (size_t)cn * SROW;
+        char *adst_n = Abuf + (cn & 1) * W_A_BYTES;
+        auto tap = [&](auto TT) {
+            constexpr int t = decltype(TT)::value;
+            const int bbuf = (s & 1) * W_B_BYTES;
+            // ---- step 1 ----
+            load_ah(AHb, pa[t] + abuf + HALF);
+            load_bx(BX, bbuf);
+            mma_h(AHt, BH, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- step 2 ----
+            load_ax(AXt, px[t] + abuf);
+            mma_h(AHb, BH, 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                  // every B fragment of stage s is in registers; stage s+1 has landed
+            // ---- step 3 ----
+            {
+                char *dst = Bbuf + bbuf + bdst;
+                XV_GLDS16_OFF(bnext, dst, 0);
+                XV_GLDS16_OFF(bnext, dst, 1024);
+                XV_GLDS16_OFF(bnext, dst, 2048);
+                XV_GLDS16_OFF(bnext, dst, 3072);
+                bnext += (s + 3 < n_stages) ? B_BYTES : 0;
+            }
+            if constexpr (t < DT) {
+#pragma unroll
+                for (int j = 0; j < slots_of(t); ++j) XV_GLDS16(anext + ag_off[t][j], adst_n + al_off[t][j]);
+            }
+            load_ax(AXb, px[t] + abuf + HALF);
+            load_bh(BH, W_B_BYTES - bbuf);
+            mma_x(AXt, BX, 0);
+            constexpr int NV = BP + slots_of(t);
+#define XV_G8W_GROUP(i)                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
+            if constexpr ((NV + 3 - (i)) / 4 > 0) __builtin_amdgcn_sched_group_barrier(0x020, (NV + 3 - (i)) / 4, 0); \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            XV_G8W_GROUP(0) XV_G8W_GROUP(1) XV_G8W_GROUP(2) XV_G8W_GROUP(3)
+#undef XV_G8W_GROUP
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- step 4 ----
+            if constexpr (t + 1 < KT) load_ah(AHt, pa[t + 1] + abuf);
+            else load_ah(AHt, pa[0] + abuf_n);               // first tap of the next slab (tail: harmless read)
+            mma_x(AXb, BX, 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ++s;
+        };
+        for_taps<0, KT>(tap);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue, 128 rows at a time ---------------------------------------------------------------------------------
+    float *T = reinterpret_cast<float *>(lds);
+    const int cg = tid & 31;                            // 8-channel group of the 256-column tile
+    const int gc0 = n0 + cg * 8;
+    float bias[8], sc[8], sh[8], al[8];
+    {
+        const f32x4 *P4 = reinterpret_cast<const f32x4 *>(Ps) + cg * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bias[i] = P4[0][i]; bias[4 + i] = P4[1][i];
+            sc[i] = P4[W_BN / 4][i]; sc[4 + i] = P4[W_BN / 4 + 1][i];
+            sh[i] = P4[2 * W_BN / 4][i]; sh[4 + i] = P4[2 * W_BN / 4 + 1][i];
+            al[i] = P4[3 * W_BN / 4][i]; al[4 + i] = P4[3 * W_BN / 4 + 1][i];
+        }
+    }
+    const bool lrelu = p.act == XV_ACT_LRELU;
+    auto act3 = [&](auto MODE, float z, float a) {
+        constexpr int mode = decltype(MODE)::value;
+        return mode == 1 ? fmaxf(a * z, z) : mode == 2 ? fmaxf(z, 0.f) : fmaxf(z, 0.f) + a * fminf(z, 0.f);
+    };
+    auto by_mode = [&](auto &&f) {
+        if (lrelu) f(std::integral_constant<int, 1>{});
+        else if (p.act == XV_ACT_RELU) f(std::integral_constant<int, 2>{});
+        else f(std::integral_constant<int, 0>{});
+    };
+    float amax = 0.f;
+    f32x4 tv[8][2];
+    float keep[8];
+    auto write_tile = [&]() {                           // this wave's 128 x 64 accumulators -> the fp32 tile of its half
+        const int col = wc * 64 + (lane & 31);
+        const int rowb = 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rr = i * 32 + rowb + (reg & 3) + 8 * (reg >> 2);
+                T[rr * W_TLD + col] = acc[i][0][reg];
+                T[rr * W_TLD + col + 32] = acc[i][1][reg];
+            }
+    };
+    // thread -> 8 rows x 8 channels of a half: POOL: the 8 rows of block tid >> 5; else rows (tid >> 5) + 16 j
+    auto read_tile = [&](int h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lr = POOL ? (tid >> 5) * 8 + j : (tid >> 5) + 16 * j;
+            tv[j][0] = *reinterpret_cast<const f32x4 *>(T + lr * W_TLD + cg * 8);
+            tv[j][1] = *reinterpret_cast<const f32x4 *>(T + lr * W_TLD + cg * 8 + 4);
+            keep[j] = Ms[h * 128 + lr] ? 1.f : 0.f;
+        }
+    };
+    auto process = [&](int h) {
+        const long mh = m0 + h * 128;
+        if constexpr (POOL) {
+            const int blk = tid >> 5;                   // 16 blocks of 8 rows
+            if (mh + blk * 8 >= p.R) return;
+            float v0[8], s1[8], s2[8];
+            float n = 0.f;
+            by_mode([&](auto MODE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    n += keep[j];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
+                        const float v = act3(MODE, z, al[i]) * sc[i] + sh[i];
+                        if (j == 0) { v0[i] = v; s1[i] = 0.f; s2[i] = 0.f; }
+                        else {
+                            const float d = (v - v0[i]) * keep[j];
+                            s1[i] += d;
+                            s2[i] += d * d;
+                        }
+                    }
+                }
+            });
+            const float rn = n > 0.f ? 1.f / n : 0.f;
+            f32x4 mean[2], m2[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mean[i >> 2][i & 3] = n > 0.f ? v0[i] + s1[i] * rn : 0.f;
+                m2[i >> 2][i & 3] = fmaxf(s2[i] - s1[i] * s1[i] * rn, 0.f);
+            }
+            float *o = p.blk + ((size_t)((mh >> 3) + blk) * 2) * p.cout + gc0;
+            *reinterpret_cast<f32x4 *>(o) = mean[0];
+            *reinterpret_cast<f32x4 *>(o + 4) = mean[1];
+            *reinterpret_cast<f32x4 *>(o + p.cout) = m2[0];
+            *reinterpret_cast<f32x4 *>(o + p.cout + 4) = m2[1];
+        } else {
+            const int ch = gc0 >> 5, slot = cg & 3;
+            char *ybase = reinterpret_cast<char *>(p.y) + (size_t)ch * SROW;
+            const size_t yrow = (size_t)p.ychunks * SROW;
+            auto rows = [&](auto MODE, auto Y8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long gr = mh + (tid >> 5) + 16 * j;
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
+                        v[i] = (act3(MODE, z, al[i]) * sc[i] + sh[i]) * keep[j];
+                    }
+                    const int sw = (int)(gr >> 1) & 7;
+                    char *row = ybase + (size_t)gr * yrow;
+                    if constexpr (decltype(Y8)::value) {
+                        xv_f16x8 hi;
+                        xv_i32x4 x8;
+                        xv_split8_encode8<true>(v, hi, x8, amax);
+                        __builtin_nontemporal_store(hi, reinterpret_cast<xv_f16x8 *>(row + ((slot ^ sw) << 4)));
+                        __builtin_nontemporal_store(x8, reinterpret_cast<xv_i32x4 *>(row + (((4 + slot) ^ sw) << 4)));
+                    } else {
+                        bf16x8 hi, lo;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            hi[i] = (__bf16)v[i];
+                            lo[i] = (__bf16)(v[i] - (float)hi[i]);
+                        }
+                        __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8 *>(row + ((slot ^ sw) << 4)));
+                        __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8 *>(row + (((4 + slot) ^ sw) << 4)));
+                    }
+                }
+            };
+            if (p.y_format == XV_FMT_SPLIT8) by_mode([&](auto MODE) { rows(MODE, std::true_type{}); });
+            else by_mode([&](auto MODE) { rows(MODE, std::false_type{}); });
+        }
+    };
+    // upper half through the tile; the lower half's accumulators go into the tile as soon as the upper half has been read
+    // into registers, i.e. BEFORE the arithmetic of the upper half (128 accumulators + 64 tile values + the arithmetic of
+    // an epilogue do not fit the register file)
+    __syncthreads();                                    // operand buffers are dead
+    if (wr == 0) write_tile();
+    __syncthreads();
+    read_tile(0);
+    __syncthreads();
+    if (wr == 1) write_tile();
+    __builtin_amdgcn_sched_barrier(0);
+    process(0);
+    __syncthreads();
+    read_tile(1);
+    __builtin_amdgcn_sched_barrier(0);
+    process(1);
+    if constexpr (!POOL)
+        if (amax > XV_SPLIT8_MAX && p.status) atomicOr(p.status, 1);
+}
+
 typedef void (*gemm8_fn)(const Gemm8Params);
 struct Gemm8Kernel {
     int kt;
@@ -531,8 +928,14 @@ const Gemm8Kernel GEMM8_KERNELS[] = {
     XV_G8(1, true, 2),  XV_G8(3, true, 2),  XV_G8(5, true, 2),  XV_G8(7, true, 2),
     XV_G8(1, false, 4), XV_G8(3, false, 4), XV_G8(5, false, 4), XV_G8(7, false, 4),
     XV_G8(1, true, 4),  XV_G8(3, true, 4),  XV_G8(5, true, 4),  XV_G8(7, true, 4),
+    // wm == 8: the 256 x 256 tile (tdnn_gemm_f16bf8_wide_kernel)
+    {3, false, 8, tdnn_gemm_f16bf8_wide_kernel<3, false>}, {5, false, 8, tdnn_gemm_f16bf8_wide_kernel<5, false>},
+    {7, false, 8, tdnn_gemm_f16bf8_wide_kernel<7, false>},
+    {3, true, 8, tdnn_gemm_f16bf8_wide_kernel<3, true>},   {5, true, 8, tdnn_gemm_f16bf8_wide_kernel<5, true>},
+    {7, true, 8, tdnn_gemm_f16bf8_wide_kernel<7, true>},
 };
 #undef XV_G8
+size_t g8_kernel_lds(const Gemm8Kernel &e) { return e.wm == 8 ? W_LDS_BYTES : g8_lds_bytes(e.kt, e.wm); }
 
 std::atomic<int> g_tile_rows8{0};
 
@@ -557,13 +960,22 @@ int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
         }
     }
     p.n_nt = (p.cout + BN - 1) / BN;
+    // tile: 128 x 128 (4 waves, two workgroups per CU), 256 x 128 (8 waves) or 256 x 256 (8 waves of 128 x 64; K > 1,
+    // Cout % 256 == 0, split-format or POOL output).  XV_TUNE_TILE_ROWS: 128 / 256 force the first two, 512 the third.
     int wm = 2;
     {
         const int want = g_tile_rows8.load(std::memory_order_relaxed);
+        const bool wide_ok = p.K > 1 && (p.cout & 255) == 0 && (p.blk != nullptr || p.y_format != XV_FMT_F32);
         const bool big_enough = ((p.R + 255) / 256) * p.n_nt >= 512;
-        if (want == 256 || (want == 0 && p.K >= 5 && big_enough)) wm = 4;
+        if (wide_ok && (want == 512 || (want == 0 && ((p.R + 255) / 256) * (p.cout / 256) >= 512))) wm = 8;
+        else if (want == 256 || (want == 0 && p.K >= 5 && big_enough)) wm = 4;
     }
-    p.n_mt = (int)((p.R + wm * 64 - 1) / (wm * 64));
+    if (wm == 8) {
+        p.n_nt = p.cout / W_BN;
+        p.n_mt = (int)((p.R + W_BM - 1) / W_BM);
+    } else {
+        p.n_mt = (int)((p.R + wm * 64 - 1) / (wm * 64));
+    }
     const Gemm8Kernel *k = nullptr;
     for (const Gemm8Kernel &e : GEMM8_KERNELS)
         if (e.kt == p.K && e.pool == (p.blk != nullptr) && e.wm == wm) k = &e;
@@ -573,12 +985,12 @@ int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
     (void)hipGetDevice(&dev);
     if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
         for (const Gemm8Kernel &e : GEMM8_KERNELS) {
-            hipError_t err = hipFuncSetAttribute((const void *)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_bytes(e.wm));
+            hipError_t err = hipFuncSetAttribute((const void *)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_kernel_lds(e));
             if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute");
         }
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL(k->fn, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(wm * 128), g8_lds_bytes(wm), st, p);
+    hipLaunchKernelGGL(k->fn, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(wm == 8 ? 512 : wm * 128), g8_kernel_lds(*k), st, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_f16bf8_kernel launch");
 }

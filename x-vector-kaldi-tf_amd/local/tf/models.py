@@ -131,8 +131,10 @@ class Model(object):
         self.meta = meta
         self.num_classes = meta["num_classes"]
         self.embedding_index = int(os.environ.get("XVECTOR_EMBEDDING_INDEX", "0"))   # models.py:159-160
-        # GEMM arithmetic: "bf16x3" (default; split-precision bf16 MFMA, ~6e-6 rel-L2 vs fp32) or "fp32" (exact)
-        self.precision = os.environ.get("XVECTOR_PRECISION", "bf16x3")
+        # GEMM arithmetic: "f16bf8" (default: hidden layers as fp16 MFMA + scaled bf8 MFMA of the cross terms, ~1e-5 rel-L2;
+        # topologies it does not cover and out-of-range windows run as bf16x3), "bf16x3" (split-precision bf16 MFMA, ~5e-6)
+        # or "fp32" (exact fp32 MFMA)
+        self.precision = os.environ.get("XVECTOR_PRECISION", "f16bf8")
         self.device_model = engine.DeviceModel(w, meta["topology"], _device(), self.embedding_index, self.precision)
         if logger is not None:
             logger.info("Graph restored from path: %s" % input_dir)
