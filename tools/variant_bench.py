@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--utts", type=int, default=10000)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--batch-rows", type=int, default=262144)
-ap.add_argument("--precision", default="bf16x3")
+ap.add_argument("--precision", default="f16bf8")
 ap.add_argument("--classes", nargs="*", default=["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelWithoutDropoutPRelu",
                                                   "ModelL2LossWithoutDropoutLRelu", "ModelL2LossWithoutDropoutLReluAttention"])
 args = ap.parse_args()
