@@ -49,7 +49,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 12). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 13). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -195,6 +195,18 @@ int xv_tdnn_layer_pool_f16bf8(const void *x, int64_t R, int cin, const void *wt,
 int xv_tdnn_first_f16bf8(const float *x, int64_t R, int cin, int ldx, const void *wt, const float *bias, const float *bn_scale,
                          const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
                          const uint8_t *row_valid, void *y, int32_t *status, void *stream);
+
+/* xv_tdnn_pair_pool_bf16x3 in the f16bf8 arithmetic: x in XV_FMT_SPLIT8, wt = xv_pack_pair_f16bf8(w1, w2)
+ * (xv_packed_pair_f16bf8_bytes bytes, 0 = unsupported: Cmid == 512, Cin % 32 == 0, Cout % 64 == 0, Cout <= 4096), same
+ * block_stats contract.  A pair of waves shares 32 frames: each wave keeps HALF of the intermediate's channels in registers
+ * (so it streams half of both layers' weights through its fragment reads) and the two partial sums of the second GEMM meet in
+ * LDS.  `status` (may be NULL): bit 0 is ORed in when the intermediate activation had to be clamped to +-57344. */
+size_t xv_packed_pair_f16bf8_bytes(int cin, int cmid, int cout);
+int xv_pack_pair_f16bf8(const float *w1, const float *w2, int cin, int cmid, int cout, void *wt, void *stream);
+int xv_tdnn_pair_pool_f16bf8(const void *x, int64_t R, int cin, int cmid, int cout, const void *wt, const float *bias1,
+                             const float *bn_scale1, const float *bn_shift1, const float *act_alpha1, const float *bias2,
+                             const float *bn_scale2, const float *bn_shift2, const float *act_alpha2, int act_kind,
+                             const uint8_t *row_valid, float *block_stats, int32_t *status, void *stream);
 
 /* xv_fc_f32 twin: fp32 rows in, fp32 rows out; wt = xv_pack_weights_bf16x3(w, 1, In, Out). */
 int xv_fc_bf16x3(const float *x, int nrows, int in_dim, const void *wt, const float *bias, const float *bn_scale,

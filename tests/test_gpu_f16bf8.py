@@ -266,3 +266,78 @@ def test_f16bf8_bad_arguments_fail_loudly(env):
         hiplib.tdnn_layer8(x8, 64, w5, None, None, None, 3, None, 1, None, y)
     assert hiplib.f16bf8_supported(5, 1) and hiplib.f16bf8_supported(3, 3) and hiplib.f16bf8_supported(1, 1)
     assert not hiplib.f16bf8_supported(9, 1) and not hiplib.f16bf8_supported(5, 3) and not hiplib.f16bf8_supported(4, 1)
+
+
+@pytest.mark.parametrize("cin,cout,act,lens", [
+    (512, 1536, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),      # layers 3 + 4 of the default topology
+    (64, 64, "prelu", [300, 25, 64, 3]),                         # two slabs, one column group
+    (96, 192, "lrelu", [1200, 33]),                              # long chunk: many blocks per chunk
+    (512, 1536, "none", [40, 129]),
+])
+def test_tdnn_pair_pool_f16bf8_matches_oracle(env, cin, cout, act, lens):
+    """xv_tdnn_pair_pool_f16bf8 (two K = 1 layers, the intermediate split over a pair of waves and kept in registers, pooling
+    block statistics) + xv_stats_pool_blocks_f32 == statistics pooling of layer(layer(x)) in the fp64 oracle; the block
+    statistics agree with the two-launch f16bf8 path; a chunk's result does not depend on its batch neighbours."""
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    cmid = 512
+    assert hiplib.pair8_supported(cin, cmid, cout) and not hiplib.pair8_supported(cin, 256, cout) and not hiplib.pair8_supported(40, cmid, cout)
+    rng = np.random.default_rng(cin + cout + len(lens) + 3)
+    mats = [(rng.standard_normal((n, cin)) * 2).astype(np.float32) for n in lens]
+    w1 = (rng.standard_normal((1, cin, cmid)) / np.sqrt(cin)).astype(np.float32)
+    w2 = (rng.standard_normal((1, cmid, cout)) / np.sqrt(cmid)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(cmid)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn1, bn2 = _rand_bn(rng, cmid), _rand_bn(rng, cout)
+    a1, a2 = _alpha(rng, act, cmid), _alpha(rng, act, cout)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    s1, o1 = hiplib.fold_bn(*(t(a) for a in bn1), 1e-3)
+    s2, o2 = hiplib.fold_bn(*(t(a) for a in bn2), 1e-3)
+    pair = hiplib.pack_pair_f16bf8(t(w1[0]), t(w2[0]))
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(ms):
+        layout = engine.BatchLayout([m.shape[0] for m in ms], 1, hiplib.POOL_BLOCK_ROWS)
+        host = np.zeros((layout.rows, cin), np.float32)
+        layout.pack(ms, host)
+        xin = hiplib.SplitBuf(layout.rows, cin, dev, hiplib.FMT_SPLIT8)
+        hiplib.split_encode(t(host), xin)
+        blk = torch.full((hiplib.block_stats_floats(layout.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
+        hiplib.tdnn_pair_pool8(xin, layout.rows, pair, (t(b1), s1, o1, t(a1)), (t(b2), s2, o2, t(a2)), CODE[act], t(layout.row_valid()),
+                               blk, status)
+        out = torch.full((len(ms), 2 * cout), float("nan"), dtype=torch.float32, device=dev)
+        hiplib.stats_pool_blocks(blk, cout, t(layout.row_start), t(layout.row_len), len(ms), 1e-5, out)
+        return out.cpu().numpy(), blk, layout, xin
+
+    got, blk, layout, xin = run(mats)
+    assert int(status.item()) == 0 and np.isfinite(got).all()
+    for i, m in enumerate(mats):
+        h = oracle.tdnn_layer(m, w1, b1, bn1, act, a1, 1, np.float64)
+        ref = oracle.stats_pool(oracle.tdnn_layer(h, w2, b2, bn2, act, a2, 1, np.float64), 1e-5, np.float64)
+        assert oracle.rel_l2(got[i, :cout], ref[:cout]) < 2 * TOL_GEMM8, (i, lens[i], oracle.rel_l2(got[i, :cout], ref[:cout]))
+        assert oracle.rel_l2(got[i, cout:], ref[cout:]) < 2 * TOL_GEMM8, (i, lens[i], oracle.rel_l2(got[i, cout:], ref[cout:]))
+    # the two-launch f16bf8 path on the same input: same quantity up to the arithmetic's rounding
+    hmid = hiplib.SplitBuf(layout.rows, cmid, dev, hiplib.FMT_SPLIT8)
+    rv = t(layout.row_valid())
+    hiplib.tdnn_layer8(xin, layout.rows, hiplib.pack_weights_f16bf8(t(w1)), t(b1), s1, o1, CODE[act], t(a1), 1, rv, hmid)
+    blk2 = torch.full_like(blk, float("nan"))
+    hiplib.tdnn_layer_pool8(hmid, layout.rows, hiplib.pack_weights_f16bf8(t(w2)), t(b2), s2, o2, CODE[act], t(a2), 1, rv, blk2)
+    b1_, b2_ = blk.cpu().numpy().reshape(-1, 2, cout), blk2.cpu().numpy().reshape(-1, 2, cout)
+    has_frames = layout.row_valid().astype(bool)
+    has_frames = np.pad(has_frames, (0, (-len(has_frames)) % 8)).reshape(-1, 8).any(axis=1)
+    assert np.isfinite(b1_[has_frames]).all() and np.allclose(b1_[has_frames], b2_[has_frames], rtol=5e-3, atol=5e-4)
+    alone, _, _, _ = run(mats[:1])
+    assert np.array_equal(alone[0], got[0])
+
+
+def test_pair_f16bf8_reports_an_out_of_range_intermediate(env):
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    R, cin, cout = 256, 64, 64
+    x = hiplib.SplitBuf(R, cin, dev, hiplib.FMT_SPLIT8)
+    hiplib.split_encode(t(np.full((R, cin), 100.0, np.float32)), x)
+    w1 = np.zeros((cin, 512), np.float32); w1[:, 5] = 10.0          # H[:, 5] = 64000 > 57344
+    w2 = np.zeros((512, cout), np.float32)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    blk = torch.zeros(hiplib.block_stats_floats(R, cout), dtype=torch.float32, device=dev)
+    hiplib.tdnn_pair_pool8(x, R, hiplib.pack_pair_f16bf8(t(w1), t(w2)), (None,) * 4, (None,) * 4, 1, None, blk, status)
+    assert int(status.item()) == 1

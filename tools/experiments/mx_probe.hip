@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 1) void rate_kernel(const uint8_t *src, float 
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
     int va = 115, vb = 127;
     asm volatile("" : "+v"(va), "+v"(vb));
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < (MODE >= 4 ? 0 : iters); ++it) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
@@ -98,6 +98,35 @@ __global__ __launch_bounds__(512, 1) void rate_kernel(const uint8_t *src, float 
                 acc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[4 + u], r[7], acc[1], 1, 1, 0, va, 0, vb);
                 acc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[5 - u / 2], r[6], acc[2], 1, 1, 0, va, 0, vb);
                 acc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[5 - u / 2], r[7], acc[3], 1, 1, 0, va, 0, vb);
+            }
+        }
+    }
+    if constexpr (MODE == 4 || MODE == 5 || MODE == 6) {
+        f16x8 a0, a1, b0, b1;
+        __builtin_memcpy(&a0, &r[0], 16); __builtin_memcpy(&a1, reinterpret_cast<char *>(&r[1]) + 16, 16);
+        __builtin_memcpy(&b0, &r[2], 16); __builtin_memcpy(&b1, reinterpret_cast<char *>(&r[3]) + 16, 16);
+        for (int it = 0; it < iters; ++it) {
+            if constexpr (MODE == 4) {              // 3 MFMAs of a unit back to back into ONE accumulator, 4 units
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[4], r[6], acc[u], 1, 1, 0, va, 0, vb);
+                }
+            } else if constexpr (MODE == 5) {       // skewed: h0(u), x(u-1), h1(u), accumulators alternate between TWO
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[u & 1], 0, 0, 0);
+                    acc[(u + 1) & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[4], r[6], acc[(u + 1) & 1], 1, 1, 0, va, 0, vb);
+                    acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[u & 1], 0, 0, 0);
+                }
+            } else {                                // skewed, accumulators rotate over FOUR (phase 1 of the pair kernel)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[u], 0, 0, 0);
+                    acc[(u + 3) & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[4], r[6], acc[(u + 3) & 3], 1, 1, 0, va, 0, vb);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[u], 0, 0, 0);
+                }
             }
         }
     }
@@ -177,6 +206,9 @@ int main()
     run_rate<1>(dS, dO, iters, "24 x f16 32x32x16", 24 * 8);
     run_rate<2>(dS, dO, iters, "8 x f16 + 4 x MX bf8 32x32x64", 8 * 8 + 4 * 16);
     run_rate<3>(dS, dO, iters, "12 x MX bf8 32x32x64", 12 * 16);
+    run_rate<4>(dS, dO, iters, "4 x [f16,f16,MX] one acc per unit", 8 * 8 + 4 * 16);
+    run_rate<5>(dS, dO, iters, "skewed, two accumulators", 8 * 8 + 4 * 16);
+    run_rate<6>(dS, dO, iters, "skewed, four accumulators", 8 * 8 + 4 * 16);
     run_rate<0>(dS, dO, iters, "24 x bf16 32x32x16 (again)", 24 * 8);
     return 0;
 }

@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/lp8
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d gpurun_out/lp8 -- python tools/layer8_bench.py 262144 > gpurun_out/l8_under_pmc.txt 2>&1
-python tools/prof_summary.py pmc $(find gpurun_out/lp8 -name "*.db" | head -1) f16bf8 > gpurun_out/l8_pmc.txt
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d gpurun_out/lp8 -- python ${1:-tools/layer8_bench.py} 262144 > gpurun_out/l8_under_pmc.txt 2>&1
+python tools/prof_summary.py pmc $(find gpurun_out/lp8 -name "*.db" | head -1) ${2:-f16bf8} > gpurun_out/l8_pmc.txt
 rm -rf gpurun_out/lp8
 python - <<'PY'
 import re,collections

@@ -1327,7 +1327,7 @@ extern "C" {
 
 void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
 
-int xv_version(void) { return 12; }
+int xv_version(void) { return 13; }
 
 int xv_set_tuning(int key, int value)
 {

@@ -1,0 +1,612 @@
+// xv_pair8.hip -- the two context-free (K = 1) frame-level layers and the first half of statistics pooling as ONE kernel
+// (frame_level_info_layer-3 -> -4 -> per-8-row block statistics; local/tf/models.py:54-76 / 470-486), in the f16bf8
+// arithmetic of xv_split8.h and with the reduction of the second GEMM split over a PAIR of waves.
+//
+// Why a second form of xv_pair.hip.  That kernel keeps the intermediate activation of 16 frames per wave in registers and
+// is bound by the LDS: every wave streams ALL weights of both layers through its fragment reads (36 MB of LDS traffic per
+// 128-frame workgroup = its whole run time).  Here
+//   * a PAIR of waves owns 32 frames; wave h of the pair computes channels [256 h, 256 h + 256) of the intermediate H for
+//     all 32 frames (v_mfma_*_32x32*: H^T tile = 32 channels x 32 frames) and keeps them in registers (128 VGPRs, as
+//     before) -- so it only ever reads HALF of the first layer's weights;
+//   * in the second GEMM wave h contracts over ITS 256 channels only (half of the second layer's weights) and the two
+//     partial sums of a 32-frame x 64-column tile meet in LDS: each wave hands the partner the 32-column half it does not
+//     finish (4 KB) and pools the other one.
+// LDS traffic per workgroup: 16 MB of fragment reads + 4 MB of weight DMA instead of 32 + 4.
+//   * products are formed as in xv_gemm8.hip: one v_mfma_f32_32x32x16_f16 on the fp16 parts + one
+//     v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64 holds [xl8 . wh8 | xh8 . wl8] of a 32-channel slab, i.e. 32 MFMA passes
+//     per 32x32x32 block where bf16x3 spends 48.
+// The accumulator of an H tile holds, in lane (frame f = lane & 31, hh = lane >> 5), the 16 channels c(r) = (r&3) + 8(r>>2)
+// + 4 hh -- after bias / activation / BN and the split8 encoding exactly the A operand (32 frames x its K share) of the second
+// GEMM for that 32-channel slab: fp16 k-step ks takes r = 8 ks .. 8 ks + 7, the scaled MFMA's K-block hh takes
+// [l8 r0..7 | h8 r0..7 | l8 r8..15 | h8 r8..15]; the packed weights of layer 4 follow that order.  No LDS round trip.
+// Weight stream: 32 KB stages [half 0: 4 units][half 1: 4 units], unit = [fp16 fragment k-step 0 | k-step 1 | 8-bit
+// fragment, two 1 KB planes], lane-linear 16-byte fragments; ring of three, DMA three stages ahead, counted vmcnt.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <atomic>
+#include <type_traits>
+
+#include "xvector_hip.h"
+#include "xv_split8.h"
+
+extern "C" void xv_internal_set_error(const char *msg);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+int fail(int code, const char *msg)
+{
+    xv_internal_set_error(msg);
+    return code;
+}
+
+constexpr int CMID = 512;                  // width of the intermediate layer
+constexpr int P8_WAVES = 8;
+constexpr int P8_ROWS = 128;               // frames per workgroup: 4 pairs x 32
+constexpr int P8_STAGE = 32768;
+constexpr int P8_RING = 3;
+constexpr int P8_X_OFF = P8_RING * P8_STAGE;           // phase 1: per pair the 4 KB frames fragments of one slab
+constexpr int P8_RED_OFF = P8_X_OFF;                   // phase 2: per wave the 4 KB partial tile for the partner ...
+constexpr int P8_KEEP_OFF = P8_X_OFF + P8_WAVES * 4096; // ... and the 4 KB it finishes itself (over the dead first-layer parameters)
+constexpr int P8_P1_OFF = P8_X_OFF + P8_WAVES * 4096;  // [bias | scale | shift | alpha][CMID] of the first layer
+constexpr size_t P8_LDS_BYTES = P8_KEEP_OFF + P8_WAVES * 4096;      // 160 KB: everything a CU has
+constexpr int SROW = 128;
+
+struct Pair8Params {
+    const uint8_t *x;          // split8 input, row 0
+    long R;
+    int n_ks;                  // cin / 32
+    int cout, n_ct;            // n_ct = cout / 64
+    const uint8_t *wt;         // packed stages: 2*n_ks of layer 1, then 4*n_ct of layer 2
+    const float *b1, *sc1, *sh1, *al1;
+    const float *b2, *sc2, *sh2, *al2;
+    int act;
+    const uint8_t *valid;
+    float *blk;                // [ceil(R/8)][2][cout]
+    long n_blocks;
+    int *status;               // bit 0: the intermediate left the fp16 range (clamped)
+};
+
+#define XV_GLDS16_OFF(gptr, lptr, imm)                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                    \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, imm, 0)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ float act_fn(float z, float a)
+{
+    return MODE == 1 ? fmaxf(a * z, z) : MODE == 2 ? fmaxf(z, 0.f) : fmaxf(z, 0.f) + a * fminf(z, 0.f);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel(const Pair8Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave >> 1, hf = wave & 1;
+    const int hh = lane >> 5, li = lane & 31;
+    const long row0 = (long)blockIdx.x * P8_ROWS + 32 * pair;     // the pair's 32 frames (a multiple of 8: four pooling blocks)
+
+    // ---- before any DMA is in flight: row validity of this lane's 16 frames, first-layer parameters -> LDS --------------
+    // (lane (li, hh) pools rows 16hh .. 16hh+15 of the pair's 32 frames, see phase 2)
+    uint32_t rows_mask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long gr = row0 + 16 * hh + k;
+        if (gr < p.R && (!p.valid || p.valid[gr])) rows_mask |= 1u << k;
+    }
+    {
+        float *P1 = reinterpret_cast<float *>(lds + P8_P1_OFF);
+        for (int c = tid; c < CMID; c += P8_WAVES * 64) {
+            P1[c] = p.b1 ? p.b1[c] : 0.f;
+            P1[CMID + c] = p.sc1 ? p.sc1[c] : 1.f;
+            P1[2 * CMID + c] = p.sh1 ? p.sh1[c] : 0.f;
+            P1[3 * CMID + c] = p.act == XV_ACT_NONE ? 1.f : p.act == XV_ACT_LRELU ? p.al1[0] : p.act == XV_ACT_PRELU ? p.al1[c] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- DMA streams -------------------------------------------------------------------------------------------------------
+    const uint8_t *wsrc = p.wt + wave * 4096 + lane * 16;
+    int wleft = 2 * p.n_ks + 4 * p.n_ct;               // stages not yet issued (the tail re-issues the last stage)
+    auto issue_w = [&](int slot_off) {
+        char *dst = lds + slot_off + wave * 4096;
+        XV_GLDS16_OFF(wsrc, dst, 0);
+        XV_GLDS16_OFF(wsrc, dst, 1024);
+        XV_GLDS16_OFF(wsrc, dst, 2048);
+        XV_GLDS16_OFF(wsrc, dst, 3072);
+        const bool more = wleft > 1;
+        wsrc += more ? P8_STAGE : 0;
+        wleft -= more ? 1 : 0;
+    };
+    // frames of the pair, slab ks: [fp16 k-step 0 | fp16 k-step 1 | 8-bit plane 0 | plane 1], 1 KB each, lane (f, hh) = 16 bytes:
+    // logical slot 2 ks16 + hh (fp16) / 4 + 2 hh + e (8-bit plane e) of row row0 + f; physical slot = logical ^ ((row >> 1) & 7).
+    // Wave 0 of the pair fetches the two fp16 pieces, wave 1 the two 8-bit planes.
+    const int sw = (int)((row0 + li) >> 1) & 7;
+    const size_t xrow_bytes = (size_t)p.n_ks * SROW;
+    const uint8_t *xrow = p.x + (row0 + li) * (long)xrow_bytes;
+    const uint8_t *xa = xrow + (((hf ? 4 + 2 * hh : hh) ^ sw) << 4);
+    const uint8_t *xb = xrow + (((hf ? 5 + 2 * hh : 2 + hh) ^ sw) << 4);
+    int xleft = p.n_ks;
+    char *xbase = lds + P8_X_OFF + pair * 4096;
+    auto issue_x = [&]() {
+        XV_GLDS16_OFF(xa, xbase + hf * 2048, 0);
+        XV_GLDS16_OFF(xb, xbase + hf * 2048 + 1024, 0);
+        const bool more = xleft > 1;
+        xa += more ? SROW : 0;
+        xb += more ? SROW : 0;
+        xleft -= more ? 1 : 0;
+    };
+    struct XFrag {
+        xv_f16x8 h0, h1;
+        xv_i32x8 x;
+    };
+    auto cat = [](xv_i32x4 u, xv_i32x4 v) { return __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7); };
+    auto load_xfrag = [&](XFrag &X) {
+        const char *b = xbase + lane * 16;
+        X.h0 = *reinterpret_cast<const xv_f16x8 *>(b);
+        X.h1 = *reinterpret_cast<const xv_f16x8 *>(b + 1024);
+        X.x = cat(*reinterpret_cast<const xv_i32x4 *>(b + 2048), *reinterpret_cast<const xv_i32x4 *>(b + 3072));
+    };
+
+    // Fragment sets (ping-pong): fp16 fragments of a unit in Hh0/Hh1[set], its 8-bit fragment in Mx[set].  The MFMAs of a unit
+    // are issued SKEWED -- fp16 k-step 0 of unit j, the 8-bit MFMA of unit j-1, fp16 k-step 1 of unit j -- so that two MFMAs
+    // into the same accumulator are never back to back (a wave has one accumulator per unit; a dependent MFMA would wait
+    // for the pipeline to drain), and the 8-bit fragment of unit j is therefore read one step later than its fp16 fragments.
+    xv_f16x8 Hh0[2], Hh1[2];
+    xv_i32x8 Mx[2];
+    Mx[1] = (xv_i32x8){0, 0, 0, 0, 0, 0, 0, 0};            // the "previous unit" of the very first step: adds zero
+    const char *fbase = lds + hf * 16384 + lane * 16;       // this wave's half of a stage
+    auto load_h = [&](auto SET, int slot, int unit) {
+        constexpr int set = decltype(SET)::value;
+        const char *b = fbase + slot + unit * 4096;
+        Hh0[set] = *reinterpret_cast<const xv_f16x8 *>(b);
+        Hh1[set] = *reinterpret_cast<const xv_f16x8 *>(b + 1024);
+    };
+    auto load_m = [&](auto SET, int slot, int unit) {
+        constexpr int set = decltype(SET)::value;
+        const char *b = fbase + slot + unit * 4096;
+        Mx[set] = cat(*reinterpret_cast<const xv_i32x4 *>(b + 2048), *reinterpret_cast<const xv_i32x4 *>(b + 3072));
+    };
+    auto next_slot = [](int slot) { return slot + P8_STAGE == P8_RING * P8_STAGE ? 0 : slot + P8_STAGE; };
+    // B(s), at the END of stage s: this wave's fragment reads of stage s are complete (its slot may be overwritten: the DMA of
+    // stage s+3 is issued at the top of stage s+1) and ALL its DMA pieces have landed -- stage s+2, issued at the top of stage s,
+    // is read from step 3 of stage s+1 on -- and after the barrier the same holds for every wave.
+    auto stage_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // MFMA / LDS-read / DMA interleave of one step: 3 MFMAs, ND ds_read_b128, NV LDS-DMA pieces.  Every fragment read goes
+    // right behind the FIRST MFMA: the next step starts with s_waitcnt lgkmcnt(0), and a read issued behind the last MFMA
+    // would have that MFMA's 32 cycles to come back.
+    auto pin = [&](auto NVMEM, auto NDS) {
+        constexpr int nv = decltype(NVMEM)::value, nd = decltype(NDS)::value;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nd, 0);
+        if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x020, (nv + 1) / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (nv > 1) __builtin_amdgcn_sched_group_barrier(0x020, nv / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int scale_a = XV_SPLIT8_E8M0, scale_b = 127;
+    asm volatile("" : "+v"(scale_a), "+v"(scale_b));
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    // ---- prologue --------------------------------------------------------------------------------------------------------------
+    issue_x();
+    issue_w(0);
+    issue_w(P8_STAGE);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // frames of slab 0 and stage 0
+    __builtin_amdgcn_s_barrier();
+    XFrag X;
+    load_xfrag(X);
+    load_h(I0{}, 0, 0);
+    int slot = 0, slot_n = P8_STAGE, slot_i = 2 * P8_STAGE;    // ring slots of stage s, of stage s+1, and the free one (stage s+2 goes there)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // everybody holds slab 0 in registers: its buffer may be refilled
+
+    // ---- phase 1: H^T[channel][frame] for this wave's 256 channels: 8 tiles of 32 channels x 32 frames ---------------------------
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = (f32x16){0};
+    xv_i32x8 Xprev = X.x;                                      // the 8-bit frames fragment the pending MFMA of the previous slab needs
+    auto f16a = [&](auto SET, auto T, const xv_f16x8 &xf, bool second) {   // A = weight fragment, B = frames fragment
+        constexpr int set = decltype(SET)::value, t = decltype(T)::value;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(second ? Hh1[set] : Hh0[set], xf, acc[t], 0, 0, 0);
+    };
+    auto mxa = [&](auto SET, auto T, const xv_i32x8 &xf) {
+        constexpr int set = decltype(SET)::value, t = decltype(T)::value;
+        acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Mx[set], xf, acc[t], 1, 1, 0, scale_b, 0, scale_a);
+    };
+    for (int ks = 0; ks < p.n_ks; ++ks) {
+        auto stage1 = [&](auto Q) {                        // stage (ks, q): tiles 4q .. 4q+3, one per step
+            constexpr int q = decltype(Q)::value;
+            typedef std::integral_constant<int, 4 * q> T0;
+            typedef std::integral_constant<int, 4 * q + 1> T1;
+            typedef std::integral_constant<int, 4 * q + 2> T2;
+            typedef std::integral_constant<int, 4 * q + 3> T3;
+            typedef std::integral_constant<int, q == 0 ? 7 : 3> TP;          // tile of the pending 8-bit MFMA
+            if constexpr (q == 0) issue_x();               // the frames of slab ks+1 (everybody holds slab ks in registers)
+            issue_w(slot_i);
+            // step 0
+            load_h(I1{}, slot, 1);
+            load_m(I0{}, slot, 0);
+            f16a(I0{}, T0{}, X.h0, false);
+            mxa(I1{}, TP{}, q == 0 ? Xprev : X.x);
+            f16a(I0{}, T0{}, X.h1, true);
+            pin(std::integral_constant<int, q == 0 ? 6 : 4>{}, std::integral_constant<int, 4>{});
+            // step 1
+            load_h(I0{}, slot, 2);
+            load_m(I1{}, slot, 1);
+            f16a(I1{}, T1{}, X.h0, false);
+            mxa(I0{}, T0{}, X.x);
+            f16a(I1{}, T1{}, X.h1, true);
+            pin(I0{}, std::integral_constant<int, 4>{});
+            // step 2
+            load_h(I1{}, slot, 3);
+            load_m(I0{}, slot, 2);
+            f16a(I0{}, T2{}, X.h0, false);
+            mxa(I1{}, T1{}, X.x);
+            f16a(I0{}, T2{}, X.h1, true);
+            pin(I0{}, std::integral_constant<int, 4>{});
+            // step 3 (the fp16 fragments of the next stage's first unit come from the next ring slot)
+            load_h(I0{}, slot_n, 0);
+            load_m(I1{}, slot, 3);
+            if constexpr (q == 1) {
+                XFrag N;
+                load_xfrag(N);                             // frames of slab ks+1: landed before the previous barrier
+                f16a(I1{}, T3{}, X.h0, false);
+                mxa(I0{}, T2{}, X.x);
+                f16a(I1{}, T3{}, X.h1, true);
+                pin(I0{}, std::integral_constant<int, 8>{});
+                Xprev = X.x;
+                X = N;
+            } else {
+                f16a(I1{}, T3{}, X.h0, false);
+                mxa(I0{}, T2{}, X.x);
+                f16a(I1{}, T3{}, X.h1, true);
+                pin(I0{}, std::integral_constant<int, 4>{});
+            }
+            stage_barrier();
+            slot_i = slot;
+            slot = slot_n;
+            slot_n = next_slot(slot_n);
+        };
+        stage1(I0{});
+        stage1(I1{});
+    }
+    mxa(I1{}, std::integral_constant<int, 7>{}, Xprev);     // the pending 8-bit MFMA of the last unit
+
+    // ---- accumulators -> A operands of the second GEMM: bias, activation, BN, split8 encoding ----------------------------------------
+    xv_f16x8 Hf0[8], Hf1[8];
+    xv_i32x8 Hx[8];
+    float amax = 0.f;
+    {
+        auto conv = [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            // tile u's parameter reads must not start before tile u-1 is converted (the optimiser would hoist all of them and
+            // spill): an opaque zero that depends on the previous result
+            int dep = 0;
+            if constexpr (u > 0) {
+                const xv_i32x8 a = Hx[u - 1];
+                asm volatile("" : "+v"(dep) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+            }
+            const f32x4 *P1 = reinterpret_cast<const f32x4 *>(lds + P8_P1_OFF + dep);
+            const f32x16 t = acc[u];
+            xv_i32x4 x8[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {                                  // r = 8g .. 8g+7: channels (r&3) + 8(r>>2) + 4hh
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c4 = (256 * hf + 32 * u + 8 * (2 * g + j) + 4 * hh) >> 2;
+                    const f32x4 b = P1[c4], s = P1[CMID / 4 + c4], o = P1[2 * CMID / 4 + c4], a = P1[3 * CMID / 4 + c4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * j + e] = act_fn<MODE>(t[8 * g + 4 * j + e] + b[e], a[e]) * s[e] + o[e];
+                }
+                xv_f16x8 hi;
+                xv_split8_encode8<true>(v, hi, x8[g], amax);
+                if (g == 0) Hf0[u] = hi;
+                else Hf1[u] = hi;
+            }
+            Hx[u] = cat(x8[0], x8[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_for<0, 8>(conv);
+    }
+    if (amax > XV_SPLIT8_MAX && p.status) atomicOr(p.status, 1);
+    load_h(I0{}, slot, 0);        // (again: the copy read inside the loop is dropped so that the conversion has the registers)
+
+    // ---- phase 2: partial Y[frame][column] over this wave's 256 channels, 64 columns at a time -----------------------------------------
+    // At the end of a column tile every wave writes BOTH halves of its partial tile to LDS: the half the partner finishes
+    // (RED) and the half it finishes itself (KEEP), element (register r, lane l) at float r*64 + l.  With the whole 32 x 32
+    // half-tile addressable, lane (column li, hh) pools the two 8-row blocks 2hh, 2hh+1 COMPLETELY (rows 16hh .. 16hh+15: no
+    // cross-lane exchange at all), one row per step of the NEXT column tile's first three stages -- 16 rows over 12 steps,
+    // ~12 VALU instructions and two ds_read_b32 each, in the shadow of that step's MFMAs; the fourth stage stays free of
+    // reads so that the next exchange cannot overtake them.
+    float *red_mine = reinterpret_cast<float *>(lds + P8_RED_OFF + wave * 4096) + lane;
+    float *keep_mine = reinterpret_cast<float *>(lds + P8_KEEP_OFF + wave * 4096) + lane;
+    // row 16hh + k of the half-tile = accumulator register 8hh + 4(k>>3) + (k&3) of lane li + 32((k>>2)&1)
+    const float *pool_keep = reinterpret_cast<const float *>(lds + P8_KEEP_OFF + wave * 4096) + 8 * hh * 64 + li;
+    const float *pool_red = reinterpret_cast<const float *>(lds + P8_RED_OFF + (wave ^ 1) * 4096) + 8 * hh * 64 + li;
+    const bool lrelu = p.act == XV_ACT_LRELU, prelu = p.act == XV_ACT_PRELU;
+    // epilogue parameters of the column this lane pools, fetched one column tile ahead (a global load at the point of use
+    // would stall the wave for a microsecond per column tile)
+    f32x4 prm = {0.f, 1.f, 0.f, 0.f}, prm_next = prm;      // {bias, scale, shift, alpha}
+    auto fetch_params = [&](int ct) {
+        const int col = ct * 64 + 32 * hf + li;
+        f32x4 v;
+        v[0] = p.b2 ? p.b2[col] : 0.f;
+        v[1] = p.sc2 ? p.sc2[col] : 1.f;
+        v[2] = p.sh2 ? p.sh2[col] : 0.f;
+        v[3] = p.act == XV_ACT_NONE ? 1.f : lrelu ? p.al2[0] : prelu ? p.al2[col] : 0.f;
+        return v;
+    };
+    float pv0 = 0.f, ps1 = 0.f, ps2 = 0.f;                 // running statistics of the block being pooled
+    auto pool_row = [&](auto K, int ct) {                  // row k of column tile ct (statistics shifted by the block's first row)
+        constexpr int k = decltype(K)::value;
+        constexpr int off = (4 * (k >> 3) + (k & 3)) * 64 + 32 * ((k >> 2) & 1);
+        const float v = act_fn<MODE>(pool_keep[off] + pool_red[off] + prm[0], prm[3]) * prm[1] + prm[2];
+        if constexpr ((k & 7) == 0) {
+            pv0 = v;
+            ps1 = 0.f;
+            ps2 = 0.f;
+        } else {
+            const float d = ((rows_mask >> k) & 1u) ? v - pv0 : 0.f;
+            ps1 += d;
+            ps2 += d * d;
+        }
+        if constexpr ((k & 7) == 7) {
+            const float n = (float)__builtin_popcount((rows_mask >> (k - 7)) & 255u);
+            const float rn = n > 0.f ? 1.f / n : 0.f;
+            const float mean = n > 0.f ? pv0 + ps1 * rn : 0.f;
+            const float m2 = fmaxf(ps2 - ps1 * ps1 * rn, 0.f);
+            const long blk_row = (row0 >> 3) + 2 * hh + (k >> 3);
+            if (blk_row < p.n_blocks && ct >= 0) {
+                float *o = p.blk + (size_t)blk_row * 2 * p.cout + ct * 64 + 32 * hf + li;
+                o[0] = mean;
+                o[p.cout] = m2;
+            }
+        }
+    };
+    // rows pooled in step j of stage q (q < 3): 2,2,1,1 | 2,1,1,1 | 2,1,1,1
+    auto pool_step = [&](auto Q, auto J, int ct) {
+        constexpr int q = decltype(Q)::value, j = decltype(J)::value;
+        if constexpr (q < 3) {
+            constexpr int first = q == 0 ? (j == 0 ? 0 : j == 1 ? 2 : j + 2) : (q == 1 ? (j == 0 ? 6 : j + 7) : (j == 0 ? 11 : j + 12));
+            constexpr int count = (j == 0 || (q == 0 && j == 1)) ? 2 : 1;
+            // (column tile -1 does not exist: its rows are read from whatever the buffers hold and never stored -- no branch
+            // that would split the scheduling region of the step)
+            pool_row(std::integral_constant<int, first>{}, ct - 1);
+            if constexpr (count == 2) pool_row(std::integral_constant<int, first + 1>{}, ct - 1);
+        }
+    };
+    prm_next = fetch_params(0);
+    for (int ct = 0; ct < p.n_ct; ++ct) {
+        f32x16 y[2];
+        y[0] = (f32x16){0};
+        y[1] = (f32x16){0};
+        auto f16b = [&](auto SET, auto U, auto C, bool second) {     // A = H fragment (registers), B = weight fragment
+            constexpr int set = decltype(SET)::value, u = decltype(U)::value, c = decltype(C)::value;
+            y[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(second ? Hf1[u] : Hf0[u], second ? Hh1[set] : Hh0[set], y[c], 0, 0, 0);
+        };
+        auto mxb = [&](auto SET, auto U, auto C) {
+            constexpr int set = decltype(SET)::value, u = decltype(U)::value, c = decltype(C)::value;
+            y[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Hx[u], Mx[set], y[c], 1, 1, 0, scale_a, 0, scale_b);
+        };
+        auto quarter = [&](auto Q) {                        // stage (ct, q): slabs 2q, 2q+1 x column tiles 0, 1
+            constexpr int q = decltype(Q)::value;
+            typedef std::integral_constant<int, 2 * q> UA;
+            typedef std::integral_constant<int, 2 * q + 1> UB;
+            typedef std::integral_constant<int, q == 0 ? 0 : 2 * q - 1> UP;   // slab of the pending 8-bit MFMA (none when q == 0)
+            typedef std::integral_constant<int, q < 3 ? 2 : 0> NR;            // ds_read_b32 of the pooled rows (at most 2 x 2 per step)
+            if constexpr (q == 0) {
+                prm = prm_next;                             // the parameters of column tile ct-1 ... fetched a whole tile ago
+                prm_next = fetch_params(ct < p.n_ct ? ct : p.n_ct - 1);
+            }
+            issue_w(slot_i);
+            // step 0: unit (2q, 0)
+            load_h(I1{}, slot, 1);
+            load_m(I0{}, slot, 0);
+            f16b(I0{}, UA{}, I0{}, false);
+            if constexpr (q > 0) mxb(I1{}, UP{}, I1{});
+            f16b(I0{}, UA{}, I0{}, true);
+            pool_step(Q, I0{}, ct);
+            pin(std::integral_constant<int, 4>{}, std::integral_constant<int, 4 + 2 * NR::value>{});
+            // step 1: unit (2q, 1)
+            load_h(I0{}, slot, 2);
+            load_m(I1{}, slot, 1);
+            f16b(I1{}, UA{}, I1{}, false);
+            mxb(I0{}, UA{}, I0{});
+            f16b(I1{}, UA{}, I1{}, true);
+            pool_step(Q, I1{}, ct);
+            pin(I0{}, std::integral_constant<int, 4 + (q == 0 ? 2 : 1) * NR::value>{});
+            // step 2: unit (2q+1, 0)
+            load_h(I1{}, slot, 3);
+            load_m(I0{}, slot, 2);
+            f16b(I0{}, UB{}, I0{}, false);
+            mxb(I1{}, UA{}, I1{});
+            f16b(I0{}, UB{}, I0{}, true);
+            pool_step(Q, std::integral_constant<int, 2>{}, ct);
+            pin(I0{}, std::integral_constant<int, 4 + NR::value>{});
+            // step 3: unit (2q+1, 1)
+            load_h(I0{}, slot_n, 0);
+            load_m(I1{}, slot, 3);
+            f16b(I1{}, UB{}, I1{}, false);
+            mxb(I0{}, UB{}, I0{});
+            f16b(I1{}, UB{}, I1{}, true);
+            pool_step(Q, std::integral_constant<int, 3>{}, ct);
+            pin(I0{}, std::integral_constant<int, 4 + NR::value>{});
+            if constexpr (q == 3) {
+                mxb(I1{}, UB{}, I1{});                      // the pending 8-bit MFMA of the tile's last unit
+                // both halves of the partial tile -> LDS; the barrier below orders the exchange (nobody reads in this stage)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    red_mine[r * 64] = hf ? y[0][r] : y[1][r];
+                    keep_mine[r * 64] = hf ? y[1][r] : y[0][r];
+                }
+            }
+            stage_barrier();
+            slot_i = slot;
+            slot = slot_n;
+            slot_n = next_slot(slot_n);
+        };
+        static_for<0, 4>(quarter);
+    }
+    // the last column tile: its exchange is behind the last barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    prm = prm_next;
+    {
+        auto tail = [&](auto K) { pool_row(K, p.n_ct - 1); };
+        static_for<0, 16>(tail);
+    }
+}
+
+// w1[cin][CMID], w2[CMID][cout] (fp32, TF's [in, out] order) -> stages in consumption order (see the kernel).  One thread per
+// (stage, half, unit, lane): its three 16/32-byte fragments.
+//   layer 1, stage 2 ks + q, half h, unit j (tile T = 4q + j): output channel o = 256 h + 32 T + (lane & 31), kh = lane >> 5
+//       fp16 k-step s: w1[32 ks + 16 s + 8 kh + e][o];  8-bit: channels 32 ks + 16 kh + {0..7 | 8..15}
+//   layer 2, stage 4 ct + q, half h, unit j (slab u = 2q + (j >> 1), column tile c = j & 1): column n = 64 ct + 32 c + (lane & 31)
+//       channel of (r, kh) = 256 h + 32 u + (r&3) + 8 (r>>2) + 4 kh;  fp16 k-step s: r = 8 s + e;  8-bit: r = {0..7 | 8..15}
+__global__ void pack_pair8_kernel(const float *__restrict__ w1, const float *__restrict__ w2, int n_ks, int cout, int n_ct,
+                                  uint8_t *__restrict__ wt, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const int unit = (int)((i >> 6) & 3);
+    const int h = (int)((i >> 8) & 1);
+    const long stage = (long)(i >> 9);
+    const int n = lane & 31, kh = lane >> 5;
+    float v[16];
+    if (stage < 2L * n_ks) {
+        const int ks = (int)(stage >> 1), q = (int)(stage & 1);
+        const int o = 256 * h + 32 * (4 * q + unit) + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = w1[(size_t)(32 * ks + 16 * (r >> 3) + 8 * kh + (r & 7)) * CMID + o];
+        // (the 8-bit fragment wants channels 16 kh + 0..15 = the same 16 values in another order: see below)
+        float w8[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w8[r] = w1[(size_t)(32 * ks + 16 * kh + r) * CMID + o];
+        xv_f16x8 h0, h1, dummy;
+        xv_i32x4 x0, x1, xd;
+        float amax = 0.f;
+        float a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = v[e]; b[e] = v[8 + e]; }
+        xv_split8_encode8<false>(a, h0, xd, amax);
+        xv_split8_encode8<false>(b, h1, xd, amax);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = w8[e]; b[e] = w8[8 + e]; }
+        xv_split8_encode8<false>(a, dummy, x0, amax);
+        xv_split8_encode8<false>(b, dummy, x1, amax);
+        uint8_t *t = wt + (size_t)stage * P8_STAGE + h * 16384 + unit * 4096 + lane * 16;
+        *reinterpret_cast<xv_f16x8 *>(t) = h0;
+        *reinterpret_cast<xv_f16x8 *>(t + 1024) = h1;
+        *reinterpret_cast<xv_i32x4 *>(t + 2048) = x0;
+        *reinterpret_cast<xv_i32x4 *>(t + 3072) = x1;
+    } else {
+        const long s2 = stage - 2L * n_ks;
+        const int ct = (int)(s2 >> 2), q = (int)(s2 & 3);
+        const int u = 2 * q + (unit >> 1), c = unit & 1;
+        const int col = 64 * ct + 32 * c + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = w2[(size_t)(256 * h + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * kh) * cout + col];
+        xv_f16x8 h0, h1;
+        xv_i32x4 x0, x1;
+        float amax = 0.f;
+        float a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = v[e]; b[e] = v[8 + e]; }
+        xv_split8_encode8<false>(a, h0, x0, amax);
+        xv_split8_encode8<false>(b, h1, x1, amax);
+        uint8_t *t = wt + (size_t)stage * P8_STAGE + h * 16384 + unit * 4096 + lane * 16;
+        *reinterpret_cast<xv_f16x8 *>(t) = h0;
+        *reinterpret_cast<xv_f16x8 *>(t + 1024) = h1;
+        *reinterpret_cast<xv_i32x4 *>(t + 2048) = x0;
+        *reinterpret_cast<xv_i32x4 *>(t + 3072) = x1;
+    }
+}
+
+bool pair8_shape_ok(int cin, int cmid, int cout) { return cmid == CMID && cin > 0 && (cin & 31) == 0 && cout > 0 && (cout & 63) == 0 && cout <= 4096; }
+
+}  // namespace
+
+extern "C" {
+
+size_t xv_packed_pair_f16bf8_bytes(int cin, int cmid, int cout)
+{
+    if (!pair8_shape_ok(cin, cmid, cout)) return 0;
+    return (size_t)(2 * (cin / 32) + 4 * (cout / 64)) * P8_STAGE;
+}
+
+int xv_pack_pair_f16bf8(const float *w1, const float *w2, int cin, int cmid, int cout, void *wt, void *stream)
+{
+    if (!w1 || !w2 || !wt) return fail(XV_ERR_BAD_ARG, "pack_pair_f16bf8: NULL pointer");
+    if (!pair8_shape_ok(cin, cmid, cout))
+        return fail(XV_ERR_UNSUPPORTED, "pack_pair_f16bf8: needs cmid == 512, cin % 32 == 0, cout % 64 == 0, cout <= 4096");
+    if (((uintptr_t)wt) & 15) return fail(XV_ERR_BAD_ARG, "pack_pair_f16bf8: wt must be 16-byte aligned");
+    const size_t total = xv_packed_pair_f16bf8_bytes(cin, cmid, cout) / 64;      // one thread per 64 packed bytes
+    hipLaunchKernelGGL(pack_pair8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, w2, cin / 32,
+                       cout, cout / 64, (uint8_t *)wt, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+int xv_tdnn_pair_pool_f16bf8(const void *x, int64_t R, int cin, int cmid, int cout, const void *wt, const float *bias1,
+                             const float *bn_scale1, const float *bn_shift1, const float *act_alpha1, const float *bias2,
+                             const float *bn_scale2, const float *bn_shift2, const float *act_alpha2, int act_kind,
+                             const uint8_t *row_valid, float *block_stats, int32_t *status, void *stream)
+{
+    if (R <= 0) return 0;
+    if (!x || !wt || !block_stats) return fail(XV_ERR_BAD_ARG, "tdnn_pair_pool_f16bf8: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_pair_pool_f16bf8: unknown act_kind");
+    if ((act_kind == XV_ACT_LRELU || act_kind == XV_ACT_PRELU) && (!act_alpha1 || !act_alpha2))
+        return fail(XV_ERR_BAD_ARG, "tdnn_pair_pool_f16bf8: act_alpha is NULL");
+    if (!pair8_shape_ok(cin, cmid, cout))
+        return fail(XV_ERR_UNSUPPORTED, "tdnn_pair_pool_f16bf8: needs cmid == 512, cin % 32 == 0, cout % 64 == 0, cout <= 4096");
+    if ((((uintptr_t)x) | ((uintptr_t)wt) | ((uintptr_t)block_stats)) & 15)
+        return fail(XV_ERR_BAD_ARG, "tdnn_pair_pool_f16bf8: x, wt and block_stats must be 16-byte aligned");
+    Pair8Params p{};
+    p.x = (const uint8_t *)x; p.R = (long)R; p.n_ks = cin / 32; p.cout = cout; p.n_ct = cout / 64; p.wt = (const uint8_t *)wt;
+    p.b1 = bias1; p.sc1 = bn_scale1; p.sh1 = bn_shift1; p.al1 = act_alpha1;
+    p.b2 = bias2; p.sc2 = bn_scale2; p.sh2 = bn_shift2; p.al2 = act_alpha2;
+    p.act = act_kind; p.valid = row_valid; p.blk = block_stats; p.n_blocks = (long)((R + 7) / 8); p.status = (int *)status;
+    typedef void (*kern_t)(const Pair8Params);
+    const kern_t kerns[3] = {tdnn_pair_pool_f16bf8_kernel<0>, tdnn_pair_pool_f16bf8_kernel<1>, tdnn_pair_pool_f16bf8_kernel<2>};
+    static std::atomic<unsigned long long> attr_done{0};      // dynamic-LDS opt-in: per device, idempotent
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        for (kern_t k : kerns) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_BYTES);
+            if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+        }
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    const int mode = act_kind == XV_ACT_LRELU ? 1 : act_kind == XV_ACT_RELU ? 2 : 0;
+    hipLaunchKernelGGL(kerns[mode], dim3((unsigned)((R + P8_ROWS - 1) / P8_ROWS)), dim3(P8_WAVES * 64), P8_LDS_BYTES,
+                       (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

@@ -297,6 +297,13 @@ class DeviceModel(object):
                     wb = weights["frame_level_info_layer-%d/w:0" % (n - 1)][0]
                     self.pair = hiplib.pack_pair_bf16x3(self._dev(wa), self._dev(wb))
             assert not (pair_kernel and self.pair is None), "pair_kernel=True but the topology / precision does not allow it"
+            self.pair8 = None
+            if self.f16bf8 and self.pair is not None and os.environ.get("XVECTOR_PAIR8_KERNEL", "1") != "0":
+                La, Lb = self.layers[-2], self.layers[-1]
+                if hiplib.pair8_supported(La["cin"], La["cout"], Lb["cout"]):
+                    n = len(self.layers)
+                    self.pair8 = hiplib.pack_pair_f16bf8(self._dev(weights["frame_level_info_layer-%d/w:0" % (n - 2)][0]),
+                                                         self._dev(weights["frame_level_info_layer-%d/w:0" % (n - 1)][0]))
             if self.f16bf8:
                 assert self.first is not None
                 n = len(self.layers)
@@ -461,17 +468,22 @@ class DeviceModel(object):
         S8, S3 = hiplib.FMT_SPLIT8, hiplib.FMT_SPLIT
         L = self.layers[0]
         stop = n - 2 if self.pair is not None else n - 1        # layers [1, stop) run on xv_tdnn_layer_f16bf8
-        h = bufs[0].view(L["cout"], S3 if (self.pair is not None and stop == 1) else S8)
+        pair_fmt = S8 if self.pair8 is not None else S3         # what the pair kernel in use reads
+        h = bufs[0].view(L["cout"], pair_fmt if (self.pair is not None and stop == 1) else S8)
         hiplib.tdnn_first(x, R, self.first, L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, h, status)
         for i in range(1, stop):
             L = self.layers[i]
-            y = bufs[i & 1].view(L["cout"], S3 if (self.pair is not None and i == stop - 1) else S8)
+            y = bufs[i & 1].view(L["cout"], pair_fmt if (self.pair is not None and i == stop - 1) else S8)
             hiplib.tdnn_layer8(h, R, L["wp8"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, y, status)
             h = y
         if self.pair is not None:
             La, Lb = self.layers[-2], self.layers[-1]
-            hiplib.tdnn_pair_pool(h, R, self.pair, (La["bias"], La["scale"], La["shift"], La["alpha"]),
-                                  (Lb["bias"], Lb["scale"], Lb["shift"], Lb["alpha"]), self.act, row_valid, self._last)
+            if self.pair8 is not None:
+                hiplib.tdnn_pair_pool8(h, R, self.pair8, (La["bias"], La["scale"], La["shift"], La["alpha"]),
+                                       (Lb["bias"], Lb["scale"], Lb["shift"], Lb["alpha"]), self.act, row_valid, self._last, status)
+            else:
+                hiplib.tdnn_pair_pool(h, R, self.pair, (La["bias"], La["scale"], La["shift"], La["alpha"]),
+                                      (Lb["bias"], Lb["scale"], Lb["shift"], Lb["alpha"]), self.act, row_valid, self._last)
         else:
             L = self.layers[-1]
             hiplib.tdnn_layer_pool8(h, R, L["wp8"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid,

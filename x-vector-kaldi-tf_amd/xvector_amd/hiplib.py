@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -22,6 +22,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_packed_first_bf16x3_bytes", "xv_pack_first_bf16x3", "xv_tdnn_first_bf16x3",
            "xv_packed_weights_f16bf8_bytes", "xv_pack_weights_f16bf8", "xv_split8_encode_f32", "xv_split8_decode_f32",
            "xv_tdnn_layer_f16bf8", "xv_tdnn_layer_pool_f16bf8", "xv_tdnn_first_f16bf8",
+           "xv_packed_pair_f16bf8_bytes", "xv_pack_pair_f16bf8", "xv_tdnn_pair_pool_f16bf8",
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
@@ -113,6 +114,12 @@ def load():
     lib.xv_tdnn_layer_pool_f16bf8.argtypes = [vp, i64, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
     lib.xv_tdnn_first_f16bf8.restype = ci
     lib.xv_tdnn_first_f16bf8.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp, vp]
+    lib.xv_packed_pair_f16bf8_bytes.restype = sz
+    lib.xv_packed_pair_f16bf8_bytes.argtypes = [ci, ci, ci]
+    lib.xv_pack_pair_f16bf8.restype = ci
+    lib.xv_pack_pair_f16bf8.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+    lib.xv_tdnn_pair_pool_f16bf8.restype = ci
+    lib.xv_tdnn_pair_pool_f16bf8.argtypes = [vp, i64, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]
     lib.xv_packed_pair_bf16x3_bytes.restype = sz
     lib.xv_packed_pair_bf16x3_bytes.argtypes = [ci, ci, ci]
     lib.xv_pack_pair_bf16x3.restype = ci
@@ -487,6 +494,47 @@ def pack_pair_bf16x3(w1, w2):
     _check(lib.xv_pack_pair_bf16x3(_ptr(w1.contiguous()), _ptr(w2.contiguous()), cin, cmid, cout, _ptr(wt), _stream()),
            "xv_pack_pair_bf16x3")
     return PackedPair(wt, cin, cmid, cout)
+
+
+class PackedPair8(object):
+    """Weights of two consecutive K = 1 layers in the stage order of xv_tdnn_pair_pool_f16bf8."""
+
+    def __init__(self, wt, cin, cmid, cout):
+        self.wt, self.cin, self.cmid, self.cout = wt, cin, cmid, cout
+
+
+def pair8_supported(cin, cmid, cout):
+    return int(load().xv_packed_pair_f16bf8_bytes(int(cin), int(cmid), int(cout))) > 0
+
+
+def pack_pair_f16bf8(w1, w2):
+    """w1[Cin, Cmid], w2[Cmid, Cout] (device fp32, TF's [in, out] order) -> PackedPair8."""
+    import torch
+    lib = require_gpu()
+    _f32(w1, "w1"); _f32(w2, "w2")
+    assert w1.dim() == 2 and w2.dim() == 2 and w1.shape[1] == w2.shape[0]
+    cin, cmid, cout = int(w1.shape[0]), int(w1.shape[1]), int(w2.shape[1])
+    nbytes = int(lib.xv_packed_pair_f16bf8_bytes(cin, cmid, cout))
+    if nbytes == 0:
+        raise XvectorHipError("xv_pack_pair_f16bf8: unsupported shape %d -> %d -> %d" % (cin, cmid, cout))
+    wt = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    _check(lib.xv_pack_pair_f16bf8(_ptr(w1.contiguous()), _ptr(w2.contiguous()), cin, cmid, cout, _ptr(wt), _stream()),
+           "xv_pack_pair_f16bf8")
+    return PackedPair8(wt, cin, cmid, cout)
+
+
+def tdnn_pair_pool8(x, R, w, p1, p2, act, row_valid, block_stats, status=None):
+    """tdnn_pair_pool in the f16bf8 arithmetic: x: SplitBuf in FMT_SPLIT8; w: PackedPair8; status: int32 device tensor (bit 0:
+    the intermediate activation was clamped)."""
+    lib = require_gpu()
+    assert isinstance(x, SplitBuf) and isinstance(w, PackedPair8)
+    assert x.channels == w.cin and x.rows >= R and x.fmt == FMT_SPLIT8
+    _f32(block_stats, "block_stats"); assert block_stats.numel() >= block_stats_floats(R, w.cout)
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_pair_pool_f16bf8(ctypes.c_void_p(x.ptr), int(R), w.cin, w.cmid, w.cout, _ptr(w.wt), _ptr(p1[0]), _ptr(p1[1]),
+                                        _ptr(p1[2]), _ptr(p1[3]), _ptr(p2[0]), _ptr(p2[1]), _ptr(p2[2]), _ptr(p2[3]), int(act),
+                                        _ptr(row_valid), _ptr(block_stats), _ptr(status), _stream()), "xv_tdnn_pair_pool_f16bf8")
 
 
 def tdnn_pair_pool(x, R, w, p1, p2, act, row_valid, block_stats):
