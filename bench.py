@@ -398,13 +398,16 @@ def main():
         # 2 in the f16bf8 arithmetic (one fp16 MFMA at the bf16 rate + one scaled 8-bit MFMA that executes 2 products at
         # twice that rate).  frac = MFMA-pipe time at nominal rates / measured kernel time.
         prev, units = feat, 0.0
+        pair8 = getattr(model, "pair8", None) is not None
         for i, (k, c) in enumerate(zip(topo["kernel_sizes"], topo["layer_sizes"])):
-            units += 2.0 * k * prev * c * frames * (2 if "wp8" in model.layers[i] else 3)
+            in_f16bf8 = "wp8" in model.layers[i] or (pair8 and i >= len(model.layers) - 2)
+            units += 2.0 * k * prev * c * frames * (2 if in_f16bf8 else 3)
             prev = c
         units = (units + 3.0 * tp.flops_per_utt(topo) * n_utts) * args.steps
         kern = {"kernel": "tdnn_first_kernel (layer 0, bf16x3) + tdnn_gemm_f16bf8_wide_kernel (layers 1-2: fp16 MFMA + scaled bf8 MFMA "
-                          "per product) + tdnn_pair_pool_kernel (layers 3+4 chained in registers, bf16x3, pooling statistics in its "
-                          "epilogue) per batch, embed FC per step",
+                          "per product) + %s (layers 3+4 chained in registers, pooling statistics in its "
+                          "epilogue) per batch, embed FC (bf16x3) per step" %
+                          ("tdnn_pair_pool_f16bf8_kernel" if pair8 else "tdnn_pair_pool_kernel (bf16x3)"),
                 "peak": fl_gemm / (units / MFMA_BF16_PEAK) / 1e12, "frac": units / t_gemm / MFMA_BF16_PEAK,
                 "executed_bf16_equivalent_tflops": units / t_gemm / 1e12,
                 "peak_note": "achieved = ALGORITHMIC (fp32-contraction) FLOPs.  A product costs 3 bf16 MFMAs in the bf16x3 kernels "
@@ -427,8 +430,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32" if args.precision == "fp32" else
-                  "f32 in/out, f32 accumulate; GEMM products as fp16 MFMA + 2^-11 x scaled bf8 MFMA of the cross terms (layers 1-2) "
-                  "and bf16x3 split MFMA (layer 0, layers 3-4, FC)" if getattr(model, "f16bf8", False) else
+                  "f32 in/out, f32 accumulate; GEMM products as fp16 MFMA + 2^-11 x scaled bf8 MFMA of the cross terms (layers 1-4) "
+                  "and bf16x3 split MFMA (layer 0, FC)" if getattr(model, "f16bf8", False) else
                   "f32 in/out, GEMMs as bf16x3 split MFMA (hi*hi+hi*lo+lo*hi) with f32 accumulate"),
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %d utts/GPU, 23-dim MFCC, T~U{%d..%d}, default x-vector topology "
