@@ -23,7 +23,6 @@ method raises.  ``use_gpu`` is accepted for signature compatibility (the referen
 passes ``--use-gpu=no``, extract_xvectors.sh:76,85) and ignored: the extractor always runs on the GPU
 selected by ``XVECTOR_DEVICE`` / ``LOCAL_RANK`` (default ``cuda:0``).
 """
-import io
 import os
 import sys
 import time
@@ -86,7 +85,6 @@ class Model(object):
     first_window_frames = 1 << 18    # ... starting with one batch's worth and doubling (pipeline fill)
     arena_bytes = 144 << 20          # in-place reading: one arena (= one window) holds ~1.6 M 23-dim frames, six batches' worth
     first_arena_bytes = 48 << 20     # ... the first one is filled to two batches' worth only, so that the GPU starts sooner
-    map_input = os.environ.get("XVECTOR_MAP_INPUT", "1") != "0"      # BytesIO / regular-file input: scan in place instead of reading
     arena_count = 4                  # read arenas in rotation (one being filled, two queued, one being packed)
     max_batch_rows = 262144
 
@@ -378,17 +376,8 @@ class Model(object):
                     without the host library, one matrix at a time for (key, matrix) iterators."""
                     first = int(self.first_arena_bytes)
                     if in_place:
-                        # an ark that already sits in memory (a BytesIO, a regular file through the page cache) is not read at
-                        # all: the scanner walks the mapping and the packer takes the rows from there
-                        mapped = kaldi_io.map_stream(input_stream) if (hasattr(input_stream, "read") and self.map_input) else None
-                        if mapped is not None:
-                            source = kaldi_io.scan_mat_ark_mapped(
-                                mapped, arena_bytes, first // 2,
-                                fallback=lambda rest: kaldi_io.scan_mat_ark_windows(io.BytesIO(rest.tobytes()), take_arena))
-                        elif hasattr(input_stream, "read"):
-                            source = kaldi_io.scan_mat_ark_windows(input_stream, take_arena, first)
-                        else:
-                            source = input_stream.windows(take_arena, first)
+                        source = kaldi_io.scan_mat_ark_windows(input_stream, take_arena, first) if hasattr(input_stream, "read") \
+                            else input_stream.windows(take_arena, first)
                         for item in source:
                             yield item
                     elif hasattr(input_stream, "read") or hasattr(input_stream, "blocks"):
