@@ -262,12 +262,34 @@ def _e2e_leg(args, weights, topo, feat):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         nvec = out.getbuffer().nbytes // (len("utt0000000") + 1 + 2 + 3 + 1 + 4 + 512 * 4)
+        # the same ark as a FILE in RAM (tmpfs): read() of a file releases the interpreter lock, the memcpy out of a BytesIO does
+        # not -- this is what `extract_embedding.py ark:feats.ark ...` on a page-cached file sees
+        shm = None
+        if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
+            fpath = os.path.join(tempfile.mkdtemp(prefix="xv_bench_e2e_", dir="/dev/shm"), "feats.ark")
+            try:
+                with open(fpath, "wb") as f:
+                    f.write(data)
+                fbest = None
+                for _ in range(2):
+                    out = io.BytesIO()
+                    t0 = time.perf_counter()
+                    with open(fpath, "rb", buffering=0) as f:
+                        models.Model().make_embedding(f, out, tmp, 25, 10000, True, log)
+                    dt = time.perf_counter() - t0
+                    fbest = dt if fbest is None else min(fbest, dt)
+                shm = {"value": n / fbest, "unit": "utt/s", "seconds": fbest, "input": "the same ark as a file on tmpfs (/dev/shm)"}
+            finally:
+                shutil.rmtree(os.path.dirname(fpath), ignore_errors=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"value": n / best, "unit": "utt/s", "utterances": n, "vectors_written": int(nvec), "seconds": best,
-            "ark_gb_in": len(data) / 1e9, "ark_gb_per_s": len(data) / 1e9 / best,
-            "path": "ark bytes in host RAM -> Model.make_embedding(min_chunk 25, chunk 10000) -> ark bytes in host RAM, incl. model "
-                    "load, Kaldi parsing, packing, H2D, D2H and FV serialisation; best of 3 passes"}
+    res = {"value": n / best, "unit": "utt/s", "utterances": n, "vectors_written": int(nvec), "seconds": best,
+           "ark_gb_in": len(data) / 1e9, "ark_gb_per_s": len(data) / 1e9 / best,
+           "path": "ark bytes in host RAM (io.BytesIO) -> Model.make_embedding(min_chunk 25, chunk 10000) -> ark bytes in host RAM, "
+                   "incl. model load, Kaldi parsing, packing, H2D, D2H and FV serialisation; best of 3 passes"}
+    if shm is not None:
+        res["from_tmpfs_file"] = shm
+    return res
 
 
 def main():
@@ -530,6 +552,8 @@ def main():
         os.environ["XVECTOR_PRECISION"] = args.precision          # Model.load_model reads it
         e2e = _e2e_leg(args, weights, topo, feat)
         e2e["fraction_of_resident_rate"] = e2e["value"] / out["value"]
+        if "from_tmpfs_file" in e2e:
+            e2e["from_tmpfs_file"]["fraction_of_resident_rate"] = e2e["from_tmpfs_file"]["value"] / out["value"]
         out["e2e_ark_to_ark"] = e2e
     print(json.dumps(out))
     if dist.is_initialized():
