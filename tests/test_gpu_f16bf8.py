@@ -341,3 +341,43 @@ def test_pair_f16bf8_reports_an_out_of_range_intermediate(env):
     blk = torch.zeros(hiplib.block_stats_floats(R, cout), dtype=torch.float32, device=dev)
     hiplib.tdnn_pair_pool8(x, R, hiplib.pack_pair_f16bf8(t(w1), t(w2)), (None,) * 4, (None,) * 4, 1, None, blk, status)
     assert int(status.item()) == 1
+
+
+@pytest.mark.parametrize("which", ["pool8", "pair8", "pool3", "pair3"])
+def test_rows_past_the_batch_cannot_leak_into_the_pooling_blocks(env, which):
+    """Activation buffers are recycled between batches of different sizes: the rows past R of an input may hold anything --
+    including byte patterns that are NaN / Inf in fp16 or bf8.  The last 8-row block of a batch whose row count is not a
+    multiple of 8 holds such rows next to real frames; its statistics must not notice (a `* 0` mask would turn NaN into NaN)."""
+    torch, hiplib, engine, dev = env["torch"], env["hiplib"], env["engine"], env["dev"]
+    rng = np.random.default_rng(3)
+    cin, cmid, cout = 64, 512, 64
+    lens = [29, 130]                                         # the last chunk ends 3 rows into its last block
+    layout = engine.BatchLayout(lens, 1, hiplib.POOL_BLOCK_ROWS)
+    R = int(layout.row_start[-1] + layout.row_len[-1] + 1)   # ... and the batch ends right behind its gap row
+    assert R % 8 != 0 and R <= layout.rows
+    host = np.zeros((layout.rows, cin), np.float32)
+    layout.pack([(rng.standard_normal((n, cin)) * 2).astype(np.float32) for n in lens], host)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rv = t(layout.row_valid()[:R])
+    w1 = (rng.standard_normal((cin, cmid)) / 8).astype(np.float32)
+    w2 = (rng.standard_normal((cmid, cout)) / 22).astype(np.float32)
+    fmt = hiplib.FMT_SPLIT8 if which.endswith("8") else hiplib.FMT_SPLIT
+    outs = []
+    for poison in (False, True):
+        x = hiplib.SplitBuf(layout.rows, cin, dev, fmt)
+        hiplib.split_encode(t(host[:R]), x, rows=R)
+        if poison:
+            x.base[(hiplib.SPLIT_PAD_BEFORE + R) * x.row_bytes:].fill_(0xFF)      # fp16 / bf16 NaN, bf8 NaN
+        blk = torch.full((hiplib.block_stats_floats(R, cout),), float("nan"), dtype=torch.float32, device=dev)
+        if which == "pool8":
+            hiplib.tdnn_layer_pool8(x, R, hiplib.pack_weights_f16bf8(t(w1[None, :, :cout])), None, None, None, 1, None, 1, rv, blk)
+        elif which == "pool3":
+            hiplib.tdnn_layer_pool(x, R, hiplib.pack_weights_bf16x3(t(w1[None, :, :cout])), None, None, None, 1, None, 1, rv, blk)
+        elif which == "pair8":
+            hiplib.tdnn_pair_pool8(x, R, hiplib.pack_pair_f16bf8(t(w1), t(w2)), (None,) * 4, (None,) * 4, 1, rv, blk)
+        else:
+            hiplib.tdnn_pair_pool(x, R, hiplib.pack_pair_bf16x3(t(w1), t(w2)), (None,) * 4, (None,) * 4, 1, rv, blk)
+        out = torch.empty((len(lens), 2 * cout), dtype=torch.float32, device=dev)
+        hiplib.stats_pool_blocks(blk, cout, t(layout.row_start), t(layout.row_len), len(lens), 1e-5, out)
+        outs.append(out.cpu().numpy())
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])

@@ -1,5 +1,5 @@
 """Randomised parity sweep (fixed seeds): random layer widths / kernel sizes / dilations / activations / pooling kind /
-feature dims / utterance lengths / chunking / batch sizes through DeviceModel + Extractor, both precisions, against the fp64
+feature dims / utterance lengths / chunking / batch sizes through DeviceModel + Extractor, every precision, against the fp64
 oracle.  Widths are multiples of 4 (the pooling and FC kernels require 16-byte rows and say so loudly otherwise)."""
 import numpy as np
 import pytest
@@ -81,6 +81,45 @@ def test_random_topologies_through_the_first_layer_and_pair_kernels(oracle_mod, 
             if g is not None:
                 worst = max(worst, oracle_mod.rel_l2(g, r))
                 assert oracle_mod.rel_l2(g, b) < 2e-5, (case, topo)
+    assert worst < 1e-4, worst
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_random_topologies_in_the_f16bf8_arithmetic(oracle_mod, seed):
+    """Random topologies the f16bf8 path covers -- layer 0 of a shape the first-layer kernel takes, hidden layers with K in
+    {1,3,5,7} and any width (ragged last slabs, column tiles that are not full), with and without the 512-wide K = 1 pair at the
+    end -- through DeviceModel(precision="f16bf8") + Extractor against the fp64 oracle, the kernels asserted to be the ones
+    that ran.  The bar is the north star's 1e-4; the arithmetic sits at 1-3e-5."""
+    from xvector_amd import engine, hiplib, synthetic
+    hiplib.require_gpu()
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for case in range(8):
+        F = int(rng.choice([23, 13, 24, 8]))
+        k0 = int(rng.choice([3, 5])) if F > 16 else int(rng.choice([3, 5, 7]))
+        paired = rng.random() < 0.5
+        n_hidden = int(rng.integers(1, 4))                                  # f16bf8 GEMM layers between layer 0 and the tail
+        ks = [k0] + [int(rng.choice([1, 3, 5, 7])) for _ in range(n_hidden)] + ([1, 1] if paired else [int(rng.choice([1, 3]))])
+        ds = [1] + [int(rng.choice([1, 2])) if k == 3 else 1 for k in ks[1:]]
+        widths = [int(rng.choice([32, 64, 160, 512]))] + [int(rng.choice([32, 40, 96, 200, 256, 512])) for _ in range(n_hidden)]
+        widths += [512, int(rng.choice([64, 192, 1536]))] if paired else [int(rng.choice([48, 256, 520]))]
+        topo = dict(layer_sizes=widths, kernel_sizes=ks, dilations=ds, embedding_sizes=[int(rng.choice([16, 40])), 16],
+                    activation=str(rng.choice(["relu", "lrelu", "prelu"])), lrelu_alpha=0.2, pooling="stats")
+        w = synthetic.trained_like(topo, F, 8, seed=int(rng.integers(1 << 30)))
+        lens = [int(x) for x in rng.integers(1, 900, size=int(rng.integers(2, 10)))]
+        mn, cs = int(rng.choice([1, 25])), int(rng.choice([-1, 200]))
+        mats = [(rng.standard_normal((t, F)) * 3).astype(np.float32) for t in lens]
+        refs = [oracle_mod.embed_utterance(m, w, topo, mn, cs, np.float64) for m in mats]
+        model = engine.DeviceModel(w, topo, "cuda:0", precision="f16bf8")
+        assert model.f16bf8 and (model.pair8 is not None) == (paired and widths[-3] % 32 == 0), topo      # (the pair kernels take Cin % 32 == 0)
+        ex = engine.Extractor(model, mn, cs, max_batch_rows=int(rng.choice([700, 262144])))
+        got = ex.extract(mats)
+        assert ex.stats.get("fallback_windows", 0) == 0
+        for g, r in zip(got, refs):
+            assert (g is None) == (r is None), (case, topo, lens, mn, cs)
+            if g is not None:
+                assert np.isfinite(g).all()
+                worst = max(worst, oracle_mod.rel_l2(g, r))
     assert worst < 1e-4, worst
 
 

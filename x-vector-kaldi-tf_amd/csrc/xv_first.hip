@@ -183,8 +183,8 @@ __global__ __launch_bounds__(FR_WAVES * 64, 4) void tdnn_first_kernel(const Firs
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = (act_fn<MODE>(lo4[e] + b0[e], a0[e]) * s0[e] + o0[e]) * keep;
-                    v[4 + e] = (act_fn<MODE>(hi4[e] + b1[e], a1[e]) * s1[e] + o1[e]) * keep;
+                    v[e] = keep != 0.f ? act_fn<MODE>(lo4[e] + b0[e], a0[e]) * s0[e] + o0[e] : 0.f;
+                    v[4 + e] = keep != 0.f ? act_fn<MODE>(hi4[e] + b1[e], a1[e]) * s1[e] + o1[e] : 0.f;
                 }
                 const int slab = cb >> 5, t = (cb & 31) >> 3;
                 uint8_t *slabp = yr + (size_t)slab * SROW;

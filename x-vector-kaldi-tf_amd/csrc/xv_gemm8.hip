@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
                     const float v = act3(MODE, z, al[i]) * sc[i] + sh[i];
                     if (j == 0) { v0[i] = v; s1[i] = 0.f; s2[i] = 0.f; }
                     else {
-                        const float d = (v - v0[i]) * keep[j];
+                        const float d = keep[j] != 0.f ? v - v0[i] : 0.f;      // (a select: a row past R may hold NaN, and NaN * 0 is NaN)
                         s1[i] += d;
                         s2[i] += d * d;
                     }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
-                        v[i] = (act3(MODE, z, al[i]) * sc[i] + sh[i]) * keep[j];
+                        v[i] = keep[j] != 0.f ? act3(MODE, z, al[i]) * sc[i] + sh[i] : 0.f;
                     }
                     const int sw = (int)(gr >> 1) & 7;
                     char *row = ybase + (size_t)gr * yrow;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gem
             for (int i = 0; i < 8; ++i) {
                 const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
                 const float a = lrelu ? fmaxf(al[i] * z, z) : fmaxf(z, 0.f) + al[i] * fminf(z, 0.f);
-                v[i] = (a * sc[i] + sh[i]) * keep[j];
+                v[i] = keep[j] != 0.f ? a * sc[i] + sh[i] : 0.f;
             }
             if (p.y_format == XV_FMT_F32) {
                 float *o = reinterpret_cast<float *>(p.y) + (size_t)gr * p.ldy + gc0;
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
                         const float v = act3(MODE, z, al[i]) * sc[i] + sh[i];
                         if (j == 0) { v0[i] = v; s1[i] = 0.f; s2[i] = 0.f; }
                         else {
-                            const float d = (v - v0[i]) * keep[j];
+                            const float d = keep[j] != 0.f ? v - v0[i] : 0.f;      // (a select: a row past R may hold NaN, and NaN * 0 is NaN)
                             s1[i] += d;
                             s2[i] += d * d;
                         }
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
-                        v[i] = (act3(MODE, z, al[i]) * sc[i] + sh[i]) * keep[j];
+                        v[i] = keep[j] != 0.f ? act3(MODE, z, al[i]) * sc[i] + sh[i] : 0.f;
                     }
                     const int sw = (int)(gr >> 1) & 7;
                     char *row = ybase + (size_t)gr * yrow;

@@ -765,7 +765,7 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_bf16x3_kernel(const Gem
                     const float v = a * sc[i] + sh[i];
                     if (j == 0) { v0[i] = v; s1[i] = 0.f; s2[i] = 0.f; }
                     else {
-                        const float d = (v - v0[i]) * keep[j];
+                        const float d = keep[j] != 0.f ? v - v0[i] : 0.f;      // (a select: a row past R may hold anything, NaN * 0 is NaN)
                         s1[i] += d;
                         s2[i] += d * d;
                     }

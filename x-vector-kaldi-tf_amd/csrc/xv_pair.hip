@@ -355,7 +355,7 @@ __global__ __launch_bounds__(PR_WAVES * 64, 2) void tdnn_pair_pool_kernel(const 
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float d = (v[r] - v0) * keep[r];
+                const float d = keep[r] != 0.f ? v[r] - v0 : 0.f;         // (a select: a row past R may hold anything, NaN * 0 is NaN)
                 s1 += d;
                 s2 += d * d;
             }

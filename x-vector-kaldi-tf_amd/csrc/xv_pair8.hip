@@ -103,6 +103,7 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
 
     // ---- before any DMA is in flight: row validity of this lane's 16 frames, first-layer parameters -> LDS --------------
     // (lane (li, hh) pools rows 16hh .. 16hh+15 of the pair's 32 frames, see phase 2)
+    const bool frame_ok = row0 + li < p.R && (!p.valid || p.valid[row0 + li]);      // the frame whose channels this lane converts
     uint32_t rows_mask = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -330,7 +331,9 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
         };
         static_for<0, 8>(conv);
     }
-    if (amax > XV_SPLIT8_MAX && p.status) atomicOr(p.status, 1);
+    // (a lane holds ONE frame's channels: frames past R or in a gap may hold anything -- stale bytes of a recycled buffer --
+    // and their H never reaches an output, so they must not raise the flag either)
+    if (amax > XV_SPLIT8_MAX && frame_ok && p.status) atomicOr(p.status, 1);
     load_h(I0{}, slot, 0);        // (again: the copy read inside the loop is dropped so that the conversion has the registers)
 
     // ---- phase 2: partial Y[frame][column] over this wave's 256 channels, 64 columns at a time -----------------------------------------
