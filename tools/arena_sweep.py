@@ -23,7 +23,7 @@ d = tempfile.mkdtemp()
 models.Model.save_model(dict(weights=w, topology=topo, model_class="Model", num_classes=64, feat_dim=23), d, None)
 log = logging.getLogger("e2e"); log.setLevel(logging.ERROR)
 models.Model().make_embedding(io.BytesIO(raw[:cut]), io.BytesIO(), d, 25, 10000, False, log)     # kernels loaded, staging pinned
-for mb, first in ((72, 48), (144, 48), (192, 48), (192, 96), (288, 48)):
+for mb, first in ((48, 48), (32, 32), (64, 64), (96, 96), (144, 48), (48, 48), (64, 64), (40, 40)):
     models.Model.arena_bytes, models.Model.first_arena_bytes = mb << 20, first << 20
     kaldi_io._ARENA_FREE.clear()
     res = []

@@ -83,8 +83,12 @@ class Model(object):
 
     window_frames = 1 << 21          # utterances are read from the stream in windows of up to ~2M frames ...
     first_window_frames = 1 << 18    # ... starting with one batch's worth and doubling (pipeline fill)
-    arena_bytes = 144 << 20          # in-place reading: one arena (= one window) holds ~1.6 M 23-dim frames, six batches' worth
-    first_arena_bytes = 48 << 20     # ... the first one is filled to two batches' worth only, so that the GPU starts sooner
+    # in-place reading: one arena = one window.  ALL windows have the same size: the reader (~7 GB/s) is barely faster than the
+    # GPU consumes ark bytes (~6.3 GB/s at 230 k utt/s), so every window that is larger than the one before it stalls the GPU for
+    # the difference of their read times -- a short first window followed by large ones (round 2's first choice: 48 -> 144 MB)
+    # cost 7 % end to end (tools/arena_sweep.py).  64 MB = ~2300 utterances of 300 frames = three even batches.
+    arena_bytes = 64 << 20
+    first_arena_bytes = 64 << 20
     arena_count = 4                  # read arenas in rotation (one being filled, two queued, one being packed)
     max_batch_rows = 262144
 
