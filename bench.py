@@ -227,6 +227,41 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
             "kernel": "tdnn_gemm_kernel (v_mfma_f32_32x32x2_f32), standalone stats_pool_kernel"}
 
 
+def _bf16x3_leg(args, weights, topo, dev, batches, n_utts, frames, feat, order, oracle_check):
+    """The same step with EVERY layer in the bf16x3 arithmetic (three bf16 MFMAs per product; the default of round 1 and the
+    twin an out-of-range window of the f16bf8 default falls back to): 1 warm-up + 3 timed passes over the resident batches."""
+    import torch
+    from xvector_amd import engine, hiplib, topology as tp
+    model = engine.DeviceModel(weights, topo, dev, precision="bf16x3")
+    model.reserve(max(b["rows"] for b in batches), max(b["n"] for b in batches), max(b["max_len"] for b in batches))
+    P = torch.empty((n_utts, model.pooled_dim), dtype=torch.float32, device=dev)
+    E = torch.empty((n_utts, model.embed_dim), dtype=torch.float32, device=dev)
+    steps = 3
+    ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in batches] for _ in range(steps + 1)]
+
+    def one(si):
+        for bi, b in enumerate(batches):
+            model.frame_level(b["x"], b["rs"], b["rl"], b["rv"], b["n"], b["max_len"], P[b["lo"]:b["hi"]], events=ev[si][bi])
+        model.segment_level(P, E)
+    one(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for si in range(1, steps + 1):
+        one(si)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    t_g = sum(e[0].elapsed_time(e[1]) for si in range(1, steps + 1) for e in ev[si]) * 1e-3
+    fl = tp.flops_per_frame(topo, feat) * frames
+    out = {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n_utts) / dt / 1e12,
+           "frac": 3 * fl * steps / t_g / MFMA_BF16_PEAK,
+           "kernel": "tdnn_first_kernel + tdnn_gemm_bf16x3_kernel + tdnn_pair_pool_kernel (3 bf16 MFMAs per product); frac = executed "
+                     "bf16 FLOPs / 2.5 PF"}
+    if oracle_check is not None:
+        out["parity_rel_l2_max_vs_fp64_oracle"] = oracle_check(E)
+    return out
+
+
 def _e2e_leg(args, weights, topo, feat):
     """ark bytes in RAM -> Model.make_embedding (reader thread, native packer, H2D, kernels, D2H, writer thread) -> ark bytes:
     the PCIe- and parsing-inclusive rate of the drop-in entry point, model load included."""
@@ -484,14 +519,15 @@ def main():
     if args.cpu_budget > 0:
         from oracle import oracle
         # parity spot check (oracle as the checker): a few utterances of the resident workload
-        worst = 0.0
-        got = xvec.cpu().numpy()
-        for j in np.linspace(0, batches[0]["n"] - 1, args.parity_utts).astype(int):
-            lay = batches[0]["lay"]
-            s, n = int(lay.row_start[j]), int(lay.row_len[j])
-            m = batches[0]["x"][s:s + n, :feat].cpu().numpy()
-            worst = max(worst, oracle.rel_l2(got[j], oracle.embed_utterance(m, weights, topo, 25, 10000, np.float64)))
-        out["parity_rel_l2_max_vs_fp64_oracle"] = worst
+        picks = np.linspace(0, batches[0]["n"] - 1, args.parity_utts).astype(int)
+        lay = batches[0]["lay"]
+        refs = [oracle.embed_utterance(batches[0]["x"][int(lay.row_start[j]):int(lay.row_start[j]) + int(lay.row_len[j]), :feat].cpu().numpy(),
+                                       weights, topo, 25, 10000, np.float64) for j in picks]
+
+        def parity_check(vectors):                     # vectors[j] = x-vector of utterance j of the first batch
+            got = vectors[:batches[0]["n"]].cpu().numpy()
+            return max(oracle.rel_l2(got[j], r) for j, r in zip(picks, refs))
+        out["parity_rel_l2_max_vs_fp64_oracle"] = parity_check(xvec)
     if args.cpu_budget > 0 and world == 1:
         from oracle import oracle, torch_ref
         sample_lens = synthetic.utterance_lengths(32, args.tmin, args.tmax, 1234)
@@ -527,6 +563,9 @@ def main():
                                                       "extract_xvectors.sh:83-88 deploy the reference (models.py:361-363)"}}
     if world == 1 and args.precision != "fp32" and not args.no_fp32_leg:
         out["fp32_exact"] = _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat)
+        if args.precision == "f16bf8":
+            out["bf16x3"] = _bf16x3_leg(args, weights, topo, dev, batches, n_utts, frames, feat, order,
+                                        parity_check if args.cpu_budget > 0 else None)
     # ---- BASELINE configs[3] asks for the rate "incl. and excl. ark write": rank 0 writes the gathered x-vectors of ONE step
     #      as a Kaldi ark + scp (outside the timed region; `value` excludes it, `with_ark_write` folds its time into a step)
     if last is not None:

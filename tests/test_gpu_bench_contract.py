@@ -40,6 +40,10 @@ def test_extraction_bench_line():
     # exact-fp32 sub-record and the PCIe / parsing-inclusive ark -> ark rate ride on the same line; neither is `value`
     f = d["fp32_exact"]
     assert f["unit"] == "utt/s" and 0 < f["value"] < d["value"] and 0 < f["frac_of_fp32_mfma_peak_157.3"] < 1
+    # the all-bf16x3 arithmetic (round 1's default, the twin of the f16bf8 default) in the same run, with its own parity figure
+    assert d["config"]["precision"] == "f16bf8"
+    b = d["bf16x3"]
+    assert b["unit"] == "utt/s" and b["value"] > 0 and 0 < b["frac"] < 1 and b["parity_rel_l2_max_vs_fp64_oracle"] < 5e-5
     e = d["e2e_ark_to_ark"]
     assert e["utterances"] == 700 and e["vectors_written"] == 700 and e["value"] > 0
     assert e["fraction_of_resident_rate"] == pytest.approx(e["value"] / d["value"])
