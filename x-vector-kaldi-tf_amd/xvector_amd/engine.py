@@ -644,6 +644,7 @@ class Extractor(object):
             free.append(flat)
 
     PACK_THREADS = int(os.environ.get("XVECTOR_PACK_THREADS", "4"))
+    ROUND_ROWS = 32768           # rows one round of resident workgroups of the GEMM kernels covers on the 256 CUs (_batch_bounds)
 
     def _batch_bounds(self, cum, lead):
         """Chunk ranges of the batches of a window: ``cum[j]`` = rows the chunks before j occupy.  The window's rows are dealt
@@ -652,6 +653,32 @@ class Extractor(object):
         nch = len(cum) - 1
         budget = max(self.max_batch_rows - lead, 1)
         total = int(cum[-1])
+        # Large windows: batch sizes in whole ROUNDS of workgroups.  The wide GEMM (256 rows x 128 of the 256 CUs per column
+        # tile) and the pair kernel (128 rows x 256 CUs) both finish 32768 rows per round of resident workgroups, and a partly
+        # filled round costs a whole one: 2.67 batches' worth of rows as 3 even batches are 3 x 7.1 -> 24 rounds, as 8 + 7 + 7
+        # rounds they are 22.  The rounds the window needs are dealt to the fewest batches as evenly as possible.
+        R = self.ROUND_ROWS
+        cap = (lead + budget) // R                                   # rounds a batch may hold (8 at 262144 rows)
+        if cap >= 2 and total > budget:
+            n_b = max(1, -(-(total + lead) // (cap * R - lead)))
+            rounds = -(-(total + n_b * lead) // R)
+            n_b = max(n_b, -(-rounds // cap))
+            per = [rounds // n_b + (1 if k < rounds % n_b else 0) for k in range(n_b)]
+            cuts, b0 = [0], 0
+            for k in range(n_b):
+                room = min(per[k], cap) * R - lead
+                b1 = int(np.searchsorted(cum, cum[b0] + room, side="right")) - 1
+                b1 = min(max(b1, b0 + 1), nch)
+                cuts.append(b1)
+                b0 = b1
+                if b0 >= nch:
+                    break
+            while b0 < nch:                                          # (chunks do not split: what the dealt rounds could not take)
+                b1 = int(np.searchsorted(cum, cum[b0] + cap * R - lead, side="right")) - 1
+                b0 = min(max(b1, b0 + 1), nch)
+                cuts.append(b0)
+            if all(int(cum[b1] - cum[b0]) <= budget or b1 - b0 == 1 for b0, b1 in zip(cuts[:-1], cuts[1:])):
+                return self._split_by_chunks(cum, cuts, lead)
         n_b = max(1, -(-total // budget))
         cuts = None
         for extra in (0, 1):
@@ -667,6 +694,9 @@ class Extractor(object):
                 b1 = int(np.searchsorted(cum, cum[b0] + budget, side="right")) - 1
                 b0 = min(max(b1, b0 + 1), nch)
                 cuts.append(b0)
+        return self._split_by_chunks(cum, cuts, lead)
+
+    def _split_by_chunks(self, cum, cuts, lead):
         bounds = []
         for b0, b1 in zip(cuts[:-1], cuts[1:]):
             while b1 - b0 > self.max_batch_chunks:   # (only with thousands of very short chunks)
