@@ -479,6 +479,32 @@ def main():
                 "executed_bf16_tflops": 3 * fl_gemm / t_gemm / 1e12,
                 "peak_note": "achieved = ALGORITHMIC (fp32-contraction) FLOPs; every product costs 3 bf16 MFMAs, so "
                              "peak = 2.5 PFLOP/s dense bf16 MFMA / 3 and frac = executed bf16 FLOPs / 2.5 PF"}
+    if getattr(model, "f16bf8", False):
+        # per-launch breakdown from a few more (untimed) passes over the largest batch: HIP events between the launches
+        big = max(batches, key=lambda b: b["rows"])
+        passes = []
+        for _ in range(6):
+            marks = []
+            model._frame_level_f16bf8(big["x"], big["rows"], big["rv"], model.status, marks)
+            passes.append(marks)
+        torch.cuda.synchronize()
+        marks = passes[-1]
+        prev_c, by = feat, []
+        fl_layer = []
+        for k, c in zip(topo["kernel_sizes"], topo["layer_sizes"]):
+            fl_layer.append(2.0 * k * prev_c * c * big["frames"])
+            prev_c = c
+        spans = [(lab, float(np.median([pm[i][1].elapsed_time(pm[i + 1][1]) for pm in passes[1:]])) * 1e-3)
+                 for i, (lab, ev) in enumerate(marks[1:])]
+        n_l = len(model.layers)
+        groups = [[0]] + [[i] for i in range(1, n_l - 2 if model.pair is not None else n_l - 1)] + \
+                 ([[n_l - 2, n_l - 1]] if model.pair is not None else [[n_l - 1]])
+        for (lab, t), idx in zip(spans, groups):
+            cost = 2 if (idx[0] > 0 and (("wp8" in model.layers[idx[0]]) or getattr(model, "pair8", None) is not None)) else 3
+            fl = sum(fl_layer[i] for i in idx)
+            by.append({"launch": lab, "ms": t * 1e3, "algorithmic_tflops": fl / t / 1e12, "mfma_time_over_time": cost * fl / t / MFMA_BF16_PEAK})
+        kern["by_launch"] = by
+        kern["by_launch_note"] = "median of 5 extra passes over the largest batch (%d rows), HIP events between the launches" % big["rows"]
     out = {
         "metric": "utterances/sec (= x-vectors/sec, 512-d) on synthetic 23-dim MFCC, T~U[200,400]",
         "value": n_utts * world * args.steps / dt,

@@ -460,9 +460,15 @@ class DeviceModel(object):
             events[2].record()
         return pooled
 
-    def _frame_level_f16bf8(self, x, R, row_valid, status):
+    def _frame_level_f16bf8(self, x, R, row_valid, status, marks=None):
         """first-layer kernel -> split8; hidden layers in the f16bf8 arithmetic; the layer in front of the pair kernel writes
-        the bf16 split format that kernel reads; block statistics end up in ``self._last``."""
+        the format that kernel reads; block statistics end up in ``self._last``.  ``marks``: optional list that receives one
+        ``(label, event)`` per launch, the event recorded right after it (bench.py's per-kernel breakdown)."""
+        def mark(label):
+            if marks is not None:
+                ev = self.torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((label, ev))
         n = len(self.layers)
         bufs = (self._ping, self._pong)
         S8, S3 = hiplib.FMT_SPLIT8, hiplib.FMT_SPLIT
@@ -470,11 +476,14 @@ class DeviceModel(object):
         stop = n - 2 if self.pair is not None else n - 1        # layers [1, stop) run on xv_tdnn_layer_f16bf8
         pair_fmt = S8 if self.pair8 is not None else S3         # what the pair kernel in use reads
         h = bufs[0].view(L["cout"], pair_fmt if (self.pair is not None and stop == 1) else S8)
+        mark("start")
         hiplib.tdnn_first(x, R, self.first, L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, h, status)
+        mark("layer 0: tdnn_first_kernel (bf16x3)")
         for i in range(1, stop):
             L = self.layers[i]
             y = bufs[i & 1].view(L["cout"], pair_fmt if (self.pair is not None and i == stop - 1) else S8)
             hiplib.tdnn_layer8(h, R, L["wp8"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, y, status)
+            mark("layer %d: tdnn_gemm_f16bf8 (K=%d, %d -> %d)" % (i, L["K"], L["cin"], L["cout"]))
             h = y
         if self.pair is not None:
             La, Lb = self.layers[-2], self.layers[-1]
@@ -488,6 +497,9 @@ class DeviceModel(object):
             L = self.layers[-1]
             hiplib.tdnn_layer_pool8(h, R, L["wp8"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid,
                                     self._last)
+        mark("layers %d+%d + pooling statistics: %s" % (n - 2, n - 1, "tdnn_pair_pool_f16bf8_kernel" if self.pair8 is not None else
+                                                        "tdnn_pair_pool_kernel (bf16x3)") if self.pair is not None else
+             "layer %d + pooling statistics: tdnn_gemm_f16bf8 POOL" % (n - 1))
 
     def _attention_scores(self, h, R, L, row_valid):
         """Last frame-level layer + attention scores (models.py:1022-1046) for one batch: leaves the per-row scores in
