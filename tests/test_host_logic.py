@@ -348,3 +348,29 @@ def test_cli_scp_sharding_helpers(tmp_path):
         seen.append(got)
     f, v, all_keys = cli._scp_shard("scp:%s" % feats, 0, 2)
     assert v is None and len(f.read().splitlines()) == 5 and [len(k) for k in all_keys] == [5, 6]
+
+
+def test_batches_come_in_whole_rounds_of_workgroups():
+    """Extractor._batch_bounds: a window larger than one batch is cut into the fewest batches, sized in whole rounds (32768 rows)
+    of resident workgroups -- the rounds paid equal the rounds the window needs -- every batch within the row budget, every
+    chunk in exactly one batch, in order; small budgets (tests, tiny batches) keep the plain even / greedy split."""
+    from xvector_amd import engine
+    ex = engine.Extractor.__new__(engine.Extractor)
+    ex.max_batch_rows, ex.max_batch_chunks = 262144, 8192
+    rng = np.random.default_rng(0)
+    for n_utt in (100, 900, 2300, 5000, 30000):
+        lens = np.sort(rng.integers(200, 401, size=n_utt))
+        cum = np.zeros(n_utt + 1, np.int64)
+        np.cumsum(engine.slot_rows(lens, 3, 8), out=cum[1:])
+        bounds = ex._batch_bounds(cum, 8)
+        assert bounds[0][0] == 0 and bounds[-1][1] == n_utt and all(a[1] == b[0] for a, b in zip(bounds[:-1], bounds[1:]))
+        rows = [r for _, _, r in bounds]
+        assert all(r == 8 + int(cum[b1] - cum[b0]) for (b0, b1, r) in bounds) and max(rows) <= 262144
+        paid = sum(-(-r // ex.ROUND_ROWS) for r in rows)
+        need = -(-(int(cum[-1]) + 8 * len(rows)) // ex.ROUND_ROWS)
+        assert paid <= need, (n_utt, rows)
+    # a budget below two rounds: the old behaviour (even split, one chunk may exceed the budget)
+    ex.max_batch_rows = 700
+    cum = np.concatenate([[0], np.cumsum([304, 304, 808, 96, 96])])
+    bounds = ex._batch_bounds(cum, 8)
+    assert [b[:2] for b in bounds] == [(0, 2), (2, 3), (3, 5)]
