@@ -46,7 +46,7 @@ __global__ void layout_kernel(const uint8_t *A, const uint8_t *B, float *D, int 
 }
 
 // ---- (2) throughput ------------------------------------------------------------------------------------------------
-template <int MODE>   // 0: 24 bf16   1: 24 f16   2: 8 f16 + 4 MX bf8   3: 12 MX only
+template <int MODE>   // 0: 24 bf16   1: 24 f16   2: 8 f16 + 4 MX bf8   3: 12 MX only   7: 8 f16 + 4 MX fp6 (e2m3)   8: 12 MX fp6 only
 __global__ __launch_bounds__(512, 1) void rate_kernel(const uint8_t *src, float *out, int iters)
 {
     const int tid = threadIdx.x;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 1) void rate_kernel(const uint8_t *src, float 
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
     int va = 115, vb = 127;
     asm volatile("" : "+v"(va), "+v"(vb));
-    for (int it = 0; it < (MODE >= 4 ? 0 : iters); ++it) {
+    for (int it = 0; it < (MODE >= 4 && MODE < 7 ? 0 : iters); ++it) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
@@ -78,6 +78,26 @@ __global__ __launch_bounds__(512, 1) void rate_kernel(const uint8_t *src, float 
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[3], 0, 0, 0);
+            }
+        } else if constexpr (MODE >= 7) {
+            if constexpr (MODE == 7) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f16x8 a0, a1, b0, b1;
+                    __builtin_memcpy(&a0, &r[u], 16); __builtin_memcpy(&a1, reinterpret_cast<char *>(&r[u + 1]) + 16, 16);
+                    __builtin_memcpy(&b0, &r[u + 2], 16); __builtin_memcpy(&b1, reinterpret_cast<char *>(&r[u + 3]) + 16, 16);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[3], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < (MODE == 7 ? 1 : 3); ++u) {
+                acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[4 + u], r[6], acc[0], 2, 2, 0, va, 0, vb);
+                acc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[4 + u], r[7], acc[1], 2, 2, 0, va, 0, vb);
+                acc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[5 - u / 2], r[6], acc[2], 2, 2, 0, va, 0, vb);
+                acc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(r[5 - u / 2], r[7], acc[3], 2, 2, 0, va, 0, vb);
             }
         } else {
             if constexpr (MODE == 2) {
@@ -209,6 +229,9 @@ int main()
     run_rate<4>(dS, dO, iters, "4 x [f16,f16,MX] one acc per unit", 8 * 8 + 4 * 16);
     run_rate<5>(dS, dO, iters, "skewed, two accumulators", 8 * 8 + 4 * 16);
     run_rate<6>(dS, dO, iters, "skewed, four accumulators", 8 * 8 + 4 * 16);
+    run_rate<7>(dS, dO, iters, "8 x f16 + 4 x MX fp6 32x32x64", 8 * 8 + 4 * 8);
+    run_rate<8>(dS, dO, iters, "12 x MX fp6 32x32x64", 12 * 8);
+    run_rate<2>(dS, dO, iters, "8 x f16 + 4 x MX bf8 (again)", 8 * 8 + 4 * 16);
     run_rate<0>(dS, dO, iters, "24 x bf16 32x32x16 (again)", 24 * 8);
     return 0;
 }

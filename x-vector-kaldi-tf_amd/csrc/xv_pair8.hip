@@ -9,8 +9,8 @@
 //     all 32 frames (v_mfma_*_32x32*: H^T tile = 32 channels x 32 frames) and keeps them in registers (128 VGPRs, as
 //     before) -- so it only ever reads HALF of the first layer's weights;
 //   * in the second GEMM wave h contracts over ITS 256 channels only (half of the second layer's weights) and the two
-//     partial sums of a 32-frame x 64-column tile meet in LDS: each wave hands the partner the 32-column half it does not
-//     finish (4 KB) and pools the other one.
+//     partial sums of a 32-frame x 64-column tile meet in LDS: each wave writes the 32-column half the partner finishes
+//     (RED, 4 KB) AND the half it finishes itself (KEEP, 4 KB), so that a lane can pool whole rows without any shuffle.
 // LDS traffic per workgroup: 16 MB of fragment reads + 4 MB of weight DMA instead of 32 + 4.
 //   * products are formed as in xv_gemm8.hip: one v_mfma_f32_32x32x16_f16 on the fp16 parts + one
 //     v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64 holds [xl8 . wh8 | xh8 . wl8] of a 32-channel slab, i.e. 32 MFMA passes
@@ -20,7 +20,9 @@
 // GEMM for that 32-channel slab: fp16 k-step ks takes r = 8 ks .. 8 ks + 7, the scaled MFMA's K-block hh takes
 // [l8 r0..7 | h8 r0..7 | l8 r8..15 | h8 r8..15]; the packed weights of layer 4 follow that order.  No LDS round trip.
 // Weight stream: 32 KB stages [half 0: 4 units][half 1: 4 units], unit = [fp16 fragment k-step 0 | k-step 1 | 8-bit
-// fragment, two 1 KB planes], lane-linear 16-byte fragments; ring of three, DMA three stages ahead, counted vmcnt.
+// fragment, two 1 KB planes], lane-linear 16-byte fragments; ring of three.  ONE barrier per stage, between its third and
+// fourth unit (the fourth unit's fragments are in registers by then): behind it the slot is refilled with stage s+3, so a
+// DMA has two full stages to land and the barrier's wait is a counted vmcnt(4), never a drain.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -55,6 +57,20 @@ constexpr int P8_KEEP_OFF = P8_X_OFF + P8_WAVES * 4096; // ... and the 4 KB it f
 constexpr int P8_P1_OFF = P8_X_OFF + P8_WAVES * 4096;  // [bias | scale | shift | alpha][CMID] of the first layer
 constexpr size_t P8_LDS_BYTES = P8_KEEP_OFF + P8_WAVES * 4096;      // 160 KB: everything a CU has
 constexpr int SROW = 128;
+
+// pooling schedule of the second GEMM: rows of the previous column tile handled in step j of stage q (see pool_step)
+constexpr int pool_count(int q, int j) { return q == 0 ? (j == 3 ? 2 : 0) : q == 3 ? (j == 0 ? 2 : j == 3 ? 0 : 1) : (j == 0 ? 2 : 1); }
+constexpr int pool_first(int q, int j)
+{
+    int k = 0;
+    for (int qq = 0; qq < 4; ++qq)
+        for (int jj = 0; jj < 4; ++jj) {
+            if (qq == q && jj == j) return k;
+            k += pool_count(qq, jj);
+        }
+    return k;
+}
+static_assert(pool_first(3, 3) + pool_count(3, 3) == 16, "16 rows per column tile");
 
 struct Pair8Params {
     const uint8_t *x;          // split8 input, row 0
@@ -184,11 +200,12 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
         Mx[set] = cat(*reinterpret_cast<const xv_i32x4 *>(b + 2048), *reinterpret_cast<const xv_i32x4 *>(b + 3072));
     };
     auto next_slot = [](int slot) { return slot + P8_STAGE == P8_RING * P8_STAGE ? 0 : slot + P8_STAGE; };
-    // B(s), at the END of stage s: this wave's fragment reads of stage s are complete (its slot may be overwritten: the DMA of
-    // stage s+3 is issued at the top of stage s+1) and ALL its DMA pieces have landed -- stage s+2, issued at the top of stage s,
-    // is read from step 3 of stage s+1 on -- and after the barrier the same holds for every wave.
+    // B(s), between steps 2 and 3 of stage s: this wave's fragment reads of stage s are complete (the fragments of its last unit
+    // are in registers: the slot is refilled with stage s+3 right behind the barrier), its DMA pieces of stage s+1 (and the frames
+    // issued with them) have landed -- issued two barriers ago; only the 4 pieces of stage s+2 may still be in flight -- and
+    // after the barrier the same holds for every wave: a DMA has two full stages to land.
     auto stage_barrier = [&]() {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
     // MFMA / LDS-read / DMA interleave of one step: 3 MFMAs, ND ds_read_b128, NV LDS-DMA pieces.  Every fragment read goes
@@ -213,14 +230,13 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     issue_x();
     issue_w(0);
     issue_w(P8_STAGE);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // frames of slab 0 and stage 0
+    issue_w(2 * P8_STAGE);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // frames of slab 0 and stage 0
     __builtin_amdgcn_s_barrier();
     XFrag X;
     load_xfrag(X);
     load_h(I0{}, 0, 0);
-    int slot = 0, slot_n = P8_STAGE, slot_i = 2 * P8_STAGE;    // ring slots of stage s, of stage s+1, and the free one (stage s+2 goes there)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                              // everybody holds slab 0 in registers: its buffer may be refilled
+    int slot = 0;
 
     // ---- phase 1: H^T[channel][frame] for this wave's 256 channels: 8 tiles of 32 channels x 32 frames ---------------------------
     f32x16 acc[8];
@@ -243,15 +259,13 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             typedef std::integral_constant<int, 4 * q + 2> T2;
             typedef std::integral_constant<int, 4 * q + 3> T3;
             typedef std::integral_constant<int, q == 0 ? 7 : 3> TP;          // tile of the pending 8-bit MFMA
-            if constexpr (q == 0) issue_x();               // the frames of slab ks+1 (everybody holds slab ks in registers)
-            issue_w(slot_i);
             // step 0
             load_h(I1{}, slot, 1);
             load_m(I0{}, slot, 0);
             f16a(I0{}, T0{}, X.h0, false);
             mxa(I1{}, TP{}, q == 0 ? Xprev : X.x);
             f16a(I0{}, T0{}, X.h1, true);
-            pin(std::integral_constant<int, q == 0 ? 6 : 4>{}, std::integral_constant<int, 4>{});
+            pin(I0{}, std::integral_constant<int, 4>{});
             // step 1
             load_h(I0{}, slot, 2);
             load_m(I1{}, slot, 1);
@@ -259,35 +273,35 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             mxa(I0{}, T0{}, X.x);
             f16a(I1{}, T1{}, X.h1, true);
             pin(I0{}, std::integral_constant<int, 4>{});
-            // step 2
+            // step 2 (also the 8-bit fragment of unit 3: everything of this slot is read before the barrier)
             load_h(I1{}, slot, 3);
             load_m(I0{}, slot, 2);
             f16a(I0{}, T2{}, X.h0, false);
             mxa(I1{}, T1{}, X.x);
-            f16a(I0{}, T2{}, X.h1, true);
-            pin(I0{}, std::integral_constant<int, 4>{});
-            // step 3 (the fp16 fragments of the next stage's first unit come from the next ring slot)
-            load_h(I0{}, slot_n, 0);
             load_m(I1{}, slot, 3);
+            f16a(I0{}, T2{}, X.h1, true);
+            pin(I0{}, std::integral_constant<int, 6>{});
+            stage_barrier();
+            if constexpr (q == 0) issue_x();               // the frames of slab ks+1 (everybody holds slab ks in registers)
+            issue_w(slot);
+            slot = next_slot(slot);
+            // step 3 (the fp16 fragments of the next stage's first unit come from the next ring slot)
+            load_h(I0{}, slot, 0);
             if constexpr (q == 1) {
                 XFrag N;
-                load_xfrag(N);                             // frames of slab ks+1: landed before the previous barrier
+                load_xfrag(N);                             // frames of slab ks+1: issued two barriers ago
                 f16a(I1{}, T3{}, X.h0, false);
                 mxa(I0{}, T2{}, X.x);
                 f16a(I1{}, T3{}, X.h1, true);
-                pin(I0{}, std::integral_constant<int, 8>{});
+                pin(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
                 Xprev = X.x;
                 X = N;
             } else {
                 f16a(I1{}, T3{}, X.h0, false);
                 mxa(I0{}, T2{}, X.x);
                 f16a(I1{}, T3{}, X.h1, true);
-                pin(I0{}, std::integral_constant<int, 4>{});
+                pin(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
             }
-            stage_barrier();
-            slot_i = slot;
-            slot = slot_n;
-            slot_n = next_slot(slot_n);
         };
         stage1(I0{});
         stage1(I1{});
@@ -388,17 +402,16 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             }
         }
     };
-    // rows pooled in step j of stage q (q < 3): 2,2,1,1 | 2,1,1,1 | 2,1,1,1
+    // Rows of the PREVIOUS column tile pooled in step j of stage q.  The exchange of a tile is written after the last unit of
+    // its stage 3, i.e. behind B(., 3), and becomes visible with B(next tile, 0): reads start in step 3 of stage 0 and end in
+    // step 2 of stage 3 (before B(., 3), behind which the next exchange is written): - - - 2 | 2 1 1 1 | 2 1 1 1 | 2 1 1 -
     auto pool_step = [&](auto Q, auto J, int ct) {
         constexpr int q = decltype(Q)::value, j = decltype(J)::value;
-        if constexpr (q < 3) {
-            constexpr int first = q == 0 ? (j == 0 ? 0 : j == 1 ? 2 : j + 2) : (q == 1 ? (j == 0 ? 6 : j + 7) : (j == 0 ? 11 : j + 12));
-            constexpr int count = (j == 0 || (q == 0 && j == 1)) ? 2 : 1;
-            // (column tile -1 does not exist: its rows are read from whatever the buffers hold and never stored -- no branch
-            // that would split the scheduling region of the step)
-            pool_row(std::integral_constant<int, first>{}, ct - 1);
-            if constexpr (count == 2) pool_row(std::integral_constant<int, first + 1>{}, ct - 1);
-        }
+        constexpr int count = pool_count(q, j), first = pool_first(q, j);
+        // (column tile -1 does not exist: its rows are read from whatever the buffers hold and never stored -- no branch
+        // that would split the scheduling region of the step)
+        if constexpr (count >= 1) pool_row(std::integral_constant<int, first>{}, ct - 1);
+        if constexpr (count == 2) pool_row(std::integral_constant<int, first + 1>{}, ct - 1);
     };
     prm_next = fetch_params(0);
     for (int ct = 0; ct < p.n_ct; ++ct) {
@@ -418,12 +431,10 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             typedef std::integral_constant<int, 2 * q> UA;
             typedef std::integral_constant<int, 2 * q + 1> UB;
             typedef std::integral_constant<int, q == 0 ? 0 : 2 * q - 1> UP;   // slab of the pending 8-bit MFMA (none when q == 0)
-            typedef std::integral_constant<int, q < 3 ? 2 : 0> NR;            // ds_read_b32 of the pooled rows (at most 2 x 2 per step)
             if constexpr (q == 0) {
-                prm = prm_next;                             // the parameters of column tile ct-1 ... fetched a whole tile ago
-                prm_next = fetch_params(ct < p.n_ct ? ct : p.n_ct - 1);
+                prm = prm_next;                             // the parameters of column tile ct-1, fetched a whole tile ago
+                prm_next = fetch_params(ct);
             }
-            issue_w(slot_i);
             // step 0: unit (2q, 0)
             load_h(I1{}, slot, 1);
             load_m(I0{}, slot, 0);
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             if constexpr (q > 0) mxb(I1{}, UP{}, I1{});
             f16b(I0{}, UA{}, I0{}, true);
             pool_step(Q, I0{}, ct);
-            pin(std::integral_constant<int, 4>{}, std::integral_constant<int, 4 + 2 * NR::value>{});
+            pin(I0{}, std::integral_constant<int, 4 + 2 * pool_count(q, 0)>{});
             // step 1: unit (2q, 1)
             load_h(I0{}, slot, 2);
             load_m(I1{}, slot, 1);
@@ -439,41 +450,41 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             mxb(I0{}, UA{}, I0{});
             f16b(I1{}, UA{}, I1{}, true);
             pool_step(Q, I1{}, ct);
-            pin(I0{}, std::integral_constant<int, 4 + (q == 0 ? 2 : 1) * NR::value>{});
-            // step 2: unit (2q+1, 0)
+            pin(I0{}, std::integral_constant<int, 4 + 2 * pool_count(q, 1)>{});
+            // step 2: unit (2q+1, 0); also the 8-bit fragment of unit 3
             load_h(I1{}, slot, 3);
             load_m(I0{}, slot, 2);
             f16b(I0{}, UB{}, I0{}, false);
             mxb(I1{}, UA{}, I1{});
+            load_m(I1{}, slot, 3);
             f16b(I0{}, UB{}, I0{}, true);
             pool_step(Q, std::integral_constant<int, 2>{}, ct);
-            pin(I0{}, std::integral_constant<int, 4 + NR::value>{});
+            pin(I0{}, std::integral_constant<int, 6 + 2 * pool_count(q, 2)>{});
+            stage_barrier();
+            issue_w(slot);
+            slot = next_slot(slot);
             // step 3: unit (2q+1, 1)
-            load_h(I0{}, slot_n, 0);
-            load_m(I1{}, slot, 3);
+            load_h(I0{}, slot, 0);
             f16b(I1{}, UB{}, I1{}, false);
             mxb(I0{}, UB{}, I0{});
             f16b(I1{}, UB{}, I1{}, true);
             pool_step(Q, std::integral_constant<int, 3>{}, ct);
-            pin(I0{}, std::integral_constant<int, 4 + NR::value>{});
+            pin(std::integral_constant<int, 4>{}, std::integral_constant<int, 2 + 2 * pool_count(q, 3)>{});
             if constexpr (q == 3) {
                 mxb(I1{}, UB{}, I1{});                      // the pending 8-bit MFMA of the tile's last unit
-                // both halves of the partial tile -> LDS; the barrier below orders the exchange (nobody reads in this stage)
+                // both halves of the partial tile -> LDS; B(next tile, 0) orders the exchange (nobody reads behind B(., 3))
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     red_mine[r * 64] = hf ? y[0][r] : y[1][r];
                     keep_mine[r * 64] = hf ? y[1][r] : y[0][r];
                 }
             }
-            stage_barrier();
-            slot_i = slot;
-            slot = slot_n;
-            slot_n = next_slot(slot_n);
         };
         static_for<0, 4>(quarter);
     }
-    // the last column tile: its exchange is behind the last barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the last column tile: make its exchange visible, then pool it
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     prm = prm_next;
     {
         auto tail = [&](auto K) { pool_row(K, p.n_ct - 1); };
