@@ -21,7 +21,7 @@ for l in stats.splitlines():
         f = l.split(); cnt += int(f[-4]); tot += float(f[-3])
 under = json.loads(rd("bench_under_prof"))
 hdr = ("# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-budget 0 --e2e-utts 0 --no-fp32-leg   (MI355X, default precision %s,\n"
-       "#   commit %s, kernel sources %s; tools/profile_round.sh).  6 steps (1 warm-up + 5 timed) x 12 batches of <= 262144 rows.\n"
+       "#   commit %s, kernel sources %s; tools/profile_round.sh).  6 steps (1 warm-up + 5 timed) x 12 batches of <= 262144 rows + the 6 passes over the largest batch behind roofline.by_launch.\n"
        "#   tdnn_first_kernel<2, true>           = layer 0 (K=5, 23 MFCC dims in 24 columns -> 512; bf16x3 arithmetic, split8 output from the accumulators)\n"
        "#   tdnn_gemm_f16bf8_wide_kernel<5|7, false> = layers 1 / 2 (K = 5 / 7, 512 -> 512): fp16 MFMA + scaled bf8 MFMA per product, 256 x 256 workgroup tiles\n"
        "#   tdnn_pair_pool_f16bf8_kernel<2>      = layers 3 + 4 (K=1, 512 -> 512 -> 1536) chained in registers (f16bf8, a pair of waves per 32 frames) + 8-row block statistics of the pooling\n"
@@ -47,7 +47,7 @@ for k, v in vals.items():
                      (k, v["GRBM_GUI_ACTIVE"][0], v["GRBM_GUI_ACTIVE"][3] / 1e3, 100 * v["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (cyc * 1024),
                       cyc / v["GRBM_GUI_ACTIVE"][3], 100 * v["SQ_WAIT_ANY"][1] / v["SQ_WAVE_CYCLES"][1] if "SQ_WAIT_ANY" in v else float("nan")))
 hdr2 = ("# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --steps 1 --warmup 0 --cpu-budget 0 --e2e-utts 0 --no-fp32-leg   (separate passes: FETCH_SIZE | WRITE_SIZE |\n"
-        "#   SQ/GRBM set; tools/profile_round.sh, commit %s, kernel sources %s).  12 batches of <= 262144 rows per pass; last column = average kernel duration in ns.\n"
+        "#   SQ/GRBM set; tools/profile_round.sh, commit %s, kernel sources %s).  12 batches of <= 262144 rows per pass (+ 6 by_launch passes over the largest batch); last column = average kernel duration in ns.\n"
         "# FETCH_SIZE / WRITE_SIZE in KiB per launch.  Fabric-side bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, verified on\n"
         "#   stats_pool_kernel: its corrected reads equal its algorithmic bytes within 0.3 %%).  FETCH_SIZE counts L2-miss requests: Infinity-Cache hits are included.\n"
         "# MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs); effective shader clock = (GRBM_GUI_ACTIVE/8) / duration (nominal 2.4 GHz):\n"
