@@ -6,10 +6,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-
 import torch
 from xvector_amd import hiplib
 dev = torch.device("cuda:0"); R = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+ZERO = os.environ.get("PAIR8_BENCH_ZERO", "")      # "w", "x" or "wx": zero weights / frames (how much of the time is the power limit)
 cin, cmid, cout = 512, 512, 1536
 w1 = torch.randn((cin, cmid), device=dev) / cin ** 0.5; w2 = torch.randn((cmid, cout), device=dev) / cmid ** 0.5
+if 'w' in ZERO: w1.zero_(); w2.zero_()
 p3, p8 = hiplib.pack_pair_bf16x3(w1, w2), hiplib.pack_pair_f16bf8(w1, w2)
 x = torch.relu(torch.randn((R, cin), device=dev)) * 1.3 - 0.4
+if 'x' in ZERO: x.zero_()
 x3 = hiplib.SplitBuf(R, cin, dev); hiplib.split_encode(x, x3)
 x8 = hiplib.SplitBuf(R, cin, dev, hiplib.FMT_SPLIT8); hiplib.split_encode(x, x8)
 b1 = torch.zeros(cmid, device=dev); b2 = torch.zeros(cout, device=dev); rv = torch.ones(R, dtype=torch.uint8, device=dev)
