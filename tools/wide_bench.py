@@ -1,0 +1,33 @@
+"""The 256 x 256-tile f16bf8 kernel on layers 1 / 2 (K = 5, 7; 512 -> 512).  WIDE_BENCH_ZERO=1 runs it on zero weights and
+frames: the chip then holds its full clock, and the difference to the random-data time is the power limit, the rest structure.
+argv[1] = rows (default 262144)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd"))
+import torch
+from xvector_amd import hiplib
+dev = torch.device("cuda:0"); R = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+ZERO = bool(os.environ.get("WIDE_BENCH_ZERO", ""))
+SPARSE = bool(os.environ.get("WIDE_BENCH_SPARSE", ""))    # frames = relu(randn): half of them exactly zero
+cin = cout = 512
+for K in (5, 7):
+    w = torch.randn((K, cin, cout), device=dev) / (K * cin) ** 0.5
+    x = torch.relu(torch.randn((R, cin), device=dev)) * 1.3 - 0.4
+    if SPARSE: x = torch.relu(torch.randn((R, cin), device=dev))
+    if ZERO: w.zero_(); x.zero_()
+    w8 = hiplib.pack_weights_f16bf8(w)
+    x8 = hiplib.SplitBuf(R, cin, dev, hiplib.FMT_SPLIT8); hiplib.split_encode(x, x8)
+    bias = torch.zeros(cout, device=dev); rv = torch.ones(R, dtype=torch.uint8, device=dev)
+    y8 = hiplib.SplitBuf(R, cout, dev, hiplib.FMT_SPLIT8); status = torch.zeros(1, dtype=torch.int32, device=dev)
+    hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 512)
+    fn = lambda: hiplib.tdnn_layer8(x8, R, w8, bias, None, None, 1, None, 1, rv, y8, status)
+    ts = []
+    for rnd in range(7):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(8): fn()
+        b.record(); torch.cuda.synchronize()
+        if rnd: ts.append(a.elapsed_time(b) / 8)
+    hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
+    ts.sort(); med = ts[len(ts) // 2]
+    print("K %d %s: median %.3f ms (min %.3f)  %.0f TF algorithmic" % (K, "zeros" if ZERO else "sparse" if SPARSE else "random", med, ts[0], 2.0 * R * cin * cout * K / 1e9 / med))
