@@ -7,7 +7,7 @@ import torch
 from xvector_amd import hiplib
 dev = torch.device("cuda:0"); R = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 ZERO = os.environ.get("PAIR8_BENCH_ZERO", "")      # "w", "x" or "wx": zero weights / frames (how much of the time is the power limit)
-cin, cmid, cout = 512, 512, 1536
+cin, cmid, cout = 512, 512, int(os.environ.get('PAIR8_BENCH_COUT', '1536'))
 w1 = torch.randn((cin, cmid), device=dev) / cin ** 0.5; w2 = torch.randn((cmid, cout), device=dev) / cmid ** 0.5
 if 'w' in ZERO: w1.zero_(); w2.zero_()
 p3, p8 = hiplib.pack_pair_bf16x3(w1, w2), hiplib.pack_pair_f16bf8(w1, w2)

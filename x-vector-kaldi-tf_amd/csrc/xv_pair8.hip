@@ -122,26 +122,6 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     const int hh = lane >> 5, li = lane & 31;
     const long row0 = (long)blockIdx.x * P8_ROWS + 32 * pair;     // the pair's 32 frames (a multiple of 8: four pooling blocks)
 
-    // ---- before any DMA is in flight: row validity of this lane's 16 frames, first-layer parameters -> LDS --------------
-    // (lane (li, hh) pools rows 16hh .. 16hh+15 of the pair's 32 frames, see phase 2)
-    const bool frame_ok = row0 + li < p.R && (!p.valid || p.valid[row0 + li]);      // the frame whose channels this lane converts
-    uint32_t rows_mask = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const long gr = row0 + 16 * hh + k;
-        if (gr < p.R && (!p.valid || p.valid[gr])) rows_mask |= 1u << k;
-    }
-    {
-        float *P1 = reinterpret_cast<float *>(lds + P8_P1_OFF);
-        for (int c = tid; c < CMID; c += P8_WAVES * 64) {
-            P1[c] = p.b1 ? p.b1[c] : 0.f;
-            P1[CMID + c] = p.sc1 ? p.sc1[c] : 1.f;
-            P1[2 * CMID + c] = p.sh1 ? p.sh1[c] : 0.f;
-            P1[3 * CMID + c] = p.act == XV_ACT_NONE ? 1.f : p.act == XV_ACT_LRELU ? p.al1[0] : p.act == XV_ACT_PRELU ? p.al1[c] : 0.f;
-        }
-    }
-    __syncthreads();
-
     // ---- DMA streams -------------------------------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.wt), 0, 0x7ffffff0, XV_RSRC_FLAGS);
     const int wvoff = wave * 4096 + lane * 16;
@@ -252,8 +232,37 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     issue_w(P8_STAGE);
     fill = 2 * P8_STAGE;
     w_piece(I0{});                                             // (pieces 1-3 of stage 2 follow in steps 0-2 of stage 0)
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");           // frames of slab 0 and stage 0
-    __builtin_amdgcn_s_barrier();
+    // ---- while the first stages are on their way: row validity of this lane's frames, first-layer parameters -> LDS --------
+    // (lane (li, hh) pools rows 16hh .. 16hh+15 of the pair's 32 frames, see phase 2; the 16 validity bytes in ONE load --
+    // sixteen dependent byte loads were most of this prologue)
+    bool frame_ok = row0 + li < p.R;                           // the frame whose channels this lane converts
+    uint32_t rows_mask = 0;
+    {
+        const long g0 = row0 + 16 * hh;
+        uint8_t vb[16];
+        if (!p.valid) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) vb[k] = 1;
+        } else if (g0 + 16 <= p.R) {
+            __builtin_memcpy(vb, p.valid + g0, 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) vb[k] = g0 + k < p.R ? p.valid[g0 + k] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (g0 + k < p.R && vb[k]) rows_mask |= 1u << k;
+        if (p.valid && frame_ok) frame_ok = p.valid[row0 + li] != 0;
+        float *P1 = reinterpret_cast<float *>(lds + P8_P1_OFF);
+        for (int c = tid; c < CMID; c += P8_WAVES * 64) {
+            P1[c] = p.b1 ? p.b1[c] : 0.f;
+            P1[CMID + c] = p.sc1 ? p.sc1[c] : 1.f;
+            P1[2 * CMID + c] = p.sh1 ? p.sh1[c] : 0.f;
+            P1[3 * CMID + c] = p.act == XV_ACT_NONE ? 1.f : p.act == XV_ACT_LRELU ? p.al1[0] : p.act == XV_ACT_PRELU ? p.al1[c] : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");           // frames of slab 0 and stage 0 (the loads above were behind them)
+    __syncthreads();
     XFrag X;
     load_xfrag(X);
     load_h(I0{}, 0, 0);
