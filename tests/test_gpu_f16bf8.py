@@ -381,3 +381,51 @@ def test_rows_past_the_batch_cannot_leak_into_the_pooling_blocks(env, which):
         hiplib.stats_pool_blocks(blk, cout, t(layout.row_start), t(layout.row_len), len(lens), 1e-5, out)
         outs.append(out.cpu().numpy())
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("which", ["pool8", "pair8", "pool3", "pair3"])
+def test_block_statistics_do_not_depend_on_the_row_position(env, which):
+    """The same frames moved down by 8, 16, 32, 64 or 128 rows give the same 8-row block statistics, BIT FOR BIT, one, two ...
+    blocks further down: the pooling code of a block must not depend on which wave, lane half or unrolled instance handles it
+    (the optimiser once contracted the sums of the two blocks a lane pools differently).  Full width: 1536 columns, so that the
+    pair kernels' in-loop AND tail pooling are covered."""
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    R, cin, cmid, cout = 1024, 512, 512, 1536
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    w1, w2 = rnd(cin, cmid) / cin ** 0.5, rnd(cmid, cout) / cmid ** 0.5
+    b1, b2 = rnd(cmid) * 0.1, rnd(cout) * 0.1
+    x = torch.relu(rnd(R, cin)) * 1.3 - 0.4
+    fmt = hiplib.FMT_SPLIT8 if which.endswith("8") else hiplib.FMT_SPLIT
+    rv = torch.ones(R, dtype=torch.uint8, device=dev)
+    if which == "pair8":
+        pk = hiplib.pack_pair_f16bf8(w1, w2)
+    elif which == "pair3":
+        pk = hiplib.pack_pair_bf16x3(w1, w2)
+    elif which == "pool8":
+        pk = hiplib.pack_weights_f16bf8(w2[None])
+    else:
+        pk = hiplib.pack_weights_bf16x3(w2[None])
+
+    def run(frames):
+        xs = hiplib.SplitBuf(R, cin, dev, fmt)
+        hiplib.split_encode(frames, xs)
+        blk = torch.zeros(hiplib.block_stats_floats(R, cout), dtype=torch.float32, device=dev)
+        if which == "pair8":
+            hiplib.tdnn_pair_pool8(xs, R, pk, (b1, None, None, None), (b2, None, None, None), 1, rv, blk)
+        elif which == "pair3":
+            hiplib.tdnn_pair_pool(xs, R, pk, (b1, None, None, None), (b2, None, None, None), 1, rv, blk)
+        elif which == "pool8":
+            hiplib.tdnn_layer_pool8(xs, R, pk, b2, None, None, 1, None, 1, rv, blk)
+        else:
+            hiplib.tdnn_layer_pool(xs, R, pk, b2, None, None, 1, None, 1, rv, blk)
+        return blk.view(-1, 2, cout).cpu().numpy()
+
+    base = run(x)
+    assert np.isfinite(base).all() and np.abs(base).max() > 0
+    for shift in (8, 16, 32, 64, 128):
+        moved = torch.zeros_like(x)
+        moved[shift:] = x[:-shift]
+        got = run(moved)
+        nb = shift // 8
+        assert np.array_equal(got[nb:], base[: R // 8 - nb]), "shift %d" % shift

@@ -440,7 +440,10 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     };
     auto pool_row = [&](auto K, auto I, int ct) {          // row k of column tile ct (statistics shifted by the block's first row)
         constexpr int k = decltype(K)::value, i = decltype(I)::value;
-        float v = act_fn<MODE>(pa[i] + pb[i] + prm[0], prm[3]) * prm[1] + prm[2];
+        // Every product-sum below is an EXPLICIT fma: left to the optimiser, the sixteen instances of this body contract (or pack
+        // into v_pk_mul / v_pk_add) differently, and a block's statistics would depend on whether it sits at an even or an odd
+        // 8-row position -- an utterance's x-vector must not depend on where in the batch it lies.
+        float v = __builtin_fmaf(act_fn<MODE>(pa[i] + pb[i] + prm[0], prm[3]), prm[1], prm[2]);
         asm volatile("" : "+v"(v));              // (computed for every lane: masked rows must not turn into a branch around the reads)
         if constexpr ((k & 7) == 0) {
             pv0 = v;
@@ -449,13 +452,15 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
         } else {
             const float d = ((rows_mask >> k) & 1u) ? v - pv0 : 0.f;
             ps1 += d;
-            ps2 += d * d;
+            ps2 = __builtin_fmaf(d, d, ps2);
         }
         if constexpr ((k & 7) == 7) {
             const float n = (float)__builtin_popcount((rows_mask >> (k - 7)) & 255u);
             const float rn = n > 0.f ? 1.f / n : 0.f;
-            const float mean = n > 0.f ? pv0 + ps1 * rn : 0.f;
-            const float m2 = fmaxf(ps2 - ps1 * ps1 * rn, 0.f);
+            const float mean = n > 0.f ? __builtin_fmaf(ps1, rn, pv0) : 0.f;
+            float sq = ps1 * ps1;
+            asm volatile("" : "+v"(sq));
+            const float m2 = fmaxf(__builtin_fmaf(-sq, rn, ps2), 0.f);
             // (blocks past n_blocks and the non-existent column tile -1 fall outside the descriptor and are dropped by the
             // range check: no branch that would split the step's scheduling region)
             const int o = ct >= 0 ? blk_voff + (k >> 3) * blk_row_bytes + ct * 256 : -1;
