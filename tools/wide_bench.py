@@ -9,8 +9,8 @@ from xvector_amd import hiplib
 dev = torch.device("cuda:0"); R = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 ZERO = bool(os.environ.get("WIDE_BENCH_ZERO", ""))
 SPARSE = bool(os.environ.get("WIDE_BENCH_SPARSE", ""))    # frames = relu(randn): half of them exactly zero
-cin = cout = 512
-for K in (5, 7):
+cout = 512
+for cin, K in [(int(c), int(k)) for c, k in (a.split(':') for a in os.environ.get('WIDE_BENCH_SHAPES', '512:5,512:7').split(','))]:
     w = torch.randn((K, cin, cout), device=dev) / (K * cin) ** 0.5
     x = torch.relu(torch.randn((R, cin), device=dev)) * 1.3 - 0.4
     if SPARSE: x = torch.relu(torch.randn((R, cin), device=dev))
@@ -30,4 +30,4 @@ for K in (5, 7):
         if rnd: ts.append(a.elapsed_time(b) / 8)
     hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
     ts.sort(); med = ts[len(ts) // 2]
-    print("K %d %s: median %.3f ms (min %.3f)  %.0f TF algorithmic" % (K, "zeros" if ZERO else "sparse" if SPARSE else "random", med, ts[0], 2.0 * R * cin * cout * K / 1e9 / med))
+    print("cin %d K %d %s: median %.3f ms (min %.3f)  %.0f TF algorithmic" % (cin, K, "zeros" if ZERO else "sparse" if SPARSE else "random", med, ts[0], 2.0 * R * cin * cout * K / 1e9 / med))
