@@ -878,8 +878,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
                         xv_f16x8 hi;
                         xv_i32x4 x8;
                         xv_split8_encode8<true>(v, hi, x8, amax);
-                        __builtin_nontemporal_store(hi, reinterpret_cast<xv_f16x8 *>(row + ((slot ^ sw) << 4)));
-                        __builtin_nontemporal_store(x8, reinterpret_cast<xv_i32x4 *>(row + (((4 + slot) ^ sw) << 4)));
+                        *reinterpret_cast<xv_f16x8 *>(row + ((slot ^ sw) << 4)) = hi;              // (plain, not non-temporal: see DESIGN 3.1e)
+                        *reinterpret_cast<xv_i32x4 *>(row + (((4 + slot) ^ sw) << 4)) = x8;
                     } else {
                         bf16x8 hi, lo;
 #pragma unroll
