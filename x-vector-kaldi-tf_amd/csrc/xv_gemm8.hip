@@ -676,8 +676,13 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
         acc[i0 + 1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A.f1, B.f1, acc[i0 + 1][1], 1, 1, 0, scale_a, 0, scale_b);
     };
 
+    // In the main loop only waves 0-3 -- one per SIMD (a workgroup's waves go to the SIMDs cyclically: w and w + 4 share one) --
+    // issue DMA.  An LDS-DMA instruction holds a wave's issue for 60-180 cycles; when all eight waves issue their pieces behind
+    // the same barrier, both waves of every SIMD stand still together and the MFMA pipe with them.  With one issuing wave per
+    // SIMD the other one keeps the pipe busy, and the issuing wave catches up while its partner waits at the next barrier.
+    constexpr int NI = 4;                              // issuing waves
     constexpr int DT = KT - 1;
-    constexpr int NS = (NP + NW - 1) / NW;
+    constexpr int NS = (NP + NI - 1) / NI;
     constexpr int PW = (NS + DT - 1) / DT;
     auto slots_of = [](int t) constexpr { return t < DT ? (NS + DT - 1 - t) / DT : 0; };
     auto slot_base = [](int t) constexpr { int b = 0; for (int u = 0; u < t; ++u) b += (NS + DT - 1 - u) / DT; return b; };
@@ -687,12 +692,15 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            int piece = (slot_base(t) + j) * NW + wave;
+            int piece = (slot_base(t) + j) * NI + (wave & 3);
             piece = piece < NP ? piece : NP - 1;
             ag_off[t][j] = (uint32_t)piece * rowstep;
             al_off[t][j] = (uint32_t)piece * 1024u;
         }
-    const uint8_t *bnext = bbase + (size_t)(2 < n_stages ? 2 : n_stages - 1) * B_BYTES;
+    // (main loop: wave w < 4 moves pieces 4w .. 4w+3 of BOTH 16 KB weight tiles of a stage)
+    const uint8_t *bnext = p.wt + ((size_t)(2 * nt) * n_stages) * B_BYTES + (wave & 3) * 4096 + lane * 16 +
+                           (size_t)(2 < n_stages ? 2 : n_stages - 1) * B_BYTES;
+    const size_t btile = (size_t)n_stages * B_BYTES;   // from column tile 2 nt to 2 nt + 1
 
     constexpr int HALF = 64 * SROW;                    // row tiles 2,3 of the wave
     SetH AHt, AHb, BH;
@@ -733,22 +741,26 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                  // every B fragment of stage s is in registers; stage s+1 has landed
             // ---- step 3 ----
-            {
-                char *dst = Bbuf + bbuf + bdst;
+            if (wave < NI) {
+                char *dst = Bbuf + bbuf + (wave & 3) * 4096;
                 XV_GLDS16_OFF(bnext, dst, 0);
                 XV_GLDS16_OFF(bnext, dst, 1024);
                 XV_GLDS16_OFF(bnext, dst, 2048);
                 XV_GLDS16_OFF(bnext, dst, 3072);
-                bnext += (s + 3 < n_stages) ? B_BYTES : 0;
-            }
-            if constexpr (t < DT) {
+                XV_GLDS16_OFF(bnext + btile, dst + B_BYTES, 0);
+                XV_GLDS16_OFF(bnext + btile, dst + B_BYTES, 1024);
+                XV_GLDS16_OFF(bnext + btile, dst + B_BYTES, 2048);
+                XV_GLDS16_OFF(bnext + btile, dst + B_BYTES, 3072);
+                if constexpr (t < DT) {
 #pragma unroll
-                for (int j = 0; j < slots_of(t); ++j) XV_GLDS16(anext + ag_off[t][j], adst_n + al_off[t][j]);
+                    for (int j = 0; j < slots_of(t); ++j) XV_GLDS16(anext + ag_off[t][j], adst_n + al_off[t][j]);
+                }
             }
+            bnext += (s + 3 < n_stages) ? B_BYTES : 0;
             load_ax(AXb, px[t] + abuf + HALF);
             load_bh(BH, W_B_BYTES - bbuf);
             mma_x(AXt, BX, 0);
-            constexpr int NV = BP + slots_of(t);
+            constexpr int NV = 0;                       // (the DMA block above is a region of its own now)
 #define XV_G8W_GROUP(i)                                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      \
             if constexpr ((NV + 3 - (i)) / 4 > 0) __builtin_amdgcn_sched_group_barrier(0x020, (NV + 3 - (i)) / 4, 0); \
