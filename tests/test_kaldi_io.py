@@ -381,6 +381,16 @@ def test_in_place_windows_equal_the_record_reader(tmp_path):
                 holders.append(holder)
         assert [k for k, _ in got] == ["k%d" % i for i in range(300)], cap
         assert all(a.shape == b.shape and np.array_equal(a.astype(np.float32), b) for (_, a), b in zip(got, mats))
+    # a plain BytesIO is copied by the host library (no interpreter lock), any other stream through its readinto: same records,
+    # and the BytesIO is free again afterwards (its exported buffer is released: it can be written to and closed)
+    class Stream(io.BytesIO):
+        pass
+    for make in (io.BytesIO, Stream):
+        src = make(data)
+        keys2 = [k for item in kaldi_io.scan_mat_ark_windows(src, lambda: kaldi_io.ArkArena(20000)) for k in item[0]]
+        assert keys2 == ["k%d" % i for i in range(300)]
+        src.write(b"x")
+        src.close()
     with pytest.raises(Exception):
         list(kaldi_io.scan_mat_ark_windows(io.BytesIO(data[:-7]), lambda: kaldi_io.ArkArena(1 << 20)))
     f = io.BytesIO(data)

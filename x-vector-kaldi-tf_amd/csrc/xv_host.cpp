@@ -18,7 +18,12 @@
 
 extern "C" {
 
-int xv_host_version(void) { return 6; }
+int xv_host_version(void) { return 7; }
+
+// memcpy callable through ctypes, i.e. WITHOUT the interpreter lock: the in-place reader fills its arenas from an in-memory
+// stream (io.BytesIO) with it -- BytesIO.readinto copies under the lock, and 64 MB at a time stalls every other thread of the
+// extraction pipeline (model load, planning, packing) for milliseconds.
+void xv_copy_bytes(void *dst, const void *src, size_t n) { memcpy(dst, src, n); }
 
 // Scans buf[pos, len).  Fills up to max_records entries; returns the number of records found.
 // *next = offset of the first byte not consumed; *stop = 0 buffer exhausted / record incomplete (need more data),

@@ -636,6 +636,9 @@ def _host_lib():
                 lib.xv_ark_scan_fm.restype = ctypes.c_int
                 lib.xv_ark_scan_fm.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int] + \
                     [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+                if hasattr(lib, "xv_copy_bytes"):
+                    lib.xv_copy_bytes.restype = None
+                    lib.xv_copy_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
                 if hasattr(lib, "xv_ark_scan_fv"):
                     lib.xv_ark_scan_fv.restype = ctypes.c_int
                     lib.xv_ark_scan_fv.argtypes = lib.xv_ark_scan_fm.argtypes
@@ -896,6 +899,14 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None):
     assert lib is not None and hasattr(lib, "xv_ark_scan_fm"), "scan_mat_ark_windows needs libxvector_host.so"
     raw = open_or_fd(file_or_fd)
     readinto = getattr(raw, "readinto", None)
+    # An in-memory stream is copied by the host library, outside the interpreter lock (BytesIO.readinto holds it for the whole
+    # memcpy: the model load, the planner and the packer of the other threads would stand still meanwhile).
+    # (getvalue() hands out the stream's own bytes object; getbuffer() would first COPY a BytesIO that still shares the bytes it
+    # was built from -- 0.2 s for a 1.4 GB ark)
+    mem = mem_addr = None
+    if type(raw) is io.BytesIO and hasattr(lib, "xv_copy_bytes"):
+        mem = raw.getvalue()
+        mem_addr = np.frombuffer(mem, dtype=np.uint8).ctypes.data if len(mem) else None
     key_off = np.empty(_SCAN_MAX, np.int64); key_len = np.empty(_SCAN_MAX, np.int32)
     data_off = np.empty(_SCAN_MAX, np.int64); rows = np.empty(_SCAN_MAX, np.int32); cols = np.empty(_SCAN_MAX, np.int32)
     nxt, stop = ctypes.c_size_t(0), ctypes.c_int(0)
@@ -911,8 +922,14 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None):
             limit = cap if not fill else min(cap, max(int(fill), end + 64))
             fill = None if not fill or limit == cap else 2 * limit
             while end < limit and not eof and not spill:
-                if readinto is not None:
-                    # in slices: an in-memory stream copies under the interpreter lock, and 72 MB in one call would stall
+                if mem_addr is not None:
+                    at = raw.tell()
+                    got = min(limit - end, len(mem) - at)
+                    if got > 0:
+                        lib.xv_copy_bytes(arena.addr + end, mem_addr + at, got)
+                        raw.seek(at + got)
+                elif readinto is not None:
+                    # in slices: a stream object may copy under the interpreter lock, and 72 MB in one call would stall
                     # every other thread of the pipeline for ~15 ms
                     got = readinto(arena.view[end:min(limit, end + (4 << 20))])
                 else:
@@ -990,6 +1007,7 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None):
                     unread = len(carry)
             del arena
     finally:
+        mem = None
         if raw is not file_or_fd:
             raw.close()
         elif unread:
