@@ -640,6 +640,16 @@ class Extractor(object):
             self._copy_stream = torch.cuda.Stream(device=self.model.device)
         return self._stage
 
+    def _reserve_caps(self, bounds):
+        """Rows / chunks to size the device buffers for: the largest REGULAR batch from the first window on (as the pinned
+        staging sets above) -- growing them when a later window brings a larger batch is a hipMalloc of gigabytes in the
+        middle of the stream (50 ms per call when the first read window was a short one)."""
+        rows = max(r for _, _, r in bounds)
+        nch = max(b1 - b0 for b0, b1, _ in bounds)
+        rows = rows if rows <= 4096 else max(rows, self.max_batch_rows)
+        nch = nch if nch <= 64 else max(nch, min(self.max_batch_chunks, 8192))
+        return rows, nch
+
     def _pinned(self, kind, shape, dtype):
         """A pinned host tensor of ``shape`` from this extractor's free list (per-window buffers: the chunk table that goes up,
         the x-vectors that come down): one hipHostMalloc per window is a millisecond the pipeline has no use for."""
@@ -759,7 +769,7 @@ class Extractor(object):
             compute = torch.cuda.current_stream()
             E_all = torch.empty((nch, model.embed_dim), dtype=torch.float32, device=dev)
             P_all = torch.empty((nch, model.pooled_dim), dtype=torch.float32, device=dev)
-            model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), int(c_len.max()))
+            model.reserve(*self._reserve_caps(bounds), int(c_len.max()))
             keep = []                                   # device inputs stay referenced until the window is done
             status = torch.zeros(1, dtype=torch.int32, device=dev) if model.f16bf8 else None
             for bi, (b0, b1, _) in enumerate(bounds):
@@ -879,7 +889,7 @@ class Extractor(object):
             compute = torch.cuda.current_stream()
             E_all = torch.empty((nch, model.embed_dim), dtype=torch.float32, device=dev)
             P_all = torch.empty((nch, model.pooled_dim), dtype=torch.float32, device=dev)
-            model.reserve(max(r for _, _, r in bounds), max(b1 - b0 for b0, b1, _ in bounds), int(c_len.max()))
+            model.reserve(*self._reserve_caps(bounds), int(c_len.max()))
             keep = []
             status = torch.zeros(1, dtype=torch.int32, device=dev) if model.f16bf8 else None
             for (b0, b1, _), (lo, hi) in zip(bounds, spans):
