@@ -201,6 +201,18 @@ class _ColumnView(object):
         return self.weights[name][self.cols]
 
 
+class _Layer(dict):
+    """Parameters of one layer in kernel layout.  ``wp`` (the bf16x3 / fp32 packing of the weights) may be deferred: an
+    f16bf8 model runs its frame-level layers from other packings (first-layer, f16bf8, pair kernels) and only the debug
+    helpers ever ask for it -- uploading and packing 17 MB for nothing was a third of the model load."""
+
+    def __missing__(self, key):
+        if key == "wp" and "_make_wp" in self:
+            self["wp"] = dict.pop(self, "_make_wp")()
+            return self["wp"]
+        raise KeyError(key)
+
+
 class DeviceModel(object):
     """Weights of one model directory resident in HBM in kernel layout, plus reusable activation
     buffers.  ``weights`` is keyed by the TF variable names (weights.py)."""
@@ -251,6 +263,7 @@ class DeviceModel(object):
         # zero, matching zero weight rows) so that layer 0 takes the 16-byte vector staging path
         self.in_dim = (self.feat_dim + 3) // 4 * 4
         self.layers = []
+        self._uploaded = {}
         with torch.cuda.device(self.device):
             for i, (k, d) in enumerate(zip(topo["kernel_sizes"], topo["dilations"])):
                 sc = "frame_level_info_layer-%d" % i
@@ -260,7 +273,7 @@ class DeviceModel(object):
                     wpad = np.zeros((k, self.in_dim, w.shape[2]), np.float32)
                     wpad[:, :self.feat_dim] = w
                     w = wpad
-                self.layers.append(self._prep(weights, sc, w, k, d))
+                self.layers.append(self._prep(weights, sc, w, k, d, defer_wp=self.f16bf8))
             if self.attention:
                 # models.py:1036-1046: h = [h1 | h2]; u = h1 . attention/w + attention/b is one more K=1 layer.  On the
                 # bf16x3 path the last frame-level layer runs as two launches over the two column halves of its weights so
@@ -293,29 +306,30 @@ class DeviceModel(object):
                 La, Lb = self.layers[-2], self.layers[-1]
                 if La["K"] == 1 and Lb["K"] == 1 and hiplib.pair_supported(La["cin"], La["cout"], Lb["cout"]):
                     n = len(self.layers)
-                    wa = weights["frame_level_info_layer-%d/w:0" % (n - 2)][0]
-                    wb = weights["frame_level_info_layer-%d/w:0" % (n - 1)][0]
-                    self.pair = hiplib.pack_pair_bf16x3(self._dev(wa), self._dev(wb))
+                    wa = self._wdev(weights, "frame_level_info_layer-%d/w:0" % (n - 2))[0]
+                    wb = self._wdev(weights, "frame_level_info_layer-%d/w:0" % (n - 1))[0]
+                    self.pair = hiplib.pack_pair_bf16x3(wa, wb)
             assert not (pair_kernel and self.pair is None), "pair_kernel=True but the topology / precision does not allow it"
             self.pair8 = None
             if self.f16bf8 and self.pair is not None and os.environ.get("XVECTOR_PAIR8_KERNEL", "1") != "0":
                 La, Lb = self.layers[-2], self.layers[-1]
                 if hiplib.pair8_supported(La["cin"], La["cout"], Lb["cout"]):
                     n = len(self.layers)
-                    self.pair8 = hiplib.pack_pair_f16bf8(self._dev(weights["frame_level_info_layer-%d/w:0" % (n - 2)][0]),
-                                                         self._dev(weights["frame_level_info_layer-%d/w:0" % (n - 1)][0]))
+                    self.pair8 = hiplib.pack_pair_f16bf8(self._wdev(weights, "frame_level_info_layer-%d/w:0" % (n - 2))[0],
+                                                         self._wdev(weights, "frame_level_info_layer-%d/w:0" % (n - 1))[0])
             if self.f16bf8:
                 assert self.first is not None
                 n = len(self.layers)
                 for i in range(1, n - 2 if self.pair is not None else n):
                     sc = "frame_level_info_layer-%d" % i
-                    self.layers[i]["wp8"] = hiplib.pack_weights_f16bf8(self._dev(weights[sc + "/w:0"]))
+                    self.layers[i]["wp8"] = hiplib.pack_weights_f16bf8(self._wdev(weights, sc + "/w:0"))
                 self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.embed = []
             for j in range(len(topo["embedding_sizes"])):
                 sc = "embed_layer-%d" % j
                 self.embed.append(self._prep(weights, sc, weights[sc + "/w:0"][None, :, :], 1, 1))
             torch.cuda.synchronize()
+        self._uploaded = {}                             # (the packings are what stays; the plain copies go)
         self.pooled_dim = tp.pooled_dim(topo)
         self.embed_dim = self.embed[self.embedding_index]["cout"]
         self._cap_rows = 0
@@ -333,15 +347,25 @@ class DeviceModel(object):
     def _dev(self, a):
         return self.torch.as_tensor(np.array(a, dtype=np.float32, order="C")).to(self.device)     # copy: sources may be read-only
 
-    def _prep(self, weights, scope, w3d, k, d, cols=slice(None)):
-        """Kernel-layout parameters of one layer (``cols``: only these output channels)."""
+    def _wdev(self, weights, key):
+        """The array ``weights[key]`` on the device, uploaded once per model (several packings read the same weights)."""
+        if key not in self._uploaded:
+            self._uploaded[key] = self._dev(weights[key])
+        return self._uploaded[key]
+
+    def _prep(self, weights, scope, w3d, k, d, cols=slice(None), defer_wp=False):
+        """Kernel-layout parameters of one layer (``cols``: only these output channels; ``defer_wp``: see _Layer)."""
         w3d = w3d[:, :, cols]
         weights = _ColumnView(weights, cols)
-        layer = dict(K=k, dil=d, cin=w3d.shape[1], cout=w3d.shape[2])
+        layer = _Layer(K=k, dil=d, cin=w3d.shape[1], cout=w3d.shape[2])
         if self.precision == "bf16x3":
-            layer["wp"] = hiplib.pack_weights_bf16x3(self._dev(w3d))                  # tiled hi/lo bf16
+            make = lambda: hiplib.pack_weights_bf16x3(self._dev(w3d))                 # tiled hi/lo bf16
         else:
-            layer["wp"] = hiplib.pack_weights(self._dev(w3d.reshape(-1, w3d.shape[2])))
+            make = lambda: hiplib.pack_weights(self._dev(w3d.reshape(-1, w3d.shape[2])))
+        if defer_wp:
+            layer["_make_wp"] = make
+        else:
+            layer["wp"] = make()
         layer["bias"] = self._dev(weights[scope + "/b:0"])
         layer["scale"], layer["shift"] = hiplib.fold_bn(*(self._dev(weights["%s/%s:0" % (scope, n)])
                                                           for n in ("gamma", "beta", "mean", "variance")),
