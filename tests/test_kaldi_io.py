@@ -415,3 +415,60 @@ def test_in_place_windows_equal_the_record_reader(tmp_path):
     want = [i for i in range(120) if i != 57]
     assert [k for k, _ in got] == ["k%d" % i for i in want]
     assert all(np.array_equal(a.astype(np.float32), mats[i]) for (_, a), i in zip(got, want))
+
+
+def test_mapped_ark_windows_equal_the_record_reader(tmp_path):
+    """map_stream + scan_mat_ark_mapped: an ark that is already in memory (a BytesIO) is scanned where it lies -- same keys and
+    matrices as the record reader, whatever the window size; a record the native scanner does not take (a double matrix) and
+    a truncated tail go through the generic reader; files and pipes are not mapped (they are read into the arenas); the
+    BytesIO stays usable (nothing of it is exported)."""
+    if kaldi_io._host_lib() is None:
+        pytest.skip("host library not built")
+    rng = np.random.default_rng(1)
+    bio = io.BytesIO()
+    mats = []
+    for i in range(300):
+        T, F = int(rng.integers(0, 60)), (23 if i < 250 else 5)
+        m = rng.standard_normal((T, F)).astype(np.float32)
+        kaldi_io.write_mat(bio, m.astype(np.float64) if i == 100 else m, key="k%d" % i)
+        mats.append(m)
+    data = bio.getvalue()
+    path = str(tmp_path / "f.ark")
+    open(path, "wb").write(data)
+
+    def collect(arr, window, first):
+        got = []
+        for keys, addr, rows, cols, holder in kaldi_io.scan_mat_ark_mapped(arr, window, first):
+            am = kaldi_io.ArkMats()
+            am.add(addr, rows, cols, holder)
+            assert len(am) == len(keys) and am.uniform_cols() == cols
+            got += [(k, np.array(am[j])) for j, k in enumerate(keys)]
+        return got
+
+    for window, first in ((1 << 20, None), (20000, 3000), (700, None), (64, None)):
+        for src in (io.BytesIO(data),):
+            arr = kaldi_io.map_stream(src)
+            assert arr is not None and arr.shape[0] == len(data) and not arr.flags.writeable
+            got = collect(arr, window, first)
+            assert [k for k, _ in got] == ["k%d" % i for i in range(300)], (window, type(src))
+            assert all(a.shape == b.shape and np.array_equal(a.astype(np.float32), b) for (_, a), b in zip(got, mats))
+            assert src.read(1) == b""                                # the stream is consumed
+            src.write(b"x")                                          # (no export pins the stream's buffer)
+            del arr, got
+            src.close()
+    # from the current position only
+    f = io.BytesIO(data)
+    first_key, first_mat = next(iter(kaldi_io.read_mat_ark(f)))      # (the record reader hands back its read-ahead)
+    assert first_key == "k0"
+    rest = collect(kaldi_io.map_stream(f), 5000, None)
+    assert [k for k, _ in rest] == ["k%d" % i for i in range(1, 300)]
+    # truncated tail: everything before it comes out, then the generic reader raises
+    with pytest.raises(Exception):
+        collect(kaldi_io.map_stream(io.BytesIO(data[:-7])), 1 << 20, None)
+    # not mapped: a regular file, a pipe
+    with open(path, "rb") as f:
+        assert kaldi_io.map_stream(f) is None and f.tell() == 0
+    fd = kaldi_io.open_or_fd("cat %s |" % path)
+    assert kaldi_io.map_stream(fd) is None
+    assert len(fd.read()) == len(data)
+    fd.close()

@@ -23,6 +23,7 @@ method raises.  ``use_gpu`` is accepted for signature compatibility (the referen
 passes ``--use-gpu=no``, extract_xvectors.sh:76,85) and ignored: the extractor always runs on the GPU
 selected by ``XVECTOR_DEVICE`` / ``LOCAL_RANK`` (default ``cuda:0``).
 """
+import io
 import os
 import sys
 import time
@@ -89,6 +90,7 @@ class Model(object):
     # cost 7 % end to end (tools/arena_sweep.py).  64 MB = ~2300 utterances of 300 frames = three even batches.
     arena_bytes = 64 << 20
     first_arena_bytes = 64 << 20
+    map_input = os.environ.get("XVECTOR_MAP_INPUT", "1") != "0"      # BytesIO / regular-file input: scan in place instead of reading
     arena_count = 4                  # read arenas in rotation (one being filled, two queued, one being packed)
     max_batch_rows = 262144
 
@@ -380,8 +382,17 @@ class Model(object):
                     without the host library, one matrix at a time for (key, matrix) iterators."""
                     first = int(self.first_arena_bytes)
                     if in_place:
-                        source = kaldi_io.scan_mat_ark_windows(input_stream, take_arena, first) if hasattr(input_stream, "read") \
-                            else input_stream.windows(take_arena, first)
+                        # an ark that already sits in memory (a BytesIO, a regular file through the page cache) is not read at
+                        # all: the scanner walks the mapping and the packer takes the rows from there
+                        mapped = kaldi_io.map_stream(input_stream) if (hasattr(input_stream, "read") and self.map_input) else None
+                        if mapped is not None:
+                            source = kaldi_io.scan_mat_ark_mapped(
+                                mapped, arena_bytes, first,
+                                fallback=lambda rest: kaldi_io.scan_mat_ark_windows(io.BytesIO(rest.tobytes()), take_arena))
+                        elif hasattr(input_stream, "read"):
+                            source = kaldi_io.scan_mat_ark_windows(input_stream, take_arena, first)
+                        else:
+                            source = input_stream.windows(take_arena, first)
                         for item in source:
                             yield item
                     elif hasattr(input_stream, "read") or hasattr(input_stream, "blocks"):
