@@ -200,10 +200,13 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
         Mx[set] = cat(*reinterpret_cast<const xv_i32x4 *>(b + 2048), *reinterpret_cast<const xv_i32x4 *>(b + 3072));
     };
     auto next_slot = [](int slot) { return slot + P8_STAGE == P8_RING * P8_STAGE ? 0 : slot + P8_STAGE; };
-    // B(s), between steps 2 and 3 of stage s: this wave's fragment reads of stage s are complete (the fragments of its last unit
-    // are in registers), and so are its DMA pieces of stage s+2 (and the frames issued with them): only the 4 pieces of stage
-    // s+3... no: of the refill in progress (piece 0 issued behind B(s-1), pieces 1-3 in steps 0-2 of this stage) may still be in
-    // flight.  After the barrier the same holds for every wave; the slot of stage s is refilled from here on.
+    // B(s), between steps 2 and 3 of stage s.  Before it this wave waits until (a) its fragment reads of stage s are complete
+    // -- the fragments of the stage's last unit are in registers -- and (b) at most 4 of its vector-memory operations are in
+    // flight.  The newest operations are the refill in progress (stage s+2: piece 0 issued behind B(s-1), pieces 1-3 in steps
+    // 0-2 of this stage) and, between them, statistics stores; loads complete in order, so a piece of the refill before
+    // (stage s+1) still in flight would put at least five operations in flight: (b) implies that stage s+1 and the frames issued
+    // with it have landed (stores in the count only make the wait stricter).  After the barrier the same holds for every
+    // wave, and the slot of stage s is refilled from here on.
     auto stage_barrier = [&]() {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
