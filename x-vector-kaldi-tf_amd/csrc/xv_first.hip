@@ -11,9 +11,9 @@
 //     brought into LDS by DMA once per pass and re-used for a strip of 4 x 128 frames; four passes cover 512 channels, and two
 //     workgroups share a CU, so one computes while the other waits for its weights;
 //   * the product is formed transposed (A = weight fragment, B = frames) on v_mfma_f32_16x16x32_bf16, so that a lane holds 4
-//     consecutive channels of one frame per tile; one cross-lane exchange per tile pair makes that 8 consecutive channels --
-//     exactly one 16-byte hi slot and one 16-byte lo slot of the split format -- and the epilogue (bias, activation, BN,
-//     gap-row mask, hi/lo split) stores them with non-temporal 16-byte stores, no LDS round trip.
+//     rows of one frame per tile; the packed weights order the rows of a tile PAIR so that a lane's 4 + 4 rows are 8 consecutive
+//     channels -- exactly one 16-byte hi slot and one 16-byte lo slot of the split format, no cross-lane exchange -- and the
+//     epilogue (bias, activation, BN, gap-row mask, hi/lo split) stores them with non-temporal 16-byte stores, no LDS round trip.
 // Arithmetic: bf16x3 as everywhere (hi*hi + hi*lo + lo*hi, fp32 accumulate).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -167,15 +167,12 @@ __global__ __launch_bounds__(FR_WAVES * 64, 4) void tdnn_first_kernel(const Firs
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xh[u], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xh[u], acc1, 0, 0, 0);
                 }
-                // lane (frame f, group G) holds channels 4G..4G+3 of both tiles.  Even groups finish tile 0 (channels
-                // 4G..4G+7: their own + the odd partner's), odd groups tile 1 (channels 4(G-1)..4(G-1)+7).
-                const bool odd = G & 1;
-                f32x4 send = odd ? acc0 : acc1, got;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) got[e] = __shfl_xor(send[e], 16, 64);
-                const f32x4 lo4 = odd ? got : acc0;               // channels cb .. cb+3
-                const f32x4 hi4 = odd ? acc1 : got;               // channels cb+4 .. cb+7
-                const int cb = pass * FR_PASS_COLS + tp * 32 + (odd ? 16 + 4 * (G - 1) : 4 * G);
+                // lane (frame f, group G) holds rows 4G..4G+3 of both tiles; the packed weights order the rows of a tile pair so
+                // that these are channels 8G..8G+3 (tile 0) and 8G+4..8G+7 (tile 1) of the pair's 32: one 16-byte slot of the
+                // output format per lane, with no exchange between lanes
+                const f32x4 lo4 = acc0;                           // channels cb .. cb+3
+                const f32x4 hi4 = acc1;                           // channels cb+4 .. cb+7
+                const int cb = pass * FR_PASS_COLS + tp * 32 + 8 * G;
                 const int c4 = cb >> 2;
                 const f32x4 b0 = P4[c4], b1 = P4[c4 + 1], s0 = P4[FR_MAX_COUT / 4 + c4], s1 = P4[FR_MAX_COUT / 4 + c4 + 1],
                             o0 = P4[2 * FR_MAX_COUT / 4 + c4], o1 = P4[2 * FR_MAX_COUT / 4 + c4 + 1],
@@ -217,7 +214,9 @@ __global__ __launch_bounds__(FR_WAVES * 64, 4) void tdnn_first_kernel(const Firs
 }
 
 // w[K][cin][cout] (TF order) -> per pass of FR_PASS_COLS output channels: [tile][k-step 0..3][hi 1 KB | lo 1 KB], fragment
-// element (lane (i, g), e) = w[tap][c][pass*FR_PASS_COLS + 16*tile + i] with k = 32u + 8g + e = tap*kc + c (zero beyond K*kc / cin)
+// element (lane (i, g), e) = w[tap][c][col] with k = 32u + 8g + e = tap*kc + c (zero beyond K*kc / cin); row i of tile 2p + t is
+// column col = pass*FR_PASS_COLS + 32p + 8(i>>2) + 4t + (i&3): the accumulator rows 4G..4G+3 of the pair's two tiles are the
+// consecutive channels 8G..8G+7 (see the kernel's epilogue)
 __global__ void pack_first_kernel(const float *__restrict__ w, int K, int cin, int kc, int cout, uint8_t *__restrict__ wt, size_t total)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one (pass, tile, k-step, lane, e)
@@ -230,7 +229,8 @@ __global__ void pack_first_kernel(const float *__restrict__ w, int K, int cin, i
     const int pass = (int)(i / (size_t)(512 * FR_NKS * TILES));
     const int k = 32 * u + 8 * (lane >> 4) + e;
     const int tap = k / kc, c = k - tap * kc;
-    const int col = pass * FR_PASS_COLS + 16 * tile + (lane & 15);
+    const int i_row = lane & 15;
+    const int col = pass * FR_PASS_COLS + 32 * (tile >> 1) + 8 * (i_row >> 2) + 4 * (tile & 1) + (i_row & 3);
     const float x = (tap < K && c < cin && col < cout) ? w[((size_t)tap * cin + c) * cout + col] : 0.f;
     const __bf16 hi = (__bf16)x;
     const __bf16 lo = (__bf16)(x - (float)hi);
