@@ -40,12 +40,18 @@ __device__ __forceinline__ void xv_split8_encode8(const float (&v)[8], xv_f16x8 
         amax = fmaxf(amax, fabsf(v[i]));
         c[i] = __builtin_amdgcn_fmed3f(v[i], -XV_SPLIT8_MAX, XV_SPLIT8_MAX);
         hi[i] = (_Float16)c[i];
-        lo[i] = (c[i] - (float)hi[i]) * XV_SPLIT8_LO_SCALE;
+        lo[i] = c[i] - (float)hi[i];
     }
-    int l0 = __builtin_amdgcn_cvt_pk_bf8_f32(lo[0], lo[1], 0, false);
-    l0 = __builtin_amdgcn_cvt_pk_bf8_f32(lo[2], lo[3], l0, true);
-    int l1 = __builtin_amdgcn_cvt_pk_bf8_f32(lo[4], lo[5], 0, false);
-    l1 = __builtin_amdgcn_cvt_pk_bf8_f32(lo[6], lo[7], l1, true);
+    // the "* 2^11" rides on the conversion: v_cvt_scalef32_pk_bf8_f32 converts x / scale, bit for bit what v_cvt_pk_bf8_f32 gives
+    // for x * 2^11 when scale = 2^-11 (tools/experiments/cvt_scale_probe.hip) -- one VALU instruction per value less
+    typedef short xv_s16x2 __attribute__((ext_vector_type(2)));
+    constexpr float inv = 1.f / XV_SPLIT8_LO_SCALE;
+    xv_s16x2 t0 = {0, 0}, t1 = {0, 0};
+    t0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t0, lo[0], lo[1], inv, false);
+    t0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t0, lo[2], lo[3], inv, true);
+    t1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t1, lo[4], lo[5], inv, false);
+    t1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t1, lo[6], lo[7], inv, true);
+    const int l0 = __builtin_bit_cast(int, t0), l1 = __builtin_bit_cast(int, t1);
     int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], 0, false);
     h0 = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], h0, true);
     int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(c[4], c[5], 0, false);
