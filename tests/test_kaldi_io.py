@@ -417,6 +417,54 @@ def test_in_place_windows_equal_the_record_reader(tmp_path):
     assert all(np.array_equal(a.astype(np.float32), mats[i]) for (_, a), i in zip(got, want))
 
 
+def test_every_arena_taken_comes_back(tmp_path):
+    """The in-place readers account for every arena they take: it is either the holder of exactly one item (the consumer
+    recycles it) or handed to ``release`` -- an arena that held only the carried bytes of an oversized record, and the arena of
+    an scp run whose first key does not match the table.  With a bounded pool a lost arena is a reader that blocks forever."""
+    import io
+    if kaldi_io._host_lib() is None:
+        pytest.skip("host library not built")
+    rng = np.random.default_rng(5)
+    mats = [rng.standard_normal((int(rng.integers(1, 40)), 23)).astype(np.float32) for _ in range(80)]
+    mats[10] = rng.standard_normal((400, 23)).astype(np.float32)            # larger than an arena: generic reader, carried bytes
+    bio = io.BytesIO()
+    for i, m in enumerate(mats):
+        kaldi_io.write_mat(bio, m, key="k%d" % i)
+    taken, released, held = [], [], []
+
+    def take():
+        taken.append(kaldi_io.ArkArena(9000))
+        return taken[-1]
+    keys = []
+    for k, addr, rows, cols, holder in kaldi_io.scan_mat_ark_windows(io.BytesIO(bio.getvalue()), take, None, released.append):
+        keys += k
+        if isinstance(holder, kaldi_io.ArkArena):
+            held.append(holder)
+    assert keys == ["k%d" % i for i in range(80)]
+    assert sorted(map(id, taken)) == sorted(map(id, held + released)) and len(set(map(id, taken))) == len(taken)
+    # scp whose keys alternate between the ark's and renamed ones: every miss gives its arena back, and after two short runs
+    # the table is read entry by entry (no further arena is taken)
+    ark, scp = str(tmp_path / "f.ark"), str(tmp_path / "f.scp")
+    with kaldi_io.TableWriter(ark, scp) as tw:
+        for i, m in enumerate(mats):
+            kaldi_io.write_mat(tw, m, key="k%d" % i)
+    lines = open(scp).read().splitlines()
+    renamed = str(tmp_path / "renamed.scp")
+    open(renamed, "wt").write("\n".join(("x" + l) if i % 2 else l for i, l in enumerate(lines)) + "\n")
+    del taken[:], released[:], held[:]
+    got = []
+    for k, addr, rows, cols, holder in kaldi_io.MatScp(renamed).windows(take, None, released.append):
+        am = kaldi_io.ArkMats()
+        am.add(addr, rows, cols, holder)
+        got += [(kk, np.array(am[j])) for j, kk in enumerate(k)]
+        if isinstance(holder, kaldi_io.ArkArena):
+            held.append(holder)
+    assert [k for k, _ in got] == [("x" if i % 2 else "") + "k%d" % i for i in range(80)]
+    assert all(np.array_equal(a, m) for (_, a), m in zip(got, mats))
+    assert sorted(map(id, taken)) == sorted(map(id, held + released))
+    assert len(taken) <= 6, "a table that does not follow its ark must stop taking arenas (took %d)" % len(taken)
+
+
 def test_mapped_ark_windows_equal_the_record_reader(tmp_path):
     """map_stream + scan_mat_ark_mapped: an ark that is already in memory (a BytesIO) is scanned where it lies -- same keys and
     matrices as the record reader, whatever the window size; a record the native scanner does not take (a double matrix) and

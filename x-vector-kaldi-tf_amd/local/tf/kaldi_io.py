@@ -984,14 +984,16 @@ def scan_mat_ark_mapped(arr, window_bytes, first_bytes=None, fallback=None):
             win = int(window_bytes)
 
 
-def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None):
+def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
     """The in-place form of ``read_mat_ark_blocks``: generator of ``(keys, addr[n] uint64, rows[n] int32, cols, holder)``.
     The stream is read (``readinto``) into arenas that ``take_arena()`` hands out (``ArkArena``; the caller recycles them once it
     is done with the window), the native scanner locates the binary float-matrix records, and NOTHING is copied: ``addr[i]``
     is where row 0 of utterance i lies inside ``holder`` (the arena).  One item per arena and column count; the bytes of a
     record cut off by the arena's end are carried to the front of the next arena.  ``first_fill``: bytes to read into the first
     arena (then doubling): a consumer pipeline starts sooner on a short first window.  Records of any other type are decoded
-    by the generic reader and come out one at a time with ``holder`` = their own float32 array.  Needs the host library."""
+    by the generic reader and come out one at a time with ``holder`` = their own float32 array.  ``release(arena)``: called for
+    an arena that was taken but became the holder of no item (it held nothing but the carried bytes of a record that went
+    through the generic reader) -- the consumer never sees such an arena, so it cannot recycle it.  Needs the host library."""
     lib = _host_lib()
     assert lib is not None and hasattr(lib, "xv_ark_scan_fm"), "scan_mat_ark_windows needs libxvector_host.so"
     raw = open_or_fd(file_or_fd)
@@ -1008,8 +1010,10 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None):
     data_off = np.empty(_SCAN_MAX, np.int64); rows = np.empty(_SCAN_MAX, np.int32); cols = np.empty(_SCAN_MAX, np.int32)
     nxt, stop = ctypes.c_size_t(0), ctypes.c_int(0)
     carry, eof, unread, fill = b"", False, 0, first_fill
+    arena, handed = None, [False]
     try:
         while carry or not eof:
+            handed = [False]
             arena = take_arena()
             cap = len(arena)
             end = min(len(carry), cap)
@@ -1041,9 +1045,7 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None):
             pos = 0
             keys, a_parts, r_parts, c_now = [], [], [], None
 
-            handed = [False]
-
-            def flush():
+            def flush(handed=handed):
                 """The records collected so far as one item.  An arena is the holder of exactly ONE item (its consumer recycles
                 it); the records of a further item of the same arena -- the column count changed inside it -- are copied out."""
                 if not keys:
@@ -1102,9 +1104,13 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None):
                 else:
                     carry = rest                                 # an incomplete record: goes to the front of the next arena
                     unread = len(carry)
-            del arena
+            if not handed[0] and release is not None:
+                release(arena)                                   # nobody downstream holds it: back to the pool from here
+            arena = None
     finally:
         mem = None
+        if arena is not None and not handed[0] and release is not None:
+            release(arena)                                       # (an error while this arena was being read or scanned)
         if raw is not file_or_fd:
             raw.close()
         elif unread:
@@ -1225,15 +1231,18 @@ class MatScp(_ScpTable):
     """Feature table: ``(key, float32 [T, F])`` / blocks ``(keys, feats[sum T, F], offsets)`` / in-place windows."""
     _ark_blocks = staticmethod(read_mat_ark_blocks)
 
-    def windows(self, take_arena, first_fill=None):
+    def windows(self, take_arena, first_fill=None, release=None):
         """``scan_mat_ark_windows`` over the table: runs of entries that follow their ark are read in place, every key is
-        checked against the table; entries that do not (subsets, shuffled lists, pipes) are read one by one."""
+        checked against the table; entries that do not (subsets, shuffled lists, pipes) are read one by one.  ``release(arena)``
+        takes back an arena none of whose records matched the table (the consumer never sees it).  Once two runs in a row ended
+        after a handful of records the table is taken not to follow its arks and is read entry by entry from there on -- a
+        table that alternates between matching and renamed keys would otherwise read a full arena per miss."""
         ents, n, i = self.entries, len(self.entries), 0
-        misses = 0
+        misses, tripped = 0, False
         while i < n:
             key, rx = ents[i]
             m = _RX_OFFSET.match(rx)
-            if m is None or rx.endswith("|") or misses >= 2 or _host_lib() is None:
+            if m is None or rx.endswith("|") or tripped or _host_lib() is None:
                 mat = self._one(rx)
                 yield [key], np.array([mat.__array_interface__["data"][0]], np.uint64), np.array([mat.shape[0]], np.int32), \
                     mat.shape[1], mat
@@ -1246,7 +1255,17 @@ class MatScp(_ScpTable):
             got = 0
             with open(path, "rb") as f:
                 f.seek(start)
-                for bkeys, addr, rows, cols, holder in scan_mat_ark_windows(f, take_arena, first_fill if i == 0 else None):
+                source = scan_mat_ark_windows(f, take_arena, first_fill if i == 0 else None, release)
+                while True:
+                    try:
+                        bkeys, addr, rows, cols, holder = next(source)
+                    except StopIteration:
+                        break
+                    except (AssertionError, UnicodeDecodeError, UnknownMatrixHeader, BadInputFormat, BadSampleSize, ValueError,
+                            struct.error):
+                        # ``start`` is a guess (the entry's offset minus the length of the TABLE's key): with a renamed key it
+                        # points into the previous record and the scanner reads garbage -- a miss, not an error
+                        break
                     want = [k for k, _ in ents[i:min(i + len(bkeys), run)]]
                     same = 0
                     while same < len(want) and bkeys[same] == want[same]:
@@ -1255,9 +1274,13 @@ class MatScp(_ScpTable):
                         yield bkeys[:same], addr[:same], rows[:same], cols, holder
                         i += same
                         got += same
+                    elif release is not None and isinstance(holder, ArkArena):
+                        release(holder)                                                # nothing of it goes downstream
                     if same < len(bkeys) or i >= run:
                         break
+                source.close()
             misses = misses + 1 if got < 4 and i < run else 0
+            tripped = tripped or misses >= 2
             if got == 0:                                                               # not even the first key matched
                 mat = self._one(rx)
                 yield [key], np.array([mat.__array_interface__["data"][0]], np.uint64), np.array([mat.shape[0]], np.int32), \

@@ -47,24 +47,7 @@ def _device():
     return "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
 
 
-class _Subset(object):
-    """Utterances ``idx`` of a window: a sequence with the ``lengths`` / ``addrs`` arrays the extractor plans and packs from;
-    a matrix is only materialised when somebody indexes it."""
-
-    def __init__(self, mats, idx, lens, addrs):
-        self.mats, self.idx = mats, np.asarray(idx, np.int64)
-        self.lengths = np.asarray(lens, np.int64)[self.idx]
-        self.addrs = None if addrs is None else np.asarray(addrs, np.uint64)[self.idx]
-
-    def __len__(self):
-        return len(self.idx)
-
-    def __getitem__(self, i):
-        return self.mats[int(self.idx[i])]
-
-    def __iter__(self):
-        for i in self.idx.tolist():
-            yield self.mats[i]
+_Subset = engine._Rows          # utterances idx of a window, not materialised (multi-GPU shares of a stream window)
 
 
 class _Cancelled(Exception):
@@ -91,7 +74,10 @@ class Model(object):
     arena_bytes = 64 << 20
     first_arena_bytes = 64 << 20
     map_input = os.environ.get("XVECTOR_MAP_INPUT", "1") != "0"      # BytesIO / regular-file input: scan in place instead of reading
-    arena_count = 4                  # read arenas in rotation (one being filled, two queued, one being packed)
+    # read arenas in rotation: one with the reader (being filled or waiting for room in the queue), two queued, one being
+    # packed, one whose window is still in flight -- an arena goes back to the pool only when its window has been COLLECTED: an
+    # f16bf8 window whose status word comes back set is packed a second time from the same addresses (Extractor.finish)
+    arena_count = 5
     max_batch_rows = 262144
 
     def __init__(self):
@@ -140,9 +126,17 @@ class Model(object):
         # GEMM arithmetic: "f16bf8" (default: hidden layers as fp16 MFMA + scaled bf8 MFMA of the cross terms, ~1e-5 rel-L2;
         # topologies it does not cover and out-of-range windows run as bf16x3), "bf16x3" (split-precision bf16 MFMA, ~5e-6)
         # or "fp32" (exact fp32 MFMA)
+        # The arithmetic is chosen PER CHECKPOINT: engine.select_model runs a small fixed batch through the loaded weights in
+        # the requested arithmetic and in the next more exact one and steps down (f16bf8 -> bf16x3 -> fp32) when they disagree by
+        # more than the probe limits (2e-5 / 4e-5; the parity bar is 1e-4).  XVECTOR_ACCURACY_PROBE=0 takes the request as given.
         self.precision = os.environ.get("XVECTOR_PRECISION", "f16bf8")
-        self.device_model = engine.DeviceModel(w, meta["topology"], _device(), self.embedding_index, self.precision)
+        self.device_model = engine.select_model(w, meta["topology"], _device(), self.embedding_index, self.precision)
+        sel = getattr(self.device_model, "selection", None) or {}
         if logger is not None:
+            if sel.get("probed"):
+                logger.info("GEMM arithmetic: %s (requested %s; accuracy probe: f16bf8 vs bf16x3 %.2e%s)" % (
+                    sel["selected"], sel["requested"], sel["f16bf8_vs_bf16x3"],
+                    ", bf16x3 vs fp32 %.2e" % sel["bf16x3_vs_fp32"] if "bf16x3_vs_fp32" in sel else ""))
             logger.info("Graph restored from path: %s" % input_dir)
 
     def create_one_hot_output_matrix(self, labels):          # models.py:164-169
@@ -346,7 +340,12 @@ class Model(object):
             if len(mine) < self.arena_count and pool.empty():
                 mine.append(kaldi_io.arena_acquire(arena_bytes))
                 return mine[-1]
-            return pool.get()
+            while True:
+                try:
+                    return pool.get(timeout=0.2)
+                except queue.Empty:
+                    if cancel.is_set():           # the consumer gave up: nobody will ever return an arena
+                        raise _Cancelled()
 
         def reader():
             try:
@@ -388,11 +387,11 @@ class Model(object):
                         if mapped is not None:
                             source = kaldi_io.scan_mat_ark_mapped(
                                 mapped, arena_bytes, first,
-                                fallback=lambda rest: kaldi_io.scan_mat_ark_windows(io.BytesIO(rest.tobytes()), take_arena))
+                                fallback=lambda rest: kaldi_io.scan_mat_ark_windows(io.BytesIO(rest.tobytes()), take_arena, None, pool.put))
                         elif hasattr(input_stream, "read"):
-                            source = kaldi_io.scan_mat_ark_windows(input_stream, take_arena, first)
+                            source = kaldi_io.scan_mat_ark_windows(input_stream, take_arena, first, pool.put)
                         else:
-                            source = input_stream.windows(take_arena, first)
+                            source = input_stream.windows(take_arena, first, pool.put)
                         for item in source:
                             yield item
                     elif hasattr(input_stream, "read") or hasattr(input_stream, "blocks"):
@@ -589,15 +588,19 @@ class Model(object):
                 addrs = mats.addrs if mats.uniform_cols() == F_dim else None
                 total_segments += len(keys)
                 nxt = submit(keys, mats, vads, addrs)
-                for held in mats.holders:
-                    if isinstance(held, kaldi_io.ArkArena):
-                        pool.put(held)                      # every batch of the window is packed: the reader may refill it
+                # the window's arenas stay out of the pool until its vectors are down: finish() may have to pack the window
+                # again (out-of-range f16bf8 window -> bf16x3 twin), and it does so from the raw addresses
+                arenas = [held for held in mats.holders if isinstance(held, kaldi_io.ArkArena)]
                 del mats, item
                 if in_flight is not None:
-                    collect(*in_flight)
-                in_flight = nxt
+                    collect(*in_flight[0])
+                    for held in in_flight[1]:
+                        pool.put(held)
+                in_flight = (nxt, arenas)
             if in_flight is not None:
-                collect(*in_flight)
+                collect(*in_flight[0])
+                for held in in_flight[1]:
+                    pool.put(held)
             if world > 1:
                 self._exchange_shards(stash, rank, world, min_chunk_size, chunk_size, emit)
         finally:
@@ -611,6 +614,12 @@ class Model(object):
             raise writer_error[0]
 
         st = ex.stats
+        if st.get("probe_windows"):
+            logger.info("Accuracy probe on the input: f16bf8 vs bf16x3 chunk vectors differ by at most %.2e over %d probed window(s)%s" % (
+                st["probe_rel_l2_max"], st["probe_windows"],
+                "; demoted to bf16x3 at window %d" % st["demoted_at_window"] if ex.demoted else ""))
+        self.last_stats = dict(st, demoted=bool(getattr(ex, "demoted", False)),
+                               selection=dict(getattr(self.device_model, "selection", None) or {}))
         logger.info("Processed %d features of average size %d frames. Done %d and failed %d" %
                     (total_segments, st["frames"] / max(total_segments, 1), num_success, num_fail))
         logger.info("Total time for neural network computations is %.2f minutes." % (compute_time / 60.0))

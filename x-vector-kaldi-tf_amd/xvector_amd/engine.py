@@ -337,6 +337,19 @@ class DeviceModel(object):
         self._pool_ws = None
         self._a0 = None
 
+    def probe_vectors(self, batch):
+        """x-vectors (host float32 [chunks, E]) of a packed host batch ``(x[R, in_dim], row_start, row_len, row_valid, max_len)``
+        in this model's arithmetic (load-time accuracy probe)."""
+        torch = self.torch
+        x, rs, rl, rv, max_len = batch
+        with torch.cuda.device(self.device):
+            dx, drs, drl, drv = (torch.from_numpy(np.ascontiguousarray(a)).to(self.device) for a in (x, rs, rl, rv))
+            out = torch.empty((len(rs), self.embed_dim), dtype=torch.float32, device=self.device)
+            if self.f16bf8:
+                self.status.zero_()
+            self.forward_packed(dx, drs, drl, drv, len(rs), int(max_len), out)
+            return out.cpu().numpy()
+
     def fallback(self):
         """The bf16x3 twin of an f16bf8 model (built on first use): repeats a batch whose activations left the fp16 range."""
         if self._fallback is None:
@@ -590,6 +603,106 @@ class DeviceModel(object):
 
 
 # ------------------------------------------------------------------------------------------------
+# which arithmetic may this checkpoint use?  (load-time accuracy probe)
+# ------------------------------------------------------------------------------------------------
+# The reference computes in IEEE fp32 (local/tf/models.py:54-76); f16bf8 and bf16x3 are faster arithmetics that reproduce it to
+# ~1e-5 / ~5e-6 relative L2 on networks whose weights and BatchNorm statistics look like a trained TDNN's.  Nothing forces a
+# checkpoint to look like that, so the arithmetic is chosen PER MODEL: a fixed synthetic batch (MFCC-like: AR(1) over the frames,
+# decaying per-coefficient scale, mean-normalised; 8 chunks x 256 frames) goes through the loaded weights in the candidate
+# arithmetic and in the next more exact one, and the candidate is kept only when their x-vectors agree to PROBE_LIMIT_*.
+PROBE_LIMIT_F16BF8 = 2e-5        # f16bf8 kept when within this of bf16x3 (typical: 1e-5); the parity bar is 1e-4
+PROBE_LIMIT_BF16X3 = 4e-5        # bf16x3 kept when within this of the exact-fp32 kernels (typical: 5e-6)
+DATA_PROBE_LIMIT = 3e-5          # run-time check on real utterances (Extractor): per-chunk vectors, shortest chunks of a window
+_PROBE_INPUT = {}
+
+
+def probe_batch(feat_dim, in_dim, gap, align, chunks=8, frames=256, seed=20240917):
+    """The fixed probe batch in kernel layout (host arrays): ``(x[R, in_dim], row_start, row_len, row_valid, max_len)``."""
+    key = (feat_dim, in_dim, gap, align, chunks, frames, seed)
+    if key not in _PROBE_INPUT:
+        rng = np.random.default_rng(seed)
+        rho = 0.92
+        # AR(1) over the frames as one lower-triangular matrix product (no per-frame loop): x_t = sum_j rho^(t-j) e_j
+        t = np.arange(frames)
+        L = np.tril(rho ** np.maximum(t[:, None] - t[None, :], 0))
+        scale = 12.0 / (1.0 + np.arange(feat_dim)) ** 0.7
+        mats = []
+        for _ in range(chunks):
+            m = L @ (rng.standard_normal((frames, feat_dim)) * np.sqrt(1.0 - rho * rho))
+            t0 = int(rng.integers(0, max(frames - 10, 1)))
+            m[t0:t0 + 10] *= 4.0                     # a burst (non-speech event): what wakes up near-dead channels
+            m *= scale
+            mats.append((m - m.mean(axis=0, keepdims=True)).astype(np.float32))
+        lay = BatchLayout([frames] * chunks, gap, align)
+        x = np.zeros((lay.rows, in_dim), np.float32)
+        lay.pack(mats, x)
+        _PROBE_INPUT[key] = (x, lay.row_start, lay.row_len, lay.row_valid(), lay.max_len)
+    return _PROBE_INPUT[key]
+
+
+def _max_rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    num = np.sqrt(((a - b) ** 2).sum(axis=1))
+    den = np.sqrt((b ** 2).sum(axis=1))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = np.where(den > 0, num / den, np.where(num > 0, np.inf, 0.0))
+    return float(np.nan_to_num(r, nan=np.inf).max()) if len(r) else 0.0
+
+
+def select_model(weights, topo, device="cuda:0", embedding_index=0, precision="f16bf8", probe=None):
+    """``DeviceModel`` in the fastest arithmetic, not faster than ``precision``, that the accuracy probe admits for THESE weights:
+    f16bf8 -> (its x-vectors of the probe batch differ from bf16x3's by more than PROBE_LIMIT_F16BF8, or are not finite, or left
+    the fp16 range) -> bf16x3 -> (differs from the exact-fp32 kernels by more than PROBE_LIMIT_BF16X3) -> fp32.  The second step
+    only runs when the first one failed: a model that passes as f16bf8 loads exactly as before plus two small forwards.
+    ``model.selection`` reports what was measured.  ``probe=False`` (or XVECTOR_ACCURACY_PROBE=0) takes ``precision`` as given."""
+    if probe is None:
+        probe = os.environ.get("XVECTOR_ACCURACY_PROBE", "1") != "0"
+    model = DeviceModel(weights, topo, device, embedding_index, precision)
+    sel = dict(requested=precision, selected=model.requested_precision if model.f16bf8 else model.precision, probed=False)
+    model.selection = sel
+    if not probe or not model.f16bf8:
+        return model
+    batch = probe_batch(model.feat_dim, model.in_dim, model.gap, model.align)
+    got = model.probe_vectors(batch)
+    clamped = int(model.status.item()) != 0
+    model.status.zero_()
+    twin = model.fallback()
+    ref = twin.probe_vectors(batch)
+    err = _max_rel_l2(got, ref)
+    sel.update(probed=True, f16bf8_vs_bf16x3=err, f16bf8_limit=PROBE_LIMIT_F16BF8, probe_left_fp16_range=clamped,
+               probe_frames=int(np.sum(batch[2])))
+    if err <= PROBE_LIMIT_F16BF8 and not clamped:
+        return model
+    exact = DeviceModel(weights, topo, device, embedding_index, "fp32")
+    err3 = _max_rel_l2(ref, exact.probe_vectors(batch))
+    sel.update(bf16x3_vs_fp32=err3, bf16x3_limit=PROBE_LIMIT_BF16X3)
+    chosen = twin if err3 <= PROBE_LIMIT_BF16X3 else exact
+    sel["selected"] = chosen.precision
+    chosen.selection = sel
+    return chosen
+
+
+class _Rows(object):
+    """Utterances ``idx`` of a window: a sequence with the ``lengths`` / ``addrs`` arrays the extractor plans and packs from;
+    a matrix is only materialised when somebody indexes it."""
+
+    def __init__(self, mats, idx, lens, addrs):
+        self.mats, self.idx = mats, np.asarray(idx, np.int64)
+        self.lengths = np.asarray(lens, np.int64)[self.idx]
+        self.addrs = None if addrs is None else np.asarray(addrs, np.uint64)[self.idx]
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, i):
+        return self.mats[int(self.idx[i])]
+
+    def __iter__(self):
+        for i in self.idx.tolist():
+            yield self.mats[i]
+
+
+# ------------------------------------------------------------------------------------------------
 # extractor: utterances in, x-vectors out
 # ------------------------------------------------------------------------------------------------
 _STAGE_CACHE = {}          # (in_dim, NBUF) -> parked pinned staging sets of finished extractors (at most 2 per key)
@@ -618,9 +731,21 @@ class Extractor(object):
     rotated, copies go through a dedicated HIP stream, and the compute stream waits on the copy's event."""
 
     NBUF = 3
+    PROBE_ROWS = 16384           # run-time accuracy check: this many rows of a window's first batch are repeated on the bf16x3 twin
+    PROBE_EVERY = 64             # ... for the first window of an extractor and every 64th after it
 
-    def __init__(self, model, min_chunk_size, chunk_size, max_batch_rows=262144, max_batch_chunks=8192):
+    def __init__(self, model, min_chunk_size, chunk_size, max_batch_rows=262144, max_batch_chunks=8192, accuracy_probe=None):
+        """accuracy_probe (f16bf8 models; default on, XVECTOR_ACCURACY_PROBE=0 turns it off): the leading (= shortest) chunks of
+        the first batch of a window -- the packed rows are already in HBM -- also run through the bf16x3 twin, and ``finish``
+        compares the two sets of chunk vectors.  Beyond DATA_PROBE_LIMIT the extractor is DEMOTED: the window is repeated on
+        the twin and every later window goes there directly.  The load-time probe (``select_model``) sees the weights on
+        synthetic input; this one sees them on the caller's features."""
         self.model = model
+        if accuracy_probe is None:
+            accuracy_probe = os.environ.get("XVECTOR_ACCURACY_PROBE", "1") != "0"
+        self.accuracy_probe = bool(accuracy_probe) and model.f16bf8
+        self.demoted = False
+        self._windows = 0
         self.min_chunk_size = int(min_chunk_size)
         self.chunk_size = int(chunk_size)
         self.max_batch_rows = int(max_batch_rows)
@@ -761,6 +886,8 @@ class Extractor(object):
         i+1 then overlaps the kernels of window i).  ``addrs``: optional ``matrix_addresses(mats, F)`` computed elsewhere
         (e.g. by the reader thread).  ``mats`` may be a lazy sequence with a ``lengths`` array (kaldi_io.ArkMats): with ``addrs``
         the native packer reads the rows in place and no matrix object is ever built."""
+        if self.demoted:
+            return self._on_twin(lambda ex: ex.submit(mats, addrs))
         torch = self.model.torch
         model = self.model
         dev = model.device
@@ -824,6 +951,8 @@ class Extractor(object):
                 compute.wait_event(ev)
                 model.frame_level(x, md[0], md[1], rv, layout.nchunks, layout.max_len, P_all[b0:b1], status=status)
                 keep.append((x, rv, md))
+                if bi == 0:
+                    self._start_probe(handle, x, md, rv, layout)
                 self.stats["batches"] += 1
                 self.stats["chunks"] += layout.nchunks
                 self.stats["frames"] += int(layout.row_len.sum())
@@ -843,6 +972,7 @@ class Extractor(object):
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
             host_flat, host = self._pinned("xvec", (len(order), model.embed_dim), torch.float32)
             host.copy_(out, non_blocking=True)
+            self._end_probe(handle, E_all)
             self._watch(handle, status, lambda ex: ex.submit(mats, addrs))
             done = torch.cuda.Event()
             done.record(compute)
@@ -859,6 +989,89 @@ class Extractor(object):
         flag.copy_(status, non_blocking=True)
         handle.update(flag=flag, flag_flat=flat, redo=redo, status=status)
 
+    def _twin(self):
+        """The extractor of the model's bf16x3 twin (out-of-range windows, windows after a demotion)."""
+        if self._fallback_ex is None:
+            self._fallback_ex = Extractor(self.model.fallback(), self.min_chunk_size, self.chunk_size, self.max_batch_rows,
+                                          self.max_batch_chunks)
+        return self._fallback_ex
+
+    def _on_twin(self, submit):
+        """A window of a demoted extractor: submitted on the twin (``finish`` follows the handle's ``owner``); its batches
+        count in this extractor's statistics."""
+        ex = self._twin()
+        before = dict(ex.stats)
+        handle = submit(ex)
+        for k in ("batches", "chunks", "frames", "rows"):
+            self.stats[k] += ex.stats[k] - before[k]
+        handle["owner"] = ex
+        return handle
+
+    PROBE_MIN_LEN = 128          # chunks the probe prefers (a vector pooled over a handful of frames is noisier in EVERY arithmetic)
+
+    def _start_probe(self, handle, x, md, rv, layout):
+        """Run-time accuracy check, first half (called right behind the first batch of a window): a run of consecutive chunks of
+        the batch -- the shortest ones of at least PROBE_MIN_LEN frames (all shorter: the longest ones), at most PROBE_ROWS rows
+        -- through the bf16x3 twin.  The rows are already in HBM: a run of slots of a packed batch, taken from ``lead`` rows
+        before its first chunk, is itself a packed batch once the chunk starts are re-based (the rows in front of it are the
+        previous chunk's tail: never read by this run's frames, whose halo ends in that chunk's zero gap rows)."""
+        self._windows += 1
+        if not self.accuracy_probe or (self._windows - 1) % self.PROBE_EVERY:
+            return
+        n = layout.nchunks
+        i0 = int(np.searchsorted(layout.row_len, self.PROBE_MIN_LEN, side="left"))        # (chunks of a batch ascend in length)
+        if i0 >= n:
+            i0 = max(0, n - 16)
+        cum = np.cumsum(layout.slots[i0:])
+        m = int(np.searchsorted(cum, self.PROBE_ROWS - layout.lead, side="right"))
+        if m == 0:
+            if int(cum[0]) > 4 * self.PROBE_ROWS:
+                self._windows -= 1                   # a very long chunk: look at the next window instead
+                return
+            m = 1
+        base = int(layout.row_start[i0]) - layout.lead
+        rows = layout.lead + int(cum[m - 1])
+        torch, twin = self.model.torch, self.model.fallback()
+        dev = twin.device
+        flat, meta = self._pinned("probe_meta", (2, m), torch.int32)
+        mh = meta.numpy()
+        mh[0] = layout.row_start[i0:i0 + m] - base
+        mh[1] = layout.row_len[i0:i0 + m]
+        with torch.cuda.stream(self._copy_stream):
+            md2 = meta.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        torch.cuda.current_stream().wait_event(ev)
+        P = torch.empty((m, twin.pooled_dim), dtype=torch.float32, device=dev)
+        E = torch.empty((m, twin.embed_dim), dtype=torch.float32, device=dev)
+        twin.frame_level(x[base:base + rows], md2[0], md2[1], rv[base:base + rows], m, int(layout.row_len[i0:i0 + m].max()), P)
+        twin.segment_level(P, E)
+        handle["probe"] = dict(i0=i0, m=m, ref=E, keep=(P, md2, meta), meta_flat=flat)
+
+    def _end_probe(self, handle, E_all):
+        """Second half (behind the window's segment-level launch): both sets of chunk vectors start their way to the host."""
+        pr = handle.get("probe")
+        if pr is None:
+            return
+        i0, m = pr["i0"], pr["m"]
+        flat, host = self._pinned("probe", (2, m, self.model.embed_dim), self.model.torch.float32)
+        host[0].copy_(E_all[i0:i0 + m], non_blocking=True)
+        host[1].copy_(pr["ref"], non_blocking=True)
+        pr.update(host=host, flat=flat)
+
+    def _probe_failed(self, handle):
+        """finish(): True when the window's probe found the f16bf8 vectors too far from the twin's -> demotion."""
+        pr = handle.pop("probe", None)
+        if pr is None or "host" not in pr:
+            return False
+        got = pr["host"].numpy()
+        err = _max_rel_l2(got[0], got[1])
+        self._unpin("probe", pr["flat"])
+        self._unpin("probe_meta", pr["meta_flat"])
+        self.stats["probe_windows"] = self.stats.get("probe_windows", 0) + 1
+        self.stats["probe_rel_l2_max"] = max(self.stats.get("probe_rel_l2_max", 0.0), err)
+        return err > DATA_PROBE_LIMIT
+
     def submit_raw(self, mats, vads, cmn_window, center=True, min_window=100, addrs=None):
         """``submit`` for RAW features: sliding-window CMN + VAD frame selection (xv_cmn_sliding_scatter_f32) run on the
         device and write every voiced, normalised frame straight into its row of the packed batch -- the selected features
@@ -866,6 +1079,13 @@ class Extractor(object):
         utterance; addrs: optional ``matrix_addresses(mats, F)``.  Returns ``(handle, lengths, vad_dropped)``: the handle for ``finish``; the number of selected frames per
         utterance; a bool mask of the utterances select-voiced-frames drops (VAD length mismatch / no voiced frame)."""
         from .frontend import select_voiced
+        if self.demoted:
+            box = []
+
+            def go(ex):
+                box[:] = ex.submit_raw(mats, vads, cmn_window, center, min_window, addrs)
+                return box[0]
+            return (self._on_twin(go),) + tuple(box[1:])
         torch = self.model.torch
         model = self.model
         dev = model.device
@@ -916,7 +1136,7 @@ class Extractor(object):
             model.reserve(*self._reserve_caps(bounds), int(c_len.max()))
             keep = []
             status = torch.zeros(1, dtype=torch.int32, device=dev) if model.f16bf8 else None
-            for (b0, b1, _), (lo, hi) in zip(bounds, spans):
+            for bi, ((b0, b1, _), (lo, hi)) in enumerate(zip(bounds, spans)):
                 layout = BatchLayout(c_len[b0:b1], gap, align)
                 U = order[lo:hi]
                 Tb = T[U]
@@ -970,6 +1190,8 @@ class Extractor(object):
                 hiplib.cmn_sliding_scatter(raw_d, utt_d[0], utt_d[1], nU, int(Tb.max()), cmn_window, center, min_window, dst_d, x)
                 model.frame_level(x, md[0], md[1], rv, layout.nchunks, layout.max_len, P_all[b0:b1], status=status)
                 keep.append((x, rv, md, raw_d, dst_d, utt_d))
+                if bi == 0:
+                    self._start_probe(handle, x, md, rv, layout)
                 self.stats["batches"] += 1
                 self.stats["chunks"] += layout.nchunks
                 self.stats["frames"] += int(layout.row_len.sum())
@@ -988,6 +1210,7 @@ class Extractor(object):
             hiplib.chunk_average(E_all, seg, cl, len(order), out)
             host_flat, host = self._pinned("xvec", (len(order), model.embed_dim), torch.float32)
             host.copy_(out, non_blocking=True)
+            self._end_probe(handle, E_all)
             self._watch(handle, status, lambda ex: ex.submit_raw(mats, vads, cmn_window, center, min_window, addrs)[0])
             done = torch.cuda.Event()
             done.record(compute)
@@ -1011,6 +1234,9 @@ class Extractor(object):
     def finish(self, handle, as_array=False):
         """Wait for a submitted window and return its x-vectors in input order: a list with None for rejected utterances,
         or with ``as_array`` the pair (float32 [n, E] array, bool [n] mask of the utterances that produced a vector)."""
+        owner = handle.get("owner")
+        if owner is not None and owner is not self:
+            return owner.finish(handle, as_array)             # a window of a demoted extractor: it ran on the twin
         n = handle["n"]
         if handle["nch"]:
             handle["done"].synchronize()
@@ -1018,9 +1244,13 @@ class Extractor(object):
                 clamped = int(handle["flag"][0]) != 0
                 self._unpin("flag", handle.pop("flag_flat"))
                 handle["flag"] = None
-                if clamped:
-                    # some activation of the window left the fp16 range of the f16bf8 arithmetic: the whole window again on
-                    # the bf16x3 twin (fp32 range) -- its results replace the clamped ones
+                if self._probe_failed(handle) and not self.demoted:
+                    self.demoted = True
+                    self.stats["demoted_at_window"] = self._windows
+                if clamped or self.demoted:
+                    # some activation of the window left the fp16 range of the f16bf8 arithmetic, or an accuracy probe failed
+                    # (this window's, or an earlier one's while this window was already in flight): the whole window again on
+                    # the bf16x3 twin -- its results replace these
                     redo = handle.pop("redo")
                     pinned = handle.pop("pinned", None)
                     if pinned is not None:
@@ -1028,10 +1258,7 @@ class Extractor(object):
                         self._unpin("xvec", pinned[1])
                     handle["keep"] = None
                     self.stats["fallback_windows"] = self.stats.get("fallback_windows", 0) + 1
-                    if self._fallback_ex is None:
-                        self._fallback_ex = Extractor(self.model.fallback(), self.min_chunk_size, self.chunk_size,
-                                                      self.max_batch_rows, self.max_batch_chunks)
-                    return self._fallback_ex.finish(redo(self._fallback_ex), as_array)
+                    return self._twin().finish(redo(self._twin()), as_array)
                 handle.pop("redo", None)
             host_out = handle["host"].numpy()
             handle["keep"] = None

@@ -10,6 +10,12 @@ used once to manufacture "trained-like" running statistics; the extractor never 
                              running statistics calibrated on a random 2000-frame input, so that BN is
                              exercised and activations stay O(1) through the stack.
 * ``make_utterances``     -- ``float32 [T,F]`` MFCC-like matrices, T uniform in [tmin, tmax].
+* ``hostile``             -- weights a trained checkpoint COULD have and ``trained_like`` never produces: heavy-tailed
+                             (Student-t, 3 degrees of freedom), per-channel scales spread over three decades, BN variances
+                             from 1e-4 to 1e2, near-dead channels, wide gamma / beta -- the stress case of the reduced-
+                             precision arithmetics (tests/test_gpu_hostile.py).
+* ``mfcc_like``           -- utterances with the statistics of real cepstra after CMN: frame-to-frame AR(1) correlation,
+                             a spectrum of per-coefficient scales, zero mean per utterance.
 """
 import numpy as np
 
@@ -140,6 +146,98 @@ def trained_like(topo, feat_dim, num_classes=64, seed=0, calib_frames=2000, inpu
     lim = np.sqrt(6.0 / (prev + num_classes))
     w["output/w:0"] = rng.uniform(-lim, lim, size=(prev, num_classes)).astype(np.float32)
     w["output/b:0"] = np.full(num_classes, 0.1, np.float32)
+    return w
+
+
+def mfcc_like(lengths, feat_dim=23, seed=0, rho=0.92, c0_scale=12.0):
+    """float32 [T, F] matrices shaped like MFCCs after sliding-window CMN: every coefficient an AR(1) process over the frames
+    (``rho``: neighbouring frames of speech are strongly correlated -- the K taps of a TDNN layer see nearly the same vector),
+    coefficient j scaled ``c0_scale / (1 + j)^0.7`` plus 5 % of its own scale shared with coefficient j-1 (cepstra of one frame
+    are not independent), the utterance mean removed.  Occasional bursts (x4 for ~10 frames) stand in for non-speech events."""
+    rng = np.random.default_rng(seed)
+    scale = c0_scale / (1.0 + np.arange(feat_dim)) ** 0.7
+    out = []
+    for T in lengths:
+        T = int(T)
+        e = rng.standard_normal((T, feat_dim)) * np.sqrt(1.0 - rho * rho)
+        x = np.empty((T, feat_dim))
+        acc = rng.standard_normal(feat_dim)
+        for t in range(T):
+            acc = rho * acc + e[t]
+            x[t] = acc
+        x[:, 1:] += 0.05 * x[:, :-1]
+        if T >= 40:
+            for _ in range(max(1, T // 400)):
+                t0 = int(rng.integers(0, T - 10))
+                x[t0:t0 + 10] *= 4.0
+        x *= scale
+        x -= x.mean(axis=0, keepdims=True)
+        out.append(x.astype(np.float32))
+    return out
+
+
+def hostile(topo, feat_dim, num_classes=64, seed=0, calib=None, decades=3.0, dead_fraction=0.06):
+    """A weight set that computes a sane network (BN statistics are CALIBRATED on ``calib`` -- default: 3000 frames of
+    ``mfcc_like`` input -- so activations stay finite and O(1) on such input) but has none of the comfortable properties of
+    ``trained_like``:
+
+    * weights ~ Student-t(3) (heavy tails: single weights 10-30x the typical one) at He scale;
+    * every output channel of every layer multiplied by 10^U(-decades+1, 1): pre-activation variances -- and therefore the
+      calibrated BN variances -- spread from ~1e-4 to ~1e2, BN scales ``gamma / sqrt(var + 1e-3)`` from ~0.1 to ~31;
+    * ``dead_fraction`` of the channels near-dead: a bias 3-4 standard deviations below zero, the ReLU fires on a few frames;
+    * gamma log-normal (sigma 0.7, a tenth of the channels another 30x down), beta ~ N(0, 0.5), and the INPUT side of the next
+      layer compensating none of it.
+    Returns the weight dictionary (same keys as ``trained_like``)."""
+    rng = np.random.default_rng(seed)
+    if calib is None:
+        calib = np.concatenate(mfcc_like([1000, 1000, 1000], feat_dim, seed=seed + 99), axis=0)
+    w = {}
+    h = np.asarray(calib, dtype=np.float64)
+    prev = feat_dim
+    n = len(topo["kernel_sizes"])
+    for i, (k, d, c) in enumerate(zip(topo["kernel_sizes"], topo["dilations"], topo["layer_sizes"])):
+        sc = "frame_level_info_layer-%d" % i
+        in_rms = np.sqrt((h * h).mean(axis=0)).mean() + 1e-12
+        wt = rng.standard_t(3, size=(k, prev, c)) / np.sqrt(3.0) * np.sqrt(2.0 / (k * prev)) / in_rms
+        ch = 10.0 ** rng.uniform(1.0 - decades, 1.0, size=c)
+        wt = wt * ch[None, None, :]
+        T = h.shape[0]
+        left = (k - 1) * d // 2
+        hp = np.zeros((T + (k - 1) * d, prev))
+        hp[left:left + T] = h
+        z0 = np.zeros((T, c))
+        for kk in range(k):
+            z0 += hp[kk * d:kk * d + T] @ wt[kk]
+        zs = z0.std(axis=0) + 1e-30
+        b = 0.3 * zs * rng.standard_normal(c)
+        dead = rng.random(c) < dead_fraction
+        b[dead] = -(3.0 + rng.random(int(dead.sum()))) * zs[dead] - z0.mean(axis=0)[dead]
+        alpha = (0.1 + 0.05 * rng.standard_normal(c))
+        r = _act(z0 + b, topo, alpha)
+        mean, var = r.mean(0), r.var(0)
+        gamma = np.exp(0.7 * rng.standard_normal(c))
+        gamma[rng.random(c) < 0.1] /= 30.0
+        if i == n - 1:
+            gamma = np.exp(0.3 * rng.standard_normal(c))             # (what pooling sees keeps a common scale)
+        beta = 0.5 * rng.standard_normal(c)
+        mean_f = (mean * (1.0 + 0.05 * rng.standard_normal(c))).astype(np.float32)
+        var_f = (var * np.exp(0.1 * rng.standard_normal(c))).astype(np.float32)
+        sbn = gamma / np.sqrt(var_f.astype(np.float64) + tp.BN_EPSILON)
+        h = r * sbn + (beta - mean_f.astype(np.float64) * sbn)
+        w[sc + "/w:0"], w[sc + "/b:0"] = wt.astype(np.float32), b.astype(np.float32)
+        w[sc + "/gamma:0"], w[sc + "/beta:0"] = gamma.astype(np.float32), beta.astype(np.float32)
+        w[sc + "/mean:0"], w[sc + "/variance:0"] = mean_f, var_f
+        if topo.get("activation") == "prelu":
+            w[sc + "/prelu/prelu:0"] = alpha.astype(np.float32)
+        prev = c
+    base = trained_like(topo, feat_dim, num_classes, seed=seed + 1, calib_frames=64)
+    for name, a in base.items():
+        if not name.startswith("frame_level_info_layer-"):
+            w[name] = a
+    # the segment layer sees [mean | std] of hostile channels: Student-t weights there as well
+    pooled = tp.pooled_dim(topo)
+    w["embed_layer-0/w:0"] = (rng.standard_t(3, size=(pooled, topo["embedding_sizes"][0])) / np.sqrt(3.0) *
+                              np.sqrt(1.0 / pooled)).astype(np.float32)
     return w
 
 
