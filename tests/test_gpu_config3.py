@@ -1,7 +1,10 @@
 """BASELINE configs[3] at PER-RANK scale on the one GPU a test box has: 1 M utterances over 8 ranks = 125 k utterances per
-rank, pushed through the scp-sharded CLI path (`extract_embedding.py` under `torch.distributed.run`, the twin of
+rank, pushed through the scp-sharded CLI path (`extract_embedding.py` under the package's launcher, the twin of
 local/tf/extract_xvectors.sh:63-95) with a forced 1-rank RCCL group, `ark,scp` output.  Checks order, keys, byte framing,
 scp offsets and parity of a sample against the fp64 oracle; the 8-rank run itself is the driver's (SCALE_rNN.json).
+The JOB-LEVEL wall clock is part of the contract: the job runs twice -- the first RCCL communicator on a
+fresh box loads librccl's device code cold (~3.5 s under the HIP runtime's lock) -- and the second run must finish within
+JOB_WALL_LIMIT seconds; both print their breakdown (xvector_amd/jobclock.py).
 Time-boxed: the subprocess is killed after 15 minutes; XV_TEST_SHARD_UTTS shrinks the shard (default 125000)."""
 import os
 import shutil
@@ -15,6 +18,10 @@ import pytest
 from conftest import ROOT, TWIN
 
 pytestmark = pytest.mark.gpu
+
+# round 2: 5.9 s warm.  Now ~3.1-3.4 s: 0.8 s `import torch` + ~1.0 s RCCL bring-up (its kernel load holds the HIP runtime's
+# lock, so it only partly overlaps the model load) + 0.65 s extraction at 190-220 k utt/s + 0.25 s D2H and ark,scp write
+JOB_WALL_LIMIT = 4.0
 
 
 def test_one_rank_share_of_the_million_utterance_job(oracle_mod, tmp_path):
@@ -45,16 +52,29 @@ def test_one_rank_share_of_the_million_utterance_job(oracle_mod, tmp_path):
             kaldi_io.write_mat(tw, pool[i % 509][:lens[i]], key=keys[i])
     t_write = time.time() - t0
     ark, scp = str(tmp_path / "xvector.ark"), str(tmp_path / "xvector.scp")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), os.path.join(TWIN, "extract_embedding.py"),
+    # one rank per GPU through the package's own launcher (xvector_amd/launch.py: the same RANK / WORLD_SIZE / MASTER_* contract as
+    # torch.distributed.run without its elastic agent -- seconds of start-up that a job-level number has no use for)
+    cmd = [sys.executable, "-m", "xvector_amd.launch", "--nproc", "1", os.path.join(TWIN, "extract_embedding.py"),
            "--use-gpu", "yes", "--min-chunk-size", "25", "--chunk-size", "10000", "--feature-rspecifier", "scp:" + feats_scp,
            "--vector-wspecifier", "ark,scp:%s,%s" % (ark, scp), "--model-dir", mdir]
-    env = dict(os.environ, XV_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    t0 = time.time()
-    run = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    t_cli = time.time() - t0
-    log = run.stdout.decode(errors="replace")
-    assert run.returncode == 0, log[-3000:]
+    env = dict(os.environ, XV_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "x-vector-kaldi-tf_amd"), os.environ.get("PYTHONPATH", "")]))
+    walls = []
+    for attempt in ("first job on this box (librccl / code objects cold)", "second job"):
+        for f in (ark, scp):
+            if os.path.exists(f):
+                os.remove(f)
+        t0 = time.time()
+        run = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        t_cli = time.time() - t0
+        walls.append(t_cli)
+        log = run.stdout.decode(errors="replace")
+        assert run.returncode == 0, log[-3000:]
+        clock = [ln for ln in log.splitlines() if "Job wall clock:" in ln]
+        assert clock, log[-2000:]
+        print("\n%s: %.2f s wall = %.0f utt/s\n  %s" % (attempt, t_cli, n / t_cli, clock[-1].split("] ", 1)[-1]))
+    if n == 125000:
+        assert walls[1] <= JOB_WALL_LIMIT, "the 125 k-utterance shard took %.2f s of wall clock (limit %.1f)" % (walls[1], JOB_WALL_LIMIT)
     assert "Done %d and failed %d" % (n - n // 5000, n // 5000) in log, log[-2000:]
     # order, keys, framing: one FV record per surviving utterance, in input order, nothing else in the file
     kept = [i for i in range(n) if lens[i] >= 25]

@@ -339,15 +339,15 @@ def test_cli_scp_sharding_helpers(tmp_path):
         got = []
         for r in range(world):
             f, v, all_keys = cli._scp_shard("scp:%s" % feats, r, world, "scp:%s" % vad)
-            fk = [ln.split()[0] for ln in f.read().splitlines()]
+            fk = [ln.split()[0] for ln in f]                             # the shard's lines (kaldi_io.MatScp takes them as they are)
             assert all_keys[r] == fk and sum(all_keys, []) == keys       # every rank knows every shard's keys: no key exchange
-            vk = [ln.split()[0] for ln in v.read().splitlines()]
+            vk = [ln.split()[0] for ln in v]
             assert vk == [k for k in fk if k != "utt04"]                  # same order as the feature shard
             got += fk
         assert got == keys
         seen.append(got)
     f, v, all_keys = cli._scp_shard("scp:%s" % feats, 0, 2)
-    assert v is None and len(f.read().splitlines()) == 5 and [len(k) for k in all_keys] == [5, 6]
+    assert v is None and len(f) == 5 and [len(k) for k in all_keys] == [5, 6]
 
 
 def test_batches_come_in_whole_rounds_of_workgroups():

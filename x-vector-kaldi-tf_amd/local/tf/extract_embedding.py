@@ -28,6 +28,22 @@ if _HERE not in sys.path:
 
 import kaldi_io  # noqa: E402
 from models import Model  # noqa: E402
+from xvector_amd import jobclock  # noqa: E402
+
+jobclock.mark("interpreter + imports")
+
+
+def _import_torch_early():
+    """``import torch`` (0.8 s, mostly dlopen) starts on a side thread the moment the worker is a main program, so that it runs
+    next to argument parsing and the reading of the scp tables; ``Model.load_model``'s own import then finds it done."""
+    import threading
+
+    def run():
+        try:
+            import torch  # noqa: F401
+        except Exception:          # the main thread's own import will report it
+            pass
+    threading.Thread(target=run, name="xv-import-torch", daemon=True).start()
 
 logger = logging.getLogger('extract_embedding')
 logger.setLevel(logging.INFO)
@@ -101,8 +117,14 @@ def process_wspecifier(wspecifier):
 
 def _open_output(wspecifier, ark, scp):
     if ark is not None and not wspecifier.lstrip().startswith('|'):
-        return kaldi_io.TableWriter(ark + '.tmp.ark', scp + '.tmp.scp')
+        # the scp lines name the FINAL ark from the start: nothing to patch after the rename (the reference has to rewrite the
+        # text because copy-vector only knows the temporary name, extract_embedding.py:139-148)
+        return kaldi_io.TableWriter(ark + '.tmp.ark', scp + '.tmp.scp', scp_ark_name=ark)
     return kaldi_io.open_or_fd(wspecifier, 'wb')
+
+
+def _native_table(wspecifier, ark):
+    return ark is not None and not wspecifier.lstrip().startswith('|')
 
 
 class _Discard(object):
@@ -173,17 +195,16 @@ def _scp_shard(spec, rank, world, vad_spec=None):
     extract_xvectors.sh:63-65).  With ``vad_spec`` (also an scp table) the second value is the VAD scp restricted to the same
     keys, in the same order.  Third value: the key lists of ALL shards (every rank can tell which utterances its peers hold,
     so the final exchange carries no keys)."""
-    import io
     lines = _scp_lines(spec)
     cuts = [len(lines) * r // world for r in range(world + 1)]
     shard_keys = [[ln.split(None, 1)[0] for ln in lines[cuts[r]:cuts[r + 1]]] for r in range(world)]
     mine = lines[cuts[rank]:cuts[rank + 1]]
     if vad_spec is None:
-        return io.StringIO("".join(mine)), None, shard_keys
+        return mine, None, shard_keys
     table = {}
     for ln in _scp_lines(vad_spec):
         table[ln.split(None, 1)[0]] = ln if ln.endswith("\n") else ln + "\n"
-    return io.StringIO("".join(mine)), io.StringIO("".join(table[k] for k in shard_keys[rank] if k in table)), shard_keys
+    return mine, [table[k] for k in shard_keys[rank] if k in table], shard_keys
 
 
 def _is_scp_table(rspecifier):
@@ -203,6 +224,12 @@ def eval_dnn(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     root = rank == 0
     grouped = world > 1 or (os.environ.get("XV_FORCE_DIST") == "1" and "RANK" in os.environ)     # the latter: 1-rank group (tests)
+    if grouped:
+        # the process group is only needed for the ONE gather at the end: RCCL comes up on a side thread while this one loads
+        # the model and extracts (nothing is written to the output before that gather, so the stdout redirection of
+        # dist.init_process_group cannot hit an 'ark:-' stream)
+        from xvector_amd import dist as xdist
+        xdist.init_process_group_async()
     presharded = grouped and _is_scp_table(args.feature_rspecifier) and \
         (not args.vad_rspecifier or _is_scp_table(args.vad_rspecifier))
     model = Model()
@@ -214,18 +241,26 @@ def eval_dnn(args):
         vad = _open_table(args.vad_rspecifier, kaldi_io.VecScp, lambda stream: stream) if args.vad_rspecifier else None
         feats = _open_table(args.feature_rspecifier, kaldi_io.MatScp, None)
     collector = _Collector() if presharded else None
+    jobclock.mark("tables opened")
     with (kaldi_io.open_or_fd(args.feature_rspecifier) if feats is None else _Null()) as input_fid:
         with (collector if presharded else _open_output(wspecifier, ark, scp) if root else _Discard()) as output_fid:
             model.make_embedding(input_fid if feats is None else feats, output_fid, args.model_dir, args.min_chunk_size,
                                  args.chunk_size, use_gpu, logger, vad_stream=vad, cmn_window=args.cmn_window,
                                  cmn_center=args.cmn_center == 'yes', distributed=not presharded)
+    jobclock.mark("extraction (reader -> kernels -> last vector down)")
     if presharded:
         _gather_and_write(model, collector, shard_keys, wspecifier, ark, scp, rank, world)
+    if grouped:
+        # every rank stays until rank 0 has the vectors (a peer that tears the group down early would take the gather with it)
+        from xvector_amd import dist as xdist
+        xdist.finish_process_group()
     if not root:
         return
     if ark is not None:
         os.rename(ark + '.tmp.ark', ark)
-    if scp is not None:
+    if scp is not None and _native_table(wspecifier, ark):
+        os.rename(scp + '.tmp.scp', scp)                   # written by TableWriter with the final ark name in it
+    elif scp is not None:
         with open(scp + '.tmp.scp', 'rt') as fid_in:
             text = fid_in.read().replace(ark + '.tmp.ark', ark)
         if text and text[-1] != '\n':
@@ -234,6 +269,8 @@ def eval_dnn(args):
             fid_out.write(text)
         os.rename(scp + '.tmp', scp)
         os.remove(scp + '.tmp.scp')
+    jobclock.mark("rename")
+    logger.info(jobclock.line())
 
 
 def _gather_and_write(model, collector, shard_keys, wspecifier, ark, scp, rank, world):
@@ -260,7 +297,10 @@ def _gather_and_write(model, collector, shard_keys, wspecifier, ark, scp, rank, 
             raise RuntimeError("sharded extraction: emitted keys are not a subsequence of the shard's scp keys")
         block[rows, 0] = 1.0
         block[rows, 1:] = np.concatenate(collector.blocks)
+    xdist.wait_process_group()
+    jobclock.mark("wait for the process group")
     blocks = xdist.gather_blocks(torch.from_numpy(block).to(dev), [len(k) for k in shard_keys], 0)
+    jobclock.mark("gather")
     if rank == 0:
         with _open_output(wspecifier, ark, scp) as output_fid:
             for r in range(world):
@@ -268,9 +308,12 @@ def _gather_and_write(model, collector, shard_keys, wspecifier, ark, scp, rank, 
                 emitted = got[:, 0] > 0.5
                 kaldi_io.write_vec_flt_batch(output_fid, [k for k, ok in zip(shard_keys[r], emitted.tolist()) if ok],
                                              np.ascontiguousarray(got[emitted, 1:]))
+        jobclock.mark("write")
 
 
 def main(argv=None):
+    if argv is None:
+        _import_torch_early()
     args = get_args(argv)          # outside the try, as in the reference: --help / usage errors exit through argparse
     try:
         eval_dnn(args)
@@ -282,3 +325,9 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+    # a finished worker has nothing left to tear down in order: the outputs are closed and renamed.  Leaving through the
+    # interpreter's shutdown (torch, the HIP runtime, RCCL's proxy threads) costs ~0.4 s of every job
+    logging.shutdown()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)

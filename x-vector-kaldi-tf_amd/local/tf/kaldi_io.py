@@ -1168,12 +1168,15 @@ class _ScpTable(object):
     subset, a shuffled list, a piped rxfile) it falls back to entry-by-entry reads, so any scp gives the same result."""
 
     def __init__(self, file_or_fd):
-        fd = open_or_fd(file_or_fd)
-        try:
-            lines = [ln.decode() if isinstance(ln, bytes) else ln for ln in fd]
-        finally:
-            if fd is not file_or_fd:
-                fd.close()
+        if isinstance(file_or_fd, (list, tuple)):               # the table's lines, already read (a shard of an scp)
+            lines = file_or_fd
+        else:
+            fd = open_or_fd(file_or_fd)
+            try:
+                lines = [ln.decode() if isinstance(ln, bytes) else ln for ln in fd]
+            finally:
+                if fd is not file_or_fd:
+                    fd.close()
         self.entries = []
         for ln in lines:
             if ln.strip():

@@ -119,7 +119,13 @@ class Model(object):
         reference, models.py:143) is accepted and ignored."""
         if logger is not None:
             logger.info("Start loading graph ...")
+        from xvector_amd import jobclock
         w, meta = wio.load_model_dir(input_dir)
+        jobclock.once("weights read")
+        import torch
+        jobclock.once("import torch")
+        torch.cuda.init()
+        jobclock.once("hip runtime up")
         self.meta = meta
         self.num_classes = meta["num_classes"]
         self.embedding_index = int(os.environ.get("XVECTOR_EMBEDDING_INDEX", "0"))   # models.py:159-160
@@ -465,9 +471,15 @@ class Model(object):
         # the input order and alone writes (the role of split_data.sh + nj jobs + `cat xvector.*.scp`,
         # extract_xvectors.sh:63-95).  An scp table is better served by extract_embedding.py's line-range sharding, where
         # the ranks do not even parse each other's utterances.
-        from xvector_amd import dist as xdist
-        rank, world = xdist.init_process_group()
-        if not distributed:
+        from xvector_amd import dist as xdist, jobclock
+        jobclock.once("weights packed on the device + accuracy probe")
+        if distributed:
+            # the group is only needed for the exchange at the end: it comes up on a side thread (RCCL's first communicator takes
+            # about a second) while this one extracts; nothing is written to the output before the exchange
+            rank, world = xdist.group_shape()
+            if xdist.group_wanted():
+                xdist.init_process_group_async()
+        else:
             # the caller already gave every rank its own part of the input (extract_embedding.py shards scp tables by line
             # range): behave as a single process and leave the exchange to the caller
             rank, world = 0, 1
@@ -588,6 +600,7 @@ class Model(object):
                 addrs = mats.addrs if mats.uniform_cols() == F_dim else None
                 total_segments += len(keys)
                 nxt = submit(keys, mats, vads, addrs)
+                jobclock.once("first window launched")
                 # the window's arenas stay out of the pool until its vectors are down: finish() may have to pack the window
                 # again (out-of-range f16bf8 window -> bf16x3 twin), and it does so from the raw addresses
                 arenas = [held for held in mats.holders if isinstance(held, kaldi_io.ArkArena)]
@@ -602,6 +615,7 @@ class Model(object):
                 for held in in_flight[1]:
                     pool.put(held)
             if world > 1:
+                xdist.wait_process_group()
                 self._exchange_shards(stash, rank, world, min_chunk_size, chunk_size, emit)
         finally:
             cancel.set()                            # (no-op after a complete pass: the reader has already returned)

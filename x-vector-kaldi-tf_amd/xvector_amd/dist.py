@@ -19,6 +19,19 @@ def env_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def group_wanted():
+    """True when this process is a rank of a job that needs a process group: WORLD_SIZE > 1, or a forced 1-rank group
+    (XV_FORCE_DIST=1 under a launcher: exercises the RCCL path on the one GPU a test box has)."""
+    rank, world, _ = env_world()
+    return world > 1 or (os.environ.get("XV_FORCE_DIST") == "1" and "RANK" in os.environ)
+
+
+def group_shape():
+    """(rank, world) of the job as the launcher's environment states it -- known before the group is up."""
+    rank, world, _ = env_world()
+    return (rank, world) if world > 1 else (0, 1)
+
+
 def init_process_group(backend=None):
     """Initialise torch.distributed from the environment if WORLD_SIZE > 1.  Returns (rank, world)."""
     import torch
@@ -51,6 +64,57 @@ def init_process_group(backend=None):
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
+
+
+_ASYNC = {}
+
+
+def init_process_group_async(backend=None):
+    """``init_process_group`` on a side thread: the communicator (RCCL: ~1 s for the first one of a process) comes up while the
+    caller loads the model and extracts; ``wait_process_group()`` joins it in front of the first collective.  Only for callers
+    that write nothing to stdout before that point (see the redirection in ``init_process_group``)."""
+    import threading
+    if "thread" in _ASYNC:
+        return
+    box = {}
+
+    def run():
+        import time
+        from . import jobclock
+        t0 = time.time()
+        try:
+            box["value"] = init_process_group(backend)
+            jobclock.note("process group up on its side thread after", time.time() - t0)
+        except BaseException as e:          # noqa: B902 -- re-raised by wait_process_group
+            box["error"] = e
+    t = threading.Thread(target=run, name="xv-process-group", daemon=True)
+    _ASYNC.update(thread=t, box=box)
+    t.start()
+
+
+def wait_process_group(backend=None):
+    """(rank, world) once the group is up: joins the side thread of ``init_process_group_async`` if there is one, else
+    initialises here."""
+    if "thread" not in _ASYNC:
+        return init_process_group(backend)
+    _ASYNC["thread"].join()
+    box = _ASYNC["box"]
+    if "error" in box:
+        raise box["error"]
+    return box["value"]
+
+
+def finish_process_group(destroy=False):
+    """Barrier at the end of a job: no rank leaves (and takes the communicator with it) while the root still reads.  The group is
+    only destroyed on request: a worker process that exits right afterwards saves the 0.2 s the teardown takes."""
+    import torch.distributed as dist
+    if "thread" in _ASYNC:
+        wait_process_group()
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        if destroy:
+            dist.destroy_process_group()
+    _ASYNC.clear()
 
 
 def partition_lpt(lengths, world):
