@@ -19,8 +19,13 @@ algorithmic FLOPs / HIP-event time measured inside the timed region; ``roofline_
 pooling kernel; ``cpu_baseline`` is a torch-CPU fp32 port of the reference forward (batch 1, like the reference) timed on
 this box's host cores on a bounded sample: the faithful 2-thread figure, a thread sweep, and ``all_cores`` = the
 reference's deployment shape (nj processes x 2 threads).  At N = 1 the line also carries ``fp32_exact`` (the same step on
-the exact-fp32 MFMA path) and ``e2e_ark_to_ark`` (ark bytes -> Model.make_embedding -> ark bytes, PCIe and Kaldi parsing
-included; never ``value``).
+the exact-fp32 MFMA path), ``bf16x3`` (all layers in the bf16x3 arithmetic), ``e2e_ark_to_ark`` (ark bytes ->
+Model.make_embedding -> ark bytes, PCIe and Kaldi parsing included; never ``value``), ``cli_job`` (the wall clock of one
+``extract_embedding.py`` worker job from process birth to renamed ark,scp), ``config2_varlen`` (BASELINE configs[2]:
+T in [25, 10000], length-bucketed) and ``train_step`` (BASELINE configs[4]: one rank's share).  ``accuracy_probe`` is what
+``engine.select_model`` measured when it admitted the arithmetic for these weights.
+
+``python bench.py --gpus N`` with N > 1 starts its own N ranks (xvector_amd/launch.py) when it is not already one.
 """
 import argparse
 import json
@@ -52,7 +57,8 @@ def parse():
     ap.add_argument("--e2e-utts", type=int, default=50000,
                     help="N = 1 only: utterances of the ark -> ark sub-measurement through Model.make_embedding (0 = skip)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the exact-fp32 sub-measurement (fp32_exact)")
-    ap.add_argument("--parity-utts", type=int, default=6)
+    ap.add_argument("--parity-utts", type=int, default=40, help="utterances, spread over ALL batches of the step, checked against the fp64 oracle")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip config2_varlen, train_step and cli_job")
     ap.add_argument("--no-fused-pool", action="store_true",
                     help="bf16x3: store the last layer and run the standalone pooling kernel (A/B against the fused epilogue)")
     ap.add_argument("--mode", choices=["extract", "train"], default="extract",
@@ -66,33 +72,36 @@ def parse():
     ap.add_argument("--head", choices=["am_softmax", "softmax"], default="am_softmax",
                     help="--mode train: classification head (BASELINE configs[4] names AM-softmax; 'softmax' = the reference's head)")
     ap.add_argument("--precision", choices=["f16bf8", "bf16x3", "fp32"], default="f16bf8",
-                    help="GEMM arithmetic: bf16x3 = split-precision bf16 MFMA with fp32 accumulate (fp32-class accuracy, "
-                         "default); fp32 = exact fp32-input MFMA")
+                    help="GEMM arithmetic: f16bf8 (default) = one fp16 MFMA + one block-scaled bf8 MFMA of the cross terms per "
+                         "product in the hidden layers, ~1.3e-5 rel-L2; bf16x3 = split-precision bf16 MFMA, ~5e-6; fp32 = exact "
+                         "fp32-input MFMA.  All accumulate in fp32; the parity bar is 1e-4")
     return ap.parse_args()
 
 
-def bench_train(args, rank, world, dev, topo, feat):
+def _train_run(args, rank, world, dev, topo, feat, precision, steps, warmup):
     """BASELINE configs[4]: minibatches of 64 chunks, one length T~U{200..400} per minibatch (create_egs.py:508-513), 64
-    synthetic speakers, softmax-CE head as in models.py:96-113, Adam; data parallel over ranks with one gradient
-    all-reduce per step.  A step = forward + backward + (all-reduce) + Adam on one resident minibatch per rank."""
+    synthetic speakers, softmax-CE head as in models.py:96-113 (or the build-defined AM-softmax head), Adam; data parallel over
+    ranks with bucketed gradient all-reduces.  A step = forward + backward + (all-reduce) + Adam on one resident minibatch per
+    rank.  Returns the measurements as a dictionary."""
     import torch
     import torch.distributed as dist
     from xvector_amd import synthetic, topology as tp, trainer
     B, n_spk = 64, 64
+    head = args.head
     if args.train_class:
         topo = tp.get(args.train_class)
-        args.head = "am_softmax" if (topo.get("head") or {}).get("type") == "am_softmax" else "softmax"
+        head = "am_softmax" if (topo.get("head") or {}).get("type") == "am_softmax" else "softmax"
     weights = synthetic.reference_init(topo, feat, n_spk, seed=1)
     for k in list(weights):                                   # fan-in scaled start so that activations stay O(1)
         if k.endswith("/w:0") and weights[k].ndim == 3:
             weights[k] = (weights[k] * (np.sqrt(2.0 / (weights[k].shape[0] * weights[k].shape[1])) / 0.1)).astype(np.float32)
     if "attention/w:0" in weights:
         weights["attention/w:0"] = (weights["attention/w:0"] * (np.sqrt(1.0 / weights["attention/w:0"].shape[0]) / 0.1)).astype(np.float32)
-    if args.head == "am_softmax" and not args.train_class:
+    if head == "am_softmax" and not args.train_class:
         topo = tp.get("ModelWithoutDropoutAMSoftmax")        # same network, build-defined additive-margin head
-    tr = trainer.Trainer(weights, topo, dev, precision=args.train_precision)
+    tr = trainer.Trainer(weights, topo, dev, precision=precision)
     rng = np.random.default_rng(1234 + rank)
-    n_total = args.warmup + args.steps
+    n_total = warmup + steps
     spk = rng.standard_normal((n_spk, feat)) * 2
     batches = []
     for _ in range(n_total):
@@ -107,11 +116,11 @@ def bench_train(args, rank, world, dev, topo, feat):
         torch.cuda.synchronize()
 
     losses = []
-    for i in range(args.warmup):
+    for i in range(warmup):
         tr.step(batches[i][0], batches[i][1], 1e-3)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_total):
+    for i in range(warmup, n_total):
         losses.append(tr.step(batches[i][0], batches[i][1], 1e-3)[0])
     fence()
     dt = time.perf_counter() - t0
@@ -119,21 +128,39 @@ def bench_train(args, rank, world, dev, topo, feat):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    frames = sum(b[0].shape[1] for b in batches[args.warmup:]) * B
-    flops = 3.0 * (tp.flops_per_frame(topo, feat) * frames + B * args.steps * (tp.flops_per_utt(topo, 1) + 2 * 512 * n_spk))
+    frames = sum(b[0].shape[1] for b in batches[warmup:]) * B
+    fwd = tp.flops_per_frame(topo, feat) * frames + B * steps * (tp.flops_per_utt(topo, 1) + 2 * 512 * n_spk)
+    # MFMA-pipe time of a step at nominal rates: forward and input-gradient GEMMs in the chosen arithmetic (bf16x3: 3 bf16 MFMAs
+    # per product at 2.5 PF), the weight-gradient GEMM always on the exact fp32 MFMA (157.3 TF)
+    pipe = (2.0 * fwd * (3.0 / MFMA_BF16_PEAK if precision == "bf16x3" else 1.0 / MFMA_F32_PEAK) + fwd / MFMA_F32_PEAK)
+    return {"chunks_per_s": B * world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "steps_per_s": steps / dt, "frames_per_s": frames * world / dt, "approx_tflops_fwd_bwd": 3.0 * fwd * world / dt / 1e12,
+            "mfma_time_over_time": pipe / dt,
+            "peak_note": "3 x forward FLOPs (forward, input gradient, weight gradient); MFMA-pipe time = forward + input gradient "
+                         "at %s + weight gradient at the 157.3 TF fp32 MFMA peak" % ("2.5 PF / 3 (bf16x3)" if precision == "bf16x3" else
+                                                                                    "the 157.3 TF fp32 MFMA peak"),
+            "precision": precision, "head": head, "class": args.train_class or "ModelWithoutDropout",
+            "first_loss": losses[0], "last_loss": losses[-1]}
+
+
+def bench_train(args, rank, world, dev, topo, feat):
+    """``--mode train``: the training step as the headline of its own line."""
+    import torch.distributed as dist
+    r = _train_run(args, rank, world, dev, topo, feat, args.train_precision, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps({
-            "metric": "training chunks/sec (64-chunk minibatches, 200-400 frames, 64-way %s, Adam)" % ("AM-softmax" if args.head == "am_softmax" else "softmax-CE"),
-            "value": B * world * args.steps / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "training chunks/sec (64-chunk minibatches, 200-400 frames, 64-way %s, Adam)" % ("AM-softmax" if r["head"] == "am_softmax" else "softmax-CE"),
+            "value": r["chunks_per_s"], "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.train_precision == "fp32" else "f32 (fwd/dgrad GEMMs as bf16x3 split MFMA, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: training, B=64 chunks/minibatch/GPU, T~U{%d..%d}, 64 speakers, "
-                                   "%s topology, head: %s%s" % (args.tmin, args.tmax, args.train_class or "ModelWithoutDropout", args.head,
-                                   " (scale 30, margin 0.2; build-defined, the reference has softmax-CE only)" if args.head == "am_softmax" else ""),
-                       "parallelism": "data parallel x%d, one bucketed gradient all-reduce per step" % world},
-            "steps_per_s": args.steps / dt, "frames_per_s": frames * world / dt,
-            "approx_tflops_fwd_bwd": flops * world / dt / 1e12, "first_loss": losses[0], "last_loss": losses[-1]}))
+                                   "%s topology, head: %s%s" % (args.tmin, args.tmax, r["class"], r["head"],
+                                   " (scale 30, margin 0.2; build-defined, the reference has softmax-CE only)" if r["head"] == "am_softmax" else ""),
+                       "parallelism": "data parallel x%d, bucketed gradient all-reduces during the backward pass" % world},
+            "steps_per_s": r["steps_per_s"], "frames_per_s": r["frames_per_s"],
+            "approx_tflops_fwd_bwd": r["approx_tflops_fwd_bwd"], "mfma_time_over_time": r["mfma_time_over_time"],
+            "first_loss": r["first_loss"], "last_loss": r["last_loss"]}))
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -195,6 +222,123 @@ def _resident_batches(args, model, lens, dev, feat, seed):
     return order, batches
 
 
+def _mfma_units(model, topo, feat, frames, n_utts):
+    """MFMA-pipe work of one pass in bf16-MFMA FLOP units: a product costs 3 in the bf16x3 arithmetic (first layer, embed FC,
+    every layer of a bf16x3 model), 2 in the f16bf8 arithmetic (one fp16 MFMA at the bf16 rate + one scaled 8-bit MFMA that
+    executes 2 products at twice that rate), and is priced separately (157.3 TF) on the exact-fp32 path."""
+    from xvector_amd import topology as tp
+    prev, units = feat, 0.0
+    pair8 = getattr(model, "pair8", None) is not None
+    for i, (k, c) in enumerate(zip(topo["kernel_sizes"], topo["layer_sizes"])):
+        in_f16bf8 = getattr(model, "f16bf8", False) and ("wp8" in model.layers[i] or (pair8 and i >= len(model.layers) - 2))
+        units += 2.0 * k * prev * c * frames * (2 if in_f16bf8 else 3)
+        prev = c
+    return units + 3.0 * tp.flops_per_utt(topo) * n_utts
+
+
+def _varlen_leg(args, model, weights, topo, dev, feat, with_oracle):
+    """BASELINE configs[2]: T ~ U{25..10000} (one utterance of exactly 25 and one of exactly 10000 frames among them),
+    length-bucketed batches of <= batch_rows rows, chunking at 10000 (every utterance is one chunk), resident in HBM: 1 warm-up
+    + 2 timed passes; parity of the shortest and the longest utterance against the fp64 oracle."""
+    import torch
+    from xvector_amd import hiplib, topology as tp
+    n = 3000
+    rng = np.random.default_rng(25_10000)
+    lens = rng.integers(25, 10001, size=n).astype(np.int64)
+    lens[0], lens[1] = 25, 10000
+    order, batches = _resident_batches(args, model, lens, dev, feat, 4242)
+    frames = int(lens.sum())
+    model.reserve(max(b["rows"] for b in batches), max(b["n"] for b in batches), max(b["max_len"] for b in batches))
+    P = torch.empty((n, model.pooled_dim), dtype=torch.float32, device=dev)
+    E = torch.empty((n, model.embed_dim), dtype=torch.float32, device=dev)
+    steps = 2
+    ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in batches] for _ in range(steps + 1)]
+
+    def one(si):
+        for bi, b in enumerate(batches):
+            model.frame_level(b["x"], b["rs"], b["rl"], b["rv"], b["n"], b["max_len"], P[b["lo"]:b["hi"]], events=ev[si][bi])
+        model.segment_level(P, E)
+    one(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for si in range(1, steps + 1):
+        one(si)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    t_g = sum(e[0].elapsed_time(e[1]) for si in range(1, steps + 1) for e in ev[si]) * 1e-3 / steps
+    fl = tp.flops_per_frame(topo, feat) * frames
+    if model.precision == "fp32":
+        frac = fl / t_g / MFMA_F32_PEAK
+    else:
+        frac = (_mfma_units(model, topo, feat, frames, n) - 3.0 * tp.flops_per_utt(topo) * n) / t_g / MFMA_BF16_PEAK
+    out = {"value": n / dt, "unit": "utt/s", "frames_per_s": frames / dt, "utterances": n, "frames": frames,
+           "batches": len(batches), "ms_per_pass": dt * 1e3, "passes": steps, "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n) / dt / 1e12,
+           "frac": frac,
+           "workload": "BASELINE configs[2]: %d utterances, T ~ U{25..10000} incl. T = 25 and T = 10000, length-bucketed batches of <= %d "
+                       "rows, one chunk per utterance (chunk size 10000)" % (n, args.batch_rows),
+           "frac_note": "MFMA-pipe time of the frame-level launches at nominal rates / their HIP-event time (as roofline.frac)"}
+    if with_oracle:
+        from oracle import oracle
+        pos = {int(u): p for p, u in enumerate(order.tolist())}
+        got = E.cpu().numpy()
+        par = {}
+        for u in (0, 1):
+            p_ = pos[u]
+            b = next(b for b in batches if b["lo"] <= p_ < b["hi"])
+            j = p_ - b["lo"]
+            lay = b["lay"]
+            m = b["x"][int(lay.row_start[j]):int(lay.row_start[j]) + int(lay.row_len[j]), :feat].cpu().numpy()
+            ref = oracle.forward(m, weights, topo, np.float64)
+            par["T=%d" % lens[u]] = oracle.rel_l2(got[p_], ref)
+        out["parity_rel_l2_vs_fp64_oracle"] = par
+    del batches
+    return out
+
+
+def _cli_job_leg(args, ark_path, scp_path, model_dir, n):
+    """One ``extract_embedding.py`` worker job as a user of the reference's extract_xvectors.sh:72-89 would run it -- a fresh
+    process under the package's launcher, scp in, ark,scp out, forced 1-rank RCCL group so that the exchange is on the path --
+    timed from outside (wall) with the job's own breakdown (xvector_amd/jobclock.py).  Run twice: the first RCCL communicator
+    on a box loads librccl's device code cold."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    out_dir = tempfile.mkdtemp(prefix="xv_bench_cli_", dir=os.path.dirname(ark_path))
+    env = dict(os.environ, XV_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", XVECTOR_PRECISION=args.precision,
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "x-vector-kaldi-tf_amd"), os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    runs = []
+    try:
+        for _ in range(2):
+            o_ark, o_scp = os.path.join(out_dir, "xvector.ark"), os.path.join(out_dir, "xvector.scp")
+            for f in (o_ark, o_scp):
+                if os.path.exists(f):
+                    os.remove(f)
+            cmd = [sys.executable, "-m", "xvector_amd.launch", "--nproc", "1",
+                   os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf", "extract_embedding.py"), "--use-gpu", "yes",
+                   "--min-chunk-size", "25", "--chunk-size", "10000", "--feature-rspecifier", "scp:" + scp_path,
+                   "--vector-wspecifier", "ark,scp:%s,%s" % (o_ark, o_scp), "--model-dir", model_dir]
+            t0 = time.perf_counter()
+            run = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            wall = time.perf_counter() - t0
+            log = run.stdout.decode(errors="replace")
+            if run.returncode != 0:
+                return {"error": log[-800:]}
+            clock = [ln for ln in log.splitlines() if "Job wall clock:" in ln]
+            parts = dict((k.strip(" ;["), float(v)) for k, v in re.findall(r"([^,;\[\]]+?) (\d+\.\d+) s", clock[-1].split("Job wall clock:", 1)[1])) if clock else {}
+            with open(o_scp) as f:
+                written = sum(1 for _ in f)
+            runs.append({"wall_s": wall, "utt_per_s": n / wall, "vectors_written": written, "breakdown_s": parts})
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    return {"value": runs[1]["utt_per_s"], "unit": "utt/s", "utterances": n, "wall_s": runs[1]["wall_s"],
+            "breakdown_s": runs[1]["breakdown_s"], "first_job_on_this_box": runs[0],
+            "path": "python -m xvector_amd.launch --nproc 1 extract_embedding.py scp: -> ark,scp: (tmpfs), forced 1-rank RCCL group; wall "
+                    "clock of the whole job from outside, second of two runs"}
+
+
 def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
     """The same step on the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulate), 1 warm-up + 2
     timed passes over the resident batches -- what the bf16x3 default is traded against."""
@@ -223,7 +367,7 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
     fl = tp.flops_per_frame(topo, feat) * frames
     return {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps,
             "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n_utts) / dt / 1e12,
-            "tdnn_gemm_tflops": fl * steps / t_g / 1e12, "frac_of_fp32_mfma_peak_157.3": fl * steps / t_g / MFMA_F32_PEAK,
+            "tdnn_gemm_tflops": fl * steps / t_g / 1e12, "frac": fl * steps / t_g / MFMA_F32_PEAK, "peak_tflops": MFMA_F32_PEAK / 1e12,
             "kernel": "tdnn_gemm_kernel (v_mfma_f32_32x32x2_f32), standalone stats_pool_kernel"}
 
 
@@ -262,9 +406,10 @@ def _bf16x3_leg(args, weights, topo, dev, batches, n_utts, frames, feat, order, 
     return out
 
 
-def _e2e_leg(args, weights, topo, feat):
+def _e2e_leg(args, weights, topo, feat, with_cli):
     """ark bytes in RAM -> Model.make_embedding (reader thread, native packer, H2D, kernels, D2H, writer thread) -> ark bytes:
-    the PCIe- and parsing-inclusive rate of the drop-in entry point, model load included."""
+    the PCIe- and parsing-inclusive rate of the drop-in entry point, model load included.  Returns (e2e record, cli_job record
+    or None): the same features, as an ark + scp on tmpfs, also go through one worker job of the CLI."""
     import io
     import logging
     import shutil
@@ -277,15 +422,19 @@ def _e2e_leg(args, weights, topo, feat):
     lens = synthetic.utterance_lengths(n, args.tmin, args.tmax, 4321)
     rng = np.random.default_rng(4321)
     pool = [(rng.standard_normal((args.tmax, feat)) * 3.0).astype(np.float32) for _ in range(257)]
-    src = io.BytesIO()
-    for i in range(n):
-        kaldi_io.write_mat(src, pool[i % 257][:lens[i]], key="utt%07d" % i)
-    data = src.getvalue()
-    del src
-    tmp = tempfile.mkdtemp(prefix="xv_bench_e2e_")
+    shm_ok = os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK)
+    work = tempfile.mkdtemp(prefix="xv_bench_e2e_", dir="/dev/shm" if shm_ok else None)
+    fpath, spath = os.path.join(work, "feats.ark"), os.path.join(work, "feats.scp")
+    with kaldi_io.TableWriter(fpath, spath) as tw:
+        for i in range(n):
+            kaldi_io.write_mat(tw, pool[i % 257][:lens[i]], key="utt%07d" % i)
+    with open(fpath, "rb") as f:
+        data = f.read()
+    tmp = os.path.join(work, "nnet")
     log = logging.getLogger("bench_e2e")
     log.addHandler(logging.NullHandler())
     log.propagate = False
+    cli = None
     try:
         models.Model.save_model(dict(weights=weights, topology=topo, model_class="ModelWithoutDropout", num_classes=64, feat_dim=feat),
                                 tmp, None)
@@ -293,50 +442,59 @@ def _e2e_leg(args, weights, topo, feat):
         for _ in range(4):                                         # the first pass also pins the staging buffers and faults the read arenas in
             out = io.BytesIO()
             t0 = time.perf_counter()
-            models.Model().make_embedding(io.BytesIO(data), out, tmp, 25, 10000, True, log)
+            model = models.Model()
+            model.make_embedding(io.BytesIO(data), out, tmp, 25, 10000, True, log)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
+        stats = getattr(model, "last_stats", {})
         nvec = out.getbuffer().nbytes // (len("utt0000000") + 1 + 2 + 3 + 1 + 4 + 512 * 4)
         # the same ark as a FILE in RAM (tmpfs): read() of a file releases the interpreter lock, the memcpy out of a BytesIO does
         # not -- this is what `extract_embedding.py ark:feats.ark ...` on a page-cached file sees
-        shm = None
-        if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
-            fpath = os.path.join(tempfile.mkdtemp(prefix="xv_bench_e2e_", dir="/dev/shm"), "feats.ark")
+        fbest = None
+        for _ in range(3):
+            out = io.BytesIO()
+            t0 = time.perf_counter()
+            with open(fpath, "rb", buffering=0) as f:
+                models.Model().make_embedding(f, out, tmp, 25, 10000, True, log)
+            dt = time.perf_counter() - t0
+            fbest = dt if fbest is None else min(fbest, dt)
+        shm = {"value": n / fbest, "unit": "utt/s", "seconds": fbest, "input": "the same ark as a file on %s" % ("tmpfs (/dev/shm)" if shm_ok else "disk")}
+        if with_cli:
             try:
-                with open(fpath, "wb") as f:
-                    f.write(data)
-                fbest = None
-                for _ in range(3):
-                    out = io.BytesIO()
-                    t0 = time.perf_counter()
-                    with open(fpath, "rb", buffering=0) as f:
-                        models.Model().make_embedding(f, out, tmp, 25, 10000, True, log)
-                    dt = time.perf_counter() - t0
-                    fbest = dt if fbest is None else min(fbest, dt)
-                shm = {"value": n / fbest, "unit": "utt/s", "seconds": fbest, "input": "the same ark as a file on tmpfs (/dev/shm)"}
-            finally:
-                shutil.rmtree(os.path.dirname(fpath), ignore_errors=True)
+                cli = _cli_job_leg(args, fpath, spath, tmp, n)
+            except Exception as e:                                 # a sub-record must not take the line down
+                cli = {"error": repr(e)}
     finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        shutil.rmtree(work, ignore_errors=True)
     res = {"value": n / best, "unit": "utt/s", "utterances": n, "vectors_written": int(nvec), "seconds": best,
            "ark_gb_in": len(data) / 1e9, "ark_gb_per_s": len(data) / 1e9 / best,
+           "run_time_accuracy_probe": {k: stats.get(k) for k in ("probe_windows", "probe_rel_l2_max", "demoted") if k in stats},
            "path": "ark bytes in host RAM (io.BytesIO) -> Model.make_embedding(min_chunk 25, chunk 10000) -> ark bytes in host RAM, "
-                   "incl. model load, Kaldi parsing, packing, H2D, D2H and FV serialisation; best of 4 passes"}
-    if shm is not None:
-        res["from_tmpfs_file"] = shm
-    return res
+                   "incl. model load + accuracy probes, Kaldi parsing, packing, H2D, D2H and FV serialisation; best of 4 passes",
+           "from_tmpfs_file": shm}
+    return res, cli
 
 
 def main():
     args = parse()
+    # `python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks ourselves -- one process per GPU, the environment
+    # contract of torch.distributed.run (xvector_amd/launch.py) -- and leave with the job's exit code
+    from xvector_amd import launch
+    rc = launch.relaunch_self_as_ranks(args.gpus)
+    if rc is not None:
+        raise SystemExit(rc)
     import torch
     import torch.distributed as dist
     from xvector_amd import dist as xdist, engine, hiplib, synthetic, topology as tp
 
-    rank, world = xdist.init_process_group()
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_env))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    visible = torch.cuda.device_count()
+    if visible < args.gpus or local >= visible:
+        raise SystemExit("bench.py: %d GPUs requested, %d visible" % (args.gpus, visible))
+    rank, world = xdist.init_process_group()
     hiplib.require_gpu()
     dev = torch.device("cuda:%d" % local)
     torch.cuda.set_device(dev)
@@ -346,8 +504,13 @@ def main():
     if args.mode == "train":
         return bench_train(args, rank, world, dev, topo, feat)
     weights = synthetic.trained_like(topo, feat, seed=1)
-    model = engine.DeviceModel(weights, topo, dev, precision=args.precision,
-                               fused_pool=(args.precision in ("bf16x3", "f16bf8") and not args.no_fused_pool))
+    if args.no_fused_pool:
+        model = engine.DeviceModel(weights, topo, dev, precision=args.precision, fused_pool=False)
+    else:
+        # the arithmetic is admitted per checkpoint (load-time accuracy probe, engine.select_model); what was measured goes into
+        # the line.  A model the probe moved off f16bf8 would run -- and be reported -- in the arithmetic it was moved to.
+        model = engine.select_model(weights, topo, dev, precision=args.precision)
+    selection = dict(getattr(model, "selection", None) or {})
 
     # ---- synthetic workload resident in HBM: ragged batches in kernel layout -------------------
     lens = synthetic.utterance_lengths(args.utts, args.tmin, args.tmax, 1234 + rank)
@@ -365,6 +528,7 @@ def main():
     n_steps_total = args.warmup + args.steps
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in batches] for _ in range(n_steps_total)]
     ev_fc = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(n_steps_total)]
+    ev_g = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(n_steps_total)]
 
     def step(si):
         for bi, b in enumerate(batches):
@@ -374,7 +538,10 @@ def main():
         ev_fc[si][1].record()
         hiplib.chunk_average(E_all, seg, clen, n_utts, xvec)
         if dist.is_initialized():
-            return xdist.gather_blocks(xvec, counts, 0)
+            ev_g[si][0].record()
+            got = xdist.gather_blocks(xvec, counts, 0)
+            ev_g[si][1].record()
+            return got
         return [xvec]
 
     def fence():
@@ -446,7 +613,7 @@ def main():
         return
 
     traffic, traffic_src = _traffic(args.batch_rows)
-    if args.precision == "fp32":
+    if model.precision == "fp32":
         kern = {"kernel": "tdnn_gemm_kernel<true> (5 TDNN layers per batch + embed FC per step)",
                 "peak": MFMA_F32_PEAK / 1e12, "frac": fl_gemm / t_gemm / MFMA_F32_PEAK,
                 "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"}
@@ -454,13 +621,8 @@ def main():
         # MFMA time a product costs, in bf16-MFMA units: 3 in the bf16x3 arithmetic (first layer, pair kernel, embed FC);
         # 2 in the f16bf8 arithmetic (one fp16 MFMA at the bf16 rate + one scaled 8-bit MFMA that executes 2 products at
         # twice that rate).  frac = MFMA-pipe time at nominal rates / measured kernel time.
-        prev, units = feat, 0.0
         pair8 = getattr(model, "pair8", None) is not None
-        for i, (k, c) in enumerate(zip(topo["kernel_sizes"], topo["layer_sizes"])):
-            in_f16bf8 = "wp8" in model.layers[i] or (pair8 and i >= len(model.layers) - 2)
-            units += 2.0 * k * prev * c * frames * (2 if in_f16bf8 else 3)
-            prev = c
-        units = (units + 3.0 * tp.flops_per_utt(topo) * n_utts) * args.steps
+        units = _mfma_units(model, topo, feat, frames, n_utts) * args.steps
         kern = {"kernel": "tdnn_first_kernel (layer 0, bf16x3) + tdnn_gemm_f16bf8_wide_kernel (layers 1-2: fp16 MFMA + scaled bf8 MFMA "
                           "per product) + %s (layers 3+4 chained in registers, pooling statistics in its "
                           "epilogue) per batch, embed FC (bf16x3) per step" %
@@ -512,7 +674,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32" if args.precision == "fp32" else
+        "dtype": ("f32" if model.precision == "fp32" else
                   "f32 in/out, f32 accumulate; GEMM products as fp16 MFMA + 2^-11 x scaled bf8 MFMA of the cross terms (layers 1-4) "
                   "and bf16x3 split MFMA (layer 0, FC)" if getattr(model, "f16bf8", False) else
                   "f32 in/out, GEMMs as bf16x3 split MFMA (hi*hi+hi*lo+lo*hi) with f32 accumulate"),
@@ -520,7 +682,8 @@ def main():
         "config": {"workload": "BASELINE configs[1]: %d utts/GPU, 23-dim MFCC, T~U{%d..%d}, default x-vector topology "
                                "[512,512,512,512,1536] k=[5,5,7,1,1], 512-d embed_layer-0" % (n_utts, args.tmin, args.tmax),
                    "utts_per_gpu": n_utts, "frames_per_gpu": frames, "batches_per_step": len(batches),
-                   "batch_rows": args.batch_rows, "precision": args.precision, "fused_pool": bool(model.fused_pool),
+                   "batch_rows": args.batch_rows, "precision": selection.get("selected", args.precision),
+                   "precision_requested": args.precision, "fused_pool": bool(model.fused_pool),
                    "pair_kernel": paired, "dist_initialized": bool(dist.is_initialized()),
                    "parallelism": "utterance-sharded x%d, one RCCL gather" % world},
         "frames_per_s": frames * world * args.steps / dt,
@@ -529,12 +692,22 @@ def main():
                           "traffic_source": traffic_src,
                           "avg_launch_ms": t_gemm / n_gemm_launch * 1e3, "launches": n_gemm_launch,
                           "algorithmic_gflop_per_launch": fl_gemm / n_gemm_launch / 1e9,
-                          "frac_of_fp32_mfma_peak_157.3": fl_gemm / t_gemm / MFMA_F32_PEAK}, **kern),
+                          # how many times the fp32-MFMA ceiling (157.3 TF: what exact fp32 products could reach at most) the
+                          # algorithmic rate is -- a speed-up over that ceiling, not a roofline fraction
+                          "algorithmic_rate_over_fp32_mfma_ceiling": fl_gemm / t_gemm / MFMA_F32_PEAK}, **kern),
         "roofline_pool": {"kernel": pool_kernel, "bound": "hbm", "achieved": by_pool / t_pool / 1e9,
                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": by_pool / t_pool / HBM_PEAK,
                           "avg_launch_ms": t_pool / pool_launches * 1e3,
                           "algorithmic_mb_per_launch": by_pool / pool_launches / 1e6},
     }
+    out["accuracy_probe"] = dict(selection, note="engine.select_model: x-vectors of a fixed MFCC-like batch through these weights in "
+                                 "f16bf8 vs bf16x3 (kept when <= f16bf8_limit), then bf16x3 vs exact fp32 if that failed")
+    out["rccl_ranks"] = dist.get_world_size() if dist.is_initialized() else 0
+    if dist.is_initialized():
+        g = [ev_g[si][0].elapsed_time(ev_g[si][1]) for si in range(args.warmup, n_steps_total)]
+        out["gather_ms"] = float(np.mean(g))
+        out["gather_note"] = "HIP-event time of xdist.gather_blocks (ONE dist.gather of the [%d, %d] fp32 blocks to rank 0) per step, " \
+                             "rank 0's stream" % (n_utts, model.embed_dim)
     if model.fused_pool:
         rows_total = sum(b["rows"] for b in batches)
         by_blk = ((rows_total + 7) // 8 * 2 * C * 4 + 4 * 2 * C * n_utts) * args.steps
@@ -544,15 +717,21 @@ def main():
 
     if args.cpu_budget > 0:
         from oracle import oracle
-        # parity spot check (oracle as the checker): a few utterances of the resident workload
-        picks = np.linspace(0, batches[0]["n"] - 1, args.parity_utts).astype(int)
-        lay = batches[0]["lay"]
-        refs = [oracle.embed_utterance(batches[0]["x"][int(lay.row_start[j]):int(lay.row_start[j]) + int(lay.row_len[j]), :feat].cpu().numpy(),
-                                       weights, topo, 25, 10000, np.float64) for j in picks]
+        # parity check (oracle as the checker): utterances spread evenly over ALL batches of the step (positions in the
+        # length-sorted order: the shortest and the longest utterance of the workload are among them)
+        picks = sorted(set(np.linspace(0, n_utts - 1, max(2, args.parity_utts)).astype(int).tolist()))
+        refs = []
+        for p_ in picks:
+            b = next(b for b in batches if b["lo"] <= p_ < b["hi"])
+            j, lay = p_ - b["lo"], b["lay"]
+            m = b["x"][int(lay.row_start[j]):int(lay.row_start[j]) + int(lay.row_len[j]), :feat].cpu().numpy()
+            refs.append(oracle.embed_utterance(m, weights, topo, 25, 10000, np.float64))
 
-        def parity_check(vectors):                     # vectors[j] = x-vector of utterance j of the first batch
-            got = vectors[:batches[0]["n"]].cpu().numpy()
-            return max(oracle.rel_l2(got[j], r) for j, r in zip(picks, refs))
+        def parity_check(vectors):                     # vectors[p] = x-vector of the utterance at sorted position p
+            got = vectors.cpu().numpy()
+            return max(oracle.rel_l2(got[p_], r) for p_, r in zip(picks, refs))
+        out["parity_utterances"] = len(picks)
+        out["parity_batches_covered"] = len(set(next(i for i, b in enumerate(batches) if b["lo"] <= p_ < b["hi"]) for p_ in picks))
         out["parity_rel_l2_max_vs_fp64_oracle"] = parity_check(xvec)
     if args.cpu_budget > 0 and world == 1:
         from oracle import oracle, torch_ref
@@ -587,9 +766,9 @@ def main():
                                              "cores": 2 * nproc, "host_logical_cores": logical, "container_granted_cores": granted,
                                              "shape": "nj independent extractor processes x 2 intra-op threads, as run.sh:229-247 / "
                                                       "extract_xvectors.sh:83-88 deploy the reference (models.py:361-363)"}}
-    if world == 1 and args.precision != "fp32" and not args.no_fp32_leg:
+    if world == 1 and model.precision != "fp32" and not args.no_fp32_leg:
         out["fp32_exact"] = _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat)
-        if args.precision == "f16bf8":
+        if getattr(model, "f16bf8", False):
             out["bf16x3"] = _bf16x3_leg(args, weights, topo, dev, batches, n_utts, frames, feat, order,
                                         parity_check if args.cpu_budget > 0 else None)
     # ---- BASELINE configs[3] asks for the rate "incl. and excl. ark write": rank 0 writes the gathered x-vectors of ONE step
@@ -612,14 +791,34 @@ def main():
                                      "note": "D2H of the gathered [N,512] block + Kaldi ark,scp write by rank 0, serial after the step"}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    if world == 1 and args.e2e_utts > 0 and args.precision != "fp32":
+    extra = world == 1 and not args.no_extra_legs and model.precision != "fp32"
+    if extra:
+        # BASELINE configs[2] and configs[4] at one rank's share, time-boxed: a couple of passes / ten steps each
+        try:
+            out["config2_varlen"] = _varlen_leg(args, model, weights, topo, dev, feat, args.cpu_budget > 0)
+        except Exception as e:                                     # a sub-record must not take the line down
+            out["config2_varlen"] = {"error": repr(e)}
+    if world == 1 and args.e2e_utts > 0 and model.precision != "fp32":
         del batches, E_all, P_all
         os.environ["XVECTOR_PRECISION"] = args.precision          # Model.load_model reads it
-        e2e = _e2e_leg(args, weights, topo, feat)
+        e2e, cli = _e2e_leg(args, weights, topo, feat, extra)
         e2e["fraction_of_resident_rate"] = e2e["value"] / out["value"]
         if "from_tmpfs_file" in e2e:
             e2e["from_tmpfs_file"]["fraction_of_resident_rate"] = e2e["from_tmpfs_file"]["value"] / out["value"]
         out["e2e_ark_to_ark"] = e2e
+        if cli is not None:
+            out["cli_job"] = cli
+    if extra:
+        try:
+            torch.cuda.empty_cache()
+            tr = {}
+            for prec in ("fp32", "bf16x3"):
+                tr[prec] = _train_run(args, 0, 1, dev, tp.get("ModelWithoutDropout"), feat, prec, 10, 2)
+            out["train_step"] = dict(tr["bf16x3"], fp32=tr["fp32"],
+                                     workload="BASELINE configs[4], one rank's share: 64-chunk minibatches, T ~ U{%d..%d}, 64 speakers, "
+                                              "AM-softmax head, Adam; 10 timed steps after 2" % (args.tmin, args.tmax))
+        except Exception as e:
+            out["train_step"] = {"error": repr(e)}
     print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -39,7 +39,8 @@ def test_extraction_bench_line():
     assert c["reference_faithful_2_threads"] > 0 and c["value"] >= max(a["value"], c["reference_faithful_2_threads"]) * 0.999
     # exact-fp32 sub-record and the PCIe / parsing-inclusive ark -> ark rate ride on the same line; neither is `value`
     f = d["fp32_exact"]
-    assert f["unit"] == "utt/s" and 0 < f["value"] < d["value"] and 0 < f["frac_of_fp32_mfma_peak_157.3"] < 1
+    assert f["unit"] == "utt/s" and 0 < f["value"] < d["value"] and 0 < f["frac"] < 1 and f["peak_tflops"] == pytest.approx(157.3)
+    assert r["algorithmic_rate_over_fp32_mfma_ceiling"] > 0 and not any(k.startswith("frac_of_fp32") for k in r)
     # the all-bf16x3 arithmetic (round 1's default, the twin of the f16bf8 default) in the same run, with its own parity figure
     assert d["config"]["precision"] == "f16bf8"
     b = d["bf16x3"]
@@ -47,12 +48,27 @@ def test_extraction_bench_line():
     e = d["e2e_ark_to_ark"]
     assert e["utterances"] == 700 and e["vectors_written"] == 700 and e["value"] > 0
     assert e["fraction_of_resident_rate"] == pytest.approx(e["value"] / d["value"])
+    assert e["run_time_accuracy_probe"]["probe_windows"] >= 1 and e["run_time_accuracy_probe"]["demoted"] is False
+    # the arithmetic was admitted by the load-time probe, and the line says what it measured
+    p = d["accuracy_probe"]
+    assert p["probed"] and p["requested"] == p["selected"] == "f16bf8" and 0 < p["f16bf8_vs_bf16x3"] <= p["f16bf8_limit"] == 2e-5
+    assert d["parity_utterances"] == 2 and d["rccl_ranks"] == 0 and "gather_ms" not in d
+    # one rank's share of BASELINE configs[2] and configs[4], and the wall clock of one CLI worker job, on the same line
+    v = d["config2_varlen"]
+    assert v["unit"] == "utt/s" and v["value"] > 0 and v["frames_per_s"] > v["value"] * 25 and 0 < v["frac"] < 1 and v["batches"] > 10
+    assert set(v["parity_rel_l2_vs_fp64_oracle"]) == {"T=25", "T=10000"} and max(v["parity_rel_l2_vs_fp64_oracle"].values()) < 1e-4
+    t = d["train_step"]
+    assert t["precision"] == "bf16x3" and 0 < t["ms_per_step"] < t["fp32"]["ms_per_step"] * 1.2 and t["chunks_per_s"] > 0
+    assert 0 < t["mfma_time_over_time"] < 1 and 0 < t["fp32"]["mfma_time_over_time"] < 1 and t["last_loss"] < t["first_loss"]
+    j = d["cli_job"]
+    assert j["utterances"] == 700 and j["first_job_on_this_box"]["vectors_written"] == 700 and 0 < j["wall_s"] < 60
+    assert j["breakdown_s"]["total"] <= j["wall_s"] and "import torch" in j["breakdown_s"] and "gather" in j["breakdown_s"]
 
 
 def test_bench_at_the_per_rank_size_of_the_million_utterance_job():
     """BASELINE configs[3] gives every one of 8 ranks 125 k utterances: the resident-input step at that size (37.5 M frames,
     ~145 batches) on one GPU."""
-    d = _run("--utts", "125000", "--steps", "1", "--warmup", "0", "--cpu-budget", "0", "--e2e-utts", "0", "--no-fp32-leg")
+    d = _run("--utts", "125000", "--steps", "1", "--warmup", "0", "--cpu-budget", "0", "--e2e-utts", "0", "--no-fp32-leg", "--no-extra-legs")
     assert d["config"]["utts_per_gpu"] == 125000 and d["config"]["batches_per_step"] > 100
     assert 36e6 < d["config"]["frames_per_gpu"] < 39e6 and d["value"] > 20000 and "fp32_exact" not in d and "e2e_ark_to_ark" not in d
     assert d["with_ark_write"]["ark_mb"] > 250
@@ -60,6 +76,7 @@ def test_bench_at_the_per_rank_size_of_the_million_utterance_job():
 
 def test_fp32_and_training_bench_lines():
     d = _run("--utts", "300", "--steps", "1", "--warmup", "1", "--cpu-budget", "0", "--precision", "fp32")
+    assert d["accuracy_probe"]["probed"] is False and "config2_varlen" not in d
     assert d["dtype"] == "f32" and d["roofline"]["peak"] == pytest.approx(157.3) and d["config"]["fused_pool"] is False
     t = _run("--mode", "train", "--steps", "3", "--warmup", "1")
     assert t["unit"] == "chunks/s" and t["value"] > 0 and t["last_loss"] > 0 and "AM-softmax" in t["metric"]

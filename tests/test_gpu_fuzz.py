@@ -115,7 +115,9 @@ def test_random_topologies_in_the_f16bf8_arithmetic(oracle_mod, seed):
         # the random draw can also hit without asking for it)
         expect_pair = ks[-1] == 1 and ks[-2] == 1 and widths[-2] == 512 and widths[-3] % 32 == 0 and widths[-1] % 64 == 0
         assert model.f16bf8 and (model.pair8 is not None) == expect_pair, topo
-        ex = engine.Extractor(model, mn, cs, max_batch_rows=int(rng.choice([700, 262144])))
+        # (the run-time accuracy probe is off: this test is about what the f16bf8 kernels themselves deliver -- on these narrow
+        # random networks the probe's 3e-5 limit would move some of them to bf16x3, which is its job)
+        ex = engine.Extractor(model, mn, cs, max_batch_rows=int(rng.choice([700, 262144])), accuracy_probe=False)
         got = ex.extract(mats)
         assert ex.stats.get("fallback_windows", 0) == 0
         for g, r in zip(got, refs):

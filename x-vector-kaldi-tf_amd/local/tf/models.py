@@ -54,6 +54,22 @@ class _Cancelled(Exception):
     pass
 
 
+_SELECTED = {}           # checkpoint identity + request -> engine.select_model's report (see Model.load_model)
+
+
+def _checkpoint_identity(model_dir):
+    """(path, mtime_ns, size) of every weight-bearing file of a model directory, or (None,) when there is nothing to stat."""
+    ident = []
+    for name in ("model.weights.npz", "model.index", "model.data-00000-of-00001"):
+        path = os.path.join(model_dir, name)
+        try:
+            st = os.stat(path)
+            ident.append((os.path.realpath(path), st.st_mtime_ns, st.st_size))
+        except OSError:
+            pass
+    return (tuple(ident) or None,)
+
+
 class _Held(object):
     """Keeps a gathered block alive as the holder of an ``ArkMats`` piece and hands out its utterances as views."""
 
@@ -135,8 +151,19 @@ class Model(object):
         # The arithmetic is chosen PER CHECKPOINT: engine.select_model runs a small fixed batch through the loaded weights in
         # the requested arithmetic and in the next more exact one and steps down (f16bf8 -> bf16x3 -> fp32) when they disagree by
         # more than the probe limits (2e-5 / 4e-5; the parity bar is 1e-4).  XVECTOR_ACCURACY_PROBE=0 takes the request as given.
+        # The verdict is a property of the checkpoint: a process that loads the same files again (a service, bench.py's repeated
+        # passes) re-uses it instead of probing again (keyed by the weight file's identity, the request and the limits).
         self.precision = os.environ.get("XVECTOR_PRECISION", "f16bf8")
-        self.device_model = engine.select_model(w, meta["topology"], _device(), self.embedding_index, self.precision)
+        key = _checkpoint_identity(input_dir) + (self.precision, self.embedding_index, _device(), engine.PROBE_LIMIT_F16BF8,
+                                                 engine.PROBE_LIMIT_BF16X3, os.environ.get("XVECTOR_ACCURACY_PROBE", "1"))
+        known = _SELECTED.get(key)
+        if known is not None:
+            self.device_model = engine.DeviceModel(w, meta["topology"], _device(), self.embedding_index, known["selected"])
+            self.device_model.selection = dict(known, cached=True)
+        else:
+            self.device_model = engine.select_model(w, meta["topology"], _device(), self.embedding_index, self.precision)
+            if key[0] is not None:
+                _SELECTED[key] = dict(getattr(self.device_model, "selection", None) or {})
         sel = getattr(self.device_model, "selection", None) or {}
         if logger is not None:
             if sel.get("probed"):
