@@ -178,8 +178,12 @@ def _tf_dir(tmp_path, class_written, meta_bytes, name_file=None, seed=5):
     return str(mdir), w
 
 
-GRAPH_RELU = b"\x0a\x10frame_level_info_layer-0/conv1d\x12\x06Conv2D\x0a\x04Relu"
-GRAPH_LRELU = GRAPH_RELU + b"\x0a\x09LeakyRelu"
+GRAPH_BODY = b"\x0a\x1fframe_level_info_layer-0/conv1d\x12\x06Conv2D"
+GRAPH_RELU = GRAPH_BODY + b"\x0a\x1dframe_level_info_layer-0/relu\x12\x04Relu"                 # tf.nn.relu(h, name="relu")
+GRAPH_LRELU = GRAPH_BODY + b"\x0a\x1eframe_level_info_layer-0/lrelu\x12\x09LeakyRelu"         # TF >= 1.13: fused op
+# TF 1.4-1.12 (the reference's time): leaky_relu is mul + Maximum under the scope 'lrelu' -- no "LeakyRelu" anywhere
+GRAPH_LRELU_COMPOSITE = GRAPH_BODY + b"\x0a\x22frame_level_info_layer-0/lrelu/mul\x12\x03Mul" \
+    b"\x0a\x26frame_level_info_layer-0/lrelu/Maximum\x12\x07Maximum"
 
 
 def test_wrong_or_missing_model_class_is_refused(tmp_path, monkeypatch, caplog):
@@ -203,6 +207,20 @@ def test_wrong_or_missing_model_class_is_refused(tmp_path, monkeypatch, caplog):
     d, _ = _tf_dir(tmp_path, "ModelWithoutDropout", GRAPH_RELU, name_file="ModelL2LossWithoutDropoutLRelu")
     with pytest.raises(ValueError, match="LeakyRelu"):
         wio.load_model_dir(d)
+    # the composite form of the reference's own TensorFlow: a correctly stated LeakyReLU class loads, a ReLU claim is refused,
+    # and without a stated class it is inferred as LeakyReLU (not silently as ReLU)
+    d, _ = _tf_dir(tmp_path, "ModelL2LossWithoutDropoutLRelu", GRAPH_LRELU_COMPOSITE, name_file="ModelL2LossWithoutDropoutLRelu")
+    assert wio.load_model_dir(d)[1]["topology"]["activation"] == "lrelu"
+    d, _ = _tf_dir(tmp_path, "ModelL2LossWithoutDropoutLRelu", GRAPH_LRELU_COMPOSITE, name_file="ModelWithoutDropout")
+    with pytest.raises(ValueError, match="LeakyRelu"):
+        wio.load_model_dir(d)
+    d, _ = _tf_dir(tmp_path, "ModelL2LossWithoutDropoutLRelu", GRAPH_LRELU_COMPOSITE)
+    assert wio.load_model_dir(d)[1]["topology"]["activation"] == "lrelu"
+    # a graph that names the layers but shows neither node is inconclusive: a stated class is taken at its word (warning) ...
+    d, _ = _tf_dir(tmp_path, "ModelL2LossWithoutDropoutLRelu", GRAPH_BODY, name_file="ModelL2LossWithoutDropoutLRelu")
+    with caplog.at_level("WARNING"):
+        assert wio.load_model_dir(d)[1]["topology"]["activation"] == "lrelu"
+    assert "at its word" in caplog.text
     # no class stated: the checkpoint's own evidence picks it (and says so) ...
     d, _ = _tf_dir(tmp_path, "ModelL2LossWithoutDropoutLRelu", GRAPH_LRELU)
     with caplog.at_level("WARNING"):
@@ -239,6 +257,16 @@ def test_adam_slots_of_a_tf_checkpoint_resume(tmp_path):
     write_bundle(str(mdir / "model"), arrays)
     adam = wio.load_optimizer_state(str(mdir))
     assert adam["t"] == 37
+    # long runs: 0.9**t underflows float32 (denormal from ~830, zero from ~985) -- the count comes from beta2_power, and when
+    # both powers are gone it is "large" (bias corrections 1), never 0
+    from xvector_amd import tf_checkpoint
+    for t_true in (5, 399, 900, 5000, 60000):
+        got = tf_checkpoint.optimizer_state_from_bundle(dict(arrays, beta1_power=np.float32(0.9) ** np.float32(t_true),
+                                                             beta2_power=np.float32(0.999 ** t_true)))["t"]
+        assert abs(got - t_true) <= max(1, t_true // 200), (t_true, got)
+    gone = tf_checkpoint.optimizer_state_from_bundle(dict(arrays, beta1_power=np.float32(0), beta2_power=np.float32(0)))
+    assert gone["t"] == tf_checkpoint.UNDERFLOWED_STEP_COUNT
+    assert tf_checkpoint.optimizer_state_from_bundle(dict(arrays, beta1_power=np.float32(1), beta2_power=np.float32(1)))["t"] == 0
     assert np.array_equal(adam["m"]["embed_layer-0/w:0"], arrays["embed_layer-0/w/Adam"])
     assert np.array_equal(adam["v"]["frame_level_info_layer-2/gamma:0"], arrays["frame_level_info_layer-2/gamma/Adam_1"])
     assert set(adam["m"]) == set(adam["v"]) == {k + ":0" for k in arrays if k + "/Adam" in arrays}

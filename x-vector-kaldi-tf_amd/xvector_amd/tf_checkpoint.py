@@ -220,8 +220,12 @@ def extraction_signature(topo):
 
 def infer_signature(arrays, metagraph=b""):
     """The same tuple read off a checkpoint: kernel sizes / widths from the variable shapes, PReLU and attention from their
-    variables, LeakyReLU from the op / name-scope token ``LeakyRelu`` that ``tf.nn.leaky_relu`` (models.py:912) leaves in
-    the MetaGraphDef ``model.meta`` -- the bundle alone cannot tell LeakyReLU from ReLU."""
+    variables; ReLU vs LeakyReLU only shows in the MetaGraphDef ``model.meta`` -- the bundle alone cannot tell them apart.
+    ``tf.nn.leaky_relu(h, alpha=0.2, name='lrelu')`` (models.py:912) is a fused ``LeakyRelu`` op from TF 1.13 on and, in the
+    TensorFlow of the reference's time (1.4-1.12), a COMPOSITE of ``mul`` + ``Maximum`` under the name scope ``lrelu`` -- no op
+    type and no node name contains "LeakyRelu" there -- so both the op token and the scope token ``<layer>/lrelu`` count as
+    LeakyReLU evidence; ``tf.nn.relu(h, name="relu")`` (models.py:64) leaves the node ``<layer>/relu``.  A graph that shows
+    neither is inconclusive (None): an absence is not evidence."""
     kernels, widths, embeds = [], [], []
     i = 0
     while "frame_level_info_layer-%d/w" % i in arrays:
@@ -234,10 +238,10 @@ def infer_signature(arrays, metagraph=b""):
         j += 1
     if any(n.endswith("/prelu/prelu") for n in arrays):
         act = "prelu"
-    elif b"LeakyRelu" in metagraph:
+    elif b"LeakyRelu" in metagraph or b"frame_level_info_layer-0/lrelu" in metagraph:
         act = "lrelu"
-    elif b"frame_level_info_layer-0" in metagraph:
-        act = "relu"                 # a real graph (it names the model's nodes) without a LeakyRelu anywhere
+    elif b"frame_level_info_layer-0/relu" in metagraph:
+        act = "relu"
     else:
         act = None                   # no usable graph: ReLU and LeakyReLU checkpoints look the same
     pooling = "attention" if any(n.startswith("attention/") for n in arrays) else "stats"
@@ -287,16 +291,34 @@ def weights_from_bundle(arrays, class_name):
     return w, topo, num_classes, feat_dim
 
 
+UNDERFLOWED_STEP_COUNT = 1000000
+
+
 def optimizer_state_from_bundle(arrays):
     """Adam state of a reference-written checkpoint in the form weights.load_optimizer_state returns: ``<var>/Adam`` is the
-    first moment, ``<var>/Adam_1`` the second, and the step count follows from ``beta1_power = 0.9**t`` (TF keeps the power,
-    not the count).  None when the bundle has no slots (a model written before any training step)."""
+    first moment, ``<var>/Adam_1`` the second.  TF keeps the POWERS ``beta1_power = 0.9**t`` / ``beta2_power = 0.999**t`` as
+    float32 scalars, not the count: 0.9**t is denormal from t ~ 830 and zero from t ~ 985 -- any checkpoint past its first
+    few hundred steps -- so the count is read off ``beta2_power`` (usable to t ~ 87 k), from ``beta1_power`` only while that is
+    a normal float32, and once both have underflowed it is "large": the bias corrections 1 - beta**t are 1 by then, which is
+    what TF itself computes from the zero powers (t = 0 would re-apply the first steps' correction of 0.15-0.3 x the learning
+    rate for hundreds of steps).  None when the bundle has no slots (a model written before any training step)."""
     m = {n[:-len("/Adam")] + ":0": np.asarray(a, np.float32) for n, a in arrays.items() if n.endswith("/Adam")}
     v = {n[:-len("/Adam_1")] + ":0": np.asarray(a, np.float32) for n, a in arrays.items() if n.endswith("/Adam_1")}
     if not m or "beta1_power" not in arrays:
         return None
-    p = float(np.asarray(arrays["beta1_power"]).reshape(-1)[0])
-    t = int(round(np.log(p) / np.log(0.9))) if 0.0 < p < 1.0 else 0
+    tiny = float(np.finfo(np.float32).tiny)
+    p1 = float(np.asarray(arrays["beta1_power"]).reshape(-1)[0])
+    p2 = float(np.asarray(arrays["beta2_power"]).reshape(-1)[0]) if "beta2_power" in arrays else None
+    if p1 >= 1.0 and (p2 is None or p2 >= 1.0):
+        t = 0                                                   # slots exist but no step was taken
+    elif p2 is not None and tiny <= p2 < 1.0:
+        t = int(round(np.log(p2) / np.log(0.999)))
+        if tiny <= p1 < 1.0 and t < 400:                        # few steps: 0.9**t resolves the count better than 0.999**t
+            t = int(round(np.log(p1) / np.log(0.9)))
+    elif tiny <= p1 < 1.0:
+        t = int(round(np.log(p1) / np.log(0.9)))
+    else:
+        t = UNDERFLOWED_STEP_COUNT                              # both powers underflowed: the bias corrections are 1
     return dict(t=t, m=m, v=v)
 
 
@@ -325,8 +347,12 @@ def load_tf_model_dir(model_dir, class_name=None):
         stated = extraction_signature(tp.get(class_name))[3]
         # the variable set is checked in weights_from_bundle; the one thing only the graph shows is LeakyReLU vs ReLU
         if seen[3] in ("relu", "lrelu") and stated in ("relu", "lrelu") and stated != seen[3]:
-            raise ValueError("'%s': class %s uses %s but the checkpoint's graph (model.meta) %s LeakyRelu ops -- wrong model class"
-                             % (model_dir, class_name, stated, "contains" if seen[3] == "lrelu" else "has no"))
+            raise ValueError("'%s': class %s uses %s but the checkpoint's graph (model.meta) shows %s nodes in the frame-level "
+                             "layers (LeakyRelu / lrelu vs relu) -- wrong model class"
+                             % (model_dir, class_name, stated, "LeakyReLU" if seen[3] == "lrelu" else "ReLU"))
+        elif seen[3] is None and stated in ("relu", "lrelu"):
+            logging.getLogger(__name__).warning("'%s': model.meta shows neither relu nor lrelu nodes; taking the stated class %s "
+                                                "(%s) at its word", model_dir, class_name, stated)
     w, topo, num_classes, feat_dim = weights_from_bundle(arrays, class_name)
     meta = dict(format="tensorflow-checkpoint", model_class=class_name, topology=topo, num_classes=num_classes,
                 feat_dim=feat_dim)
