@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from conftest import PKG
 from xvector_amd import dist as xdist
@@ -243,17 +244,25 @@ EMBED_WORKER = textwrap.dedent("""
     log = logging.getLogger("w"); log.addHandler(logging.NullHandler())
     out = io.BytesIO()
     with open(sys.argv[1], "rb") as fin:
-        models.Model().make_embedding(fin, out, "unused", 10, -1, True, log)
+        src = fin
+        if len(sys.argv) > 3 and sys.argv[3] == "pipe":          # a stream nobody can seek in or split (stands in for a pipe)
+            src = io.BufferedReader(io.BytesIO(fin.read()))
+        models.Model().make_embedding(src, out, "unused", 10, -1, True, log)
     rank = int(os.environ.get("RANK", "0"))
     open(sys.argv[2] + ".%%d" %% rank, "wb").write(out.getvalue())
     print("EMBED_OK collectives=%%s" %% ",".join(_calls))
+    print("RANGE_BYTES=%%d" %% kaldi_io.FileRange.bytes_read)
 """)
 
 
-def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path):
-    """Model.make_embedding under a 2-rank gloo group (stand-in extractor): every rank reads the stream, extracts its
-    frame-balanced shard of each window, ONE gather at the very end (however many windows), rank 0 alone writes -- and writes
-    exactly the bytes a single process writes (input order restored, rejected utterances dropped)."""
+@pytest.mark.parametrize("mode", ["file", "pipe", "file_with_a_double_record"])
+def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path, mode):
+    """Model.make_embedding under a 2-rank gloo group (stand-in extractor), ONE gather at the very end (however many windows),
+    rank 0 alone writes -- exactly the bytes a single process writes (input order restored, rejected utterances dropped).
+    * ``pipe``: a stream nobody can split -- every rank reads it and extracts its frame-balanced shard of each window;
+    * ``file``: a seekable ark file is split by BYTE RANGES (one header-only index pass per rank, no collective for it): each
+      rank reads only its own records' bytes -- together exactly the file, neither of them more than its share;
+    * a file holding a record the index pass does not take (a double-precision matrix) falls back to the stream mode."""
     import kaldi_io
     from conftest import TWIN
     rng = np.random.default_rng(2)
@@ -261,18 +270,20 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path):
     ark = tmp_path / "feats.ark"
     with open(ark, "wb") as f:
         for i, t in enumerate(lens):
-            kaldi_io.write_mat(f, rng.standard_normal((t, 5)).astype(np.float32), key="utt%02d" % i)
+            m = rng.standard_normal((t, 5)).astype(np.float32)
+            kaldi_io.write_mat(f, m.astype(np.float64) if (mode == "file_with_a_double_record" and i == 6) else m, key="utt%02d" % i)
     script = tmp_path / "embed_worker.py"
     script.write_text(EMBED_WORKER % (PKG, TWIN, os.path.dirname(PKG)))
-    single = subprocess.run([sys.executable, str(script), str(ark), str(tmp_path / "single")], stdout=subprocess.PIPE,
+    extra = ["pipe"] if mode == "pipe" else []
+    single = subprocess.run([sys.executable, str(script), str(ark), str(tmp_path / "single")] + extra, stdout=subprocess.PIPE,
                             stderr=subprocess.STDOUT, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}, timeout=240)
     assert single.returncode == 0, single.stdout.decode()
     port = 33000 + (os.getpid() % 2000)
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), str(ark), str(tmp_path / "dist")], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(ark), str(tmp_path / "dist")] + extra, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     want = open(str(tmp_path / "single.0"), "rb").read()
@@ -282,6 +293,12 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path):
     assert all("EMBED_OK collectives=gather\n" in o for o in outs), outs         # the whole job: exactly one data-path collective
     assert list(got) == ["utt%02d" % i for i, t in enumerate(lens) if t >= 10]
     assert got["utt05"][-1] == 200.0
+    ranged = [int(o.split("RANGE_BYTES=")[1].split()[0]) for o in outs]
+    if mode == "file":
+        size = os.path.getsize(str(ark))
+        assert sum(ranged) == size and 0 < min(ranged) and max(ranged) <= 0.7 * size, (ranged, size)
+    else:
+        assert ranged == [0, 0]                                 # the whole stream went through every rank's reader
 
 
 CLI_WORKER = textwrap.dedent("""

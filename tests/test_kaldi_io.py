@@ -465,6 +465,46 @@ def test_every_arena_taken_comes_back(tmp_path):
     assert len(taken) <= 6, "a table that does not follow its ark must stop taking arenas (took %d)" % len(taken)
 
 
+def test_header_only_index_of_an_ark_file(tmp_path):
+    """kaldi_io.index_mat_ark_file: offsets / shapes / keys of every record from one small pread per record (the matrices are
+    hopped over) == what the record reader sees; a file with another record type or a truncated tail gives None (callers read
+    the stream the ordinary way); FileRange reads exactly its bytes and leaves the file object's own position alone."""
+    if kaldi_io._host_lib() is None or not hasattr(kaldi_io._host_lib(), "xv_ark_index_fd"):
+        pytest.skip("host library not built")
+    rng = np.random.default_rng(11)
+    mats = [rng.standard_normal((int(rng.integers(0, 50)), 7)).astype(np.float32) for _ in range(200)]
+    keys = ["spk%d-utt_%03d.a" % (i % 7, i) for i in range(200)]
+    keys[17] = "k" * 400                                                   # a key longer than the first header read
+    path = str(tmp_path / "f.ark")
+    with open(path, "wb") as f:
+        for k, m in zip(keys, mats):
+            kaldi_io.write_mat(f, m, key=k)
+    with open(path, "rb") as f:
+        off, rows, cols, got_keys = kaldi_io.index_mat_ark_file(f)
+        assert f.tell() == 0
+        assert got_keys == keys and rows.tolist() == [m.shape[0] for m in mats] and set(cols.tolist()) == {7}
+        assert off[0] == 0 and off[-1] == os.path.getsize(path) and len(off) == 201
+        # a range of records read through FileRange == the same records of the whole file
+        part = kaldi_io.FileRange(f, off[40], off[90])
+        sub = list(kaldi_io.read_mat_ark(part))
+        assert [k for k, _ in sub] == keys[40:90] and all(np.array_equal(a, b) for (_, a), b in zip(sub, mats[40:90]))
+        assert f.tell() == 0
+        f.seek(off[150])
+        off2, _, _, keys2 = kaldi_io.index_mat_ark_file(f)                  # from the stream position on
+        assert keys2 == keys[150:] and off2[0] == off[150]
+        assert kaldi_io.index_mat_ark_file(f, with_keys=False)[3] is None
+    with open(path, "ab") as f:
+        kaldi_io.write_mat(f, mats[3].astype(np.float64), key="double")
+    with open(path, "rb") as f:
+        assert kaldi_io.index_mat_ark_file(f) is None
+    cut = str(tmp_path / "cut.ark")
+    open(cut, "wb").write(open(path, "rb").read()[:int(off[120]) + 9])
+    with open(cut, "rb") as f:
+        assert kaldi_io.index_mat_ark_file(f) is None
+    import io
+    assert kaldi_io.index_mat_ark_file(io.BytesIO(b"abc")) is None and not kaldi_io.is_regular_file(io.BytesIO(b""))
+
+
 def test_mapped_ark_windows_equal_the_record_reader(tmp_path):
     """map_stream + scan_mat_ark_mapped: an ark that is already in memory (a BytesIO) is scanned where it lies -- same keys and
     matrices as the record reader, whatever the window size; a record the native scanner does not take (a double matrix) and

@@ -12,13 +12,70 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <thread>
 #include <vector>
 
 extern "C" {
 
-int xv_host_version(void) { return 7; }
+int xv_host_version(void) { return 8; }
+
+// Index pass over an ark FILE of binary float-matrix records without reading the matrices: per record one pread of the header
+// ("<key> \0BFM \4<rows>\4<cols>"), then a hop over rows*cols*4 payload bytes.  This is what lets the ranks of a job split a
+// seekable ark by BYTE RANGES (local/tf/models.py make_embedding): the format has no sync marks, so record boundaries can only
+// be found from the front -- but finding them costs one small read per record (~1 us), not a parse of the 27 KB behind it.
+// rec_off[i] = offset of record i (its key), rows[i] / cols[i] its shape; keys (optional) receives the keys back to back with
+// '\n' separators, *keys_used the bytes written.  Returns the number of records; *next = offset behind the last one taken;
+// *stop = 0 end of range reached, 1 a record that is not a complete binary FM record (caller falls back), 2 max_records or the
+// key buffer is full (call again from *next).
+int64_t xv_ark_index_fd(int fd, int64_t pos, int64_t end, int64_t max_records, int64_t *rec_off, int32_t *rows, int32_t *cols,
+                        uint8_t *keys, int64_t keys_cap, int64_t *keys_used, int64_t *next, int *stop)
+{
+    int64_t n = 0, kw = 0;
+    *stop = 0;
+    uint8_t hdr[4096];
+    while (pos < end) {
+        if (n == max_records) { *stop = 2; break; }
+        size_t want = 320;
+        ssize_t got = pread(fd, hdr, want, (off_t)pos);
+        if (got <= 0) { *stop = 1; break; }
+        const uint8_t *sp = (const uint8_t *)memchr(hdr, ' ', (size_t)got);
+        if (!sp && got == (ssize_t)want) {                         // a very long key: look again with the large buffer
+            got = pread(fd, hdr, sizeof(hdr), (off_t)pos);
+            sp = got > 0 ? (const uint8_t *)memchr(hdr, ' ', (size_t)got) : nullptr;
+        }
+        if (!sp) { *stop = 1; break; }
+        const size_t klen = (size_t)(sp - hdr), h = klen + 1;
+        if (h + 15 > (size_t)got) {
+            if (pos + (int64_t)h + 15 > end) { *stop = 1; break; } // truncated header
+            got = pread(fd, hdr, sizeof(hdr), (off_t)pos);
+            if (got < (ssize_t)(h + 15)) { *stop = 1; break; }
+        }
+        if (hdr[h] != 0 || hdr[h + 1] != 'B' || hdr[h + 2] != 'F' || hdr[h + 3] != 'M' || hdr[h + 4] != ' ' || hdr[h + 5] != 4 ||
+            hdr[h + 10] != 4) { *stop = 1; break; }
+        int32_t r, c;
+        memcpy(&r, hdr + h + 6, 4);
+        memcpy(&c, hdr + h + 11, 4);
+        if (r < 0 || c < 0) { *stop = 1; break; }
+        const int64_t after = pos + (int64_t)h + 15 + (int64_t)r * (int64_t)c * 4;
+        if (after > end) { *stop = 1; break; }                     // truncated payload
+        if (keys) {
+            if (kw + (int64_t)klen + 1 > keys_cap) { *stop = 2; break; }
+            memcpy(keys + kw, hdr, klen);
+            kw += (int64_t)klen;
+            keys[kw++] = '\n';
+        }
+        rec_off[n] = pos;
+        rows[n] = r;
+        cols[n] = c;
+        ++n;
+        pos = after;
+    }
+    if (keys_used) *keys_used = kw;
+    *next = pos;
+    return n;
+}
 
 // memcpy callable through ctypes, i.e. WITHOUT the interpreter lock: the in-place reader fills its arenas from an in-memory
 // stream (io.BytesIO) with it -- BytesIO.readinto copies under the lock, and 64 MB at a time stalls every other thread of the

@@ -27,7 +27,7 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 import kaldi_io  # noqa: E402
-from models import Model  # noqa: E402
+from models import Model, VectorCollector  # noqa: E402
 from xvector_amd import jobclock  # noqa: E402
 
 jobclock.mark("interpreter + imports")
@@ -161,29 +161,6 @@ def _open_table(rspecifier, scp_reader, ark_reader):
     return ark_reader(kaldi_io.open_or_fd(spec))
 
 
-class _Collector(object):
-    """In-memory sink of one rank's x-vectors (kaldi_io.write_vec_flt_batch hands over (keys, vectors) as they are)."""
-    mode = "wb"
-
-    def __init__(self):
-        self.keys, self.blocks = [], []
-
-    def write_vectors(self, keys, vecs):
-        import numpy as np
-        if len(keys):
-            self.keys.extend(keys)
-            self.blocks.append(np.asarray(vecs, dtype=np.float32).reshape(len(keys), -1))
-
-    def write(self, data):
-        raise IOError("the sharded extractor writes vectors, not bytes")
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
-
-
 def _scp_lines(spec):
     with kaldi_io.open_or_fd(spec.split(':', 1)[1].strip(), 'rb') as fid:
         return [ln for ln in fid.read().decode().splitlines(True) if ln.strip()]
@@ -240,7 +217,7 @@ def eval_dnn(args):
     else:
         vad = _open_table(args.vad_rspecifier, kaldi_io.VecScp, lambda stream: stream) if args.vad_rspecifier else None
         feats = _open_table(args.feature_rspecifier, kaldi_io.MatScp, None)
-    collector = _Collector() if presharded else None
+    collector = VectorCollector() if presharded else None
     jobclock.mark("tables opened")
     with (kaldi_io.open_or_fd(args.feature_rspecifier) if feats is None else _Null()) as input_fid:
         with (collector if presharded else _open_output(wspecifier, ark, scp) if root else _Discard()) as output_fid:
@@ -274,40 +251,14 @@ def eval_dnn(args):
 
 
 def _gather_and_write(model, collector, shard_keys, wspecifier, ark, scp, rank, world):
-    """The single exchange of the sharded mode (extract_xvectors.sh:92-95 concatenates the jobs' outputs; here ONE RCCL
-    gather does).  Every rank knows every shard's key list -- the line ranges of the scp are deterministic -- so only
-    numbers travel: rank r sends one row per utterance of ITS shard, in scp order, ``[emitted? | x-vector]``; the blocks
-    are padded to the largest shard so that a single fixed-shape ``dist.gather`` moves everything (xvector_amd.dist).
-    Rank 0 reads the flags (utterances rejected for their length or by the VAD emitted nothing), pairs the rest with the
-    keys it already has and writes the shards in rank order = input order."""
-    import numpy as np
-    import torch
-    from xvector_amd import dist as xdist
-    dim, dev = model.device_model.embed_dim, model.device_model.device
-    mine = shard_keys[rank]
-    block = np.zeros((len(mine), dim + 1), np.float32)
-    if collector.keys:
-        # the emitted keys are a subsequence of the shard's keys (make_embedding keeps input order)
-        rows, j = np.empty(len(collector.keys), np.int64), 0
-        for i, k in enumerate(mine):
-            if j < len(rows) and collector.keys[j] == k:
-                rows[j] = i
-                j += 1
-        if j != len(rows):
-            raise RuntimeError("sharded extraction: emitted keys are not a subsequence of the shard's scp keys")
-        block[rows, 0] = 1.0
-        block[rows, 1:] = np.concatenate(collector.blocks)
-    xdist.wait_process_group()
-    jobclock.mark("wait for the process group")
-    blocks = xdist.gather_blocks(torch.from_numpy(block).to(dev), [len(k) for k in shard_keys], 0)
-    jobclock.mark("gather")
+    """The single exchange of the scp-sharded mode (models.gather_shard_vectors: ONE gather of ``[emitted? | x-vector]`` rows,
+    no keys travel), then rank 0 writes the shards in rank order = input order."""
+    from models import gather_shard_vectors
+    shards = gather_shard_vectors(model.device_model, collector, shard_keys, rank, world)
     if rank == 0:
         with _open_output(wspecifier, ark, scp) as output_fid:
-            for r in range(world):
-                got = blocks[r].cpu().numpy()
-                emitted = got[:, 0] > 0.5
-                kaldi_io.write_vec_flt_batch(output_fid, [k for k, ok in zip(shard_keys[r], emitted.tolist()) if ok],
-                                             np.ascontiguousarray(got[emitted, 1:]))
+            for keys, vecs in shards:
+                kaldi_io.write_vec_flt_batch(output_fid, keys, vecs)
         jobclock.mark("write")
 
 

@@ -650,6 +650,12 @@ def _host_lib():
                     lib.xv_ark_gather_fm.restype = ctypes.c_int64
                     lib.xv_ark_gather_fm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                      ctypes.c_void_p]
+                if hasattr(lib, "xv_ark_index_fd"):
+                    lib.xv_ark_index_fd.restype = ctypes.c_int64
+                    lib.xv_ark_index_fd.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                    ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                                    ctypes.POINTER(ctypes.c_int)]
                 _HOST_LIB = lib
             except OSError:
                 _HOST_LIB = None
@@ -1118,6 +1124,102 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
                 raw.seek(-unread, 1)
             except Exception:
                 pass
+
+
+def is_regular_file(stream):
+    """True for an open binary file object over a regular, seekable file (not a pipe, socket, BytesIO or decompressor)."""
+    import stat
+    try:
+        return stat.S_ISREG(os.fstat(stream.fileno()).st_mode) and stream.seekable()
+    except (AttributeError, OSError, ValueError, io.UnsupportedOperation):
+        return False
+
+
+def index_mat_ark_file(stream, with_keys=True):
+    """Record index of the rest of an ark FILE of binary float matrices, without reading the matrices (``xv_ark_index_fd``: one
+    small pread per record): ``(offsets int64[n+1], rows int32[n], cols int32[n], keys or None)`` -- record i occupies bytes
+    ``[offsets[i], offsets[i+1])`` -- or None when the host library is missing or the file holds anything else (another record
+    type, a truncated tail): callers then read the stream the ordinary way."""
+    lib = _host_lib()
+    if lib is None or not hasattr(lib, "xv_ark_index_fd") or not is_regular_file(stream):
+        return None
+    fd = stream.fileno()
+    pos, end = int(stream.tell()), int(os.fstat(fd).st_size)
+    cap = 1 << 16
+    offs, rows_all, cols_all, key_parts = [], [], [], []
+    nxt, used, stop = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+    off = np.empty(cap, np.int64); rows = np.empty(cap, np.int32); cols = np.empty(cap, np.int32)
+    kbuf = np.empty(cap * 48, np.uint8) if with_keys else None
+    while pos < end:
+        n = int(lib.xv_ark_index_fd(fd, pos, end, cap, off.ctypes.data, rows.ctypes.data, cols.ctypes.data,
+                                    kbuf.ctypes.data if with_keys else None, len(kbuf) if with_keys else 0, ctypes.byref(used),
+                                    ctypes.byref(nxt), ctypes.byref(stop)))
+        if stop.value == 1:
+            return None
+        if n == 0:
+            if with_keys and stop.value == 2:
+                kbuf = np.empty(len(kbuf) * 4, np.uint8)            # one key longer than the whole buffer
+                continue
+            return None
+        offs.append(off[:n].copy()); rows_all.append(rows[:n].copy()); cols_all.append(cols[:n].copy())
+        if with_keys:
+            key_parts.append(kbuf[:used.value].tobytes())
+        pos = int(nxt.value)
+    offsets = np.concatenate(offs + [np.array([pos], np.int64)]) if offs else np.array([pos], np.int64)
+    keys = None
+    if with_keys:
+        keys = [k.strip() for k in b"".join(key_parts).decode().split("\n")[:-1]]
+        bad = [k for k in keys if _KEY_OK.match(k) is None]
+        assert not bad, "malformed key %r" % bad[0]
+    return offsets, (np.concatenate(rows_all) if rows_all else np.zeros(0, np.int32)), \
+        (np.concatenate(cols_all) if cols_all else np.zeros(0, np.int32)), keys
+
+
+class FileRange(object):
+    """Bytes ``[start, end)`` of an open regular file as a read-only binary stream (``readinto`` / ``read`` / ``tell``) with its
+    own position (pread: the underlying file object's position is not touched, several ranges of one file can be read at
+    once).  ``FileRange.bytes_read`` counts what this process pulled through such ranges (tests: a rank reads its share only)."""
+    bytes_read = 0
+
+    def __init__(self, stream, start, end):
+        self._fd, self._pos, self._end = stream.fileno(), int(start), int(end)
+        self._owner = stream
+
+    def readinto(self, b):
+        view = memoryview(b).cast("B")
+        want = min(len(view), self._end - self._pos)
+        if want <= 0:
+            return 0
+        got = os.preadv(self._fd, [view[:want]], self._pos)
+        self._pos += got
+        FileRange.bytes_read += got
+        return got
+
+    def read(self, n=-1):
+        want = self._end - self._pos if n is None or n < 0 else min(int(n), self._end - self._pos)
+        if want <= 0:
+            return b""
+        data = os.pread(self._fd, want, self._pos)
+        self._pos += len(data)
+        FileRange.bytes_read += len(data)
+        return data
+
+    def tell(self):
+        return self._pos
+
+    def seek(self, offset, whence=0):
+        base = {0: 0, 1: self._pos, 2: self._end}[whence]
+        self._pos = max(0, min(self._end, base + int(offset)))
+        return self._pos
+
+    def seekable(self):
+        return True
+
+    def readable(self):
+        return True
+
+    def close(self):
+        pass
 
 
 def read_mat_ark(file_or_fd):

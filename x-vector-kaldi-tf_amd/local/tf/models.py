@@ -54,6 +54,66 @@ class _Cancelled(Exception):
     pass
 
 
+class VectorCollector(object):
+    """In-memory sink of one rank's x-vectors (kaldi_io.write_vec_flt_batch hands over (keys, vectors) as they are): what a rank
+    of a sharded job writes to instead of the output table, until the ONE gather at the end."""
+    mode = "wb"
+
+    def __init__(self):
+        self.keys, self.blocks = [], []
+
+    def write_vectors(self, keys, vecs):
+        if len(keys):
+            self.keys.extend(keys)
+            self.blocks.append(np.asarray(vecs, dtype=np.float32).reshape(len(keys), -1))
+
+    def write(self, data):
+        raise IOError("the sharded extractor writes vectors, not bytes")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def gather_shard_vectors(device_model, collector, shard_keys, rank, world):
+    """The single exchange of a sharded job (extract_xvectors.sh:92-95 concatenates the jobs' outputs; here ONE RCCL gather
+    does).  Every rank knows every shard's key list -- the line ranges of an scp, or the byte ranges of an indexed ark, are
+    deterministic -- so only numbers travel: rank r sends one row per utterance of ITS shard, in input order,
+    ``[emitted? | x-vector]``; the blocks are padded to the largest shard so that a single fixed-shape ``dist.gather`` moves
+    everything (xvector_amd.dist).  On rank 0 returns ``[(keys, vectors)]`` per shard in rank order = input order, with the
+    utterances that emitted nothing (rejected for their length or by the VAD) dropped; None on the other ranks."""
+    import torch
+    from xvector_amd import dist as xdist, jobclock
+    dim, dev = device_model.embed_dim, device_model.device
+    mine = shard_keys[rank]
+    block = np.zeros((len(mine), dim + 1), np.float32)
+    if collector.keys:
+        # the emitted keys are a subsequence of the shard's keys (make_embedding keeps input order)
+        rows, j = np.empty(len(collector.keys), np.int64), 0
+        for i, k in enumerate(mine):
+            if j < len(rows) and collector.keys[j] == k:
+                rows[j] = i
+                j += 1
+        if j != len(rows):
+            raise RuntimeError("sharded extraction: emitted keys are not a subsequence of the shard's keys")
+        block[rows, 0] = 1.0
+        block[rows, 1:] = np.concatenate(collector.blocks)
+    xdist.wait_process_group()
+    jobclock.mark("wait for the process group")
+    blocks = xdist.gather_blocks(torch.from_numpy(block).to(dev), [len(k) for k in shard_keys], 0)
+    jobclock.mark("gather")
+    if rank != 0:
+        return None
+    out = []
+    for r in range(world):
+        got = blocks[r].cpu().numpy()
+        emitted = got[:, 0] > 0.5
+        out.append(([k for k, ok in zip(shard_keys[r], emitted.tolist()) if ok], np.ascontiguousarray(got[emitted, 1:])))
+    return out
+
+
 _SELECTED = {}           # checkpoint identity + request -> engine.select_model's report (see Model.load_model)
 
 
@@ -342,6 +402,40 @@ class Model(object):
             valid = np.array([bool(engine.plan_chunks(int(t), min_chunk_size, chunk_size)) for t in lens], dtype=bool)
             emit(keys, lens, full, valid)
 
+    def _extract_byte_ranges(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger):
+        """Multi-GPU extraction from a seekable ark FILE (no scp): instead of every rank parsing the whole stream, each rank
+        runs ONE cheap index pass over the record headers (kaldi_io.index_mat_ark_file: a small pread per record, the matrices
+        are hopped over), takes the records whose first byte falls into its 1/world slice of the payload bytes -- deterministic,
+        so no rank has to tell another where to start -- reads ONLY those bytes (kaldi_io.FileRange) through the single-process
+        pipeline, and the one gather at the end brings the vectors to rank 0, which knows every shard's keys from its own index.
+        Returns False (nothing consumed) when this does not apply: no group, not a regular file, a record type the index does
+        not take -- the caller then reads the stream the ordinary way (a pipe cannot be split)."""
+        from xvector_amd import dist as xdist
+        rank, world = xdist.group_shape()
+        if world <= 1 or not kaldi_io.is_regular_file(input_stream):
+            return False
+        index = kaldi_io.index_mat_ark_file(input_stream)
+        if index is None:
+            return False
+        offsets, rows, _, keys = index
+        xdist.init_process_group_async()
+        first, last = int(offsets[0]), int(offsets[-1])
+        cuts = np.searchsorted(offsets[:-1], [first + (last - first) * r // world for r in range(world + 1)], side="left")
+        cuts[0], cuts[-1] = 0, len(keys)
+        shard_keys = [keys[cuts[r]:cuts[r + 1]] for r in range(world)]
+        collector = VectorCollector()
+        mine = kaldi_io.FileRange(input_stream, offsets[cuts[rank]], offsets[cuts[rank + 1]])
+        if logger is not None:
+            logger.info("rank %d of %d: records %d..%d of %d, bytes %d..%d of the ark" % (
+                rank, world, cuts[rank], cuts[rank + 1], len(keys), offsets[cuts[rank]], offsets[cuts[rank + 1]]))
+        self.make_embedding(mine, collector, model_dir, min_chunk_size, chunk_size, use_gpu, logger, distributed=False)
+        input_stream.seek(last)                                     # the caller's stream is consumed, as after a full read
+        shards = gather_shard_vectors(self.device_model, collector, shard_keys, rank, world)
+        if shards is not None:
+            for skeys, vecs in shards:
+                kaldi_io.write_vec_flt_batch(output_stream, skeys, vecs)
+        return True
+
     # -- the hot path ------------------------------------------------------------------------------
     def make_embedding(self, input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger,
                        vad_stream=None, cmn_window=0, cmn_center=True, distributed=True):
@@ -355,6 +449,9 @@ class Model(object):
         import queue
         import threading
         start_time = time.time()
+        if distributed and vad_stream is None and cmn_window <= 0 and self._extract_byte_ranges(
+                input_stream, output_stream, model_dir, min_chunk_size, chunk_size, use_gpu, logger):
+            return
         # A reader thread parses the next window of the ark stream while the GPU works on the current one
         # (bounded queue: at most 2 parsed windows in memory).  Order is preserved; a parse error is re-raised here.
         windows = queue.Queue(maxsize=2)
