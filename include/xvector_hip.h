@@ -258,6 +258,11 @@ int xv_rows_affine_f32(const float *x, int ldx, int64_t R, int c, const float *s
 size_t xv_wgrad_workspace_bytes(int64_t R, int cin, int cout, int K);
 int xv_wgrad_f32(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation,
                  float *dw, void *workspace, void *stream);
+/* The same gradient in the bf16x3 arithmetic of xv_tdnn_layer_bf16x3 (operands split hi + lo while they are staged, three bf16
+ * MFMAs per product, fp32 accumulate; ~5e-6 relative): what `--train-precision bf16x3` runs.  Same arguments, same workspace,
+ * same deterministic split merge; falls back to xv_wgrad_f32 when R * ld * 4 >= 2^31 (32-bit buffer offsets). */
+int xv_wgrad_bf16x3(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation,
+                    float *dw, void *workspace, void *stream);
 /* sum_a[c] = sum_r a[r,c];  sum_ab[c] = sum_r a[r,c]*b[r,c]  (b, sum_ab may be NULL). */
 size_t xv_col_sums_workspace_bytes(int64_t R, int c);
 int xv_col_sums_f32(const float *a, int lda, const float *b, int ldb, int64_t R, int c, float *sum_a, float *sum_ab,

@@ -199,7 +199,7 @@ def test_wgrad_and_reductions_unit(env):
     """xv_wgrad_f32 / xv_col_sums_f32 on their own, incl. the split + ordered-merge path (R > 4096) and a ragged Cin."""
     torch, hiplib = env["torch"], env["hiplib"]
     rng = np.random.default_rng(11)
-    for (R, cin, cout, K, d) in ((300, 24, 64, 5, 1), (9000, 64, 96, 3, 2), (70, 96, 10, 1, 1)):
+    for (R, cin, cout, K, d) in ((300, 24, 64, 5, 1), (9000, 64, 96, 3, 2), (70, 96, 10, 1, 1), (19000, 512, 512, 7, 1), (4097, 130, 257, 3, 3)):
         x = rng.standard_normal((R, cin)).astype(np.float32)
         dz = rng.standard_normal((R, cout)).astype(np.float32)
         dw = torch.empty((K, cin, cout), dtype=torch.float32, device="cuda:0")
@@ -211,6 +211,10 @@ def test_wgrad_and_reductions_unit(env):
             lo, hi = max(0, -s), min(R, R - s)
             ref[k] = x[lo + s:hi + s].astype(np.float64).T @ dz[lo:hi].astype(np.float64)
         assert _rel(dw.cpu().numpy(), ref) < 2e-6, (R, cin, cout, K, d)
+        # the same gradient in the bf16x3 arithmetic (xv_wgrad_bf16x3: operands split hi + lo on their way into LDS, transposed there)
+        dw3 = torch.full((K, cin, cout), float("nan"), dtype=torch.float32, device="cuda:0")
+        hiplib.wgrad(torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda(), K, d, dw3, "bf16x3")
+        assert _rel(dw3.cpu().numpy(), ref) < 2e-5, (R, cin, cout, K, d)
         sa = torch.empty(cout, dtype=torch.float32, device="cuda:0"); sab = torch.empty_like(sa)
         b = rng.standard_normal((R, cout)).astype(np.float32)
         hiplib.col_sums(torch.from_numpy(dz).cuda(), torch.from_numpy(b).cuda(), sa, sab)

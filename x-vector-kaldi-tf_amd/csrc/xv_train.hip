@@ -206,15 +206,18 @@ __global__ __launch_bounds__(256) void col_sums_kernel(const float *__restrict__
 // 64 channels x 4 split groups per block: group g sums the splits j = g, g+4, ... in order, the four group sums are then
 // added in group order (fixed order -> deterministic); 4x the parallelism and a quarter of the dependent loads of one
 // thread per channel.
-__global__ __launch_bounds__(256) void col_sums_merge_kernel(const double *__restrict__ part, int C, int nsplit,
-                                                             float *__restrict__ out_a, float *__restrict__ out_ab)
+// 64 channels x 16 groups of splits per workgroup: a launch has only C / 64 workgroups, so what a thread does serially is the
+// whole run time (150 splits over 4 groups were 38 dependent-latency loads = 11 us for a few kilobytes; 16 groups: 10)
+constexpr int CSM_GROUPS = 16;
+__global__ __launch_bounds__(64 * CSM_GROUPS) void col_sums_merge_kernel(const double *__restrict__ part, int C, int nsplit,
+                                                                         float *__restrict__ out_a, float *__restrict__ out_ab)
 {
-    __shared__ double sh[2][4][64];
+    __shared__ double sh[2][CSM_GROUPS][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0, sab = 0.0;
     if (c < C) {
-        for (int j = g; j < nsplit; j += 4) {
+        for (int j = g; j < nsplit; j += CSM_GROUPS) {
             s += part[(size_t)j * 2 * C + c];
             sab += part[(size_t)j * 2 * C + C + c];
         }
@@ -223,40 +226,93 @@ __global__ __launch_bounds__(256) void col_sums_merge_kernel(const double *__res
     sh[1][g][cl] = sab;
     __syncthreads();
     if (g == 0 && c < C) {
-        out_a[c] = (float)(((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl]);
-        if (out_ab) out_ab[c] = (float)(((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl]);
+        double ta = 0.0, tb = 0.0;
+#pragma unroll
+        for (int k = 0; k < CSM_GROUPS; ++k) {               // fixed order: deterministic
+            ta += sh[0][k][cl];
+            tb += sh[1][k][cl];
+        }
+        out_a[c] = (float)ta;
+        if (out_ab) out_ab[c] = (float)tb;
     }
 }
 
-// per-chunk (mean, biased var) -> moments over all frames of all chunks (Chan merge in chunk order, fp64)
-__global__ void merge_moments_kernel(const float *__restrict__ cm, const int *__restrict__ row_len, int nchunks, int C,
-                                     float *__restrict__ mean, float *__restrict__ var)
+// per-chunk (mean, biased var) -> moments over all frames of all chunks, fp64, two passes over the chunk table:
+// mu = sum_b n_b m_b / N, then var = sum_b n_b (v_b + (m_b - mu)^2) / N -- the definition, no cancellation.  64 channels x 16 groups of
+// chunks per workgroup (a serial Chan merge of 64 chunks with its fp64 divisions was 17 us on the handful of workgroups a launch has).
+constexpr int MM_GROUPS = 16;
+__global__ __launch_bounds__(64 * MM_GROUPS) void merge_moments_kernel(const float *__restrict__ cm, const int *__restrict__ row_len,
+                                                                       int nchunks, int C, float *__restrict__ mean, float *__restrict__ var)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double n = 0.0, mu = 0.0, m2 = 0.0;
-    for (int b = 0; b < nchunks; ++b) {
+    __shared__ double sh[2][MM_GROUPS][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool ok = c < C;
+    double n = 0.0, s1 = 0.0;
+    for (int b = g; b < nchunks; b += MM_GROUPS) {
         const double m = (double)row_len[b];
-        if (m <= 0.0) continue;
-        const double bm = cm[(size_t)b * 2 * C + c], bv = cm[(size_t)b * 2 * C + C + c];
-        const double nn = n + m, d = bm - mu;
-        mu += d * (m / nn);
-        m2 += bv * m + d * d * (n * m / nn);
-        n = nn;
+        if (m > 0.0 && ok) {
+            n += m;
+            s1 += m * (double)cm[(size_t)b * 2 * C + c];
+        }
     }
-    mean[c] = (float)mu;
-    var[c] = (float)(n > 0.0 ? m2 / n : 0.0);
+    sh[0][g][cl] = n;
+    sh[1][g][cl] = s1;
+    __syncthreads();
+    double N = 0.0, S1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < MM_GROUPS; ++k) {                    // fixed order: deterministic
+        N += sh[0][k][cl];
+        S1 += sh[1][k][cl];
+    }
+    const double mu = N > 0.0 ? S1 / N : 0.0;
+    __syncthreads();
+    double m2 = 0.0;
+    for (int b = g; b < nchunks; b += MM_GROUPS) {
+        const double m = (double)row_len[b];
+        if (m > 0.0 && ok) {
+            const double d = (double)cm[(size_t)b * 2 * C + c] - mu;
+            m2 += m * ((double)cm[(size_t)b * 2 * C + C + c] + d * d);
+        }
+    }
+    sh[0][g][cl] = m2;
+    __syncthreads();
+    if (g == 0 && ok) {
+        double M2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < MM_GROUPS; ++k) M2 += sh[0][k][cl];
+        mean[c] = (float)mu;
+        var[c] = (float)(N > 0.0 ? M2 / N : 0.0);
+    }
 }
 
-__global__ void rows_affine_kernel(const float *__restrict__ x, long R, int C, int ldx, const float *__restrict__ scale,
-                                   const float *__restrict__ shift, const uint8_t *__restrict__ valid, float *__restrict__ y, int ldy)
+// (one workgroup row = 256 threads x 4 channels; rows along blockIdx.y with a stride loop: no 64-bit division per element)
+template <bool VEC>
+__global__ __launch_bounds__(256) void rows_affine_kernel(const float *__restrict__ x, long R, int C, int ldx, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, const uint8_t *__restrict__ valid,
+                                                          float *__restrict__ y, int ldy)
 {
-    const size_t n = (size_t)R * C;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const long r = (long)(i / C);
-        const int c = (int)(i - (size_t)r * C);
-        const float v = x[(size_t)r * ldx + c] * scale[c] + shift[c];
-        y[(size_t)r * ldy + c] = (!valid || valid[r]) ? v : 0.f;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc[i] = c + i < C ? scale[c + i] : 0.f;
+        sh[i] = c + i < C ? shift[c + i] : 0.f;
+    }
+    for (long r = blockIdx.y; r < R; r += gridDim.y) {
+        const bool keep = !valid || valid[r];
+        if constexpr (VEC) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (size_t)r * ldx + c);
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = keep ? v[i] * sc[i] + sh[i] : 0.f;
+            *reinterpret_cast<f32x4 *>(y + (size_t)r * ldy + c) = o;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c + i < C) y[(size_t)r * ldy + c + i] = keep ? x[(size_t)r * ldx + c + i] * sc[i] + sh[i] : 0.f;
+        }
     }
 }
 
@@ -564,7 +620,7 @@ int xv_col_sums_f32(const float *a, int lda, const float *b, int ldb, int64_t R,
                        (double *)workspace);
     int rc = tcheck("col_sums_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(col_sums_merge_kernel, dim3((c + 63) / 64), dim3(256), 0, st, (const double *)workspace, c, splits, sum_a,
+    hipLaunchKernelGGL(col_sums_merge_kernel, dim3((c + 63) / 64), dim3(64 * CSM_GROUPS), 0, st, (const double *)workspace, c, splits, sum_a,
                        b ? sum_ab : nullptr);
     return tcheck("col_sums_merge_kernel");
 }
@@ -572,8 +628,8 @@ int xv_col_sums_f32(const float *a, int lda, const float *b, int ldb, int64_t R,
 int xv_merge_moments_f32(const float *chunk_mean_var, const int32_t *row_len, int nchunks, int c, float *mean, float *var, void *stream)
 {
     if (!chunk_mean_var || !row_len || !mean || !var || nchunks <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "merge_moments: bad argument");
-    hipLaunchKernelGGL(merge_moments_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunk_mean_var, row_len, nchunks,
-                       c, mean, var);
+    hipLaunchKernelGGL(merge_moments_kernel, dim3((c + 63) / 64), dim3(64 * MM_GROUPS), 0, (hipStream_t)stream, chunk_mean_var, row_len,
+                       nchunks, c, mean, var);
     return tcheck("merge_moments_kernel");
 }
 
@@ -581,8 +637,10 @@ int xv_rows_affine_f32(const float *x, int ldx, int64_t R, int c, const float *s
                        float *y, int ldy, void *stream)
 {
     if (!x || !y || !scale || !shift || R <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "rows_affine: bad argument");
-    hipLaunchKernelGGL(rows_affine_kernel, dim3(gs_blocks((size_t)R * c)), dim3(256), 0, (hipStream_t)stream, x, (long)R, c, ldx, scale,
-                       shift, row_valid, y, ldy);
+    const bool vec = !(c & 3) && !(ldx & 3) && !(ldy & 3) && !(((uintptr_t)x | (uintptr_t)y) & 15);
+    const dim3 grid((unsigned)((c + 1023) / 1024), (unsigned)(R < 4096 ? R : 4096));
+    if (vec) hipLaunchKernelGGL(rows_affine_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)R, c, ldx, scale, shift, row_valid, y, ldy);
+    else hipLaunchKernelGGL(rows_affine_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)R, c, ldx, scale, shift, row_valid, y, ldy);
     return tcheck("rows_affine_kernel");
 }
 

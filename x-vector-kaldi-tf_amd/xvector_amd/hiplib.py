@@ -24,7 +24,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_tdnn_layer_f16bf8", "xv_tdnn_layer_pool_f16bf8", "xv_tdnn_first_f16bf8",
            "xv_packed_pair_f16bf8_bytes", "xv_pack_pair_f16bf8", "xv_tdnn_pair_pool_f16bf8",
            # training step
-           "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32",
+           "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
@@ -140,6 +140,8 @@ def load():
     lib.xv_wgrad_workspace_bytes.argtypes = [i64, ci, ci, ci]
     lib.xv_wgrad_f32.restype = ci
     lib.xv_wgrad_f32.argtypes = [vp, ci, vp, ci, i64, ci, ci, ci, ci, vp, vp, vp]
+    lib.xv_wgrad_bf16x3.restype = ci
+    lib.xv_wgrad_bf16x3.argtypes = lib.xv_wgrad_f32.argtypes
     lib.xv_col_sums_workspace_bytes.restype = sz
     lib.xv_col_sums_workspace_bytes.argtypes = [i64, ci]
     lib.xv_col_sums_f32.restype = ci
@@ -678,16 +680,16 @@ def rows_affine(x, scale, shift, row_valid, y, rows=None):
                                   _ptr(_f32(y, "y")), y.stride(0), _stream()), "xv_rows_affine_f32")
 
 
-def wgrad(x, dz, K, dilation, dw):
-    """dw[K, Cin, Cout] (contiguous) = sum_r x[r + tap shift] (x) dz[r]."""
+def wgrad(x, dz, K, dilation, dw, precision="fp32"):
+    """dw[K, Cin, Cout] (contiguous) = sum_r x[r + tap shift] (x) dz[r]; precision "fp32" (exact fp32 MFMA) or "bf16x3"."""
     lib = require_gpu()
+    fn, name = (lib.xv_wgrad_bf16x3, "xv_wgrad_bf16x3") if precision == "bf16x3" else (lib.xv_wgrad_f32, "xv_wgrad_f32")
     _rows2d(x, "x"); _f32(dz, "dz"); _f32(dw, "dw")
     R, cin = x.shape
     cout = dz.shape[1]
     assert dz.shape[0] == R and tuple(dw.shape) == (K, cin, cout)
     ws = _ws(lib.xv_wgrad_workspace_bytes(R, cin, cout, K), x.device)
-    _check(lib.xv_wgrad_f32(_ptr(x), x.stride(0), _ptr(dz), dz.stride(0), R, cin, cout, int(K), int(dilation), _ptr(dw), _ptr(ws),
-                            _stream()), "xv_wgrad_f32")
+    _check(fn(_ptr(x), x.stride(0), _ptr(dz), dz.stride(0), R, cin, cout, int(K), int(dilation), _ptr(dw), _ptr(ws), _stream()), name)
 
 
 def col_sums(a, b, sum_a, sum_ab=None):

@@ -26,9 +26,9 @@ BN_DECAY = 0.95                                        # batch_norm_wrapper(h, d
 
 class Trainer(object):
     def __init__(self, weights, topo, device="cuda:0", adam=None, precision="fp32"):
-        """precision: arithmetic of the forward and input-gradient GEMMs -- "fp32" (exact fp32 MFMA) or "bf16x3" (split
-        bf16 MFMA with fp32 accumulate, fp32 rows in/out; ~1e-5 relative on every activation/gradient).  Weight
-        gradients, reductions, BN, loss and Adam are fp32/fp64-accumulated either way."""
+        """precision: arithmetic of the forward, input-gradient and weight-gradient GEMMs -- "fp32" (exact fp32 MFMA) or "bf16x3"
+        (split bf16 MFMA with fp32 accumulate, fp32 rows in/out; ~1e-5 relative on every activation/gradient).  Reductions,
+        BN, loss and Adam are fp32/fp64-accumulated either way."""
         import torch
         hiplib.require_gpu()
         assert precision in ("fp32", "bf16x3")
@@ -283,10 +283,10 @@ class Trainer(object):
         gw, db = self.G[scope + "/w:0"], self.G[scope + "/b:0"]
         if scope == self.frame_scopes[0] and self.in_dim != self.feat_dim:
             dw = torch.empty((K, cin, cout), dtype=torch.float32, device=self.device)
-            hiplib.wgrad(x_in, dz, K, dil, dw)
+            hiplib.wgrad(x_in, dz, K, dil, dw, self.precision)
             gw.copy_(dw[:, :self.feat_dim, :])                          # drop the padding column
         else:
-            hiplib.wgrad(x_in, dz, K, dil, gw.view(K, cin, cout))
+            hiplib.wgrad(x_in, dz, K, dil, gw.view(K, cin, cout), self.precision)
         hiplib.col_sums(dz, None, db)
         grads[scope + "/w:0"] = gw
         grads[scope + "/b:0"] = db
@@ -360,7 +360,7 @@ class Trainer(object):
             E = S["xh"].shape[1]
             dwh = torch.empty((1, E, self.num_classes), dtype=torch.float32, device=self.device)
             self.G["output/b:0"].zero_()
-            hiplib.wgrad(S["xh"], g, 1, 1, dwh)
+            hiplib.wgrad(S["xh"], g, 1, 1, dwh, self.precision)
             dxh = torch.empty_like(S["xh"])
             hiplib.tdnn_layer(g, hiplib.pack_weights(S["wh_t"]), None, None, None, tp.ACT_NONE, None, 1, 1, None, dxh)
             d = hiplib.l2_normalize_backward(dxh, S["xh"], S["xnorm"])
