@@ -14,12 +14,15 @@
  *    (hipStream_t passed as void*; NULL = the null stream).
  *  - return value: 0 on success, otherwise a hipError_t / negative argument-error code;
  *    xv_last_error() returns a thread-local message.  No exceptions cross the ABI.
- *  - arithmetic: the *_f32 GEMM entry points are exact IEEE fp32 (f32-input MFMA: exact fp32 products, fp32
- *    accumulation).  The *_bf16x3 twins compute the same fp32-in / fp32-out contraction with every operand
- *    split x = hi + lo into two bf16 and the product accumulated in fp32 as hi*hi + hi*lo + lo*hi on the
- *    bf16 matrix cores (16x the f32-MFMA rate; the dropped lo*lo term is ~2^-16 relative): measured
- *    ~3e-6 relative L2 on the x-vector against the fp64 oracle, inside the 1e-4 parity bar.  Pooling,
- *    epilogues and the chunk average are fp32 in both.
+ *  - arithmetic: three GEMM arithmetics behind the same fp32-in / fp32-out contraction, all accumulating in fp32:
+ *      *_f32      exact IEEE fp32 (f32-input MFMA: exact fp32 products) -- the reference's own arithmetic;
+ *      *_bf16x3   every operand split x = hi + lo into two bf16, a product formed as hi*hi + hi*lo + lo*hi on the bf16 matrix
+ *                 cores (16x the f32-MFMA rate; the dropped lo*lo term is ~2^-16 relative): ~5e-6 relative L2 on the x-vector;
+ *      *_f16bf8   hi = fp16(x), the two cross terms through ONE block-scaled e5m2 MFMA at twice the 16-bit rate (csrc/xv_split8.h):
+ *                 ~1.3e-5.  This is what the host side runs BY DEFAULT for the hidden frame-level layers (layer 0 and the segment
+ *                 FCs stay bf16x3) -- per checkpoint, after an accuracy probe admitted it (xvector_amd/engine.py select_model;
+ *                 DESIGN.md 5.1); a model whose f16bf8 results drift from bf16x3 runs as bf16x3, then as f32.
+ *    All are inside the 1e-4 parity bar against the fp64 oracle.  Pooling, epilogues and the chunk average are fp32 in all three.
  *
  * Ragged batch layout ("packed rows with gaps")
  *    A batch of utterance chunks is ONE row-major matrix x[R, C].  Chunk b owns rows

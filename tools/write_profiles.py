@@ -20,7 +20,7 @@ for l in stats.splitlines():
     if l.startswith(GEMM):
         f = l.split(); cnt += int(f[-4]); tot += float(f[-3])
 under = json.loads(rd("bench_under_prof"))
-hdr = ("# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-budget 0 --e2e-utts 0 --no-fp32-leg   (MI355X, default precision %s,\n"
+hdr = ("# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-budget 0 --e2e-utts 0 --no-fp32-leg --no-extra-legs   (MI355X, default precision %s,\n"
        "#   commit %s, kernel sources %s; tools/profile_round.sh).  6 steps (1 warm-up + 5 timed) x 12 batches of <= 262144 rows + the 6 passes over the largest batch behind roofline.by_launch.\n"
        "#   tdnn_first_kernel<2, true>           = layer 0 (K=5, 23 MFCC dims in 24 columns -> 512; bf16x3 arithmetic, split8 output from the accumulators)\n"
        "#   tdnn_gemm_f16bf8_wide_kernel<5|7, false> = layers 1 / 2 (K = 5 / 7, 512 -> 512): fp16 MFMA + scaled bf8 MFMA per product, 256 x 256 workgroup tiles\n"
@@ -46,7 +46,7 @@ for k, v in vals.items():
         lines.append("#   %-48s %4d launches  avg %8.1f us  MFMA busy %5.1f %% of cycles at %.2f GHz  waves parked (s_waitcnt/barrier) %4.1f %%" %
                      (k, v["GRBM_GUI_ACTIVE"][0], v["GRBM_GUI_ACTIVE"][3] / 1e3, 100 * v["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (cyc * 1024),
                       cyc / v["GRBM_GUI_ACTIVE"][3], 100 * v["SQ_WAIT_ANY"][1] / v["SQ_WAVE_CYCLES"][1] if "SQ_WAIT_ANY" in v else float("nan")))
-hdr2 = ("# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --steps 1 --warmup 0 --cpu-budget 0 --e2e-utts 0 --no-fp32-leg   (separate passes: FETCH_SIZE | WRITE_SIZE |\n"
+hdr2 = ("# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --steps 1 --warmup 0 --cpu-budget 0 --e2e-utts 0 --no-fp32-leg --no-extra-legs   (separate passes: FETCH_SIZE | WRITE_SIZE |\n"
         "#   SQ/GRBM set; tools/profile_round.sh, commit %s, kernel sources %s).  12 batches of <= 262144 rows per pass (+ 6 by_launch passes over the largest batch); last column = average kernel duration in ns.\n"
         "# FETCH_SIZE / WRITE_SIZE in KiB per launch.  Fabric-side bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md, verified on\n"
         "#   stats_pool_kernel: its corrected reads equal its algorithmic bytes within 0.3 %%).  FETCH_SIZE counts L2-miss requests: Infinity-Cache hits are included.\n"
@@ -56,7 +56,7 @@ open("profiles/%s_pmc.txt" % tag, "w").write(hdr2 + "\n".join(keep) + "\n")
 fs = sum(v["FETCH_SIZE"][2] for k, v in vals.items() if k.startswith(GEMM) and "FETCH_SIZE" in v)
 ws = sum(v["WRITE_SIZE"][2] for k, v in vals.items() if k.startswith(GEMM) and "WRITE_SIZE" in v)
 n = sum(v["FETCH_SIZE"][0] for k, v in vals.items() if k.startswith(GEMM) and "FETCH_SIZE" in v)
-json.dump({"round": 2, "kernel": "GEMM kernels of a step (tdnn_first_kernel, tdnn_gemm_f16bf8_wide_kernel, tdnn_pair_pool_f16bf8_kernel, tdnn_gemm_bf16x3_kernel; launch-weighted mean)",
+json.dump({"round": 3, "kernel": "GEMM kernels of a step (tdnn_first_kernel, tdnn_gemm_f16bf8_wide_kernel, tdnn_pair_pool_f16bf8_kernel, tdnn_gemm_bf16x3_kernel; launch-weighted mean)",
            "source": "profiles/%s_pmc.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, default bench.py workload)" % tag,
            "kernel_sha": sha, "commit": commit, "batch_rows": under["config"]["batch_rows"], "launches": n,
            "gemm_fetch_kib_raw": round(fs / n, 1), "gemm_write_kib": round(ws / n, 1),
