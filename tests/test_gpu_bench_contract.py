@@ -65,6 +65,28 @@ def test_extraction_bench_line():
     assert j["breakdown_s"]["total"] <= j["wall_s"] and "import torch" in j["breakdown_s"] and "gather" in j["breakdown_s"]
 
 
+def test_two_ranks_through_the_self_launcher_on_one_gpu():
+    """`python bench.py --gpus 2`, the driver's command form: bench.py starts its own two ranks (xvector_amd/launch.py), they form
+    a group, run the sharded step with the gather and the max-over-ranks timing, and rank 0 alone prints ONE line.  A test box has
+    one GPU and RCCL refuses two ranks on one device, so the ranks share it over gloo (XV_BENCH_SHARE_GPU / XVECTOR_DIST_BACKEND):
+    the control flow of the N > 1 path on real kernels; the 8-GPU RCCL run itself is the driver's."""
+    env = dict(os.environ, XV_BENCH_SHARE_GPU="1", XVECTOR_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--utts", "600", "--steps", "2", "--warmup", "1",
+                          "--cpu-budget", "4", "--parity-utts", "4", "--e2e-utts", "0"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert run.returncode == 0, run.stderr.decode()[-2000:]
+    out = run.stdout.decode().strip().splitlines()
+    assert len(out) == 1, out
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["gather_ms"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 600 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]           # whole-job aggregate over both ranks
+    assert d["parity_rel_l2_max_vs_fp64_oracle"] < 1e-4 and "TEST MODE" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d and "e2e_ark_to_ark" not in d and "config2_varlen" not in d        # N = 1 only
+    assert d["with_ark_write"]["ark_mb"] > 2 * 600 * 2000 / 1e6                                          # both ranks' vectors reached rank 0
+
+
 def test_bench_at_the_per_rank_size_of_the_million_utterance_job():
     """BASELINE configs[3] gives every one of 8 ranks 125 k utterances: the resident-input step at that size (37.5 M frames,
     ~145 batches) on one GPU."""

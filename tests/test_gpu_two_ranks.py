@@ -1,0 +1,70 @@
+"""Two ranks of the REAL extractor on the one GPU a test box has.  RCCL refuses two ranks on one device, so the group runs over
+gloo (XVECTOR_DIST_BACKEND) and both ranks use cuda:0 (XVECTOR_DEVICE): everything of the N > 1 path except the transport --
+the launcher, the side-thread group bring-up, scp line-range sharding, ark byte-range sharding, the stream mode, the one
+gather, rank 0's writes -- against the bytes a single process writes.  The 8-GPU RCCL job itself is the driver's run."""
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, TWIN
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(nproc, args, env):
+    cmd = [sys.executable, "-m", "xvector_amd.launch", "--nproc", str(nproc), os.path.join(TWIN, "extract_embedding.py")] + args
+    run = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    log = run.stdout.decode(errors="replace")
+    assert run.returncode == 0, log[-3000:]
+    return log
+
+
+def test_two_rank_jobs_write_the_single_process_bytes(tmp_path, oracle_mod):
+    import kaldi_io
+    import models
+    from xvector_amd import hiplib, synthetic, topology
+    hiplib.require_gpu()
+    topo = topology.get("ModelWithoutDropout")
+    w = synthetic.trained_like(topo, 23, seed=5)
+    mdir = str(tmp_path / "nnet")
+    models.Model.save_model(dict(weights=w, topology=topo, model_class="ModelWithoutDropout", num_classes=64, feat_dim=23), mdir, None)
+    rng = np.random.default_rng(5)
+    n = 3000
+    lens = rng.integers(40, 400, size=n)
+    lens[::97] = 11                                                   # rejected: shorter than min_chunk_size
+    pool = [(rng.standard_normal((400, 23)) * 3.0).astype(np.float32) for _ in range(61)]
+    ark, scp = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")
+    with kaldi_io.TableWriter(ark, scp) as tw:
+        for i in range(n):
+            kaldi_io.write_mat(tw, pool[i % 61][:lens[i]], key="utt%05d" % i)
+    base = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG, os.environ.get("PYTHONPATH", "")]), XVECTOR_DEVICE="cuda:0",
+                XVECTOR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "XV_FORCE_DIST"):
+        base.pop(k, None)
+    common = ["--use-gpu", "yes", "--min-chunk-size", "25", "--chunk-size", "10000", "--model-dir", mdir]
+
+    def job(tag, nproc, rspec):
+        out_ark, out_scp = str(tmp_path / (tag + ".ark")), str(tmp_path / (tag + ".scp"))
+        log = _run(nproc, common + ["--feature-rspecifier", rspec, "--vector-wspecifier", "ark,scp:%s,%s" % (out_ark, out_scp)], base)
+        return open(out_ark, "rb").read(), open(out_scp).read().replace(out_ark, "ARK"), log
+
+    one_ark, one_scp, _ = job("one", 1, "scp:" + scp)
+    kept = int((lens >= 25).sum())
+    assert len(one_scp.splitlines()) == kept
+    # (a) scp table: sharded by line range;  (b) the ark file itself: sharded by byte range;  (c) a pipe: every rank reads it
+    for tag, rspec, marker in (("scp2", "scp:" + scp, None), ("ark2", "ark:" + ark, "bytes"), ("pipe2", "ark:cat %s |" % ark, None)):
+        got_ark, got_scp, log = job(tag, 2, rspec)
+        assert got_ark == one_ark and got_scp == one_scp, tag
+        assert "Job wall clock:" in log
+        if marker == "bytes":                          # both ranks report the byte range they took
+            assert "rank 0 of 2: records 0.." in log and "rank 1 of 2: records " in log, log[-1500:]
+    # parity of a sample against the fp64 oracle (what all four jobs wrote)
+    got = dict(kaldi_io.read_vec_flt_ark(io.BytesIO(one_ark)))
+    for i in (0, 1, n // 2, n - 1):
+        if lens[i] >= 25:
+            ref = oracle_mod.embed_utterance(pool[i % 61][:lens[i]], w, topo, 25, 10000, np.float64)
+            assert oracle_mod.rel_l2(got["utt%05d" % i], ref) < 1e-4

@@ -43,26 +43,27 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # XVECTOR_DIST_BACKEND=gloo: the control flow of a multi-rank job on a box with ONE GPU (all ranks share it; RCCL
+            # refuses two ranks on one device) -- what tests/test_gpu_bench_contract.py uses to run bench.py at N = 2
+            backend = os.environ.get("XVECTOR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-            # RCCL prints a five-line version banner through C stdio's stdout when its first communicator is created;
-            # callers of this package promise machine-readable stdout (bench.py: ONE JSON line), so fd 1 points at
-            # stderr while the communicator is brought up (a barrier forces it) and the C buffers are flushed
-            import ctypes
-            import sys
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group(backend=backend, rank=rank, world_size=world)
-                dist.barrier()
-                ctypes.CDLL(None).fflush(None)
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
-        else:
+        # RCCL prints a five-line version banner (and gloo its "[Gloo] Rank r is connected to ..." line) through C stdio's
+        # stdout when its first communicator is created; callers of this package promise machine-readable stdout (bench.py:
+        # ONE JSON line), so fd 1 points at stderr while the communicator is brought up (a barrier forces it) and the C
+        # buffers are flushed
+        import ctypes
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.barrier()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     return rank, world
 
 
@@ -150,11 +151,13 @@ def gather_blocks(local, counts, dst=0, group=None):
         padded = torch.zeros((cap, local.shape[1]), dtype=local.dtype, device=local.device)
         padded[: local.shape[0]] = local
     padded = padded.contiguous()
-    bucket = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, bucket, dst=dst, group=group)
+    staged = dist.get_backend(group) == "gloo" and padded.is_cuda       # gloo gathers host tensors only
+    send = padded.cpu() if staged else padded
+    bucket = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bucket, dst=dst, group=group)
     if rank != dst:
         return None
-    return [b[: counts[r]] for r, b in enumerate(bucket)]
+    return [(b.to(padded.device) if staged else b)[: counts[r]] for r, b in enumerate(bucket)]
 
 
 def unshard(blocks, shards, total, dim):
