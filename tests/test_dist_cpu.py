@@ -229,6 +229,7 @@ EMBED_WORKER = textwrap.dedent("""
     engine.Extractor = FakeExtractor
     models.Model.load_model = fake_load
     models.Model.window_frames = 400          # several windows, still ONE gather
+    models.Model.arena_bytes = models.Model.first_arena_bytes = 4096      # (in-place reader: one arena = one window)
 
     import torch.distributed as _d
     _calls = []
@@ -255,14 +256,15 @@ EMBED_WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("mode", ["file", "pipe", "file_with_a_double_record"])
+@pytest.mark.parametrize("mode", ["file", "pipe", "file_with_a_double_record", "pipe_exchange_every_2_windows"])
 def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path, mode):
     """Model.make_embedding under a 2-rank gloo group (stand-in extractor), ONE gather at the very end (however many windows),
     rank 0 alone writes -- exactly the bytes a single process writes (input order restored, rejected utterances dropped).
     * ``pipe``: a stream nobody can split -- every rank reads it and extracts its frame-balanced shard of each window;
     * ``file``: a seekable ark file is split by BYTE RANGES (one header-only index pass per rank, no collective for it): each
       rank reads only its own records' bytes -- together exactly the file, neither of them more than its share;
-    * a file holding a record the index pass does not take (a double-precision matrix) falls back to the stream mode."""
+    * a file holding a record the index pass does not take (a double-precision matrix) falls back to the stream mode;
+    * XVECTOR_EXCHANGE_WINDOWS=2: the stream mode exchanges (and rank 0 writes) every two windows instead of once at the end."""
     import kaldi_io
     from conftest import TWIN
     rng = np.random.default_rng(2)
@@ -274,7 +276,7 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path, mode):
             kaldi_io.write_mat(f, m.astype(np.float64) if (mode == "file_with_a_double_record" and i == 6) else m, key="utt%02d" % i)
     script = tmp_path / "embed_worker.py"
     script.write_text(EMBED_WORKER % (PKG, TWIN, os.path.dirname(PKG)))
-    extra = ["pipe"] if mode == "pipe" else []
+    extra = ["pipe"] if mode.startswith("pipe") else []
     single = subprocess.run([sys.executable, str(script), str(ark), str(tmp_path / "single")] + extra, stdout=subprocess.PIPE,
                             stderr=subprocess.STDOUT, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}, timeout=240)
     assert single.returncode == 0, single.stdout.decode()
@@ -282,6 +284,8 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path, mode):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if mode == "pipe_exchange_every_2_windows":
+            env["XVECTOR_EXCHANGE_WINDOWS"] = "2"
         procs.append(subprocess.Popen([sys.executable, str(script), str(ark), str(tmp_path / "dist")] + extra, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
@@ -290,7 +294,11 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path, mode):
     got = {k: v for k, v in kaldi_io.read_vec_flt_ark(str(tmp_path / "dist.0"))}
     assert open(str(tmp_path / "dist.0"), "rb").read() == want
     assert open(str(tmp_path / "dist.1"), "rb").read() == b""                      # the non-root rank writes nothing
-    assert all("EMBED_OK collectives=gather\n" in o for o in outs), outs         # the whole job: exactly one data-path collective
+    if mode == "pipe_exchange_every_2_windows":      # XVECTOR_EXCHANGE_WINDOWS: a bounded stash -- more gathers, still nothing but gathers
+        calls = [o.split("EMBED_OK collectives=")[1].split()[0].split(",") for o in outs]
+        assert calls[0] == calls[1] and len(calls[0]) >= 2 and set(calls[0]) == {"gather"}, calls
+    else:
+        assert all("EMBED_OK collectives=gather\n" in o for o in outs), outs     # the whole job: exactly one data-path collective
     assert list(got) == ["utt%02d" % i for i, t in enumerate(lens) if t >= 10]
     assert got["utt05"][-1] == 200.0
     ranged = [int(o.split("RANGE_BYTES=")[1].split()[0]) for o in outs]

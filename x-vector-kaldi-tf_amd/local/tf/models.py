@@ -115,6 +115,8 @@ def gather_shard_vectors(device_model, collector, shard_keys, rank, world):
 
 
 _SELECTED = {}           # checkpoint identity + request -> engine.select_model's report (see Model.load_model)
+_IDLE_MODELS = {}        # the same key -> DeviceModels of finished make_embedding calls (at most _IDLE_KEEP per key)
+_IDLE_KEEP = 1
 
 
 def _checkpoint_identity(model_dir):
@@ -154,6 +156,7 @@ class Model(object):
     # packed, one whose window is still in flight -- an arena goes back to the pool only when its window has been COLLECTED: an
     # f16bf8 window whose status word comes back set is packed a second time from the same addresses (Extractor.finish)
     arena_count = 5
+    exchange_windows = int(os.environ.get("XVECTOR_EXCHANGE_WINDOWS", "0"))      # multi-GPU stream mode: see make_embedding
     max_batch_rows = 262144
 
     def __init__(self):
@@ -217,13 +220,24 @@ class Model(object):
         key = _checkpoint_identity(input_dir) + (self.precision, self.embedding_index, _device(), engine.PROBE_LIMIT_F16BF8,
                                                  engine.PROBE_LIMIT_BF16X3, os.environ.get("XVECTOR_ACCURACY_PROBE", "1"))
         known = _SELECTED.get(key)
-        if known is not None:
+        idle = _IDLE_MODELS.get(key)
+        self._model_key = None
+        if known is not None and idle and getattr(self, "_may_borrow", False):
+            # the same checkpoint, loaded before in this process and not in use: its weights are packed on the device, its
+            # activation buffers allocated, its bf16x3 twin (accuracy probe, out-of-range windows) built -- a service that
+            # calls make_embedding per request pays the ~10 ms of all that once.  make_embedding hands the model back when it
+            # returns normally.
+            self.device_model = idle.pop()
+            self._model_key = key
+        elif known is not None:
             self.device_model = engine.DeviceModel(w, meta["topology"], _device(), self.embedding_index, known["selected"])
             self.device_model.selection = dict(known, cached=True)
+            self._model_key = key
         else:
             self.device_model = engine.select_model(w, meta["topology"], _device(), self.embedding_index, self.precision)
             if key[0] is not None:
                 _SELECTED[key] = dict(getattr(self.device_model, "selection", None) or {})
+                self._model_key = key
         sel = getattr(self.device_model, "selection", None) or {}
         if logger is not None:
             if sel.get("probed"):
@@ -573,10 +587,13 @@ class Model(object):
         reader_thread.start()
 
         try:
+            self._may_borrow = os.environ.get("XVECTOR_MODEL_CACHE", "1") != "0"
             self.load_model(None, model_dir, logger)
         except BaseException:
             cancel.set()
             raise
+        finally:
+            self._may_borrow = False
         F_dim = self.device_model.feat_dim
         ex = engine.Extractor(self.device_model, min_chunk_size, chunk_size, max_batch_rows=self.max_batch_rows)
         front = None
@@ -668,6 +685,13 @@ class Model(object):
             compute_time += time.time() - t0
             if len(out) == 3:                     # multi-GPU: this rank's share of the window; exchanged once, at the end
                 stash.append((keys, lens, out[1], out[2]))
+                # XVECTOR_EXCHANGE_WINDOWS=N (default 0 = the single gather at the very end): exchange -- and let rank 0 write --
+                # every N windows instead: bounds what a rank holds and what a late failure loses on an endless pipe, at the
+                # price of N-th as many collectives.  Every rank sees the same windows, so the counts agree without talking.
+                if self.exchange_windows > 0 and len(stash) >= self.exchange_windows:
+                    xdist.wait_process_group()
+                    self._exchange_shards(stash, rank, world, min_chunk_size, chunk_size, emit)
+                    del stash[:]
                 return
             emit(keys, lens, *out)
 
@@ -738,7 +762,7 @@ class Model(object):
                 collect(*in_flight[0])
                 for held in in_flight[1]:
                     pool.put(held)
-            if world > 1:
+            if world > 1 and (stash or not self.exchange_windows):
                 xdist.wait_process_group()
                 self._exchange_shards(stash, rank, world, min_chunk_size, chunk_size, emit)
         finally:
@@ -751,6 +775,10 @@ class Model(object):
         if writer_error:
             raise writer_error[0]
 
+        if getattr(self, "_model_key", None) is not None and hasattr(self.device_model, "frame_level"):
+            parked = _IDLE_MODELS.setdefault(self._model_key, [])         # (only after a complete pass: the model is in a known state)
+            if len(parked) < _IDLE_KEEP and all(m is not self.device_model for m in parked):
+                parked.append(self.device_model)
         st = ex.stats
         if st.get("probe_windows"):
             logger.info("Accuracy probe on the input: f16bf8 vs bf16x3 chunk vectors differ by at most %.2e over %d probed window(s)%s" % (
