@@ -642,6 +642,8 @@ def probe_batch(feat_dim, in_dim, gap, align, chunks=8, frames=256, seed=2024091
 
 def _max_rel_l2(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if not (np.isfinite(a).all() and np.isfinite(b).all()):
+        return float("inf")                       # a NaN on either side must never read as agreement
     num = np.sqrt(((a - b) ** 2).sum(axis=1))
     den = np.sqrt((b ** 2).sum(axis=1))
     with np.errstate(invalid="ignore", divide="ignore"):
