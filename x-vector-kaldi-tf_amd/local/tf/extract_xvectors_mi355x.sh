@@ -28,7 +28,9 @@ model_dir=$srcdir; [[ -e $srcdir/model_final ]] && model_dir=$srcdir/model_final
 mkdir -p "$dir/log"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 launcher=(python)
-[[ $ngpu -gt 1 ]] && launcher=(python -m torch.distributed.run --nnodes=1 --nproc-per-node "$ngpu" --master-addr 127.0.0.1 --master-port 29511)
+# one process per GPU through the package's own launcher (xvector_amd/launch.py: torch.distributed.run's environment contract
+# without its elastic agent -- seconds of start-up per job); `python -m torch.distributed.run --nproc-per-node N ...` works as well
+[[ $ngpu -gt 1 ]] && launcher=(env PYTHONPATH="$here/../..${PYTHONPATH:+:$PYTHONPATH}" python -m xvector_amd.launch --nproc "$ngpu")
 "${launcher[@]}" "$here/extract_embedding.py" --use-gpu=yes --min-chunk-size="$min_chunk_size" --chunk-size="$chunk_size" \
     --feature-rspecifier="scp:$data/feats.scp" --vad-rspecifier="scp:$data/vad.scp" --cmn-window="$cmn_window" --cmn-center=yes \
     --vector-wspecifier="ark,scp:$dir/xvector.ark,$dir/xvector.scp" --model-dir="$model_dir" 2>&1 | tee "$dir/log/extract.log"
