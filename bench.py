@@ -116,14 +116,31 @@ def _train_run(args, rank, world, dev, topo, feat, precision, steps, warmup):
         torch.cuda.synchronize()
 
     losses = []
+    # one untimed step at the LONGEST minibatch first: torch's caching allocator then owns blocks every later step can be carved
+    # from (each new length otherwise costs a round of hipMalloc calls -- a training run pays that in its first few hundred steps,
+    # a 30-step measurement would be mostly that; steady state: tools/train_drift.py)
+    lab0 = rng.integers(0, n_spk, B)
+    tr.step((spk[lab0][:, None, :] + rng.standard_normal((B, args.tmax, feat)) * 3).astype(np.float16), lab0.astype(np.int32), 0.0)
     for i in range(warmup):
         tr.step(batches[i][0], batches[i][1], 1e-3)
+    # the interpreter's cyclic garbage collector stays out of the timed region: a full collection of this process's object
+    # graph is a 40 ms pause -- one of them inside a 30-step window moved the result from 3.7 to 4.8 ms per step
+    import gc
+    gc.collect()
+    gc.disable()
     fence()
     t0 = time.perf_counter()
+    per_step = []
     for i in range(warmup, n_total):
+        t1 = time.perf_counter()
         losses.append(tr.step(batches[i][0], batches[i][1], 1e-3)[0])
+        per_step.append(time.perf_counter() - t1)              # (every step ends with the read-back of its loss)
+
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("XV_BENCH_STEP_TIMES") == "1":
+        sys.stderr.write("step ms: " + " ".join("%.2f" % (t * 1e3) for t in per_step) + "\n")
     if dist.is_initialized():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -561,6 +578,9 @@ def main():
 
     for si in range(args.warmup):
         step(si)
+    import gc
+    gc.collect()
+    gc.disable()                             # (no 40 ms collector pause inside the timed region; see _train_run)
     fence()
     t0 = time.perf_counter()
     last = None
@@ -568,6 +588,7 @@ def main():
         last = step(si)
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     if dist.is_initialized():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

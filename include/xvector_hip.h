@@ -297,6 +297,11 @@ int xv_sumsq_f32(const float *x, int64_t n, float *out, void *workspace, void *s
  * 1/keep_prob) iff the top 32 bits of splitmix64(seed ^ 0x9E3779B97F4A7C15*(r*C + c + 1)) < keep_prob*2^32, else zeroed.
  * Stateless: the same call on the gradient buffer is the backward pass.  keep_prob == 1 is a no-op. */
 int xv_dropout_f32(float *x, int ldx, int64_t R, int c, uint64_t seed, float keep_prob, void *stream);
+/* A training minibatch src[B, T, F] (float16 when src_is_f16, else float32; DEVICE pointer like everything else) -> the packed
+ * rows-with-gaps matrix dst[rows, in_dim] of the header comment: chunk b at rows gap + b*(T+gap), all other rows and the columns
+ * F..in_dim-1 zero; rows >= gap + B*(T+gap).  Replaces the feed_dict hand-over of models.py:255-262 (the egs hold float16). */
+int xv_pack_minibatch_f32(const void *src, int src_is_f16, int B, int T, int F, int gap, int in_dim, float *dst, int64_t rows,
+                          void *stream);
 
 /* PReLU backward (tf_block.py:38-47): on entry dr = dL/d(activation output), z = pre-activation; on exit
  * dr = dL/dz = dr * (z > 0 ? 1 : alpha[c]) and z = dr_in * min(z, 0), whose column sums (xv_col_sums_f32) are dL/dalpha. */

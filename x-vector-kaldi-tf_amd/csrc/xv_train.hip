@@ -555,6 +555,30 @@ __global__ __launch_bounds__(64) void sumsq_final_kernel(const double *__restric
     }
 }
 
+// A minibatch [B, T, F] (fp16 or fp32, as the egs loader hands it over: examples_io.py:165,176 store float16) -> the packed fp32
+// rows with gaps the TDNN kernels read: chunk b at rows gap + b (T + gap) .. + T, every other row and the padding columns zero.
+// (Round 3: this was host work -- np.zeros, astype, a strided assignment and a pageable copy, 0.7 ms in front of every step with
+// the GPU idle; now the raw bytes go up from a pinned buffer and one small kernel converts and scatters.)
+template <typename T_IN>
+__global__ void pack_minibatch_kernel(const T_IN *__restrict__ src, int B, int T, int F, int gap, int in_dim, long rows,
+                                      float *__restrict__ dst)
+{
+    const size_t n = (size_t)rows * in_dim;
+    const int slot = T + gap;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const long r = (long)(i / (unsigned)in_dim);
+        const int c = (int)(i - (size_t)r * in_dim);
+        float v = 0.f;
+        if (r >= gap && c < F) {
+            const long q = r - gap;
+            const long b = q / slot;
+            const int t = (int)(q - b * slot);
+            if (b < B && t < T) v = (float)src[((size_t)b * T + t) * F + c];
+        }
+        dst[i] = v;
+    }
+}
+
 inline unsigned gs_blocks(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 }  // namespace
@@ -724,6 +748,22 @@ int xv_sumsq_f32(const float *x, int64_t n, float *out, void *workspace, void *s
     if (rc) return rc;
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)workspace, nb, out);
     return tcheck("sumsq_final_kernel");
+}
+
+int xv_pack_minibatch_f32(const void *src, int src_is_f16, int B, int T, int F, int gap, int in_dim, float *dst, int64_t rows,
+                          void *stream)
+{
+    if (!src || !dst || B <= 0 || T <= 0 || F <= 0 || gap < 0 || in_dim < F || rows < (int64_t)gap + (int64_t)B * (T + gap))
+        return tfail(XV_ERR_BAD_ARG, "pack_minibatch: bad argument");
+    const size_t n = (size_t)rows * in_dim;
+    const dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 4096));
+    if (src_is_f16)
+        hipLaunchKernelGGL(pack_minibatch_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)src, B, T, F, gap,
+                           in_dim, (long)rows, dst);
+    else
+        hipLaunchKernelGGL(pack_minibatch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, B, T, F, gap, in_dim,
+                           (long)rows, dst);
+    return tcheck("pack_minibatch_kernel");
 }
 
 int xv_dropout_f32(float *x, int ldx, int64_t R, int c, uint64_t seed, float keep_prob, void *stream)

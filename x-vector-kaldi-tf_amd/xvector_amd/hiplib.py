@@ -26,7 +26,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
-           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32",
+           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32", "xv_pack_minibatch_f32",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
            "xv_cmn_sliding_scatter_f32",
@@ -164,6 +164,8 @@ def load():
     lib.xv_sumsq_f32.argtypes = [vp, i64, vp, vp, vp]
     lib.xv_dropout_f32.restype = ci
     lib.xv_dropout_f32.argtypes = [vp, ci, i64, ci, ctypes.c_uint64, cf, vp]
+    lib.xv_pack_minibatch_f32.restype = ci
+    lib.xv_pack_minibatch_f32.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, i64, vp]
     lib.xv_prelu_backward_f32.restype = ci
     lib.xv_prelu_backward_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp]
     lib.xv_l2_normalize_rows_f32.restype = ci
@@ -194,13 +196,21 @@ def load():
     return lib
 
 
+_GPU_SEEN = []
+
+
 def require_gpu():
-    """Load the library and insist on a visible GPU.  Called by every compute entry point."""
+    """Load the library and insist on a visible GPU.  Called by every compute entry point.  (Only the POSITIVE answer is
+    remembered: a training step makes ~150 calls, and torch.cuda.is_available() behind each of them was a tenth of the host
+    time of a step; without a GPU every call still raises.)"""
+    if _GPU_SEEN:
+        return _GPU_SEEN[0]
     lib = load()
     import torch
     if not torch.cuda.is_available():
         raise XvectorHipError("no MI355X visible (torch.cuda.is_available() is False): the x-vector hot path "
                               "has no CPU fallback")
+    _GPU_SEEN.append(lib)
     return lib
 
 
@@ -219,8 +229,19 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = []
+
+
 def _stream():
+    """The HIP stream torch considers current on the current device (the launches of this package go where torch's own work
+    goes).  Through torch's raw-stream accessor when it has one: building a torch.cuda.Stream object per launch was a fifth of
+    the host time of a training step."""
     import torch
+    if not _RAW_STREAM:
+        _RAW_STREAM.append(getattr(torch._C, "_cuda_getCurrentRawStream", None))
+    raw = _RAW_STREAM[0]
+    if raw is not None:
+        return ctypes.c_void_p(raw(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -753,6 +774,17 @@ def sumsq(x, out):
     assert x.is_contiguous()
     ws = _ws(lib.xv_sumsq_workspace_bytes(x.numel()), x.device)
     _check(lib.xv_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _ptr(ws), _stream()), "xv_sumsq_f32")
+
+
+def pack_minibatch(src, B, T, F, gap, dst):
+    """src: device tensor holding a [B, T, F] minibatch (float16 or float32, contiguous) -> dst[rows, in_dim] float32: the packed
+    rows with gaps (chunk b at rows gap + b*(T+gap)), everything else zero."""
+    import torch
+    lib = require_gpu()
+    assert src.is_cuda and src.is_contiguous() and src.dtype in (torch.float16, torch.float32) and src.numel() >= B * T * F
+    _f32(dst, "dst"); assert dst.dim() == 2 and dst.is_contiguous()
+    _check(lib.xv_pack_minibatch_f32(_ptr(src), 1 if src.dtype == torch.float16 else 0, int(B), int(T), int(F), int(gap), dst.shape[1],
+                                     _ptr(dst), dst.shape[0], _stream()), "xv_pack_minibatch_f32")
 
 
 def dropout(x, seed, keep_prob, rows=None):

@@ -115,17 +115,26 @@ class Trainer(object):
         """[(kind, index)] of the tf.nn.dropout sites: after every frame-level / embedding layer but the last of its group."""
         return [("frame", i) for i in range(len(self.frame_scopes) - 1)] + [("embed", j) for j in range(len(self.embed_scopes) - 1)]
 
-    def _l2_value(self):
-        """beta * sum coef * tf.nn.l2_loss(t) over the penalised tensors (0 for classes without the L2 term)."""
+    def _l2_launch(self):
+        """The sums of squares of the penalised tensors, enqueued (None for classes without the L2 term): read by _l2_read."""
         if not self.l2_beta:
-            return 0.0
+            return None
         torch = self.torch
         names = [sc + s for sc, _ in self.l2_terms for s in ("/w:0", "/b:0")]
         out = torch.empty(len(names), dtype=torch.float32, device=self.device)
         for i, n in enumerate(names):
             hiplib.sumsq(self.P[n], out[i:i + 1])
+        return out
+
+    def _l2_read(self, out):
+        if out is None:
+            return 0.0
         v = out.cpu().numpy().astype(np.float64)
         return float(self.l2_beta * sum(coef * 0.5 * (v[2 * i] + v[2 * i + 1]) for i, (_, coef) in enumerate(self.l2_terms)))
+
+    def _l2_value(self):
+        """beta * sum coef * tf.nn.l2_loss(t) over the penalised tensors (0 for classes without the L2 term)."""
+        return self._l2_read(self._l2_launch())
 
     # -- weights in kernel layout (re-packed after every optimizer step) -----------------------------------------
     def _w3(self, scope, k):
@@ -155,11 +164,30 @@ class Trainer(object):
         self._packed = pk
         return pk
 
+    def _stage_in(self, x):
+        """A contiguous float16 / float32 / int32 host array -> a device tensor of the same dtype, through one of two alternating
+        pinned buffers per dtype (the copy is asynchronous -- a pageable ``.to(device)`` in the middle of a step makes the host
+        wait for everything enqueued before it; the buffer of step i is not touched again before step i+2, and every step ends
+        with a read-back of its loss)."""
+        torch = self.torch
+        dt = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32}[x.dtype]
+        slots = self.__dict__.setdefault("_in_stage", {})
+        turns = self.__dict__.setdefault("_in_turn", {})
+        turn = turns[dt] = turns.get(dt, 0) ^ 1
+        pin = slots.get((dt, turn))
+        if pin is None or pin.numel() < x.size:
+            pin = slots[(dt, turn)] = torch.empty(max(x.size, 1) * 5 // 4 + 64, dtype=dt).pin_memory()
+        host = pin[:x.size]
+        host.numpy()[:] = x.reshape(-1)
+        return host.to(self.device, non_blocking=True)
+
     def _layout(self, B, T):
         key = (B, T)
         if key not in self._layouts:
             torch = self.torch
             lay = BatchLayout([T] * B, self.gap)
+            # (pageable copies, i.e. host synchronisations -- but once per distinct T and at the very start of a step, where the
+            # stream is empty anyway; pinning three small arrays per new T costs more than it saves)
             self._layouts[key] = dict(lay=lay, rs=torch.from_numpy(lay.row_start).to(self.device),
                                       rl=torch.from_numpy(lay.row_len).to(self.device),
                                       rv=torch.from_numpy(lay.row_valid()).to(self.device),
@@ -199,10 +227,14 @@ class Trainer(object):
                                                   labels.max() if labels.size else "-"))
         L = self._layout(B, T)
         lay = L["lay"]
-        host = np.zeros((lay.rows, self.in_dim), np.float32)
-        view = host[self.gap:self.gap + B * (T + self.gap)].reshape(B, T + self.gap, self.in_dim)
-        view[:, :T, :F] = x.astype(np.float32)
-        X = torch.from_numpy(host).to(self.device)
+        lab = self._stage_in(np.ascontiguousarray(labels, dtype=np.int32))
+        # the minibatch goes up as it is (float16 from the egs loader, examples_io.py:165,176) through a pinned staging buffer;
+        # conversion to fp32 and the scatter into rows with gaps happen on the device (xv_pack_minibatch_f32)
+        if x.dtype not in (np.float16, np.float32):
+            x = x.astype(np.float32)
+        raw = self._stage_in(np.ascontiguousarray(x))
+        X = torch.empty((lay.rows, self.in_dim), dtype=torch.float32, device=self.device)
+        hiplib.pack_minibatch(raw, B, T, F, self.gap, X)
         pk = self._pack()
         drop = train and self.has_dropout and keep_prob < 1.0
         sites = self._dropout_sites()
@@ -250,7 +282,6 @@ class Trainer(object):
                 hiplib.dropout(a, S["seeds"][("embed", j)], S["keep"])
             S["e_r"].append(r); S["e_z"].append(z); S["e_in"].append(a); S["e_mean"].append(mean); S["e_var"].append(var)
         logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=self.device)
-        lab = torch.from_numpy(np.asarray(labels, dtype=np.int32)).to(self.device)
         if self.am:
             # cosines of the L2-normalised features and class vectors (columns of output/w), then margin + scale in place
             S["xh"], S["xnorm"] = hiplib.l2_normalize_rows(S["e_in"][-1])
@@ -341,7 +372,7 @@ class Trainer(object):
                     for suffix in ("/w:0", "/b:0"):
                         hiplib.axpy(grads[sc + suffix], self.P[sc + suffix], self.l2_beta * coef)
 
-    def gradients(self, x, labels, dropout_proportion=0.0, seed=0, on_bucket=None):
+    def gradients(self, x, labels, dropout_proportion=0.0, seed=0, on_bucket=None, defer_loss=False):
         """Forward (train phase, updates the moving statistics) + backward.  Returns (loss, acc, {name: grad tensor});
         ``on_bucket(i)`` (optional) is called as soon as range i of ``_ready_ranges()`` is final;
         the tensors are views into ``self.flat_g`` and are overwritten by the next call.
@@ -405,6 +436,11 @@ class Trainer(object):
                                       L["rv"])
             if on_bucket is not None and i in fire_after:
                 on_bucket(fire_after[i])
+        if defer_loss:
+            # (step(): loss, accuracy and the L2 penalty of the CURRENT weights are computed here, in stream order in front of
+            # the optimizer update, but read back only after that update has been enqueued -- the read is the step's one host
+            # synchronisation, and everything launched before it runs while the host waits)
+            return (S["loss_acc"], self._l2_launch()), None, grads
         la = S["loss_acc"].cpu().numpy()
         return float(la[0]) + self._l2_value(), float(la[1]), grads
 
@@ -427,7 +463,7 @@ class Trainer(object):
                 works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, async_op=True))
         else:
             on_bucket = None
-        loss, acc, grads = self.gradients(x, labels, dropout_proportion, seed, on_bucket)     # every grad is a view into flat_g
+        pending, _, grads = self.gradients(x, labels, dropout_proportion, seed, on_bucket, defer_loss=True)   # grads: views into flat_g
         for w in works:
             w.wait()
         if works and dist.get_world_size() > 1:
@@ -436,7 +472,8 @@ class Trainer(object):
         lr_t = learning_rate * math.sqrt(1.0 - ADAM_B2 ** self.t) / (1.0 - ADAM_B1 ** self.t)
         hiplib.adam(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS)
         self._packed = None
-        return loss, acc
+        la = pending[0].cpu().numpy()
+        return float(la[0]) + self._l2_read(pending[1]), float(la[1])
 
     def export(self):
         """-> (weights {tf name: float32 ndarray}, adam {"t", "m", "v"}) for the model directory."""
