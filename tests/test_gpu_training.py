@@ -222,6 +222,25 @@ def test_wgrad_and_reductions_unit(env):
         assert _rel(sab.cpu().numpy(), (dz.astype(np.float64) * b).sum(0)) < 1e-6
 
 
+def test_pack_minibatch_on_the_device(env):
+    """xv_pack_minibatch_f32: a [B, T, F] minibatch (float16 as the egs store it, or float32) -> the packed fp32 rows with gaps:
+    chunk b at rows gap + b (T + gap), every gap row, every row past the last chunk and the padding columns exactly zero; values
+    are the exact float32 images of the inputs."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    rng = np.random.default_rng(3)
+    for (B, T, F, gap, in_dim, extra) in ((64, 37, 23, 3, 24, 0), (3, 5, 8, 0, 8, 2), (7, 200, 23, 4, 24, 5)):
+        rows = gap + B * (T + gap) + extra
+        for dt in (np.float16, np.float32):
+            x = (rng.standard_normal((B, T, F)) * 3).astype(dt)
+            dst = torch.full((rows, in_dim), float("nan"), dtype=torch.float32, device="cuda:0")
+            hiplib.pack_minibatch(torch.from_numpy(x).cuda(), B, T, F, gap, dst)
+            want = np.zeros((rows, in_dim), np.float32)
+            for b in range(B):
+                r0 = gap + b * (T + gap)
+                want[r0:r0 + T, :F] = x[b].astype(np.float32)
+            assert np.array_equal(dst.cpu().numpy(), want), (B, T, F, gap, in_dim, dt)
+
+
 def test_l2_loss_class_gradients(env):
     """ModelL2LossWithoutDropoutLRelu: loss and gradients include beta*(0.1*l2(embed-0) + l2(embed-1) + l2(output))."""
     topo, w, rng = _setup(env, "ModelL2LossWithoutDropoutLRelu", seed=13)
