@@ -390,3 +390,24 @@ def test_two_rank_gloo_cli_shards_an_scp_table(tmp_path):
     assert not os.path.exists(str(tmp_path / "two.ark.tmp.ark"))
     # north star: "a single RCCL gather at the end" -- no object collectives for counts or keys (the line ranges are deterministic)
     assert all("CLI_OK collectives=gather\n" in o for o in outs), outs
+    # XVECTOR_SHARD_OUTPUT=files: the reference's own protocol (extract_xvectors.sh:83-95) -- every rank writes its own ark while
+    # it extracts, rank 0 concatenates the scp parts; no process group, no collective at all; same keys, order and vectors
+    port += 1
+    procs = []
+    for r in range(2):
+        env = dict(base_env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   XVECTOR_SHARD_OUTPUT="files")
+        procs.append(subprocess.Popen([sys.executable, str(script)] + flags("three"), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("CLI_OK collectives=\n" in o for o in outs), outs
+    want = list(kaldi_io.read_vec_flt_scp(str(tmp_path / "one.scp")))
+    got = list(kaldi_io.read_vec_flt_scp(str(tmp_path / "three.scp")))
+    assert [k for k, _ in got] == [k for k, _ in want] and all(np.array_equal(a, b) for (_, a), (_, b) in zip(got, want))
+    lines = open(str(tmp_path / "three.scp")).read().splitlines()
+    assert {ln.split()[1].rsplit(":", 1)[0] for ln in lines} == {str(tmp_path / "three.ark.0"), str(tmp_path / "three.ark.1")}
+    assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f or ".tmp" in f]
+    # (a second call finds the table complete and returns, like the reference's extract_embedding.py:126-128)
+    again = subprocess.run([sys.executable, str(script)] + flags("three"), env=dict(base_env, XVECTOR_SHARD_OUTPUT="files"),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert again.returncode == 0 and "Both output ark and scp files exist" in again.stdout.decode()

@@ -75,6 +75,19 @@ def test_one_rank_share_of_the_million_utterance_job(oracle_mod, tmp_path):
         print("\n%s: %.2f s wall = %.0f utt/s\n  %s" % (attempt, t_cli, n / t_cli, clock[-1].split("] ", 1)[-1]))
     if n == 125000:
         assert walls[1] <= JOB_WALL_LIMIT, "the 125 k-utterance shard took %.2f s of wall clock (limit %.1f)" % (walls[1], JOB_WALL_LIMIT)
+    # the same shard with XVECTOR_SHARD_OUTPUT=files (the reference's own protocol: one ark per job + a concatenated scp,
+    # extract_xvectors.sh:83-95): no process group, so nothing of RCCL's bring-up is in the job; same vectors, same order
+    f_ark, f_scp = str(tmp_path / "xvector_f.ark"), str(tmp_path / "xvector_f.scp")
+    cmd_f = [c.replace("ark,scp:%s,%s" % (ark, scp), "ark,scp:%s,%s" % (f_ark, f_scp)) for c in cmd]
+    t0 = time.time()
+    run = subprocess.run(cmd_f, env=dict(env, XVECTOR_SHARD_OUTPUT="files"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    t_files = time.time() - t0
+    log_f = run.stdout.decode(errors="replace")
+    assert run.returncode == 0, log_f[-3000:]
+    clock = [ln for ln in log_f.splitlines() if "Job wall clock:" in ln]
+    print("\nXVECTOR_SHARD_OUTPUT=files: %.2f s wall = %.0f utt/s\n  %s" % (t_files, n / t_files, clock[-1].split("] ", 1)[-1]))
+    assert open(f_scp).read().replace(f_ark + ".0", "ARK") == open(scp).read().replace(ark, "ARK")
+    assert open(f_ark + ".0", "rb").read() == open(ark, "rb").read()
     assert "Done %d and failed %d" % (n - n // 5000, n // 5000) in log, log[-2000:]
     # order, keys, framing: one FV record per surviving utterance, in input order, nothing else in the file
     kept = [i for i in range(n) if lens[i] >= 25]

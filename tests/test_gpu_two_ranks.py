@@ -62,7 +62,15 @@ def test_two_rank_jobs_write_the_single_process_bytes(tmp_path, oracle_mod):
         assert "Job wall clock:" in log
         if marker == "bytes":                          # both ranks report the byte range they took
             assert "rank 0 of 2: records 0.." in log and "rank 1 of 2: records " in log, log[-1500:]
-    # parity of a sample against the fp64 oracle (what all four jobs wrote)
+    # (d) XVECTOR_SHARD_OUTPUT=files: one ark per rank + a concatenated scp, no process group at all: same keys, order, vectors
+    files_env = dict(base, XVECTOR_SHARD_OUTPUT="files")
+    f_ark, f_scp = str(tmp_path / "files.ark"), str(tmp_path / "files.scp")
+    _run(2, common + ["--feature-rspecifier", "scp:" + scp, "--vector-wspecifier", "ark,scp:%s,%s" % (f_ark, f_scp)], files_env)
+    want = list(kaldi_io.read_vec_flt_ark(io.BytesIO(one_ark)))
+    got_f = list(kaldi_io.read_vec_flt_scp(f_scp))
+    assert [k for k, _ in got_f] == [k for k, _ in want] and all(np.array_equal(a, b) for (_, a), (_, b) in zip(got_f, want))
+    assert os.path.exists(f_ark + ".0") and os.path.exists(f_ark + ".1") and not os.path.exists(f_scp + ".0.part")
+    # parity of a sample against the fp64 oracle (what all the jobs wrote)
     got = dict(kaldi_io.read_vec_flt_ark(io.BytesIO(one_ark)))
     for i in (0, 1, n // 2, n - 1):
         if lens[i] >= 25:

@@ -192,7 +192,7 @@ def _is_scp_table(rspecifier):
 def eval_dnn(args):
     use_gpu = args.use_gpu == 'yes'
     wspecifier, ark, scp = process_wspecifier(args.vector_wspecifier)
-    if ark is not None and os.path.exists(ark) and scp is not None and os.path.exists(scp):
+    if ark is not None and scp is not None and os.path.exists(scp) and (os.path.exists(ark) or os.path.exists(ark + '.0')):
         logger.info('Both output ark and scp files exist. Return from this call.')
         return
     # under torchrun (one process per GPU) only rank 0 owns the output table.  An scp feature table is sharded by line
@@ -201,6 +201,9 @@ def eval_dnn(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     root = rank == 0
     grouped = world > 1 or (os.environ.get("XV_FORCE_DIST") == "1" and "RANK" in os.environ)     # the latter: 1-rank group (tests)
+    if grouped and _is_scp_table(args.feature_rspecifier) and (not args.vad_rspecifier or _is_scp_table(args.vad_rspecifier)) and \
+            _native_table(wspecifier, ark) and os.environ.get("XVECTOR_SHARD_OUTPUT", "gather") == "files":
+        return _extract_into_shard_files(args, use_gpu, ark, scp, rank, world)
     if grouped:
         # the process group is only needed for the ONE gather at the end: RCCL comes up on a side thread while this one loads
         # the model and extracts (nothing is written to the output before that gather, so the stdout redirection of
@@ -247,6 +250,49 @@ def eval_dnn(args):
         os.rename(scp + '.tmp', scp)
         os.remove(scp + '.tmp.scp')
     jobclock.mark("rename")
+    logger.info(jobclock.line())
+
+
+def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
+    """XVECTOR_SHARD_OUTPUT=files -- the reference's own output protocol instead of the gather: there every job writes
+    ``xvector.JOB.ark`` / ``.scp`` and the script concatenates the scp files (extract_xvectors.sh:83-95).  Here rank r extracts its
+    line range of the scp into ``<ark>.r`` while it runs (no collector, no final burst of writes through one rank), and rank 0
+    concatenates the ranks' scp parts -- whose lines name ``<ark>.r`` -- into ``<scp>`` in rank order = input order.  No process
+    group exists in this mode: nothing waits for RCCL's bring-up (about a third of a short job's wall clock), N ranks write N
+    files at once, and what is left of a job that dies late are the complete shards of the ranks that finished.  The ranks meet
+    through the file system: a part appears under its final name (``<scp>.r.part``) only when it is complete."""
+    import time
+    feat_scp, vad_scp, _ = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
+    feats = kaldi_io.MatScp(feat_scp)
+    vad = kaldi_io.VecScp(vad_scp) if vad_scp is not None else None
+    jobclock.mark("tables opened")
+    my_ark, my_scp = '%s.%d' % (ark, rank), '%s.%d.part' % (scp, rank)
+    for stale in (my_ark, my_scp):
+        if os.path.exists(stale):
+            os.remove(stale)
+    with kaldi_io.TableWriter(my_ark + '.tmp.ark', my_scp + '.tmp', scp_ark_name=my_ark) as out:
+        Model().make_embedding(feats, out, args.model_dir, args.min_chunk_size, args.chunk_size, use_gpu, logger, vad_stream=vad,
+                               cmn_window=args.cmn_window, cmn_center=args.cmn_center == 'yes', distributed=False)
+    os.rename(my_ark + '.tmp.ark', my_ark)
+    os.rename(my_scp + '.tmp', my_scp)
+    jobclock.mark("extraction + write of this rank's shard")
+    if rank != 0:
+        return
+    deadline = time.time() + float(os.environ.get("XVECTOR_SHARD_TIMEOUT", "3600"))
+    parts = ['%s.%d.part' % (scp, r) for r in range(world)]
+    while not all(os.path.exists(p) for p in parts):
+        if time.time() > deadline:
+            raise RuntimeError("sharded extraction: still waiting for %s" % ", ".join(p for p in parts if not os.path.exists(p)))
+        time.sleep(0.02)
+    jobclock.mark("wait for the other ranks' shards")
+    with open(scp + '.tmp', 'wb') as fid_out:
+        for p in parts:
+            with open(p, 'rb') as fid_in:
+                fid_out.write(fid_in.read())
+    os.rename(scp + '.tmp', scp)
+    for p in parts:
+        os.remove(p)
+    jobclock.mark("scp concatenated")
     logger.info(jobclock.line())
 
 
