@@ -328,11 +328,9 @@ def _cli_job_leg(args, ark_path, scp_path, model_dir, n):
         env.pop(k, None)
     runs = []
     try:
-        for _ in range(2):
-            o_ark, o_scp = os.path.join(out_dir, "xvector.ark"), os.path.join(out_dir, "xvector.scp")
-            for f in (o_ark, o_scp):
-                if os.path.exists(f):
-                    os.remove(f)
+        for attempt in range(3):                               # 0, 1: the RCCL gather (cold, warm); 2: XVECTOR_SHARD_OUTPUT=files
+            o_ark, o_scp = os.path.join(out_dir, "xvector%d.ark" % attempt), os.path.join(out_dir, "xvector%d.scp" % attempt)
+            env["XVECTOR_SHARD_OUTPUT"] = "files" if attempt == 2 else "gather"
             cmd = [sys.executable, "-m", "xvector_amd.launch", "--nproc", "1",
                    os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf", "extract_embedding.py"), "--use-gpu", "yes",
                    "--min-chunk-size", "25", "--chunk-size", "10000", "--feature-rspecifier", "scp:" + scp_path,
@@ -352,6 +350,8 @@ def _cli_job_leg(args, ark_path, scp_path, model_dir, n):
         shutil.rmtree(out_dir, ignore_errors=True)
     return {"value": runs[1]["utt_per_s"], "unit": "utt/s", "utterances": n, "wall_s": runs[1]["wall_s"],
             "breakdown_s": runs[1]["breakdown_s"], "first_job_on_this_box": runs[0],
+            "shard_files": dict(runs[2], note="XVECTOR_SHARD_OUTPUT=files: one ark per rank + a concatenated scp (the reference's "
+                                              "own protocol, extract_xvectors.sh:83-95), no process group"),
             "path": "python -m xvector_amd.launch --nproc 1 extract_embedding.py scp: -> ark,scp: (tmpfs), forced 1-rank RCCL group; wall "
                     "clock of the whole job from outside, second of two runs"}
 

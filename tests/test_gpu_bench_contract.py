@@ -63,6 +63,7 @@ def test_extraction_bench_line():
     j = d["cli_job"]
     assert j["utterances"] == 700 and j["first_job_on_this_box"]["vectors_written"] == 700 and 0 < j["wall_s"] < 60
     assert j["breakdown_s"]["total"] <= j["wall_s"] and "import torch" in j["breakdown_s"] and "gather" in j["breakdown_s"]
+    assert j["shard_files"]["vectors_written"] == 700 and "gather" not in j["shard_files"]["breakdown_s"]
 
 
 def test_two_ranks_through_the_self_launcher_on_one_gpu():
