@@ -419,6 +419,124 @@ def test_tdnn_first_layer_kernel_matches_oracle_and_the_general_kernel(env, feat
     assert (np.abs(tail) > 1e30).all()
 
 
+@pytest.mark.parametrize("fmt", ["split8", "split"])
+@pytest.mark.parametrize("cout,tiles", [(512, 1), (512, 2), (512, 3), (512, 5), (512, 8), (288, 7), (512, 0)])
+def test_tdnn_first_layer_any_number_of_tiles_per_wave(env, cout, tiles, fmt):
+    """The first-layer kernel gives every wave a run of 16-frame tiles and walks through them three at a time while the weights of
+    the four 128-channel passes alternate between two LDS buffers, fetched a step ahead and awaited with a COUNTED vmcnt when the
+    wave issued a full step's stores behind the fetch (24 or 16).  XV_TUNE_FIRST_TILES forces the run length: 1 and 2 (one group, the
+    drain path), 3 (vmcnt(24) between the passes), 5 (groups of 3 + 2: both counted waits), 7 / 8 (three groups, Cout = 288: a
+    ragged last pass), 0 = the launcher's own choice -- all against the general bf16x3 kernel on 6 k rows that end in the middle of
+    a tile, gap rows included, bit for bit between the run lengths."""
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    K, feat, in_dim, dil = 5, 23, 24, 1
+    rng = np.random.default_rng(cout)
+    lens = [int(v) for v in rng.integers(1, 700, 18)]
+    mats = [(rng.standard_normal((t, feat)) * 3).astype(np.float32) for t in lens]
+    w = np.zeros((K, in_dim, cout), np.float32)
+    w[:, :feat] = rng.standard_normal((K, feat, cout)) / np.sqrt(K * feat)
+    layout = engine.BatchLayout(lens, 2, 8)
+    host = np.zeros((layout.rows, in_dim), np.float32)
+    layout.pack(mats, host)
+    R = layout.rows - 5                                            # not a multiple of 16
+    t = lambda a: torch.from_numpy(a).to(dev)
+    x, rv = t(host), t(layout.row_valid())
+    b = t((0.1 * rng.standard_normal(cout)).astype(np.float32))
+    scale, shift = hiplib.fold_bn(*(t(a) for a in _rand_bn(rng, cout)), 1e-3)
+    first = hiplib.pack_first_bf16x3(t(w))
+    f = hiplib.FMT_SPLIT8 if fmt == "split8" else hiplib.FMT_SPLIT
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(n):
+        y = hiplib.SplitBuf(layout.rows, cout, dev, f)
+        y.base.fill_(0x7f)
+        hiplib.set_tuning(hiplib.TUNE_FIRST_TILES, n)
+        try:
+            hiplib.tdnn_first(x, R, first, b, scale, shift, 1, None, dil, rv, y, status if f == hiplib.FMT_SPLIT8 else None)
+            torch.cuda.synchronize()
+        finally:
+            hiplib.set_tuning(hiplib.TUNE_FIRST_TILES, 0)
+        return y.base.cpu().numpy().copy(), hiplib.split_decode(y, layout.rows).cpu().numpy()
+    raw, got = run(tiles)
+    raw1, _ = run(4)
+    assert np.array_equal(raw, raw1)                               # the run length changes nothing, poison behind row R included
+    y2 = hiplib.SplitBuf(layout.rows, cout, dev)
+    hiplib.tdnn_layer(x, hiplib.pack_weights_bf16x3(t(w)), b, scale, shift, 1, None, K, dil, rv, y2, None, rows=R)
+    two = hiplib.split_decode(y2, layout.rows).cpu().numpy()
+    assert np.isfinite(got[:R]).all()
+    assert oracle.rel_l2(got[:R], two[:R]) < (2e-5 if fmt == "split8" else 5e-6)
+    assert (got[:R][~layout.row_valid().astype(bool)[:R]] == 0).all()
+    assert int(status.item()) == 0
+
+
+def test_tdnn_first_layer_beyond_one_buffer_descriptor(env):
+    """The first-layer kernel addresses y through a buffer descriptor (rows past the end are dropped by its range check), which
+    covers 2^19 rows per launch: 2^19 + 1000 rows go out as two launches; against the general kernel, and the last rows exactly."""
+    torch, hiplib, oracle, dev = env["torch"], env["hiplib"], env["oracle"], env["dev"]
+    K, in_dim, cout = 5, 24, 64
+    R = (1 << 19) + 1000
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((R, in_dim), generator=g).mul_(3.0)
+    x[:, 23] = 0
+    x = x.to(dev)
+    w = (torch.randn((K, in_dim, cout), generator=g) / (K * 23) ** 0.5).to(dev)
+    b = (0.1 * torch.randn(cout, generator=g)).to(dev)
+    rv = torch.ones(R, dtype=torch.uint8, device=dev)
+    rv[(1 << 19) - 3:(1 << 19) + 2] = 0                            # gap rows across the seam
+    first = hiplib.pack_first_bf16x3(w)
+    y = hiplib.SplitBuf(R, cout, dev)
+    y.base.fill_(0x7f)
+    hiplib.tdnn_first(x, R, first, b, None, None, 1, None, 1, rv, y)
+    got = hiplib.split_decode(y, R)
+    y2 = hiplib.SplitBuf(R, cout, dev)
+    hiplib.tdnn_layer(x, hiplib.pack_weights_bf16x3(w), b, None, None, 1, None, K, 1, rv, y2, None, rows=R)
+    two = hiplib.split_decode(y2, R)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all())
+    num = float(((got.double() - two.double()) ** 2).sum().sqrt()), float((two.double() ** 2).sum().sqrt())
+    assert num[0] / num[1] < 5e-6
+    seam = slice((1 << 19) - 40, (1 << 19) + 40)
+    assert oracle.rel_l2(got[seam].cpu().numpy(), two[seam].cpu().numpy()) < 5e-6
+    assert oracle.rel_l2(got[-50:].cpu().numpy(), two[-50:].cpu().numpy()) < 5e-6
+    assert bool((got[(1 << 19) - 3:(1 << 19) + 2] == 0).all())
+
+
+def test_tdnn_first_layer_clamps_and_flags_out_of_range_values(env):
+    """split8 output of the first layer: a value beyond +-57344 is clamped and raises the status word (the kernel starts on a form
+    without the clamp and repeats the tile pair with it once its running maximum leaves the range); everything else is untouched."""
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    K, in_dim, cout = 5, 24, 64
+    R = 700
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = torch.randn((R, in_dim), generator=g)
+    x[:, 23] = 0
+    x = x.to(dev)
+    w = (torch.randn((K, in_dim, cout), generator=g) / (K * 23) ** 0.5).to(dev)
+    b = torch.zeros(cout, device=dev)
+    scale = torch.ones(cout, device=dev)
+    shift = torch.zeros(cout, device=dev)
+    rv = torch.ones(R, dtype=torch.uint8, device=dev)
+    first = hiplib.pack_first_bf16x3(w)
+
+    def run(sc):
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        y = hiplib.SplitBuf(R, cout, dev, hiplib.FMT_SPLIT8)
+        hiplib.tdnn_first(x, R, first, b, sc, shift, 1, None, 1, rv, y, status)
+        return hiplib.split_decode(y, R).cpu().numpy(), int(status.item())
+    base, st0 = run(scale)
+    assert st0 == 0 and np.abs(base).max() < 100
+    big = scale.clone()
+    big[37] = 1e6                                                  # relu output of channel 37 x 1e6: far beyond the range
+    got, st1 = run(big)
+    assert st1 == 1
+    hot = base[:, 37] * 1e6 > 57344
+    assert hot.any() and (got[hot, 37] == 57344.0).all()
+    keep = np.ones(cout, bool); keep[37] = False
+    assert np.array_equal(got[:, keep], base[:, keep])
+    small = base[:, 37] * 1e6 < 50000
+    assert np.allclose(got[small, 37], base[small, 37] * 1e6, rtol=2e-3)
+
+
 @pytest.mark.parametrize("cin,cout,act,lens", [
     (512, 1536, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),      # layers 3 + 4 of the default topology
     (64, 64, "prelu", [300, 25, 64, 3]),                         # two k-steps, one column group

@@ -5,15 +5,22 @@
 // each of the four column tiles with the fp32 -> hi/lo conversion of the same input rows done four times.  What bounds the
 // layer is its OUTPUT: 2 KB per frame in the split activation format, 0.54 GB per 262144-row batch.  This kernel is laid out
 // around that:
-//   * a wave owns 16 frames; its im2col operand (16 frames x 128 k, k = tap*24 + channel) is built ONCE in registers straight
-//     from the fp32 feature rows (8 x 32-byte loads per lane, L2 hits; rows outside [0, R) read as zero) and split to hi/lo;
-//   * the weights of 128 output channels (8 tiles x 4 k-steps x hi/lo fragments = 64 KB, packed in MFMA-fragment order) are
-//     brought into LDS by DMA once per pass and re-used for a strip of 4 x 128 frames; four passes cover 512 channels, and two
-//     workgroups share a CU, so one computes while the other waits for its weights;
+//   * one workgroup per CU, eight waves; every wave owns a contiguous run of 16-frame tiles and works on three at a time: their
+//     im2col operands (16 frames x 128 k, k = tap*24 + channel) are built ONCE in registers straight from the fp32 feature rows
+//     (8 x 32-byte loads per lane; rows outside [0, R) read as zero), split to hi/lo, and stay there for all 512 channels;
+//   * the weights of 128 output channels (8 tiles x 4 k-steps x hi/lo fragments = 64 KB, packed in MFMA-fragment order) alternate
+//     between two LDS buffers, fetched by DMA one step (= one 128-channel pass of one group of tiles) ahead; the wait for them is a
+//     COUNTED vmcnt -- a wave's stores of the step in between need not have retired;
+//   * the weight fragments and epilogue parameters of a tile pair (32 channels) are read from LDS once for the wave's three
+//     tiles (a third of the fragment reads of the earlier one-tile-at-a-time form);
 //   * the product is formed transposed (A = weight fragment, B = frames) on v_mfma_f32_16x16x32_bf16, so that a lane holds 4
 //     rows of one frame per tile; the packed weights order the rows of a tile PAIR so that a lane's 4 + 4 rows are 8 consecutive
 //     channels -- exactly one 16-byte hi slot and one 16-byte lo slot of the split format, no cross-lane exchange -- and the
-//     epilogue (bias, activation, BN, gap-row mask, hi/lo split) stores them with non-temporal 16-byte stores, no LDS round trip.
+//     epilogue (bias as the accumulators' start value, activation, BN, gap-row mask, hi/lo split) stores them with non-temporal
+//     16-byte buffer stores (rows past the end: dropped by the descriptor's range check), no LDS round trip;
+//   * every output row is 2 KB, so workgroups that all write the same 128-byte slab of their rows at the same moment send the
+//     whole chip's stores to the same few memory channels: the workgroups start at different passes and the waves of a workgroup
+//     at different tile pairs (measured: 0.184 -> 0.156 ms).
 // Arithmetic: bf16x3 as everywhere (hi*hi + hi*lo + lo*hi, fp32 accumulate).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,9 +35,12 @@
 extern "C" void xv_internal_set_error(const char *msg);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
+
+std::atomic<int> g_first_tiles{0};        // xv_internal_first_tiles(): tiles per wave, 0 = spread over the CUs
 
 int fail(int code, const char *msg)
 {
@@ -38,16 +48,16 @@ int fail(int code, const char *msg)
     return code;
 }
 
-constexpr int FR_WAVES = 8;
-constexpr int FR_ROWS = 16 * FR_WAVES;      // frames per row tile
-constexpr int FR_STRIP = 4;                 // row tiles per workgroup (weights are loaded once per pass and strip)
+constexpr int FR_WAVES = 8;                // one workgroup per CU, two waves per SIMD: 256 VGPRs each
+constexpr int FR_TILES = 3;                // 16-frame tiles a wave works on at a time: a tile pair's weights and parameters are read once for the three
 constexpr int FR_NKS = 4;                   // k-steps of 32: K * ceil8(Cin) <= 128
-constexpr int FR_PASS_COLS = 128;           // output channels whose weights are resident at a time (64 KB: two workgroups per CU)
+constexpr int FR_PASS_COLS = 128;           // output channels of one pass: their weights are 64 KB, two such buffers alternate
 constexpr int FR_W_BYTES = (FR_PASS_COLS / 16) * FR_NKS * 2048;      // 64 KB
-constexpr int FR_P_OFF = FR_W_BYTES;        // [bias | scale | shift | alpha][cout <= 512]
+constexpr int FR_P_OFF = 2 * FR_W_BYTES;    // [bias | scale | shift | alpha][cout <= 512]
 constexpr int FR_MAX_COUT = 512;
 constexpr size_t FR_LDS_BYTES = FR_P_OFF + 4 * FR_MAX_COUT * 4;
 constexpr int SROW = 128;
+static_assert(FR_TILES == 3, "tdnn_first_kernel dispatches first_block<.., 1 | 2 | 3>");
 
 struct FirstParams {
     const float *x;
@@ -60,6 +70,9 @@ struct FirstParams {
     const uint8_t *valid;
     uint8_t *y;                // split-format output, row 0
     int ychunks;
+    long row_base, rows_here;  // this launch writes rows [row_base, row_base + rows_here) (a buffer descriptor addresses < 4 GB of y)
+    long n_tiles;              // 16-frame tiles of this launch: ceil(rows_here / 16)
+    int tpw;                   // tiles per wave: wave w of workgroup b owns tiles [(8b + w) tpw, +tpw)
     int *status;               // Y8: bit 0 set when a value had to be clamped (may be NULL)
 };
 
@@ -70,22 +83,161 @@ struct FirstParams {
 template <int MODE>
 __device__ __forceinline__ float act_fn(float z, float a)
 {
+    // relu as ONE instruction: fmaxf() first canonicalises an MFMA result (v_max z, z); the signed-integer maximum of the bit pattern
+    // with 0 is the same function (negative floats are negative integers; -0 and negative NaNs become +0).  (Not inline assembly:
+    // the compiler's hazard recogniser does not see an asm statement that reads an MFMA result.)
+    if constexpr (MODE == 2) return __builtin_bit_cast(float, max(__builtin_bit_cast(int, z), 0));
     return MODE == 1 ? fmaxf(a * z, z) : MODE == 2 ? fmaxf(z, 0.f) : fmaxf(z, 0.f) + a * fminf(z, 0.f);
+}
+
+// c - (float)h for the fp16 in the low / high half of a register: ONE v_fma_mix_f32 (the compiler's own form is a conversion plus a
+// subtraction); exact, like the subtraction
+template <int HALF>
+__device__ __forceinline__ float sub_f16_half(float c, int hpair)
+{
+    float r;
+    if constexpr (HALF == 0)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(c));
+    else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(c));
+    return r;
+}
+
+constexpr int FR_STORE_AUX = 2;                        // nt
+
+constexpr int FR_RSRC_FLAGS = 0x00020000;            // raw buffer, 32-bit data format (gfx9 family dword 3)
+
+// One tile pair (32 output channels) of NT 16-frame tiles: 24 MFMAs per tile, then activation / BN / gap-row mask / split encoding
+// and two 16-byte stores per lane, without a branch (rows past the end are dropped by the buffer descriptor's range check).
+// MASK: the group has a gap row (zeroed after the arithmetic); CLAMP: clamp to the fp16 / bf8 range first -- the caller starts
+// without and repeats the pair with it once the running maximum says so.
+template <int MODE, bool Y8, int NT, bool MASK, bool CLAMP>
+__device__ __forceinline__ void first_block(const bf16x8 (&xh)[FR_TILES][FR_NKS], const bf16x8 (&xl)[FR_TILES][FR_NKS],
+                                            const bf16x8 (&wh0)[FR_NKS], const bf16x8 (&wl0)[FR_NKS], const bf16x8 (&wh1)[FR_NKS],
+                                            const bf16x8 (&wl1)[FR_NKS], const f32x4 b0, const f32x4 b1, const f32x4 s0, const f32x4 s1,
+                                            const f32x4 o0, const f32x4 o1, const f32x4 a0, const f32x4 a1, const int (&keepm)[FR_TILES],
+                                            const unsigned (&hioff)[FR_TILES], const int slab_off, const __amdgpu_buffer_rsrc_t yrs,
+                                            float &amax)
+{
+    f32x4 m0[NT], m1[NT];
+    auto mfma_tile = [&](int j) {
+        m0[j] = b0; m1[j] = b1;                                   // the bias is where the sums start
+#pragma unroll
+        for (int u = 0; u < FR_NKS; ++u) {
+            m0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl0[u], xh[j][u], m0[j], 0, 0, 0);
+            m1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl1[u], xh[j][u], m1[j], 0, 0, 0);
+            m0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0[u], xl[j][u], m0[j], 0, 0, 0);
+            m1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1[u], xl[j][u], m1[j], 0, 0, 0);
+            m0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0[u], xh[j][u], m0[j], 0, 0, 0);
+            m1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1[u], xh[j][u], m1[j], 0, 0, 0);
+        }
+    };
+    auto epilogue = [&](int j) {
+        // lane (frame f, group G) holds rows 4G..4G+3 of both tiles; the packed weights order the rows of a tile pair so that these
+        // are channels 8G..8G+3 (tile 0) and 8G+4..8G+7 (tile 1) of the pair's 32: one 16-byte slot of the output format per lane
+        const f32x4 z0 = m0[j], z1 = m1[j];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {                          // activation, then BN as packed FMAs
+            const f32x2 r0 = {act_fn<MODE>(z0[e], a0[e]), act_fn<MODE>(z0[e + 1], a0[e + 1])};
+            const f32x2 r1 = {act_fn<MODE>(z1[e], a1[e]), act_fn<MODE>(z1[e + 1], a1[e + 1])};
+            const f32x2 y0 = __builtin_elementwise_fma(r0, (f32x2){s0[e], s0[e + 1]}, (f32x2){o0[e], o0[e + 1]});
+            const f32x2 y1 = __builtin_elementwise_fma(r1, (f32x2){s1[e], s1[e + 1]}, (f32x2){o1[e], o1[e + 1]});
+            v[e] = y0[0]; v[e + 1] = y0[1]; v[4 + e] = y1[0]; v[5 + e] = y1[1];
+        }
+        if constexpr (Y8) {
+            // xv_split8_encode8's results; the running maximum and the clamp come before the gap-row mask (the values are known
+            // to be canonical there: one v_max3 per pair, no v_max x, x in front of it)
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            xv_i32x4 vh, vx;
+            float lo[8];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                amax = fmaxf(amax, fmaxf(fabsf(v[i]), fabsf(v[i + 1])));
+                float ca = v[i], cb = v[i + 1];
+                if constexpr (CLAMP) {
+                    ca = __builtin_amdgcn_fmed3f(ca, -XV_SPLIT8_MAX, XV_SPLIT8_MAX);
+                    cb = __builtin_amdgcn_fmed3f(cb, -XV_SPLIT8_MAX, XV_SPLIT8_MAX);
+                }
+                if constexpr (MASK) {
+                    ca = __builtin_bit_cast(float, __builtin_bit_cast(int, ca) & keepm[j]);
+                    cb = __builtin_bit_cast(float, __builtin_bit_cast(int, cb) & keepm[j]);
+                }
+                const f16x2 h = {(_Float16)ca, (_Float16)cb};
+                vh[i >> 1] = __builtin_bit_cast(int, h);
+                lo[i] = sub_f16_half<0>(ca, vh[i >> 1]);
+                lo[i + 1] = sub_f16_half<1>(cb, vh[i >> 1]);
+                v[i] = ca; v[i + 1] = cb;
+            }
+            constexpr float inv = 1.f / XV_SPLIT8_LO_SCALE;
+            s16x2 t0 = {0, 0}, t1 = {0, 0};
+            t0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t0, lo[0], lo[1], inv, false);
+            t0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t0, lo[2], lo[3], inv, true);
+            t1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t1, lo[4], lo[5], inv, false);
+            t1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(t1, lo[6], lo[7], inv, true);
+            int h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+            h0 = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], h0, true);
+            int h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], 0, false);
+            h1 = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], h1, true);
+            vx = (xv_i32x4){__builtin_bit_cast(int, t0), __builtin_bit_cast(int, t1), h0, h1};
+            __builtin_amdgcn_raw_buffer_store_b128(vh, yrs, hioff[j], slab_off, FR_STORE_AUX);             // slot g ...
+            __builtin_amdgcn_raw_buffer_store_b128(vx, yrs, hioff[j] ^ 64u, slab_off, FR_STORE_AUX);       // ... and slot 4 + g, same swizzle
+        } else {
+            bf16x8 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float m = MASK ? __builtin_bit_cast(float, __builtin_bit_cast(int, v[e]) & keepm[j]) : v[e];
+                const __bf16 h = (__bf16)m;
+                vh[e] = h;
+                vl[e] = (__bf16)(m - (float)h);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xv_i32x4, vh), yrs, hioff[j], slab_off, FR_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xv_i32x4, vl), yrs, hioff[j] ^ 64u, slab_off, FR_STORE_AUX);
+        }
+    };
+    mfma_tile(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 1; j < NT; ++j) {
+        mfma_tile(j);
+        epilogue(j - 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    epilogue(NT - 1);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Y8: write XV_FMT_SPLIT8 rows (fp16 hi + bf8 cross bytes, xv_split8.h) instead of the bf16 hi/lo planes
 template <int MODE, bool Y8>
-__global__ __launch_bounds__(FR_WAVES * 64, 4) void tdnn_first_kernel(const FirstParams p)
+__global__ __launch_bounds__(FR_WAVES * 64) void tdnn_first_kernel(const FirstParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = lane >> 4, f = lane & 15;
-    const long strip0 = (long)blockIdx.x * (FR_STRIP * FR_ROWS);
+    const long tile0 = ((long)blockIdx.x * FR_WAVES + wave) * p.tpw;
     const int left = ((p.K - 1) * p.dil) >> 1;
+    const int n_pass = (p.cout + FR_PASS_COLS - 1) / FR_PASS_COLS;
+    const int n_groups = (p.tpw + FR_TILES - 1) / FR_TILES;
+    const int steps = n_groups * n_pass;                         // a step = one pass of one group of tiles; the same for every wave
+    const unsigned yrow = (unsigned)p.ychunks * SROW;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)p.row_base * yrow, 0, (int)(unsigned)(p.rows_here * yrow), FR_RSRC_FLAGS);
 
-    // epilogue parameters -> LDS (before any DMA is in flight)
+    // weights of pass `ps` -> buffer `buf`: n_pairs * 2 tiles * 4 k-steps * 2 KB of lane-linear fragments, 1 KB DMA pieces
+    auto fetch_weights = [&](int ps, int buf) {
+        const int pieces = (min(FR_PASS_COLS, p.cout - ps * FR_PASS_COLS) >> 5) * 2 * FR_NKS * 2;
+        const uint8_t *src = p.wt + (size_t)ps * FR_W_BYTES + lane * 16;
+        char *dst = lds + buf * FR_W_BYTES;
+        for (int pc = wave; pc < pieces; pc += FR_WAVES) XV_GLDS16_OFF(src + (size_t)pc * 1024, dst + pc * 1024, 0);
+    };
+    // Every output row is 2 KB: workgroups that all write the same 128-byte slab of their rows at the same time send the whole
+    // chip's stores to the same few memory channels.  The workgroups therefore start at different passes (and the waves of a
+    // workgroup at different tile pairs of a pass, below).
+    const int rot = (int)(blockIdx.x % (unsigned)n_pass);
+    fetch_weights(rot, 0);
+    // epilogue parameters -> LDS (the first step's barrier publishes them)
     {
         float *P = reinterpret_cast<float *>(lds + FR_P_OFF);
         for (int c = tid; c < p.cout; c += FR_WAVES * 64) {
@@ -96,118 +248,118 @@ __global__ __launch_bounds__(FR_WAVES * 64, 4) void tdnn_first_kernel(const Firs
         }
     }
     const f32x4 *P4 = reinterpret_cast<const f32x4 *>(lds + FR_P_OFF);
-    // this lane's im2col slots: k-step u, group G -> k = 32u + 8G .. +7 = (tap, channels c0 .. c0+7)
-    int tap_off[FR_NKS], c0[FR_NKS];
-    bool live[FR_NKS];
-#pragma unroll
-    for (int u = 0; u < FR_NKS; ++u) {
-        const int k = 32 * u + 8 * G;
-        const int tap = k / p.kc;
-        live[u] = tap < p.K;
-        tap_off[u] = (tap - 0) * p.dil - left;
-        c0[u] = k - tap * p.kc;
-    }
-    const size_t yrow = (size_t)p.ychunks * SROW;
+
+    bf16x8 xh[FR_TILES][FR_NKS], xl[FR_TILES][FR_NKS];   // B operands of the current group: im2col fragments, fp32 -> hi/lo
+    int keepm[FR_TILES];                      // all ones: the row is a frame; zero: gap row, written as zeros
+    unsigned hioff[FR_TILES];                 // byte offset of the lane's hi slot in slab 0 of its row, in this launch's part of y
+                                              // (rows past the end: an offset the buffer descriptor's range check drops)
+    bool group_masked = false, clamping = false;   // (wave-uniform) a gap row in the group; a value beyond the fp16 / bf8 range was seen
+    int n_live = 0;                           // (wave-uniform) tiles of the current group that exist: the first n_live
     float amax = 0.f;
-    const int n_pass = (p.cout + FR_PASS_COLS - 1) / FR_PASS_COLS;
+    int pass = rot, group = 0, in_group = 0;   // in_group: passes of the current group done so far
+    int stores_behind_fetch = -1;             // global stores this wave has issued since its last weight fetch (-1: unknown)
 
-    for (int pass = 0; pass < n_pass; ++pass) {
-        const int pass_cols = min(FR_PASS_COLS, p.cout - pass * FR_PASS_COLS);
-        const int n_pairs = pass_cols >> 5;                       // tile pairs (32 channels) of this pass
-        // ---- weights of this pass: n_pairs * 2 tiles * 4 k-steps * 2 KB, lane-linear fragments, 1 KB DMA pieces ----------
-        __syncthreads();                                          // everybody is done with the previous pass's weights
-        {
-            const int pieces = n_pairs * 2 * FR_NKS * 2;
-            const uint8_t *src = p.wt + (size_t)pass * FR_W_BYTES + lane * 16;
-            for (int pc = wave; pc < pieces; pc += FR_WAVES) XV_GLDS16_OFF(src + (size_t)pc * 1024, lds + pc * 1024, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-
-        for (int rt = 0; rt < FR_STRIP; ++rt) {
-            const long row0 = strip0 + (long)rt * FR_ROWS + 16 * wave;       // this wave's 16 frames
-            if (row0 >= p.R) break;                                            // (wave-uniform)
-            const long row = row0 + f;
-            // ---- B operand: the wave's frames as im2col fragments, fp32 -> hi/lo ------------------------------------
-            bf16x8 xh[FR_NKS], xl[FR_NKS];
+    for (int s = 0; s < steps; ++s) {
+        if (in_group == 0) {
+            // ---- a new group of tiles: B operands ONCE for all 512 channels.  lane (f, G), k-step u: k = 32u + 8G .. +7 = (tap, channels c0 .. c0+7)
+            const long gtile = tile0 + (long)group * FR_TILES;
+            const long lrow0 = gtile * 16;                         // first row of the group, relative to row_base
+            n_live = 0;
+#pragma unroll
+            for (int j = 0; j < FR_TILES; ++j) {
+                const bool ex = group * FR_TILES + j < p.tpw && gtile + j < p.n_tiles;
+                n_live += ex ? 1 : 0;
+                const long lrow = lrow0 + 16 * j + f, row = p.row_base + lrow;
+                const bool in = ex && lrow < p.rows_here;
+                keepm[j] = (in && (!p.valid || p.valid[row])) ? -1 : 0;
+                hioff[j] = in ? (unsigned)lrow * yrow + (unsigned)((G ^ ((int)(row >> 1) & 7)) << 4) : 0x80000000u;
+            }
 #pragma unroll
             for (int u = 0; u < FR_NKS; ++u) {
-                const long r = row + tap_off[u];
-                f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-                if (live[u] && r >= 0 && r < p.R) {
-                    const float *src = p.x + (size_t)r * p.ldx + c0[u];
-                    a = *reinterpret_cast<const f32x4 *>(src);
-                    b = *reinterpret_cast<const f32x4 *>(src + 4);
-                }
+                const int k = 32 * u + 8 * G;
+                const int tap = k / p.kc;
+                const bool live = tap < p.K;
+                const int tap_off = tap * p.dil - left;
+                const int c0 = k - tap * p.kc;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const __bf16 ha = (__bf16)a[e], hb = (__bf16)b[e];
-                    xh[u][e] = ha; xh[u][4 + e] = hb;
-                    xl[u][e] = (__bf16)(a[e] - (float)ha); xl[u][4 + e] = (__bf16)(b[e] - (float)hb);
+                for (int j = 0; j < FR_TILES; ++j) {
+                    const long r = p.row_base + lrow0 + 16 * j + f + tap_off;
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+                    if (live && j < n_live && r >= 0 && r < p.R) {
+                        const float *src = p.x + (size_t)r * p.ldx + c0;
+                        a = *reinterpret_cast<const f32x4 *>(src);
+                        b = *reinterpret_cast<const f32x4 *>(src + 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const __bf16 ha = (__bf16)a[e], hb = (__bf16)b[e];
+                        xh[j][u][e] = ha; xh[j][u][4 + e] = hb;
+                        xl[j][u][e] = (__bf16)(a[e] - (float)ha); xl[j][u][4 + e] = (__bf16)(b[e] - (float)hb);
+                    }
                 }
             }
-            const float keep = (row < p.R && (!p.valid || p.valid[row])) ? 1.f : 0.f;
-            const int sw = (int)(row >> 1) & 7;
-            uint8_t *yr = p.y + (size_t)row * yrow;
+            group_masked = __builtin_amdgcn_ballot_w64(keepm[0] == 0 || keepm[1] == 0 || keepm[2] == 0) != 0;
+            stores_behind_fetch = -1;
+        }
+        // ---- this step's weights have landed (fetched a step ahead), everybody is done with the other buffer --------------------
+        // A wave's vector-memory operations retire in order, stores included: waiting for the fetch means waiting for everything
+        // issued before it, NOT for the stores of the previous step that were issued behind it -- when their number is known.
+        if (stores_behind_fetch == 2 * 4 * FR_TILES) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (stores_behind_fetch == 2 * 4 * (FR_TILES - 1)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int n_pairs = min(FR_PASS_COLS, p.cout - pass * FR_PASS_COLS) >> 5;      // tile pairs (32 channels) of this pass
+        if (s + 1 < steps) fetch_weights(pass + 1 == n_pass ? 0 : pass + 1, (s + 1) & 1);
+        stores_behind_fetch = 0;
+        const char *wbuf = lds + (s & 1) * FR_W_BYTES + lane * 16;
 
-            for (int tp = 0; tp < n_pairs; ++tp) {
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-                const char *w0 = lds + (size_t)(tp * 2) * (FR_NKS * 2048) + lane * 16;
-                const char *w1 = w0 + FR_NKS * 2048;
+        if (n_live > 0) {
+            for (int t = 0; t < n_pairs; ++t) {
+                const int tp = (t + wave) % n_pairs;
+                // weights and parameters of this tile pair: registers, for the wave's three tiles
+                bf16x8 wh0[FR_NKS], wl0[FR_NKS], wh1[FR_NKS], wl1[FR_NKS];
+                const char *w0 = wbuf + (size_t)(tp * 2) * (FR_NKS * 2048);
 #pragma unroll
                 for (int u = 0; u < FR_NKS; ++u) {
-                    const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(w0 + u * 2048);
-                    const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(w0 + u * 2048 + 1024);
-                    const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(w1 + u * 2048);
-                    const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(w1 + u * 2048 + 1024);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0, xh[u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1, xh[u], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xl[u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xl[u], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, xh[u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, xh[u], acc1, 0, 0, 0);
+                    wh0[u] = *reinterpret_cast<const bf16x8 *>(w0 + u * 2048);
+                    wl0[u] = *reinterpret_cast<const bf16x8 *>(w0 + u * 2048 + 1024);
+                    wh1[u] = *reinterpret_cast<const bf16x8 *>(w0 + FR_NKS * 2048 + u * 2048);
+                    wl1[u] = *reinterpret_cast<const bf16x8 *>(w0 + FR_NKS * 2048 + u * 2048 + 1024);
                 }
-                // lane (frame f, group G) holds rows 4G..4G+3 of both tiles; the packed weights order the rows of a tile pair so
-                // that these are channels 8G..8G+3 (tile 0) and 8G+4..8G+7 (tile 1) of the pair's 32: one 16-byte slot of the
-                // output format per lane, with no exchange between lanes
-                const f32x4 lo4 = acc0;                           // channels cb .. cb+3
-                const f32x4 hi4 = acc1;                           // channels cb+4 .. cb+7
                 const int cb = pass * FR_PASS_COLS + tp * 32 + 8 * G;
                 const int c4 = cb >> 2;
                 const f32x4 b0 = P4[c4], b1 = P4[c4 + 1], s0 = P4[FR_MAX_COUT / 4 + c4], s1 = P4[FR_MAX_COUT / 4 + c4 + 1],
-                            o0 = P4[2 * FR_MAX_COUT / 4 + c4], o1 = P4[2 * FR_MAX_COUT / 4 + c4 + 1],
-                            a0 = P4[3 * FR_MAX_COUT / 4 + c4], a1 = P4[3 * FR_MAX_COUT / 4 + c4 + 1];
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = keep != 0.f ? act_fn<MODE>(lo4[e] + b0[e], a0[e]) * s0[e] + o0[e] : 0.f;
-                    v[4 + e] = keep != 0.f ? act_fn<MODE>(hi4[e] + b1[e], a1[e]) * s1[e] + o1[e] : 0.f;
-                }
-                const int slab = cb >> 5, t = (cb & 31) >> 3;
-                uint8_t *slabp = yr + (size_t)slab * SROW;
-                if constexpr (Y8) {
-                    xv_f16x8 vh;
-                    xv_i32x4 vx;
-                    xv_split8_encode8<true>(v, vh, vx, amax);
-                    if (row < p.R) {
-                        __builtin_nontemporal_store(vh, reinterpret_cast<xv_f16x8 *>(slabp + ((t ^ sw) << 4)));
-                        __builtin_nontemporal_store(vx, reinterpret_cast<xv_i32x4 *>(slabp + (((4 + t) ^ sw) << 4)));
-                    }
-                } else {
-                    bf16x8 vh, vl;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const __bf16 h = (__bf16)v[e];
-                        vh[e] = h;
-                        vl[e] = (__bf16)(v[e] - (float)h);
-                    }
-                    if (row < p.R) {
-                        __builtin_nontemporal_store(vh, reinterpret_cast<bf16x8 *>(slabp + ((t ^ sw) << 4)));
-                        __builtin_nontemporal_store(vl, reinterpret_cast<bf16x8 *>(slabp + (((4 + t) ^ sw) << 4)));
+                            o0 = P4[2 * FR_MAX_COUT / 4 + c4], o1 = P4[2 * FR_MAX_COUT / 4 + c4 + 1];
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+                if constexpr (MODE != 2) { a0 = P4[3 * FR_MAX_COUT / 4 + c4]; a1 = P4[3 * FR_MAX_COUT / 4 + c4 + 1]; }
+                const int slab_off = (pass * (FR_PASS_COLS / 32) + tp) * SROW;       // (wave-uniform: the store's scalar offset)
+                // fast form first: no gap-row mask when the group has no gap row, no clamp; a value beyond the range (absurd for a
+                // BN-normalised network; the caller repeats the batch in bf16x3 anyway) sends the wave through the clamping form
+                // from then on -- the pair is done again, its stores simply land twice
+                auto run = [&](auto nt, auto mask, auto clamp) {
+                    first_block<MODE, Y8, decltype(nt)::value, decltype(mask)::value, decltype(clamp)::value>(
+                        xh, xl, wh0, wl0, wh1, wl1, b0, b1, s0, s1, o0, o1, a0, a1, keepm, hioff, slab_off, yrs, amax);
+                };
+                auto run_nt = [&](auto mask, auto clamp) {
+                    if (n_live == 3) run(std::integral_constant<int, 3>{}, mask, clamp);
+                    else if (n_live == 2) run(std::integral_constant<int, 2>{}, mask, clamp);
+                    else run(std::integral_constant<int, 1>{}, mask, clamp);
+                };
+                if (Y8 && clamping) run_nt(std::true_type{}, std::true_type{});
+                else {
+                    if (group_masked) run_nt(std::true_type{}, std::false_type{});
+                    else run_nt(std::false_type{}, std::false_type{});
+                    if (Y8 && __builtin_amdgcn_ballot_w64(!(amax <= XV_SPLIT8_MAX)) != 0) {
+                        clamping = true;
+                        run_nt(std::true_type{}, std::true_type{});
+                        stores_behind_fetch = -1000;              // (the count is off now: the next wait drains)
                     }
                 }
+                stores_behind_fetch += 2 * n_live;
             }
         }
+        if (++pass == n_pass) pass = 0;
+        if (++in_group == n_pass) { in_group = 0; ++group; }
     }
     if constexpr (Y8)
         if (amax > XV_SPLIT8_MAX && p.status) atomicOr(p.status, 1);
@@ -248,6 +400,8 @@ bool first_shape_ok(int K, int cin, int cout)
 }  // namespace
 
 extern "C" {
+
+void xv_internal_first_tiles(int tiles) { g_first_tiles.store(tiles, std::memory_order_relaxed); }
 
 size_t xv_packed_first_bf16x3_bytes(int K, int cin, int cout)
 {
@@ -300,9 +454,26 @@ static int first_launch(const float *x, int64_t R, int cin, int ldx, const void 
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const int mode = act_kind == XV_ACT_LRELU ? 1 : act_kind == XV_ACT_RELU ? 2 : 0;
-    const long strip = (long)FR_STRIP * FR_ROWS;
-    hipLaunchKernelGGL(kerns[mode + (y8 ? 3 : 0)], dim3((unsigned)((R + strip - 1) / strip)), dim3(FR_WAVES * 64), FR_LDS_BYTES,
-                       (hipStream_t)stream, p);
+    // one workgroup per CU, each wave a contiguous run of 16-frame tiles (at least one): the weights cycle through LDS once per
+    // FR_TILES tiles of every wave, and nobody ends a round early
+    static std::atomic<int> n_cu{0};
+    int cus = n_cu.load(std::memory_order_relaxed);
+    if (cus <= 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        n_cu.store(cus, std::memory_order_relaxed);
+    }
+    const int forced = g_first_tiles.load(std::memory_order_relaxed);
+    const long waves = (long)cus * FR_WAVES;
+    constexpr long MAX_ROWS = 1L << 19;                            // x 2 KB per row = 1 GB: one buffer descriptor of y, offsets < 2^31
+    for (long r0 = 0; r0 < p.R; r0 += MAX_ROWS) {
+        p.row_base = r0;
+        p.rows_here = p.R - r0 < MAX_ROWS ? p.R - r0 : MAX_ROWS;
+        p.n_tiles = (p.rows_here + 15) / 16;
+        p.tpw = forced > 0 ? forced : (int)((p.n_tiles + waves - 1) / waves);
+        const long per_wg = (long)p.tpw * FR_WAVES;
+        hipLaunchKernelGGL(kerns[mode + (y8 ? 3 : 0)], dim3((unsigned)((p.n_tiles + per_wg - 1) / per_wg)), dim3(FR_WAVES * 64), FR_LDS_BYTES,
+                           (hipStream_t)stream, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail((int)e, hipGetErrorString(e));
     return 0;

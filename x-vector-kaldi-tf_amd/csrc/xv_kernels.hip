@@ -1390,6 +1390,7 @@ int check_launch(const char *what)
 extern "C" {
 
 void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
+void xv_internal_first_tiles(int tiles);          // xv_first.hip
 
 int xv_version(void) { return 13; }
 
@@ -1401,6 +1402,10 @@ int xv_set_tuning(int key, int value)
             return fail(XV_ERR_BAD_ARG, "xv_set_tuning: tile rows must be 0, 128, 256 or 512");
         g_tile_rows.store(value == 512 ? 256 : value, std::memory_order_relaxed);
         xv_internal_gemm8_tile_rows(value);
+        return 0;
+    case XV_TUNE_FIRST_TILES:
+        if (value < 0 || value > 4096) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: first-layer tiles per wave must be 0 .. 4096");
+        xv_internal_first_tiles(value);
         return 0;
     default:
         return fail(XV_ERR_BAD_ARG, "xv_set_tuning: unknown key");

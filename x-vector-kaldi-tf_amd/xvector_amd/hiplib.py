@@ -37,6 +37,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
 FMT_F32, FMT_SPLIT, FMT_SPLIT8 = 0, 1, 2
 SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 264
 TUNE_TILE_ROWS = 1
+TUNE_FIRST_TILES = 2
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
