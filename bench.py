@@ -361,7 +361,7 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
     timed passes over the resident batches -- what the bf16x3 default is traded against."""
     import torch
     from xvector_amd import engine, hiplib, topology as tp
-    model = engine.DeviceModel(weights, topo, dev, precision="fp32", fused_pool=False)
+    model = engine.DeviceModel(weights, topo, dev, precision="fp32")
     model.reserve(max(b["rows"] for b in batches), max(b["n"] for b in batches), max(b["max_len"] for b in batches))
     P = torch.empty((n_utts, model.pooled_dim), dtype=torch.float32, device=dev)
     E = torch.empty((n_utts, model.embed_dim), dtype=torch.float32, device=dev)
@@ -385,7 +385,7 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
     return {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps,
             "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n_utts) / dt / 1e12,
             "tdnn_gemm_tflops": fl * steps / t_g / 1e12, "frac": fl * steps / t_g / MFMA_F32_PEAK, "peak_tflops": MFMA_F32_PEAK / 1e12,
-            "kernel": "tdnn_gemm_kernel (v_mfma_f32_32x32x2_f32), standalone stats_pool_kernel"}
+            "kernel": "tdnn_gemm_kernel (v_mfma_f32_32x32x2_f32); the last layer reduced to 8-row block statistics in its epilogue + stats_pool_blocks_kernel"}
 
 
 def _bf16x3_leg(args, weights, topo, dev, batches, n_utts, frames, feat, order, oracle_check):
@@ -612,9 +612,9 @@ def main():
     by_pool = (4 * C * frames + 4 * 2 * C * n_utts) * args.steps
     pool_kernel = "stats_pool_kernel"
     if model.fused_pool:
-        # the timed path reduces the last layer inside the GEMM epilogue; the standalone pooling kernel (fp32 path, training)
+        # the timed path reduces the last layer inside the GEMM epilogue; the standalone pooling kernel (attention-free models without the fused epilogue, training)
         # is timed here, outside the timed region, on a materialised [rows, 1536] fp32 activation of the largest batch
-        pool_kernel = "stats_pool_kernel (standalone, measured outside the timed region: the bf16x3 path reduces the last layer " \
+        pool_kernel = "stats_pool_kernel (standalone, measured outside the timed region: the timed path reduces the last layer " \
                       "to 8-row block statistics in the GEMM epilogue + stats_pool_blocks_kernel)"
         big = max(batches, key=lambda b: b["rows"])
         hbuf = torch.randn((big["rows"], C), device=dev, dtype=torch.float32)

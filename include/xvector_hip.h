@@ -136,6 +136,12 @@ int xv_tdnn_layer_pool_bf16x3(const void *x, int x_format, int64_t R, int cin, i
                               int dilation, int cout, const uint8_t *row_valid, float *block_stats, void *stream);
 int xv_stats_pool_blocks_f32(const float *block_stats, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
                              float eps, float *out, void *stream);
+/* The same fused last layer in the exact-fp32 arithmetic (xv_tdnn_layer_f32's GEMM with the block-statistics epilogue: the
+ * 4 * Cout bytes per frame of y are neither written nor re-read).  x / wp as for xv_tdnn_layer_f32; needs Cout % 4 == 0 and
+ * 16-byte aligned bias / bn_scale / bn_shift / per-channel act_alpha. */
+int xv_tdnn_layer_pool_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
+                           const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                           const uint8_t *row_valid, float *block_stats, void *stream);
 
 /* The FIRST frame-level layer (frame_level_info_layer-0: conv1d over the MFCC rows, models.py:54-67) as a kernel built around
  * its output stream: the im2col operand of a wave's 16 frames is formed in registers straight from the fp32 feature rows, the

@@ -100,6 +100,6 @@ def test_bench_at_the_per_rank_size_of_the_million_utterance_job():
 def test_fp32_and_training_bench_lines():
     d = _run("--utts", "300", "--steps", "1", "--warmup", "1", "--cpu-budget", "0", "--precision", "fp32")
     assert d["accuracy_probe"]["probed"] is False and "config2_varlen" not in d
-    assert d["dtype"] == "f32" and d["roofline"]["peak"] == pytest.approx(157.3) and d["config"]["fused_pool"] is False
+    assert d["dtype"] == "f32" and d["roofline"]["peak"] == pytest.approx(157.3) and d["config"]["fused_pool"] is True
     t = _run("--mode", "train", "--steps", "3", "--warmup", "1")
     assert t["unit"] == "chunks/s" and t["value"] > 0 and t["last_loss"] > 0 and "AM-softmax" in t["metric"]

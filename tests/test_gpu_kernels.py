@@ -306,6 +306,53 @@ def test_stats_pool_matches_oracle(env, C, lens, split):
         assert oracle.rel_l2(got[i, C:], ref[C:]) < TOL_POOL
 
 
+@pytest.mark.parametrize("cin,cout,K,dil,act,lens", [
+    (512, 1536, 1, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),      # layer 4 of the default topology (64-row tiles: a small batch)
+    (512, 1536, 1, 1, "relu", [300] * 90 + [25, 1, 7]),                # ... on 128-row tiles
+    (64, 200, 3, 1, "prelu", [300, 25, 64]),                          # ragged last column tile, K > 1
+    (40, 48, 5, 2, "lrelu", [1200, 33]),
+])
+def test_tdnn_layer_pool_f32_blocks_match_oracle(env, cin, cout, K, dil, act, lens):
+    """xv_tdnn_layer_pool_f32 (the exact-fp32 GEMM with the block-statistics epilogue) + xv_stats_pool_blocks_f32 == statistics
+    pooling of the layer output in the fp64 oracle, at the tolerance of the fp32 GEMM; the block statistics of a chunk do not
+    depend on where it sits in the batch (a second batch with the chunks in reverse order: bit-identical pooled rows)."""
+    torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]
+    rng = np.random.default_rng(cin + cout + K + len(lens))
+    mats = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in lens]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = None
+    if act == "lrelu":
+        alpha = np.array([0.2], np.float32)
+    elif act == "prelu":
+        alpha = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    gap = max(1, (K - 1) * dil // 2)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    wp = hiplib.pack_weights(t(w.reshape(K * cin, cout)))
+    scale, shift = hiplib.fold_bn(*(t(a) for a in bn), 1e-3)
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+
+    def run(ms):
+        layout = engine.BatchLayout([m.shape[0] for m in ms], gap, hiplib.POOL_BLOCK_ROWS)
+        host = np.zeros((layout.rows, cin), np.float32)
+        layout.pack(ms, host)
+        blk = torch.full((hiplib.block_stats_floats(layout.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
+        hiplib.tdnn_layer_pool(t(host), layout.rows, wp, t(b), scale, shift, code, t(alpha), dil, t(layout.row_valid()), blk, K=K)
+        out = torch.full((len(ms), 2 * cout), float("nan"), dtype=torch.float32, device=dev)
+        hiplib.stats_pool_blocks(blk, cout, t(layout.row_start), t(layout.row_len), len(ms), 1e-5, out)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    got = run(mats)
+    assert np.isfinite(got).all()
+    for i in list(range(min(len(mats), 8))) + [len(mats) - 1]:
+        ref = oracle.stats_pool(oracle.tdnn_layer(mats[i], w, b, bn, act, alpha, dil, np.float64), 1e-5, np.float64)
+        assert oracle.rel_l2(got[i, :cout], ref[:cout]) < TOL_GEMM, (i, lens[i])
+        assert oracle.rel_l2(got[i, cout:], ref[cout:]) < TOL_GEMM, (i, lens[i])
+    if len(mats) < 20:                                             # (same tile height in both runs)
+        assert np.array_equal(run(mats[::-1])[::-1], got)
+
+
 @pytest.mark.parametrize("fmt", ["f32", "split"])
 @pytest.mark.parametrize("cin,cout,K,dil,act,lens", [
     (512, 1536, 1, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000]),      # layer 4 of the default topology

@@ -1,0 +1,29 @@
+"""Per-layer timing of the exact-fp32 GEMM (xv_tdnn_layer_f32) on random data: every layer shape of the default topology against
+the 157.3 TF fp32-MFMA peak.  argv[1] = rows per batch (default 262144)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd"))
+import torch
+from xvector_amd import hiplib
+dev = torch.device("cuda:0"); R = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+tot_ms = tot_fl = 0.0
+for (cin, cout, K) in ((24, 512, 5), (512, 512, 5), (512, 512, 7), (512, 512, 1), (512, 1536, 1)):
+    w = torch.randn((K * cin, cout), device=dev) / (K * cin) ** 0.5
+    wp = hiplib.pack_weights(w)
+    x = torch.relu(torch.randn((R, cin), device=dev))
+    bias = torch.zeros(cout, device=dev); rv = torch.ones(R, dtype=torch.uint8, device=dev)
+    scale = torch.ones(cout, device=dev); shift = torch.zeros(cout, device=dev)
+    y = torch.empty((R, cout), device=dev)
+    fn = lambda: hiplib.tdnn_layer(x, wp, bias, scale, shift, 1, None, K, 1, rv, y)
+    ts = []
+    for rnd in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(4): fn()
+        b.record(); torch.cuda.synchronize()
+        if rnd: ts.append(a.elapsed_time(b) / 4)
+    ts.sort(); ms = ts[len(ts) // 2]
+    fl = 2.0 * R * cin * cout * K
+    tot_ms += ms; tot_fl += fl
+    print("%4d -> %4d K=%d: %.3f ms  %.1f TF = %.3f of 157.3   (output %.2f GB at %.2f TB/s)" % (cin, cout, K, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3, R * cout * 4 / 1e9, R * cout * 4 / ms / 1e9))
+print("all five: %.3f ms, %.1f TF = %.3f" % (tot_ms, tot_fl / tot_ms / 1e9, tot_fl / tot_ms / 1e9 / 157.3))

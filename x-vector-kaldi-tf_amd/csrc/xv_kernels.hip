@@ -65,6 +65,7 @@ struct GemmParams {
     float *y;
     int ldy;
     float *ypre;
+    float *blk;         // POOL epilogue (no y / ypre): per-8-row-block (mean, M2) planes [ceil(R/8)][2][cout], as Gemm3Params::blk
     int n_mt, n_nt;
     int vec_out;        // outputs take 16-byte stores: cout % 4 == 0, ldy % 4 == 0, y / ypre / per-column parameters 16-byte aligned
 };
@@ -154,6 +155,53 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams &p, float *T
     f32x4 al = zero;
     if (p.act == XV_ACT_LRELU) al = (f32x4){p.alpha[0], p.alpha[0], p.alpha[0], p.alpha[0]};
     else if (p.act == XV_ACT_PRELU) al = *reinterpret_cast<const f32x4 *>(p.alpha + gc);
+    if (p.blk) {
+        // POOL: the layer output is not stored; every 8-row block of the tile is reduced to per-channel (mean, M2) of its valid
+        // rows, shifted by the block's first row (as the POOL epilogue of tdnn_gemm_bf16x3_kernel: same planes, same finalize).
+        // Thread = (4 channels, blocks rp and rp + 8).  Explicit fma: the two unrolled instances must round alike, a block's
+        // statistics may not depend on where it sits in the tile.
+#pragma unroll
+        for (int bb = 0; bb < BMT / 64; ++bb) {
+            const int blk = rp + 8 * bb;
+            if (m0 + blk * 8 >= p.R) continue;
+            f32x4 tv[8];
+            float keep[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                tv[j] = *reinterpret_cast<const f32x4 *>(T + (blk * 8 + j) * TLD + cg * 4);
+                keep[j] = Ms[blk * 8 + j] ? 1.f : 0.f;
+            }
+            f32x4 v0 = zero, s1 = zero, s2 = zero;
+            float n = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                n += keep[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = __builtin_fmaf(apply_act(tv[j][i] + bias[i], p.act, al[i]), sc[i], sh[i]);
+                    if (j == 0) v0[i] = v;
+                    else {
+                        const float d = keep[j] != 0.f ? v - v0[i] : 0.f;       // (a select: a row past R may hold anything)
+                        s1[i] += d;
+                        s2[i] = __builtin_fmaf(d, d, s2[i]);
+                    }
+                }
+            }
+            // row 0 of a block is valid whenever any row is (chunks start on block boundaries, gaps follow the frames)
+            const float rn = n > 0.f ? 1.f / n : 0.f;
+            f32x4 mean, m2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t = s1[i] * rn;
+                mean[i] = n > 0.f ? v0[i] + t : 0.f;
+                m2[i] = fmaxf(__builtin_fmaf(-t, s1[i], s2[i]), 0.f);
+            }
+            float *o = p.blk + ((size_t)((m0 >> 3) + blk) * 2) * p.cout + gc;
+            *reinterpret_cast<f32x4 *>(o) = mean;
+            *reinterpret_cast<f32x4 *>(o + p.cout) = m2;
+        }
+        return;
+    }
 #pragma unroll 4
     for (int j = 0; j < BMT / 8; ++j) {
         const int lr = rp + 8 * j;
@@ -1072,7 +1120,8 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
     const bool vec = (p.cin % 4 == 0) && (p.ldx % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) && (((uintptr_t)p.wp) % 16 == 0);
     const uintptr_t out_bits = (uintptr_t)p.y | (uintptr_t)p.ypre | (uintptr_t)p.bias | (uintptr_t)p.scale | (uintptr_t)p.shift |
                                (p.act == XV_ACT_PRELU ? (uintptr_t)p.alpha : 0);
-    p.vec_out = (p.cout % 4 == 0) && (p.ldy % 4 == 0) && (out_bits % 16 == 0) && std::getenv("XV_FP32_SCALAR_EPILOGUE") == nullptr;
+    p.vec_out = (p.cout % 4 == 0) && (p.ldy % 4 == 0) && (out_bits % 16 == 0) && (p.blk || std::getenv("XV_FP32_SCALAR_EPILOGUE") == nullptr);
+    if (p.blk && !p.vec_out) return fail(XV_ERR_UNSUPPORTED, "tdnn_pool: needs cout % 4 == 0 and 16-byte aligned per-column parameters");
     typedef void (*kern_t)(const GemmParams);
     const kern_t all[] = {tdnn_gemm_kernel<true, 128>, tdnn_gemm_kernel<false, 128>, tdnn_gemm_kernel<true, 64>,
                           tdnn_gemm_kernel<false, 64>};
@@ -1441,6 +1490,20 @@ int xv_tdnn_layer_f32(const float *x, int64_t R, int cin, int ldx, const float *
     p.x = x; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wp = wp;
     p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
     p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid; p.y = y; p.ldy = ldy; p.ypre = y_preact;
+    return launch_gemm(p, (hipStream_t)stream);
+}
+
+int xv_tdnn_layer_pool_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
+                           const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                           const uint8_t *row_valid, float *block_stats, void *stream)
+{
+    if (!x || !wp || !block_stats) return fail(XV_ERR_BAD_ARG, "tdnn_pool: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_pool: unknown act_kind");
+    if (((uintptr_t)block_stats) & 15) return fail(XV_ERR_BAD_ARG, "tdnn_pool: block_stats must be 16-byte aligned");
+    GemmParams p{};
+    p.x = x; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wp = wp;
+    p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
+    p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid; p.ldy = cout; p.blk = block_stats;
     return launch_gemm(p, (hipStream_t)stream);
 }
 

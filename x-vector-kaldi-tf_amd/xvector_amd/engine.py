@@ -221,9 +221,10 @@ class DeviceModel(object):
 
     def __init__(self, weights, topo, device="cuda:0", embedding_index=0, precision="bf16x3", fused_pool=None, pair_kernel=None):
         """precision: "fp32" = exact fp32 MFMA GEMMs; "bf16x3" = split-precision bf16 MFMA GEMMs (fp32-class
-        accuracy, ~3e-6 rel-L2 on the x-vector; see include/xvector_hip.h).  fused_pool (default: on for bf16x3): the
-        last frame-level layer reduces its output to 8-row block statistics in the GEMM epilogue instead of storing it
-        (xv_tdnn_layer_pool_bf16x3); batches must then be laid out with ``align`` = 8.  pair_kernel (default: on with
+        accuracy, ~3e-6 rel-L2 on the x-vector; see include/xvector_hip.h).  fused_pool (default: on; fp32 needs a last layer whose
+        width is a multiple of 4; never with attention pooling): the last frame-level layer reduces its output to 8-row block
+        statistics in the GEMM epilogue instead of storing it (xv_tdnn_layer_pool_bf16x3 / _f32); batches must then be laid
+        out with ``align`` = 8.  pair_kernel (default: on with
         fused_pool when the last two layers have kernel size 1 and a shape xv_tdnn_pair_pool_bf16x3 supports;
         XVECTOR_PAIR_KERNEL=0 turns it off): those two layers and the block statistics run as one launch whose
         intermediate activation stays in registers."""
@@ -248,8 +249,11 @@ class DeviceModel(object):
         self._weights = weights if self.f16bf8 else None
         self._fallback = None
         self.attention = tp.is_attention(topo)
-        self.fused_pool = (precision == "bf16x3" and not self.attention) if fused_pool is None else bool(fused_pool)
-        assert not (self.fused_pool and precision != "bf16x3"), "fused pooling exists on the bf16x3 path only"
+        # fused pooling: the last layer's GEMM epilogue reduces 8-row blocks to (mean, M2) instead of storing the layer (bf16x3 /
+        # f16bf8 kernels, and the exact-fp32 GEMM when its width allows 16-byte stores)
+        can_fuse = not self.attention and (precision == "bf16x3" or int(topo["layer_sizes"][-1]) % 4 == 0)
+        self.fused_pool = can_fuse if fused_pool is None else bool(fused_pool)
+        assert not (self.fused_pool and precision == "fp32" and int(topo["layer_sizes"][-1]) % 4), "fused fp32 pooling needs Cout % 4 == 0"
         assert not (self.fused_pool and self.attention), "the fused epilogue computes plain statistics, not attention-weighted ones"
         self.align = hiplib.POOL_BLOCK_ROWS if self.fused_pool else 1
         self.torch = torch
@@ -302,7 +306,7 @@ class DeviceModel(object):
                 self.first = hiplib.pack_first_bf16x3(self._dev(wpad))
             self.pair = None
             want_pair = (os.environ.get("XVECTOR_PAIR_KERNEL", "1") != "0") if pair_kernel is None else bool(pair_kernel)
-            if want_pair and self.fused_pool and len(self.layers) >= 3:
+            if want_pair and self.fused_pool and precision == "bf16x3" and len(self.layers) >= 3:
                 La, Lb = self.layers[-2], self.layers[-1]
                 if La["K"] == 1 and Lb["K"] == 1 and hiplib.pair_supported(La["cin"], La["cout"], Lb["cout"]):
                     n = len(self.layers)
@@ -472,8 +476,8 @@ class DeviceModel(object):
                                       (Lb["bias"], Lb["scale"], Lb["shift"], Lb["alpha"]), self.act, row_valid, self._last)
                 break
             if last and self.fused_pool:
-                hiplib.tdnn_layer_pool(h, R, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"],
-                                       row_valid, self._last)
+                hiplib.tdnn_layer_pool(h, R, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid,
+                                       self._last, K=L["K"])
                 break
             if last and self.attention:
                 h = self._attention_scores(h, R, L, row_valid)

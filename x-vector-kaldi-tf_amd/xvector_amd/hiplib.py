@@ -17,7 +17,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32",
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_split_row_bytes", "xv_split_encode_f32",
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
-           "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32",
+           "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32", "xv_tdnn_layer_pool_f32",
            "xv_packed_pair_bf16x3_bytes", "xv_pack_pair_bf16x3", "xv_tdnn_pair_pool_bf16x3",
            "xv_packed_first_bf16x3_bytes", "xv_pack_first_bf16x3", "xv_tdnn_first_bf16x3",
            "xv_packed_weights_f16bf8_bytes", "xv_pack_weights_f16bf8", "xv_split8_encode_f32", "xv_split8_decode_f32",
@@ -93,6 +93,8 @@ def load():
     lib.xv_fc_bf16x3.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
     lib.xv_block_stats_bytes.restype = ctypes.c_size_t
     lib.xv_block_stats_bytes.argtypes = [i64, ci]
+    lib.xv_tdnn_layer_pool_f32.restype = ci
+    lib.xv_tdnn_layer_pool_f32.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
     lib.xv_tdnn_layer_pool_bf16x3.restype = ci
     lib.xv_tdnn_layer_pool_bf16x3.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]
     lib.xv_packed_first_bf16x3_bytes.restype = sz
@@ -371,21 +373,30 @@ def block_stats_floats(rows, cout):
     return int(load().xv_block_stats_bytes(int(rows), int(cout))) // 4
 
 
-def tdnn_layer_pool(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, block_stats):
-    """Last frame-level layer with the block-statistics epilogue (bf16x3 only): block_stats = flat fp32 tensor of
-    >= block_stats_floats(R, w.cout) elements, laid out [ceil(R/8)][2][Cout]."""
+def tdnn_layer_pool(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, block_stats, K=None):
+    """Last frame-level layer with the block-statistics epilogue: block_stats = flat fp32 tensor of
+    >= block_stats_floats(R, cout) elements, laid out [ceil(R/8)][2][Cout].  w: Packed3 (bf16x3) or the packed fp32 weights
+    of pack_weights() together with ``K`` (exact fp32, x: fp32 rows)."""
     lib = require_gpu()
-    assert isinstance(w, Packed3)
+    _f32(block_stats, "block_stats")
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    if not isinstance(w, Packed3):
+        _rows2d(x, "x"); _f32(w, "wp")
+        cin, cout = x.shape[1], w.shape[0]
+        assert K is not None and w.shape[1] == int(K) * cin and x.shape[0] >= R
+        assert block_stats.numel() >= block_stats_floats(R, cout), "block_stats too small"
+        _check(lib.xv_tdnn_layer_pool_f32(_ptr(x), int(R), cin, x.stride(0), _ptr(w), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+                                          _ptr(alpha), int(K), int(dilation), cout, _ptr(row_valid), _ptr(block_stats), _stream()),
+               "xv_tdnn_layer_pool_f32")
+        return
     if isinstance(x, SplitBuf):
         assert x.channels == w.cin and x.rows >= R and x.fmt == FMT_SPLIT
         xp, ldx, fmt = ctypes.c_void_p(x.ptr), 0, FMT_SPLIT
     else:
         _f32(x, "x"); assert x.shape[1] == w.cin and x.shape[0] >= R
         xp, ldx, fmt = _ptr(x), x.stride(0), FMT_F32
-    _f32(block_stats, "block_stats")
     assert block_stats.numel() >= block_stats_floats(R, w.cout), "block_stats too small"
-    if row_valid is not None:
-        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
     _check(lib.xv_tdnn_layer_pool_bf16x3(xp, fmt, int(R), w.cin, ldx, _ptr(w.wt), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
                                          _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), _ptr(block_stats), _stream()),
            "xv_tdnn_layer_pool_bf16x3")
