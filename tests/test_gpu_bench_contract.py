@@ -88,6 +88,22 @@ def test_two_ranks_through_the_self_launcher_on_one_gpu():
     assert d["with_ark_write"]["ark_mb"] > 2 * 600 * 2000 / 1e6                                          # both ranks' vectors reached rank 0
 
 
+def test_two_training_ranks_through_the_self_launcher_on_one_gpu():
+    """`python bench.py --mode train --gpus 2` (BASELINE configs[4], N > 1): two trainer ranks on the shared GPU over gloo -- bucketed
+    gradient all-reduces during the backward pass, max-over-ranks timing, ONE line from rank 0 with the whole job's chunks per second."""
+    env = dict(os.environ, XV_BENCH_SHARE_GPU="1", XVECTOR_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert run.returncode == 0, run.stderr.decode()[-2000:]
+    out = run.stdout.decode().strip().splitlines()
+    assert len(out) == 1, out
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["unit"] == "chunks/s" and d["scaling"] == "weak" and "x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] and d["last_loss"] > 0
+
+
 def test_bench_at_the_per_rank_size_of_the_million_utterance_job():
     """BASELINE configs[3] gives every one of 8 ranks 125 k utterances: the resident-input step at that size (37.5 M frames,
     ~145 batches) on one GPU."""

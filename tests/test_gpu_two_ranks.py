@@ -76,3 +76,80 @@ def test_two_rank_jobs_write_the_single_process_bytes(tmp_path, oracle_mod):
         if lens[i] >= 25:
             ref = oracle_mod.embed_utterance(pool[i % 61][:lens[i]], w, topo, 25, 10000, np.float64)
             assert oracle_mod.rel_l2(got["utt%05d" % i], ref) < 1e-4
+
+
+_TRAIN_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["XV_TEST_PKG"])
+from xvector_amd import dist as xdist, synthetic, topology, trainer
+rank, world = xdist.init_process_group()
+assert world == 2
+topo = topology.get("ModelWithoutDropout")
+topo["layer_sizes"] = [64, 64, 64, 64, 96]; topo["embedding_sizes"] = [32, 32]
+w = synthetic.trained_like(topo, 23, num_classes=10, seed=3)
+tr = trainer.Trainer(w, topo, device="cuda:0", precision=os.environ["XV_TEST_PRECISION"])
+for step in range(2):
+    rng = np.random.default_rng(100 * step + rank)
+    x = (rng.standard_normal((6, 80 + 10 * step, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, 6)
+    tr.step(x, lab, 1e-3)
+np.save(os.path.join(os.environ["XV_TEST_OUT"], "p%d.npy" % rank), tr.flat_p.cpu().numpy())
+np.save(os.path.join(os.environ["XV_TEST_OUT"], "s%d.npy" % rank), tr.flat_moving.cpu().numpy())
+xdist.finish_process_group()
+'''
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_two_rank_training_steps_average_the_gradients(tmp_path, precision):
+    """BASELINE configs[4] with N > 1: two ranks of the REAL trainer on cuda:0 (gloo transport), each on its own minibatches, two
+    optimizer steps with the four bucketed all-reduces issued during the backward pass.  Both ranks end with bit-identical
+    weights -- the ones a single process gets that runs both replicas itself, sums their gradients, halves them and applies
+    Adam once -- while the batch-norm moving statistics stay per replica."""
+    import math
+    import torch
+    from xvector_amd import hiplib, synthetic, topology, trainer
+    hiplib.require_gpu()
+    script = str(tmp_path / "train_worker.py")
+    open(script, "w").write(_TRAIN_WORKER)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG, os.environ.get("PYTHONPATH", "")]), XVECTOR_DEVICE="cuda:0",
+               XVECTOR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", XV_TEST_PKG=PKG, XV_TEST_OUT=str(tmp_path),
+               XV_TEST_PRECISION=precision)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "XV_FORCE_DIST"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, "-m", "xvector_amd.launch", "--nproc", "2", script], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=600)
+    assert run.returncode == 0, run.stdout.decode(errors="replace")[-3000:]
+    p0, p1 = np.load(str(tmp_path / "p0.npy")), np.load(str(tmp_path / "p1.npy"))
+    s0, s1 = np.load(str(tmp_path / "s0.npy")), np.load(str(tmp_path / "s1.npy"))
+    assert np.array_equal(p0, p1) and not np.array_equal(s0, s1)
+    # the same two steps in ONE process: replicas A and B, gradients summed and halved exactly as Trainer.step does
+    topo = topology.get("ModelWithoutDropout")
+    topo["layer_sizes"] = [64, 64, 64, 64, 96]; topo["embedding_sizes"] = [32, 32]
+    w = synthetic.trained_like(topo, 23, num_classes=10, seed=3)
+    reps = [trainer.Trainer(w, topo, device="cuda:0", precision=precision) for _ in range(2)]
+    for step in range(2):
+        g = []
+        for rank, tr in enumerate(reps):
+            rng = np.random.default_rng(100 * step + rank)
+            x = (rng.standard_normal((6, 80 + 10 * step, 23)) * 3).astype(np.float32)
+            lab = rng.integers(0, 10, 6)
+            tr.gradients(x, lab)
+            g.append(tr.flat_g.clone())
+        total = g[0] + g[1]
+        for tr in reps:
+            tr.flat_g.copy_(total)
+            hiplib.axpy(tr.flat_g, tr.flat_g, 1.0 / 2 - 1.0)
+            tr.t += 1
+            lr_t = 1e-3 * math.sqrt(1.0 - trainer.ADAM_B2 ** tr.t) / (1.0 - trainer.ADAM_B1 ** tr.t)
+            hiplib.adam(tr.flat_p, tr.flat_g, tr.flat_m, tr.flat_v, lr_t, trainer.ADAM_B1, trainer.ADAM_B2, trainer.ADAM_EPS)
+            tr._packed = None
+    torch.cuda.synchronize()
+    assert np.array_equal(reps[0].flat_p.cpu().numpy(), p0)
+    assert np.array_equal(reps[0].flat_moving.cpu().numpy(), s0) and np.array_equal(reps[1].flat_moving.cpu().numpy(), s1)
+    alone = trainer.Trainer(w, topo, device="cuda:0", precision=precision)
+    for step in range(2):
+        rng = np.random.default_rng(100 * step)
+        x = (rng.standard_normal((6, 80 + 10 * step, 23)) * 3).astype(np.float32)
+        alone.step(x, rng.integers(0, 10, 6), 1e-3)
+    assert not np.array_equal(alone.flat_p.cpu().numpy(), p0)       # (the exchange did something)
