@@ -3,6 +3,8 @@
 //   mode 0:  8 x f16 32x32x16 + 4 x MX bf8 32x32x64      (the shipped stage of the 256 x 256 kernel)
 //   mode 1: 16 x f16 16x16x32 + 8 x MX bf8 16x16x128     (quarter-size accumulators, twice the operand registers per FLOP)
 //   mode 2 / 3: the f16 halves alone;  mode 4 / 5: the MX halves alone
+//   mode 6: as 5 with K blocks 2 and 3 of both operands zero -- what a 16x16x128 instruction costs when only one (tap, slab) item
+//           fills it (the padding an odd number of taps needs);  mode 7: as 5 with only the A operand's blocks 2, 3 zero
 //   hipcc --offload-arch=gfx950 -O3 -o shape_probe shape_probe.hip && ./shape_probe
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,6 +32,9 @@ __global__ __launch_bounds__(512, 1) void rate_kernel(const uint8_t *src, float 
     asm volatile("" : "+v"(va), "+v"(vb));
     f16x8 h[8];
     for (int j = 0; j < 8; ++j) __builtin_memcpy(&h[j], reinterpret_cast<char *>(&r[j]) + (j & 1) * 16, 16);
+    // operands whose K blocks 2, 3 (lanes 32..63 of a 16x16x128 operand) are zero
+    i32x8 z[4];
+    for (int j = 0; j < 4; ++j) z[j] = (tid & 32) ? (i32x8){0, 0, 0, 0, 0, 0, 0, 0} : r[4 + j];
     for (int it = 0; it < iters; ++it) {
         if constexpr (MODE == 0 || MODE == 2) {
 #pragma unroll
@@ -55,6 +60,11 @@ __global__ __launch_bounds__(512, 1) void rate_kernel(const uint8_t *src, float 
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 sm[u + 4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(r[4 + (u & 1)], r[6 + ((u >> 1) & 1)], sm[u + 4], 1, 1, 0, va, 0, vb);
+        }
+        if constexpr (MODE == 6 || MODE == 7) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                sm[u + 4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(z[u & 1], MODE == 6 ? z[2 + ((u >> 1) & 1)] : r[6 + ((u >> 1) & 1)], sm[u + 4], 1, 1, 0, va, 0, vb);
         }
     }
     float t = 0.f;
@@ -106,6 +116,8 @@ int main(int argc, char **argv)
         run_rate<3>(dS, dO, iters, "16 x f16 16x16x32");
         run_rate<4>(dS, dO, iters, "4 x MX 32x32x64");
         run_rate<5>(dS, dO, iters, "8 x MX 16x16x128");
+        run_rate<6>(dS, dO, iters, "8 x MX 16x16x128, K blocks 2,3 zero (A, B)");
+        run_rate<7>(dS, dO, iters, "8 x MX 16x16x128, K blocks 2,3 zero (A)");
     }
     return 0;
 }
