@@ -473,9 +473,14 @@ struct Gemm3Params {
 // the current slab, PW pieces per wave per tap (K=1: 4 -- every stage loads its own slab --, K=3: 3, K=5: 2, K=7: 1).
 // POOL: the layer output is not stored; the epilogue reduces every 8-row block of the tile to per-channel (mean, M2)
 // for the statistics pooling that follows the last frame-level layer (see stats_pool_blocks_kernel).
-template <bool SPLIT_A, int KT, bool POOL, int WM>
-__global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)
+// S16 (split input, K > 1, an even number of slabs): the same tile and the same bytes through LDS on v_mfma_f32_16x16x32_bf16 -- a
+// dot product twice as long per instruction, quarter-size accumulator tiles: fewer joules per product on the power-limited pipe
+// (tools/experiments/shape_probe.hip).  A wave holds ALL 16 fragments of a stage (4 row tiles + 4 column tiles, hi and lo: 64
+// VGPRs) and reads the next stage's 16 behind the 48 MFMAs of the current one: two fragment sets + 64 accumulators = 192 VGPRs.
+template <bool SPLIT_A, int KT, bool POOL, int WM, bool S16 = false>
+__global__ __launch_bounds__(WM * 128, (S16 && WM == 4) ? 1 : 2) void tdnn_gemm_bf16x3_kernel(const Gemm3Params p)
 {
+    static_assert(!S16 || (SPLIT_A && KT > 1), "the 16 x 16 form exists for split input and K > 1");
     constexpr int NW = 2 * WM;                         // waves per workgroup
     constexpr int NT = NW * 64;                        // threads (shadows the file-scope constant of the fp32 kernel)
     constexpr int BM = WM * 64;                        // rows per workgroup tile
@@ -655,12 +660,122 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_bf16x3_kernel(const Gem
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     Frags F = {}, G = {};
-    load_frags(F, 0, 0, 0, 0);
+    if constexpr (!S16) load_frags(F, 0, 0, 0, 0);
 
     int c0 = 0, t0 = 0;                       // (chunk, tap) of stage s
     int c2 = c1, t2 = t1;                     // (chunk, tap) of stage s+2
     advance(c2, t2);
-    if constexpr (SPLIT_A) {
+    f32x4 acc16[4][4];                        // S16: row tile i, column tile j of the wave's 64 x 64
+    if constexpr (S16) {
+        constexpr int NP = BM / 8 + 1;
+        constexpr int DT = KT - 1;
+        constexpr int NS = (NP + NW - 1) / NW;
+        constexpr int PW = (NS + DT - 1) / DT;
+        auto slots_of = [](int t) constexpr { return t < DT ? (NS + DT - 1 - t) / DT : 0; };
+        auto slot_base = [](int t) constexpr { int b = 0; for (int u = 0; u < t; ++u) b += (NS + DT - 1 - u) / DT; return b; };
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // lane (row / column l & 15, k block l >> 4 = the 16-byte slot of the 32-channel slab)
+        const int kb = lane >> 4;
+        int pa16[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int lr0 = wr * 64 + (lane & 15) + t * p.dil;
+            pa16[t] = lr0 * SROW + (((((lr0 + goff) & 15) >> 1) ^ kb) << 4);      // (+ 16 i rows: the same swizzle; lo plane: ^ 64)
+        }
+        const int col16 = wc * 64 + (lane & 15);
+        const int pb16 = 2 * A3_BYTES + col16 * 64 + ((kb ^ ((col16 >> 2) & 3)) << 4);   // (+ 16 j columns: + 1024, the same swizzle)
+        const uint32_t rowstep = 8u * (uint32_t)xrow_bytes;
+        uint32_t ag_off[DT][PW], al_off[DT][PW];
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                int piece = (slot_base(t) + j) * NW + wave;
+                piece = piece < NP ? piece : NP - 1;
+                ag_off[t][j] = (uint32_t)piece * rowstep;
+                al_off[t][j] = (uint32_t)piece * 1024u;
+            }
+        const uint8_t *bnext = bsrc;
+        if (n_stages <= 2) bnext = bsrc - B3_BYTES;
+        const uint8_t *abase = reinterpret_cast<const uint8_t *>(p.x) + (m0 - left + (lane >> 3)) * (long)xrow_bytes + (lane & 7) * 16;
+        struct Set16 { bf16x8 ah[4], al[4], bh[4], bl[4]; };
+        auto load16 = [&](Set16 &X, int abase_off, int bbase_off) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                X.ah[i] = *reinterpret_cast<const bf16x8 *>(lds + abase_off + i * 16 * SROW);
+                X.al[i] = *reinterpret_cast<const bf16x8 *>(lds + (abase_off ^ 64) + i * 16 * SROW);
+                X.bh[i] = *reinterpret_cast<const bf16x8 *>(lds + bbase_off + i * 1024);
+                X.bl[i] = *reinterpret_cast<const bf16x8 *>(lds + bbase_off + B3_PLANE + i * 1024);
+            }
+        };
+        auto mma16 = [&](const Set16 &X) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X.al[i], X.bh[j], acc16[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X.ah[i], X.bl[j], acc16[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X.ah[i], X.bh[j], acc16[i][j], 0, 0, 0);
+        };
+        Set16 F16, G16;
+        load16(F16, pa16[0], pb16);
+        int s = 0;
+        for (int c = 0; c < p.n_chunks; c += 2) {         // two slabs per trip: the fragment sets swap roles every stage, K is odd
+            auto stage = [&](auto UU) {
+                constexpr int u = decltype(UU)::value;
+                constexpr int t = u % KT;
+                const int cc = c + u / KT;
+                const int abuf = (cc & 1) * A3_BYTES;
+                const int cn = (cc + 1 < p.n_chunks) ? cc + 1 : p.n_chunks - 1;
+                const uint8_t *anext = abase + (size_t)cn * SROW;
+                char *adst_n = Abuf + (cn & 1) * A3_BYTES;
+                const int bbuf = (s & 1) * B3_BYTES;
+                // stage s is in registers (everybody's reads of it have returned), stage s+1 has landed
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                {
+                    char *dst = Bbuf + bbuf + wave * (BP * 1024);
+                    XV_GLDS16_OFF(bnext, dst, 0);
+                    XV_GLDS16_OFF(bnext, dst, 1024);
+                    if constexpr (BP == 4) {
+                        XV_GLDS16_OFF(bnext, dst, 2048);
+                        XV_GLDS16_OFF(bnext, dst, 3072);
+                    }
+                    bnext += (s + 3 < n_stages) ? B3_BYTES : 0;
+                }
+                if constexpr (t < KT - 1) {
+#pragma unroll
+                    for (int j = 0; j < slots_of(t); ++j) XV_GLDS16(anext + ag_off[t][j], adst_n + al_off[t][j]);
+                }
+                const int a_next = (t + 1 < KT) ? pa16[(t + 1) % KT] + abuf : pa16[0] + (A3_BYTES - abuf);
+                if constexpr ((u & 1) == 0) { load16(G16, a_next, pb16 + (B3_BYTES - bbuf)); mma16(F16); }
+                else { load16(F16, a_next, pb16 + (B3_BYTES - bbuf)); mma16(G16); }
+                constexpr int NV = BP + slots_of(t);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (LDS-DMA piece)
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 48 - 32 - NV, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                ++s;
+            };
+            for_taps<0, 2 * KT>(stage);
+        }
+    } else if constexpr (SPLIT_A) {
         // Straight-line iteration body (no branches): DMA is issued unconditionally (clamped at the tail, where it
         // rewrites identical bytes), so that sched_group_barrier can interleave every memory instruction with the
         // MFMAs of the same wave: the wave overlaps its own memory issue instead of relying on the co-resident block.
@@ -811,7 +926,16 @@ __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_bf16x3_kernel(const Gem
 
     // ---- epilogue: accumulators -> LDS fp32 tile (the operand buffers are dead after the last barrier) ------
     float *T = reinterpret_cast<float *>(lds);
-    {
+    if constexpr (S16) {
+        const int col = wc * 64 + (lane & 15);
+        const int rowb = wr * 64 + 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(rowb + 16 * i + e) * T_LD + col + 16 * j] = acc16[i][j][e];
+    } else {
         const int col = wc * 64 + (lane & 31);
         const int rowb = wr * 64 + 4 * (lane >> 5);
 #pragma unroll
@@ -1019,6 +1143,7 @@ struct Gemm3Kernel {
     bool pool;
     int wm;
     gemm3_fn fn;
+    bool s16 = false;
 };
 #define XV_G3(SPLIT, KT, POOL, WM) {KT, POOL, WM, tdnn_gemm_bf16x3_kernel<SPLIT, KT, POOL, WM>}
 const Gemm3Kernel GEMM3_KERNELS[] = {
@@ -1027,12 +1152,17 @@ const Gemm3Kernel GEMM3_KERNELS[] = {
     XV_G3(true, 1, true, 2),  XV_G3(true, 3, true, 2),  XV_G3(true, 5, true, 2),  XV_G3(true, 7, true, 2),
     XV_G3(true, 1, false, 4), XV_G3(true, 3, false, 4), XV_G3(true, 5, false, 4), XV_G3(true, 7, false, 4),
     XV_G3(true, 1, true, 4),  XV_G3(true, 3, true, 4),  XV_G3(true, 5, true, 4),  XV_G3(true, 7, true, 4),
+    // the 16 x 16 MFMA form (split input, K > 1)
+#define XV_G3S(KT, POOL, WM) {KT, POOL, WM, tdnn_gemm_bf16x3_kernel<true, KT, POOL, WM, true>, true}
+    XV_G3S(3, false, 2), XV_G3S(5, false, 2), XV_G3S(7, false, 2), XV_G3S(3, true, 2), XV_G3S(5, true, 2), XV_G3S(7, true, 2),
+    XV_G3S(3, false, 4), XV_G3S(5, false, 4), XV_G3S(7, false, 4), XV_G3S(3, true, 4), XV_G3S(5, true, 4), XV_G3S(7, true, 4),
+#undef XV_G3S
 };
 #undef XV_G3
-const Gemm3Kernel *find_gemm3(int kt, bool pool, int wm)
+const Gemm3Kernel *find_gemm3(int kt, bool pool, int wm, bool s16 = false)
 {
     for (const Gemm3Kernel &e : GEMM3_KERNELS)
-        if (e.kt == kt && e.pool == pool && e.wm == wm) return &e;
+        if (e.kt == kt && e.pool == pool && e.wm == wm && e.s16 == s16) return &e;
     return nullptr;
 }
 
@@ -1076,16 +1206,20 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
     // workgroup tile: 256 rows (8 waves, one workgroup per CU) for the wide-context layers when the input is in the split
     // format and there are enough rows to fill the chip with such tiles, else 128 rows (4 waves, two per CU);
     // xv_set_tuning(XV_TUNE_TILE_ROWS) overrides
+    // the 16 x 16 MFMA form where it exists: split input, K > 1, an even number of 32-channel slabs (XV_BF16X3_S16=0: off)
+    static const bool s16_on = !(std::getenv("XV_BF16X3_S16") != nullptr && std::getenv("XV_BF16X3_S16")[0] == '0');
+    const bool s16 = s16_on && p.x_split && kt > 1 && (p.n_chunks & 1) == 0;
     int wm = 2;
     if (p.x_split) {
         const int want = g_tile_rows.load(std::memory_order_relaxed);
         // measured on 262144-row batches (tools/layer_bench.py, profiles/r02a_layer_tile.txt): K = 7 +2.7 %, K = 5 +1.2 %,
-        // K = 1 -1.5 ... -3.5 % (with one workgroup per CU the prologue and epilogue of a 16-stage tile are exposed)
+        // K = 1 -1.5 ... -3.5 % (with one workgroup per CU the prologue and epilogue of a 16-stage tile are exposed).  The
+        // 16 x 16 form is faster on 128-row tiles (K = 5 1.306 against 1.357 ms, K = 7 1.759 against 1.773)
         const bool big_enough = ((p.R + 255) / 256) * p.n_nt >= 512;          // two rounds of 256 CUs
-        if (want == 256 || (want == 0 && p.K >= 5 && big_enough)) wm = 4;
+        if (want == 256 || (want == 0 && p.K >= 5 && big_enough && !s16)) wm = 4;
     }
     p.n_mt = (int)((p.R + wm * 64 - 1) / (wm * 64));
-    const Gemm3Kernel *k = find_gemm3(kt, p.blk != nullptr, wm);
+    const Gemm3Kernel *k = find_gemm3(kt, p.blk != nullptr, wm, s16);
     if (!k) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: no kernel for this configuration");
     // the dynamic-LDS opt-in is per device and idempotent: one bit per device id, set after the first successful pass
     static std::atomic<unsigned long long> attr_done{0};
