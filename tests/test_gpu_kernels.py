@@ -131,6 +131,7 @@ def test_fp32_gemm_both_tile_heights(env):
     (512, 512, 3, 3, "relu"),       # dilated
     (64, 48, 5, 1, "prelu"),        # ragged Cout
     (40, 200, 3, 2, "lrelu"),       # Cin not a multiple of 32
+    (96, 64, 5, 1, "relu"),         # three 32-channel slabs: the 16 x 16 MFMA form needs an even number, this one runs on 32 x 32 tiles
 ])
 def test_tdnn_layer_bf16x3_matches_oracle(env, cin, cout, K, dil, act, fmt):
     oracle = env["oracle"]
