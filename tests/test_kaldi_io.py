@@ -417,6 +417,71 @@ def test_in_place_windows_equal_the_record_reader(tmp_path):
     assert all(np.array_equal(a.astype(np.float32), mats[i]) for (_, a), i in zip(got, want))
 
 
+def test_compressed_matrices_through_the_in_place_reader(tmp_path):
+    """Kaldi's default feature arks are CompressedMatrix records ("CM "): the in-place reader hands them to the host library's
+    decoder (xv_ark_decode_cm: Kaldi's float32 arithmetic, a few threads, into arenas of their own) instead of reading them one
+    by one through NumPy.  Bit-identical to the generic reader (which the reference-recorded fixtures pin) on a stream that mixes
+    compressed and plain matrices, widths that change, a one-row matrix and a matrix larger than an arena; input order kept;
+    every arena accounted for; the same through an scp table."""
+    import io
+    from fixture_inputs import encode_cm_record
+    if kaldi_io._host_lib() is None or not hasattr(kaldi_io._host_lib(), "xv_ark_decode_cm"):
+        pytest.skip("host library not built")
+    rng = np.random.default_rng(11)
+    bio, want = io.BytesIO(), []
+    for i in range(400):
+        t = 1 if i == 7 else 3000 if i == 150 else int(rng.integers(2, 300))
+        f = 40 if 200 <= i < 260 else 23
+        m = (rng.standard_normal((t, f)) * (1 + i % 4) + (i % 3)).astype(np.float32)
+        if i % 9 == 4:
+            kaldi_io.write_mat(bio, m, key="plain%03d" % i)
+        else:
+            bio.write(encode_cm_record("utt%03d" % i, m))
+        want.append(("plain%03d" % i) if i % 9 == 4 else ("utt%03d" % i))
+    raw = bio.getvalue()
+    ref = dict(kaldi_io.read_mat_ark(io.BytesIO(raw)))              # the generic reader: NumPy decode, record by record
+    assert list(ref) == want
+    taken, released, held, got = [], [], [], {}
+
+    def take():
+        taken.append(kaldi_io.ArkArena(1 << 18))                    # 256 KB: the 3000 x 23 matrix (276 KB decoded) does not fit
+        return taken[-1]
+    order = []
+    for keys, addr, rows, cols, holder in kaldi_io.scan_mat_ark_windows(io.BytesIO(raw), take, None, released.append):
+        am = kaldi_io.ArkMats()
+        am.add(addr, rows, cols, holder)
+        for j, k in enumerate(keys):
+            got[k] = np.array(am[j])
+        order += keys
+        if isinstance(holder, kaldi_io.ArkArena):
+            held.append(holder)
+    assert order == want
+    assert all(got[k].dtype == np.float32 and np.array_equal(got[k], ref[k]) for k in want)
+    assert sorted(map(id, taken)) == sorted(map(id, held + released)) and len(set(map(id, taken))) == len(taken)
+    # the same records behind an scp table
+    ark, scp = str(tmp_path / "c.ark"), str(tmp_path / "c.scp")
+    lines, pos = [], 0
+    with open(ark, "wb") as f:
+        f.write(raw)
+    stream = io.BytesIO(raw)
+    while True:
+        at = stream.tell()
+        key = kaldi_io.read_key(stream)
+        if not key:
+            break
+        lines.append("%s %s:%d" % (key, ark, at + len(key) + 1))
+        kaldi_io.read_mat(stream)
+    open(scp, "wt").write("\n".join(lines) + "\n")
+    n = 0
+    for keys, addr, rows, cols, holder in kaldi_io.MatScp(scp).windows(lambda: kaldi_io.ArkArena(1 << 18), None, lambda a: None):
+        am = kaldi_io.ArkMats()
+        am.add(addr, rows, cols, holder)
+        for j, k in enumerate(keys):
+            assert np.array_equal(np.array(am[j]), ref[k])
+            n += 1
+    assert n == len(want)
+
+
 def test_every_arena_taken_comes_back(tmp_path):
     """The in-place readers account for every arena they take: it is either the holder of exactly one item (the consumer
     recycles it) or handed to ``release`` -- an arena that held only the carried bytes of an oversized record, and the arena of

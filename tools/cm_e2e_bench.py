@@ -1,0 +1,35 @@
+"""ark -> ark through Model.make_embedding on Kaldi's DEFAULT feature format, CompressedMatrix records ("CM ", what
+steps/make_mfcc.sh writes): the in-place reader decodes them natively (xv_ark_decode_cm).  Compares the x-vectors with those of the
+same matrices stored as plain float matrices (must be bit-identical: the decode is Kaldi's arithmetic either way) and times both;
+XVECTOR_NO_HOST_LIB=1 shows the NumPy record-by-record reader.  argv[1] = utterances (default 50000)."""
+import io, logging, os, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "x-vector-kaldi-tf_amd"), os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import kaldi_io, models
+from fixture_inputs import encode_cm_record
+from xvector_amd import synthetic, topology as tp
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+topo = tp.get("ModelWithoutDropout"); w = synthetic.trained_like(topo, 23, seed=1)
+d = tempfile.mkdtemp()
+models.Model.save_model(dict(weights=w, topology=topo, model_class="Model", num_classes=64, feat_dim=23), d, None)
+rng = np.random.default_rng(3)
+pool_cm = [encode_cm_record("k", synthetic.mfcc_like([int(rng.integers(200, 401))], 23, seed=i)[0])[2:] for i in range(200)]
+cm = b"".join(("utt%07d" % i).encode() + b" " + pool_cm[i % 200] for i in range(n))
+# the same matrices, decoded by the generic reader, as plain float matrices
+dec = [m for _, m in kaldi_io.read_mat_ark(io.BytesIO(b"".join(("p%03d" % i).encode() + b" " + pool_cm[i] for i in range(200))))]
+bio = io.BytesIO()
+for i in range(n):
+    kaldi_io.write_mat(bio, dec[i % 200], key="utt%07d" % i)
+fm = bio.getvalue()
+log = logging.getLogger("e2e"); log.setLevel(logging.ERROR)
+outs = {}
+for name, raw in (("FM ", fm), ("CM ", cm)):
+    for rep in range(3):
+        out = io.BytesIO(); t0 = time.time()
+        models.Model().make_embedding(io.BytesIO(raw), out, d, 25, 10000, False, log); dt = time.time() - t0
+        print("%s ark -> ark: %d utts, %.1f MB in, %.3f s -> %.0f utt/s" % (name, n, len(raw) / 1e6, dt, n / dt))
+    outs[name] = out.getvalue()
+print("x-vector arks identical:", outs["FM "] == outs["CM "], len(outs["CM "]))

@@ -19,7 +19,7 @@
 
 extern "C" {
 
-int xv_host_version(void) { return 8; }
+int xv_host_version(void) { return 9; }
 
 // Index pass over an ark FILE of binary float-matrix records without reading the matrices: per record one pread of the header
 // ("<key> \0BFM \4<rows>\4<cols>"), then a hop over rows*cols*4 payload bytes.  This is what lets the ranks of a job split a
@@ -118,6 +118,103 @@ int xv_ark_scan_fm(const uint8_t *buf, size_t pos, size_t len, int max_records, 
     }
     if (n == max_records) *stop = 2;
     *next = pos;
+    return n;
+}
+
+// Kaldi CompressedMatrix records of the speech-feature kind ("<key> \0BCM " + {float min, float range, int32 rows, int32 cols} +
+// cols x {uint16 percentile 0, 25, 75, 100} + cols x rows bytes, COLUMN-major): what steps/make_mfcc.sh writes by default, i.e. what a
+// feats.scp points at when the extractor reads the features itself (its own CMN / VAD front-end) instead of being fed by Kaldi's
+// pipes.  Scans buf[pos, len) for consecutive complete CM records with the column count of the first one, decodes them -- the
+// float32 arithmetic of local/tf/kaldi_io.py:455-502, which is Kaldi's, operation for operation (this file is built with
+// -ffp-contract=off) -- into `out` as row-major float32 matrices, on `nthreads` threads.  out_off[i] = byte offset of matrix i
+// in out.  *stop: 0 buffer exhausted / record incomplete, 1 the next record is not such a record, 2 max_records reached, 3 out is
+// full, 4 the column count changed.
+static inline float cm_u16(float gmin, float grange, uint16_t v) { return gmin + grange * 1.52590218966964e-05f * (float)v; }
+
+static void cm_decode_one(const uint8_t *rec, int rows, int cols, float *out, std::vector<float> &tmp)
+{
+    float gmin, grange;
+    memcpy(&gmin, rec, 4);
+    memcpy(&grange, rec + 4, 4);
+    const uint8_t *hdr = rec + 16;
+    const uint8_t *data = hdr + (size_t)cols * 8;
+    const float step = grange * 1.52590218966964e-05f;            // (evaluated left to right, as NumPy does: (range * step) * pct)
+    // pass 1: column by column as the bytes lie (contiguous loads and stores: the compiler vectorises it); pass 2: transpose
+    if (tmp.size() < (size_t)rows * cols) tmp.resize((size_t)rows * cols);
+    float *t = tmp.data();
+    for (int c = 0; c < cols; ++c) {
+        uint16_t q[4];
+        memcpy(q, hdr + (size_t)c * 8, 8);
+        const float p0 = gmin + step * (float)q[0], p25 = gmin + step * (float)q[1], p75 = gmin + step * (float)q[2],
+                    p100 = gmin + step * (float)q[3];
+        const float a = (p25 - p0) / 64.f, b = (p75 - p25) / 128.f, d = (p100 - p75) / 63.f;
+        const uint8_t *u = data + (size_t)c * rows;
+        float *o = t + (size_t)c * rows;
+        for (int r = 0; r < rows; ++r) {
+            const float uf = (float)u[r];
+            const float lo = p0 + a * uf, mid = p25 + b * (uf - 64.f), hi = p75 + d * (uf - 192.f);
+            o[r] = u[r] <= 64 ? lo : (u[r] <= 192 ? mid : hi);
+        }
+    }
+    for (int r = 0; r < rows; ++r) {
+        float *o = out + (size_t)r * cols;
+        const float *ti = t + r;
+        for (int c = 0; c < cols; ++c) o[c] = ti[(size_t)c * rows];
+    }
+}
+
+int xv_ark_decode_cm(const uint8_t *buf, size_t pos, size_t len, int max_records, uint8_t *out, size_t out_cap, int64_t *key_off,
+                     int32_t *key_len, int64_t *out_off, int32_t *rows, int32_t *cols, size_t *next, int *stop, int nthreads)
+{
+    int n = 0;
+    size_t used = 0;
+    int c0 = -1;
+    *stop = 0;
+    std::vector<const uint8_t *> recs;
+    while (true) {
+        if (n == max_records) { *stop = 2; break; }
+        const uint8_t *sp = (const uint8_t *)memchr(buf + pos, ' ', len - pos);
+        if (!sp) break;
+        const size_t kend = (size_t)(sp - buf);
+        const size_t h = kend + 1;                                 // "\0B" "CM " + 16-byte global header
+        if (h + 21 > len) break;
+        if (buf[h] != 0 || buf[h + 1] != 'B' || buf[h + 2] != 'C' || buf[h + 3] != 'M' || buf[h + 4] != ' ') { *stop = 1; break; }
+        int32_t r, c;
+        memcpy(&r, buf + h + 13, 4);
+        memcpy(&c, buf + h + 17, 4);
+        if (r < 0 || c < 0) { *stop = 1; break; }
+        if (c0 >= 0 && c != c0) { *stop = 4; break; }
+        const size_t d = h + 5;
+        const size_t nbytes = 16 + (size_t)c * 8 + (size_t)r * (size_t)c;
+        if (d + nbytes > len) break;                               // payload incomplete
+        const size_t need = ((size_t)r * (size_t)c * 4 + 63) & ~(size_t)63;
+        if (used + need > out_cap) { *stop = 3; break; }
+        c0 = c;
+        key_off[n] = (int64_t)pos;
+        key_len[n] = (int32_t)(kend - pos);
+        out_off[n] = (int64_t)used;
+        rows[n] = r;
+        cols[n] = c;
+        recs.push_back(buf + d);
+        used += need;
+        ++n;
+        pos = d + nbytes;
+    }
+    *next = pos;
+    if (n > 0) {
+        const int nt = nthreads < 1 ? 1 : (nthreads > n ? n : nthreads);
+        auto work = [&](int t) {
+            std::vector<float> tmp;
+            for (int i = t; i < n; i += nt) cm_decode_one(recs[i], rows[i], cols[i], reinterpret_cast<float *>(out + out_off[i]), tmp);
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+    }
     return n;
 }
 

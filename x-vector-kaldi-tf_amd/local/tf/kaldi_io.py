@@ -656,6 +656,11 @@ def _host_lib():
                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                     ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                                     ctypes.POINTER(ctypes.c_int)]
+                if hasattr(lib, "xv_ark_decode_cm"):
+                    lib.xv_ark_decode_cm.restype = ctypes.c_int
+                    lib.xv_ark_decode_cm.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                                     ctypes.c_size_t] + [ctypes.c_void_p] * 5 + \
+                        [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
                 _HOST_LIB = lib
             except OSError:
                 _HOST_LIB = None
@@ -990,18 +995,30 @@ def scan_mat_ark_mapped(arr, window_bytes, first_bytes=None, fallback=None):
             win = int(window_bytes)
 
 
+_CM_THREADS = max(1, int(os.environ.get("XVECTOR_CM_THREADS", "0")) or min(4, (os.cpu_count() or 2) // 2))    # decoder threads of xv_ark_decode_cm
+
+
+def _cm_record_at(view, pos, end):
+    """True when the record at ``view[pos:end]`` is a binary compressed matrix of the speech-feature kind ("<key> \\0BCM ")."""
+    head = bytes(view[pos:min(end, pos + 4096)])
+    sp = head.find(b" ")
+    return sp >= 0 and head[sp + 1:sp + 6] == b"\0BCM "
+
+
 def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
     """The in-place form of ``read_mat_ark_blocks``: generator of ``(keys, addr[n] uint64, rows[n] int32, cols, holder)``.
     The stream is read (``readinto``) into arenas that ``take_arena()`` hands out (``ArkArena``; the caller recycles them once it
     is done with the window), the native scanner locates the binary float-matrix records, and NOTHING is copied: ``addr[i]``
     is where row 0 of utterance i lies inside ``holder`` (the arena).  One item per arena and column count; the bytes of a
     record cut off by the arena's end are carried to the front of the next arena.  ``first_fill``: bytes to read into the first
-    arena (then doubling): a consumer pipeline starts sooner on a short first window.  Records of any other type are decoded
+    arena (then doubling): a consumer pipeline starts sooner on a short first window.  Compressed speech-feature matrices
+    ("CM ") are decoded by the host library into further arenas (``holder`` = that arena).  Records of any other type are decoded
     by the generic reader and come out one at a time with ``holder`` = their own float32 array.  ``release(arena)``: called for
     an arena that was taken but became the holder of no item (it held nothing but the carried bytes of a record that went
     through the generic reader) -- the consumer never sees such an arena, so it cannot recycle it.  Needs the host library."""
     lib = _host_lib()
     assert lib is not None and hasattr(lib, "xv_ark_scan_fm"), "scan_mat_ark_windows needs libxvector_host.so"
+    has_cm = hasattr(lib, "xv_ark_decode_cm")
     raw = open_or_fd(file_or_fd)
     readinto = getattr(raw, "readinto", None)
     # An in-memory stream is copied by the host library, outside the interpreter lock (BytesIO.readinto holds it for the whole
@@ -1086,8 +1103,34 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
                     i0 = i1
                 pos = nxt.value
                 unread = end - pos
-                if stop.value != 2:
-                    break                                       # 2 = scanner table full: scan on in the same arena
+                if stop.value == 2:
+                    continue                                    # scanner table full: scan on in the same arena
+                if stop.value == 1 and has_cm and _cm_record_at(arena.view, pos, end):
+                    # compressed speech-feature matrices (what make_mfcc.sh writes by default): decoded natively, on a few
+                    # threads, into arenas of their own -- each the holder of one item; this arena keeps only the bytes
+                    item = flush()
+                    if item:
+                        yield item
+                    c_now = None
+                    while True:
+                        darena = take_arena()
+                        n = lib.xv_ark_decode_cm(arena.addr, pos, end, _SCAN_MAX, darena.addr, len(darena), key_off.ctypes.data,
+                                                 key_len.ctypes.data, data_off.ctypes.data, rows.ctypes.data, cols.ctypes.data,
+                                                 ctypes.byref(nxt), ctypes.byref(stop), _CM_THREADS)
+                        if n > 0:
+                            dkeys = _decode_keys(lib, arena.addr, arena.buf, key_off[:n], key_len[:n])
+                            yield dkeys, data_off[:n].astype(np.uint64) + np.uint64(darena.addr), rows[:n].copy(), int(cols[0]), darena
+                        elif release is not None:
+                            release(darena)
+                        pos = nxt.value
+                        unread = end - pos
+                        if stop.value not in (2, 3, 4) or (n == 0 and stop.value == 3):
+                            break                               # (a single matrix larger than an arena: the generic reader takes it)
+                    if stop.value == 3:
+                        stop.value = 1                          # ONE record through the generic reader below
+                    elif stop.value == 1:
+                        continue                                # another record type follows: back to the float-matrix scanner
+                break
             item = flush()
             if item:
                 yield item
