@@ -256,13 +256,14 @@ EMBED_WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("mode", ["file", "pipe", "file_with_a_double_record", "pipe_exchange_every_2_windows"])
+@pytest.mark.parametrize("mode", ["file", "pipe", "file_with_a_double_record", "pipe_exchange_every_2_windows", "file_of_compressed_matrices"])
 def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path, mode):
     """Model.make_embedding under a 2-rank gloo group (stand-in extractor), ONE gather at the very end (however many windows),
     rank 0 alone writes -- exactly the bytes a single process writes (input order restored, rejected utterances dropped).
     * ``pipe``: a stream nobody can split -- every rank reads it and extracts its frame-balanced shard of each window;
     * ``file``: a seekable ark file is split by BYTE RANGES (one header-only index pass per rank, no collective for it): each
       rank reads only its own records' bytes -- together exactly the file, neither of them more than its share;
+    * the same for a file of CompressedMatrix records (Kaldi's default feature format): indexed by their headers, decoded natively;
     * a file holding a record the index pass does not take (a double-precision matrix) falls back to the stream mode;
     * XVECTOR_EXCHANGE_WINDOWS=2: the stream mode exchanges (and rank 0 writes) every two windows instead of once at the end."""
     import kaldi_io
@@ -273,6 +274,10 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path, mode):
     with open(ark, "wb") as f:
         for i, t in enumerate(lens):
             m = rng.standard_normal((t, 5)).astype(np.float32)
+            if mode == "file_of_compressed_matrices" and t > 0:
+                from fixture_inputs import encode_cm_record
+                f.write(encode_cm_record("utt%02d" % i, m))
+                continue
             kaldi_io.write_mat(f, m.astype(np.float64) if (mode == "file_with_a_double_record" and i == 6) else m, key="utt%02d" % i)
     script = tmp_path / "embed_worker.py"
     script.write_text(EMBED_WORKER % (PKG, TWIN, os.path.dirname(PKG)))
@@ -302,7 +307,7 @@ def test_two_rank_gloo_make_embedding_equals_single_process(tmp_path, mode):
     assert list(got) == ["utt%02d" % i for i, t in enumerate(lens) if t >= 10]
     assert got["utt05"][-1] == 200.0
     ranged = [int(o.split("RANGE_BYTES=")[1].split()[0]) for o in outs]
-    if mode == "file":
+    if mode in ("file", "file_of_compressed_matrices"):
         size = os.path.getsize(str(ark))
         assert sum(ranged) == size and 0 < min(ranged) and max(ranged) <= 0.7 * size, (ranged, size)
     else:

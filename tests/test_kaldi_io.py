@@ -458,6 +458,18 @@ def test_compressed_matrices_through_the_in_place_reader(tmp_path):
     assert order == want
     assert all(got[k].dtype == np.float32 and np.array_equal(got[k], ref[k]) for k in want)
     assert sorted(map(id, taken)) == sorted(map(id, held + released)) and len(set(map(id, taken))) == len(taken)
+    # a consumer that recycles every holder at once, from a small pool: an arena that went downstream as the holder of a plain
+    # matrix must not come back as a decode arena while its own tail is still being scanned
+    pool = [kaldi_io.ArkArena(1 << 18) for _ in range(4)]
+    free, again = list(pool), {}
+    for keys, addr, rows, cols, holder in kaldi_io.scan_mat_ark_windows(io.BytesIO(raw), free.pop, 4096, free.append):
+        am = kaldi_io.ArkMats()
+        am.add(addr, rows, cols, holder)
+        for j, k in enumerate(keys):
+            again[k] = np.array(am[j])
+        if isinstance(holder, kaldi_io.ArkArena):
+            free.append(holder)
+    assert list(again) == want and all(np.array_equal(again[k], ref[k]) for k in want) and len(free) == 4
     # the same records behind an scp table
     ark, scp = str(tmp_path / "c.ark"), str(tmp_path / "c.scp")
     lines, pos = [], 0
@@ -558,6 +570,23 @@ def test_header_only_index_of_an_ark_file(tmp_path):
         off2, _, _, keys2 = kaldi_io.index_mat_ark_file(f)                  # from the stream position on
         assert keys2 == keys[150:] and off2[0] == off[150]
         assert kaldi_io.index_mat_ark_file(f, with_keys=False)[3] is None
+    # compressed speech-feature matrices are indexed the same way (their header carries the shape)
+    from fixture_inputs import encode_cm_record
+    cpath = str(tmp_path / "c.ark")
+    cm = [rng.standard_normal((int(rng.integers(1, 300)), 23)).astype(np.float32) for _ in range(60)]
+    with open(cpath, "wb") as f:
+        for i, m in enumerate(cm):
+            if i % 5 == 2:
+                kaldi_io.write_mat(f, m, key="plain%d" % i)
+            else:
+                f.write(encode_cm_record("cm%d" % i, m))
+    with open(cpath, "rb") as f:
+        coff, crows, ccols, ckeys = kaldi_io.index_mat_ark_file(f)
+        assert ckeys == [("plain%d" if i % 5 == 2 else "cm%d") % i for i in range(60)]
+        assert crows.tolist() == [m.shape[0] for m in cm] and set(ccols.tolist()) == {23} and coff[-1] == os.path.getsize(cpath)
+        whole = list(kaldi_io.read_mat_ark(cpath))
+        sub = list(kaldi_io.read_mat_ark(kaldi_io.FileRange(f, coff[13], coff[41])))
+        assert [k for k, _ in sub] == ckeys[13:41] and all(np.array_equal(a, b) for (_, a), (_, b) in zip(sub, whole[13:41]))
     with open(path, "ab") as f:
         kaldi_io.write_mat(f, mats[3].astype(np.float64), key="double")
     with open(path, "rb") as f:

@@ -21,8 +21,8 @@ extern "C" {
 
 int xv_host_version(void) { return 9; }
 
-// Index pass over an ark FILE of binary float-matrix records without reading the matrices: per record one pread of the header
-// ("<key> \0BFM \4<rows>\4<cols>"), then a hop over rows*cols*4 payload bytes.  This is what lets the ranks of a job split a
+// Index pass over an ark FILE of binary float-matrix records (plain "FM " or compressed "CM ") without reading the matrices: per
+// record one pread of the header ("<key> \0BFM \4<rows>\4<cols>" / "<key> \0BCM <min><range><rows><cols>"), then a hop over the payload.  This is what lets the ranks of a job split a
 // seekable ark by BYTE RANGES (local/tf/models.py make_embedding): the format has no sync marks, so record boundaries can only
 // be found from the front -- but finding them costs one small read per record (~1 us), not a parse of the 27 KB behind it.
 // rec_off[i] = offset of record i (its key), rows[i] / cols[i] its shape; keys (optional) receives the keys back to back with
@@ -52,13 +52,26 @@ int64_t xv_ark_index_fd(int fd, int64_t pos, int64_t end, int64_t max_records, i
             got = pread(fd, hdr, sizeof(hdr), (off_t)pos);
             if (got < (ssize_t)(h + 15)) { *stop = 1; break; }
         }
-        if (hdr[h] != 0 || hdr[h + 1] != 'B' || hdr[h + 2] != 'F' || hdr[h + 3] != 'M' || hdr[h + 4] != ' ' || hdr[h + 5] != 4 ||
-            hdr[h + 10] != 4) { *stop = 1; break; }
         int32_t r, c;
-        memcpy(&r, hdr + h + 6, 4);
-        memcpy(&c, hdr + h + 11, 4);
-        if (r < 0 || c < 0) { *stop = 1; break; }
-        const int64_t after = pos + (int64_t)h + 15 + (int64_t)r * (int64_t)c * 4;
+        int64_t after;
+        if (hdr[h] == 0 && hdr[h + 1] == 'B' && hdr[h + 2] == 'C' && hdr[h + 3] == 'M' && hdr[h + 4] == ' ') {
+            // compressed speech-feature matrix: {float min, float range, int32 rows, int32 cols}, cols x 8 header bytes, rows x cols bytes
+            if (h + 21 > (size_t)got) {
+                got = pread(fd, hdr, sizeof(hdr), (off_t)pos);
+                if (got < (ssize_t)(h + 21)) { *stop = 1; break; }
+            }
+            memcpy(&r, hdr + h + 13, 4);
+            memcpy(&c, hdr + h + 17, 4);
+            if (r < 0 || c < 0) { *stop = 1; break; }
+            after = pos + (int64_t)h + 21 + (int64_t)c * 8 + (int64_t)r * (int64_t)c;
+        } else {
+            if (hdr[h] != 0 || hdr[h + 1] != 'B' || hdr[h + 2] != 'F' || hdr[h + 3] != 'M' || hdr[h + 4] != ' ' || hdr[h + 5] != 4 ||
+                hdr[h + 10] != 4) { *stop = 1; break; }
+            memcpy(&r, hdr + h + 6, 4);
+            memcpy(&c, hdr + h + 11, 4);
+            if (r < 0 || c < 0) { *stop = 1; break; }
+            after = pos + (int64_t)h + 15 + (int64_t)r * (int64_t)c * 4;
+        }
         if (after > end) { *stop = 1; break; }                     // truncated payload
         if (keys) {
             if (kw + (int64_t)klen + 1 > keys_cap) { *stop = 2; break; }

@@ -1112,18 +1112,23 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
                     if item:
                         yield item
                     c_now = None
+                    if handed[0]:
+                        # this arena already went downstream as the holder of an item and may come back from take_arena() below
+                        # while its tail is still needed: the tail goes to the front of the next arena instead
+                        stop.value = 0
+                        break
                     while True:
                         darena = take_arena()
                         n = lib.xv_ark_decode_cm(arena.addr, pos, end, _SCAN_MAX, darena.addr, len(darena), key_off.ctypes.data,
                                                  key_len.ctypes.data, data_off.ctypes.data, rows.ctypes.data, cols.ctypes.data,
                                                  ctypes.byref(nxt), ctypes.byref(stop), _CM_THREADS)
+                        pos = nxt.value
+                        unread = end - pos
                         if n > 0:
                             dkeys = _decode_keys(lib, arena.addr, arena.buf, key_off[:n], key_len[:n])
                             yield dkeys, data_off[:n].astype(np.uint64) + np.uint64(darena.addr), rows[:n].copy(), int(cols[0]), darena
                         elif release is not None:
                             release(darena)
-                        pos = nxt.value
-                        unread = end - pos
                         if stop.value not in (2, 3, 4) or (n == 0 and stop.value == 3):
                             break                               # (a single matrix larger than an arena: the generic reader takes it)
                     if stop.value == 3:
