@@ -494,6 +494,41 @@ def test_compressed_matrices_through_the_in_place_reader(tmp_path):
     assert n == len(want)
 
 
+def test_subset_scp_tables_are_read_in_place(tmp_path):
+    """A feats.scp that lists a SUBSET of its ark, in the ark's order (utterances removed by a filter -- the usual state of a Kaldi
+    data directory): the in-place reader skips the records the table leaves out instead of giving up at the first gap and reading
+    entry by entry.  Same matrices as the record-by-record reader; nearly all of them come out of arenas; a sparse table (one entry
+    in ten) and a table in another order than its ark still read correctly (entry by entry)."""
+    if kaldi_io._host_lib() is None:
+        pytest.skip("host library not built")
+    rng = np.random.default_rng(21)
+    mats = [rng.standard_normal((int(rng.integers(1, 60)), 13)).astype(np.float32) for _ in range(600)]
+    ark, scp = str(tmp_path / "f.ark"), str(tmp_path / "f.scp")
+    with kaldi_io.TableWriter(ark, scp) as tw:
+        for i, m in enumerate(mats):
+            kaldi_io.write_mat(tw, m, key="utt%04d" % i)
+    lines = open(scp).read().splitlines()
+
+    def read(sel):
+        p = str(tmp_path / "sel.scp")
+        open(p, "wt").write("\n".join(sel) + "\n")
+        out, in_place = [], 0
+        for keys, addr, rows, cols, holder in kaldi_io.MatScp(p).windows(lambda: kaldi_io.ArkArena(1 << 16), None, lambda a: None):
+            am = kaldi_io.ArkMats()
+            am.add(addr, rows, cols, holder)
+            out += [(k, np.array(am[j])) for j, k in enumerate(keys)]
+            in_place += len(keys) if isinstance(holder, (kaldi_io.ArkArena, list)) else 0
+        return out, in_place
+    for name, sel in (("90 %", [l for l in lines if rng.random() < 0.9]), ("50 %", [l for l in lines if rng.random() < 0.5]),
+                      ("one in ten", lines[::10]), ("reversed", lines[::-1][:80])):
+        got, in_place = read(sel)
+        idx = [int(l.split()[0][3:]) for l in sel]
+        assert [k for k, _ in got] == [l.split()[0] for l in sel], name
+        assert all(np.array_equal(a, mats[i]) for (_, a), i in zip(got, idx)), name
+        if name in ("90 %", "50 %"):
+            assert in_place >= 0.9 * len(sel), (name, in_place, len(sel))
+
+
 def test_every_arena_taken_comes_back(tmp_path):
     """The in-place readers account for every arena they take: it is either the holder of exactly one item (the consumer
     recycles it) or handed to ``release`` -- an arena that held only the carried bytes of an oversized record, and the arena of

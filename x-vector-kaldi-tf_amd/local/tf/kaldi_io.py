@@ -1386,7 +1386,9 @@ class MatScp(_ScpTable):
 
     def windows(self, take_arena, first_fill=None, release=None):
         """``scan_mat_ark_windows`` over the table: runs of entries that follow their ark are read in place, every key is
-        checked against the table; entries that do not (subsets, shuffled lists, pipes) are read one by one.  ``release(arena)``
+        checked against the table, records of the ark that the table does not list are skipped (a subset table costs the bytes
+        of the records it leaves out, not a seek per gap); entries that do not follow their ark (shuffled lists, pipes) are read
+        one by one.  ``release(arena)``
         takes back an arena none of whose records matched the table (the consumer never sees it).  Once two runs in a row ended
         after a handful of records the table is taken not to follow its arks and is read entry by entry from there on -- a
         table that alternates between matching and renamed keys would otherwise read a full arena per miss."""
@@ -1419,17 +1421,26 @@ class MatScp(_ScpTable):
                         # ``start`` is a guess (the entry's offset minus the length of the TABLE's key): with a renamed key it
                         # points into the previous record and the scanner reads garbage -- a miss, not an error
                         break
-                    want = [k for k, _ in ents[i:min(i + len(bkeys), run)]]
-                    same = 0
-                    while same < len(want) and bkeys[same] == want[same]:
-                        same += 1
-                    if same:
-                        yield bkeys[:same], addr[:same], rows[:same], cols, holder
-                        i += same
-                        got += same
+                    # the table's entries of this ark, in order, against the records as they lie: records the table does not
+                    # list (a subset table: utterances removed by a filter) are skipped, not a reason to stop
+                    take, nxt_i = [], i
+                    for j, k in enumerate(bkeys):
+                        if nxt_i < run and k == ents[nxt_i][0]:
+                            take.append(j)
+                            nxt_i += 1
+                    if len(take) == len(bkeys):
+                        yield bkeys, addr, rows, cols, holder
+                    elif take:
+                        idx = np.asarray(take)
+                        yield [bkeys[j] for j in take], addr[idx], rows[idx], cols, \
+                            ([holder[j] for j in take] if isinstance(holder, list) else holder)
                     elif release is not None and isinstance(holder, ArkArena):
                         release(holder)                                                # nothing of it goes downstream
-                    if same < len(bkeys) or i >= run:
+                    i = nxt_i
+                    got += len(take)
+                    if len(take) * 4 < len(bkeys) or i >= run:
+                        # mostly records nobody asked for: a sparse table is read entry by entry from here on
+                        tripped = tripped or (len(bkeys) >= 16 and i < run)
                         break
                 source.close()
             misses = misses + 1 if got < 4 and i < run else 0
