@@ -527,6 +527,9 @@ def test_subset_scp_tables_are_read_in_place(tmp_path):
         assert all(np.array_equal(a, mats[i]) for (_, a), i in zip(got, idx)), name
         if name in ("90 %", "50 %"):
             assert in_place >= 0.9 * len(sel), (name, in_place, len(sel))
+        # the block form (what a vad.scp restricted to the features' keys goes through)
+        blk = [(k, v[int(o[j]):int(o[j + 1])]) for ks, v, o in kaldi_io.MatScp(str(tmp_path / "sel.scp")).blocks() for j, k in enumerate(ks)]
+        assert [k for k, _ in blk] == [l.split()[0] for l in sel] and all(np.array_equal(a, mats[i]) for (_, a), i in zip(blk, idx)), name
 
 
 def test_every_arena_taken_comes_back(tmp_path):

@@ -1362,18 +1362,27 @@ class _ScpTable(object):
             with open(path, "rb") as f:
                 f.seek(start)
                 for bkeys, feats, off in type(self)._ark_blocks(f, alloc):
-                    want = [k for k, _ in ents[i:min(i + len(bkeys), run)]]
-                    same = 0
-                    while same < len(want) and bkeys[same] == want[same]:
-                        same += 1
-                    if same:
+                    # entries of the table against the records as they lie; records the table leaves out are skipped
+                    take, nxt_i = [], i
+                    for j, k in enumerate(bkeys):
+                        if nxt_i < run and k == ents[nxt_i][0]:
+                            take.append(j)
+                            nxt_i += 1
+                    if take and take[-1] == len(take) - 1:                             # a prefix of the block: views
+                        same = len(take)
                         yield bkeys[:same], feats[:int(off[same])], off[:same + 1]
-                        i += same
-                        got += same
-                    if same < len(bkeys) or i >= run:
+                    elif take:
+                        lens = np.array([int(off[j + 1] - off[j]) for j in take], np.int64)
+                        sel = np.concatenate([feats[int(off[j]):int(off[j + 1])] for j in take]) if int(lens.sum()) else feats[:0]
+                        yield [bkeys[j] for j in take], sel, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                    i = nxt_i
+                    got += len(take)
+                    if len(take) * 4 < len(bkeys) or i >= run:
+                        if len(bkeys) >= 16 and i < run:
+                            misses = 2                                                 # a sparse table: entry by entry from here on
                         break
             # a run that ended after a handful of records means the table does not follow the ark: stop re-seeking for it
-            misses = misses + 1 if got < 4 and i < run else 0
+            misses = max(misses, 2) if misses >= 2 else (misses + 1 if got < 4 and i < run else 0)
             if got == 0:                                                               # not even the first key matched
                 mat = self._one(rx)
                 yield [key], mat, np.array([0, mat.shape[0]], np.int64)
