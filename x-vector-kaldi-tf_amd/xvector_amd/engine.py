@@ -241,9 +241,9 @@ class DeviceModel(object):
             precision = "bf16x3"
             ks, ds = list(topo["kernel_sizes"]), list(topo["dilations"])
             w0 = weights["frame_level_info_layer-0/w:0"]
-            self.f16bf8 = (not tp.is_attention(topo) and fused_pool in (None, True) and len(ks) >= 3 and
-                           os.environ.get("XVECTOR_FIRST_KERNEL", "1") != "0" and
-                           hiplib.first_supported(ks[0], (w0.shape[1] + 7) // 8 * 8, w0.shape[2]) and (ks[0] - 1) * ds[0] <= 8 and
+            # (layer 0 stays in bf16x3: on the first-layer kernel where its shape fits -- K * ceil8(Cin) <= 128 --, else on the
+            # general kernel + one encoding pass, e.g. 30-dimensional MFCCs with K = 5)
+            self.f16bf8 = (not tp.is_attention(topo) and fused_pool in (None, True) and len(ks) >= 3 and (ks[0] - 1) * ds[0] <= 8 and
                            all(hiplib.f16bf8_supported(k, d) for k, d in zip(ks[1:], ds[1:])))
         self.precision = precision
         self._weights = weights if self.f16bf8 else None
@@ -322,7 +322,8 @@ class DeviceModel(object):
                     self.pair8 = hiplib.pack_pair_f16bf8(self._wdev(weights, "frame_level_info_layer-%d/w:0" % (n - 2))[0],
                                                          self._wdev(weights, "frame_level_info_layer-%d/w:0" % (n - 1))[0])
             if self.f16bf8:
-                assert self.first is not None
+                if self.first is None:
+                    self.layers[0]["wp"]                          # (deferred above: this model does use layer 0's bf16x3 packing)
                 n = len(self.layers)
                 for i in range(1, n - 2 if self.pair is not None else n):
                     sc = "frame_level_info_layer-%d" % i
@@ -409,6 +410,8 @@ class DeviceModel(object):
             else:
                 self._ping = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
                 self._pong = torch.empty((self._cap_rows, wmax), dtype=torch.float32, device=self.device)
+            if self.f16bf8 and self.first is None:
+                self._l0_rows = torch.empty((self._cap_rows, self.layers[0]["cout"]), dtype=torch.float32, device=self.device)
             if self.fused_pool:
                 self._last = torch.empty(hiplib.block_stats_floats(self._cap_rows, self.layers[-1]["cout"]), dtype=torch.float32,
                                          device=self.device)
@@ -518,8 +521,15 @@ class DeviceModel(object):
         pair_fmt = S8 if self.pair8 is not None else S3         # what the pair kernel in use reads
         h = bufs[0].view(L["cout"], pair_fmt if (self.pair is not None and stop == 1) else S8)
         mark("start")
-        hiplib.tdnn_first(x, R, self.first, L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, h, status)
-        mark("layer 0: tdnn_first_kernel (bf16x3)")
+        if self.first is not None:
+            hiplib.tdnn_first(x, R, self.first, L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["dil"], row_valid, h, status)
+            mark("layer 0: tdnn_first_kernel (bf16x3)")
+        else:
+            # a first layer the dedicated kernel does not take: the general bf16x3 GEMM into fp32 rows, then one encoding pass
+            y32 = self._l0_rows[:R]
+            hiplib.tdnn_layer(x, L["wp"], L["bias"], L["scale"], L["shift"], self.act, L["alpha"], L["K"], L["dil"], row_valid, y32, rows=R)
+            hiplib.split_encode(y32, h, rows=R, status=status if h.fmt == S8 else None)
+            mark("layer 0: tdnn_gemm_bf16x3_kernel + split encode")
         for i in range(1, stop):
             L = self.layers[i]
             y = bufs[i & 1].view(L["cout"], pair_fmt if (self.pair is not None and i == stop - 1) else S8)
