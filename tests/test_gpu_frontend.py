@@ -167,3 +167,58 @@ def test_device_front_end_path_equals_host_round_trip(tmp_path):
         for i in range(len(mats)):
             if i not in keep:
                 assert got[i] is None
+
+
+def test_cli_on_a_kaldi_shaped_data_directory(env, tmp_path):
+    """What a Kaldi data directory really holds: COMPRESSED feature matrices (make_mfcc.sh's default) spread over several arks, a
+    feats.scp that lists a subset of them (utterances removed by a filter), a vad.scp over ALL utterances.  The CLI with the device
+    front-end reads it through the native paths (xv_ark_decode_cm, gap-tolerant tables) and writes byte for byte the x-vector ark it
+    writes for the same matrices stored as plain float matrices in one ark with exactly matching tables."""
+    import kaldi_io
+    import models
+    import extract_embedding as ee
+    from fixture_inputs import encode_cm_record
+    from xvector_amd import synthetic
+    topo = synthetic.SMALL_TOPOLOGY
+    w = synthetic.trained_like(topo, 23, num_classes=8, seed=12)
+    mdir = str(tmp_path / "nnet")
+    models.Model.save_model(dict(weights=w, topology=topo, model_class="Model", num_classes=8, feat_dim=23), mdir, None)
+    rng = np.random.default_rng(2)
+    n = 240
+    keys = ["spk%02d-utt%04d" % (i % 7, i) for i in range(n)]
+    recs = [encode_cm_record(k, (rng.standard_normal((int(rng.integers(30, 400)), 23)) * 3 + 2).astype(np.float32)) for k in keys]
+    mats = [m for _, m in kaldi_io.read_mat_ark(__import__("io").BytesIO(b"".join(recs)))]       # what the compressed bytes decode to
+    vads = [(rng.random(m.shape[0]) < 0.8).astype(np.float32) for m in mats]
+    # (a) the Kaldi-shaped directory: three compressed arks, scp offsets, 85 % of the utterances listed; vad.scp lists all
+    lines = []
+    for part in range(3):
+        path = str(tmp_path / ("raw_mfcc.%d.ark" % (part + 1)))
+        with open(path, "wb") as f:
+            for i in range(part * 80, (part + 1) * 80):
+                lines.append("%s %s:%d" % (keys[i], path, f.tell() + len(keys[i]) + 1))
+                f.write(recs[i])
+    keep = [i for i in range(n) if rng.random() < 0.85]
+    feats_scp = str(tmp_path / "feats.scp")
+    open(feats_scp, "wt").write("\n".join(lines[i] for i in keep) + "\n")
+    vad_ark, vad_scp = str(tmp_path / "vad.ark"), str(tmp_path / "vad.scp")
+    with kaldi_io.TableWriter(vad_ark, vad_scp) as tw:
+        for k, v in zip(keys, vads):
+            kaldi_io.write_vec_flt(tw, v, key=k)
+    # (b) the same utterances as plain float matrices in one ark, tables that list exactly them
+    pf_ark, pf_scp = str(tmp_path / "plain.ark"), str(tmp_path / "plain.scp")
+    with kaldi_io.TableWriter(pf_ark, pf_scp) as tw:
+        for i in keep:
+            kaldi_io.write_mat(tw, mats[i], key=keys[i])
+    pv_ark, pv_scp = str(tmp_path / "pvad.ark"), str(tmp_path / "pvad.scp")
+    with kaldi_io.TableWriter(pv_ark, pv_scp) as tw:
+        for i in keep:
+            kaldi_io.write_vec_flt(tw, vads[i], key=keys[i])
+    out = {}
+    for tag, fs, vs in (("kaldi", feats_scp, vad_scp), ("plain", pf_scp, pv_scp)):
+        ark = str(tmp_path / (tag + "_xvector.ark"))
+        ee.main(["--min-chunk-size", "25", "--chunk-size", "300", "--feature-rspecifier", "scp:" + fs, "--vector-wspecifier", "ark:" + ark,
+                 "--model-dir", mdir, "--cmn-window", "300", "--vad-rspecifier", "scp:" + vs])
+        out[tag] = open(ark, "rb").read()
+    assert len(out["plain"]) > 1000 and out["kaldi"] == out["plain"]
+    got = [k for k, _ in kaldi_io.read_vec_flt_ark(__import__("io").BytesIO(out["kaldi"]))]
+    assert got == [keys[i] for i in keep if vads[i].sum() >= 25]
