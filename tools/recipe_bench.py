@@ -1,6 +1,7 @@
 """Development aid: file -> ark rate of Model.make_embedding in the recipe's mode (raw feats.scp + vad.scp + sliding CMN on the
 device) with block tables (kaldi_io.MatScp / VecScp) and with the per-entry scp generators; checks that all runs write the same
-bytes.  Usage: python tools/recipe_bench.py [n_utts]"""
+bytes.  Then the same on a Kaldi-shaped directory: COMPRESSED feature matrices, a feats.scp that lists 90 % of them, the vad.scp all.
+Usage: python tools/recipe_bench.py [n_utts]"""
 import io, logging, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "x-vector-kaldi-tf_amd"), os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf")):
@@ -31,3 +32,25 @@ for name, mf, mv in (("warm", lambda: kaldi_io.MatScp(d + "/f.scp"), lambda: kal
     print("%-32s %d utts in %.3f s -> %.0f utt/s" % (name, n, dt, n / dt))
 assert len(set(outs.values())) == 1, "outputs differ"
 print("all outputs identical:", len(outs["warm"]), "bytes")
+
+# ---- the shape of a real Kaldi data directory: compressed features, a subset feats.scp, vad.scp over everything ----
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fixture_inputs import encode_cm_record
+pool = [encode_cm_record("k", synthetic.mfcc_like([int(rng.integers(200, 401))], 23, seed=i)[0])[2:] for i in range(200)]
+plen = [m.shape[0] for _, m in kaldi_io.read_mat_ark(io.BytesIO(b"".join(("p%03d" % i).encode() + b" " + pool[i] for i in range(200))))]
+lines = []
+with open(d + "/c.ark", "wb") as f, kaldi_io.TableWriter(d + "/cv.ark", d + "/cv.scp") as tv:
+    for i in range(n):
+        key = "utt%07d" % i
+        lines.append("%s %s:%d" % (key, d + "/c.ark", f.tell() + len(key) + 1))
+        f.write(key.encode() + b" " + pool[i % 200])
+        kaldi_io.write_vec_flt(tv, (rng.random(plen[i % 200]) < 0.8).astype(np.float32), key=key)
+keep = [l for l in lines if rng.random() < 0.9]
+open(d + "/c.scp", "wt").write("\n".join(keep) + "\n")
+for rep in range(3):
+    out = io.BytesIO()
+    t0 = time.perf_counter()
+    models.Model().make_embedding(kaldi_io.MatScp(d + "/c.scp"), out, mdir, 25, 10000, True, log, vad_stream=kaldi_io.VecScp(d + "/cv.scp"),
+                                  cmn_window=300, cmn_center=True)
+    dt = time.perf_counter() - t0
+    print("%-32s %d utts in %.3f s -> %.0f utt/s" % ("compressed, 90 % subset table", len(keep), dt, len(keep) / dt))
