@@ -57,13 +57,15 @@ def test_compressed_matrix_decodes_like_reference(g):
 
 
 def test_compressed_cm2_cm3():
+    """The two-byte / one-byte forms Kaldi's automatic method picks for matrices of at most 8 rows.  Tokens carry Kaldi's trailing space
+    ("CM2 ", compressed-matrix.cc CompressedMatrix::Write -> WriteToken); the reference reader asserts 'CM ' and knows neither."""
     rows, cols = 3, 5
     hdr = np.array([-1.0, 2.0], "<f4").tobytes() + np.array([rows, cols], "<i4").tobytes()
     u16 = np.arange(rows * cols, dtype="<u2").reshape(rows, cols) * 4000
-    m2 = kaldi_io.read_mat(io.BytesIO(b"\x00BCM2" + hdr + u16.tobytes()))
+    m2 = kaldi_io.read_mat(io.BytesIO(b"\x00BCM2 " + hdr + u16.tobytes()))
     assert np.allclose(m2, -1.0 + 2.0 * u16 / 65535.0, atol=1e-6) and m2.shape == (rows, cols)
     u8 = (np.arange(rows * cols, dtype=np.uint8).reshape(rows, cols) * 17)
-    m3 = kaldi_io.read_mat(io.BytesIO(b"\x00BCM3" + hdr + u8.tobytes()))
+    m3 = kaldi_io.read_mat(io.BytesIO(b"\x00BCM3 " + hdr + u8.tobytes()))
     assert np.allclose(m3, -1.0 + 2.0 * u8 / 255.0, atol=1e-6)
 
 
@@ -435,6 +437,11 @@ def test_compressed_matrices_through_the_in_place_reader(tmp_path):
         m = (rng.standard_normal((t, f)) * (1 + i % 4) + (i % 3)).astype(np.float32)
         if i % 9 == 4:
             kaldi_io.write_mat(bio, m, key="plain%03d" % i)
+        elif i % 31 == 5:                                          # the two-byte / one-byte forms (Kaldi: matrices of <= 8 rows)
+            import struct
+            two = i % 2 == 0
+            u = rng.integers(0, 65536 if two else 256, size=m.shape).astype("<u2" if two else np.uint8)
+            bio.write(("utt%03d" % i).encode() + (b" \0BCM2 " if two else b" \0BCM3 ") + struct.pack("<ffii", -3.0, 7.5, t, f) + u.tobytes())
         else:
             bio.write(encode_cm_record("utt%03d" % i, m))
         want.append(("plain%03d" % i) if i % 9 == 4 else ("utt%03d" % i))

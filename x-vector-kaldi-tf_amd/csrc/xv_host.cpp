@@ -54,16 +54,21 @@ int64_t xv_ark_index_fd(int fd, int64_t pos, int64_t end, int64_t max_records, i
         }
         int32_t r, c;
         int64_t after;
-        if (hdr[h] == 0 && hdr[h + 1] == 'B' && hdr[h + 2] == 'C' && hdr[h + 3] == 'M' && hdr[h + 4] == ' ') {
-            // compressed speech-feature matrix: {float min, float range, int32 rows, int32 cols}, cols x 8 header bytes, rows x cols bytes
-            if (h + 21 > (size_t)got) {
+        if (hdr[h] == 0 && hdr[h + 1] == 'B' && hdr[h + 2] == 'C' && hdr[h + 3] == 'M' &&
+            (hdr[h + 4] == ' ' || ((hdr[h + 4] == '2' || hdr[h + 4] == '3') && hdr[h + 5] == ' '))) {
+            // compressed matrix: {float min, float range, int32 rows, int32 cols}, then "CM ": cols x 8 header bytes + rows x cols
+            // bytes; "CM2" / "CM3": rows x cols uint16 / uint8
+            const int kind = hdr[h + 4] == ' ' ? 1 : hdr[h + 4] - '0';
+            const size_t tag = kind == 1 ? 5 : 6;
+            if (h + tag + 16 > (size_t)got) {
                 got = pread(fd, hdr, sizeof(hdr), (off_t)pos);
-                if (got < (ssize_t)(h + 21)) { *stop = 1; break; }
+                if (got < (ssize_t)(h + tag + 16)) { *stop = 1; break; }
             }
-            memcpy(&r, hdr + h + 13, 4);
-            memcpy(&c, hdr + h + 17, 4);
+            memcpy(&r, hdr + h + tag + 8, 4);
+            memcpy(&c, hdr + h + tag + 12, 4);
             if (r < 0 || c < 0) { *stop = 1; break; }
-            after = pos + (int64_t)h + 21 + (int64_t)c * 8 + (int64_t)r * (int64_t)c;
+            after = pos + (int64_t)h + (int64_t)tag + 16 +
+                    (kind == 1 ? (int64_t)c * 8 + (int64_t)r * (int64_t)c : (int64_t)r * (int64_t)c * (kind == 2 ? 2 : 1));
         } else {
             if (hdr[h] != 0 || hdr[h + 1] != 'B' || hdr[h + 2] != 'F' || hdr[h + 3] != 'M' || hdr[h + 4] != ' ' || hdr[h + 5] != 4 ||
                 hdr[h + 10] != 4) { *stop = 1; break; }
@@ -144,11 +149,29 @@ int xv_ark_scan_fm(const uint8_t *buf, size_t pos, size_t len, int max_records, 
 // full, 4 the column count changed.
 static inline float cm_u16(float gmin, float grange, uint16_t v) { return gmin + grange * 1.52590218966964e-05f * (float)v; }
 
-static void cm_decode_one(const uint8_t *rec, int rows, int cols, float *out, std::vector<float> &tmp)
+static void cm_decode_one(const uint8_t *rec, int rows, int cols, float *out, std::vector<float> &tmp, int kind)
 {
     float gmin, grange;
     memcpy(&gmin, rec, 4);
     memcpy(&grange, rec + 4, 4);
+    if (kind != 1) {
+        // "CM2" (row-major uint16) / "CM3" (row-major uint8): what Kaldi's automatic method writes for matrices of <= 8 rows
+        const size_t n = (size_t)rows * cols;
+        if (kind == 2) {
+            const float step2 = grange * 1.52590218966964e-05f;
+            const uint8_t *d = rec + 16;
+            for (size_t i = 0; i < n; ++i) {
+                uint16_t v;
+                memcpy(&v, d + 2 * i, 2);
+                out[i] = gmin + step2 * (float)v;
+            }
+        } else {
+            const float step3 = grange * (float)(1.0 / 255.0);
+            const uint8_t *d = rec + 16;
+            for (size_t i = 0; i < n; ++i) out[i] = gmin + step3 * (float)d[i];
+        }
+        return;
+    }
     const uint8_t *hdr = rec + 16;
     const uint8_t *data = hdr + (size_t)cols * 8;
     const float step = grange * 1.52590218966964e-05f;            // (evaluated left to right, as NumPy does: (range * step) * pct)
@@ -184,6 +207,7 @@ int xv_ark_decode_cm(const uint8_t *buf, size_t pos, size_t len, int max_records
     int c0 = -1;
     *stop = 0;
     std::vector<const uint8_t *> recs;
+    std::vector<int> kinds;
     while (true) {
         if (n == max_records) { *stop = 2; break; }
         const uint8_t *sp = (const uint8_t *)memchr(buf + pos, ' ', len - pos);
@@ -191,14 +215,18 @@ int xv_ark_decode_cm(const uint8_t *buf, size_t pos, size_t len, int max_records
         const size_t kend = (size_t)(sp - buf);
         const size_t h = kend + 1;                                 // "\0B" "CM " + 16-byte global header
         if (h + 21 > len) break;
-        if (buf[h] != 0 || buf[h + 1] != 'B' || buf[h + 2] != 'C' || buf[h + 3] != 'M' || buf[h + 4] != ' ') { *stop = 1; break; }
+        if (buf[h] != 0 || buf[h + 1] != 'B' || buf[h + 2] != 'C' || buf[h + 3] != 'M' ||
+            (buf[h + 4] != ' ' && buf[h + 4] != '2' && buf[h + 4] != '3') || (buf[h + 4] != ' ' && buf[h + 5] != ' ')) { *stop = 1; break; }
+        const int kind = buf[h + 4] == ' ' ? 1 : buf[h + 4] - '0';                // "CM " | "CM2 " | "CM3 "
+        const size_t tag = kind == 1 ? 5 : 6;
+        if (h + tag + 16 > len) break;
         int32_t r, c;
-        memcpy(&r, buf + h + 13, 4);
-        memcpy(&c, buf + h + 17, 4);
+        memcpy(&r, buf + h + tag + 8, 4);
+        memcpy(&c, buf + h + tag + 12, 4);
         if (r < 0 || c < 0) { *stop = 1; break; }
         if (c0 >= 0 && c != c0) { *stop = 4; break; }
-        const size_t d = h + 5;
-        const size_t nbytes = 16 + (size_t)c * 8 + (size_t)r * (size_t)c;
+        const size_t d = h + tag;
+        const size_t nbytes = 16 + (kind == 1 ? (size_t)c * 8 + (size_t)r * (size_t)c : (size_t)r * (size_t)c * (kind == 2 ? 2 : 1));
         if (d + nbytes > len) break;                               // payload incomplete
         const size_t need = ((size_t)r * (size_t)c * 4 + 63) & ~(size_t)63;
         if (used + need > out_cap) { *stop = 3; break; }
@@ -209,6 +237,7 @@ int xv_ark_decode_cm(const uint8_t *buf, size_t pos, size_t len, int max_records
         rows[n] = r;
         cols[n] = c;
         recs.push_back(buf + d);
+        kinds.push_back(kind);
         used += need;
         ++n;
         pos = d + nbytes;
@@ -218,7 +247,7 @@ int xv_ark_decode_cm(const uint8_t *buf, size_t pos, size_t len, int max_records
         const int nt = nthreads < 1 ? 1 : (nthreads > n ? n : nthreads);
         auto work = [&](int t) {
             std::vector<float> tmp;
-            for (int i = t; i < n; i += nt) cm_decode_one(recs[i], rows[i], cols[i], reinterpret_cast<float *>(out + out_off[i]), tmp);
+            for (int i = t; i < n; i += nt) cm_decode_one(recs[i], rows[i], cols[i], reinterpret_cast<float *>(out + out_off[i]), tmp, kinds[i]);
         };
         if (nt == 1) work(0);
         else {

@@ -548,6 +548,10 @@ def _read_compressed_mat(fd, fmt):
     """Kaldi CompressedMatrix.  'CM ' = per-column percentile headers + column-major uint8 with a
     3-segment piecewise-linear decode; 'CM2' = row-major uint16; 'CM3' = row-major uint8.
     All arithmetic in float32, as Kaldi (and the reference under NumPy>=2) evaluates it."""
+    if fmt != "CM ":
+        # Kaldi writes every token with a trailing space (WriteToken): "CM " is complete in three bytes, "CM2" / "CM3" are not
+        if _read_exact(fd, 1) != b" ":
+            raise UnknownMatrixHeader("The header contained '%s' without the separating space" % fmt)
     hdr = _read_exact(fd, 16)
     gmin, grange = np.frombuffer(hdr[:8], dtype="<f4")
     rows, cols = (int(v) for v in np.frombuffer(hdr[8:], dtype="<i4"))
@@ -1002,7 +1006,7 @@ def _cm_record_at(view, pos, end):
     """True when the record at ``view[pos:end]`` is a binary compressed matrix of the speech-feature kind ("<key> \\0BCM ")."""
     head = bytes(view[pos:min(end, pos + 4096)])
     sp = head.find(b" ")
-    return sp >= 0 and head[sp + 1:sp + 6] == b"\0BCM "
+    return sp >= 0 and (head[sp + 1:sp + 6] == b"\0BCM " or head[sp + 1:sp + 7] in (b"\0BCM2 ", b"\0BCM3 "))
 
 
 def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
