@@ -38,7 +38,18 @@ def trainable_names(topo):
     return names + ["output/w:0", "output/b:0"]
 
 
+# Every activation here has a kink at z = 0.  A float32 implementation whose pre-activation differs from the float64 one by its rounding
+# error (~1e-6 of the layer's rms) can land on the other side of it, and ONE such element changes a layer's gradients by 1 / sqrt(elements)
+# (3e-3 for 8 x 156 x 88) -- a property of the comparison, not an error of either side.  ``kink_margin`` lets a test tell: the smallest
+# |z| / rms(z) over the activation sites of the last forward() call.
+kink_margin = [float("inf")]
+
+
 def _act(z, topo, alpha):
+    with torch.no_grad():
+        rms = float((z * z).mean().sqrt())
+        if rms > 0:
+            kink_margin[0] = min(kink_margin[0], float(z.abs().min()) / rms)
     a = topo.get("activation", "relu")
     if a == "relu":
         return F.relu(z)
@@ -53,6 +64,7 @@ def forward(params, stats, topo, x, labels, train, dropout=None):
     tf.nn.dropout sites of class Model (models.py:70-72, 92-94: after BN of every layer but the last of its group), with
     the mask handed in (TF's random stream cannot be reproduced; the GPU build uses a counter-based mask)."""
     new_stats = {}
+    kink_margin[0] = float("inf")
 
     def drop(h, scope):
         if not (train and dropout and scope in dropout):

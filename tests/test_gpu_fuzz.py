@@ -131,7 +131,11 @@ def test_random_topologies_in_the_f16bf8_arithmetic(oracle_mod, seed):
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_topologies_gradients_match_autograd(seed):
     """The training step (fp32 kernels) on random topologies -- widths, kernel sizes, dilations, activation, pooling kind,
-    L2 term, dropout-free -- against the float64 autograd oracle: loss 1e-5, every gradient tensor 5e-4 relative L2."""
+    L2 term, dropout-free -- against the float64 autograd oracle: loss 1e-5, every gradient tensor 5e-4 relative L2 (relative to
+    its own norm, or to a tenth of the median tensor norm where a gradient is zero by construction -- a shift in front of a batch
+    normalisation -- and float32 leaves 1e-5 of the terms that cancel).  A failure message carries the oracle's kink margin: a pre-activation within float32 rounding (~1e-6 rms) of
+    the activation's kink may fall on the other side of it on the GPU, which moves every gradient below it by 1 / sqrt(elements)
+    (oracle/train_ref.py: kink_margin; tools/fuzz_many.py reports such cases apart)."""
     from oracle import train_ref
     from xvector_amd import hiplib, synthetic, trainer
     hiplib.require_gpu()
@@ -153,8 +157,9 @@ def test_random_topologies_gradients_match_autograd(seed):
         rl, ra, _, _, rg = train_ref.train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3)
         assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)), (case, topo)
         bad = {}
+        floor = 0.1 * float(np.median([np.linalg.norm(ref) for ref in rg.values()]))
         for n, ref in rg.items():
-            e = float(np.linalg.norm(grads[n].cpu().numpy().astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30))
+            e = float(np.linalg.norm(grads[n].cpu().numpy().astype(np.float64) - ref) / max(np.linalg.norm(ref), floor))
             if e > 5e-4:
                 bad[n] = e
-        assert not bad, (case, topo, bad)
+        assert not bad, ("kink margin %.1e" % train_ref.kink_margin[0], case, topo, bad)
