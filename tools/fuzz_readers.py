@@ -97,10 +97,17 @@ def scp_main(argv):
         lim = None if rng.random() < 0.5 else int(rng.choice([1, 5, 100]))
         out = []
         try:
-            for keys, addr, rows, cols, holder in kaldi_io.MatScp(p).windows(lambda: kaldi_io.ArkArena(asz), lim, lambda a: None):
+            taken, released, held = [], [], []          # every arena taken is either the holder of one item or handed to release
+
+            def take():
+                taken.append(kaldi_io.ArkArena(asz))
+                return taken[-1]
+            for keys, addr, rows, cols, holder in kaldi_io.MatScp(p).windows(take, lim, released.append):
                 am = kaldi_io.ArkMats(); am.add(addr, rows, cols, holder)
                 out += [(k, np.array(am[j])) for j, k in enumerate(keys)]
+                if isinstance(holder, kaldi_io.ArkArena): held.append(holder)
             ok = [k for k, _ in out] == [l.split()[0] for l in sel] and all(np.array_equal(a, ref[k]) for k, a in out)
+            ok = ok and sorted(map(id, taken)) == sorted(map(id, held + released))
             blk = [(k, v[int(o[j]):int(o[j + 1])]) for ks, v, o in kaldi_io.MatScp(p).blocks() for j, k in enumerate(ks)]
             ok = ok and [k for k, _ in blk] == [l.split()[0] for l in sel] and all(np.array_equal(a, ref[k]) for k, a in blk)
         except Exception as e:
