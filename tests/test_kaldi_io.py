@@ -698,4 +698,21 @@ def test_mapped_ark_windows_equal_the_record_reader(tmp_path):
     fd = kaldi_io.open_or_fd("cat %s |" % path)
     assert kaldi_io.map_stream(fd) is None
     assert len(fd.read()) == len(data)
+    # compressed matrices behind plain ones: the mapped walk ends at the first of them and the rest goes through the arena reader
+    # WITHOUT being copied first (kaldi_io.MemStream over the mapped bytes)
+    from fixture_inputs import encode_cm_record
+    mixed = io.BytesIO()
+    for i in range(40):
+        m = rng.standard_normal((int(rng.integers(1, 50)), 23)).astype(np.float32)
+        if i < 15:
+            kaldi_io.write_mat(mixed, m, key="m%d" % i)
+        else:
+            mixed.write(encode_cm_record("m%d" % i, m))
+    want = list(kaldi_io.read_mat_ark(io.BytesIO(mixed.getvalue())))
+    got = collect(kaldi_io.map_stream(io.BytesIO(mixed.getvalue())), 1 << 20, None)
+    assert [k for k, _ in got] == [k for k, _ in want] and all(np.array_equal(a, b) for (_, a), (_, b) in zip(got, want))
+    ms = kaldi_io.MemStream(np.frombuffer(b"0123456789", np.uint8))
+    buf = bytearray(4)
+    assert ms.read(3) == b"012" and ms.readinto(buf) == 4 and bytes(buf) == b"3456" and ms.tell() == 7
+    assert ms.seek(-2, 2) == 8 and ms.read() == b"89" and ms.read(5) == b"" and ms.seek(-1, 1) == 9
     fd.close()

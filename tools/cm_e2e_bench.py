@@ -33,3 +33,17 @@ for name, raw in (("FM ", fm), ("CM ", cm)):
         print("%s ark -> ark: %d utts, %.1f MB in, %.3f s -> %.0f utt/s" % (name, n, len(raw) / 1e6, dt, n / dt))
     outs[name] = out.getvalue()
 print("x-vector arks identical:", outs["FM "] == outs["CM "], len(outs["CM "]))
+# the same compressed ark as a regular file (tmpfs): read into the arenas instead of being walked in place
+path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else d, "cm_e2e_%d.ark" % os.getpid())
+with open(path, "wb") as f:
+    f.write(cm)
+try:
+    for rep in range(3):
+        out = io.BytesIO(); t0 = time.time()
+        with open(path, "rb") as f:
+            models.Model().make_embedding(f, out, d, 25, 10000, False, log)
+        dt = time.time() - t0
+        print("CM  file -> ark: %d utts, %.3f s -> %.0f utt/s" % (n, dt, n / dt))
+    print("x-vector arks identical:", out.getvalue() == outs["CM "])
+finally:
+    os.unlink(path)

@@ -932,6 +932,36 @@ def map_stream(file_or_fd):
     return None
 
 
+class MemStream(object):
+    """A read-only binary stream over a uint8 array that is already in memory (the rest of a mapped ark), WITHOUT a copy of it:
+    what ``io.BytesIO(arr.tobytes())`` would be, minus the 0.1-0.2 s per GB of the copy.  ``scan_mat_ark_windows`` moves its bytes
+    into the arenas with the host library's copy, outside the interpreter lock, as it does for a BytesIO."""
+
+    def __init__(self, arr):
+        self.arr = arr
+        self.pos = 0
+
+    def tell(self):
+        return self.pos
+
+    def seek(self, pos, whence=0):
+        self.pos = max(0, min(len(self.arr), int(pos) + (0 if whence == 0 else self.pos if whence == 1 else len(self.arr))))
+        return self.pos
+
+    def read(self, n=-1):
+        end = len(self.arr) if n is None or n < 0 else min(len(self.arr), self.pos + int(n))
+        out = self.arr[self.pos:end].tobytes()
+        self.pos = end
+        return out
+
+    def readinto(self, b):
+        view = memoryview(b).cast("B")
+        n = min(len(view), len(self.arr) - self.pos)
+        view[:n] = memoryview(self.arr[self.pos:self.pos + n])
+        self.pos += n
+        return n
+
+
 def scan_mat_ark_mapped(arr, window_bytes, first_bytes=None, fallback=None):
     """``scan_mat_ark_windows`` over an ark that is already in memory (``map_stream``): the native scanner walks ``arr`` in
     windows of about ``window_bytes`` (the first one ``first_bytes``) and yields ``(keys, addr, rows, cols, holder)`` with the
@@ -989,7 +1019,7 @@ def scan_mat_ark_mapped(arr, window_bytes, first_bytes=None, fallback=None):
                     def take():
                         pool.append(ArkArena(max(len(b) + 64, 1 << 20)))
                         return pool[-1]
-                    return scan_mat_ark_windows(io.BytesIO(b.tobytes()), take)
+                    return scan_mat_ark_windows(MemStream(b), take)
             for item in fallback(rest):
                 yield item
             return
@@ -1033,6 +1063,9 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
     if type(raw) is io.BytesIO and hasattr(lib, "xv_copy_bytes"):
         mem = raw.getvalue()
         mem_addr = np.frombuffer(mem, dtype=np.uint8).ctypes.data if len(mem) else None
+    elif isinstance(raw, MemStream) and hasattr(lib, "xv_copy_bytes"):
+        mem = raw.arr
+        mem_addr = int(mem.ctypes.data) if len(mem) else None
     key_off = np.empty(_SCAN_MAX, np.int64); key_len = np.empty(_SCAN_MAX, np.int32)
     data_off = np.empty(_SCAN_MAX, np.int64); rows = np.empty(_SCAN_MAX, np.int32); cols = np.empty(_SCAN_MAX, np.int32)
     nxt, stop = ctypes.c_size_t(0), ctypes.c_int(0)

@@ -531,7 +531,7 @@ class Model(object):
                         if mapped is not None:
                             source = kaldi_io.scan_mat_ark_mapped(
                                 mapped, arena_bytes, first,
-                                fallback=lambda rest: kaldi_io.scan_mat_ark_windows(io.BytesIO(rest.tobytes()), take_arena, None, pool.put))
+                                fallback=lambda rest: kaldi_io.scan_mat_ark_windows(kaldi_io.MemStream(rest), take_arena, None, pool.put))
                         elif hasattr(input_stream, "read"):
                             source = kaldi_io.scan_mat_ark_windows(input_stream, take_arena, first, pool.put)
                         else:
