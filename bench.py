@@ -477,6 +477,10 @@ def _e2e_leg(args, weights, topo, feat, with_cli):
             dt = time.perf_counter() - t0
             fbest = dt if fbest is None else min(fbest, dt)
         shm = {"value": n / fbest, "unit": "utt/s", "seconds": fbest, "input": "the same ark as a file on %s" % ("tmpfs (/dev/shm)" if shm_ok else "disk")}
+        try:
+            comp = _compressed_leg(kaldi_io, models, n, lens, feat, tmp, log)
+        except Exception as e:                                     # a sub-record must not take the line down
+            comp = {"error": repr(e)}
         if with_cli:
             try:
                 cli = _cli_job_leg(args, fpath, spath, tmp, n)
@@ -493,8 +497,43 @@ def _e2e_leg(args, weights, topo, feat, with_cli):
                    "process.  The FIRST pass (passes_s[0]) also loads the model (weights packed on the device, load-time accuracy "
                    "probe), pins the staging buffers and faults the read arenas in; later calls of the same process re-use the loaded "
                    "model of the same checkpoint (XVECTOR_MODEL_CACHE=0 turns that off)",
-           "from_tmpfs_file": shm}
+           "from_tmpfs_file": shm, "compressed_input": comp}
     return res, cli
+
+
+def _compressed_leg(kaldi_io, models, n, lens, feat, model_dir, log):
+    """The same number of utterances as Kaldi's DEFAULT feature records -- CompressedMatrix, "CM ": what steps/make_mfcc.sh writes and a
+    feats.scp points at -- through the same entry point: the in-place reader decodes them natively (xv_ark_decode_cm).  Synthetic
+    records (random bytes on the format's piecewise-linear scale, increasing per-column percentiles); the x-vectors of a sample are
+    compared, byte for byte, with those of the same matrices decoded by the generic reader and stored as plain float matrices."""
+    import io
+    import struct
+    rng = np.random.default_rng(99)
+    recs = []
+    for j in range(257):
+        rows = int(lens[j % len(lens)])
+        q = np.sort(rng.integers(2000, 63000, size=(feat, 4)), axis=1).astype(np.uint16) + np.arange(4, dtype=np.uint16)[None, :]
+        recs.append(b" \0BCM " + struct.pack("<ffii", -10.0, 20.0, rows, feat) + q.tobytes() +
+                    rng.integers(0, 256, size=(feat, rows), dtype=np.uint8).tobytes())
+    data = b"".join(("utt%07d" % i).encode() + recs[i % 257] for i in range(n))
+    best = None
+    for _ in range(3):
+        out = io.BytesIO()
+        t0 = time.perf_counter()
+        models.Model().make_embedding(io.BytesIO(data), out, model_dir, 25, 10000, True, log)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    nvec = out.getbuffer().nbytes // (len("utt0000000") + 1 + 2 + 3 + 1 + 4 + 512 * 4)
+    sample = b"".join(("utt%07d" % i).encode() + recs[i] for i in range(257))
+    plain = io.BytesIO()
+    for key, m in kaldi_io.read_mat_ark(io.BytesIO(sample)):
+        kaldi_io.write_mat(plain, m, key=key)
+    o1, o2 = io.BytesIO(), io.BytesIO()
+    models.Model().make_embedding(io.BytesIO(sample), o1, model_dir, 25, 10000, True, log)
+    models.Model().make_embedding(io.BytesIO(plain.getvalue()), o2, model_dir, 25, 10000, True, log)
+    return {"value": n / best, "unit": "utt/s", "seconds": best, "vectors_written": int(nvec), "ark_gb_in": len(data) / 1e9,
+            "same_bytes_as_plain_float_input": bool(o1.getvalue() == o2.getvalue() and len(o1.getvalue()) > 0),
+            "input": "Kaldi CompressedMatrix records (\"CM \", one byte per element) in host RAM"}
 
 
 def main():
