@@ -374,3 +374,52 @@ def test_batches_come_in_whole_rounds_of_workgroups():
     cum = np.concatenate([[0], np.cumsum([304, 304, 808, 96, 96])])
     bounds = ex._batch_bounds(cum, 8)
     assert [b[:2] for b in bounds] == [(0, 2), (2, 3), (3, 5)]
+
+
+def test_raw_row_plan_matches_the_array_formulation():
+    """xv_raw_row_plan (libxvector_host.so): the destination row of every raw frame of a batch -- voiced frames counted per
+    utterance, cut into the plan's chunks, chunks of other batches and dropped tails marked -1 -- against the same rule written
+    with whole-array operations (what Extractor.submit_raw did before), on random windows with and without a VAD."""
+    import ctypes
+    from xvector_amd import engine
+    lib = engine._host_lib()
+    if lib is None:
+        pytest.skip("host library not built")
+    rng = np.random.default_rng(8)
+    for trial in range(60):
+        nU = int(rng.integers(1, 40))
+        T = rng.integers(1, 300, nU).astype(np.int64)
+        with_vad = trial % 3 != 0
+        vstart = np.zeros(nU, np.int64)
+        np.cumsum(T[:-1], out=vstart[1:])
+        voiced = (rng.random(int(T.sum())) < rng.choice([0.2, 0.8, 1.0])) if with_vad else None
+        V = np.add.reduceat(voiced, vstart).astype(np.int64) if with_vad else T.copy()
+        size = np.maximum(1, rng.integers(20, 120, nU)).astype(np.int64)
+        kept = np.minimum(rng.integers(0, 5, nU), -(-V // size)).astype(np.int64)          # chunks of the utterance that exist
+        seg = np.zeros(nU, np.int64)
+        np.cumsum(kept[:-1], out=seg[1:])
+        nch = int(kept.sum())
+        b0 = int(rng.integers(0, max(1, nch // 2 + 1)))
+        b1 = int(rng.integers(b0, nch + 1))
+        row_start = (np.arange(max(b1 - b0, 1)) * 137 + 5).astype(np.int32)
+        # whole-array formulation
+        p = np.repeat(np.arange(nU), T)
+        if voiced is None:
+            vm = np.ones(int(T.sum()), bool)
+            vidx = np.arange(int(T.sum()), dtype=np.int64) - np.repeat(vstart, T)
+        else:
+            vm = voiced
+            cv = np.cumsum(vm, dtype=np.int64)
+            before = cv[vstart + T - 1] - V
+            vidx = cv - 1 - np.repeat(before, T)
+        k = vidx // size[p]
+        cid = seg[p] + k
+        ok = vm & (k < kept[p]) & (cid >= b0) & (cid < b1)
+        want = np.where(ok, row_start[np.clip(cid - b0, 0, len(row_start) - 1)] + (vidx - k * size[p]), -1).astype(np.int32)
+        got = np.full(int(T.sum()) + 3, 12345, np.int32)
+        fl = np.ascontiguousarray(voiced) if voiced is not None else None
+        rc = lib.xv_raw_row_plan(nU, T.ctypes.data, fl.ctypes.data if fl is not None else None, vstart.ctypes.data, size.ctypes.data,
+                                 kept.ctypes.data, seg.ctypes.data, b0, b1, row_start.ctypes.data, got.ctypes.data, int(T.sum()))
+        assert rc == 0 and np.array_equal(got[:-3], want) and np.all(got[-3:] == 12345), trial
+        assert lib.xv_raw_row_plan(nU, T.ctypes.data, None, vstart.ctypes.data, size.ctypes.data, kept.ctypes.data, seg.ctypes.data, b0, b1,
+                                   row_start.ctypes.data, got.ctypes.data, int(T.sum()) - 1) == -1

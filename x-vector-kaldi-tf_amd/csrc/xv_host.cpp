@@ -20,7 +20,7 @@
 
 extern "C" {
 
-int xv_host_version(void) { return 9; }
+int xv_host_version(void) { return 10; }
 
 // Index pass over an ark FILE of binary float-matrix records (plain "FM " or compressed "CM ") without reading the matrices: per
 // record one pread of the header ("<key> \0BFM \4<rows>\4<cols>" / "<key> \0BCM <min><range><rows><cols>"), then a hop over the payload.  This is what lets the ranks of a job split a
@@ -400,6 +400,35 @@ int64_t xv_ark_gather_fm(const uint8_t *buf, const int64_t *data_off, const int3
         for (auto &th : pool) th.join();
     }
     return first[n];
+}
+
+// xv_raw_row_plan: where every RAW frame of a batch's utterances goes (Extractor.submit_raw of xvector_amd/engine.py: sliding CMN +
+// select-voiced-frames on the device, extract_xvectors.sh:68).  Utterance i brings T[i] frames; its voiced flags are voiced + vstart[i]
+// (one byte per frame, non-zero = voiced; voiced == NULL: every frame).  Its voiced frames, counted from 0, fall into chunks of
+// size[i] frames; the first kept[i] of them exist, and chunk k of the utterance is chunk seg[i] + k of the window -- of which this
+// batch holds chunks [b0, b1), chunk c at row row_start[c - b0].  dst[frame] = row of the packed batch, or -1 (unvoiced, a dropped
+// tail, a chunk of another batch).  One pass over the frames instead of a dozen NumPy passes over 8-byte temporaries.
+// Returns 0, or -1 when the frames do not fit dst_cap.
+int xv_raw_row_plan(int n_utt, const int64_t *T, const uint8_t *voiced, const int64_t *vstart, const int64_t *size, const int64_t *kept,
+                    const int64_t *seg, int64_t b0, int64_t b1, const int32_t *row_start, int32_t *dst, int64_t dst_cap)
+{
+    int64_t o = 0;
+    for (int i = 0; i < n_utt; ++i) {
+        const int64_t Ti = T[i];
+        if (Ti < 0 || o + Ti > dst_cap) return -1;
+        const uint8_t *fl = voiced ? voiced + vstart[i] : nullptr;
+        const int64_t sz = size[i], kp = sz > 0 ? kept[i] : 0, sg = seg[i];
+        int32_t *d = dst + o;
+        int64_t k = 0, r = 0;                               // chunk of the utterance, frame inside it
+        for (int64_t t = 0; t < Ti; ++t) {
+            if (fl && !fl[t]) { d[t] = -1; continue; }
+            const int64_t cid = sg + k;
+            d[t] = (k < kp && cid >= b0 && cid < b1) ? row_start[cid - b0] + (int32_t)r : -1;
+            if (++r == sz) { r = 0; ++k; }
+        }
+        o += Ti;
+    }
+    return 0;
 }
 
 // Chunks must be given in ascending, non-overlapping dst_row order.  Columns [feat_dim, dst_ld) of dst are not touched (the

@@ -39,6 +39,9 @@ def _host_lib():
             lib.xv_pack_rows_f32.restype = ctypes.c_int
             lib.xv_pack_rows_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+            lib.xv_raw_row_plan.restype = ctypes.c_int
+            lib.xv_raw_row_plan.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                                                                  ctypes.c_void_p, ctypes.c_int64]
         except (OSError, AttributeError):
             lib = None
         _HOST.append(lib)
@@ -1137,8 +1140,12 @@ class Extractor(object):
         cum = np.zeros(nch + 1, dtype=np.int64)
         np.cumsum(slot_rows(c_len, gap, align), out=cum[1:])
         bounds = self._batch_bounds(cum, lead)
-        kept = np.diff(seg_start)                             # chunks per utterance of `order`
-        first_len = c_len[seg_start[:-1]]                     # = the chunk size the plan used for the utterance
+        kept = np.ascontiguousarray(np.diff(seg_start), dtype=np.int64)                  # chunks per utterance of `order`
+        first_len = np.ascontiguousarray(c_len[seg_start[:-1]], dtype=np.int64)          # = the chunk size the plan used for the utterance
+        seg_o = np.ascontiguousarray(seg_start[:-1], dtype=np.int64)
+        vstart_o = np.ascontiguousarray(vstart[order], dtype=np.int64)                   # (per utterance of `order`, like the three above)
+        if voiced is not None:
+            voiced = np.ascontiguousarray(voiced, dtype=np.bool_)
         # utterances (positions in `order`) touched by each batch, and the raw rows they bring
         spans = [(int(np.searchsorted(seg_start, b0, side="right")) - 1, int(np.searchsorted(seg_start, b1, side="left")))
                  for b0, b1, _ in bounds]
@@ -1159,21 +1166,6 @@ class Extractor(object):
                 nU, rows_in = len(U), int(Tb.sum())
                 ustart = np.zeros(nU, dtype=np.int64)
                 np.cumsum(Tb[:-1], out=ustart[1:])
-                # destination row of every raw frame of the batch's utterances (-1: unvoiced / chunk of another batch / dropped tail)
-                p = np.repeat(np.arange(nU), Tb)
-                if voiced is None:
-                    vm = np.ones(rows_in, dtype=bool)
-                    vidx = np.arange(rows_in, dtype=np.int64) - np.repeat(ustart, Tb)
-                else:
-                    vm = np.concatenate([voiced[vstart[u]:vstart[u] + T[u]] for u in U.tolist()])
-                    cv = np.cumsum(vm, dtype=np.int64)
-                    before = cv[ustart + Tb - 1] - V[U]                       # voiced frames of the batch before each utterance
-                    vidx = cv - 1 - np.repeat(before, Tb)
-                size = first_len[lo:hi][p]
-                k = vidx // size
-                cid = seg_start[lo:hi][p] + k
-                ok = vm & (k < kept[lo:hi][p]) & (cid >= b0) & (cid < b1)
-                dst = np.where(ok, layout.row_start[np.clip(cid - b0, 0, layout.nchunks - 1)] + (vidx - k * size), -1).astype(np.int32)
                 st = self._raw_stage[self._turn % self.NBUF]
                 sx = self._stage[self._turn % self.NBUF]
                 self._turn += 1
@@ -1184,7 +1176,12 @@ class Extractor(object):
                 rc = lib.xv_pack_rows_f32(src_b.ctypes.data, len_b.ctypes.data, start_b.ctypes.data, nU, F,
                                           st["raw"].numpy().ctypes.data, F, rows_in, None, self.PACK_THREADS)
                 assert rc == 0, "xv_pack_rows_f32 rejected the raw layout"
-                st["dst"].numpy()[:rows_in] = dst
+                # destination row of every raw frame of the batch's utterances (-1: unvoiced / chunk of another batch / dropped tail),
+                # straight into the pinned array (native: one pass over the frames)
+                rc = lib.xv_raw_row_plan(nU, Tb.ctypes.data, voiced.ctypes.data if voiced is not None else None, vstart_o[lo:hi].ctypes.data,
+                                         first_len[lo:hi].ctypes.data, kept[lo:hi].ctypes.data, seg_o[lo:hi].ctypes.data, int(b0), int(b1),
+                                         layout.row_start.ctypes.data, st["dst"].numpy().ctypes.data, rows_in)
+                assert rc == 0, "xv_raw_row_plan rejected the raw layout"
                 um = st["utt"].numpy()
                 um[0, :nU] = ustart
                 um[1, :nU] = Tb

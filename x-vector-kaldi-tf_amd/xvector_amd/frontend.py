@@ -37,8 +37,9 @@ def select_voiced(mats, vads):
     np.cumsum(T[cand][:-1], out=starts[1:])
     counts = np.add.reduceat(voiced, starts) if len(cand) else np.zeros(0, np.int64)
     has = counts > 0                                                          # ... and so does a VAD without a voiced frame
-    voiced = voiced[np.repeat(has, T[cand])]
-    cand = cand[has]
+    if not has.all():                                                         # (the usual window drops nobody: no pass over the frames)
+        voiced = voiced[np.repeat(has, T[cand])]
+        cand = cand[has]
     dropped = int(np.count_nonzero(vl >= 0)) - int(np.count_nonzero(vl[cand] >= 0))
     return T, cand, voiced, empty, dropped
 
