@@ -423,3 +423,56 @@ def test_raw_row_plan_matches_the_array_formulation():
         assert rc == 0 and np.array_equal(got[:-3], want) and np.all(got[-3:] == 12345), trial
         assert lib.xv_raw_row_plan(nU, T.ctypes.data, None, vstart.ctypes.data, size.ctypes.data, kept.ctypes.data, seg.ctypes.data, b0, b1,
                                    row_start.ctypes.data, got.ctypes.data, int(T.sum()) - 1) == -1
+
+
+def test_select_voiced_window_rules_match_the_per_utterance_oracle(oracle_mod):
+    """frontend.select_voiced (the utterance-level rules of select-voiced-frames for a whole window, on concatenated arrays) against
+    the oracle's per-utterance restatement: a VAD of another length or without a voiced frame drops the utterance, no VAD means every
+    frame, an utterance with neither frames nor a VAD stays an empty matrix; flags of the surviving utterances in order."""
+    from xvector_amd import frontend
+    rng = np.random.default_rng(4)
+    for trial in range(40):
+        n = int(rng.integers(1, 60))
+        mats, vads = [], []
+        for i in range(n):
+            T = int(rng.choice([0, 1, 5, 40, 300], p=[.05, .1, .15, .4, .3]))
+            mats.append(rng.standard_normal((T, 5)).astype(np.float32))
+            r = rng.random()
+            if r < 0.15:
+                vads.append(None)
+            elif r < 0.25:
+                vads.append(np.zeros(T, np.float32))                                   # nothing voiced
+            elif r < 0.35:
+                vads.append((rng.random(max(0, T + int(rng.choice([-1, 1, 7])))) < 0.7).astype(np.float32))       # another length
+            else:
+                vads.append((rng.random(T) < rng.choice([0.3, 0.9, 1.0])).astype(np.float32).reshape(-1, 1) if trial % 2 else
+                            (rng.random(T) < 0.8).astype(np.float32))
+        if trial % 5 == 0:
+            vads_in = None
+        else:
+            vads_in = vads
+        T, cand, voiced, empty, dropped = frontend.select_voiced(mats, vads_in)
+        assert T.tolist() == [m.shape[0] for m in mats]
+        want_cand, want_flags, want_empty, want_dropped = [], [], [], 0
+        for i, m in enumerate(mats):
+            v = None if vads_in is None else vads_in[i]
+            if v is None:
+                if m.shape[0] > 0:
+                    want_cand.append(i)
+                    want_flags.append(np.ones(m.shape[0], bool))
+                else:
+                    want_empty.append(i)
+                continue
+            v1 = np.asarray(v).reshape(-1)
+            sel = oracle_mod.select_voiced(m, v1) if m.shape[0] > 0 else None
+            if sel is None:
+                want_dropped += 1
+            else:
+                want_cand.append(i)
+                want_flags.append(v1 != 0)
+                assert np.array_equal(sel, m[v1 != 0])
+        assert cand.tolist() == want_cand and sorted(empty) == want_empty and dropped == want_dropped, trial
+        if vads_in is None:
+            assert voiced is None
+        else:
+            assert np.array_equal(voiced, np.concatenate(want_flags) if want_flags else np.zeros(0, bool)), trial

@@ -31,8 +31,21 @@ def select_voiced(mats, vads):
     vl = np.fromiter((-1 if v is None else v.shape[0] for v in flat), dtype=np.int64, count=n)
     empty = np.flatnonzero((vl < 0) & (T == 0)).tolist()
     cand = np.flatnonzero(((vl == T) | (vl < 0)) & (T > 0))                  # a length mismatch drops the key
-    voiced = np.concatenate([np.ones(int(T[i]), bool) if flat[i] is None else flat[i] != 0 for i in cand.tolist()]) \
-        if len(cand) else np.zeros(0, bool)
+    if len(cand):
+        # ONE comparison over the concatenated decisions (not one small array operation per utterance); an utterance without a VAD
+        # contributes a slice of ones
+        ones = None
+        parts = []
+        for i in cand.tolist():
+            v = flat[i]
+            if v is None:
+                if ones is None:
+                    ones = np.ones(int(T[cand].max()), np.float32)
+                v = ones[:int(T[i])]
+            parts.append(v)
+        voiced = np.concatenate(parts) != 0
+    else:
+        voiced = np.zeros(0, bool)
     starts = np.zeros(len(cand), dtype=np.int64)
     np.cumsum(T[cand][:-1], out=starts[1:])
     counts = np.add.reduceat(voiced, starts) if len(cand) else np.zeros(0, np.int64)
