@@ -9,6 +9,14 @@
 // xv_pack_rows_f32: the batch packer of the extractor (xvector_amd/engine.py BatchLayout): chunk i = len[i] rows of
 // feat_dim floats at address src[i] -> rows [dst_row[i], dst_row[i]+len[i]) of the (pinned) staging matrix, every other
 // row zeroed, row_valid filled.  One GIL-free call on a few threads instead of one np.concatenate per batch.
+//
+// The other entry points, each described where it is defined: xv_ark_scan_fv (float-vector records: the VAD tables),
+// xv_ark_index_fd (header-only index of an ark FILE: byte-range sharding across ranks), xv_ark_decode_cm (Kaldi's
+// CompressedMatrix records decoded into arenas, Kaldi's float32 arithmetic), xv_ark_keys / xv_ark_gather_fm (keys and
+// matrices of a scanned block gathered into one array each), xv_copy_bytes (a memcpy outside the interpreter lock),
+// xv_raw_row_plan (destination row of every raw frame of a batch: the recipe's CMN + VAD mode).
+// An internal helper library of the Python host side (ctypes, local/tf/kaldi_io.py and xvector_amd/engine.py) -- the drop-in
+// boundary of the compute path is libxvector_hip.so (include/xvector_hip.h).  Built for x86-64-v3 (AVX2).
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
