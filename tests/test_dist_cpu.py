@@ -31,7 +31,7 @@ WORKER = textwrap.dedent("""
     import numpy as np, torch, torch.distributed as dist
     from xvector_amd import dist as xdist
     rank, world = xdist.init_process_group("gloo")
-    lens = np.random.default_rng(3).integers(25, 400, size=37)
+    lens = np.random.default_rng(3).integers(25, 400, size=int(os.environ.get("XV_TEST_UTTS", "37")))
     dim = 16
     def fake_extract(idx):      # stand-in for the GPU forward: row i = f(utterance i)
         return torch.stack([torch.full((dim,), float(i)) + torch.arange(dim) * float(lens[i]) for i in idx]) if len(idx) else torch.zeros((0, dim))
@@ -47,17 +47,21 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def test_two_rank_gloo_sharded_gather(tmp_path):
+@pytest.mark.parametrize("world,utts", [(2, 37), (3, 37), (8, 37), (8, 5)])
+def test_two_rank_gloo_sharded_gather(tmp_path, world, utts):
+    """(also at the driver's largest launch, 8 ranks -- and with fewer utterances than ranks: empty shards take part in the ONE
+    padded gather like the others)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % PKG)
-    port = 29000 + (os.getpid() % 2000)
+    port = 29000 + (os.getpid() % 2000) + 7 * world + utts
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   XV_TEST_UTTS=str(utts), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK 2" in outs[0]
+    assert "GATHER_OK %d" % world in outs[0]
 
 
 SKIP_WORKER = textwrap.dedent("""
