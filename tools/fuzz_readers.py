@@ -3,6 +3,7 @@ scp tables: subsets, several arks, repeated and reversed entries) against the re
 
     python tools/fuzz_readers.py ark 0 150      # seeds 0..149 of the ark-stream fuzzer
     python tools/fuzz_readers.py scp 0 120
+    python tools/fuzz_readers.py mixed 0 120    # every record type in one stream; arena reader and mapped walk
 """
 import io
 import os
@@ -117,5 +118,54 @@ def scp_main(argv):
             bad += 1; print("seed", seed, "BAD", n, narks, cm, dens, asz, lim, len(out), len(sel))
     print("done bad", bad)
 
+def mixed_main(argv):
+    """Streams that mix every record type the reader knows (float, double, text and compressed matrices, empty ones), through the arena
+    reader and through the mapped walk with its copy-free fallback (kaldi_io.MemStream); arena accounting."""
+    sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT + "/x-vector-kaldi-tf_amd")
+    from local.tf import kaldi_io
+    from fixture_inputs import encode_cm_record
+    bad = 0
+    for seed in range(int(argv[0]), int(argv[1])):
+        rng = np.random.default_rng(7000 + seed)
+        bio, want = io.BytesIO(), []
+        n = int(rng.integers(1, 200)); f = int(rng.choice([5, 23, 40]))
+        for i in range(n):
+            t = int(rng.choice([0, 1, 3, 9, 50, 300, 1500], p=[.03,.07,.1,.1,.3,.3,.1]))
+            m = (rng.standard_normal((t, f)) * 3).astype(np.float32)
+            key = "k%d_%d" % (seed, i)
+            r = rng.random()
+            if r < 0.45 or t == 0 and r < 0.9: kaldi_io.write_mat(bio, m, key=key)
+            elif r < 0.6: kaldi_io.write_mat(bio, m.astype(np.float64), key=key)
+            elif r < 0.7 and t > 0:
+                bio.write((key + "  [\n" + "\n".join(" ".join("%.6g" % v for v in row) for row in m) + " ]\n").encode())
+            elif t > 0: bio.write(encode_cm_record(key, m))
+            else: kaldi_io.write_mat(bio, m, key=key)
+            want.append(key)
+        raw = bio.getvalue()
+        ref = dict(kaldi_io.read_mat_ark(io.BytesIO(raw)))
+        assert list(ref) == want
+        asz = int(rng.choice([1 << 13, 1 << 16, 1 << 20]))
+        lim = None if rng.random() < 0.5 else int(rng.choice([1, 64, 4096]))
+        for src in ("bytesio", "mapped"):
+            pool = [kaldi_io.ArkArena(asz) for _ in range(4)]; free, got = list(pool), {}
+            try:
+                if src == "bytesio":
+                    it = kaldi_io.scan_mat_ark_windows(io.BytesIO(raw), free.pop, lim, free.append)
+                else:
+                    it = kaldi_io.scan_mat_ark_mapped(kaldi_io.map_stream(io.BytesIO(raw)), asz, lim,
+                                                      fallback=lambda rest: kaldi_io.scan_mat_ark_windows(kaldi_io.MemStream(rest), free.pop, None, free.append))
+                for keys, addr, rows, cols, holder in it:
+                    am = kaldi_io.ArkMats(); am.add(addr, rows, cols, holder)
+                    for j, k in enumerate(keys): got[k] = np.array(am[j])
+                    if isinstance(holder, kaldi_io.ArkArena): free.append(holder)
+                ok = list(got) == want and all(got[k].shape == ref[k].shape and np.array_equal(got[k].astype(np.float32), ref[k].astype(np.float32)) for k in want) and len(free) == 4
+            except Exception as e:
+                import traceback; traceback.print_exc(); ok = False
+            if not ok:
+                bad += 1; print("seed", seed, src, "BAD", n, f, asz, lim, len(got), len(want), len(free))
+    print("done bad", bad)
+
+
+
 if __name__ == "__main__":
-    (ark_main if sys.argv[1] == "ark" else scp_main)(sys.argv[2:4])
+    {"ark": ark_main, "scp": scp_main, "mixed": mixed_main}[sys.argv[1]](sys.argv[2:4])
