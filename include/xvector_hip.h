@@ -59,8 +59,8 @@ const char *xv_last_error(void);
 /* Process-wide launch tuning (no TF counterpart; the analogue of the session's ConfigProto knobs,
  * local/tf/models.py:361-363).  Results do not depend on any of these.
  *   XV_TUNE_TILE_ROWS  rows per workgroup tile of the bf16x3 / f16bf8 GEMMs with split-format input: 128 (4 waves, two
- *                      workgroups per CU), 256 (8 waves, one per CU), 512 (f16bf8: the 256 x 256 tile where the shape allows
- *                      it, else as 0; bf16x3: as 256), 0 = built-in choice.
+ *                      workgroups per CU), 256 (8 waves, one per CU), 512 / 1024 (f16bf8: the 256 x 256 tile on the 32 x 32 /
+ *                      16 x 16 MFMA shapes where the shape allows it, else as 0; bf16x3: as 256), 0 = built-in choice.
  *   XV_TUNE_FIRST_TILES  16-frame tiles per wave of the first-layer kernel (xv_tdnn_first_*): 1..4096, 0 = spread the rows evenly
  *                      over one workgroup per CU (tests use small values to walk through several groups of tiles on small inputs). */
 #define XV_TUNE_TILE_ROWS 1

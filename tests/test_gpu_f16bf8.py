@@ -74,7 +74,8 @@ def test_split8_roundtrip_layout_and_overflow_flag(env):
     assert int(status.item()) == 1 and back[7, 7] == 57344.0 and back[8, 1] == -57344.0
 
 
-@pytest.mark.parametrize("tile_rows", [128, 256, 512])      # 512 = the 256 x 256 tile where the shape allows it, else the built-in choice
+@pytest.mark.parametrize("tile_rows", [128, 256, 512, 1024])      # 512 / 1024 = the 256 x 256 tile on the 32 x 32 / 16 x 16 MFMA shapes
+                                                                  # where the shape allows it, else the built-in choice
 @pytest.mark.parametrize("cin,cout,K,dil,act,yfmt", [
     (512, 512, 5, 1, "relu", "split8"),       # layer 1 of the default topology
     (512, 512, 7, 1, "relu", "split"),        # layer 2, feeding the bf16x3 pair kernel
@@ -154,6 +155,34 @@ def test_f16bf8_tile_heights_agree_bitwise(env):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("K,dil", [(5, 1), (7, 1), (3, 1), (3, 3), (3, 4)])
+def test_f16bf8_16x16_form_agrees_with_the_32x32_form(env, K, dil):
+    """The 256 x 256 tile on v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4 (tap pairs) forms the same products as
+    the 32 x 32 form and adds them in another order: equal to fp32 rounding, not bit for bit; several row and column tiles, a
+    ragged last row tile, gap rows."""
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    rng = np.random.default_rng(50 + K + dil)
+    R, cin, cout = 1500, 512, 512
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = hiplib.SplitBuf(R, cin, dev, hiplib.FMT_SPLIT8)
+    hiplib.split_encode(t(rng.standard_normal((R, cin)).astype(np.float32)), x)
+    wp = hiplib.pack_weights_f16bf8(t((rng.standard_normal((K, cin, cout)) / 50).astype(np.float32)))
+    valid = np.ones(R, np.uint8)
+    valid[700:704] = 0
+    outs = []
+    for rows in (512, 1024):
+        hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, rows)
+        try:
+            y = hiplib.SplitBuf(R, cout, dev, hiplib.FMT_SPLIT8)
+            hiplib.tdnn_layer8(x, R, wp, None, None, None, 1, None, dil, t(valid), y)
+            outs.append(hiplib.split_decode(y, R).cpu().numpy().astype(np.float64))
+        finally:
+            hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
+    assert np.abs(outs[0]).max() > 0.5
+    assert np.linalg.norm(outs[0] - outs[1]) / np.linalg.norm(outs[0]) < 5e-6       # (measured 2.2e-6 ... 2.4e-6)
+    assert (outs[1][700:704] == 0).all()
+
+
 def test_f16bf8_overflow_sets_the_status_word(env):
     torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
     R, cin, cout = 300, 64, 128
@@ -182,6 +211,9 @@ def test_f16bf8_overflow_sets_the_status_word(env):
     (40, 48, 5, 2, "lrelu", [1200, 33], 0),
     (96, 512, 3, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000], 512),      # the 256 x 256 tile with the POOL epilogue
     (64, 256, 5, 1, "prelu", [300, 25, 64], 512),
+    (64, 256, 5, 1, "prelu", [300, 25, 64], 1024),                         # ... and on the 16 x 16 MFMA shapes (an even number of slabs)
+    (128, 512, 7, 1, "relu", [25, 1, 7, 8, 9, 130, 257, 1000], 1024),
+    (64, 256, 3, 2, "lrelu", [300, 25, 64], 1024),
 ])
 def test_tdnn_layer_pool_f16bf8_blocks_match_oracle(env, cin, cout, K, dil, act, lens, tile_rows):
     torch, hiplib, engine, oracle, dev = env["torch"], env["hiplib"], env["engine"], env["oracle"], env["dev"]

@@ -18,6 +18,7 @@
 #include <stdio.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "xvector_hip.h"
@@ -61,6 +62,13 @@ constexpr int g8_tile_bytes(int wm) { return wm * 64 * T_LD * 4; }
 constexpr int g8_mask_off(int kt, int wm) { return g8_oper_bytes(kt, wm) > g8_tile_bytes(wm) ? g8_oper_bytes(kt, wm) : g8_tile_bytes(wm); }
 constexpr size_t g8_lds_bytes(int kt, int wm) { return (size_t)g8_mask_off(kt, wm) + wm * 64 + 4 * BN * sizeof(float); }
 
+template <int K, class F0, class... Fs>
+__device__ __forceinline__ void call_kth(F0 &&f0, Fs &&...fs)
+{
+    if constexpr (K == 0) f0();
+    else call_kth<K - 1>(fs...);
+}
+
 template <int T, int KT, class F>
 __device__ __forceinline__ void for_taps(F &f)
 {
@@ -91,6 +99,24 @@ struct Gemm8Params {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                    \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, imm, 0)
 #define XV_GLDS16(gptr, lptr) XV_GLDS16_OFF(gptr, lptr, 0)
+// MUBUF form: 16 bytes per lane from buffer rsrc at voff (per lane) + soff (wave-uniform) + imm to LDS lptr + imm + 16 * lane
+#define XV_BLDS16(rsrc, lptr, voff, soff, imm)                                                                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lptr), 16, voff, soff, imm, 0)
+#define XV_BLDS16_X4(rsrc, lptr, voff, soff, imm)                                                               \
+    do {                                                                                                        \
+        XV_BLDS16(rsrc, lptr, voff, soff, (imm));                                                               \
+        XV_BLDS16(rsrc, lptr, voff, soff, (imm) + 1024);                                                        \
+        XV_BLDS16(rsrc, lptr, voff, soff, (imm) + 2048);                                                        \
+        XV_BLDS16(rsrc, lptr, voff, soff, (imm) + 3072);                                                        \
+    } while (0)
+constexpr int XV_RSRC_FLAGS = 0x00020000;              // raw buffer, 32-bit data format (gfx9 family dword 3)
+#define XV_GLDS16_X4(gptr, lptr, imm)                                                                           \
+    do {                                                                                                        \
+        XV_GLDS16_OFF(gptr, lptr, (imm));                                                                       \
+        XV_GLDS16_OFF(gptr, lptr, (imm) + 1024);                                                                \
+        XV_GLDS16_OFF(gptr, lptr, (imm) + 2048);                                                                \
+        XV_GLDS16_OFF(gptr, lptr, (imm) + 3072);                                                                \
+    } while (0)
 
 template <int KT, bool POOL, int WM>
 __global__ __launch_bounds__(WM * 128, 2) void tdnn_gemm_f16bf8_kernel(const Gemm8Params p)
@@ -546,6 +572,143 @@ constexpr int W_TILE = 128 * W_TLD * 4;                    // 133120
 constexpr int W_MASK_OFF = W_OPER > W_TILE ? W_OPER : W_TILE;
 constexpr size_t W_LDS_BYTES = (size_t)W_MASK_OFF + W_BM + 4 * W_BN * sizeof(float);
 
+// Epilogue of the 256 x 256 kernels (both MFMA shapes), 128 rows at a time through an fp32 tile that re-uses the operand area:
+// write_tile(T) puts the calling wave's 128 x 64 accumulators into the tile of its half.
+template <bool POOL, class WriteTile>
+__device__ __forceinline__ void wide_epilogue(const Gemm8Params &p, char *lds, const uint8_t *Ms, const float *Ps, long m0, int n0,
+                                              int tid, int wr, WriteTile &&write_tile)
+{
+    float *T = reinterpret_cast<float *>(lds);
+    const int cg = tid & 31;                            // 8-channel group of the 256-column tile
+    const int gc0 = n0 + cg * 8;
+    float bias[8], sc[8], sh[8], al[8];
+    {
+        const f32x4 *P4 = reinterpret_cast<const f32x4 *>(Ps) + cg * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bias[i] = P4[0][i]; bias[4 + i] = P4[1][i];
+            sc[i] = P4[W_BN / 4][i]; sc[4 + i] = P4[W_BN / 4 + 1][i];
+            sh[i] = P4[2 * W_BN / 4][i]; sh[4 + i] = P4[2 * W_BN / 4 + 1][i];
+            al[i] = P4[3 * W_BN / 4][i]; al[4 + i] = P4[3 * W_BN / 4 + 1][i];
+        }
+    }
+    const bool lrelu = p.act == XV_ACT_LRELU;
+    auto act3 = [&](auto MODE, float z, float a) {
+        constexpr int mode = decltype(MODE)::value;
+        return mode == 1 ? fmaxf(a * z, z) : mode == 2 ? fmaxf(z, 0.f) : fmaxf(z, 0.f) + a * fminf(z, 0.f);
+    };
+    auto by_mode = [&](auto &&f) {
+        if (lrelu) f(std::integral_constant<int, 1>{});
+        else if (p.act == XV_ACT_RELU) f(std::integral_constant<int, 2>{});
+        else f(std::integral_constant<int, 0>{});
+    };
+    float amax = 0.f;
+    f32x4 tv[8][2];
+    float keep[8];
+    // thread -> 8 rows x 8 channels of a half: POOL: the 8 rows of block tid >> 5; else rows (tid >> 5) + 16 j
+    auto read_tile = [&](int h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lr = POOL ? (tid >> 5) * 8 + j : (tid >> 5) + 16 * j;
+            tv[j][0] = *reinterpret_cast<const f32x4 *>(T + lr * W_TLD + cg * 8);
+            tv[j][1] = *reinterpret_cast<const f32x4 *>(T + lr * W_TLD + cg * 8 + 4);
+            keep[j] = Ms[h * 128 + lr] ? 1.f : 0.f;
+        }
+    };
+    auto process = [&](int h) {
+        const long mh = m0 + h * 128;
+        if constexpr (POOL) {
+            const int blk = tid >> 5;                   // 16 blocks of 8 rows
+            if (mh + blk * 8 >= p.R) return;
+            float v0[8], s1[8], s2[8];
+            float n = 0.f;
+            by_mode([&](auto MODE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    n += keep[j];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
+                        const float v = act3(MODE, z, al[i]) * sc[i] + sh[i];
+                        if (j == 0) { v0[i] = v; s1[i] = 0.f; s2[i] = 0.f; }
+                        else {
+                            const float d = keep[j] != 0.f ? v - v0[i] : 0.f;      // (a select: a row past R may hold NaN, and NaN * 0 is NaN)
+                            s1[i] += d;
+                            s2[i] += d * d;
+                        }
+                    }
+                }
+            });
+            const float rn = n > 0.f ? 1.f / n : 0.f;
+            f32x4 mean[2], m2[2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mean[i >> 2][i & 3] = n > 0.f ? v0[i] + s1[i] * rn : 0.f;
+                m2[i >> 2][i & 3] = fmaxf(s2[i] - s1[i] * s1[i] * rn, 0.f);
+            }
+            float *o = p.blk + ((size_t)((mh >> 3) + blk) * 2) * p.cout + gc0;
+            *reinterpret_cast<f32x4 *>(o) = mean[0];
+            *reinterpret_cast<f32x4 *>(o + 4) = mean[1];
+            *reinterpret_cast<f32x4 *>(o + p.cout) = m2[0];
+            *reinterpret_cast<f32x4 *>(o + p.cout + 4) = m2[1];
+        } else {
+            const int ch = gc0 >> 5, slot = cg & 3;
+            char *ybase = reinterpret_cast<char *>(p.y) + (size_t)ch * SROW;
+            const size_t yrow = (size_t)p.ychunks * SROW;
+            auto rows = [&](auto MODE, auto Y8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long gr = mh + (tid >> 5) + 16 * j;
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
+                        v[i] = keep[j] != 0.f ? act3(MODE, z, al[i]) * sc[i] + sh[i] : 0.f;
+                    }
+                    const int sw = (int)(gr >> 1) & 7;
+                    char *row = ybase + (size_t)gr * yrow;
+                    if constexpr (decltype(Y8)::value) {
+                        xv_f16x8 hi;
+                        xv_i32x4 x8;
+                        xv_split8_encode8<true>(v, hi, x8, amax);
+                        *reinterpret_cast<xv_f16x8 *>(row + ((slot ^ sw) << 4)) = hi;              // (plain, not non-temporal: see DESIGN 3.1e)
+                        *reinterpret_cast<xv_i32x4 *>(row + (((4 + slot) ^ sw) << 4)) = x8;
+                    } else {
+                        bf16x8 hi, lo;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            hi[i] = (__bf16)v[i];
+                            lo[i] = (__bf16)(v[i] - (float)hi[i]);
+                        }
+                        __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8 *>(row + ((slot ^ sw) << 4)));
+                        __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8 *>(row + (((4 + slot) ^ sw) << 4)));
+                    }
+                }
+            };
+            if (p.y_format == XV_FMT_SPLIT8) by_mode([&](auto MODE) { rows(MODE, std::true_type{}); });
+            else by_mode([&](auto MODE) { rows(MODE, std::false_type{}); });
+        }
+    };
+    // upper half through the tile; the lower half's accumulators go into the tile as soon as the upper half has been read
+    // into registers, i.e. BEFORE the arithmetic of the upper half (128 accumulators + 64 tile values + the arithmetic of
+    // an epilogue do not fit the register file)
+    __syncthreads();                                    // operand buffers are dead
+    if (wr == 0) write_tile(T);
+    __syncthreads();
+    read_tile(0);
+    __syncthreads();
+    if (wr == 1) write_tile(T);
+    __builtin_amdgcn_sched_barrier(0);
+    process(0);
+    __syncthreads();
+    read_tile(1);
+    __builtin_amdgcn_sched_barrier(0);
+    process(1);
+    if constexpr (!POOL)
+        if (amax > XV_SPLIT8_MAX && p.status) atomicOr(p.status, 1);
+}
+
+
 template <int KT, bool POOL>
 __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gemm8Params p)
 {
@@ -785,34 +948,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue, 128 rows at a time ---------------------------------------------------------------------------------
-    float *T = reinterpret_cast<float *>(lds);
-    const int cg = tid & 31;                            // 8-channel group of the 256-column tile
-    const int gc0 = n0 + cg * 8;
-    float bias[8], sc[8], sh[8], al[8];
-    {
-        const f32x4 *P4 = reinterpret_cast<const f32x4 *>(Ps) + cg * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bias[i] = P4[0][i]; bias[4 + i] = P4[1][i];
-            sc[i] = P4[W_BN / 4][i]; sc[4 + i] = P4[W_BN / 4 + 1][i];
-            sh[i] = P4[2 * W_BN / 4][i]; sh[4 + i] = P4[2 * W_BN / 4 + 1][i];
-            al[i] = P4[3 * W_BN / 4][i]; al[4 + i] = P4[3 * W_BN / 4 + 1][i];
-        }
-    }
-    const bool lrelu = p.act == XV_ACT_LRELU;
-    auto act3 = [&](auto MODE, float z, float a) {
-        constexpr int mode = decltype(MODE)::value;
-        return mode == 1 ? fmaxf(a * z, z) : mode == 2 ? fmaxf(z, 0.f) : fmaxf(z, 0.f) + a * fminf(z, 0.f);
-    };
-    auto by_mode = [&](auto &&f) {
-        if (lrelu) f(std::integral_constant<int, 1>{});
-        else if (p.act == XV_ACT_RELU) f(std::integral_constant<int, 2>{});
-        else f(std::integral_constant<int, 0>{});
-    };
-    float amax = 0.f;
-    f32x4 tv[8][2];
-    float keep[8];
-    auto write_tile = [&]() {                           // this wave's 128 x 64 accumulators -> the fp32 tile of its half
+    auto write_tile = [&](float *T) {                   // this wave's 128 x 64 accumulators -> the fp32 tile of its half
         const int col = wc * 64 + (lane & 31);
         const int rowb = 4 * (lane >> 5);
 #pragma unroll
@@ -824,107 +960,356 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
                 T[rr * W_TLD + col + 32] = acc[i][1][reg];
             }
     };
-    // thread -> 8 rows x 8 channels of a half: POOL: the 8 rows of block tid >> 5; else rows (tid >> 5) + 16 j
-    auto read_tile = [&](int h) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int lr = POOL ? (tid >> 5) * 8 + j : (tid >> 5) + 16 * j;
-            tv[j][0] = *reinterpret_cast<const f32x4 *>(T + lr * W_TLD + cg * 8);
-            tv[j][1] = *reinterpret_cast<const f32x4 *>(T + lr * W_TLD + cg * 8 + 4);
-            keep[j] = Ms[h * 128 + lr] ? 1.f : 0.f;
-        }
-    };
-    auto process = [&](int h) {
-        const long mh = m0 + h * 128;
-        if constexpr (POOL) {
-            const int blk = tid >> 5;                   // 16 blocks of 8 rows
-            if (mh + blk * 8 >= p.R) return;
-            float v0[8], s1[8], s2[8];
-            float n = 0.f;
-            by_mode([&](auto MODE) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    n += keep[j];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
-                        const float v = act3(MODE, z, al[i]) * sc[i] + sh[i];
-                        if (j == 0) { v0[i] = v; s1[i] = 0.f; s2[i] = 0.f; }
-                        else {
-                            const float d = keep[j] != 0.f ? v - v0[i] : 0.f;      // (a select: a row past R may hold NaN, and NaN * 0 is NaN)
-                            s1[i] += d;
-                            s2[i] += d * d;
-                        }
-                    }
-                }
-            });
-            const float rn = n > 0.f ? 1.f / n : 0.f;
-            f32x4 mean[2], m2[2];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                mean[i >> 2][i & 3] = n > 0.f ? v0[i] + s1[i] * rn : 0.f;
-                m2[i >> 2][i & 3] = fmaxf(s2[i] - s1[i] * s1[i] * rn, 0.f);
-            }
-            float *o = p.blk + ((size_t)((mh >> 3) + blk) * 2) * p.cout + gc0;
-            *reinterpret_cast<f32x4 *>(o) = mean[0];
-            *reinterpret_cast<f32x4 *>(o + 4) = mean[1];
-            *reinterpret_cast<f32x4 *>(o + p.cout) = m2[0];
-            *reinterpret_cast<f32x4 *>(o + p.cout + 4) = m2[1];
+    wide_epilogue<POOL>(p, lds, Ms, Ps, m0, n0, tid, wr, write_tile);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 256 x 256 tile on the 16 x 16 MFMA shapes (round 4): v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4.
+// On the power-limited chip a product costs ~8 % fewer joules on these shapes (tools/experiments/shape_probe.hip).  Same tile,
+// same operand formats, the same bytes through LDS, the same 128 accumulator registers per wave (8 x 4 tiles of 16 x 16).
+//   * fp16: a lane holds slot kb = lane >> 4 of row / column lane & 15 -- a 32-channel slab is ONE k-step.
+//   * 8-bit: K = 128 is four 32-byte K blocks = the cross terms of TWO (slab, tap) items.  K block kb: item kb >> 1 of the pair,
+//     slots 4 + (kb & 1) and 6 + (kb & 1) of the row-slab (channels 8c..8c+7 and 16+8c..16+8c+7, c = kb & 1; the weight tile holds
+//     [h8 | l8] at the same positions).  Lanes 0-31 of an A / B fragment therefore read item 0's rows / weight tile, lanes 32-63
+//     item 1's -- a per-lane address, nothing else.  Items are paired in stage order (slab-major, tap-minor); K is odd, so the
+//     middle pair of two slabs straddles the slab boundary and the loop is unrolled over two slabs = K pairs.
+//   * MFMA tile row i is row ROW16(i) of the 16, column j is COL16(j) (the permutations found for the bf16x3 S16 form: every
+//     lane group of a ds_read_b128 touches 16 different 16-byte chunks for every tap offset; the 8-bit slots 4+c / 6+c differ
+//     from the fp16 slots only by a constant XOR, which keeps that property).
+//   * LDS: two halo buffers as before; the weight area (64 KB) is four 16 KB regions H0 | H1 | X0 | X1 = the fp16 / 8-bit planes
+//     of the even / odd item of a pair (each [column tile 2nt: 8 KB][2nt+1: 8 KB]), fetched from the unchanged 16 KB weight
+//     tiles.  All B fragments of a pair live in registers (BH 16, BX 32), A fragments are streamed in quarters of the wave's
+//     128 rows (two sets of AH 8 / AX 16 registers).
+// Per pair and wave, 2048 MFMA cycles, two barriers:
+//     phase A   32 fp16 MFMAs (item 0, quarters 0-3)   | read BX(pair), AH quarters, AX q0, q1
+//     barrier 1 [BX in registers, H1 of this pair landed]         -> DMA X0, X1, H0 of the next pair
+//     phase B   16 scaled MFMAs (quarters 0, 1)        | read BH(item 1), AX q2, AH(item 1) q0, q1
+//     phase C   32 fp16 MFMAs (item 1)                 | read AH quarters, AX q3
+//     barrier 2 [X, H0 of the next pair landed]                   -> DMA H1 of the next pair, halo pieces
+//     phase D   16 scaled MFMAs (quarters 2, 3)        | read BH, AH q0 of the next pair's item 0
+// Needs an even number of slabs, K in {3, 5, 7}, Cout % 256 == 0, split-format or POOL output (else the 32 x 32 form).
+// ------------------------------------------------------------------------------------------------
+constexpr int W16_H = 2 * W_A_BYTES;                 // H0 (even item), H1 = + B_BYTES
+constexpr int W16_X = 2 * W_A_BYTES + 2 * B_BYTES;   // X0, X1 = + B_BYTES
+
+template <int KT, bool POOL>
+__global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const Gemm8Params p)
+{
+    static_assert(KT == 3 || KT == 5 || KT == 7, "pairs of (slab, tap) items over two slabs: K odd");
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *Abuf = lds;
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + W_MASK_OFF);
+    float *Ps = reinterpret_cast<float *>(lds + W_MASK_OFF + W_BM);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int nwg = p.n_mt * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q_ = nwg >> 3, r_ = nwg & 7;
+    const int wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx;
+    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const long m0 = (long)mt * W_BM;
+    const int n0 = nt * W_BN;
+
+    const int span = (KT - 1) * p.dil;
+    const int left = span >> 1;
+    const int n_stages = p.n_chunks * KT;              // (slab, tap) items; even
+    const int n_pairs = n_stages >> 1;
+    const int goff = (int)((m0 - left) & 15);
+
+    if (tid < W_BM) {
+        const long gr = m0 + tid;
+        Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
+    } else {
+        const int c = tid - W_BM, gc = n0 + c;
+        Ps[c] = p.bias ? p.bias[gc] : 0.f;
+        Ps[W_BN + c] = p.scale ? p.scale[gc] : 1.f;
+        Ps[2 * W_BN + c] = p.shift ? p.shift[gc] : 0.f;
+        Ps[3 * W_BN + c] = p.act == XV_ACT_NONE ? 1.f : p.act == XV_ACT_LRELU ? p.alpha[0] : p.act == XV_ACT_PRELU ? p.alpha[gc] : 0.f;
+    }
+
+    const size_t xrow_bytes = (size_t)p.xchunks * SROW;
+    const int kb = lane >> 4, kc = kb & 1, kp = kb >> 1;
+    const int row16 = (int)((0x48c67dbf391502eaull >> (4 * (lane & 15))) & 15);        // ROW16
+    const int col16 = (int)((0xfedc76543210ba98ull >> (4 * (lane & 15))) & 15);        // COL16
+
+    // ---- DMA streams (MUBUF buffer_load ... lds: an SGPR descriptor + ONE per-lane offset register per stream; the FLAT form needs a
+    //      64-bit per-lane pointer and 64-bit VALU adds per piece).  A 16 KB weight tile (column tile 2nt + h, item u) =
+    //      [fp16 plane: pieces 0-7][8-bit plane: 8-15].
+    //      waves 0-3: the 8-bit plane of item (wave & 1) of a pair, column tile h = wave >> 1 (8 pieces) -- and the halo pieces;
+    //      waves 4-7: half (wave & 1) of the fp16 plane of an item, column tile h = (wave >> 1) & 1 (4 pieces per item).
+    const int dh = (wave >> 1) & 1;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(p.wt) + ((size_t)(2 * nt + dh) * n_stages) * B_BYTES, 0, 0x7ffffff0, XV_RSRC_FLAGS);
+    const int wvoff = lane * 16;
+    int wsoff;                                         // this wave's share of the pair in flight (items 2P, 2P+1)
+    char *bdst;
+    if (wave < 4) {
+        wsoff = (wave & 1) * B_BYTES + B_PLANE;
+        bdst = lds + W16_X + (wave & 1) * B_BYTES + dh * B_PLANE;
+    } else {
+        wsoff = (wave & 1) * 4096;
+        bdst = lds + W16_H + dh * B_PLANE + (wave & 1) * 4096;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(p.x) + (m0 - left) * (long)xrow_bytes, 0, 0x7ffffff0, XV_RSRC_FLAGS);
+    const int xvoff = (lane >> 3) * (int)xrow_bytes + (lane & 7) * 16;     // (264 rows of a workgroup: far below 2^31 bytes)
+    constexpr int NP = W_BM / 8 + 1;
+    {   // prologue: pair 0 and the halo tile of slab 0
+        if (wave < 4) {
+            XV_BLDS16_X4(wrs, bdst, wvoff, wsoff, 0);
+            XV_BLDS16_X4(wrs, bdst + 4096, wvoff, wsoff + 4096, 0);      // (a MUBUF immediate has 12 bits)
         } else {
-            const int ch = gc0 >> 5, slot = cg & 3;
-            char *ybase = reinterpret_cast<char *>(p.y) + (size_t)ch * SROW;
-            const size_t yrow = (size_t)p.ychunks * SROW;
-            auto rows = [&](auto MODE, auto Y8) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const long gr = mh + (tid >> 5) + 16 * j;
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float z = (i < 4 ? tv[j][0][i] : tv[j][1][i - 4]) + bias[i];
-                        v[i] = keep[j] != 0.f ? act3(MODE, z, al[i]) * sc[i] + sh[i] : 0.f;
-                    }
-                    const int sw = (int)(gr >> 1) & 7;
-                    char *row = ybase + (size_t)gr * yrow;
-                    if constexpr (decltype(Y8)::value) {
-                        xv_f16x8 hi;
-                        xv_i32x4 x8;
-                        xv_split8_encode8<true>(v, hi, x8, amax);
-                        *reinterpret_cast<xv_f16x8 *>(row + ((slot ^ sw) << 4)) = hi;              // (plain, not non-temporal: see DESIGN 3.1e)
-                        *reinterpret_cast<xv_i32x4 *>(row + (((4 + slot) ^ sw) << 4)) = x8;
-                    } else {
-                        bf16x8 hi, lo;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            hi[i] = (__bf16)v[i];
-                            lo[i] = (__bf16)(v[i] - (float)hi[i]);
-                        }
-                        __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8 *>(row + ((slot ^ sw) << 4)));
-                        __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8 *>(row + (((4 + slot) ^ sw) << 4)));
-                    }
-                }
-            };
-            if (p.y_format == XV_FMT_SPLIT8) by_mode([&](auto MODE) { rows(MODE, std::true_type{}); });
-            else by_mode([&](auto MODE) { rows(MODE, std::false_type{}); });
+            XV_BLDS16_X4(wrs, bdst, wvoff, wsoff, 0);
+            XV_BLDS16_X4(wrs, bdst + B_BYTES, wvoff, wsoff + B_BYTES, 0);
         }
+        for (int piece = wave; piece < NP; piece += NW) XV_BLDS16(xrs, Abuf + piece * 1024, xvoff, piece * 8 * (int)xrow_bytes, 0);
+    }
+    wsoff += (n_pairs > 1) ? 2 * B_BYTES : 0;          // -> pair 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int scale_a = XV_SPLIT8_E8M0, scale_b = 127;
+    asm volatile("" : "+v"(scale_a), "+v"(scale_b));
+
+    // per-lane fragment addresses, computed per pair (held in registers they would be 2 K + 2 K values -- spills):
+    //   fp16, tap t:  row wr*128 + ROW16 + t*dil, slot kb                   (+ 16 i rows: + 2048, the same swizzle)
+    //   8-bit, pair:  lanes of K blocks 0,1 read the pair's first item, those of 2,3 the second: slot 4 + kc = the fp16 address
+    //                 ^ ((4 ^ 2 kp) << 4); ^ 32 for slot 6 + kc
+    const int rowbase = wr * 128 + row16;
+    const int kb16 = kb << 4;
+    const int xorc = (4 ^ (2 * kp)) << 4;
+    auto addr_h = [&](int tdil, int rb) {               // rb: an opaque copy of rowbase made inside the loop (else "rowbase + t dil"
+        const int lr0 = rb + tdil;                      // is hoisted out of the loop for every tap: K registers)
+        return (lr0 << 7) + ((((lr0 + goff) & 14) << 3) ^ kb16);
     };
-    // upper half through the tile; the lower half's accumulators go into the tile as soon as the upper half has been read
-    // into registers, i.e. BEFORE the arithmetic of the upper half (128 accumulators + 64 tile values + the arithmetic of
-    // an epilogue do not fit the register file)
-    __syncthreads();                                    // operand buffers are dead
-    if (wr == 0) write_tile();
-    __syncthreads();
-    read_tile(0);
-    __syncthreads();
-    if (wr == 1) write_tile();
-    __builtin_amdgcn_sched_barrier(0);
-    process(0);
-    __syncthreads();
-    read_tile(1);
-    __builtin_amdgcn_sched_barrier(0);
-    process(1);
-    if constexpr (!POOL)
-        if (amax > XV_SPLIT8_MAX && p.status) atomicOr(p.status, 1);
+    auto addr_x = [&](int a0, int a1, int j) {          // pair j of the period from the fp16 addresses of its two items
+        return (kp ? a1 + ((2 * j + 1) / KT) * W_A_BYTES : a0 + ((2 * j) / KT) * W_A_BYTES) ^ xorc;
+    };
+    const int colin = (wc & 1) * 64 + col16;
+    const int bsw = (colin >> 2) & 3;
+    const int pbh = W16_H + (wc >> 1) * B_PLANE + colin * 64 + ((kb ^ bsw) << 4);                 // + (u & 1) * B_BYTES, + 1024 j
+    const int pbx = W16_X + kp * B_BYTES + (wc >> 1) * B_PLANE + colin * 64 + ((kc ^ bsw) << 4);  // + 1024 j
+
+    // Fragment registers: BH 16, BX 32 (the pair's weights), AH 2 x 8, AX 16 (quarters of the wave's 128 rows) = 80.  One AX set is
+    // enough: X jobs never follow each other (two H jobs lie between them and cover the refill), H jobs come in twos.
+    xv_f16x8 AH[2][2], BH[4];
+    xv_i32x4 AXl[2], AXh[2], BXl[4], BXh[4];             // a 32-byte 8-bit fragment = two 16-byte reads
+    auto cat = [](xv_i32x4 u, xv_i32x4 v) { return __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7); };
+    // The MFMAs are TIED inline asm (dst = srcC).  The compiler has no tied form of the 16 x 16 MFMAs (only the shapes with more
+    // than four passes have one): left to the builtins its register allocator let the 32 accumulator tiles wander -- 82 % of the
+    // MFMAs wrote their tile somewhere else, 500 copies per period, 130-190 registers spilled inside the loop.  Nothing in
+    // the loop needs the hazard recogniser (which does not look into asm): every MFMA operand comes from ds_read (waited for
+    // by s_waitcnt, which the compiler still inserts per register), from an MFMA at least 8 MFMAs back, or from a constant.
+    // asm volatile statements also keep their order among themselves and against memory operations, so the interleave of MFMAs,
+    // fragment reads and LDS-DMA below IS the source order (no sched_group_barrier needed, none possible).
+    auto mfma_h = [&](f32x4 &c, const xv_f16x8 &a, const xv_f16x8 &b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    };
+    auto mfma_x = [&](f32x4 &c, const xv_i32x8 &a, const xv_i32x8 &b) {
+        asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:1 blgp:1"
+                     : "+v"(c) : "v"(a), "v"(b), "v"(scale_a), "v"(scale_b));
+    };
+    // job = 8 MFMAs of a quarter (two row tiles x four column tiles), interleaved one to one with up to 8 fragment reads
+    auto job_h = [&](auto SET, auto Q, auto &&...loads) {
+        constexpr int set = decltype(SET)::value, q = decltype(Q)::value;
+        auto step = [&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            mfma_h(acc[2 * q + (k & 1)][k >> 1], AH[set][k & 1], BH[k >> 1]);
+            if constexpr (k < (int)sizeof...(loads)) call_kth<k>(loads...);
+        };
+        for_taps<0, 8>(step);
+    };
+    auto job_x = [&](auto Q, auto &&...loads) {               // column tile outer: BX of tiles 2, 3 may still be on its way
+        constexpr int q = decltype(Q)::value;
+        auto step = [&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            mfma_x(acc[2 * q + (k & 1)][k >> 1], cat(AXl[k & 1], AXh[k & 1]), cat(BXl[k >> 1], BXh[k >> 1]));
+            if constexpr (k < (int)sizeof...(loads)) call_kth<k>(loads...);
+        };
+        for_taps<0, 8>(step);
+    };
+    // single 16-byte fragment reads
+#define XV_LD(dst, T, ptr, off) dst = *reinterpret_cast<const T *>((ptr) + (off))
+    // (every address is a per-lane BASE POINTER plus a compile-time offset that the ds_read carries in its offset field; with the
+    // offset added to an integer first the compiler hoisted "base + 1024 j" out of the loop into registers of their own)
+    auto ld_ah = [&](auto SET, auto R, const char *ah, int buf, int q) {
+        return [&, ah, buf, q] { XV_LD(AH[decltype(SET)::value][decltype(R)::value], xv_f16x8, ah, buf * W_A_BYTES + q * 32 * SROW + decltype(R)::value * 16 * SROW); };
+    };
+    auto ld_axl = [&](auto R, const char *px, int q) {
+        return [&, px, q] { XV_LD(AXl[decltype(R)::value], xv_i32x4, px, q * 32 * SROW + decltype(R)::value * 16 * SROW); };
+    };
+    auto ld_axh = [&](auto R, const char *px2, int q) {
+        return [&, px2, q] { XV_LD(AXh[decltype(R)::value], xv_i32x4, px2, q * 32 * SROW + decltype(R)::value * 16 * SROW); };
+    };
+    // (opaque: else the compiler splits off the region base -- 0x10800 and up, too large for an offset field -- and keeps
+    // "lane part + region + 1024 j" in a register per j)
+    int pbh_o = pbh, pbx_o = pbx, pbx2_o = pbx ^ 32;
+    asm volatile("" : "+v"(pbh_o), "+v"(pbx_o), "+v"(pbx2_o));
+    const char *const pBH = lds + pbh_o, *const pBX = lds + pbx_o, *const pBX2 = lds + pbx2_o;
+    auto ld_bh = [&](auto J, int par) { return [&, par] { XV_LD(BH[decltype(J)::value], xv_f16x8, pBH, par * B_BYTES + decltype(J)::value * 1024); }; };
+    auto ld_bxl = [&](auto J) { return [&] { XV_LD(BXl[decltype(J)::value], xv_i32x4, pBX, decltype(J)::value * 1024); }; };
+    auto ld_bxh = [&](auto J) { return [&] { XV_LD(BXh[decltype(J)::value], xv_i32x4, pBX2, decltype(J)::value * 1024); }; };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+
+    // halo pieces: the next ODD slab goes out in DMA slots 0 .. K-3 of the period (slot 2j: behind barrier 1 of pair j, 2j+1:
+    // behind barrier 2), the next EVEN slab in slots K+1 .. 2K-2 -- between the last read of the buffer's old slab and the
+    // barrier in front of the first read of the new one.  NS one-piece-per-wave slots dealt over K-2 DMA slots, waves 0-3.
+    constexpr int NI = 4;
+    constexpr int DT = KT - 2;
+    constexpr int NS = (NP + NI - 1) / NI;
+    constexpr int PW = (NS + DT - 1) / DT;
+    auto slots_of = [](int t) constexpr { return t < DT ? (NS + DT - 1 - t) / DT : 0; };
+    auto slot_base = [](int t) constexpr { int b = 0; for (int u = 0; u < t; ++u) b += (NS + DT - 1 - u) / DT; return b; };
+    const int rowstep = 8 * (int)xrow_bytes;
+    int ag_off[DT][PW], al_off[DT][PW];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            int piece = (slot_base(t) + j) * NI + (wave & 3);
+            piece = piece < NP ? piece : NP - 1;
+            ag_off[t][j] = piece * rowstep;
+            al_off[t][j] = piece * 1024;
+        }
+
+    // Jobs of pair p (H = 8 fp16 MFMAs of item u0 / u1 on a quarter, X = 8 scaled MFMAs of the pair on a quarter), with the reads
+    // issued behind them (a set is refilled right behind the job that consumed it, one or two jobs before its next use):
+    //   J1  H u0 q0 | BX tiles 0,1; AX <- q0                     J7  H u1 q0 | AX <- q2
+    //   J2  H u0 q1 | BX tiles 2,3; AH[0] <- u0 q2               J8  H u1 q1 | AH[0] <- u1 q2
+    //   barrier 1: BX(p) read, H1(p) landed -> DMA X(p+1), H0(p+1)   barrier 2: X(p+1), H0(p+1) landed -> DMA H1(p+1), halo pieces
+    //   J3  X q0    | AH[1] <- u0 q3                              J9  X q2    | AH[1] <- u1 q3
+    //   J4  H u0 q2 | AX <- q1                                    J10 H u1 q2 | AX <- q3
+    //   J5  H u0 q3 | AH[0] <- u1 q0                              J11 X q3    | AH[0] <- u0' q0
+    //   J6  X q1    | BH <- u1; AH[1] <- u1 q1                    J12 H u1 q3 | BH <- u0' tile by tile; AH[1] <- u0' q1
+    // EVERY quarter accumulates a pair as  H u0, X, H u1: an output row's bits must not depend on where in a tile the row lies
+    // (a chunk's result is independent of its batch neighbours).  That fixes the order more than it seems: the refill
+    // of BH between the two items wants an X job to hide behind, and an X job in that place lies between H u0 and H u1 of its quarter --
+    // so all four must, and none is left to cover the refill of BH for the NEXT pair: J12 refills BH tile by tile instead.
+    const char *ah0 = lds + addr_h(0, rowbase);        // fp16 address of the current pair's first item
+    const char *px, *px2;                              // 8-bit addresses of the current pair (slots 4 + kc / 6 + kc)
+    {   // what J11, J12 of a pair "-1" would have read
+        const int x0 = addr_x(addr_h(0, rowbase), addr_h((1 % KT) * p.dil, rowbase), 0);
+        px = lds + x0;
+        px2 = lds + (x0 ^ 32);
+        ld_bh(I0{}, 0)(); ld_bh(I1{}, 0)(); ld_bh(I2{}, 0)(); ld_bh(I3{}, 0)();
+        ld_ah(I0{}, I0{}, ah0, 0, 0)(); ld_ah(I0{}, I1{}, ah0, 0, 0)();
+        ld_ah(I1{}, I0{}, ah0, 0, 1)(); ld_ah(I1{}, I1{}, ah0, 0, 1)();
+    }
+
+    int pairs_left = n_pairs - 2;                      // pairs behind the one wsoff points at
+    for (int c = 0; c < p.n_chunks; c += 2) {
+        const int ce = (c + 2 < p.n_chunks) ? c + 2 : p.n_chunks - 1;
+        const int a_odd = (c + 1) * SROW, a_even = ce * SROW;
+        char *d_odd = Abuf + W_A_BYTES;
+        char *d_even = Abuf + (ce & 1) * W_A_BYTES;
+        auto halo = [&](auto D) {                       // DMA slot d of the period (waves 0-3)
+            constexpr int d = decltype(D)::value;
+            if constexpr (d <= KT - 3) {
+#pragma unroll
+                for (int j = 0; j < slots_of(d); ++j) {
+                    // (the scalar offset through a local: with the array element as the builtin's argument the HOST pass of hipcc
+                    // silently drops the kernel's launch stub -- the library then fails to load with an undefined symbol)
+                    const int so = a_odd + ag_off[d][j];
+                    XV_BLDS16(xrs, d_odd + al_off[d][j], xvoff, so, 0);
+                }
+            } else if constexpr (d >= KT + 1 && d <= 2 * KT - 2) {
+#pragma unroll
+                for (int j = 0; j < slots_of(d - (KT + 1)); ++j) {
+                    const int so = a_even + ag_off[d - (KT + 1)][j];
+                    XV_BLDS16(xrs, d_even + al_off[d - (KT + 1)][j], xvoff, so, 0);
+                }
+            }
+        };
+        auto pair = [&](auto JJ) {
+            constexpr int j = decltype(JJ)::value;
+            constexpr int u0 = 2 * j, u1 = 2 * j + 1;
+            constexpr int un = (2 * j + 2) % (2 * KT), un1 = (2 * j + 3) % (2 * KT);     // the next pair's items (next period: the same offsets)
+            constexpr int b0 = u0 / KT, b1 = u1 / KT, bn = un / KT;                      // halo buffers
+            int lz = rowbase;
+            asm volatile("" : "+v"(lz));
+            job_h(I0{}, I0{}, ld_bxl(I0{}), ld_bxh(I0{}), ld_bxl(I1{}), ld_bxh(I1{}),
+                  ld_axl(I0{}, px, 0), ld_axh(I0{}, px2, 0), ld_axl(I1{}, px, 0), ld_axh(I1{}, px2, 0));                                  // J1
+            job_h(I1{}, I1{}, ld_bxl(I2{}), ld_bxh(I2{}), ld_bxl(I3{}), ld_bxh(I3{}), ld_ah(I0{}, I0{}, ah0, b0, 2), ld_ah(I0{}, I1{}, ah0, b0, 2));  // J2
+            // barrier 1.  This wave's DMA pieces have landed; its BX reads are complete (LDS operations return in order and the two
+            // newest are the AH reads of J2) -- the X regions may be overwritten.  No full drain: the AH reads stay in flight.
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave < 4) {
+                XV_BLDS16_X4(wrs, bdst, wvoff, wsoff, 0);
+                XV_BLDS16_X4(wrs, bdst + 4096, wvoff, wsoff + 4096, 0);      // (a MUBUF immediate has 12 bits)
+                halo(std::integral_constant<int, 2 * j>{});
+            } else {
+                XV_BLDS16_X4(wrs, bdst, wvoff, wsoff, 0);
+            }
+            job_x(I0{}, ld_ah(I1{}, I0{}, ah0, b0, 3), ld_ah(I1{}, I1{}, ah0, b0, 3));                                                     // J3
+            const char *ah1 = lds + addr_h((u1 % KT) * p.dil, lz);       // (ah0 is dead from here on)
+            job_h(I0{}, I2{}, ld_axl(I0{}, px, 1), ld_axh(I0{}, px2, 1), ld_axl(I1{}, px, 1), ld_axh(I1{}, px2, 1));                      // J4
+            job_h(I1{}, I3{}, ld_ah(I0{}, I0{}, ah1, b1, 0), ld_ah(I0{}, I1{}, ah1, b1, 0));                                               // J5
+            job_x(I1{}, ld_bh(I0{}, 1), ld_bh(I1{}, 1), ld_bh(I2{}, 1), ld_bh(I3{}, 1), ld_ah(I1{}, I0{}, ah1, b1, 1), ld_ah(I1{}, I1{}, ah1, b1, 1));  // J6
+            job_h(I0{}, I0{}, ld_axl(I0{}, px, 2), ld_axh(I0{}, px2, 2), ld_axl(I1{}, px, 2), ld_axh(I1{}, px2, 2));                      // J7
+            job_h(I1{}, I1{}, ld_ah(I0{}, I0{}, ah1, b1, 2), ld_ah(I0{}, I1{}, ah1, b1, 2));                                               // J8
+            // barrier 2.  Nothing read since barrier 1 is rewritten behind it that an MFMA has not consumed already (BH of u1: J7).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (wave < 4) {
+                halo(std::integral_constant<int, 2 * j + 1>{});
+            } else {
+                XV_BLDS16_X4(wrs, bdst + B_BYTES, wvoff, wsoff + B_BYTES, 0);
+            }
+            wsoff += pairs_left > 0 ? 2 * B_BYTES : 0;
+            --pairs_left;
+            job_x(I2{}, ld_ah(I1{}, I0{}, ah1, b1, 3), ld_ah(I1{}, I1{}, ah1, b1, 3));                                                     // J9
+            job_h(I0{}, I2{}, ld_axl(I0{}, px, 3), ld_axh(I0{}, px2, 3), ld_axl(I1{}, px, 3), ld_axh(I1{}, px2, 3));                      // J10
+            // the next pair's addresses (ah1, px, px2 are dead from here on)
+            const int ahn_i = addr_h((un % KT) * p.dil, lz);
+            const char *ahn = lds + ahn_i;
+            const int xn = addr_x(ahn_i, addr_h((un1 % KT) * p.dil, lz), (j + 1) % KT);
+            job_x(I3{}, ld_ah(I0{}, I0{}, ahn, bn, 0), ld_ah(I0{}, I1{}, ahn, bn, 0));                                                     // J11
+            // J12: the weights of column tile t are dead behind its two MFMAs -- BH is refilled tile by tile (no X job can cover this
+            // refill: see the note on the order above), AH[1] behind the last use of each of its halves
+            auto none = [] {};
+            job_h(I1{}, I3{}, none, ld_bh(I0{}, 0), none, ld_bh(I1{}, 0), none, ld_bh(I2{}, 0), ld_ah(I1{}, I0{}, ahn, bn, 1),
+                  [&] { ld_bh(I3{}, 0)(); ld_ah(I1{}, I1{}, ahn, bn, 1)(); });                                                              // J12
+            ah0 = ahn;
+            px = lds + xn;
+            px2 = lds + (xn ^ 32);
+        };
+        for_taps<0, KT>(pair);
+    }
+#undef XV_LD
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");       // (the last MFMAs' results: the asm is opaque to the hazard recogniser)
+
+    // ---- epilogue ----  (lane constants recomputed from an opaque copy of the lane id: not kept in registers across the loop)
+    int lane2 = lane;
+    asm volatile("" : "+v"(lane2));
+    int rows4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rows4[e] = (int)((0x48c67dbf391502eaull >> (4 * (4 * (lane2 >> 4) + e))) & 15);
+    const int col16e = (int)((0xfedc76543210ba98ull >> (4 * (lane2 & 15))) & 15);
+    auto write_tile = [&](float *T) {                   // result of tile (i, j): lane = column COL16(lane & 15), rows ROW16(4 kb + e)
+        const int col = wc * 64 + col16e;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(16 * i + rows4[e]) * W_TLD + col + 16 * j] = acc[i][j][e];
+    };
+    wide_epilogue<POOL>(p, lds, Ms, Ps, m0, n0, tid, wr, write_tile);
 }
 
 typedef void (*gemm8_fn)(const Gemm8Params);
@@ -945,16 +1330,28 @@ const Gemm8Kernel GEMM8_KERNELS[] = {
     {7, false, 8, tdnn_gemm_f16bf8_wide_kernel<7, false>},
     {3, true, 8, tdnn_gemm_f16bf8_wide_kernel<3, true>},   {5, true, 8, tdnn_gemm_f16bf8_wide_kernel<5, true>},
     {7, true, 8, tdnn_gemm_f16bf8_wide_kernel<7, true>},
+    // wm == 16: the 256 x 256 tile on the 16 x 16 MFMA shapes (tdnn_gemm_f16bf8_wide16_kernel)
+    {3, false, 16, tdnn_gemm_f16bf8_wide16_kernel<3, false>}, {5, false, 16, tdnn_gemm_f16bf8_wide16_kernel<5, false>},
+    {7, false, 16, tdnn_gemm_f16bf8_wide16_kernel<7, false>},
+    {3, true, 16, tdnn_gemm_f16bf8_wide16_kernel<3, true>},   {5, true, 16, tdnn_gemm_f16bf8_wide16_kernel<5, true>},
+    {7, true, 16, tdnn_gemm_f16bf8_wide16_kernel<7, true>},
 };
 #undef XV_G8
-size_t g8_kernel_lds(const Gemm8Kernel &e) { return e.wm == 8 ? W_LDS_BYTES : g8_lds_bytes(e.kt, e.wm); }
+size_t g8_kernel_lds(const Gemm8Kernel &e) { return e.wm >= 8 ? W_LDS_BYTES : g8_lds_bytes(e.kt, e.wm); }
 
 std::atomic<int> g_tile_rows8{0};
+std::atomic<int> g_wide16{1};          // XV_F16BF8_S16=0: the built-in choice keeps the 32 x 32 form of the 256 x 256 tile
 
 int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
 {
     Gemm8Params p = p0;
     if (p.R <= 0 || p.cout <= 0) return 0;
+    static const bool env_once = [] {
+        const char *e = std::getenv("XV_F16BF8_S16");
+        if (e && e[0] == '0') g_wide16.store(0, std::memory_order_relaxed);
+        return true;
+    }();
+    (void)env_once;
     if (p.cin <= 0 || p.dil <= 0) return fail(XV_ERR_BAD_ARG, "tdnn_f16bf8: dims > 0");
     const int span = (p.K - 1) * p.dil;
     if ((p.K != 1 && p.K != 3 && p.K != 5 && p.K != 7) || (p.K > 1 && (span < 2 || span > MAX_SPAN)))
@@ -973,16 +1370,21 @@ int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
     }
     p.n_nt = (p.cout + BN - 1) / BN;
     // tile: 128 x 128 (4 waves, two workgroups per CU), 256 x 128 (8 waves) or 256 x 256 (8 waves of 128 x 64; K > 1,
-    // Cout % 256 == 0, split-format or POOL output).  XV_TUNE_TILE_ROWS: 128 / 256 force the first two, 512 the third.
+    // Cout % 256 == 0, split-format or POOL output; on the 16 x 16 MFMA shapes where the number of slabs is even, else on the
+    // 32 x 32 ones).  XV_TUNE_TILE_ROWS: 128 / 256 force the first two, 512 the 32 x 32 form of the third, 1024 the 16 x 16 form.
     int wm = 2;
     {
         const int want = g_tile_rows8.load(std::memory_order_relaxed);
         const bool wide_ok = p.K > 1 && (p.cout & 255) == 0 && (p.blk != nullptr || p.y_format != XV_FMT_F32);
         const bool big_enough = ((p.R + 255) / 256) * p.n_nt >= 512;
-        if (wide_ok && (want == 512 || (want == 0 && ((p.R + 255) / 256) * (p.cout / 256) >= 512))) wm = 8;
+        // the 16 x 16 MFMA form of the 256 x 256 tile pairs (slab, tap) items over two slabs: an even number of slabs
+        const bool w16_ok = wide_ok && (p.n_chunks & 1) == 0;
+        const bool wide_pays = ((p.R + 255) / 256) * (p.cout / 256) >= 512;
+        if (w16_ok && (want == 1024 || (want == 0 && wide_pays && g_wide16.load(std::memory_order_relaxed)))) wm = 16;
+        else if (wide_ok && (want == 512 || want == 1024 || (want == 0 && wide_pays))) wm = 8;
         else if (want == 256 || (want == 0 && p.K >= 5 && big_enough)) wm = 4;
     }
-    if (wm == 8) {
+    if (wm >= 8) {
         p.n_nt = p.cout / W_BN;
         p.n_mt = (int)((p.R + W_BM - 1) / W_BM);
     } else {
@@ -1002,7 +1404,7 @@ int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
         }
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL(k->fn, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(wm == 8 ? 512 : wm * 128), g8_kernel_lds(*k), st, p);
+    hipLaunchKernelGGL(k->fn, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(wm >= 8 ? 512 : wm * 128), g8_kernel_lds(*k), st, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_f16bf8_kernel launch");
 }

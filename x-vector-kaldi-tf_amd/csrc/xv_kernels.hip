@@ -1590,9 +1590,9 @@ int xv_set_tuning(int key, int value)
 {
     switch (key) {
     case XV_TUNE_TILE_ROWS:
-        if (value != 0 && value != 128 && value != 256 && value != 512)
-            return fail(XV_ERR_BAD_ARG, "xv_set_tuning: tile rows must be 0, 128, 256 or 512");
-        g_tile_rows.store(value == 512 ? 256 : value, std::memory_order_relaxed);
+        if (value != 0 && value != 128 && value != 256 && value != 512 && value != 1024)
+            return fail(XV_ERR_BAD_ARG, "xv_set_tuning: tile rows must be 0, 128, 256, 512 or 1024");
+        g_tile_rows.store(value >= 512 ? 256 : value, std::memory_order_relaxed);
         xv_internal_gemm8_tile_rows(value);
         return 0;
     case XV_TUNE_FIRST_TILES:
