@@ -855,7 +855,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide_kernel(const Gem
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            int piece = (slot_base(t) + j) * NI + (wave & 3);
+            int piece = (slot_base(t) + j) * NI + wave;
             piece = piece < NP ? piece : NP - 1;
             ag_off[t][j] = (uint32_t)piece * rowstep;
             al_off[t][j] = (uint32_t)piece * 1024u;
@@ -1040,34 +1040,31 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const G
 
     // ---- DMA streams (MUBUF buffer_load ... lds: an SGPR descriptor + ONE per-lane offset register per stream; the FLAT form needs a
     //      64-bit per-lane pointer and 64-bit VALU adds per piece).  A 16 KB weight tile (column tile 2nt + h, item u) =
-    //      [fp16 plane: pieces 0-7][8-bit plane: 8-15].
-    //      waves 0-3: the 8-bit plane of item (wave & 1) of a pair, column tile h = wave >> 1 (8 pieces) -- and the halo pieces;
-    //      waves 4-7: half (wave & 1) of the fp16 plane of an item, column tile h = (wave >> 1) & 1 (4 pieces per item).
+    //      [fp16 plane: pieces 0-7][8-bit plane: 8-15].  EVERY wave moves the same share of a pair, one piece at a time between
+    //      its MFMAs (an LDS-DMA instruction holds a wave's issue for 60-180 cycles: issued in bursts behind the barriers, the two
+    //      waves of a SIMD stood still together and the MFMA pipe with them -- 13 % of the loop at full clock):
+    //        8-bit planes (4 per pair: item e x column tile h): wave w moves pieces 4 (w >> 2) .. + 3 of plane e = w & 1, h = (w >> 1) & 1;
+    //        fp16 planes (2 per item): pieces 2 hidx, 2 hidx + 1 of plane h, hidx = (w & 1) + 2 (w >> 2);  halo piece 8 slot + w.
     const int dh = (wave >> 1) & 1;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(p.wt) + ((size_t)(2 * nt + dh) * n_stages) * B_BYTES, 0, 0x7ffffff0, XV_RSRC_FLAGS);
     const int wvoff = lane * 16;
-    int wsoff;                                         // this wave's share of the pair in flight (items 2P, 2P+1)
-    char *bdst;
-    if (wave < 4) {
-        wsoff = (wave & 1) * B_BYTES + B_PLANE;
-        bdst = lds + W16_X + (wave & 1) * B_BYTES + dh * B_PLANE;
-    } else {
-        wsoff = (wave & 1) * 4096;
-        bdst = lds + W16_H + dh * B_PLANE + (wave & 1) * 4096;
-    }
+    const int hidx = (wave & 1) + 2 * (wave >> 2);
+    const int xs_rel = (wave & 1) * B_BYTES + B_PLANE + (wave >> 2) * 4096;        // source offsets inside a pair's 32 KB
+    const int hs_rel = hidx * 2048;
+    char *const xdst = lds + W16_X + (wave & 1) * B_BYTES + dh * B_PLANE + (wave >> 2) * 4096;
+    char *const hdst = lds + W16_H + dh * B_PLANE + hidx * 2048;
+    int wsoff = 0;                                     // the pair in flight (items 2P, 2P+1)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(p.x) + (m0 - left) * (long)xrow_bytes, 0, 0x7ffffff0, XV_RSRC_FLAGS);
     const int xvoff = (lane >> 3) * (int)xrow_bytes + (lane & 7) * 16;     // (264 rows of a workgroup: far below 2^31 bytes)
     constexpr int NP = W_BM / 8 + 1;
     {   // prologue: pair 0 and the halo tile of slab 0
-        if (wave < 4) {
-            XV_BLDS16_X4(wrs, bdst, wvoff, wsoff, 0);
-            XV_BLDS16_X4(wrs, bdst + 4096, wvoff, wsoff + 4096, 0);      // (a MUBUF immediate has 12 bits)
-        } else {
-            XV_BLDS16_X4(wrs, bdst, wvoff, wsoff, 0);
-            XV_BLDS16_X4(wrs, bdst + B_BYTES, wvoff, wsoff + B_BYTES, 0);
-        }
+        XV_BLDS16_X4(wrs, xdst, wvoff, wsoff + xs_rel, 0);
+        XV_BLDS16(wrs, hdst, wvoff, wsoff + hs_rel, 0);
+        XV_BLDS16(wrs, hdst, wvoff, wsoff + hs_rel, 1024);
+        XV_BLDS16(wrs, hdst + B_BYTES, wvoff, wsoff + hs_rel + B_BYTES, 0);
+        XV_BLDS16(wrs, hdst + B_BYTES, wvoff, wsoff + hs_rel + B_BYTES, 1024);
         for (int piece = wave; piece < NP; piece += NW) XV_BLDS16(xrs, Abuf + piece * 1024, xvoff, piece * 8 * (int)xrow_bytes, 0);
     }
     wsoff += (n_pairs > 1) ? 2 * B_BYTES : 0;          // -> pair 1
@@ -1167,8 +1164,8 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const G
 
     // halo pieces: the next ODD slab goes out in DMA slots 0 .. K-3 of the period (slot 2j: behind barrier 1 of pair j, 2j+1:
     // behind barrier 2), the next EVEN slab in slots K+1 .. 2K-2 -- between the last read of the buffer's old slab and the
-    // barrier in front of the first read of the new one.  NS one-piece-per-wave slots dealt over K-2 DMA slots, waves 0-3.
-    constexpr int NI = 4;
+    // barrier in front of the first read of the new one.  NS one-piece-per-wave slots dealt over K-2 DMA slots, all waves.
+    constexpr int NI = 8;
     constexpr int DT = KT - 2;
     constexpr int NS = (NP + NI - 1) / NI;
     constexpr int PW = (NS + DT - 1) / DT;
@@ -1180,7 +1177,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const G
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            int piece = (slot_base(t) + j) * NI + (wave & 3);
+            int piece = (slot_base(t) + j) * NI + wave;
             piece = piece < NP ? piece : NP - 1;
             ag_off[t][j] = piece * rowstep;
             al_off[t][j] = piece * 1024;
@@ -1216,7 +1213,7 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const G
         const int a_odd = (c + 1) * SROW, a_even = ce * SROW;
         char *d_odd = Abuf + W_A_BYTES;
         char *d_even = Abuf + (ce & 1) * W_A_BYTES;
-        auto halo = [&](auto D) {                       // DMA slot d of the period (waves 0-3)
+        auto halo = [&](auto D) {                       // DMA slot d of the period
             constexpr int d = decltype(D)::value;
             if constexpr (d <= KT - 3) {
 #pragma unroll
@@ -1241,6 +1238,13 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const G
             constexpr int b0 = u0 / KT, b1 = u1 / KT, bn = un / KT;                      // halo buffers
             int lz = rowbase;
             asm volatile("" : "+v"(lz));
+            auto none = [] {};
+            // this wave's DMA pieces of the next pair (X planes and H0 behind barrier 1, H1 and the halo pieces behind barrier 2)
+            auto dx = [&](auto I) { return [&] { XV_BLDS16(wrs, xdst, wvoff, wsoff + xs_rel, decltype(I)::value * 1024); }; };
+            auto dh0 = [&](auto I) { return [&] { XV_BLDS16(wrs, hdst, wvoff, wsoff + hs_rel, decltype(I)::value * 1024); }; };
+            auto dh1 = [&](auto I) { return [&] { XV_BLDS16(wrs, hdst + B_BYTES, wvoff, wsoff + hs_rel + B_BYTES, decltype(I)::value * 1024); }; };
+            auto halo1 = [&] { halo(std::integral_constant<int, 2 * j>{}); };
+            auto halo2 = [&] { halo(std::integral_constant<int, 2 * j + 1>{}); };
             job_h(I0{}, I0{}, ld_bxl(I0{}), ld_bxh(I0{}), ld_bxl(I1{}), ld_bxh(I1{}),
                   ld_axl(I0{}, px, 0), ld_axh(I0{}, px2, 0), ld_axl(I1{}, px, 0), ld_axh(I1{}, px2, 0));                                  // J1
             job_h(I1{}, I1{}, ld_bxl(I2{}), ld_bxh(I2{}), ld_bxl(I3{}), ld_bxh(I3{}), ld_ah(I0{}, I0{}, ah0, b0, 2), ld_ah(I0{}, I1{}, ah0, b0, 2));  // J2
@@ -1248,31 +1252,19 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const G
             // newest are the AH reads of J2) -- the X regions may be overwritten.  No full drain: the AH reads stay in flight.
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(2)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (wave < 4) {
-                XV_BLDS16_X4(wrs, bdst, wvoff, wsoff, 0);
-                XV_BLDS16_X4(wrs, bdst + 4096, wvoff, wsoff + 4096, 0);      // (a MUBUF immediate has 12 bits)
-                halo(std::integral_constant<int, 2 * j>{});
-            } else {
-                XV_BLDS16_X4(wrs, bdst, wvoff, wsoff, 0);
-            }
-            job_x(I0{}, ld_ah(I1{}, I0{}, ah0, b0, 3), ld_ah(I1{}, I1{}, ah0, b0, 3));                                                     // J3
+            job_x(I0{}, ld_ah(I1{}, I0{}, ah0, b0, 3), ld_ah(I1{}, I1{}, ah0, b0, 3), dx(I0{}), none, dx(I1{}), none, dx(I2{}), none);    // J3
             const char *ah1 = lds + addr_h((u1 % KT) * p.dil, lz);       // (ah0 is dead from here on)
-            job_h(I0{}, I2{}, ld_axl(I0{}, px, 1), ld_axh(I0{}, px2, 1), ld_axl(I1{}, px, 1), ld_axh(I1{}, px2, 1));                      // J4
-            job_h(I1{}, I3{}, ld_ah(I0{}, I0{}, ah1, b1, 0), ld_ah(I0{}, I1{}, ah1, b1, 0));                                               // J5
+            job_h(I0{}, I2{}, ld_axl(I0{}, px, 1), ld_axh(I0{}, px2, 1), ld_axl(I1{}, px, 1), ld_axh(I1{}, px2, 1), none, dx(I3{}), none, dh0(I0{}));  // J4
+            job_h(I1{}, I3{}, ld_ah(I0{}, I0{}, ah1, b1, 0), ld_ah(I0{}, I1{}, ah1, b1, 0), none, dh0(I1{}), none, halo1);                // J5
             job_x(I1{}, ld_bh(I0{}, 1), ld_bh(I1{}, 1), ld_bh(I2{}, 1), ld_bh(I3{}, 1), ld_ah(I1{}, I0{}, ah1, b1, 1), ld_ah(I1{}, I1{}, ah1, b1, 1));  // J6
             job_h(I0{}, I0{}, ld_axl(I0{}, px, 2), ld_axh(I0{}, px2, 2), ld_axl(I1{}, px, 2), ld_axh(I1{}, px2, 2));                      // J7
             job_h(I1{}, I1{}, ld_ah(I0{}, I0{}, ah1, b1, 2), ld_ah(I0{}, I1{}, ah1, b1, 2));                                               // J8
             // barrier 2.  Nothing read since barrier 1 is rewritten behind it that an MFMA has not consumed already (BH of u1: J7).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (wave < 4) {
-                halo(std::integral_constant<int, 2 * j + 1>{});
-            } else {
-                XV_BLDS16_X4(wrs, bdst + B_BYTES, wvoff, wsoff + B_BYTES, 0);
-            }
+            job_x(I2{}, ld_ah(I1{}, I0{}, ah1, b1, 3), ld_ah(I1{}, I1{}, ah1, b1, 3), dh1(I0{}), none, dh1(I1{}), none, halo2);           // J9
             wsoff += pairs_left > 0 ? 2 * B_BYTES : 0;
             --pairs_left;
-            job_x(I2{}, ld_ah(I1{}, I0{}, ah1, b1, 3), ld_ah(I1{}, I1{}, ah1, b1, 3));                                                     // J9
             job_h(I0{}, I2{}, ld_axl(I0{}, px, 3), ld_axh(I0{}, px2, 3), ld_axl(I1{}, px, 3), ld_axh(I1{}, px2, 3));                      // J10
             // the next pair's addresses (ah1, px, px2 are dead from here on)
             const int ahn_i = addr_h((un % KT) * p.dil, lz);
@@ -1281,7 +1273,6 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const G
             job_x(I3{}, ld_ah(I0{}, I0{}, ahn, bn, 0), ld_ah(I0{}, I1{}, ahn, bn, 0));                                                     // J11
             // J12: the weights of column tile t are dead behind its two MFMAs -- BH is refilled tile by tile (no X job can cover this
             // refill: see the note on the order above), AH[1] behind the last use of each of its halves
-            auto none = [] {};
             job_h(I1{}, I3{}, none, ld_bh(I0{}, 0), none, ld_bh(I1{}, 0), none, ld_bh(I2{}, 0), ld_ah(I1{}, I0{}, ahn, bn, 1),
                   [&] { ld_bh(I3{}, 0)(); ld_ah(I1{}, I1{}, ahn, bn, 1)(); });                                                              // J12
             ah0 = ahn;
