@@ -501,6 +501,33 @@ def test_compressed_matrices_through_the_in_place_reader(tmp_path):
     assert n == len(want)
 
 
+def test_a_compressed_record_the_decoder_refuses_raises_instead_of_spinning():
+    """"CM " header with rows = -1.  The native decoder stops at it with nothing decoded; the in-place reader used
+    to go back to the float-matrix scanner, which stopped at the same byte -- for ever, one arena per turn.  Now the record goes to the
+    generic reader, which raises as it does for any malformed matrix; good records in front of it still come out."""
+    import io, struct
+    from fixture_inputs import encode_cm_record
+    if kaldi_io._host_lib() is None or not hasattr(kaldi_io._host_lib(), "xv_ark_decode_cm"):
+        pytest.skip("host library not built")
+    rng = np.random.default_rng(3)
+    good = encode_cm_record("good", rng.standard_normal((12, 5)).astype(np.float32))
+    bad = b"utt1 \0BCM " + struct.pack("<ffii", -1.0, 2.0, -1, 5) + bytes(64)
+    for raw, n_good in ((bad, 0), (good + bad, 1), (good + good + bad + good, 2)):
+        taken = []
+
+        def take():
+            assert len(taken) < 20, "the reader keeps taking arenas at a record it cannot decode"
+            taken.append(kaldi_io.ArkArena(1 << 16))
+            return taken[-1]
+        keys = []
+        with pytest.raises(kaldi_io.BadInputFormat):
+            for item in kaldi_io.scan_mat_ark_windows(io.BytesIO(raw), take, None, lambda a: None):
+                keys += item[0]
+        assert keys == ["good"] * n_good
+        with pytest.raises(kaldi_io.BadInputFormat):                  # the generic reader on the same bytes
+            list(kaldi_io.read_mat_ark(io.BytesIO(raw)))
+
+
 def test_subset_scp_tables_are_read_in_place(tmp_path):
     """A feats.scp that lists a SUBSET of its ark, in the ark's order (utterances removed by a filter -- the usual state of a Kaldi
     data directory): the in-place reader skips the records the table leaves out instead of giving up at the first gap and reading

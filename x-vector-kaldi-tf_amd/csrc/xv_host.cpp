@@ -76,18 +76,24 @@ int64_t xv_ark_index_fd(int fd, int64_t pos, int64_t end, int64_t max_records, i
             memcpy(&r, hdr + h + tag + 8, 4);
             memcpy(&c, hdr + h + tag + 12, 4);
             if (r < 0 || c < 0) { *stop = 1; break; }
+            // (payload checked against the range BEFORE it is added: r x c near 2^31 x 2^31 times the element size leaves int64 and
+            // "after" would move backwards)
+            const uint64_t room = (uint64_t)(end - pos), esz = kind == 2 ? 2 : 1;
+            if ((uint64_t)c * 8 > room || (c != 0 && (uint64_t)r > (room / esz) / (uint64_t)c)) { *stop = 1; break; }
             after = pos + (int64_t)h + (int64_t)tag + 16 +
-                    (kind == 1 ? (int64_t)c * 8 + (int64_t)r * (int64_t)c : (int64_t)r * (int64_t)c * (kind == 2 ? 2 : 1));
+                    (kind == 1 ? (int64_t)c * 8 + (int64_t)r * (int64_t)c : (int64_t)r * (int64_t)c * (int64_t)esz);
         } else {
             if (hdr[h] != 0 || hdr[h + 1] != 'B' || hdr[h + 2] != 'F' || hdr[h + 3] != 'M' || hdr[h + 4] != ' ' || hdr[h + 5] != 4 ||
                 hdr[h + 10] != 4) { *stop = 1; break; }
             memcpy(&r, hdr + h + 6, 4);
             memcpy(&c, hdr + h + 11, 4);
             if (r < 0 || c < 0) { *stop = 1; break; }
+            if (c != 0 && (uint64_t)r > ((uint64_t)(end - pos) / 4) / (uint64_t)c) { *stop = 1; break; }
             after = pos + (int64_t)h + 15 + (int64_t)r * (int64_t)c * 4;
         }
-        if (after > end) { *stop = 1; break; }                     // truncated payload
+        if (after > end || after <= pos) { *stop = 1; break; }     // truncated payload
         if (keys) {
+            if (memchr(hdr, '\n', klen)) { *stop = 1; break; }     // keys come back newline-separated: such a key cannot
             if (kw + (int64_t)klen + 1 > keys_cap) { *stop = 2; break; }
             memcpy(keys + kw, hdr, klen);
             kw += (int64_t)klen;

@@ -260,13 +260,23 @@ def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
     concatenates the ranks' scp parts -- whose lines name ``<ark>.r`` -- into ``<scp>`` in rank order = input order.  No process
     group exists in this mode: nothing waits for RCCL's bring-up (about a third of a short job's wall clock), N ranks write N
     files at once, and what is left of a job that dies late are the complete shards of the ranks that finished.  The ranks meet
-    through the file system: a part appears under its final name (``<scp>.r.part``) only when it is complete."""
+    through the file system: a part appears under its final name (``<scp>.r.<job>.part``) only when it is complete.  ``<job>`` tells
+    the parts of THIS job from what a job that died before its concatenation left behind (a rank 0 that reaches the wait loop first
+    would otherwise take a stale part for rank r's result): XVECTOR_JOB_TOKEN, else the rendezvous port + the launcher's pid,
+    which all ranks of a job share."""
+    import glob
     import time
+    token = os.environ.get("XVECTOR_JOB_TOKEN") or "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+    token = "".join(ch if ch.isalnum() or ch in "-_" else "_" for ch in token)
+    if rank == 0:
+        for stale in glob.glob(glob.escape(scp) + '.*.part'):        # other jobs' leftovers (also ranks >= world of a larger run)
+            if not stale.endswith('.%s.part' % token):
+                os.remove(stale)
     feat_scp, vad_scp, _ = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
     feats = kaldi_io.MatScp(feat_scp)
     vad = kaldi_io.VecScp(vad_scp) if vad_scp is not None else None
     jobclock.mark("tables opened")
-    my_ark, my_scp = '%s.%d' % (ark, rank), '%s.%d.part' % (scp, rank)
+    my_ark, my_scp = '%s.%d' % (ark, rank), '%s.%d.%s.part' % (scp, rank, token)
     for stale in (my_ark, my_scp):
         if os.path.exists(stale):
             os.remove(stale)
@@ -279,7 +289,7 @@ def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
     if rank != 0:
         return
     deadline = time.time() + float(os.environ.get("XVECTOR_SHARD_TIMEOUT", "3600"))
-    parts = ['%s.%d.part' % (scp, r) for r in range(world)]
+    parts = ['%s.%d.%s.part' % (scp, r, token) for r in range(world)]
     while not all(os.path.exists(p) for p in parts):
         if time.time() > deadline:
             raise RuntimeError("sharded extraction: still waiting for %s" % ", ".join(p for p in parts if not os.path.exists(p)))

@@ -555,6 +555,9 @@ def _read_compressed_mat(fd, fmt):
     hdr = _read_exact(fd, 16)
     gmin, grange = np.frombuffer(hdr[:8], dtype="<f4")
     rows, cols = (int(v) for v in np.frombuffer(hdr[8:], dtype="<i4"))
+    if rows < 0 or cols < 0:
+        # (the reference would go on with read(-n), i.e. swallow the rest of the stream as this matrix's bytes)
+        raise BadInputFormat("compressed matrix header with negative dimensions: %d x %d" % (rows, cols))
     if fmt == "CM ":
         pct = np.frombuffer(_read_exact(fd, cols * 8), dtype="<u2").reshape(cols, 4)
         q = (gmin + grange * _U16_STEP * pct.astype(np.float32)).astype(np.float32)   # [cols,4]
@@ -1154,6 +1157,7 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
                         # while its tail is still needed: the tail goes to the front of the next arena instead
                         stop.value = 0
                         break
+                    cm_from = pos
                     while True:
                         darena = take_arena()
                         n = lib.xv_ark_decode_cm(arena.addr, pos, end, _SCAN_MAX, darena.addr, len(darena), key_off.ctypes.data,
@@ -1170,8 +1174,11 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
                             break                               # (a single matrix larger than an arena: the generic reader takes it)
                     if stop.value == 3:
                         stop.value = 1                          # ONE record through the generic reader below
-                    elif stop.value == 1:
+                    elif stop.value == 1 and pos > cm_from:
                         continue                                # another record type follows: back to the float-matrix scanner
+                    # (stop == 1 with nothing decoded: a "CM" record the decoder refuses -- negative dimensions, say.  Going back to
+                    # the scanner would stop at the same byte again, for ever, an arena per turn: the generic reader takes the record
+                    # and raises on it as it does for any malformed matrix)
                 break
             item = flush()
             if item:
@@ -1253,9 +1260,15 @@ def index_mat_ark_file(stream, with_keys=True):
     offsets = np.concatenate(offs + [np.array([pos], np.int64)]) if offs else np.array([pos], np.int64)
     keys = None
     if with_keys:
-        keys = [k.strip() for k in b"".join(key_parts).decode().split("\n")[:-1]]
-        bad = [k for k in keys if _KEY_OK.match(k) is None]
-        assert not bad, "malformed key %r" % bad[0]
+        # record keys are arbitrary bytes up to the first space: one that is not UTF-8, or that does not match the table grammar, or
+        # a count that does not line up with the offsets sends the caller to the documented fallback (None: the generic reader,
+        # which raises where the reference's would) -- byte-range sharding must never pair a vector with the wrong key
+        try:
+            keys = [k.strip() for k in b"".join(key_parts).decode().split("\n")[:-1]]
+        except UnicodeDecodeError:
+            return None
+        if len(keys) != len(offsets) - 1 or any(_KEY_OK.match(k) is None for k in keys):
+            return None
     return offsets, (np.concatenate(rows_all) if rows_all else np.zeros(0, np.int32)), \
         (np.concatenate(cols_all) if cols_all else np.zeros(0, np.int32)), keys
 

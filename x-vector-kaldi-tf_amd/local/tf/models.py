@@ -619,7 +619,13 @@ class Model(object):
             # about a second) while this one extracts; nothing is written to the output before the exchange
             rank, world = xdist.group_shape()
             if xdist.group_wanted():
-                xdist.init_process_group_async()
+                if world > 1:
+                    xdist.init_process_group_async()
+                else:
+                    # a forced one-rank group (XV_FORCE_DIST=1): this process emits vectors as windows finish, and fd 1 points at
+                    # stderr while a communicator comes up (dist.init_process_group) -- an 'ark:-' output would lose records to
+                    # stderr.  Nothing to overlap with in this mode: the group comes up first.
+                    xdist.wait_process_group()
         else:
             # the caller already gave every rank its own part of the input (extract_embedding.py shards scp tables by line
             # range): behave as a single process and leave the exchange to the caller
