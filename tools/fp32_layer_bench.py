@@ -11,6 +11,9 @@ SHAPES = ((24, 512, 5), (512, 512, 5), (512, 512, 7), (512, 512, 1), (512, 1536,
 for (cin, cout, K) in (SHAPES if len(sys.argv) < 3 else SHAPES[int(sys.argv[2]):int(sys.argv[2]) + 1]):
     w = torch.randn((K * cin, cout), device=dev) / (K * cin) ** 0.5
     wp = hiplib.pack_weights(w)
+    torch.manual_seed(cin * 7 + cout + K)
+    w = torch.randn((K * cin, cout), device=dev) / (K * cin) ** 0.5
+    wp = hiplib.pack_weights(w)
     x = torch.relu(torch.randn((R, cin), device=dev))
     bias = torch.zeros(cout, device=dev); rv = torch.ones(R, dtype=torch.uint8, device=dev)
     scale = torch.ones(cout, device=dev); shift = torch.zeros(cout, device=dev)
@@ -26,5 +29,6 @@ for (cin, cout, K) in (SHAPES if len(sys.argv) < 3 else SHAPES[int(sys.argv[2]):
     ts.sort(); ms = ts[len(ts) // 2]
     fl = 2.0 * R * cin * cout * K
     tot_ms += ms; tot_fl += fl
-    print("%4d -> %4d K=%d: %.3f ms  %.1f TF = %.3f of 157.3   (output %.2f GB at %.2f TB/s)" % (cin, cout, K, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3, R * cout * 4 / 1e9, R * cout * 4 / ms / 1e9))
+    bits = int(y.view(torch.int32).to(torch.int64).sum().item())      # (a checksum of the bit patterns: XV_FP32_DMA=0 / 1 must agree)
+    print("%4d -> %4d K=%d: %.3f ms  %.1f TF = %.3f of 157.3   (output %.2f GB at %.2f TB/s)  bits %d" % (cin, cout, K, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3, R * cout * 4 / 1e9, R * cout * 4 / ms / 1e9, bits))
 print("all five: %.3f ms, %.1f TF = %.3f" % (tot_ms, tot_fl / tot_ms / 1e9, tot_fl / tot_ms / 1e9 / 157.3))

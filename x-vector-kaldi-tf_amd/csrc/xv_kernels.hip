@@ -1246,6 +1246,190 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_bf16x3_kernel launch");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exact-fp32 GEMM, DMA-fed (round 4): the arithmetic of tdnn_gemm_kernel -- the same v_mfma_f32_32x32x2_f32 sequence on the same
+// fragments in the same order, hence bit-identical results -- in the form of the 16-bit kernels:
+//  * both operands go global -> LDS by buffer_load ... lds straight from the fp32 rows x[R, Cin] and the packed weights wp[Cout, K Cin]
+//    as they lie (no staging registers, no ds_write, no exec-masked blocks of bounds logic: rows and columns outside the matrices
+//    come back as zeros from the buffer descriptors' range check);
+//  * an LDS row is 128 bytes (32 channels), unpadded; the 16-byte slot s of row r holds channel group s ^ ((r >> 1) & 7) -- the
+//    swizzle is applied on the GLOBAL side of the DMA (lane (row, slot) of an 8-row piece fetches group slot ^ swz), fragment reads
+//    are conflict-free for every tap offset;
+//  * K is a template constant, the stage loop is unrolled over the taps of a slab; ONE barrier per stage, placed in front of the last
+//    quarter of the stage's MFMAs: behind it the DMA of stage s + 2 goes out and the first fragments of stage s + 1 are read under the
+//    remaining 16 MFMAs (two fragment sets, k-group granularity) -- no wave starts a stage with an empty pipe.
+// Needs Cin % 32 == 0, 16-byte aligned rows, matrices below 2^31 bytes, the row-wise epilogue (else tdnn_gemm_kernel).
+// ------------------------------------------------------------------------------------------------
+#define XV_BLDS16(rsrc, lptr, voff, soff, imm)                                                                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lptr), 16, voff, soff, imm, 0)
+constexpr int XV_RSRC_FLAGS = 0x00020000;              // raw buffer, 32-bit data format (gfx9 family dword 3)
+constexpr int F_SROW = 128;
+constexpr int F_A_BYTES = (BM + MAX_SPAN) * F_SROW;    // 17408
+constexpr int F_B_BYTES = BN * F_SROW;                 // 16384
+constexpr int F_OPER = 2 * F_A_BYTES + 2 * F_B_BYTES;  // 67584 = the epilogue's 128 x 132 fp32 tile
+constexpr size_t F_LDS_BYTES = (size_t)F_OPER + BM;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void f_static_for(F &f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        f_static_for<I + 1, N>(f);
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(NT, 2) void tdnn_gemm_dma_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char flds[];
+    char *Abuf = flds;                                 // [2][BM + 8 rows][128 B]
+    char *Bbuf = flds + 2 * F_A_BYTES;                 // [2][BN cols][128 B]
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(flds + F_OPER);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nwg = p.n_mt * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int span = (KT - 1) * p.dil;
+    const int left = span >> 1;
+    const int n_chunks = p.cin / BK;
+    const int n_stages = n_chunks * KT;
+
+    if (tid < BM) {
+        const long gr = m0 + tid;
+        Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
+    }
+
+    // ---- DMA: piece pc = 8 rows (columns) x 128 bytes; wave w moves pieces w, w + 4, ...: their parity is the wave's, and with it
+    // bit 2 of (row >> 1) & 7 -- the swizzle of the row a lane moves is a per-lane constant.  The row part of an address sits in
+    // the VGPR offset (what the range check looks at), the channel / tap part in the scalar offset.
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)(p.R * p.ldx * 4), XV_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, (int)((long)p.cout * p.kred * 4), XV_RSRC_FLAGS);
+    const int slotb = ((lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7)) << 4;
+    const int arow_bytes = p.ldx * 4, brow_bytes = p.kred * 4;
+    const int va0 = (int)(m0 - left + 8 * wave + (lane >> 3)) * arow_bytes + slotb;        // piece `wave`; piece wave + 4 j: + 32 j rows
+    const int vb0 = (n0 + 8 * wave + (lane >> 3)) * brow_bytes + slotb;
+    constexpr int NP = KT == 1 ? BM / 8 : BM / 8 + 1;   // pieces of a halo tile (BM + span rows, span <= 8)
+    auto dma_b = [&](int stage, int buf) {              // the weight tile of (slab, tap) = stage, four pieces per wave
+        const int st = stage < n_stages ? stage : n_stages - 1;
+        const int c = st / KT, t = st - c * KT;
+        const int so = (t * p.cin + c * BK) * 4;
+        char *dst = Bbuf + buf * F_B_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) XV_BLDS16(brs, dst + j * 4096, vb0 + j * 32 * brow_bytes, so, 0);
+    };
+    auto dma_a_piece = [&](int chunk, int j) {          // piece wave + 4 j of slab `chunk` (clamped: the tail rewrites identical bytes)
+        const int c = chunk < n_chunks ? chunk : n_chunks - 1;
+        XV_BLDS16(ars, Abuf + (c & 1) * F_A_BYTES + (wave + 4 * j) * 1024, va0 + j * 32 * arow_bytes, c * BK * 4, 0);
+    };
+    auto dma_a_all = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_a_piece(chunk, j);
+        if (NP > 16 && wave == 0) dma_a_piece(chunk, 4);
+    };
+    dma_b(0, 0);
+    dma_b(1, 1);
+    dma_a_all(0);
+    if (KT == 1) dma_a_all(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    struct Fr { f32x4 a0, a1, b0, b1; };
+    // fragment addresses: lane (row l & 31, k half kh = l >> 5) reads channels 8 kk + 4 kh .. + 3 = slot 2 kk + kh of its row
+    const int kh = lane >> 5;
+    int pa[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int lr0 = wr * 64 + (lane & 31) + t * p.dil;
+        pa[t] = lr0 * F_SROW + ((((lr0 >> 1) & 7) ^ kh) << 4);          // + 32 rows: + 4096, the same swizzle; k group kk: ^ (kk << 5)
+    }
+    const int bcol = wc * 64 + (lane & 31);
+    const int pb = 2 * F_A_BYTES + bcol * F_SROW + ((((bcol >> 1) & 7) ^ kh) << 4);
+    auto load = [&](Fr &X, int abase, int bbase, int kk) {
+        X.a0 = *reinterpret_cast<const f32x4 *>(flds + (abase ^ (kk << 5)));
+        X.a1 = *reinterpret_cast<const f32x4 *>(flds + (abase ^ (kk << 5)) + 32 * F_SROW);
+        X.b0 = *reinterpret_cast<const f32x4 *>(flds + (bbase ^ (kk << 5)));
+        X.b1 = *reinterpret_cast<const f32x4 *>(flds + (bbase ^ (kk << 5)) + 32 * F_SROW);
+    };
+    auto mma = [&](const Fr &X) {                        // (the order of tdnn_gemm_kernel: results are bit-identical)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.a0[j], X.b0[j], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.a0[j], X.b1[j], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.a1[j], X.b0[j], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.a1[j], X.b1[j], acc11, 0, 0, 0);
+        }
+    };
+    auto pin = [&]() {                                   // 16 MFMAs, the four fragment reads behind the first four
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // halo pieces of the NEXT slab, dealt over taps 0 .. K-2 of the current one (K > 1): five one-piece-per-wave slots
+    constexpr int DT = KT == 1 ? 1 : KT - 1;
+    constexpr int NS = KT == 1 ? 4 : 5;
+    auto slots_of = [](int t) constexpr { return t < DT ? (NS + DT - 1 - t) / DT : 0; };
+    auto slot_base = [](int t) constexpr { int b = 0; for (int u = 0; u < t; ++u) b += (NS + DT - 1 - u) / DT; return b; };
+
+    Fr F, G;
+    load(F, pa[0], pb, 0);
+    int s = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int abuf = (c & 1) * F_A_BYTES;
+        auto tap = [&](auto TT) {
+            constexpr int t = decltype(TT)::value;
+            const int ab = pa[t] + abuf, bb = pb + (s & 1) * F_B_BYTES;
+            load(G, ab, bb, 1);
+            mma(F);
+            pin();
+            load(F, ab, bb, 2);
+            mma(G);
+            pin();
+            load(G, ab, bb, 3);
+            mma(F);
+            pin();
+            // every fragment of stage s is in registers (the reads of k group 3 went out 1024 MFMA cycles ago), stage s + 1 has landed
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_b(s + 2, s & 1);
+            if constexpr (KT == 1) {
+                dma_a_all(s + 2);
+            } else if constexpr (t < DT) {
+#pragma unroll
+                for (int j = 0; j < slots_of(t); ++j) {
+                    const int jj = slot_base(t) + j;
+                    if (jj < 4 || wave == 0) dma_a_piece(c + 1, jj);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (t + 1 < KT) load(F, pa[t + 1] + abuf, pb + ((s + 1) & 1) * F_B_BYTES, 0);
+            else load(F, pa[0] + (F_A_BYTES - abuf), pb + ((s + 1) & 1) * F_B_BYTES, 0);      // first tap of the next slab (tail: harmless)
+            mma(G);
+            pin();
+            ++s;
+        };
+        f_static_for<0, KT>(tap);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the tail's clamped pieces must have landed before the tile below reuses the LDS)
+    __syncthreads();
+    gemm_epilogue_rows<BM>(p, reinterpret_cast<float *>(flds), Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11);
+}
+
 int launch_gemm(const GemmParams &p0, hipStream_t st)
 {
     GemmParams p = p0;
@@ -1268,6 +1452,7 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
     typedef void (*kern_t)(const GemmParams);
     const kern_t all[] = {tdnn_gemm_kernel<true, 128>, tdnn_gemm_kernel<false, 128>, tdnn_gemm_kernel<true, 64>,
                           tdnn_gemm_kernel<false, 64>};
+    const kern_t dma_all[] = {tdnn_gemm_dma_kernel<1>, tdnn_gemm_dma_kernel<3>, tdnn_gemm_dma_kernel<5>, tdnn_gemm_dma_kernel<7>};
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1276,9 +1461,24 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
         }
+        for (kern_t k : dma_all) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        }
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const dim3 grid((unsigned)(p.n_mt * p.n_nt));
+    // the DMA-fed form (128-row tiles): whole 32-channel slabs, 16-byte aligned rows, byte offsets that fit the descriptors' 32 bits
+    static const bool dma_on = !(std::getenv("XV_FP32_DMA") != nullptr && std::getenv("XV_FP32_DMA")[0] == '0');
+    const bool dma_ok = dma_on && !small && vec && p.vec_out && (p.cin % BK) == 0 && (p.K == 1 || p.K == 3 || p.K == 5 || p.K == 7) &&
+                        (p.R + BM + MAX_SPAN) * (long)p.ldx * 4 < (1l << 31) && (long)(p.cout + BN) * p.kred * 4 < (1l << 31);
+    if (dma_ok) {
+        const kern_t dk = p.K == 1 ? tdnn_gemm_dma_kernel<1> : p.K == 3 ? tdnn_gemm_dma_kernel<3> : p.K == 5 ? tdnn_gemm_dma_kernel<5>
+                                                                                                             : tdnn_gemm_dma_kernel<7>;
+        hipLaunchKernelGGL(dk, grid, dim3(NT), F_LDS_BYTES, st, p);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_dma_kernel launch");
+    }
     hipLaunchKernelGGL(all[(small ? 2 : 0) + (vec ? 0 : 1)], grid, dim3(NT), GEMM_LDS_BYTES, st, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_kernel launch");
