@@ -182,6 +182,32 @@ def bench_train(args, rank, world, dev, topo, feat):
         dist.destroy_process_group()
 
 
+def _trained_checkpoint_leg(dev, feat):
+    """The arithmetic the accuracy guard admits for a checkpoint that was TRAINED (300 Adam steps of the product's own training step
+    on 64 synthetic speakers), its probe values, and its parity against the fp64 oracle on MFCC-like utterances -- every other
+    weight set of this line is a draw (synthetic.trained_like)."""
+    from oracle import oracle                                  # the checker, here as in the parity leg
+    from xvector_amd import engine, synthetic, topology as tp
+    topo = tp.get("ModelWithoutDropout")
+    w, info = synthetic.trained_checkpoint(topo, feat, n_spk=64, steps=300, seed=3, device=dev)
+    mats = synthetic.mfcc_like([25, 120, 300, 411], feat, seed=5)
+    refs = [oracle.embed_utterance(m, w, topo, 25, 10000, np.float64) for m in mats]
+    res = {"training": info, "parity_utterances": len(mats), "limit_f16bf8_vs_bf16x3": engine.PROBE_LIMIT_F16BF8}
+    for precision in ("f16bf8", "bf16x3", "fp32"):
+        model = engine.select_model(w, topo, dev, precision=precision)
+        ex = engine.Extractor(model, 25, 10000)
+        vecs = ex.extract(mats)
+        sel = model.selection
+        res[precision] = {"selected": ("bf16x3" if ex.demoted and sel["selected"] == "f16bf8" else sel["selected"]),
+                          "load_time_probe": sel.get("f16bf8_vs_bf16x3"), "run_time_probe": ex.stats.get("probe_rel_l2_max"),
+                          "demoted_at_run_time": bool(ex.demoted),
+                          "parity_rel_l2_max_vs_fp64_oracle": float(max(oracle.rel_l2(v, r) for v, r in zip(vecs, refs)))}
+    res["selected"] = res["f16bf8"]["selected"]
+    res["probe"] = res["f16bf8"]["load_time_probe"]
+    res["parity"] = res["f16bf8"]["parity_rel_l2_max_vs_fp64_oracle"]
+    return res
+
+
 def _kernel_source_sha():
     """Hash of the kernel sources: profiles/traffic.json is only quoted when it was measured on these very kernels."""
     import hashlib
@@ -889,6 +915,10 @@ def main():
                                               "AM-softmax head, Adam; 10 timed steps after 2" % (args.tmin, args.tmax))
         except Exception as e:
             out["train_step"] = {"error": repr(e)}
+        try:
+            out["trained_checkpoint"] = _trained_checkpoint_leg(dev, feat)
+        except Exception as e:
+            out["trained_checkpoint"] = {"error": repr(e)}
     print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -209,7 +209,8 @@ def eval_dnn(args):
         # the model and extracts (nothing is written to the output before that gather, so the stdout redirection of
         # dist.init_process_group cannot hit an 'ark:-' stream)
         from xvector_amd import dist as xdist
-        xdist.init_process_group_async()
+        # (XVECTOR_GROUP_START=early: from the start of the job, next to the model load -- the round-3 behaviour, for A/B)
+        xdist.init_process_group_async(after_mark=None if os.environ.get("XVECTOR_GROUP_START") == "early" else "first window launched")
     presharded = grouped and _is_scp_table(args.feature_rspecifier) and \
         (not args.vad_rspecifier or _is_scp_table(args.vad_rspecifier))
     model = Model()

@@ -70,18 +70,30 @@ def init_process_group(backend=None):
 _ASYNC = {}
 
 
-def init_process_group_async(backend=None):
+def init_process_group_async(backend=None, after_mark=None):
     """``init_process_group`` on a side thread: the communicator (RCCL: ~1 s for the first one of a process) comes up while the
-    caller loads the model and extracts; ``wait_process_group()`` joins it in front of the first collective.  Only for callers
-    that write nothing to stdout before that point (see the redirection in ``init_process_group``)."""
+    caller extracts; ``wait_process_group()`` joins it in front of the first collective.  Only for callers that write nothing to
+    stdout before that point (see the redirection in ``init_process_group``).
+    ``after_mark``: the bring-up starts when the job clock marks that name (jobclock.on; extract_embedding.py: "first window
+    launched") -- RCCL's kernel-load phase (0.8 s of its second) holds the HIP runtime's lock, and a model load next to it takes
+    0.9 s instead of 0.12: with the model on the device and the first window's kernels queued before the lock is taken, what
+    stalls next to the bring-up is the rest of the extraction, which it outlasts anyway.  ``wait_process_group`` releases a
+    thread that is still waiting for its mark (an input without a single window)."""
     import threading
     if "thread" in _ASYNC:
         return
     box = {}
+    go = threading.Event()
+    if after_mark is None:
+        go.set()
+    else:
+        from . import jobclock
+        jobclock.on(after_mark, go.set)
 
     def run():
         import time
         from . import jobclock
+        go.wait()
         t0 = time.time()
         try:
             box["value"] = init_process_group(backend)
@@ -89,7 +101,7 @@ def init_process_group_async(backend=None):
         except BaseException as e:          # noqa: B902 -- re-raised by wait_process_group
             box["error"] = e
     t = threading.Thread(target=run, name="xv-process-group", daemon=True)
-    _ASYNC.update(thread=t, box=box)
+    _ASYNC.update(thread=t, box=box, go=go)
     t.start()
 
 
@@ -98,6 +110,7 @@ def wait_process_group(backend=None):
     initialises here."""
     if "thread" not in _ASYNC:
         return init_process_group(backend)
+    _ASYNC["go"].set()
     _ASYNC["thread"].join()
     box = _ASYNC["box"]
     if "error" in box:

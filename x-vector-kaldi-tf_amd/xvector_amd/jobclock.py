@@ -28,8 +28,22 @@ def note(name, seconds):
     _NOTES.append((name, float(seconds)))
 
 
+_HOOKS = {}
+
+
+def on(name, fn):
+    """``fn()`` runs (once) when ``name`` is marked -- or at once if it already was.  The process group's side thread waits for
+    "first window launched" this way (dist.init_process_group_async)."""
+    if any(n == name for n, _ in _MARKS):
+        fn()
+    else:
+        _HOOKS.setdefault(name, []).append(fn)
+
+
 def mark(name):
     _MARKS.append((name, time.time()))
+    for fn in _HOOKS.pop(name, []):
+        fn()
 
 
 def once(name):

@@ -259,3 +259,38 @@ def make_utterances(n, tmin, tmax, feat_dim=23, seed=1234, scale=3.0, key_fmt="u
 SMALL_TOPOLOGY = dict(layer_sizes=[32, 32, 32, 32, 48], kernel_sizes=[5, 5, 7, 1, 1],
                       dilations=[1, 1, 1, 1, 1], embedding_sizes=[16, 16], activation="relu",
                       lrelu_alpha=0.2)
+
+
+def speaker_minibatches(n_steps, feat_dim=23, n_spk=64, batch=64, tmin=200, tmax=400, seed=0, noise=3.0, spread=2.0):
+    """Generator of ``(x float16 [batch, T, feat], labels int32 [batch])``: every speaker a mean vector ~ N(0, spread^2) under
+    frame noise ~ N(0, noise^2), one length T ~ U{tmin..tmax} per minibatch (create_egs.py:508-513) -- the training input of
+    BASELINE configs[4] and of ``trained_checkpoint`` below."""
+    rng = np.random.default_rng(seed)
+    spk = rng.standard_normal((n_spk, feat_dim)) * spread
+    for _ in range(n_steps):
+        T = int(rng.integers(tmin, tmax + 1))
+        lab = rng.integers(0, n_spk, batch)
+        yield (spk[lab][:, None, :] + rng.standard_normal((batch, T, feat_dim)) * noise).astype(np.float16), lab.astype(np.int32)
+
+
+def trained_checkpoint(topo, feat_dim=23, n_spk=64, steps=300, learning_rate=1e-3, seed=0, device="cuda:0", precision="bf16x3"):
+    """A checkpoint that was TRAINED, not sampled: reference-style initial weights (fan-in scaled), ``steps`` Adam steps of the
+    product's own training step (xvector_amd/trainer.py, the twin of Model.train_one_iteration, local/tf/models.py:216-305) on
+    ``speaker_minibatches`` -- the closest thing to a ``model_final`` (run_xvector.sh:88-107) an image without corpora can produce:
+    the weights, biases and BatchNorm moving statistics are whatever the optimiser and the data made them, not draws chosen by the
+    builder.  -> (weights {tf name: float32 ndarray}, dict(first_loss, last_loss, accuracy_last, seconds))."""
+    import time
+    from . import trainer
+    w = reference_init(topo, feat_dim, n_spk, seed=seed)
+    for k in list(w):                                         # fan-in scaled start so that activations stay O(1)
+        if k.endswith("/w:0") and w[k].ndim == 3:
+            w[k] = (w[k] * (np.sqrt(2.0 / (w[k].shape[0] * w[k].shape[1])) / 0.1)).astype(np.float32)
+    tr = trainer.Trainer(w, topo, device, precision=precision)
+    t0 = time.time()
+    first = last = acc = None
+    for x, lab in speaker_minibatches(steps, feat_dim, n_spk, seed=seed + 1):
+        last, acc = tr.step(x, lab, learning_rate)
+        if first is None:
+            first = last
+    out, _ = tr.export()
+    return out, dict(first_loss=float(first), last_loss=float(last), accuracy_last=float(acc), seconds=time.time() - t0, steps=steps)
