@@ -1371,7 +1371,11 @@ int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
         // the 16 x 16 MFMA form of the 256 x 256 tile pairs (slab, tap) items over two slabs: an even number of slabs
         const bool w16_ok = wide_ok && (p.n_chunks & 1) == 0;
         const bool wide_pays = ((p.R + 255) / 256) * (p.cout / 256) >= 512;
-        if (w16_ok && (want == 1024 || (want == 0 && wide_pays && g_wide16.load(std::memory_order_relaxed)))) wm = 16;
+        // The 16 x 16 form adds an element's products in another order than the 32 x 32 tiles (which agree among themselves bit for
+        // bit), so a shape that can take it ALWAYS takes it, whatever the number of rows: an utterance's x-vector must not depend on
+        // how many utterances share its batch -- on the sharding of a job over ranks, say (tests/test_gpu_eight_ranks.py: 8 ranks
+        // write the single process's bytes).  A batch too small to fill the chip twice with 256 x 256 tiles loses a few per cent.
+        if (w16_ok && (want == 1024 || (want == 0 && g_wide16.load(std::memory_order_relaxed)))) wm = 16;
         else if (wide_ok && (want == 512 || want == 1024 || (want == 0 && wide_pays))) wm = 8;
         else if (want == 256 || (want == 0 && p.K >= 5 && big_enough)) wm = 4;
     }
