@@ -411,7 +411,9 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
     return {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps,
             "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n_utts) / dt / 1e12,
             "tdnn_gemm_tflops": fl * steps / t_g / 1e12, "frac": fl * steps / t_g / MFMA_F32_PEAK, "peak_tflops": MFMA_F32_PEAK / 1e12,
-            "kernel": "tdnn_gemm_kernel (v_mfma_f32_32x32x2_f32); the last layer reduced to 8-row block statistics in its epilogue + stats_pool_blocks_kernel"}
+            "kernel": "tdnn_gemm_dma_kernel (layers 1-4: v_mfma_f32_32x32x2_f32 fed by buffer_load ... lds, bit-identical to tdnn_gemm_kernel, "
+                      "which still runs layer 0: Cin = 24 is no whole 32-channel slab); the last layer reduced to 8-row block statistics in its "
+                      "epilogue + stats_pool_blocks_kernel"}
 
 
 def _bf16x3_leg(args, weights, topo, dev, batches, n_utts, frames, feat, order, oracle_check):
@@ -719,8 +721,8 @@ def main():
         # twice that rate).  frac = MFMA-pipe time at nominal rates / measured kernel time.
         pair8 = getattr(model, "pair8", None) is not None
         units = _mfma_units(model, topo, feat, frames, n_utts) * args.steps
-        kern = {"kernel": "tdnn_first_kernel (layer 0, bf16x3) + tdnn_gemm_f16bf8_wide_kernel (layers 1-2: fp16 MFMA + scaled bf8 MFMA "
-                          "per product) + %s (layers 3+4 chained in registers, pooling statistics in its "
+        kern = {"kernel": "tdnn_first_kernel (layer 0, bf16x3) + tdnn_gemm_f16bf8_wide16_kernel (layers 1-2: fp16 MFMA + scaled bf8 MFMA "
+                          "per product on the 16 x 16 shapes, v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4) + %s (layers 3+4 chained in registers, pooling statistics in its "
                           "epilogue) per batch, embed FC (bf16x3) per step" %
                           ("tdnn_pair_pool_f16bf8_kernel" if pair8 else "tdnn_pair_pool_kernel (bf16x3)"),
                 "peak": fl_gemm / (units / MFMA_BF16_PEAK) / 1e12, "frac": units / t_gemm / MFMA_BF16_PEAK,

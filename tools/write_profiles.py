@@ -14,7 +14,7 @@ for f in sorted(os.listdir(d)):
 sha = h.hexdigest()[:16]
 stats = open("gpurun_out/round_stats.txt").read()
 rd = lambda n: open("gpurun_out/%s.json" % n).read().strip()
-GEMM = ("tdnn_gemm_bf16x3_kernel", "tdnn_gemm_f16bf8_wide_kernel", "tdnn_gemm_f16bf8_kernel", "tdnn_pair_pool_kernel", "tdnn_pair_pool_f16bf8_kernel", "tdnn_first_kernel")
+GEMM = ("tdnn_gemm_bf16x3_kernel", "tdnn_gemm_f16bf8_wide16_kernel", "tdnn_gemm_f16bf8_wide_kernel", "tdnn_gemm_f16bf8_kernel", "tdnn_pair_pool_kernel", "tdnn_pair_pool_f16bf8_kernel", "tdnn_first_kernel")
 tot = cnt = 0
 for l in stats.splitlines():
     if l.startswith(GEMM):
@@ -23,7 +23,7 @@ under = json.loads(rd("bench_under_prof"))
 hdr = ("# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-budget 0 --e2e-utts 0 --no-fp32-leg --no-extra-legs   (MI355X, default precision %s,\n"
        "#   commit %s, kernel sources %s; tools/profile_round.sh).  6 steps (1 warm-up + 5 timed) x 12 batches of <= 262144 rows + the 6 passes over the largest batch behind roofline.by_launch.\n"
        "#   tdnn_first_kernel<2, true>           = layer 0 (K=5, 23 MFCC dims in 24 columns -> 512; bf16x3 arithmetic, split8 output from the accumulators)\n"
-       "#   tdnn_gemm_f16bf8_wide_kernel<5|7, false> = layers 1 / 2 (K = 5 / 7, 512 -> 512): fp16 MFMA + scaled bf8 MFMA per product, 256 x 256 workgroup tiles\n"
+       "#   tdnn_gemm_f16bf8_wide16_kernel<5|7, false> = layers 1 / 2 (K = 5 / 7, 512 -> 512): fp16 MFMA + scaled bf8 MFMA per product on the 16 x 16 shapes, 256 x 256 workgroup tiles\n"
        "#   tdnn_pair_pool_f16bf8_kernel<2>      = layers 3 + 4 (K=1, 512 -> 512 -> 1536) chained in registers (f16bf8, a pair of waves per 32 frames) + 8-row block statistics of the pooling\n"
        "#   tdnn_gemm_bf16x3_kernel<false,0,false,2> = the per-step segment FC (embed_layer-0)\n"
        "# All GEMM kernels together: %d launches, total %.1f us, average %.2f us per launch  (bench.py roofline.avg_launch_ms %.4f under the profiler)\n"
@@ -56,7 +56,7 @@ open("profiles/%s_pmc.txt" % tag, "w").write(hdr2 + "\n".join(keep) + "\n")
 fs = sum(v["FETCH_SIZE"][2] for k, v in vals.items() if k.startswith(GEMM) and "FETCH_SIZE" in v)
 ws = sum(v["WRITE_SIZE"][2] for k, v in vals.items() if k.startswith(GEMM) and "WRITE_SIZE" in v)
 n = sum(v["FETCH_SIZE"][0] for k, v in vals.items() if k.startswith(GEMM) and "FETCH_SIZE" in v)
-json.dump({"round": 3, "kernel": "GEMM kernels of a step (tdnn_first_kernel, tdnn_gemm_f16bf8_wide_kernel, tdnn_pair_pool_f16bf8_kernel, tdnn_gemm_bf16x3_kernel; launch-weighted mean)",
+json.dump({"round": 4, "kernel": "GEMM kernels of a step (tdnn_first_kernel, tdnn_gemm_f16bf8_wide16_kernel, tdnn_pair_pool_f16bf8_kernel, tdnn_gemm_bf16x3_kernel; launch-weighted mean)",
            "source": "profiles/%s_pmc.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, default bench.py workload)" % tag,
            "kernel_sha": sha, "commit": commit, "batch_rows": under["config"]["batch_rows"], "launches": n,
            "gemm_fetch_kib_raw": round(fs / n, 1), "gemm_write_kib": round(ws / n, 1),
