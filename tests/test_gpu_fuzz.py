@@ -163,3 +163,130 @@ def test_random_topologies_gradients_match_autograd(seed):
             if e > 5e-4:
                 bad[n] = e
         assert not bad, ("kink margin %.1e" % train_ref.kink_margin[0], case, topo, bad)
+
+
+@pytest.mark.parametrize("seed", [61, 62, 63])
+def test_random_shapes_through_the_16x16_f16bf8_kernel(oracle_mod, seed):
+    """The 256 x 256 f16bf8 tile on the 16 x 16 MFMA shapes (round 4) at kernel level: random K in {3, 5, 7}, dilations up to a span
+    of 8, an even number of 32-channel slabs, Cout in {256, 512, 768}, every activation, split8 / bf16-split / pooled output, ragged
+    utterance lengths with gap rows -- against the fp64 oracle, gap rows exactly zero, an utterance alone == in the batch bitwise."""
+    import torch
+    from xvector_amd import engine, hiplib
+    hiplib.require_gpu()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    CODE = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for case in range(5):
+        K = int(rng.choice([3, 5, 7]))
+        dil = int(rng.integers(1, 8 // (K - 1) + 1))
+        cin = 64 * int(rng.integers(1, 9))
+        cout = int(rng.choice([256, 512, 768]))
+        act = str(rng.choice(["none", "relu", "lrelu", "prelu"]))
+        mode = str(rng.choice(["split8", "split", "pool"]))
+        lens = [int(x) for x in rng.integers(1, 600, size=int(rng.integers(1, 7)))]
+        mats = [(rng.standard_normal((n, cin)) * 2).astype(np.float32) for n in lens]
+        w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        bn = ((1 + 0.1 * rng.standard_normal(cout)).astype(np.float32), (0.1 * rng.standard_normal(cout)).astype(np.float32),
+              (0.2 * rng.standard_normal(cout)).astype(np.float32), np.exp(0.2 * rng.standard_normal(cout)).astype(np.float32))
+        alpha = np.array([0.2], np.float32) if act == "lrelu" else (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32) if act == "prelu" else None
+        scale, shift = hiplib.fold_bn(*(t(a) for a in bn), 1e-3)
+        wp = hiplib.pack_weights_f16bf8(t(w))
+        gap = max(1, (K - 1) * dil // 2)
+
+        def run(ms):
+            layout = engine.BatchLayout([m.shape[0] for m in ms], gap, hiplib.POOL_BLOCK_ROWS if mode == "pool" else 1)
+            host = np.zeros((layout.rows, cin), np.float32)
+            layout.pack(ms, host)
+            xin = hiplib.SplitBuf(layout.rows, cin, dev, hiplib.FMT_SPLIT8)
+            hiplib.split_encode(t(host), xin)
+            rv = t(layout.row_valid())
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            if mode == "pool":
+                blk = torch.full((hiplib.block_stats_floats(layout.rows, cout),), float("nan"), dtype=torch.float32, device=dev)
+                hiplib.tdnn_layer_pool8(xin, layout.rows, wp, t(b), scale, shift, CODE[act], t(alpha), dil, rv, blk)
+                out = torch.full((len(ms), 2 * cout), float("nan"), dtype=torch.float32, device=dev)
+                hiplib.stats_pool_blocks(blk, cout, t(layout.row_start), t(layout.row_len), len(ms), 1e-5, out)
+                return out.cpu().numpy(), None, layout
+            y = hiplib.SplitBuf(layout.rows, cout, dev, hiplib.FMT_SPLIT8 if mode == "split8" else hiplib.FMT_SPLIT)
+            y.base.fill_(0x7b)
+            hiplib.tdnn_layer8(xin, layout.rows, wp, t(b), scale, shift, CODE[act], t(alpha), dil, rv, y, status)
+            assert int(status.item()) == 0
+            yh = hiplib.split_decode(y, layout.rows).cpu().numpy()
+            return [yh[s0:s0 + n] for s0, n in zip(layout.row_start, layout.row_len)], yh, layout
+
+        hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 1024)
+        try:
+            outs, yh, layout = run(mats)
+            alone, _, _ = run([mats[-1]])
+        finally:
+            hiplib.set_tuning(hiplib.TUNE_TILE_ROWS, 0)
+        tag = (seed, case, K, dil, cin, cout, act, mode, lens)
+        for i, m in enumerate(mats):
+            ref = oracle_mod.tdnn_layer(m, w, b, bn, act, alpha, dil, np.float64)
+            if mode == "pool":
+                ref = oracle_mod.stats_pool(ref, 1e-5, np.float64)
+                assert oracle_mod.rel_l2(outs[i][:cout], ref[:cout]) < 4e-5 and oracle_mod.rel_l2(outs[i][cout:], ref[cout:]) < 4e-5, tag
+            else:
+                assert np.isfinite(outs[i]).all() and oracle_mod.rel_l2(outs[i], ref) < 4e-5, (tag, oracle_mod.rel_l2(outs[i], ref))
+        if mode == "pool":
+            assert np.array_equal(alone[0], outs[-1]), tag
+        else:
+            assert (yh[~layout.row_valid().astype(bool)] == 0).all(), tag
+            assert np.array_equal(alone[0], outs[-1]), tag
+
+
+@pytest.mark.parametrize("seed", [71, 72])
+def test_random_shapes_through_the_dma_fed_fp32_gemm(oracle_mod, seed):
+    """The exact-fp32 GEMM fed by LDS-DMA (round 4) against its register-staged form: random K, dilation, Cin a multiple of 32, ragged
+    Cout, row counts that are no multiple of anything, random gap rows -- the two forms agree BIT FOR BIT (XV_TUNE_FP32_GEMM), rows past
+    the end and columns past Cout come back as zeros from the descriptors' range check; a sample of rows against the fp64 oracle."""
+    import torch
+    from xvector_amd import hiplib
+    hiplib.require_gpu()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    for case in range(4):
+        K = int(rng.choice([1, 3, 5, 7]))
+        dil = 1 if K == 1 else int(rng.integers(1, 8 // (K - 1) + 1))
+        cin = 32 * int(rng.integers(1, 9))
+        cout = int(rng.choice([128, 200, 512, 516, 640]))
+        n_nt = (cout + 127) // 128
+        R = int(rng.integers(768 // n_nt * 128 + 1, 768 // n_nt * 128 + 4000))           # just above the size where 128-row tiles are chosen
+        act = int(rng.integers(0, 4))
+        x = (torch.randn((R, cin), device=dev) * 2)
+        valid = (torch.rand(R, device=dev) > 0.03).to(torch.uint8)
+        x *= valid[:, None].float()
+        w = torch.randn((K * cin, cout), device=dev) / (K * cin) ** 0.5
+        wp = hiplib.pack_weights(w)
+        bias = torch.randn(cout, device=dev) * 0.1
+        scale = 1 + 0.1 * torch.randn(cout, device=dev)
+        shift = 0.1 * torch.randn(cout, device=dev)
+        alpha = torch.full((1,), 0.2, device=dev) if act == 2 else (0.1 + 0.05 * torch.randn(cout, device=dev)) if act == 3 else None
+        outs = []
+        for form in (1, 2):
+            hiplib.set_tuning(hiplib.TUNE_FP32_GEMM, form)
+            try:
+                y = torch.full((R, cout), float("nan"), device=dev)
+                hiplib.tdnn_layer(x, wp, bias, scale, shift, act, alpha, K, dil, valid, y)
+                outs.append(y.cpu().numpy())
+            finally:
+                hiplib.set_tuning(hiplib.TUNE_FP32_GEMM, 0)
+        tag = (seed, case, K, dil, cin, cout, R, act)
+        assert np.isfinite(outs[1]).all(), tag
+        assert np.array_equal(outs[0], outs[1]), tag
+        # the first, the last and a few random rows against the fp64 definition (zero rows outside [0, R))
+        xh, wh = x.cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64).reshape(K, cin, cout)
+        a = None if alpha is None else alpha.cpu().numpy().astype(np.float64)
+        for r in [0, 1, R - 1, R - 2] + [int(v) for v in rng.integers(0, R, 6)]:
+            z = bias.cpu().numpy().astype(np.float64).copy()
+            for k in range(K):
+                rr = r + (k - (K - 1) // 2) * dil
+                if 0 <= rr < R:
+                    z += xh[rr] @ wh[k]
+            v = z if act == 0 else np.maximum(z, 0) if act == 1 else np.maximum(a[0] * z, z) if act == 2 else np.maximum(z, 0) + a * np.minimum(z, 0)
+            v = v * scale.cpu().numpy() + shift.cpu().numpy()
+            if not int(valid[r].item()):
+                v = np.zeros_like(v)
+            assert np.linalg.norm(outs[1][r] - v) <= 2e-6 * max(np.linalg.norm(v), 1e-3) + 1e-6, (tag, r)

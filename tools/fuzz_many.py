@@ -7,6 +7,17 @@ import test_gpu_fuzz as tf
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (40, 64)
 bad = 0
 only_grad = len(sys.argv) > 3 and sys.argv[3] == "grad"          # (third argument "grad": the training-step part only)
+if len(sys.argv) > 3 and sys.argv[3] == "r4":                    # (third argument "r4": the kernel-level fuzzers of the round-4 kernels only)
+    for name in ("test_random_shapes_through_the_16x16_f16bf8_kernel", "test_random_shapes_through_the_dma_fed_fp32_gemm"):
+        for seed in range(lo, hi):
+            try:
+                getattr(tf, name)(oracle, seed)
+            except AssertionError as e:
+                bad += 1
+                print(name, seed, "FAIL", str(e)[:300])
+        print(name, "seeds %d..%d done" % (lo, hi - 1))
+    print("failures:", bad)
+    sys.exit(1 if bad else 0)
 for name in () if only_grad else ("test_random_topologies_match_the_oracle", "test_random_topologies_through_the_first_layer_and_pair_kernels",
              "test_random_topologies_in_the_f16bf8_arithmetic"):
     fn = getattr(tf, name)

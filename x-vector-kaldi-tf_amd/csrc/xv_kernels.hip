@@ -1430,6 +1430,8 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_dma_kernel(const GemmParams p
     gemm_epilogue_rows<BM>(p, reinterpret_cast<float *>(flds), Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11);
 }
 
+std::atomic<int> g_fp32_form{0};
+
 int launch_gemm(const GemmParams &p0, hipStream_t st)
 {
     GemmParams p = p0;
@@ -1469,7 +1471,9 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
     }
     const dim3 grid((unsigned)(p.n_mt * p.n_nt));
     // the DMA-fed form (128-row tiles): whole 32-channel slabs, 16-byte aligned rows, byte offsets that fit the descriptors' 32 bits
-    static const bool dma_on = !(std::getenv("XV_FP32_DMA") != nullptr && std::getenv("XV_FP32_DMA")[0] == '0');
+    static const bool dma_env = !(std::getenv("XV_FP32_DMA") != nullptr && std::getenv("XV_FP32_DMA")[0] == '0');
+    const int form = g_fp32_form.load(std::memory_order_relaxed);       // XV_TUNE_FP32_GEMM: 0 built-in, 1 register-staged, 2 DMA-fed
+    const bool dma_on = form == 2 || (form == 0 && dma_env);
     const bool dma_ok = dma_on && !small && vec && p.vec_out && (p.cin % BK) == 0 && (p.K == 1 || p.K == 3 || p.K == 5 || p.K == 7) &&
                         (p.R + BM + MAX_SPAN) * (long)p.ldx * 4 < (1l << 31) && (long)(p.cout + BN) * p.kred * 4 < (1l << 31);
     if (dma_ok) {
@@ -1798,6 +1802,10 @@ int xv_set_tuning(int key, int value)
     case XV_TUNE_FIRST_TILES:
         if (value < 0 || value > 4096) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: first-layer tiles per wave must be 0 .. 4096");
         xv_internal_first_tiles(value);
+        return 0;
+    case XV_TUNE_FP32_GEMM:
+        if (value < 0 || value > 2) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: fp32 GEMM form must be 0, 1 or 2");
+        g_fp32_form.store(value, std::memory_order_relaxed);
         return 0;
     default:
         return fail(XV_ERR_BAD_ARG, "xv_set_tuning: unknown key");
