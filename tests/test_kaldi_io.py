@@ -528,66 +528,6 @@ def test_a_compressed_record_the_decoder_refuses_raises_instead_of_spinning():
             list(kaldi_io.read_mat_ark(io.BytesIO(raw)))
 
 
-def test_regular_files_are_read_into_the_arenas_by_several_threads(tmp_path, monkeypatch):
-    """A regular file fills an arena with positional reads on a few threads (_parallel_fill; one thread copies ~6 GB/s out of the page
-    cache, less than the GPU consumes): the same windows as the one-thread reader, the file position where the sequential reader leaves
-    it, byte-range streams (FileRange) inside their range, a short tail, and a pipe is untouched by it."""
-    import io
-    if kaldi_io._host_lib() is None:
-        pytest.skip("host library not built")
-    rng = np.random.default_rng(21)
-    path = str(tmp_path / "big.ark")
-    want = []
-    with open(path, "wb") as f:
-        for i in range(900):
-            m = rng.standard_normal((int(rng.integers(200, 700)), 23)).astype(np.float32)
-            kaldi_io.write_mat(f, m, key="utt%04d" % i)
-            want.append(("utt%04d" % i, m))
-    size = os.path.getsize(path)
-    assert size > 30 << 20
-
-    def read_all(stream, arena_bytes=24 << 20):
-        out = []
-        for keys, addr, rows, cols, holder in kaldi_io.scan_mat_ark_windows(stream, lambda: kaldi_io.ArkArena(arena_bytes), None, lambda a: None):
-            am = kaldi_io.ArkMats()
-            am.add(addr, rows, cols, holder)
-            out += [(k, np.array(am[j])) for j, k in enumerate(keys)]
-        return out
-
-    calls = []
-    real = kaldi_io._parallel_fill
-    monkeypatch.setattr(kaldi_io, "_parallel_fill", lambda raw, view, n: calls.append(real(raw, view, n)) or calls[-1])
-    with open(path, "rb") as f:
-        got = read_all(f)
-    assert [k for k, _ in got] == [k for k, _ in want] and all(np.array_equal(a, b) for (_, a), (_, b) in zip(got, want))
-    assert any(c for c in calls if c) and sum(c for c in calls if c) == size        # every byte came through the threaded fill
-    monkeypatch.setenv("XVECTOR_READ_THREADS", "1")
-    del calls[:]
-    with open(path, "rb") as f:
-        one = read_all(f)
-    assert all(c is None for c in calls) and all(np.array_equal(a, b) for (_, a), (_, b) in zip(one, want))
-    monkeypatch.delenv("XVECTOR_READ_THREADS")
-    # a byte-range stream: only its range, counted
-    with open(path, "rb") as f:
-        offs, _, _, keys = kaldi_io.index_mat_ark_file(f)
-        lo, hi = int(offs[100]), int(offs[700])
-        before = kaldi_io.FileRange.bytes_read
-        part = read_all(kaldi_io.FileRange(f, lo, hi))
-        assert [k for k, _ in part] == keys[100:700] and kaldi_io.FileRange.bytes_read - before == hi - lo
-        assert all(np.array_equal(a, b) for (_, a), (_, b) in zip(part, want[100:700]))
-    # a pipe end is read the ordinary way
-    del calls[:]
-    r, w = os.pipe()
-    import threading
-    blob = open(path, "rb").read()[:int(offs[40])]
-    th = threading.Thread(target=lambda: (os.write(w, blob), os.close(w)))
-    th.start()
-    with os.fdopen(r, "rb") as pr:
-        piped = read_all(pr)
-    th.join()
-    assert [k for k, _ in piped] == keys[:40] and all(c is None for c in calls)
-
-
 def test_subset_scp_tables_are_read_in_place(tmp_path):
     """A feats.scp that lists a SUBSET of its ark, in the ark's order (utterances removed by a filter -- the usual state of a Kaldi
     data directory): the in-place reader skips the records the table leaves out instead of giving up at the first gap and reading

@@ -1042,65 +1042,6 @@ def _cm_record_at(view, pos, end):
     return sp >= 0 and (head[sp + 1:sp + 6] == b"\0BCM " or head[sp + 1:sp + 7] in (b"\0BCM2 ", b"\0BCM3 "))
 
 
-_READ_POOL = [None]
-
-
-def _read_threads():
-    try:
-        return max(1, int(os.environ.get("XVECTOR_READ_THREADS", "4")))
-    except ValueError:
-        return 4
-
-
-def _parallel_fill(raw, view, want):
-    """Fill ``view[:want]`` from the current position of a REGULAR FILE with positional reads on a few threads (os.preadv releases
-    the interpreter lock; one thread copies ~6 GB/s out of the page cache -- a 1.4 GB feature ark read that way takes longer than
-    the GPU needs for its 50 k utterances).  Returns the number of bytes read (0 at the end of the file), or None when ``raw`` is
-    not a regular file / the read is too small to split: the caller then reads the ordinary way.  ``FileRange`` streams (byte-range
-    shards) are read the same way inside their range."""
-    nthr = _read_threads()
-    if nthr < 2 or want < (8 << 20):
-        return None
-    if isinstance(raw, FileRange):
-        fd, pos0, size = raw._fd, raw._pos, raw._end
-    elif is_regular_file(raw):
-        try:
-            fd, pos0, size = raw.fileno(), raw.tell(), os.fstat(raw.fileno()).st_size
-        except (OSError, ValueError):
-            return None
-    else:
-        return None
-    got = min(want, size - pos0)
-    if got <= 0:
-        return 0
-    if _READ_POOL[0] is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _READ_POOL[0] = ThreadPoolExecutor(max_workers=8, thread_name_prefix="xv-read")
-    step = -(-got // nthr)
-    step = (step + 4095) & ~4095
-
-    def part(a):
-        b, at = min(got, a + step), a
-        while at < b:
-            n = os.preadv(fd, [view[at:b]], pos0 + at)
-            if n <= 0:
-                return at - a                                    # the file shrank under us
-            at += n
-        return b - a
-    done = list(_READ_POOL[0].map(part, range(0, got, step)))
-    total = 0
-    for a, n in zip(range(0, got, step), done):                  # the contiguous prefix that was read
-        total += n
-        if n < min(got, a + step) - a:
-            break
-    if isinstance(raw, FileRange):
-        raw._pos += total
-        FileRange.bytes_read += total
-    else:
-        raw.seek(pos0 + total)
-    return total
-
-
 def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
     """The in-place form of ``read_mat_ark_blocks``: generator of ``(keys, addr[n] uint64, rows[n] int32, cols, holder)``.
     The stream is read (``readinto``) into arenas that ``take_arena()`` hands out (``ArkArena``; the caller recycles them once it
@@ -1152,11 +1093,9 @@ def scan_mat_ark_windows(file_or_fd, take_arena, first_fill=None, release=None):
                         lib.xv_copy_bytes(arena.addr + end, mem_addr + at, got)
                         raw.seek(at + got)
                 elif readinto is not None:
-                    got = _parallel_fill(raw, arena.view[end:limit], limit - end)      # regular files: a few threads of pread
-                    if got is None:
-                        # in slices: a stream object may copy under the interpreter lock, and 72 MB in one call would stall
-                        # every other thread of the pipeline for ~15 ms
-                        got = readinto(arena.view[end:min(limit, end + (4 << 20))])
+                    # in slices: a stream object may copy under the interpreter lock, and 72 MB in one call would stall
+                    # every other thread of the pipeline for ~15 ms
+                    got = readinto(arena.view[end:min(limit, end + (4 << 20))])
                 else:
                     blk = raw.read(limit - end)
                     got = len(blk) if blk else 0
