@@ -401,17 +401,23 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     load_h(I0{}, slot, 0);        // (again: the copy read inside the loop is dropped so that the conversion has the registers)
 
     // ---- phase 2: partial Y[frame][column] over this wave's 256 channels, 64 columns at a time -----------------------------------------
-    // At the end of a column tile every wave writes BOTH halves of its partial tile to LDS: the half the partner finishes
-    // (RED) and the half it finishes itself (KEEP), element (register r, lane l) at float r*64 + l.  With the whole 32 x 32
-    // half-tile addressable, lane (column li, hh) pools the two 8-row blocks 2hh, 2hh+1 COMPLETELY (rows 16hh .. 16hh+15: no
-    // cross-lane exchange at all), one row per step of the NEXT column tile's first three stages -- 16 rows over 12 steps,
-    // ~12 VALU instructions and two ds_read_b32 each, in the shadow of that step's MFMAs; the fourth stage stays free of
-    // reads so that the next exchange cannot overtake them.
+    // Of a 32-frame x 64-column tile wave hf FINISHES the 32 columns 32 hf .. 32 hf + 31 (its KEEP half) and contributes a partial sum to
+    // the partner's 32 (its RED half).  The two halves are not accumulated side by side but one after the other: stages 0-1 of a column
+    // tile run the wave's eight slabs against the RED half's weights, stages 2-3 against the KEEP half's (the packed stream of a half is
+    // ordered that way, pack_pair8_kernel).  So
+    //   * the RED half is complete in the MIDDLE of a tile: it goes to LDS in the first two steps of stage 2 (sixteen ds_write_b32,
+    //     element (register r, lane l) at float r*64 + l; two buffers, by the parity of the tile) and is visible to the partner from the
+    //     tile's last barrier on;
+    //   * the KEEP half is complete at the END of a tile and never leaves the registers: eight v_permlane32_swap turn "lane (column, hh)
+    //     holds rows (r&3) + 8(r>>2) + 4hh" into "lane (column, hh) holds rows 16hh .. 16hh+15" -- the two 8-row blocks 2hh, 2hh+1 of its
+    //     column COMPLETELY -- and the lane pools them during stages 0-1 of the NEXT tile, two rows per step (one ds_read_b32 of the
+    //     partner's partial sum and ~10 VALU instructions per row, in the shadow of the step's MFMAs), while those stages accumulate
+    //     into the RED half's registers; at stage 2 the KEEP registers are free again.  No extra accumulator registers, a quarter
+    //     of the earlier form's exchange traffic (it wrote BOTH halves to LDS and read both back).
     float *red_mine = reinterpret_cast<float *>(lds + P8_RED_OFF + wave * 4096) + lane;
-    float *keep_mine = reinterpret_cast<float *>(lds + P8_KEEP_OFF + wave * 4096) + lane;
     // row 16hh + k of the half-tile = accumulator register 8hh + 4(k>>3) + (k&3) of lane li + 32((k>>2)&1)
-    const float *pool_keep = reinterpret_cast<const float *>(lds + P8_KEEP_OFF + wave * 4096) + 8 * hh * 64 + li;
     const float *pool_red = reinterpret_cast<const float *>(lds + P8_RED_OFF + (wave ^ 1) * 4096) + 8 * hh * 64 + li;
+    constexpr int RED_BUF_FLOATS = P8_WAVES * 1024;        // the second buffer lies over the dead first-layer parameters
     const bool lrelu = p.act == XV_ACT_LRELU, prelu = p.act == XV_ACT_PRELU;
     // epilogue parameters of the column this lane pools, fetched one column tile ahead (a global load at the point of use
     // would stall the wave for a microsecond per column tile)
@@ -433,20 +439,23 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
         p.blk + (size_t)blk0 * 2 * p.cout, 0, (int)(blk_left <= 0 ? 0 : (blk_left < P8_ROWS / 8 ? blk_left : P8_ROWS / 8) * blk_row_bytes), XV_RSRC_FLAGS);
     const int blk_voff = (4 * pair + 2 * hh) * blk_row_bytes + (32 * hf + li) * 4;
     float pv0 = 0.f, ps1 = 0.f, ps2 = 0.f;                 // running statistics of the block being pooled
-    // row k of the exchanged tile: the two partial sums (read early in a step, used behind its last MFMA)
-    float pa[2], pb[2];
+    f32x16 yR, yK;                                         // the two halves of the partial tile, by ROLE (column half: RED 1-hf, KEEP hf)
+    yK = (f32x16){0};                                      // ("the tile before the first": pooled like any other, its stores are dropped)
+    const float *pool_cur = pool_red;                      // the partner's RED half of the tile being pooled
+    float pb[2];                                           // row k of it (read early in a step, used behind its last MFMA)
     auto pool_read = [&](auto K, auto I) {
         constexpr int k = decltype(K)::value, i = decltype(I)::value;
         constexpr int off = (4 * (k >> 3) + (k & 3)) * 64 + 32 * ((k >> 2) & 1);
-        pa[i] = pool_keep[off];
-        pb[i] = pool_red[off];
+        pb[i] = pool_cur[off];
     };
     auto pool_row = [&](auto K, auto I, int ct) {          // row k of column tile ct (statistics shifted by the block's first row)
         constexpr int k = decltype(K)::value, i = decltype(I)::value;
+        // after the swap: row k sits in register (k&3) + 4(k>>3), + 8 for the rows whose source lane was in the upper half
+        constexpr int reg = (k & 3) + 4 * (k >> 3) + 8 * ((k >> 2) & 1);
         // Every product-sum below is an EXPLICIT fma: left to the optimiser, the sixteen instances of this body contract (or pack
         // into v_pk_mul / v_pk_add) differently, and a block's statistics would depend on whether it sits at an even or an odd
         // 8-row position -- an utterance's x-vector must not depend on where in the batch it lies.
-        float v = __builtin_fmaf(act_fn<MODE>(pa[i] + pb[i] + prm[0], prm[3]), prm[1], prm[2]);
+        float v = __builtin_fmaf(act_fn<MODE>(yK[reg] + pb[i] + prm[0], prm[3]), prm[1], prm[2]);
         asm volatile("" : "+v"(v));              // (computed for every lane: masked rows must not turn into a branch around the reads)
         if constexpr ((k & 7) == 0) {
             pv0 = v;
@@ -471,113 +480,141 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, m2), brs, o, p.cout * 4, 0);
         }
     };
-    // Rows of the PREVIOUS column tile pooled in step j of stage q.  The exchange of a tile is written after the last unit of
-    // its stage 3, i.e. behind B(., 3), and becomes visible with B(next tile, 0): reads start in step 3 of stage 0 and end in
-    // step 2 of stage 3 (before B(., 3), behind which the next exchange is written): - - - 2 | 2 1 1 1 | 2 1 1 1 | 2 1 1 -
+    // Inline asm on purpose: this compiler's __builtin_amdgcn_permlane32_swap hands back the FIRST result for both halves of its
+    // pair when both are used (seen in the ISA: sixteen rows pooled from eight registers).  The hazard recogniser does not look
+    // into asm, so the distance to the MFMA that wrote the KEEP half is kept by construction: the swaps sit behind the first
+    // MFMA of the next tile and its LDS-DMA piece (>= 100 cycles after the 64-cycle MFMA in question has left the pipe), the
+    // tail waits explicitly.
+    auto swap_keep = [&](auto TAIL) {                      // rows (r&3) + 8(r>>2) + 4hh  ->  rows 16hh .. 16hh+15 (see pool_row)
+        if constexpr (decltype(TAIL)::value) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        else asm volatile("s_nop 7");
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float a = yK[r], b = yK[r + 8];
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+            yK[r] = a;
+            yK[r + 8] = b;
+        }
+    };
+    // Rows of the PREVIOUS column tile pooled in step j of stage q: 2 in every step of stages 0 and 1 (rows 8q + 2j, + 1).  The
+    // partner wrote them in stage 2 of that tile (before B(., 2)); the buffer is written again two tiles later.
     auto pool_load = [&](auto Q, auto J) {
         constexpr int q = decltype(Q)::value, j = decltype(J)::value;
-        constexpr int count = pool_count(q, j), first = pool_first(q, j);
-        if constexpr (count >= 1) pool_read(std::integral_constant<int, first>{}, I0{});
-        if constexpr (count == 2) pool_read(std::integral_constant<int, first + 1>{}, I1{});
+        if constexpr (q < 2) {
+            pool_read(std::integral_constant<int, 8 * q + 2 * j>{}, I0{});
+            pool_read(std::integral_constant<int, 8 * q + 2 * j + 1>{}, I1{});
+        }
     };
     auto pool_step = [&](auto Q, auto J, int ct) {
         constexpr int q = decltype(Q)::value, j = decltype(J)::value;
-        constexpr int count = pool_count(q, j), first = pool_first(q, j);
         // (column tile -1 does not exist: its rows are read from whatever the buffers hold and never stored -- no branch
         // that would split the scheduling region of the step)
-        if constexpr (count >= 1) pool_row(std::integral_constant<int, first>{}, I0{}, ct - 1);
-        if constexpr (count == 2) pool_row(std::integral_constant<int, first + 1>{}, I1{}, ct - 1);
+        if constexpr (q < 2) {
+            pool_row(std::integral_constant<int, 8 * q + 2 * j>{}, I0{}, ct - 1);
+            pool_row(std::integral_constant<int, 8 * q + 2 * j + 1>{}, I1{}, ct - 1);
+        }
     };
     prm_next = fetch_params(0);
     for (int ct = 0; ct < p.n_ct; ++ct) {
-        f32x16 y[2];
-        y[0] = (f32x16){0};
-        y[1] = (f32x16){0};
-        auto f16b = [&](auto SET, auto U, auto C, bool second) {     // A = H fragment (registers), B = weight fragment
-            constexpr int set = decltype(SET)::value, u = decltype(U)::value, c = decltype(C)::value;
-            y[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(second ? Hf1[u] : Hf0[u], second ? Hh1[set] : Hh0[set], y[c], 0, 0, 0);
+        auto f16b = [&](auto SET, auto U, auto ROLE, auto FIRST, bool second) {     // A = H fragment (registers), B = weight fragment
+            constexpr int set = decltype(SET)::value, u = decltype(U)::value, role = decltype(ROLE)::value;
+            constexpr bool first = decltype(FIRST)::value;
+            const xv_f16x8 a = second ? Hf1[u] : Hf0[u], b = second ? Hh1[set] : Hh0[set];
+            if constexpr (role == 0) yR = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, first ? (f32x16){0} : yR, 0, 0, 0);
+            else yK = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, first ? (f32x16){0} : yK, 0, 0, 0);
         };
-        auto mxb = [&](auto SET, auto U, auto C) {
-            constexpr int set = decltype(SET)::value, u = decltype(U)::value, c = decltype(C)::value;
-            y[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Hx[u], Mx[set], y[c], 1, 1, 0, scale_a, 0, scale_b);
+        auto mxb = [&](auto SET, auto U, auto ROLE) {
+            constexpr int set = decltype(SET)::value, u = decltype(U)::value, role = decltype(ROLE)::value;
+            if constexpr (role == 0) yR = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Hx[u], Mx[set], yR, 1, 1, 0, scale_a, 0, scale_b);
+            else yK = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Hx[u], Mx[set], yK, 1, 1, 0, scale_a, 0, scale_b);
         };
-        auto quarter = [&](auto Q) {                        // stage (ct, q): slabs 2q, 2q+1 x column tiles 0, 1
+        auto quarter = [&](auto Q) {                        // stage (ct, q): slabs 4(q&1) .. 4(q&1)+3 of half-tile q >> 1 (0: RED, 1: KEEP)
             constexpr int q = decltype(Q)::value;
-            typedef std::integral_constant<int, 2 * q> UA;
-            typedef std::integral_constant<int, 2 * q + 1> UB;
-            typedef std::integral_constant<int, q == 0 ? 0 : 2 * q - 1> UP;   // slab of the pending 8-bit MFMA (none when q == 0)
+            typedef std::integral_constant<int, (q >> 1)> RL;
+            typedef std::integral_constant<int, 4 * (q & 1)> U0;
+            typedef std::integral_constant<int, 4 * (q & 1) + 1> U1;
+            typedef std::integral_constant<int, 4 * (q & 1) + 2> U2;
+            typedef std::integral_constant<int, 4 * (q & 1) + 3> U3;
+            typedef std::integral_constant<int, 3> UP;        // slab of the 8-bit MFMA pending from the stage before (q odd only)
+            typedef std::integral_constant<bool, (q & 1) == 0> FIRST;
+            typedef std::integral_constant<bool, false> NO;
             if constexpr (q == 0) {
                 prm = prm_next;                             // the parameters of column tile ct-1, fetched a whole tile ago
                 prm_next = fetch_params(ct);
+                pool_cur = pool_red + ((ct + 1) & 1) * RED_BUF_FLOATS;
             }
-            // step 0: unit (2q, 0)
+            // step 0: slab 4(q&1)
             load_h(I1{}, slot, 1);
             load_m(I0{}, slot, 0);
-            f16b(I0{}, UA{}, I0{}, false);
-            if constexpr (q > 0) mxb(I1{}, UP{}, I1{});
+            f16b(I0{}, U0{}, RL{}, FIRST{}, false);
+            if constexpr ((q & 1) != 0) mxb(I1{}, UP{}, RL{});
             pool_load(Q, I0{});
-            if constexpr (q > 0) pin_a(std::integral_constant<int, 4 + 2 * pool_count(q, 0)>{});
-            else { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr ((q & 1) != 0) pin_a(std::integral_constant<int, 4 + (q < 2 ? 2 : 0)>{});
+            else { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 4 + (q < 2 ? 2 : 0), 0); __builtin_amdgcn_sched_barrier(0); }
             w_piece(I1{});
             pin_b();
-            f16b(I0{}, UA{}, I0{}, true);
+            if constexpr (q == 0) swap_keep(NO{});          // (the KEEP half of tile ct-1, complete since the end of its stage 3)
+            f16b(I0{}, U0{}, RL{}, NO{}, true);
             pool_step(Q, I0{}, ct);
+            if constexpr (q == 2) {                         // the RED half of this tile (complete since the end of stage 1) -> LDS
+                float *rw = red_mine + (ct & 1) * RED_BUF_FLOATS;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) rw[r * 64] = yR[r];
+            }
             pin_c();
-            // step 1: unit (2q, 1)
+            // step 1
             load_h(I0{}, slot, 2);
             load_m(I1{}, slot, 1);
-            f16b(I1{}, UA{}, I1{}, false);
-            mxb(I0{}, UA{}, I0{});
+            f16b(I1{}, U1{}, RL{}, NO{}, false);
+            mxb(I0{}, U0{}, RL{});
             pool_load(Q, I1{});
-            pin_a(std::integral_constant<int, 4 + 2 * pool_count(q, 1)>{});
+            pin_a(std::integral_constant<int, 4 + (q < 2 ? 2 : 0)>{});
             w_piece(I2{});
             pin_b();
-            f16b(I1{}, UA{}, I1{}, true);
+            f16b(I1{}, U1{}, RL{}, NO{}, true);
             pool_step(Q, I1{}, ct);
+            if constexpr (q == 2) {
+                float *rw = red_mine + (ct & 1) * RED_BUF_FLOATS;
+#pragma unroll
+                for (int r = 8; r < 16; ++r) rw[r * 64] = yR[r];
+            }
             pin_c();
-            // step 2: unit (2q+1, 0); also the 8-bit fragment of unit 3
+            // step 2; also the 8-bit fragment of unit 3
             load_h(I1{}, slot, 3);
             load_m(I0{}, slot, 2);
-            f16b(I0{}, UB{}, I0{}, false);
-            mxb(I1{}, UA{}, I1{});
+            f16b(I0{}, U2{}, RL{}, NO{}, false);
+            mxb(I1{}, U1{}, RL{});
             load_m(I1{}, slot, 3);
             pool_load(Q, I2{});
-            pin_a(std::integral_constant<int, 6 + 2 * pool_count(q, 2)>{});
+            pin_a(std::integral_constant<int, 6 + (q < 2 ? 2 : 0)>{});
             w_piece(I3{});
             pin_b();
-            f16b(I0{}, UB{}, I0{}, true);
+            f16b(I0{}, U2{}, RL{}, NO{}, true);
             pool_step(Q, I2{}, ct);
             pin_c();
             stage_barrier();
             fill = slot;
             slot = next_slot(slot);
-            // step 3: unit (2q+1, 1)
+            // step 3
             load_h(I0{}, slot, 0);
-            f16b(I1{}, UB{}, I1{}, false);
-            mxb(I0{}, UB{}, I0{});
+            f16b(I1{}, U3{}, RL{}, NO{}, false);
+            mxb(I0{}, U2{}, RL{});
             pool_load(Q, I3{});
-            pin_a(std::integral_constant<int, 2 + 2 * pool_count(q, 3)>{});
+            pin_a(std::integral_constant<int, 2 + (q < 2 ? 2 : 0)>{});
             w_piece(I0{});
             pin_b();
-            f16b(I1{}, UB{}, I1{}, true);
+            f16b(I1{}, U3{}, RL{}, NO{}, true);
             pool_step(Q, I3{}, ct);
             pin_c();
-            if constexpr (q == 3) {
-                mxb(I1{}, UB{}, I1{});                      // the pending 8-bit MFMA of the tile's last unit
-                // both halves of the partial tile -> LDS; B(next tile, 0) orders the exchange (nobody reads behind B(., 3))
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    red_mine[r * 64] = hf ? y[0][r] : y[1][r];
-                    keep_mine[r * 64] = hf ? y[1][r] : y[0][r];
-                }
-            }
+            if constexpr ((q & 1) != 0) mxb(I1{}, U3{}, RL{});   // the pending 8-bit MFMA of the half-tile's last slab
         };
         static_for<0, 4>(quarter);
     }
-    // the last column tile: make its exchange visible, then pool it
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // the last column tile: its RED halves were written before B(last, 2); pool it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     prm = prm_next;
+    pool_cur = pool_red + ((p.n_ct + 1) & 1) * RED_BUF_FLOATS;
+    swap_keep(std::integral_constant<bool, true>{});
     {
         auto tail = [&](auto K) { pool_read(K, I0{}); pool_row(K, I0{}, p.n_ct - 1); };
         static_for<0, 16>(tail);
@@ -588,7 +625,7 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
 // (stage, half, unit, lane): its three 16/32-byte fragments.
 //   layer 1, stage 2 ks + q, half h, unit j (tile T = 4q + j): output channel o = 256 h + 32 T + (lane & 31), kh = lane >> 5
 //       fp16 k-step s: w1[32 ks + 16 s + 8 kh + e][o];  8-bit: channels 32 ks + 16 kh + {0..7 | 8..15}
-//   layer 2, stage 4 ct + q, half h, unit j (slab u = 2q + (j >> 1), column tile c = j & 1): column n = 64 ct + 32 c + (lane & 31)
+//   layer 2, stage 4 ct + q, half h, unit j (slab u = 4 (q & 1) + j, column tile c = 1 - h for q < 2, h for q >= 2): column n = 64 ct + 32 c + (lane & 31)
 //       channel of (r, kh) = 256 h + 32 u + (r&3) + 8 (r>>2) + 4 kh;  fp16 k-step s: r = 8 s + e;  8-bit: r = {0..7 | 8..15}
 __global__ void pack_pair8_kernel(const float *__restrict__ w1, const float *__restrict__ w2, int n_ks, int cout, int n_ct,
                                   uint8_t *__restrict__ wt, size_t total)
@@ -630,7 +667,7 @@ __global__ void pack_pair8_kernel(const float *__restrict__ w1, const float *__r
     } else {
         const long s2 = stage - 2L * n_ks;
         const int ct = (int)(s2 >> 2), q = (int)(s2 & 3);
-        const int u = 2 * q + (unit >> 1), c = unit & 1;
+        const int u = 4 * (q & 1) + unit, c = (q >> 1) ? h : 1 - h;   // stages 0-1: the half the PARTNER finishes, 2-3: this wave's own
         const int col = 64 * ct + 32 * c + n;
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = w2[(size_t)(256 * h + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * kh) * cout + col];
