@@ -35,6 +35,7 @@
 
 extern "C" void xv_internal_set_error(const char *msg);
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -438,24 +439,30 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
         p.blk + (size_t)blk0 * 2 * p.cout, 0, (int)(blk_left <= 0 ? 0 : (blk_left < P8_ROWS / 8 ? blk_left : P8_ROWS / 8) * blk_row_bytes), XV_RSRC_FLAGS);
     const int blk_voff = (4 * pair + 2 * hh) * blk_row_bytes + (32 * hf + li) * 4;
-    float pv0 = 0.f, ps1 = 0.f, ps2 = 0.f;                 // running statistics of the block being pooled
     f32x16 yR, yK;                                         // the two halves of the partial tile, by ROLE (column half: RED 1-hf, KEEP hf)
     yK = (f32x16){0};                                      // ("the tile before the first": pooled like any other, its stores are dropped)
     const float *pool_cur = pool_red;                      // the partner's RED half of the tile being pooled
-    float pb[2];                                           // row k of it (read early in a step, used behind its last MFMA)
-    auto pool_read = [&](auto K, auto I) {
+    // two rows of it per step, read ONE STEP AHEAD (pn) of the step that pools them (pb): the wait in front of the pooling
+    // arithmetic then is for the previous step's reads, not a drain of the fragment reads just issued
+    float pb[2] = {0.f, 0.f}, pn[2] = {0.f, 0.f};
+    auto pool_read = [&](auto K, auto I, const float *from) {
         constexpr int k = decltype(K)::value, i = decltype(I)::value;
         constexpr int off = (4 * (k >> 3) + (k & 3)) * 64 + 32 * ((k >> 2) & 1);
-        pb[i] = pool_cur[off];
+        pn[i] = from[off];
     };
-    auto pool_row = [&](auto K, auto I, int ct) {          // row k of column tile ct (statistics shifted by the block's first row)
+    // Row k of column tile ct.  Statistics are taken of the ACTIVATION, shifted by the block's first row; the BatchNorm that
+    // follows it is affine per column and is applied to the block's (mean, M2) when they are stored -- mean' = scale * mean +
+    // shift, M2' = scale^2 * M2 -- instead of to every element.  (The two-wide form of this body, v_pk_add_f32 / v_pk_fma_f32 on
+    // row pairs, was measured 1 % SLOWER than one row at a time.)
+    float pv0 = 0.f, ps1 = 0.f, ps2 = 0.f;                 // running statistics of the block being pooled
+    auto pool_row = [&](auto K, auto I, int ct) {
         constexpr int k = decltype(K)::value, i = decltype(I)::value;
         // after the swap: row k sits in register (k&3) + 4(k>>3), + 8 for the rows whose source lane was in the upper half
         constexpr int reg = (k & 3) + 4 * (k >> 3) + 8 * ((k >> 2) & 1);
         // Every product-sum below is an EXPLICIT fma: left to the optimiser, the sixteen instances of this body contract (or pack
         // into v_pk_mul / v_pk_add) differently, and a block's statistics would depend on whether it sits at an even or an odd
         // 8-row position -- an utterance's x-vector must not depend on where in the batch it lies.
-        float v = __builtin_fmaf(act_fn<MODE>(yK[reg] + pb[i] + prm[0], prm[3]), prm[1], prm[2]);
+        float v = act_fn<MODE>(yK[reg] + pb[i] + prm[0], prm[3]);
         asm volatile("" : "+v"(v));              // (computed for every lane: masked rows must not turn into a branch around the reads)
         if constexpr ((k & 7) == 0) {
             pv0 = v;
@@ -469,10 +476,14 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
         if constexpr ((k & 7) == 7) {
             const float n = (float)__builtin_popcount((rows_mask >> (k - 7)) & 255u);
             const float rn = n > 0.f ? 1.f / n : 0.f;
-            const float mean = n > 0.f ? __builtin_fmaf(ps1, rn, pv0) : 0.f;
+            const float mean_a = __builtin_fmaf(ps1, rn, pv0);
             float sq = ps1 * ps1;
             asm volatile("" : "+v"(sq));
-            const float m2 = fmaxf(__builtin_fmaf(-sq, rn, ps2), 0.f);
+            const float m2_a = fmaxf(__builtin_fmaf(-sq, rn, ps2), 0.f);
+            const float mean = n > 0.f ? __builtin_fmaf(mean_a, prm[1], prm[2]) : 0.f;
+            float s2 = prm[1] * prm[1];
+            asm volatile("" : "+v"(s2));
+            const float m2 = m2_a * s2;
             // (blocks past n_blocks and the non-existent column tile -1 fall outside the descriptor and are dropped by the
             // range check: no branch that would split the step's scheduling region)
             const int o = ct >= 0 ? blk_voff + (k >> 3) * blk_row_bytes + ct * 256 : -1;
@@ -498,11 +509,21 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     };
     // Rows of the PREVIOUS column tile pooled in step j of stage q: 2 in every step of stages 0 and 1 (rows 8q + 2j, + 1).  The
     // partner wrote them in stage 2 of that tile (before B(., 2)); the buffer is written again two tiles later.
-    auto pool_load = [&](auto Q, auto J) {
+    // (step (3, 3) reads the first two rows of the tile that is just being finished: the partner wrote them before B(., 2))
+    constexpr auto pool_ahead = [](int q, int j) { return q == 0 || (q == 1 && j < 3) || (q == 3 && j == 3); };
+    auto pool_load = [&](auto Q, auto J, int ct) {
         constexpr int q = decltype(Q)::value, j = decltype(J)::value;
         if constexpr (q < 2) {
-            pool_read(std::integral_constant<int, 8 * q + 2 * j>{}, I0{});
-            pool_read(std::integral_constant<int, 8 * q + 2 * j + 1>{}, I1{});
+            pb[0] = pn[0];
+            pb[1] = pn[1];
+        }
+        if constexpr (q == 3 && j == 3) {
+            const float *nxt = pool_red + (ct & 1) * RED_BUF_FLOATS;
+            pool_read(I0{}, I0{}, nxt);
+            pool_read(I1{}, I1{}, nxt);
+        } else if constexpr (pool_ahead(q, j)) {
+            pool_read(std::integral_constant<int, 8 * q + 2 * j + 2>{}, I0{}, pool_cur);
+            pool_read(std::integral_constant<int, 8 * q + 2 * j + 3>{}, I1{}, pool_cur);
         }
     };
     auto pool_step = [&](auto Q, auto J, int ct) {
@@ -548,9 +569,9 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             load_m(I0{}, slot, 0);
             f16b(I0{}, U0{}, RL{}, FIRST{}, false);
             if constexpr ((q & 1) != 0) mxb(I1{}, UP{}, RL{});
-            pool_load(Q, I0{});
-            if constexpr ((q & 1) != 0) pin_a(std::integral_constant<int, 4 + (q < 2 ? 2 : 0)>{});
-            else { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 4 + (q < 2 ? 2 : 0), 0); __builtin_amdgcn_sched_barrier(0); }
+            pool_load(Q, I0{}, ct);
+            if constexpr ((q & 1) != 0) pin_a(std::integral_constant<int, 4 + (pool_ahead(q, 0) ? 1 : 0)>{});
+            else { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 4 + (pool_ahead(q, 0) ? 1 : 0), 0); __builtin_amdgcn_sched_barrier(0); }
             w_piece(I1{});
             pin_b();
             if constexpr (q == 0) swap_keep(NO{});          // (the KEEP half of tile ct-1, complete since the end of its stage 3)
@@ -567,8 +588,8 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             load_m(I1{}, slot, 1);
             f16b(I1{}, U1{}, RL{}, NO{}, false);
             mxb(I0{}, U0{}, RL{});
-            pool_load(Q, I1{});
-            pin_a(std::integral_constant<int, 4 + (q < 2 ? 2 : 0)>{});
+            pool_load(Q, I1{}, ct);
+            pin_a(std::integral_constant<int, 4 + (pool_ahead(q, 1) ? 1 : 0)>{});
             w_piece(I2{});
             pin_b();
             f16b(I1{}, U1{}, RL{}, NO{}, true);
@@ -585,8 +606,8 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             f16b(I0{}, U2{}, RL{}, NO{}, false);
             mxb(I1{}, U1{}, RL{});
             load_m(I1{}, slot, 3);
-            pool_load(Q, I2{});
-            pin_a(std::integral_constant<int, 6 + (q < 2 ? 2 : 0)>{});
+            pool_load(Q, I2{}, ct);
+            pin_a(std::integral_constant<int, 6 + (pool_ahead(q, 2) ? 1 : 0)>{});
             w_piece(I3{});
             pin_b();
             f16b(I0{}, U2{}, RL{}, NO{}, true);
@@ -599,8 +620,8 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             load_h(I0{}, slot, 0);
             f16b(I1{}, U3{}, RL{}, NO{}, false);
             mxb(I0{}, U2{}, RL{});
-            pool_load(Q, I3{});
-            pin_a(std::integral_constant<int, 2 + (q < 2 ? 2 : 0)>{});
+            pool_load(Q, I3{}, ct);
+            pin_a(std::integral_constant<int, 2 + (pool_ahead(q, 3) ? 1 : 0)>{});
             w_piece(I0{});
             pin_b();
             f16b(I1{}, U3{}, RL{}, NO{}, true);
@@ -616,8 +637,16 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     pool_cur = pool_red + ((p.n_ct + 1) & 1) * RED_BUF_FLOATS;
     swap_keep(std::integral_constant<bool, true>{});
     {
-        auto tail = [&](auto K) { pool_read(K, I0{}); pool_row(K, I0{}, p.n_ct - 1); };
-        static_for<0, 16>(tail);
+        auto tail = [&](auto H) {
+            constexpr int k = 2 * decltype(H)::value;
+            pool_read(std::integral_constant<int, k>{}, I0{}, pool_cur);
+            pool_read(std::integral_constant<int, k + 1>{}, I1{}, pool_cur);
+            pb[0] = pn[0];
+            pb[1] = pn[1];
+            pool_row(std::integral_constant<int, k>{}, I0{}, p.n_ct - 1);
+            pool_row(std::integral_constant<int, k + 1>{}, I1{}, p.n_ct - 1);
+        };
+        static_for<0, 8>(tail);
     }
 }
 
