@@ -415,7 +415,6 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
     //     partner's partial sum and ~10 VALU instructions per row, in the shadow of the step's MFMAs), while those stages accumulate
     //     into the RED half's registers; at stage 2 the KEEP registers are free again.  No extra accumulator registers, a quarter
     //     of the earlier form's exchange traffic (it wrote BOTH halves to LDS and read both back).
-    float *red_mine = reinterpret_cast<float *>(lds + P8_RED_OFF + wave * 4096) + lane;
     // row 16hh + k of the half-tile = accumulator register 8hh + 4(k>>3) + (k&3) of lane li + 32((k>>2)&1)
     const float *pool_red = reinterpret_cast<const float *>(lds + P8_RED_OFF + (wave ^ 1) * 4096) + 8 * hh * 64 + li;
     constexpr int RED_BUF_FLOATS = P8_WAVES * 1024;        // the second buffer lies over the dead first-layer parameters
@@ -535,6 +534,27 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             pool_row(std::integral_constant<int, 8 * q + 2 * j + 1>{}, I1{}, ct - 1);
         }
     };
+    // Registers 8 half .. 8 half + 7 of the RED half -> LDS, element (register r, lane l) at float r*64 + l of this wave's slot:
+    // ds_write_addtid_b32 (address = M0 + offset + 4 * lane: no address register, 2 LDS cycles per instruction where
+    // ds_write_b32 takes 4).  M0 also carries the LDS address of the compiler's LDS-DMA instructions: saved and restored here.
+    const unsigned red_base = (unsigned)(size_t)(lds + P8_RED_OFF + wave * 4096);
+    auto red_write = [&](auto HALF, int ct) {
+        constexpr int h = decltype(HALF)::value;
+        const unsigned base = __builtin_amdgcn_readfirstlane(red_base + (unsigned)(ct & 1) * (RED_BUF_FLOATS * 4) + h * 2048);
+        unsigned keep_m0;
+        const f32x16 &y = yR;
+        const float r0 = y[8 * h], r1 = y[8 * h + 1], r2 = y[8 * h + 2], r3 = y[8 * h + 3], r4 = y[8 * h + 4], r5 = y[8 * h + 5],
+                    r6 = y[8 * h + 6], r7 = y[8 * h + 7];
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %1 offset:0\n\tds_write_addtid_b32 %2 offset:256\n\t"
+                     "ds_write_addtid_b32 %3 offset:512\n\tds_write_addtid_b32 %4 offset:768\n\t"
+                     "ds_write_addtid_b32 %5 offset:1024\n\tds_write_addtid_b32 %6 offset:1280\n\t"
+                     "ds_write_addtid_b32 %7 offset:1536\n\tds_write_addtid_b32 %8 offset:1792\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep_m0)
+                     : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7), "s"(base)
+                     : "memory");
+    };
     prm_next = fetch_params(0);
     for (int ct = 0; ct < p.n_ct; ++ct) {
         auto f16b = [&](auto SET, auto U, auto ROLE, auto FIRST, bool second) {     // A = H fragment (registers), B = weight fragment
@@ -577,11 +597,7 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             if constexpr (q == 0) swap_keep(NO{});          // (the KEEP half of tile ct-1, complete since the end of its stage 3)
             f16b(I0{}, U0{}, RL{}, NO{}, true);
             pool_step(Q, I0{}, ct);
-            if constexpr (q == 2) {                         // the RED half of this tile (complete since the end of stage 1) -> LDS
-                float *rw = red_mine + (ct & 1) * RED_BUF_FLOATS;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) rw[r * 64] = yR[r];
-            }
+            if constexpr (q == 2) red_write(I0{}, ct);      // the RED half of this tile (complete since the end of stage 1) -> LDS
             pin_c();
             // step 1
             load_h(I0{}, slot, 2);
@@ -594,11 +610,7 @@ __global__ __launch_bounds__(P8_WAVES * 64, 2) void tdnn_pair_pool_f16bf8_kernel
             pin_b();
             f16b(I1{}, U1{}, RL{}, NO{}, true);
             pool_step(Q, I1{}, ct);
-            if constexpr (q == 2) {
-                float *rw = red_mine + (ct & 1) * RED_BUF_FLOATS;
-#pragma unroll
-                for (int r = 8; r < 16; ++r) rw[r * 64] = yR[r];
-            }
+            if constexpr (q == 2) red_write(I1{}, ct);
             pin_c();
             // step 2; also the 8-bit fragment of unit 3
             load_h(I1{}, slot, 3);
