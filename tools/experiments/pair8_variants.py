@@ -2,9 +2,10 @@
 XVECTOR_HIP_LIB by tools/pair8_bench.py: what the exchange of partial tiles through LDS, the pooling arithmetic, the stage barriers
 and the weight DMA cost (the LDS budget of a stage: 512 cycles of fragment reads + ~256 of DMA writes + ~256 of exchange writes +
 ~128 of pooling reads against 1024 MFMA cycles).
-  nokeep   the half a wave finishes itself is not written to / read back from LDS (pooled from a register instead)
-  noexch   neither half is written or read back
+  noexch   the partner's half is neither written nor read back
   nopool   no pooling arithmetic, exchange reads or statistics stores
+  noswap   no v_permlane32_swap of the half a wave finishes itself
+  noconv   no bias / activation / BatchNorm / split8 encoding between the two GEMMs
   nobar    no stage barriers
   nodma    no weight / frames DMA in the loops
 """
@@ -22,28 +23,28 @@ def rep(s, old, new, count=None):
 
 def variant(name):
     s = src
-    if name in ("nokeep", "noexch"):
-        s = rep(s, "                    keep_mine[r * 64] = hf ? y[1][r] : y[0][r];\n", "")
-        s = rep(s, "        pa[i] = pool_keep[off];\n", "        pa[i] = prm[1] + (float)off;\n")
-        if name == "noexch":
-            s = rep(s, "                    red_mine[r * 64] = hf ? y[0][r] : y[1][r];\n", "                    { float t0 = y[0][r], t1 = y[1][r]; asm volatile(\"\" :: \"v\"(t0), \"v\"(t1)); }\n")
-            s = rep(s, "        pb[i] = pool_red[off];\n", "        pb[i] = prm[2] + (float)off;\n")
-    elif name == "nopool":
-        s = rep(s, "        if constexpr (count >= 1) pool_read(std::integral_constant<int, first>{}, I0{});\n        if constexpr (count == 2) pool_read(std::integral_constant<int, first + 1>{}, I1{});\n", "")
-        s = rep(s, "        if constexpr (count >= 1) pool_row(std::integral_constant<int, first>{}, I0{}, ct - 1);\n        if constexpr (count == 2) pool_row(std::integral_constant<int, first + 1>{}, I1{}, ct - 1);\n", "")
-        s = s.replace("pin_a(std::integral_constant<int, 4 + 2 * pool_count(q, 0)>{})", "pin_a(std::integral_constant<int, 4>{})")
-        s = s.replace("pin_a(std::integral_constant<int, 4 + 2 * pool_count(q, 1)>{})", "pin_a(std::integral_constant<int, 4>{})")
-        s = s.replace("pin_a(std::integral_constant<int, 6 + 2 * pool_count(q, 2)>{})", "pin_a(std::integral_constant<int, 6>{})")
-        s = s.replace("pin_a(std::integral_constant<int, 2 + 2 * pool_count(q, 3)>{})", "pin_a(std::integral_constant<int, 2>{})")
+    if name == "noexch":        # the partner's half neither written nor read back (the KEEP half stays in registers anyway since round 4)
+        s = rep(s, "            if constexpr (q == 2) red_write(I0{}, ct);", "            if constexpr (q == 2) { float t0 = yR[0], t1 = yR[9]; asm volatile(\"\" :: \"v\"(t0), \"v\"(t1)); }")
+        s = rep(s, "            if constexpr (q == 2) red_write(I1{}, ct);\n", "")
+        s = rep(s, "        pn[i] = from[off];\n", "        pn[i] = prm[2] + (float)off;\n")
+    elif name == "nopool":      # no pooling arithmetic, exchange reads or statistics stores
+        s = rep(s, "            pool_row(std::integral_constant<int, 8 * q + 2 * j>{}, I0{}, ct - 1);\n            pool_row(std::integral_constant<int, 8 * q + 2 * j + 1>{}, I1{}, ct - 1);\n", "")
+        s = rep(s, "        pn[i] = from[off];\n", "")
+    elif name == "noswap":      # the KEEP half pooled as it lies (wrong rows): what the eight v_permlane32_swap cost
+        s = rep(s, '            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));\n', "")
     elif name == "nobar":
         s = rep(s, '        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");\n        __builtin_amdgcn_s_barrier();\n', '        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");\n')
     elif name == "nodma":
         s = rep(s, "        XV_BLDS16(wrs, lds + fill + wave * 4096, wvoff, wsoff, k * 1024);\n", "        if (wleft < 0) XV_BLDS16(wrs, lds + fill + wave * 4096, wvoff, wsoff, k * 1024);\n")
+    elif name == "noconv":      # H = the raw accumulators' bits: no bias / activation / BN / split8 encoding between the GEMMs
+        s = rep(s, "                xv_split8_encode8<true>(v, hi, x8[g], amax);\n", "                hi = __builtin_bit_cast(xv_f16x8, (f32x4){v[0], v[1], v[2], v[3]}); x8[g] = __builtin_bit_cast(xv_i32x4, (f32x4){v[4], v[5], v[6], v[7]});\n")
+        s = rep(s, "                    for (int e = 0; e < 4; ++e) v[4 * j + e] = act_fn<MODE>(t[8 * g + 4 * j + e] + b[e], a[e]) * s[e] + o[e];\n", "                    for (int e = 0; e < 4; ++e) v[4 * j + e] = t[8 * g + 4 * j + e];\n")
     else:
         raise SystemExit("unknown variant " + name)
     return s
 
 
+os.makedirs(OUT, exist_ok=True)
 for name in sys.argv[1:]:
     path = os.path.join(OUT, "xv_pair8_%s.hip" % name)
     open(path, "w").write(variant(name))

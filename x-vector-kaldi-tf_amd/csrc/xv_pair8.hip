@@ -8,9 +8,13 @@
 //   * a PAIR of waves owns 32 frames; wave h of the pair computes channels [256 h, 256 h + 256) of the intermediate H for
 //     all 32 frames (v_mfma_*_32x32*: H^T tile = 32 channels x 32 frames) and keeps them in registers (128 VGPRs, as
 //     before) -- so it only ever reads HALF of the first layer's weights;
-//   * in the second GEMM wave h contracts over ITS 256 channels only (half of the second layer's weights) and the two
-//     partial sums of a 32-frame x 64-column tile meet in LDS: each wave writes the 32-column half the partner finishes
-//     (RED, 4 KB) AND the half it finishes itself (KEEP, 4 KB), so that a lane can pool whole rows without any shuffle.
+//   * in the second GEMM wave h contracts over ITS 256 channels only (half of the second layer's weights).  Of a 32-frame x
+//     64-column tile it FINISHES the 32 columns of half h (KEEP) and hands the partner its partial sums of the other 32 (RED):
+//     the two halves are accumulated one after the other, so RED is complete in the middle of a tile and goes to LDS there
+//     (ds_write_addtid_b32, 4 KB per wave), while KEEP never leaves the registers -- eight v_permlane32_swap give a lane the
+//     sixteen rows of its column that make up two whole 8-row pooling blocks, and it pools them (one ds_read of the partner's
+//     partial sum per two rows) in the shadow of the next tile's first two stages.  Round 4; before, both halves went through
+//     LDS and back.
 // LDS traffic per workgroup: 16 MB of fragment reads + 4 MB of weight DMA instead of 32 + 4.
 //   * products are formed as in xv_gemm8.hip: one v_mfma_f32_32x32x16_f16 on the fp16 parts + one
 //     v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64 holds [xl8 . wh8 | xh8 . wl8] of a 32-channel slab, i.e. 32 MFMA passes
@@ -53,25 +57,11 @@ constexpr int P8_ROWS = 128;               // frames per workgroup: 4 pairs x 32
 constexpr int P8_STAGE = 32768;
 constexpr int P8_RING = 3;
 constexpr int P8_X_OFF = P8_RING * P8_STAGE;           // phase 1: per pair the 4 KB frames fragments of one slab
-constexpr int P8_RED_OFF = P8_X_OFF;                   // phase 2: per wave the 4 KB partial tile for the partner ...
-constexpr int P8_KEEP_OFF = P8_X_OFF + P8_WAVES * 4096; // ... and the 4 KB it finishes itself (over the dead first-layer parameters)
+constexpr int P8_RED_OFF = P8_X_OFF;                   // phase 2: per wave the 4 KB half tile for the partner, tiles of even parity ...
+constexpr int P8_KEEP_OFF = P8_X_OFF + P8_WAVES * 4096; // ... and of odd parity (over the dead first-layer parameters)
 constexpr int P8_P1_OFF = P8_X_OFF + P8_WAVES * 4096;  // [bias | scale | shift | alpha][CMID] of the first layer
 constexpr size_t P8_LDS_BYTES = P8_KEEP_OFF + P8_WAVES * 4096;      // 160 KB: everything a CU has
 constexpr int SROW = 128;
-
-// pooling schedule of the second GEMM: rows of the previous column tile handled in step j of stage q (see pool_step)
-constexpr int pool_count(int q, int j) { return q == 0 ? (j == 3 ? 2 : 0) : q == 3 ? (j == 0 ? 2 : j == 3 ? 0 : 1) : (j == 0 ? 2 : 1); }
-constexpr int pool_first(int q, int j)
-{
-    int k = 0;
-    for (int qq = 0; qq < 4; ++qq)
-        for (int jj = 0; jj < 4; ++jj) {
-            if (qq == q && jj == j) return k;
-            k += pool_count(qq, jj);
-        }
-    return k;
-}
-static_assert(pool_first(3, 3) + pool_count(3, 3) == 16, "16 rows per column tile");
 
 struct Pair8Params {
     const uint8_t *x;          // split8 input, row 0
