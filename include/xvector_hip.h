@@ -116,6 +116,13 @@ int xv_tdnn_layer_f32(const float *x, int64_t R, int cin, int ldx, const float *
 #define XV_SPLIT_PAD_AFTER 264
 size_t xv_packed_weights_bf16x3_bytes(int K, int cin, int cout);
 int xv_pack_weights_bf16x3(const float *w, int K, int cin, int cout, void *wt, void *stream);
+/* The tiles of n layers in ONE launch, each in one or both orientations (the training step re-packs every weight after every
+ * optimizer step): wt_fwd[i] = xv_pack_weights_bf16x3 of w[i][K, cin, cout] with cin padded by zero rows to cin_pad[i]
+ * (xv_packed_weights_bf16x3_bytes(K, cin_pad, cout) bytes); wt_bwd[i] = the operand of the input-gradient GEMM,
+ * w'[k, o, c] = w[K-1-k, c, o] as [K, cout, cin_pad] (xv_packed_weights_bf16x3_bytes(K, cout, cin_pad) bytes) -- what
+ * tf.gradients builds for conv1d / xw_plus_b (local/tf/models.py:112).  Either destination of a layer may be NULL. */
+int xv_pack_weights_bf16x3_many(int n, const float *const *w, const int32_t *K, const int32_t *cin, const int32_t *cin_pad,
+                                const int32_t *cout, void *const *wt_fwd, void *const *wt_bwd, void *stream);
 size_t xv_split_row_bytes(int channels);
 int xv_split_encode_f32(const float *x, int64_t R, int c, int ldx, void *xs, void *stream);
 int xv_split_decode_f32(const void *xs, int64_t R, int c, float *x, int ldx, void *stream);

@@ -210,6 +210,31 @@ def test_bf16x3_256_row_tiles_equal_128_row_tiles_bitwise(env, cin, cout, K, dil
     assert np.array_equal(got[128][1], got[256][1], equal_nan=True)
 
 
+def test_pack_weights_bf16x3_many_equals_the_single_packs(env):
+    """xv_pack_weights_bf16x3_many: every layer's forward tiles == xv_pack_weights_bf16x3(w padded to cin_pad), its input-gradient
+    tiles == xv_pack_weights_bf16x3(w'[k, o, c] = w[K-1-k, c, o]) -- byte for byte; and a second call follows the weights."""
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    g = torch.Generator().manual_seed(7)
+    shapes = [(5, 23, 24, 64), (5, 64, 64, 64), (7, 64, 64, 96), (1, 96, 96, 200), (1, 200, 200, 32), (1, 32, 32, 10), (3, 40, 40, 512)]
+    ws = [torch.randn((K, cin, cout), generator=g).to(dev) for K, cin, _, cout in shapes]
+    plan = hiplib.PackPlan([(w, pad, i != 5) for i, (w, (_, _, pad, _)) in enumerate(zip(ws, shapes))])
+    for rnd in range(2):
+        plan.repack()
+        for i, (w, (K, cin, pad, cout)) in enumerate(zip(ws, shapes)):
+            wpad = torch.cat([w, torch.zeros((K, pad - cin, cout), device=dev)], dim=1) if pad != cin else w
+            ref_f = hiplib.pack_weights_bf16x3(wpad.contiguous())
+            assert (plan.fwd[i].K, plan.fwd[i].cin, plan.fwd[i].cout) == (K, pad, cout)
+            assert torch.equal(plan.fwd[i].wt, ref_f.wt), (rnd, i)
+            if i == 5:
+                assert plan.bwd[i] is None
+                continue
+            ref_b = hiplib.pack_weights_bf16x3(wpad.flip(0).permute(0, 2, 1).contiguous())
+            assert (plan.bwd[i].K, plan.bwd[i].cin, plan.bwd[i].cout) == (K, cout, pad)
+            assert torch.equal(plan.bwd[i].wt, ref_b.wt), (rnd, i)
+        for w in ws:
+            w.mul_(1.5).add_(0.25)               # (in place: the plan holds the pointers, as the trainer's flat buffer)
+
+
 def test_split_format_roundtrip_and_layout(env):
     """xv_split_encode_f32 / xv_split_decode_f32 against a NumPy statement of the documented layout
     (include/xvector_hip.h): slot t = plane*4 + (k>>3) stored at t ^ ((r>>1)&7), value = hi + lo."""

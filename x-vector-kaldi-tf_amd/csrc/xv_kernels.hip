@@ -1727,6 +1727,56 @@ __global__ void pack_weights_bf16x3_kernel(const float *__restrict__ w, int K, i
     *reinterpret_cast<uint16_t *>(t + B3_PLANE) = __builtin_bit_cast(uint16_t, lo);
 }
 
+// The same tiles for MANY layers in one launch, each in one or both of two orientations (the training step re-packs every
+// weight after every optimizer step: sixteen launches and as many torch flip / permute / cat kernels per step before this):
+//   forward   wt_fwd = pack(w[K, cin_pad, cout])                                    (columns cin .. cin_pad-1 read as zero)
+//   backward  wt_bwd = pack(w'[K, cout, cin_pad]),  w'[k, o, c] = w[K-1-k, c, o]    (the input-gradient GEMM's operand)
+struct PackJob {
+    const float *w;
+    uint8_t *wt;
+    int K, cin_src, cin, cout, cout_src;      // logical [K, cin, cout] of the tiles; the source is w[K, cin_src, cout_src]
+    int transposed;
+    unsigned first_block;
+    unsigned long long total;
+};
+constexpr int PACK_MAX_JOBS = 24;
+struct PackJobs {
+    int n;
+    PackJob j[PACK_MAX_JOBS];
+};
+
+__global__ void pack_weights_bf16x3_many_kernel(const PackJobs jobs)
+{
+    int ji = 0;
+#pragma unroll 1
+    for (int t = 1; t < jobs.n; ++t)
+        if (blockIdx.x >= jobs.j[t].first_block) ji = t;
+    const PackJob &J = jobs.j[ji];
+    const size_t i = (size_t)(blockIdx.x - J.first_block) * blockDim.x + threadIdx.x;      // one (tile, col, k) element
+    if (i >= J.total) return;
+    const int n_chunks = (J.cin + BK - 1) / BK;
+    const int k = (int)(i & 31);
+    const int n = (int)((i >> 5) & 127);
+    const size_t tile = i >> 12;
+    const int tap = (int)(tile % J.K);
+    const int chunk = (int)((tile / J.K) % n_chunks);
+    const int nt = (int)(tile / ((size_t)J.K * n_chunks));
+    const int c = chunk * 32 + k, gn = nt * 128 + n;
+    float x = 0.f;
+    if (c < J.cin && gn < J.cout) {
+        if (!J.transposed) {
+            if (c < J.cin_src) x = J.w[((size_t)tap * J.cin_src + c) * J.cout_src + gn];
+        } else if (gn < J.cin_src) {                       // logical input channel c = source column, output gn = source row
+            x = J.w[((size_t)(J.K - 1 - tap) * J.cin_src + gn) * J.cout_src + c];
+        }
+    }
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    uint8_t *t = J.wt + tile * B3_BYTES + n * 64 + (((k >> 3) ^ ((n >> 2) & 3)) << 4) + (k & 7) * 2;
+    *reinterpret_cast<uint16_t *>(t) = __builtin_bit_cast(uint16_t, hi);
+    *reinterpret_cast<uint16_t *>(t + B3_PLANE) = __builtin_bit_cast(uint16_t, lo);
+}
+
 // fp32 rows -> split format (test / tooling helper; the layers write the format themselves)
 __global__ void split_encode_kernel(const float *__restrict__ x, long R, int c, int ldx, uint8_t *__restrict__ xs, int chunks)
 {
@@ -1788,7 +1838,7 @@ extern "C" {
 void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
 void xv_internal_first_tiles(int tiles);          // xv_first.hip
 
-int xv_version(void) { return 13; }
+int xv_version(void) { return 14; }
 
 int xv_set_tuning(int key, int value)
 {
@@ -1881,6 +1931,41 @@ int xv_pack_weights_bf16x3(const float *w, int K, int cin, int cout, void *wt, v
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, K,
                        cin, cout, n_chunks, (uint8_t *)wt, total);
     return check_launch("pack_weights_bf16x3_kernel");
+}
+
+int xv_pack_weights_bf16x3_many(int n, const float *const *w, const int32_t *K, const int32_t *cin, const int32_t *cin_pad,
+                                const int32_t *cout, void *const *wt_fwd, void *const *wt_bwd, void *stream)
+{
+    if (n <= 0) return 0;
+    if (!w || !K || !cin || !cin_pad || !cout || !wt_fwd || !wt_bwd) return fail(XV_ERR_BAD_ARG, "pack_weights_bf16x3_many: NULL pointer");
+    PackJobs jobs{};
+    unsigned blocks = 0;
+    auto flush = [&]() -> int {
+        if (jobs.n == 0) return 0;
+        hipLaunchKernelGGL(pack_weights_bf16x3_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs);
+        jobs.n = 0;
+        blocks = 0;
+        return check_launch("pack_weights_bf16x3_many_kernel");
+    };
+    for (int i = 0; i < n; ++i) {
+        if (!w[i] || K[i] <= 0 || cin[i] <= 0 || cin_pad[i] < cin[i] || cout[i] <= 0)
+            return fail(XV_ERR_BAD_ARG, "pack_weights_bf16x3_many: bad layer shape");
+        for (int dir = 0; dir < 2; ++dir) {
+            void *dst = dir ? wt_bwd[i] : wt_fwd[i];
+            if (!dst) continue;
+            if (((uintptr_t)dst) & 15) return fail(XV_ERR_BAD_ARG, "pack_weights_bf16x3_many: destinations must be 16-byte aligned");
+            if (jobs.n == PACK_MAX_JOBS)
+                if (int e = flush()) return e;
+            PackJob &J = jobs.j[jobs.n++];
+            J.w = w[i]; J.wt = (uint8_t *)dst; J.K = K[i]; J.cin_src = cin[i]; J.cout_src = cout[i]; J.transposed = dir;
+            J.cin = dir ? cout[i] : cin_pad[i];
+            J.cout = dir ? cin_pad[i] : cout[i];
+            J.total = xv_packed_weights_bf16x3_bytes(J.K, J.cin, J.cout) / 4;
+            J.first_block = blocks;
+            blocks += (unsigned)((J.total + 255) / 256);
+        }
+    }
+    return flush();
 }
 
 size_t xv_split_row_bytes(int channels) { return channels <= 0 ? 0 : (size_t)((channels + 31) / 32) * SROW; }

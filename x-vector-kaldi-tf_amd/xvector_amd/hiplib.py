@@ -10,12 +10,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
            "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32",
-           "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_split_row_bytes", "xv_split_encode_f32",
+           "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_pack_weights_bf16x3_many", "xv_split_row_bytes", "xv_split_encode_f32",
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32", "xv_tdnn_layer_pool_f32",
            "xv_packed_pair_bf16x3_bytes", "xv_pack_pair_bf16x3", "xv_tdnn_pair_pool_bf16x3",
@@ -82,6 +82,8 @@ def load():
     lib.xv_packed_weights_bf16x3_bytes.argtypes = [ci, ci, ci]
     lib.xv_pack_weights_bf16x3.restype = ci
     lib.xv_pack_weights_bf16x3.argtypes = [vp, ci, ci, ci, vp, vp]
+    lib.xv_pack_weights_bf16x3_many.restype = ci
+    lib.xv_pack_weights_bf16x3_many.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.xv_split_row_bytes.restype = sz
     lib.xv_split_row_bytes.argtypes = [ci]
     lib.xv_split_encode_f32.restype = ci
@@ -286,6 +288,52 @@ def pack_weights_bf16x3(w3d):
     wt = torch.empty(nbytes, dtype=torch.uint8, device=w3d.device)
     _check(lib.xv_pack_weights_bf16x3(_ptr(w3d), K, cin, cout, _ptr(wt), _stream()), "xv_pack_weights_bf16x3")
     return Packed3(wt, K, cin, cout)
+
+
+class PackPlan(object):
+    """The bf16x3 tiles of several layers, forward and (optionally) input-gradient orientation, re-packed by ONE launch
+    (xv_pack_weights_bf16x3_many) into one persistent device buffer: what a training step does after every optimizer update.
+    ``layers``: [(w3d [K, Cin, Cout] fp32 device tensor -- a VIEW whose storage the optimizer updates in place --, cin_pad, want_bwd)]."""
+
+    def __init__(self, layers):
+        import ctypes
+        import torch
+        lib = require_gpu()
+        n = len(layers)
+        self.n = n
+        dev = layers[0][0].device
+        sizes, offs, total = [], [], 0
+        for w, cin_pad, want_bwd in layers:
+            _f32(w, "w")
+            K, cin, cout = w.shape
+            assert cin_pad >= cin
+            f = int(lib.xv_packed_weights_bf16x3_bytes(K, cin_pad, cout))
+            b = int(lib.xv_packed_weights_bf16x3_bytes(K, cout, cin_pad)) if want_bwd else 0
+            offs.append((total, total + f))
+            total += f + b
+            sizes.append((f, b))
+        self.buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        base = self.buf.data_ptr()
+        assert base % 16 == 0
+        arr_p, arr_i = ctypes.c_void_p * n, ctypes.c_int32 * n
+        self._w = arr_p(*[w.data_ptr() for w, _, _ in layers])
+        self._K = arr_i(*[int(w.shape[0]) for w, _, _ in layers])
+        self._cin = arr_i(*[int(w.shape[1]) for w, _, _ in layers])
+        self._pad = arr_i(*[int(c) for _, c, _ in layers])
+        self._cout = arr_i(*[int(w.shape[2]) for w, _, _ in layers])
+        self._fwd = arr_p(*[base + o[0] for o in offs])
+        self._bwd = arr_p(*[(base + o[1]) if sz[1] else None for o, sz in zip(offs, sizes)])
+        self._keep = [w for w, _, _ in layers]
+        self.fwd, self.bwd = [], []
+        for (w, cin_pad, want_bwd), o, sz in zip(layers, offs, sizes):
+            K, cin, cout = w.shape
+            self.fwd.append(Packed3(self.buf[o[0]:o[0] + sz[0]], K, cin_pad, cout))
+            self.bwd.append(Packed3(self.buf[o[1]:o[1] + sz[1]], K, cout, cin_pad) if want_bwd else None)
+
+    def repack(self):
+        lib = require_gpu()
+        _check(lib.xv_pack_weights_bf16x3_many(self.n, self._w, self._K, self._cin, self._pad, self._cout, self._fwd, self._bwd,
+                                               _stream()), "xv_pack_weights_bf16x3_many")
 
 
 class SplitBuf(object):

@@ -13,6 +13,7 @@ Tdnn / PReLU / LRelu variants, the L2-loss terms of the ``ModelL2Loss*`` classes
 stateless counter-based mask (xv_dropout_f32) instead of TF's random stream.
 """
 import math
+import os
 
 import numpy as np
 
@@ -96,7 +97,11 @@ class Trainer(object):
             if adam and n in adam["v"]:
                 self.v[n].copy_(torch.as_tensor(np.array(adam["v"][n], np.float32)).to(self.device).view(shape))
         self._packed = None
+        self._plan = None
         self._layouts = {}
+        self._side_busy = False
+        self.two_streams = os.environ.get("XVECTOR_TRAIN_STREAMS", "2") != "1"
+        self._side = None                                          # second stream: weight gradients beside the input-gradient GEMMs
         self.l2_beta = float(topo.get("l2_beta", 0.0))
         self.l2_terms = (("embed_layer-0", 0.1), ("embed_layer-1", 1.0), ("output", 1.0))       # models.py:811-832
         head = topo.get("head") or {}
@@ -149,18 +154,29 @@ class Trainer(object):
     def _pack(self):
         if self._packed is not None:
             return self._packed
+        scopes = self.frame_scopes + self.embed_scopes + ["output"] + (["attention"] if self.attention else [])
         pk = {}
-        for sc in self.frame_scopes + self.embed_scopes + ["output"] + (["attention"] if self.attention else []):
+        plan_scopes = []
+        for sc in scopes:
+            w = self.P[sc + "/w:0"]
+            K, cin, cout = (1,) + tuple(w.shape) if w.dim() == 2 else tuple(w.shape)
+            cin_pad = self.in_dim if sc == self.frame_scopes[0] else cin
+            if self.precision == "bf16x3" and cin_pad % 4 == 0 and cout % 4 == 0:
+                plan_scopes.append((sc, w.view(K, cin, cout), cin_pad))
+                continue
             w = self._w3(sc, None)                                           # [K, Cin, Cout]
-            K, cin, cout = w.shape
             # dgrad: dx[r,c] = sum_{k,o} dz[r - (k-(K-1)/2)d, o] w[k,c,o]  == the forward kernel on w'[k',o,c] = w[K-1-k',c,o]
             wt = w.flip(0).permute(0, 2, 1).contiguous()                     # [K, Cout, Cin]
-            if self.precision == "bf16x3" and cin % 4 == 0 and cout % 4 == 0:
-                pk[sc] = hiplib.pack_weights_bf16x3(w)
-                pk[sc + "/T"] = hiplib.pack_weights_bf16x3(wt)
-            else:
-                pk[sc] = hiplib.pack_weights(w.reshape(K * cin, cout))
-                pk[sc + "/T"] = hiplib.pack_weights(wt.reshape(K * cout, cin))
+            pk[sc] = hiplib.pack_weights(w.reshape(K * cin_pad, cout))
+            pk[sc + "/T"] = hiplib.pack_weights(wt.reshape(K * cout, cin_pad))
+        if plan_scopes:
+            # the parameters are views into ONE flat buffer that Adam updates in place: the plan (pointers, destinations) is built
+            # once, a step re-packs every layer in both orientations with a single launch (xv_pack_weights_bf16x3_many)
+            if self._plan is None:
+                self._plan = hiplib.PackPlan([(w, cin_pad, True) for _, w, cin_pad in plan_scopes])
+            self._plan.repack()
+            for i, (sc, _, _) in enumerate(plan_scopes):
+                pk[sc], pk[sc + "/T"] = self._plan.fwd[i], self._plan.bwd[i]
         self._packed = pk
         return pk
 
@@ -312,20 +328,43 @@ class Trainer(object):
         R, cin = x_in.shape
         cout = dz.shape[1]
         gw, db = self.G[scope + "/w:0"], self.G[scope + "/b:0"]
-        if scope == self.frame_scopes[0] and self.in_dim != self.feat_dim:
-            dw = torch.empty((K, cin, cout), dtype=torch.float32, device=self.device)
-            hiplib.wgrad(x_in, dz, K, dil, dw, self.precision)
-            gw.copy_(dw[:, :self.feat_dim, :])                          # drop the padding column
-        else:
-            hiplib.wgrad(x_in, dz, K, dil, gw.view(K, cin, cout), self.precision)
-        hiplib.col_sums(dz, None, db)
+
+        def weight_side():
+            if scope == self.frame_scopes[0] and self.in_dim != self.feat_dim:
+                dw = torch.empty((K, cin, cout), dtype=torch.float32, device=self.device)
+                hiplib.wgrad(x_in, dz, K, dil, dw, self.precision)
+                gw.copy_(dw[:, :self.feat_dim, :])                          # drop the padding column
+            else:
+                hiplib.wgrad(x_in, dz, K, dil, gw.view(K, cin, cout), self.precision)
+            hiplib.col_sums(dz, None, db)
+
         grads[scope + "/w:0"] = gw
         grads[scope + "/b:0"] = db
+        # dW / db and dx only share their inputs: the weight side goes to a second stream, so that its workgroups fill the
+        # last, partly empty round of the input-gradient GEMM (a minibatch is 1.2 rounds of 128-row tiles) and vice versa;
+        # whoever reads the gradients next (a bucket's all-reduce, Adam) waits for that stream (_join_side)
+        if need_dx and self.two_streams:
+            main = torch.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                weight_side()
+            dz.record_stream(self._side)
+            x_in.record_stream(self._side)
+            self._side_busy = True
+        else:
+            weight_side()
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else torch.empty((R, cin), dtype=torch.float32, device=self.device)
         hiplib.tdnn_layer(dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid, dx)
         return dx
+
+    def _join_side(self):
+        if self._side_busy:
+            self.torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._side_busy = False
 
     def _bn_backward(self, scope, dh, r, z, mean, var, n_frames, valid, grads):
         torch = self.torch
@@ -367,6 +406,7 @@ class Trainer(object):
     def _l2_grad(self, scope, grads):
         """g += beta*coef*t for the penalised tensors of ``scope`` (models.py:811-842), right after they were produced."""
         if self.l2_beta:
+            self._join_side()                                   # (the weight gradient it adds to may still be on its way)
             for sc, coef in self.l2_terms:
                 if sc == scope:
                     for suffix in ("/w:0", "/b:0"):
@@ -426,6 +466,7 @@ class Trainer(object):
             hiplib.pool_backward(S["h"][-1], L["rs"], L["rl"], B, S["pooled"], d, dh)
         fire_after = {after: k for k, (_, _, after) in enumerate(self._ready_ranges())}     # frame layer -> bucket final after it
         if on_bucket is not None:
+            self._join_side()
             on_bucket(fire_after[None])                                    # segment-level tail (embed / attention / output)
         for i in reversed(range(len(self.frame_scopes))):
             sc = self.frame_scopes[i]
@@ -435,7 +476,9 @@ class Trainer(object):
             dh = self._dense_backward(sc, S["h"][i], dz, self.topo["kernel_sizes"][i], self.topo["dilations"][i], grads, i > 0,
                                       L["rv"])
             if on_bucket is not None and i in fire_after:
+                self._join_side()
                 on_bucket(fire_after[i])
+        self._join_side()
         if defer_loss:
             # (step(): loss, accuracy and the L2 penalty of the CURRENT weights are computed here, in stream order in front of
             # the optimizer update, but read back only after that update has been enqueued -- the read is the step's one host
