@@ -1752,29 +1752,42 @@ __global__ void pack_weights_bf16x3_many_kernel(const PackJobs jobs)
     for (int t = 1; t < jobs.n; ++t)
         if (blockIdx.x >= jobs.j[t].first_block) ji = t;
     const PackJob &J = jobs.j[ji];
-    const size_t i = (size_t)(blockIdx.x - J.first_block) * blockDim.x + threadIdx.x;      // one (tile, col, k) element
+    // one thread per 16-byte slot (8 channels of one column): the four slots of a column's 64-byte row are neighbouring lanes, so a wave
+    // writes 1 KB contiguous per plane; the transposed orientation also READS 32 contiguous bytes per thread
+    const size_t i = (size_t)(blockIdx.x - J.first_block) * blockDim.x + threadIdx.x;
     if (i >= J.total) return;
     const int n_chunks = (J.cin + BK - 1) / BK;
-    const int k = (int)(i & 31);
-    const int n = (int)((i >> 5) & 127);
-    const size_t tile = i >> 12;
+    const int k8 = (int)(i & 3);
+    const int n = (int)((i >> 2) & 127);
+    const size_t tile = i >> 9;
     const int tap = (int)(tile % J.K);
     const int chunk = (int)((tile / J.K) % n_chunks);
     const int nt = (int)(tile / ((size_t)J.K * n_chunks));
-    const int c = chunk * 32 + k, gn = nt * 128 + n;
-    float x = 0.f;
-    if (c < J.cin && gn < J.cout) {
+    const int c0 = chunk * 32 + k8 * 8, gn = nt * 128 + n;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = 0.f;
+    if (gn < J.cout) {
         if (!J.transposed) {
-            if (c < J.cin_src) x = J.w[((size_t)tap * J.cin_src + c) * J.cout_src + gn];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c0 + e < J.cin_src) x[e] = J.w[((size_t)tap * J.cin_src + c0 + e) * J.cout_src + gn];
         } else if (gn < J.cin_src) {                       // logical input channel c = source column, output gn = source row
-            x = J.w[((size_t)(J.K - 1 - tap) * J.cin_src + gn) * J.cout_src + c];
+            const float *row = J.w + ((size_t)(J.K - 1 - tap) * J.cin_src + gn) * J.cout_src;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c0 + e < J.cin) x[e] = row[c0 + e];
         }
     }
-    const __bf16 hi = (__bf16)x;
-    const __bf16 lo = (__bf16)(x - (float)hi);
-    uint8_t *t = J.wt + tile * B3_BYTES + n * 64 + (((k >> 3) ^ ((n >> 2) & 3)) << 4) + (k & 7) * 2;
-    *reinterpret_cast<uint16_t *>(t) = __builtin_bit_cast(uint16_t, hi);
-    *reinterpret_cast<uint16_t *>(t + B3_PLANE) = __builtin_bit_cast(uint16_t, lo);
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)x[e];
+        lo[e] = (__bf16)(x[e] - (float)hi[e]);
+    }
+    uint8_t *t = J.wt + tile * B3_BYTES + n * 64 + ((k8 ^ ((n >> 2) & 3)) << 4);
+    *reinterpret_cast<bf16x8 *>(t) = hi;
+    *reinterpret_cast<bf16x8 *>(t + B3_PLANE) = lo;
 }
 
 // fp32 rows -> split format (test / tooling helper; the layers write the format themselves)
@@ -1960,7 +1973,7 @@ int xv_pack_weights_bf16x3_many(int n, const float *const *w, const int32_t *K, 
             J.w = w[i]; J.wt = (uint8_t *)dst; J.K = K[i]; J.cin_src = cin[i]; J.cout_src = cout[i]; J.transposed = dir;
             J.cin = dir ? cout[i] : cin_pad[i];
             J.cout = dir ? cin_pad[i] : cout[i];
-            J.total = xv_packed_weights_bf16x3_bytes(J.K, J.cin, J.cout) / 4;
+            J.total = xv_packed_weights_bf16x3_bytes(J.K, J.cin, J.cout) / 32;     // one thread per 16-byte slot of each plane
             J.first_block = blocks;
             blocks += (unsigned)((J.total + 255) / 256);
         }
