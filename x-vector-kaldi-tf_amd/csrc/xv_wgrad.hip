@@ -18,14 +18,9 @@
 //   * its 16 values become 16 hi + 16 lo bf16 = 4 x 16 bytes, written with ds_write_b128 into a [channel][row] image
 //     (80-byte channel stride: both the writes' 8-lane groups and the reads' 16-lane groups touch distinct 16-byte slots);
 //   * a fragment is then ONE ds_read_b128 per (32-channel tile, k-step, plane): 16 reads for the 24 MFMAs of a step and wave.
-// Workgroup = 4 waves as 2 x 2, 128 x 128 tile, 64 x 64 per wave.  The LDS image is double-buffered (round 4: 2 x 40 KB, two
-// workgroups fill a CU's 160 KB exactly): the conversion and the ds_writes of step s+1 and the 32 loads per thread of step s+2 are
-// issued in front of the 24 MFMAs of step s and run under them -- ONE barrier per step; before, a step was stage | barrier | MFMAs |
-// barrier and a wave's ~600 cycles of conversion VALU never overlapped its own 768 MFMA cycles.
+// Workgroup = 4 waves as 2 x 2, 128 x 128 tile, 64 x 64 per wave; next step's 32 loads per thread are in flight under the MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#include <atomic>
 
 #include "xvector_hip.h"
 
@@ -40,7 +35,6 @@ constexpr int WT = 128;           // tile edge (channels)
 constexpr int WR = 32;            // rows per step = two MFMA k-steps
 constexpr int CH_STRIDE = 80;     // bytes per channel in the LDS image: 32 rows x 2 bytes + 16 (see above)
 constexpr int PLANE = WT * CH_STRIDE;                  // 10240: one operand, one of hi / lo
-constexpr int BUF = 4 * PLANE;                         // one step's image; two of them
 constexpr int RSRC_FLAGS = 0x00020000;                 // raw buffer, 32-bit data format (gfx9 family dword 3)
 
 struct WgradParams {
@@ -55,7 +49,7 @@ struct WgradParams {
 
 __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const WgradParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds[];         // 2 x [x hi | x lo | dz hi | dz lo]
+    __shared__ __attribute__((aligned(16))) char lds[4 * PLANE];       // [x hi | x lo | dz hi | dz lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     int t = blockIdx.x;
@@ -109,32 +103,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const WgradParams 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
     // fragment of tile i, k-step ks: channel wi*64 + 32 i + (lane & 31), rows 16 ks + 8 (lane >> 5) .. + 7
-    const int afrag = (wi * 64 + (lane & 31)) * CH_STRIDE + 16 * (lane >> 5);
-    const int bfrag = 2 * PLANE + (wj * 64 + (lane & 31)) * CH_STRIDE + 16 * (lane >> 5);
+    const char *afrag = lds + (wi * 64 + (lane & 31)) * CH_STRIDE + 16 * (lane >> 5);
+    const char *bfrag = lds + 2 * PLANE + (wj * 64 + (lane & 31)) * CH_STRIDE + 16 * (lane >> 5);
 
     load(r_begin);
-    stage(vx, xc_ok, lds);
-    stage(vz, zc_ok, lds + 2 * PLANE);
-    if (r_begin + WR < r_end) load(r_begin + WR);
-    __syncthreads();
-    int cur = 0;
     for (long r0 = r_begin; r0 < r_end; r0 += WR) {
-        const char *buf = lds + cur * BUF;
-        if (r0 + WR < r_end) {                           // step s+1 -> the other buffer (everybody left it at the last barrier)
-            char *nxt = lds + (cur ^ 1) * BUF;
-            stage(vx, xc_ok, nxt);
-            stage(vz, zc_ok, nxt + 2 * PLANE);
-            if (r0 + 2 * WR < r_end) load(r0 + 2 * WR);  // in flight under the 24 MFMAs below
-        }
+        stage(vx, xc_ok, lds);
+        stage(vz, zc_ok, lds + 2 * PLANE);
+        __syncthreads();
+        if (r0 + WR < r_end) load(r0 + WR);              // in flight under the 24 MFMAs below
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8 *>(buf + afrag + i * 32 * CH_STRIDE + ks * 32);
-                al[i] = *reinterpret_cast<const bf16x8 *>(buf + afrag + i * 32 * CH_STRIDE + ks * 32 + PLANE);
-                bh[i] = *reinterpret_cast<const bf16x8 *>(buf + bfrag + i * 32 * CH_STRIDE + ks * 32);
-                bl[i] = *reinterpret_cast<const bf16x8 *>(buf + bfrag + i * 32 * CH_STRIDE + ks * 32 + PLANE);
+                ah[i] = *reinterpret_cast<const bf16x8 *>(afrag + i * 32 * CH_STRIDE + ks * 32);
+                al[i] = *reinterpret_cast<const bf16x8 *>(afrag + i * 32 * CH_STRIDE + ks * 32 + PLANE);
+                bh[i] = *reinterpret_cast<const bf16x8 *>(bfrag + i * 32 * CH_STRIDE + ks * 32);
+                bl[i] = *reinterpret_cast<const bf16x8 *>(bfrag + i * 32 * CH_STRIDE + ks * 32 + PLANE);
             }
             // small terms first, as in the forward kernel (xv_kernels.hip): lo*hi + hi*lo + hi*hi
 #pragma unroll
@@ -151,7 +137,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const WgradParams 
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
-        cur ^= 1;
     }
     // D: col = lane & 31 (cout), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (cin)
     float *out = p.out + ((size_t)blockIdx.y * p.K + k) * (size_t)p.cin * p.cout;
@@ -205,18 +190,7 @@ int xv_wgrad_bf16x3(const float *x, int ldx, const float *dz, int lddz, int64_t 
     }
     p.out = splits > 1 ? (float *)workspace : dw;
     hipStream_t st = (hipStream_t)stream;
-    static std::atomic<unsigned long long> attr_done{0};      // dynamic-LDS opt-in (80 KB): per device, idempotent
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        hipError_t ae = hipFuncSetAttribute((const void *)wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
-        if (ae != hipSuccess) {
-            xv_internal_set_error(hipGetErrorString(ae));
-            return (int)ae;
-        }
-        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
-    }
-    hipLaunchKernelGGL(wgrad_bf16x3_kernel, dim3((unsigned)(K * p.n_ct * p.n_ot), (unsigned)splits), dim3(256), 2 * BUF, st, p);
+    hipLaunchKernelGGL(wgrad_bf16x3_kernel, dim3((unsigned)(K * p.n_ct * p.n_ot), (unsigned)splits), dim3(256), 0, st, p);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && splits > 1) {
         const size_t n = (size_t)K * cin * cout;
