@@ -911,13 +911,13 @@ def main():
             torch.cuda.empty_cache()
             tr = {}
             for prec in ("fp32", "bf16x3"):
-                tr[prec] = _train_run(args, 0, 1, dev, tp.get("ModelWithoutDropout"), feat, prec, 10, 2)
+                tr[prec] = _train_run(args, 0, 1, dev, tp.get("ModelWithoutDropout"), feat, prec, 30, 3)
             out["train_step"] = dict(tr["bf16x3"], fp32=tr["fp32"],
                                      product_default="fp32: Model.train_one_iteration (local/tf/models.py, the twin of the reference's "
                                                      "models.py:216-305) and train_dnn.py run the exact-fp32 step (the `fp32` entry here) unless "
                                                      "XVECTOR_TRAIN_PRECISION=bf16x3 is set; the top-level figures of this object are the bf16x3 step",
                                      workload="BASELINE configs[4], one rank's share: 64-chunk minibatches, T ~ U{%d..%d}, 64 speakers, "
-                                              "AM-softmax head, Adam; 10 timed steps after 2" % (args.tmin, args.tmax))
+                                              "AM-softmax head, Adam; 30 timed steps after 3 (minibatch lengths are drawn per step: ten steps were too few for a steady figure)" % (args.tmin, args.tmax))
         except Exception as e:
             out["train_step"] = {"error": repr(e)}
         try:
