@@ -476,3 +476,40 @@ def test_select_voiced_window_rules_match_the_per_utterance_oracle(oracle_mod):
             assert voiced is None
         else:
             assert np.array_equal(voiced, np.concatenate(want_flags) if want_flags else np.zeros(0, bool)), trial
+
+
+def test_vad_runs_select_like_the_list_of_vectors():
+    """frontend.VadRuns -- the VAD vectors of a window as a few (values, offsets) runs, what the reader hands over while the VAD table's
+    keys arrive in the order of the features -- gives select_voiced's answers for the list of per-utterance vectors it stands for, and
+    reads back as that list."""
+    from xvector_amd import frontend
+    rng = np.random.default_rng(9)
+    for trial in range(40):
+        n = int(rng.integers(1, 80))
+        mats, vads = [], []
+        for i in range(n):
+            T = int(rng.choice([0, 1, 5, 40, 300], p=[.05, .1, .15, .4, .3]))
+            mats.append(rng.standard_normal((T, 3)).astype(np.float32))
+            r = rng.random()
+            if r < 0.1 and trial % 3:
+                vads.append(np.zeros(T, np.float32))                                   # nothing voiced
+            elif r < 0.2 and trial % 3:
+                vads.append((rng.random(max(0, T + int(rng.choice([-1, 1, 7])))) < 0.7).astype(np.float32))       # another length
+            else:
+                vads.append((rng.random(T) < rng.choice([0.3, 0.9, 1.0])).astype(np.float32))
+        runs = frontend.VadRuns()
+        i = 0
+        while i < n:                                       # runs of random lengths, now and then a single vector
+            m = int(rng.integers(1, 12))
+            part = vads[i:i + m]
+            if m == 1 or rng.random() < 0.2:
+                for v in part:
+                    runs.add_one(v)
+            else:
+                offs = np.concatenate([[0], np.cumsum([len(v) for v in part])])
+                runs.add_run(np.concatenate(part) if part else np.zeros(0, np.float32), offs)
+            i += m
+        assert len(runs) == n and all(np.array_equal(a, b) for a, b in zip(runs, vads)) and np.array_equal(runs[n - 1], vads[n - 1])
+        got, want = frontend.select_voiced(mats, runs), frontend.select_voiced(mats, vads)
+        assert got[0].tolist() == want[0].tolist() and got[1].tolist() == want[1].tolist(), trial
+        assert np.array_equal(got[2], want[2]) and list(got[3]) == list(want[3]) and got[4] == want[4], trial

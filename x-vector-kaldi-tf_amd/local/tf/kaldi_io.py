@@ -1378,11 +1378,18 @@ class _ScpTable(object):
                 if fd is not file_or_fd:
                     fd.close()
             lines = (text.decode() if isinstance(text, bytes) else text).split("\n")
-        self.entries = []
-        for ln in lines:
-            if ln and not ln.isspace():
-                key, rx = ln.rstrip("\n").split(" ", 1)
-                self.entries.append((key, rx.strip()))
+        # parsed on first use: a job builds its tables before it starts its reader thread, and the 20-30 ms per 50 k lines then run
+        # on that thread, beside the model load, instead of in front of it
+        self._lines, self._entries = lines, None
+
+    @property
+    def entries(self):
+        if self._entries is None:
+            # key = up to the first whitespace, rxfile = the rest without surrounding whitespace (a line without one raises, as a
+            # malformed table should)
+            self._entries = [(k, r.rstrip()) for k, r in (ln.split(None, 1) for ln in self._lines if ln and not ln.isspace())]
+            self._lines = None
+        return self._entries
 
     def __len__(self):
         return len(self.entries)

@@ -35,7 +35,7 @@ if _PKG_ROOT not in sys.path:
     sys.path.insert(0, _PKG_ROOT)
 
 import kaldi_io  # noqa: E402  (the sibling module, as in the reference)
-from xvector_amd import engine, synthetic, topology, weights as wio  # noqa: E402
+from xvector_amd import engine, frontend, synthetic, topology, weights as wio  # noqa: E402
 
 VAR2STD_EPSILON = topology.VAR2STD_EPSILON        # models.py:16
 
@@ -491,22 +491,64 @@ class Model(object):
                     if cancel.is_set():           # the consumer gave up: nobody will ever return an arena
                         raise _Cancelled()
 
+        def prefetched(blocks, depth=2):
+            """``blocks`` read by a thread of its own, ``depth`` ahead (the VAD table beside the features: its reads release the
+            interpreter lock, so the two files are read side by side)."""
+            q, end = queue.Queue(maxsize=depth), object()
+
+            def run():
+                def put(x):
+                    while not cancel.is_set():
+                        try:
+                            q.put(x, timeout=0.2)
+                            return True
+                        except queue.Full:
+                            pass
+                    return False
+                try:
+                    for b in blocks:
+                        if not put(b):
+                            return
+                    put(end)
+                except BaseException as e:      # noqa: B902 -- forwarded to the consumer
+                    put(e)
+            threading.Thread(target=run, daemon=True).start()
+            while True:
+                b = q.get()
+                if b is end:
+                    return
+                if isinstance(b, BaseException):
+                    raise b
+                yield b
+
         def reader():
             try:
-                keys, vads = [], []
+                keys, vads = [], None
                 vad_it, pending = None, {}
+                vad_blocks, vad_cur = None, None               # block source of the VAD table and [keys, values, offsets, position] in it
                 if vad_stream is not None:
-                    # an ark stream or a table with blocks() (kaldi_io.VecScp) is read in scanner passes, one view per key
+                    vads = frontend.VadRuns()
+                    # an ark stream or a table with blocks() (kaldi_io.VecScp) is read in scanner passes; while its keys arrive in the
+                    # order of the features -- the recipe's tables do -- whole runs of a block go into the window (frontend.VadRuns),
+                    # no Python step per utterance
                     if hasattr(vad_stream, "read") or hasattr(vad_stream, "blocks"):
-                        def vad_records():
-                            src = kaldi_io.read_vec_flt_ark_blocks(vad_stream) if hasattr(vad_stream, "read") else vad_stream.blocks()
-                            for vkeys, vals, voff in src:
-                                vo = voff.tolist()
-                                for n_, k_ in enumerate(vkeys):
-                                    yield k_, vals[vo[n_]:vo[n_ + 1]]
-                        vad_it = vad_records()
+                        vad_blocks = prefetched(kaldi_io.read_vec_flt_ark_blocks(vad_stream) if hasattr(vad_stream, "read") else vad_stream.blocks())
                     else:
                         vad_it = iter(vad_stream)
+
+                def vad_records():
+                    """The rest of the block source one vector at a time (after the first key out of order)."""
+                    cur = vad_cur
+                    while True:
+                        if cur is not None:
+                            vkeys, vals, vo, pos = cur
+                            o = vo.tolist()
+                            for n_ in range(pos, len(vkeys)):
+                                yield vkeys[n_], vals[o[n_]:o[n_ + 1]]
+                        nxt = next(vad_blocks, None)
+                        if nxt is None:
+                            return
+                        cur = [list(nxt[0]), nxt[1], np.asarray(nxt[2], np.int64), 0]
 
                 def vad_for(key):
                     # same key order as the features (extract_xvectors.sh reads it as scp,s,cs); out-of-order tables still
@@ -518,6 +560,55 @@ class Model(object):
                             return v
                         pending[k] = v
                     return np.zeros(0, np.float32)        # no VAD for this key -> length mismatch -> dropped with a warning
+
+                def take_vads(bkeys, runs):
+                    """The VAD vectors of the utterances ``bkeys`` (a piece of a window) -> runs."""
+                    nonlocal vad_it, vad_blocks, vad_cur
+                    i, n = 0, len(bkeys)
+                    while vad_blocks is not None and i < n:
+                        if vad_cur is None or vad_cur[3] == len(vad_cur[0]):
+                            nxt = next(vad_blocks, None)
+                            if nxt is None:                    # table exhausted: the remaining keys have no VAD
+                                vad_blocks, vad_cur, vad_it = None, None, iter(())
+                                break
+                            vad_cur = [list(nxt[0]), nxt[1], np.asarray(nxt[2], np.int64), 0]
+                            continue
+                        vkeys, vals, vo, pos = vad_cur
+                        m = min(n - i, len(vkeys) - pos)
+                        if vkeys[pos:pos + m] == bkeys[i:i + m]:
+                            runs.add_run(vals[int(vo[pos]):int(vo[pos + m])], vo[pos:pos + m + 1] - vo[pos])
+                            vad_cur[3] = pos + m
+                            i += m
+                        else:
+                            # the first key that differs: the longest common prefix goes as a run; then either the table has entries
+                            # the features do not (a feats.scp that lists a subset: skip them, kept in case they are asked for
+                            # later) or the key is one that was skipped before
+                            c = 0
+                            while vkeys[pos + c] == bkeys[i + c]:
+                                c += 1
+                            if c:
+                                runs.add_run(vals[int(vo[pos]):int(vo[pos + c])], vo[pos:pos + c + 1] - vo[pos])
+                                pos += c
+                                i += c
+                            key = bkeys[i]
+                            if key in pending:
+                                runs.add_one(pending.pop(key))
+                                vad_cur[3] = pos
+                                i += 1
+                                continue
+                            try:
+                                j = vkeys.index(key, pos)
+                            except ValueError:                 # not in this block: one vector at a time from here on
+                                vad_cur[3] = pos
+                                vad_it = vad_records()
+                                vad_blocks = None
+                                break
+                            o = vo.tolist()
+                            for q in range(pos, j):
+                                pending[vkeys[q]] = vals[o[q]:o[q + 1]]
+                            vad_cur[3] = j
+                    for key in bkeys[i:]:
+                        runs.add_one(vad_for(key))
 
                 def pieces():
                     """(keys, addr[n], rows[n], cols, holder) -- utterances where they lie: whole arenas for ark streams and scp
@@ -553,7 +644,7 @@ class Model(object):
                 mats, frames = kaldi_io.ArkMats(), 0
 
                 def put():
-                    item = (keys, mats, vads if vad_it is not None else None)
+                    item = (keys, mats, vads)
                     while not cancel.is_set():
                         try:
                             windows.put(item, timeout=0.2)
@@ -567,12 +658,12 @@ class Model(object):
                 for bkeys, addr, rows, cols, holder in pieces():
                     keys.extend(bkeys)
                     mats.add(addr, rows, cols, holder)
-                    if vad_it is not None:
-                        vads.extend(vad_for(key) for key in bkeys)
+                    if vads is not None:
+                        take_vads(list(bkeys), vads)
                     frames += int(np.sum(rows))
                     if frames >= limit or in_place:
                         put()
-                        keys, vads, mats, frames = [], [], kaldi_io.ArkMats(), 0
+                        keys, vads, mats, frames = [], (None if vads is None else frontend.VadRuns()), kaldi_io.ArkMats(), 0
                         limit = min(self.window_frames, 2 * limit)
                 if keys:
                     put()
@@ -598,7 +689,6 @@ class Model(object):
         ex = engine.Extractor(self.device_model, min_chunk_size, chunk_size, max_batch_rows=self.max_batch_rows)
         front = None
         if cmn_window > 0 or vad_stream is not None:
-            from xvector_amd import frontend
             front = frontend.FrontEnd(self.device_model.device, cmn_window, cmn_center)     # cmn_window <= 0: selection only
 
         total_segments = 0

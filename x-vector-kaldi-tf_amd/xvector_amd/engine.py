@@ -1097,7 +1097,7 @@ class Extractor(object):
         never exist on the host.  mats: float32 [T, F] arrays; vads: None or one 1-D array (non-zero = voiced) / None per
         utterance; addrs: optional ``matrix_addresses(mats, F)``.  Returns ``(handle, lengths, vad_dropped)``: the handle for ``finish``; the number of selected frames per
         utterance; a bool mask of the utterances select-voiced-frames drops (VAD length mismatch / no voiced frame)."""
-        from .frontend import select_voiced
+        from .frontend import VadRuns, select_voiced
         if self.demoted:
             box = []
 
@@ -1129,7 +1129,8 @@ class Extractor(object):
         if vads is None:
             vad_dropped[:] = False
         else:
-            vad_dropped &= np.fromiter((v is not None for v in vads), dtype=bool, count=n)
+            if not isinstance(vads, VadRuns):             # (runs: every utterance has a vector)
+                vad_dropped &= np.fromiter((v is not None for v in vads), dtype=bool, count=n)
         order, c_utt, c_start, c_len, seg_start = plan_chunk_table(V, self.min_chunk_size, self.chunk_size)
         nch = len(c_utt)
         handle = dict(n=n, order=order, nch=nch)

@@ -17,6 +17,54 @@ import numpy as np
 from . import hiplib
 
 
+class VadRuns(object):
+    """The VAD vectors of consecutive utterances as a few RUNS -- (values, offsets) pairs that cover many utterances each -- instead
+    of one small array per utterance: what the reader of a vad.scp / VAD ark hands over when the keys arrive in the order of the
+    features (extract_xvectors.sh reads them as scp,s,cs).  Behaves as the sequence of per-utterance vectors it stands for; the
+    frame selection takes the concatenation directly (50 k generator steps and 50 k tiny arrays per job otherwise)."""
+
+    def __init__(self):
+        self._vals, self._offs, self._n = [], [], 0
+        self._flat = None
+
+    def add_run(self, vals, offs):
+        """vals: the decisions of m utterances back to back; offs: their m + 1 offsets into vals (offs[0] == 0)."""
+        if len(offs) > 1:
+            self._vals.append(np.asarray(vals).reshape(-1))
+            self._offs.append(np.asarray(offs, np.int64))
+            self._n += len(offs) - 1
+            self._flat = None
+
+    def add_one(self, v):
+        v = np.asarray(v).reshape(-1)
+        self.add_run(v, np.array([0, v.shape[0]], np.int64))
+
+    def __len__(self):
+        return self._n
+
+    def flat(self):
+        """(values of all utterances concatenated, their n + 1 offsets)."""
+        if self._flat is None:
+            if not self._vals:
+                self._flat = (np.zeros(0, np.float32), np.zeros(1, np.int64))
+            elif len(self._vals) == 1:
+                self._flat = (self._vals[0], self._offs[0])
+            else:
+                base = np.cumsum([0] + [int(o[-1]) for o in self._offs[:-1]])
+                offs = np.concatenate([self._offs[0][:1]] + [o[1:] + b for o, b in zip(self._offs, base)])
+                self._flat = (np.concatenate(self._vals), offs)
+        return self._flat
+
+    def __iter__(self):
+        vals, offs = self.flat()
+        o = offs.tolist()
+        return (vals[o[i]:o[i + 1]] for i in range(self._n))
+
+    def __getitem__(self, i):
+        vals, offs = self.flat()
+        return vals[int(offs[i]):int(offs[i + 1])]
+
+
 def select_voiced(mats, vads):
     """The utterance-level rules of select-voiced-frames for a window, vectorised.  Returns
     ``(T, cand, voiced, empty, dropped)``: frame counts of all utterances; indices of the utterances that go on (T > 0, VAD of
@@ -27,6 +75,26 @@ def select_voiced(mats, vads):
     T = np.asarray(mats.lengths, np.int64) if hasattr(mats, "lengths") else np.fromiter((m.shape[0] for m in mats), dtype=np.int64, count=n)
     if vads is None:
         return T, np.flatnonzero(T > 0), None, np.flatnonzero(T == 0).tolist(), 0
+    if isinstance(vads, VadRuns):
+        # every utterance has a vector (possibly empty), and they lie back to back already
+        assert len(vads) == n
+        vals, offs = vads.flat()
+        vl = np.diff(offs)
+        cand = np.flatnonzero((vl == T) & (T > 0))                            # a length mismatch drops the key
+        if len(cand) == n:
+            voiced = vals != 0
+        elif len(cand):
+            voiced = vals[np.repeat((vl == T) & (T > 0), vl)] != 0
+        else:
+            voiced = np.zeros(0, bool)
+        starts = np.zeros(len(cand), dtype=np.int64)
+        np.cumsum(T[cand][:-1], out=starts[1:])
+        counts = np.add.reduceat(voiced, starts) if len(cand) else np.zeros(0, np.int64)
+        has = counts > 0
+        if not has.all():
+            voiced = voiced[np.repeat(has, T[cand])]
+            cand = cand[has]
+        return T, cand, voiced, [], n - len(cand)
     flat = [None if v is None else np.asarray(v).reshape(-1) for v in vads]
     vl = np.fromiter((-1 if v is None else v.shape[0] for v in flat), dtype=np.int64, count=n)
     empty = np.flatnonzero((vl < 0) & (T == 0)).tolist()
