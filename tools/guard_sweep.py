@@ -20,9 +20,18 @@ def main():
     oracle.build()
     print("%-13s %4s | %9s %9s | %9s %8s | %9s %9s %9s | selected" % ("weights", "seed", "load", "b3|fp32", "run-time", "demoted",
                                                                        "f16bf8", "bf16x3", "fp32"))
-    for kind in ("trained_like", "hostile"):
+    # "trained": checkpoints that were TRAINED by the product's own training step (synthetic.trained_checkpoint) -- seeds, step counts
+    # (100 ... 1200) and learning rates vary, so that the table holds barely trained and long-trained models alike
+    kinds = ("trained", "trained_like", "hostile") if cls == "ModelWithoutDropout" else ("trained_like", "hostile")
+    for kind in kinds:
         for seed in range(100, 100 + n):
-            w = getattr(synthetic, kind)(topo, 23, seed=seed)
+            if kind == "trained":
+                steps = (100, 300, 600, 1200)[seed % 4]
+                w, info = synthetic.trained_checkpoint(topo, 23, n_spk=64, steps=steps, learning_rate=(1e-3, 3e-3)[(seed >> 2) & 1], seed=seed)
+                print("#   trained %d: %d Adam steps, loss %.3f -> %.4f, accuracy %.2f" % (seed, steps, info["first_loss"], info["last_loss"],
+                                                                                          info["accuracy_last"]), flush=True)
+            else:
+                w = getattr(synthetic, kind)(topo, 23, seed=seed)
             mats = synthetic.mfcc_like([30, 64, 150, 256, 400, 777], 23, seed=seed + 1)
             refs = [oracle.embed_utterance(m, w, topo, 25, 10000, np.float64) for m in mats]
 
