@@ -222,3 +222,59 @@ def test_cli_on_a_kaldi_shaped_data_directory(env, tmp_path):
     assert len(out["plain"]) > 1000 and out["kaldi"] == out["plain"]
     got = [k for k, _ in kaldi_io.read_vec_flt_ark(__import__("io").BytesIO(out["kaldi"]))]
     assert got == [keys[i] for i in keep if vads[i].sum() >= 25]
+
+
+def test_vad_tables_in_any_order_give_the_same_vectors(tmp_path):
+    """Model.make_embedding with the device front-end takes the VAD vectors in RUNS while the VAD table's keys arrive in the order of the
+    features (frontend.VadRuns), steps over entries the features do not have, and falls back to one vector at a time when a key is
+    out of order: a VAD table in feature order, one with extra keys, a shuffled one and a per-key iterator all write the same bytes;
+    a table that lacks keys drops exactly those utterances."""
+    import io
+    import logging
+    import kaldi_io
+    import models
+    from xvector_amd import synthetic, topology, weights as wio
+    topo = topology.get("ModelWithoutDropout")
+    w = synthetic.trained_like(topo, 23, seed=2)
+    mdir = str(tmp_path / "m")
+    wio.save_model_dir(mdir, w, topo, "ModelWithoutDropout", 8, 23)
+    rng = np.random.default_rng(21)
+    n = 70
+    keys = ["utt%03d" % i for i in range(n)]
+    mats = [(rng.standard_normal((int(rng.integers(60, 400)), 23)) * 3).astype(np.float32) for _ in range(n)]
+    vads = [(rng.random(m.shape[0]) < 0.75).astype(np.float32) for m in mats]
+    with kaldi_io.TableWriter(str(tmp_path / "f.ark"), str(tmp_path / "f.scp")) as t:
+        for k, m in zip(keys, mats):
+            kaldi_io.write_mat(t, m, key=k)
+    extra = [("zzz%02d" % i, np.ones(17, np.float32)) for i in range(5)]
+
+    def vad_table(name, order, with_extra=False, drop=()):
+        entries = [(keys[i], vads[i]) for i in order if keys[i] not in drop]
+        if with_extra:                                       # entries the features do not have, in between and at both ends
+            entries = [("aaa", np.ones(9, np.float32))] + entries[:20] + extra[:2] + entries[20:51] + extra[2:] + entries[51:]
+        with kaldi_io.TableWriter(str(tmp_path / (name + ".ark")), str(tmp_path / (name + ".scp"))) as tv:
+            for k, v in entries:
+                kaldi_io.write_vec_flt(tv, v, key=k)
+        return str(tmp_path / (name + ".scp"))
+
+    log = logging.getLogger("vad-order")
+    log.addHandler(logging.NullHandler())
+
+    def run(vad_source):
+        out = io.BytesIO()
+        models.ModelWithoutDropout().make_embedding(kaldi_io.MatScp(str(tmp_path / "f.scp")), out, mdir, 25, 10000, True, log,
+                                                    vad_stream=vad_source, cmn_window=300)
+        return out.getvalue()
+
+    in_order = run(kaldi_io.VecScp(vad_table("v0", range(n))))
+    got = dict(kaldi_io.read_vec_flt_ark(io.BytesIO(in_order)))
+    assert list(got) == keys
+    assert run(kaldi_io.VecScp(vad_table("v1", range(n), with_extra=True))) == in_order
+    shuffled = list(rng.permutation(n))
+    assert run(kaldi_io.VecScp(vad_table("v2", shuffled))) == in_order
+    assert run(open(str(tmp_path / "v0.ark"), "rb")) == in_order                               # the VAD ark as a stream
+    assert run(iter(list(zip(keys, vads)))) == in_order                                          # (key, vector) pairs
+    missing = {keys[3], keys[40], keys[69]}
+    part = dict(kaldi_io.read_vec_flt_ark(io.BytesIO(run(kaldi_io.VecScp(vad_table("v3", range(n), drop=missing))))))
+    assert list(part) == [k for k in keys if k not in missing]
+    assert all(np.array_equal(part[k], got[k]) for k in part)

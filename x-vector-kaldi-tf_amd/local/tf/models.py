@@ -536,16 +536,15 @@ class Model(object):
                     else:
                         vad_it = iter(vad_stream)
 
-                def vad_records():
+                def vad_records(blocks, cur):
                     """The rest of the block source one vector at a time (after the first key out of order)."""
-                    cur = vad_cur
                     while True:
                         if cur is not None:
                             vkeys, vals, vo, pos = cur
                             o = vo.tolist()
                             for n_ in range(pos, len(vkeys)):
                                 yield vkeys[n_], vals[o[n_]:o[n_ + 1]]
-                        nxt = next(vad_blocks, None)
+                        nxt = next(blocks, None)
                         if nxt is None:
                             return
                         cur = [list(nxt[0]), nxt[1], np.asarray(nxt[2], np.int64), 0]
@@ -600,7 +599,7 @@ class Model(object):
                                 j = vkeys.index(key, pos)
                             except ValueError:                 # not in this block: one vector at a time from here on
                                 vad_cur[3] = pos
-                                vad_it = vad_records()
+                                vad_it = vad_records(vad_blocks, list(vad_cur))
                                 vad_blocks = None
                                 break
                             o = vo.tolist()
