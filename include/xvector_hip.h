@@ -275,6 +275,10 @@ int xv_merge_moments_f32(const float *chunk_mean_var, const int32_t *row_len, in
 /* y[r,:] = row_valid[r] ? x[r,:]*scale + shift : 0   (batch-norm with batch statistics folded by xv_fold_bn_f32). */
 int xv_rows_affine_f32(const float *x, int ldx, int64_t R, int c, const float *scale, const float *shift,
                        const uint8_t *row_valid, float *y, int ldy, void *stream);
+/* The same with a second copy of y in the bf16 split activation format (XV_FMT_SPLIT; y_split = row 0 of a buffer with the format's
+ * padding rows, c % 32 == 0; NULL = xv_rows_affine_f32): the training step's K = 1 layers then take the DMA-fed GEMM. */
+int xv_rows_affine_split_f32(const float *x, int ldx, int64_t R, int c, const float *scale, const float *shift,
+                             const uint8_t *row_valid, float *y, int ldy, void *y_split, void *stream);
 /* Weight gradient of a TDNN/FC layer: dw[k,ci,co] = sum_r x[r + (k-(K-1)/2)*dilation, ci] * dz[r, co]  (TF layout
  * [K,Cin,Cout]; rows outside [0,R) read as zero; gap rows of x and dz are zero by contract). */
 size_t xv_wgrad_workspace_bytes(int64_t R, int cin, int cout, int K);
@@ -296,6 +300,11 @@ int xv_bn_act_backward_f32(const float *dh, const float *r, int ld, int64_t R, i
                            const float *sum_dh_r, const float *mean, const float *var, const float *gamma, float eps,
                            float n_frames, int act_kind, float act_alpha, const uint8_t *row_valid, float *dgamma,
                            float *dbeta, float *coef_ws, float *dz, void *stream);
+/* The same with a second copy of dz in the bf16 split activation format (dz_split as y_split above; NULL = the plain form). */
+int xv_bn_act_backward_split_f32(const float *dh, const float *r, int ld, int64_t R, int c, const float *sum_dh,
+                                 const float *sum_dh_r, const float *mean, const float *var, const float *gamma, float eps,
+                                 float n_frames, int act_kind, float act_alpha, const uint8_t *row_valid, float *dgamma,
+                                 float *dbeta, float *coef_ws, float *dz, void *dz_split, void *stream);
 /* Gradient of statistics pooling: dh[t,c] = dmu[c]/T + dsig[c]*(h[t,c]-mu[c])/(T*sig[c]); dh gap rows are zeroed. */
 int xv_pool_backward_f32(const float *h, int ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
                          int64_t R, const float *pooled, const float *dpooled, float *dh, void *stream);

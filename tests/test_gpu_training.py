@@ -555,3 +555,59 @@ def test_bucketed_allreduce_ranges_and_single_rank_group(env, monkeypatch):
         assert torch.equal(grouped.flat_p, plain.flat_p)
     finally:
         dist.destroy_process_group()
+
+
+def test_split_copies_of_bn_outputs_and_gradients(env):
+    """xv_rows_affine_split_f32 / xv_bn_act_backward_split_f32: the fp32 rows are those of the plain entries, bit for bit, and the second
+    copy is the bf16 split format of exactly those rows (== xv_split_encode_f32 of them, byte for byte) -- what lets the training
+    step's K = 1 layers take the DMA-fed GEMM.  Shapes with gap rows and more than one 32-channel slab."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    for R, C in ((1000, 64), (777, 512), (130, 1536)):
+        x = torch.randn((R, C), generator=g).to(dev)
+        scale, shift = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+        valid = (torch.rand(R, generator=g) < 0.9).to(torch.uint8).to(dev)
+        y0, y1 = torch.empty_like(x), torch.empty_like(x)
+        hiplib.rows_affine(x, scale, shift, valid, y0)
+        ys = hiplib.SplitBuf(R + 50, C, dev)
+        hiplib.rows_affine(x, scale, shift, valid, y1, y_split=ys)
+        ref = hiplib.SplitBuf(R + 50, C, dev)
+        hiplib.split_encode(y0, ref, rows=R)
+        assert torch.equal(y0, y1)
+        nb = R * ys.row_bytes
+        off = hiplib.SPLIT_PAD_BEFORE * ys.row_bytes
+        assert torch.equal(ys.base[off:off + nb], ref.base[off:off + nb])
+        assert torch.equal(hiplib.split_decode(ys, R), hiplib.split_decode(ref, R))
+        # the batch-norm backward: same contract
+        dh, r = torch.randn((R, C), generator=g).to(dev), torch.relu(torch.randn((R, C), generator=g)).to(dev)
+        s1, s2 = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+        mean, var, gamma = torch.randn(C, generator=g).to(dev), (torch.rand(C, generator=g) + 0.1).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+        outs = []
+        for split in (None, hiplib.SplitBuf(R + 50, C, dev)):
+            dg, db, dz = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty((R, C), device=dev)
+            hiplib.bn_act_backward(dh, r, s1, s2, mean, var, gamma, 1e-3, float(R), 1, 0.0, valid, dg, db, dz, dz_split=split)
+            outs.append((dg, db, dz, split))
+        assert all(torch.equal(a, b) for a, b in zip(outs[0][:3], outs[1][:3]))
+        ref = hiplib.SplitBuf(R + 50, C, dev)
+        hiplib.split_encode(outs[0][2], ref, rows=R)
+        assert torch.equal(outs[1][3].base[off:off + nb], ref.base[off:off + nb])
+        assert bool((outs[0][2][valid == 0] == 0).all())
+
+
+def test_bf16x3_step_with_and_without_split_k1_inputs(env, monkeypatch):
+    """The K = 1 layers of a bf16x3 step on the split copies (default) against the same step on the fp32 rows (XVECTOR_TRAIN_SPLIT_K1=0):
+    the two GEMM forms accumulate in the same order -- losses and gradients bit-identical."""
+    topo, w, rng = _setup(env, "ModelWithoutDropout", seed=5)
+    x = (rng.standard_normal((8, 157, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, 8)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("XVECTOR_TRAIN_SPLIT_K1", flag)
+        tr = env["trainer"].Trainer(w, topo, precision="bf16x3")
+        assert tr.split_k1 == (flag == "1")
+        loss, acc, grads = tr.gradients(x, lab)
+        res.append((loss, {n: g.cpu().numpy().copy() for n, g in grads.items()}))
+        assert bool(tr._splits) == (flag == "1")
+    assert res[0][0] == res[1][0]
+    assert all(np.array_equal(res[0][1][n], res[1][1][n]) for n in res[0][1])

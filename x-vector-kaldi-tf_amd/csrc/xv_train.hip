@@ -287,10 +287,28 @@ __global__ __launch_bounds__(64 * MM_GROUPS) void merge_moments_kernel(const flo
 }
 
 // (one workgroup row = 256 threads x 4 channels; rows along blockIdx.y with a stride loop: no 64-bit division per element)
-template <bool VEC>
+// SPLIT: the same values once more in the bf16 split activation format (include/xvector_hip.h: per row and 32-channel slab 128 bytes =
+// 4 hi slots + 4 lo slots of 8 bf16, slot t at t ^ ((row >> 1) & 7)) -- a thread's 4 channels are half a slot of either plane.  The
+// K = 1 layers of the training step read it: the DMA-fed GEMM instead of the one that splits fp32 rows while staging them.
+typedef __bf16 tbf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_split4(uint8_t *ys, long r, int C, int c, const f32x4 &o)
+{
+    tbf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (__bf16)o[i];
+        lo[i] = (__bf16)(o[i] - (float)hi[i]);
+    }
+    const int q = (c & 31) >> 2, sw = (int)(r >> 1) & 7;
+    uint8_t *row = ys + ((size_t)r * (C >> 5) + (c >> 5)) * 128 + (q & 1) * 8;
+    *reinterpret_cast<tbf16x4 *>(row + (((q >> 1)) ^ sw) * 16) = hi;
+    *reinterpret_cast<tbf16x4 *>(row + ((4 + (q >> 1)) ^ sw) * 16) = lo;
+}
+
+template <bool VEC, bool SPLIT = false>
 __global__ __launch_bounds__(256) void rows_affine_kernel(const float *__restrict__ x, long R, int C, int ldx, const float *__restrict__ scale,
                                                           const float *__restrict__ shift, const uint8_t *__restrict__ valid,
-                                                          float *__restrict__ y, int ldy)
+                                                          float *__restrict__ y, int ldy, uint8_t *__restrict__ ys = nullptr)
 {
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= C) return;
@@ -308,6 +326,7 @@ __global__ __launch_bounds__(256) void rows_affine_kernel(const float *__restric
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = keep ? v[i] * sc[i] + sh[i] : 0.f;
             *reinterpret_cast<f32x4 *>(y + (size_t)r * ldy + c) = o;
+            if constexpr (SPLIT) store_split4(ys, r, C, c, o);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -391,6 +410,36 @@ __global__ void bn_act_backward_kernel(const float *__restrict__ dh, const float
         if (act == XV_ACT_RELU) dr = rv > 0.f ? dr : 0.f;
         else if (act == XV_ACT_LRELU) dr = rv > 0.f ? dr : alpha * dr;
         dz[o] = (!valid || valid[row]) ? dr : 0.f;
+    }
+}
+
+// The same per 4 channels (one workgroup row = 256 threads x 4 channels, rows along blockIdx.y: no 64-bit division per element), with an
+// optional copy of dz in the bf16 split format (the input-gradient GEMM of a K = 1 layer reads that)
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void bn_act_backward_vec_kernel(const float *__restrict__ dh, const float *__restrict__ r, long R, int C, int ld,
+                                                                  const float *__restrict__ coefA, const float *__restrict__ coefB,
+                                                                  const float *__restrict__ coefC, int act, float alpha,
+                                                                  const uint8_t *__restrict__ valid, float *__restrict__ dz,
+                                                                  uint8_t *__restrict__ dzs)
+{
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(coefA + c), b = *reinterpret_cast<const f32x4 *>(coefB + c),
+                k = *reinterpret_cast<const f32x4 *>(coefC + c);
+    for (long row = blockIdx.y; row < R; row += gridDim.y) {
+        const size_t o = (size_t)row * ld + c;
+        const f32x4 rv = *reinterpret_cast<const f32x4 *>(r + o), g = *reinterpret_cast<const f32x4 *>(dh + o);
+        const bool keep = !valid || valid[row];
+        f32x4 out;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float dr = a[i] * g[i] + b[i] * rv[i] + k[i];
+            if (act == XV_ACT_RELU) dr = rv[i] > 0.f ? dr : 0.f;
+            else if (act == XV_ACT_LRELU) dr = rv[i] > 0.f ? dr : alpha * dr;
+            out[i] = keep ? dr : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(dz + o) = out;
+        if constexpr (SPLIT) store_split4(dzs, row, C, c, out);
     }
 }
 
@@ -660,9 +709,22 @@ int xv_merge_moments_f32(const float *chunk_mean_var, const int32_t *row_len, in
 int xv_rows_affine_f32(const float *x, int ldx, int64_t R, int c, const float *scale, const float *shift, const uint8_t *row_valid,
                        float *y, int ldy, void *stream)
 {
+    return xv_rows_affine_split_f32(x, ldx, R, c, scale, shift, row_valid, y, ldy, nullptr, stream);
+}
+
+int xv_rows_affine_split_f32(const float *x, int ldx, int64_t R, int c, const float *scale, const float *shift, const uint8_t *row_valid,
+                             float *y, int ldy, void *y_split, void *stream)
+{
     if (!x || !y || !scale || !shift || R <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "rows_affine: bad argument");
     const bool vec = !(c & 3) && !(ldx & 3) && !(ldy & 3) && !(((uintptr_t)x | (uintptr_t)y) & 15);
     const dim3 grid((unsigned)((c + 1023) / 1024), (unsigned)(R < 4096 ? R : 4096));
+    if (y_split) {
+        if (!vec || (c & 31) || (((uintptr_t)y_split) & 15))
+            return tfail(XV_ERR_UNSUPPORTED, "rows_affine: the split copy needs c % 32 == 0 and 16-byte aligned fp32 rows");
+        hipLaunchKernelGGL((rows_affine_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, (long)R, c, ldx, scale, shift, row_valid,
+                           y, ldy, (uint8_t *)y_split);
+        return tcheck("rows_affine_kernel");
+    }
     if (vec) hipLaunchKernelGGL(rows_affine_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)R, c, ldx, scale, shift, row_valid, y, ldy);
     else hipLaunchKernelGGL(rows_affine_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)R, c, ldx, scale, shift, row_valid, y, ldy);
     return tcheck("rows_affine_kernel");
@@ -673,6 +735,15 @@ int xv_bn_act_backward_f32(const float *dh, const float *r, int ld, int64_t R, i
                            float act_alpha, const uint8_t *row_valid, float *dgamma, float *dbeta, float *coef_ws, float *dz,
                            void *stream)
 {
+    return xv_bn_act_backward_split_f32(dh, r, ld, R, c, sum_dh, sum_dh_r, mean, var, gamma, eps, n_frames, act_kind, act_alpha, row_valid,
+                                        dgamma, dbeta, coef_ws, dz, nullptr, stream);
+}
+
+int xv_bn_act_backward_split_f32(const float *dh, const float *r, int ld, int64_t R, int c, const float *sum_dh, const float *sum_dh_r,
+                                 const float *mean, const float *var, const float *gamma, float eps, float n_frames, int act_kind,
+                                 float act_alpha, const uint8_t *row_valid, float *dgamma, float *dbeta, float *coef_ws, float *dz,
+                                 void *dz_split, void *stream)
+{
     if (!dh || !r || !sum_dh || !sum_dh_r || !mean || !var || !gamma || !dgamma || !dbeta || !coef_ws || !dz || R <= 0 || c <= 0)
         return tfail(XV_ERR_BAD_ARG, "bn_act_backward: bad argument");
     if (act_kind == XV_ACT_PRELU) return tfail(XV_ERR_UNSUPPORTED, "bn_act_backward: PReLU training is not implemented");
@@ -681,6 +752,19 @@ int xv_bn_act_backward_f32(const float *dh, const float *r, int ld, int64_t R, i
                        dgamma, dbeta, coef_ws, coef_ws + c, coef_ws + 2 * c);
     int rc = tcheck("bn_coeffs_kernel");
     if (rc) return rc;
+    const bool vec = !(c & 3) && !(ld & 3) && !(((uintptr_t)dh | (uintptr_t)r | (uintptr_t)dz | (uintptr_t)coef_ws) & 15);
+    if (dz_split && (!vec || (c & 31) || (((uintptr_t)dz_split) & 15)))
+        return tfail(XV_ERR_UNSUPPORTED, "bn_act_backward: the split copy needs c % 32 == 0 and 16-byte aligned fp32 rows");
+    if (vec) {
+        const dim3 grid((unsigned)((c + 1023) / 1024), (unsigned)(R < 4096 ? R : 4096));
+        if (dz_split)
+            hipLaunchKernelGGL(bn_act_backward_vec_kernel<true>, grid, dim3(256), 0, st, dh, r, (long)R, c, ld, coef_ws, coef_ws + c,
+                               coef_ws + 2 * c, act_kind, act_alpha, row_valid, dz, (uint8_t *)dz_split);
+        else
+            hipLaunchKernelGGL(bn_act_backward_vec_kernel<false>, grid, dim3(256), 0, st, dh, r, (long)R, c, ld, coef_ws, coef_ws + c,
+                               coef_ws + 2 * c, act_kind, act_alpha, row_valid, dz, (uint8_t *)nullptr);
+        return tcheck("bn_act_backward_vec_kernel");
+    }
     hipLaunchKernelGGL(bn_act_backward_kernel, dim3(gs_blocks((size_t)R * c)), dim3(256), 0, st, dh, r, (long)R, c, ld, coef_ws,
                        coef_ws + c, coef_ws + 2 * c, act_kind, act_alpha, row_valid, dz);
     return tcheck("bn_act_backward_kernel");

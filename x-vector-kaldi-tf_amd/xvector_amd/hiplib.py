@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -24,8 +24,8 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_tdnn_layer_f16bf8", "xv_tdnn_layer_pool_f16bf8", "xv_tdnn_first_f16bf8",
            "xv_packed_pair_f16bf8_bytes", "xv_pack_pair_f16bf8", "xv_tdnn_pair_pool_f16bf8",
            # training step
-           "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
-           "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_pool_backward_f32",
+           "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_rows_affine_split_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
+           "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_bn_act_backward_split_f32", "xv_pool_backward_f32",
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32", "xv_pack_minibatch_f32",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
@@ -142,6 +142,8 @@ def load():
     lib.xv_merge_moments_f32.argtypes = [vp, vp, ci, ci, vp, vp, vp]
     lib.xv_rows_affine_f32.restype = ci
     lib.xv_rows_affine_f32.argtypes = [vp, ci, i64, ci, vp, vp, vp, vp, ci, vp]
+    lib.xv_rows_affine_split_f32.restype = ci
+    lib.xv_rows_affine_split_f32.argtypes = [vp, ci, i64, ci, vp, vp, vp, vp, ci, vp, vp]
     lib.xv_wgrad_workspace_bytes.restype = sz
     lib.xv_wgrad_workspace_bytes.argtypes = [i64, ci, ci, ci]
     lib.xv_wgrad_f32.restype = ci
@@ -154,6 +156,8 @@ def load():
     lib.xv_col_sums_f32.argtypes = [vp, ci, vp, ci, i64, ci, vp, vp, vp, vp]
     lib.xv_bn_act_backward_f32.restype = ci
     lib.xv_bn_act_backward_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp]
+    lib.xv_bn_act_backward_split_f32.restype = ci
+    lib.xv_bn_act_backward_split_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp, vp]
     lib.xv_pool_backward_f32.restype = ci
     lib.xv_pool_backward_f32.argtypes = [vp, ci, ci, vp, vp, ci, i64, vp, vp, vp, vp]
     lib.xv_softmax_ce_f32.restype = ci
@@ -755,11 +759,15 @@ def merge_moments(cm, row_len, nchunks, mean, var):
            "xv_merge_moments_f32")
 
 
-def rows_affine(x, scale, shift, row_valid, y, rows=None):
+def rows_affine(x, scale, shift, row_valid, y, rows=None, y_split=None):
+    """y_split: optional SplitBuf (bf16 split format) that receives a second copy of y."""
     lib = require_gpu()
     R = x.shape[0] if rows is None else int(rows)
-    _check(lib.xv_rows_affine_f32(_ptr(_f32(x, "x")), x.stride(0), R, x.shape[1], _ptr(scale), _ptr(shift), _ptr(row_valid),
-                                  _ptr(_f32(y, "y")), y.stride(0), _stream()), "xv_rows_affine_f32")
+    if y_split is not None:
+        assert y_split.fmt == FMT_SPLIT and y_split.channels == x.shape[1] and y_split.rows >= R
+    _check(lib.xv_rows_affine_split_f32(_ptr(_f32(x, "x")), x.stride(0), R, x.shape[1], _ptr(scale), _ptr(shift), _ptr(row_valid),
+                                        _ptr(_f32(y, "y")), y.stride(0), ctypes.c_void_p(y_split.ptr) if y_split is not None else None,
+                                        _stream()), "xv_rows_affine_split_f32")
 
 
 def wgrad(x, dz, K, dilation, dw, precision="fp32"):
@@ -783,15 +791,19 @@ def col_sums(a, b, sum_a, sum_ab=None):
                                _ptr(ws), _stream()), "xv_col_sums_f32")
 
 
-def bn_act_backward(dh, r, sum_dh, sum_dh_r, mean, var, gamma, eps, n_frames, act, alpha, row_valid, dgamma, dbeta, dz):
+def bn_act_backward(dh, r, sum_dh, sum_dh_r, mean, var, gamma, eps, n_frames, act, alpha, row_valid, dgamma, dbeta, dz, dz_split=None):
+    """dz_split: optional SplitBuf (bf16 split format) that receives a second copy of dz."""
     import torch
     lib = require_gpu()
     R, c = dh.shape
     coef = torch.empty(3 * c, dtype=torch.float32, device=dh.device)
-    _check(lib.xv_bn_act_backward_f32(_ptr(_f32(dh, "dh")), _ptr(_f32(r, "r")), dh.stride(0), R, c, _ptr(sum_dh), _ptr(sum_dh_r),
-                                      _ptr(mean), _ptr(var), _ptr(gamma), float(eps), float(n_frames), int(act), float(alpha),
-                                      _ptr(row_valid), _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_f32(dz, "dz")), _stream()),
-           "xv_bn_act_backward_f32")
+    if dz_split is not None:
+        assert dz_split.fmt == FMT_SPLIT and dz_split.channels == c and dz_split.rows >= R
+    _check(lib.xv_bn_act_backward_split_f32(_ptr(_f32(dh, "dh")), _ptr(_f32(r, "r")), dh.stride(0), R, c, _ptr(sum_dh), _ptr(sum_dh_r),
+                                            _ptr(mean), _ptr(var), _ptr(gamma), float(eps), float(n_frames), int(act), float(alpha),
+                                            _ptr(row_valid), _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_f32(dz, "dz")),
+                                            ctypes.c_void_p(dz_split.ptr) if dz_split is not None else None, _stream()),
+           "xv_bn_act_backward_split_f32")
 
 
 def pool_backward(h, row_start, row_len, nchunks, pooled, dpooled, dh):

@@ -101,6 +101,8 @@ class Trainer(object):
         self._layouts = {}
         self._side_busy = False
         self.two_streams = os.environ.get("XVECTOR_TRAIN_STREAMS", "2") != "1"
+        self._splits = {}                                          # split-format copies for the K = 1 layers' GEMMs (bf16x3)
+        self.split_k1 = os.environ.get("XVECTOR_TRAIN_SPLIT_K1", "1") != "0"
         self._side = None                                          # second stream: weight gradients beside the input-gradient GEMMs
         self.l2_beta = float(topo.get("l2_beta", 0.0))
         self.l2_terms = (("embed_layer-0", 0.1), ("embed_layer-1", 1.0), ("output", 1.0))       # models.py:811-832
@@ -180,6 +182,20 @@ class Trainer(object):
         self._packed = pk
         return pk
 
+    def _split_for(self, role, rows, channels):
+        """A bf16 split-format buffer (hiplib.SplitBuf) of ``channels`` channels for >= ``rows`` rows, one per role, kept across steps.
+        The K = 1 layers of a bf16x3 step read their GEMM input from it -- written by the kernel that produces the fp32 rows anyway
+        (xv_rows_affine_split_f32 / xv_bn_act_backward_split_f32) -- and so take the DMA-fed GEMM (K as a template constant) instead of
+        the one that splits fp32 rows while staging them: at K = 1 that one stages a new A tile in EVERY stage.  Rows past ``rows`` hold
+        an earlier minibatch's values: only tile rows past R read them, and those are not written."""
+        buf = self._splits.get((role, channels))
+        if buf is None or buf.rows < rows:
+            buf = self._splits[(role, channels)] = hiplib.SplitBuf(max(rows, 28672), channels, self.device)
+        return buf
+
+    def _wants_split(self, K, channels):
+        return self.split_k1 and self.precision == "bf16x3" and K == 1 and channels % 32 == 0 and not self.prelu
+
     def _stage_in(self, x):
         """A contiguous float16 / float32 / int32 host array -> a device tensor of the same dtype, through one of two alternating
         pinned buffers per dtype (the copy is asynchronous -- a pageable ``.to(device)`` in the middle of a step makes the host
@@ -211,7 +227,7 @@ class Trainer(object):
                                       one_len=torch.full((1,), B, dtype=torch.int32, device=self.device))
         return self._layouts[key]
 
-    def _bn_scopes_stats(self, r, scope, L, rows_per_chunk, nchunks, train, valid, frame_level):
+    def _bn_scopes_stats(self, r, scope, L, rows_per_chunk, nchunks, train, valid, frame_level, split_out=None):
         """BN (train: batch statistics + moving-average update; eval: moving statistics) applied to r -> h."""
         torch = self.torch
         C = r.shape[1]
@@ -225,7 +241,7 @@ class Trainer(object):
             mean, var = self.P[scope + "/mean:0"], self.P[scope + "/variance:0"]
         scale, shift = hiplib.fold_bn(self.P[scope + "/gamma:0"], self.P[scope + "/beta:0"], mean, var, tp.BN_EPSILON)
         h = torch.empty_like(r)
-        hiplib.rows_affine(r, scale, shift, valid, h)
+        hiplib.rows_affine(r, scale, shift, valid, h, y_split=split_out)
         return h, mean, var
 
     # -- forward ---------------------------------------------------------------------------------------------------
@@ -254,15 +270,22 @@ class Trainer(object):
         pk = self._pack()
         drop = train and self.has_dropout and keep_prob < 1.0
         sites = self._dropout_sites()
-        S = dict(L=L, B=B, T=T, R=lay.rows, X=X, r=[], z=[], h=[X], mean=[], var=[], keep=float(keep_prob) if drop else 1.0,
+        S = dict(L=L, B=B, T=T, R=lay.rows, X=X, r=[], z=[], h=[X], hs=None, mean=[], var=[], keep=float(keep_prob) if drop else 1.0,
                  seeds={site: self.dropout_seed(seed, self.t, n) for n, site in enumerate(sites)})
         for i, sc in enumerate(self.frame_scopes):
             K, d = self.topo["kernel_sizes"][i], self.topo["dilations"][i]
             C = self.topo["layer_sizes"][i]
             r = torch.empty((lay.rows, C), dtype=torch.float32, device=self.device)
             z = torch.empty_like(r) if (self.prelu and want_grad) else None            # PReLU backward needs the pre-activation
-            hiplib.tdnn_layer(S["h"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act, self._alpha(sc), K, d, L["rv"], r, z)
-            h, mean, var = self._bn_scopes_stats(r, sc, L, T, B, train, L["rv"], True)
+            hiplib.tdnn_layer(S["hs"] if S["hs"] is not None else S["h"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act,
+                              self._alpha(sc), K, d, L["rv"], r, z, rows=lay.rows)
+            # the next layer's input once more in the split format when that layer is context-free (and nothing rewrites h after BN)
+            nxt_split = None
+            if i + 1 < len(self.frame_scopes) and self._wants_split(self.topo["kernel_sizes"][i + 1], C) and \
+                    not (drop and ("frame", i) in S["seeds"]):
+                nxt_split = self._split_for("h%d" % (i & 1), lay.rows, C)
+            h, mean, var = self._bn_scopes_stats(r, sc, L, T, B, train, L["rv"], True, split_out=nxt_split)
+            S["hs"] = nxt_split
             if drop and ("frame", i) in S["seeds"]:
                 hiplib.dropout(h, S["seeds"][("frame", i)], S["keep"])
             S["r"].append(r); S["z"].append(z); S["h"].append(h); S["mean"].append(mean); S["var"].append(var)
@@ -321,7 +344,7 @@ class Trainer(object):
         return float(la[0]) + self._l2_value(), float(la[1])
 
     # -- backward + Adam -------------------------------------------------------------------------------------------
-    def _dense_backward(self, scope, x_in, dz, K, dil, grads, need_dx, valid, dx_out=None):
+    def _dense_backward(self, scope, x_in, dz, K, dil, grads, need_dx, valid, dx_out=None, dz_split=None):
         """dW, db (and dx) of  z = conv(x_in, W) + b  given dz.  dx_out: optional [R, Cin] rows that receive dx."""
         torch = self.torch
         pk = self._pack()
@@ -358,7 +381,8 @@ class Trainer(object):
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else torch.empty((R, cin), dtype=torch.float32, device=self.device)
-        hiplib.tdnn_layer(dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid, dx)
+        hiplib.tdnn_layer(dz_split if dz_split is not None else dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid, dx,
+                          rows=R)
         return dx
 
     def _join_side(self):
@@ -366,7 +390,7 @@ class Trainer(object):
             self.torch.cuda.current_stream(self.device).wait_stream(self._side)
             self._side_busy = False
 
-    def _bn_backward(self, scope, dh, r, z, mean, var, n_frames, valid, grads):
+    def _bn_backward(self, scope, dh, r, z, mean, var, n_frames, valid, grads, split_out=None):
         torch = self.torch
         C = r.shape[1]
         s1 = torch.empty(C, dtype=torch.float32, device=self.device)
@@ -375,7 +399,7 @@ class Trainer(object):
         dgamma, dbeta = self.G[scope + "/gamma:0"], self.G[scope + "/beta:0"]
         dz = torch.empty_like(r)
         hiplib.bn_act_backward(dh, r, s1, s2, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames,
-                               tp.ACT_NONE if self.prelu else self.act, self.alpha, valid, dgamma, dbeta, dz)
+                               tp.ACT_NONE if self.prelu else self.act, self.alpha, valid, dgamma, dbeta, dz, dz_split=split_out)
         if self.prelu:
             # dz holds dL/d(act output); z the pre-activation: -> dz = dL/dz, z = dr*min(z,0) whose column sums are dalpha
             hiplib.prelu_backward(dz, z, self.P[scope + "/prelu/prelu:0"])
@@ -472,9 +496,10 @@ class Trainer(object):
             sc = self.frame_scopes[i]
             if S["keep"] < 1.0 and ("frame", i) in S["seeds"]:
                 hiplib.dropout(dh, S["seeds"][("frame", i)], S["keep"])
-            dz = self._bn_backward(sc, dh, S["r"][i], S["z"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads)
-            dh = self._dense_backward(sc, S["h"][i], dz, self.topo["kernel_sizes"][i], self.topo["dilations"][i], grads, i > 0,
-                                      L["rv"])
+            Ki = self.topo["kernel_sizes"][i]
+            dzs = self._split_for("dz", S["R"], S["r"][i].shape[1]) if (i > 0 and self._wants_split(Ki, S["r"][i].shape[1])) else None
+            dz = self._bn_backward(sc, dh, S["r"][i], S["z"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads, split_out=dzs)
+            dh = self._dense_backward(sc, S["h"][i], dz, Ki, self.topo["dilations"][i], grads, i > 0, L["rv"], dz_split=dzs)
             if on_bucket is not None and i in fire_after:
                 self._join_side()
                 on_bucket(fire_after[i])
