@@ -1,0 +1,106 @@
+"""GPU parity of the Toom-Cook F(2, K) form of the wide-context layers (xv_tdnn_layer_toom_f32, csrc/xv_toom.hip) through the C ABI
+against the fp64 oracle of the DIRECT K-tap contraction (local/tf/models.py:60-65): the transform must not be visible beyond
+rounding.  Tolerance: TOL_GEMM of test_gpu_kernels.py (2e-6 relative L2 per layer; the direct fp32 kernel sits at ~3e-7, this
+form at ~1e-6)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_GEMM = 2e-6
+
+
+@pytest.fixture(scope="module")
+def env(oracle_mod):
+    import torch
+    from xvector_amd import engine, hiplib
+    hiplib.require_gpu()
+    return dict(torch=torch, hiplib=hiplib, engine=engine, oracle=oracle_mod, dev=torch.device("cuda:0"))
+
+
+def _rand_bn(rng, c):
+    return ((1 + 0.1 * rng.standard_normal(c)).astype(np.float32), (0.1 * rng.standard_normal(c)).astype(np.float32),
+            (0.2 * rng.standard_normal(c)).astype(np.float32), np.exp(0.2 * rng.standard_normal(c)).astype(np.float32))
+
+
+def _run(env, mats, w, b, bn, act, alpha, align=8, direct=False):
+    torch, hiplib, engine, dev = env["torch"], env["hiplib"], env["engine"], env["dev"]
+    K, cin, cout = w.shape
+    layout = engine.BatchLayout([m.shape[0] for m in mats], (K - 1) // 2, align)
+    host = np.zeros((layout.rows, cin), np.float32)
+    layout.pack(mats, host)
+    x = torch.from_numpy(host).to(dev)
+    rv = torch.from_numpy(layout.row_valid()).to(dev)
+    wd = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
+    wp = hiplib.pack_weights(wd.reshape(K * cin, cout)) if direct else hiplib.pack_weights_toom(wd)
+    scale, shift = hiplib.fold_bn(*(torch.from_numpy(a).to(dev) for a in bn), 1e-3)
+    al = None if alpha is None else torch.from_numpy(np.atleast_1d(alpha).astype(np.float32)).to(dev)
+    y = torch.full((layout.rows, cout), float("nan"), dtype=torch.float32, device=dev)
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+    hiplib.tdnn_layer(x, wp, torch.from_numpy(b).to(dev), scale, shift, code, al, K, 1, rv, y)
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy()
+    return [yh[s:s + n] for s, n in zip(layout.row_start, layout.row_len)], yh, layout
+
+
+@pytest.mark.parametrize("cin,cout,K,act", [
+    (512, 512, 5, "relu"),          # layer 1 of the default topology
+    (512, 512, 7, "relu"),          # layer 2
+    (64, 48, 5, "prelu"),           # ragged column tile, two slabs, PReLU epilogue
+    (96, 200, 7, "lrelu"),          # odd slab count, two column tiles
+    (32, 4, 5, "none"),             # one slab, a 4-column layer
+])
+def test_toom_layer_matches_oracle(env, cin, cout, K, act):
+    oracle = env["oracle"]
+    rng = np.random.default_rng(cin * 1000 + cout + K * 7)
+    lens = [25, 1, 130, 257, 64, 3, 2, 127]          # chunks shorter than the halo, odd lengths, spanning tile boundaries
+    mats = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in lens]
+    w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = None
+    if act == "lrelu":
+        alpha = np.array([0.2], np.float32)
+    elif act == "prelu":
+        alpha = (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32)
+    outs, yh, layout = _run(env, mats, w, b, bn, act, alpha)
+    for m, got in zip(mats, outs):
+        ref = oracle.tdnn_layer(m, w, b, bn, act, alpha, 1, np.float64)
+        assert np.isfinite(got).all()
+        assert oracle.rel_l2(got, ref) < TOL_GEMM, (m.shape, oracle.rel_l2(got, ref))
+    valid = layout.row_valid().astype(bool)
+    assert (yh[~valid] == 0).all()                   # gap rows are written as exact zeros
+
+
+def test_toom_bits_do_not_depend_on_batch_neighbours(env):
+    """Row pairs sit on even global rows and chunks start on rows that are multiples of 8: a chunk alone and the same chunk in a
+    26 k-row batch (other tiles, other neighbours, a neighbour's first row right behind its gap) come out bit-identical."""
+    oracle = env["oracle"]
+    rng = np.random.default_rng(11)
+    for K in (5, 7):
+        cin, cout = 64, 128
+        w = (rng.standard_normal((K, cin, cout)) / np.sqrt(K * cin)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        bn = _rand_bn(rng, cout)
+        # lengths chosen so that some chunks end 3 / 4 rows before the next one starts (T % 8 in {5, 4}) and some on odd rows
+        probe = [(rng.standard_normal((t, cin)) * 2).astype(np.float32) for t in (133, 28, 257, 5, 300)]
+        alone = [_run(env, [m], w, b, bn, "relu", None)[0][0] for m in probe]
+        crowd = [(rng.standard_normal((int(t), cin)) * 2).astype(np.float32) for t in rng.integers(1, 400, 120)]
+        mixed = crowd[:40] + [probe[0]] + crowd[40:80] + probe[1:3] + crowd[80:] + probe[3:]
+        outs, _, _ = _run(env, mixed, w, b, bn, "relu", None)
+        got = [outs[40], outs[81], outs[82], outs[-2], outs[-1]]
+        for m, a, g in zip(probe, alone, got):
+            assert np.array_equal(a, g)
+            assert oracle.rel_l2(a, oracle.tdnn_layer(m, w, b, bn, "relu", None, 1, np.float64)) < TOL_GEMM
+
+
+def test_toom_unsupported_shapes_are_refused(env):
+    hiplib, torch, dev = env["hiplib"], env["torch"], env["dev"]
+    assert hiplib.toom_supported(5, 1, 512, 512) and hiplib.toom_supported(7, 1, 32, 4)
+    for K, d, cin, cout in ((3, 1, 512, 512), (5, 2, 512, 512), (5, 1, 24, 512), (7, 1, 512, 510), (1, 1, 512, 512)):
+        assert not hiplib.toom_supported(K, d, cin, cout)
+    lib = hiplib.load()
+    assert lib.xv_packed_weights_toom_f32_floats(5, 24, 512) == 0
+    w = torch.zeros((5, 24, 512), device=dev)
+    with pytest.raises(AssertionError):
+        hiplib.pack_weights_toom(w)

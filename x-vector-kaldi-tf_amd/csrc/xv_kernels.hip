@@ -1851,7 +1851,7 @@ extern "C" {
 void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
 void xv_internal_first_tiles(int tiles);          // xv_first.hip
 
-int xv_version(void) { return 15; }
+int xv_version(void) { return 16; }
 
 int xv_set_tuning(int key, int value)
 {

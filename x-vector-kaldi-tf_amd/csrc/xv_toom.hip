@@ -1,0 +1,474 @@
+// xv_toom.hip -- the wide-context frame-level layers (tf.nn.conv1d 'SAME' + bias + activation + BN-eval, local/tf/models.py:54-67,
+// kernel sizes 5 and 7 of models.py:28) with FEWER MULTIPLICATIONS than the K-tap contraction states: Toom-Cook F(2, K) over time.
+//
+// Two consecutive output rows (2P, 2P+1) of a K-tap correlation read K + 1 input rows d_0 .. d_K = x[2P - (K-1)/2 ...]; instead of
+// 2 K row-by-matrix products they are
+//        out_q = sum_j AT[q][j] * ( V_j . U_j ),      V_j = sum_i BT[j][i] d_i     (K + 1 transformed rows, formed here on the fly)
+//                                                    U_j = sum_k G[j][k]  w[k]    (K + 1 transformed taps, formed once at load)
+// i.e. K + 1 products per row PAIR: 6 instead of 10 (K = 5), 8 instead of 14 (K = 7) -- 0.60 / 0.57 of the MFMA work of the direct
+// form (tdnn_gemm_dma_kernel in xv_kernels.hip), exact fp32 products and fp32 accumulation as there.  Evaluation points 0, +-1, +-2
+// (, +-1/2), infinity; matrices generated and checked in exact rationals by tools/experiments/toomcook_gen.py.  The result is NOT
+// bit-identical to the direct form (different rounding: ~1e-6 relative L2 per layer against fp64 where the direct form has ~3e-7;
+// 3e-7 against 2e-7 on the x-vector), which is why this is a separate arithmetic ("fp32tc") with its own entry point.
+//
+// Kernel = the DMA-fed fp32 GEMM's design with the taps replaced by the transformed products:
+//  * tile 128 output rows (64 row pairs) x 128 columns, 4 waves (2 x 2), a wave owns 32 pairs x 64 columns;
+//  * the halo tile of a 32-channel slab (128 + K - 1 rows) goes global -> LDS by buffer_load ... lds, EVEN and ODD rows into two
+//    regions so that the 32 lanes of a fragment read (rows 2P + i for consecutive P) walk consecutive 128-byte LDS rows: the
+//    conflict-free XOR-swizzled pattern of the direct kernel;
+//  * stage = (slab, product j): the wave reads the <= 6 raw fragments row j of BT needs, forms V_j with <= 6 FMAs per channel
+//    (nothing beside a 64-cycle v_mfma_f32_32x32x2_f32) and accumulates V_j . U_j over the slab into a TEMPORARY tile (two of them,
+//    alternating by stage); the temporary of stage s - 1 is folded into the two output-row accumulators (AT's coefficients) under
+//    the MFMAs of stage s;
+//  * one barrier per stage, weights double-buffered, the next slab's halo pieces dealt over the first stages of the current one.
+// Row pairs are aligned to EVEN global rows; chunks start on even rows (the host lays batches out with align 8), so a chunk's bits
+// do not depend on its batch neighbours.  Gap rows are zero and masked as everywhere else.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <atomic>
+#include <type_traits>
+
+#include "xvector_hip.h"
+
+extern "C" void xv_internal_set_error(const char *msg);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+int fail(int code, const char *msg)
+{
+    xv_internal_set_error(msg);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *where)
+{
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", where, hipGetErrorString(e));
+    xv_internal_set_error(buf);
+    return (int)e;
+}
+
+// ---- F(2, K) matrices (tools/experiments/toomcook_gen.py prints these; exactness checked there) ------------------------------
+template <int KT>
+struct Toom;
+
+template <>
+struct Toom<5> {                                  // points 0, 1, -1, 2, -2, inf
+    static constexpr int J = 6;
+    static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                       {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    static constexpr float AT[2][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 1}};
+    static constexpr double G[6][5] = {{1. / 4, 0, 0, 0, 0},
+                                       {-1. / 6, -1. / 6, -1. / 6, -1. / 6, -1. / 6},
+                                       {-1. / 6, 1. / 6, -1. / 6, 1. / 6, -1. / 6},
+                                       {1. / 24, 1. / 12, 1. / 6, 1. / 3, 2. / 3},
+                                       {1. / 24, -1. / 12, 1. / 6, -1. / 3, 2. / 3},
+                                       {0, 0, 0, 0, 1}};
+};
+
+template <>
+struct Toom<7> {                                  // points 0, 1, -1, 2, -2, 1/2, -1/2, inf
+    static constexpr int J = 8;
+    static constexpr float BT[8][8] = {{-4, 0, 21, 0, -21, 0, 4, 0},  {0, 4, 4, -17, -17, 4, 4, 0},  {0, -4, 4, 17, -17, -4, 4, 0},
+                                       {0, 2, 1, -10, -5, 8, 4, 0},   {0, -2, 1, 10, -5, -8, 4, 0},  {0, 4, 8, -5, -10, 1, 2, 0},
+                                       {0, -4, 8, 5, -10, -1, 2, 0},  {0, -4, 0, 21, 0, -21, 0, 4}};
+    static constexpr float AT[2][8] = {{1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0.5f, -0.5f, 1}};
+    static constexpr double G[8][7] = {{-1. / 4, 0, 0, 0, 0, 0, 0},
+                                       {-1. / 18, -1. / 18, -1. / 18, -1. / 18, -1. / 18, -1. / 18, -1. / 18},
+                                       {-1. / 18, 1. / 18, -1. / 18, 1. / 18, -1. / 18, 1. / 18, -1. / 18},
+                                       {1. / 360, 1. / 180, 1. / 90, 1. / 45, 2. / 45, 4. / 45, 8. / 45},
+                                       {1. / 360, -1. / 180, 1. / 90, -1. / 45, 2. / 45, -4. / 45, 8. / 45},
+                                       {16. / 45, 8. / 45, 4. / 45, 2. / 45, 1. / 45, 1. / 90, 1. / 180},
+                                       {16. / 45, -8. / 45, 4. / 45, -2. / 45, 1. / 45, -1. / 90, 1. / 180},
+                                       {0, 0, 0, 0, 0, 0, 1. / 4}};
+};
+
+constexpr int BM = 128;                      // output rows per workgroup tile (64 row pairs)
+constexpr int BN = 128;                      // output channels per workgroup tile
+constexpr int BK = 32;                       // input channels per slab
+constexpr int NT = 256;
+constexpr int SROW = 128;                    // bytes per (row, slab)
+constexpr int REGION_ROWS = 72;              // LDS rows per parity region: 9 pieces of 8 (64 + K/2 + 1 <= 68 are read)
+constexpr int A_PIECES = 18;
+constexpr int A_BYTES = A_PIECES * 1024;     // 18432
+constexpr int B_BYTES = BN * SROW;           // 16384
+constexpr int OPER = 2 * A_BYTES + 2 * B_BYTES;   // 69632
+constexpr int TLD = BN + 4;                  // epilogue fp32 tile row (floats)
+static_assert(BM * TLD * 4 <= OPER, "the epilogue tile must fit the operand buffers");
+constexpr size_t LDS_BYTES = (size_t)OPER + BM;
+constexpr int RSRC_FLAGS = 0x00020000;       // raw buffer, 32-bit data format (gfx9 family dword 3)
+
+#define XV_BLDS16(rsrc, lptr, voff, soff, imm)                                                                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lptr), 16, voff, soff, imm, 0)
+
+struct ToomParams {
+    const float *x;
+    long R;
+    int cin, ldx;
+    const float *wp;            // [cout][J * cin]: U_j[c][o] at wp[o][j * cin + c]
+    int kred;                   // J * cin
+    const float *bias, *scale, *shift;
+    int act;
+    const float *alpha;
+    int cout;
+    const uint8_t *valid;
+    float *y;
+    int ldy;
+    int n_mt, n_nt;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ float apply_act(float z, int act, float a)
+{
+    switch (act) {
+    case XV_ACT_RELU: return fmaxf(z, 0.0f);
+    case XV_ACT_LRELU: return z > 0.0f ? z : a * z;
+    case XV_ACT_PRELU: return fmaxf(z, 0.0f) + a * fminf(z, 0.0f);
+    default: return z;
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams p)
+{
+    using TC = Toom<KT>;
+    constexpr int J = TC::J;                           // products per row pair = input rows per row pair
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *Abuf = lds;                                  // [2][2 regions][72 rows][128 B]
+    char *Bbuf = lds + 2 * A_BYTES;                    // [2][BN cols][128 B]
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(lds + OPER);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nwg = p.n_mt * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    constexpr int left = (KT - 1) / 2;
+    const int n_chunks = p.cin / BK;
+    const int n_stages = n_chunks * J;
+
+    if (tid < BM) {
+        const long gr = m0 + tid;
+        Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
+    }
+
+    // ---- DMA.  Piece q = 8 LDS rows x 128 bytes; q < 9: even tile rows 16 q + 2 j8, q >= 9: odd tile rows 16 (q - 9) + 1 + 2 j8
+    // (tile row lr = global row m0 - left + lr).  Wave w moves pieces w, w + 4, ...: their parity is the wave's, and with it bit 2
+    // of (LDS row >> 1) & 7 -- the swizzle of the row a lane moves is a per-lane constant.  Row part of an address in the VGPR
+    // offset (range-checked: rows outside [0, R) come back as zeros), slab part in the scalar offset.
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)(p.R * p.ldx * 4), RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, (int)((long)p.cout * p.kred * 4), RSRC_FLAGS);
+    const int slotb = ((lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7)) << 4;
+    const int arow_bytes = p.ldx * 4, brow_bytes = p.kred * 4;
+    const int va0 = (int)(m0 - left + 2 * (lane >> 3)) * arow_bytes + slotb;
+    const int vb0 = (n0 + 8 * wave + (lane >> 3)) * brow_bytes + slotb;
+    auto dma_b = [&](int stage, int buf) {              // the weight tile of (slab, product) = stage, four pieces per wave
+        const int st = stage < n_stages ? stage : n_stages - 1;
+        const int c = st / J, j = st - c * J;
+        const int so = (j * p.cin + c * BK) * 4;
+        char *dst = Bbuf + buf * B_BYTES + wave * 1024;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) XV_BLDS16(brs, dst + t * 4096, vb0 + t * 32 * brow_bytes, so, 0);
+    };
+    auto dma_a_piece = [&](int chunk, int t) {          // piece wave + 4 t of slab `chunk` (clamped: the tail rewrites identical bytes)
+        const int c = chunk < n_chunks ? chunk : n_chunks - 1;
+        const int q = wave + 4 * t;
+        const int rows = q < 9 ? 16 * q : 16 * (q - 9) + 1;
+        XV_BLDS16(ars, Abuf + (c & 1) * A_BYTES + q * 1024, va0 + rows * arow_bytes, c * BK * 4, 0);
+    };
+    auto dma_a_slot = [&](int chunk, int t) {           // slot t of 5: every wave one piece, the last slot waves 0 and 1 only
+        if (t < 4 || wave < 2) dma_a_piece(chunk, t);
+    };
+    dma_b(0, 0);
+    dma_b(1, 1);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) dma_a_slot(0, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- fragments.  Lane (pair pr = lane & 31, k half kh = lane >> 5) reads channels 8 kk + 4 kh .. + 3 = slot 2 kk + kh of a row.
+    // Input i of the wave's pair P = wr * 32 + pr: tile row 2 P + i = LDS row (i & 1) * 72 + P + (i >> 1).
+    const int kh = lane >> 5;
+    int pa[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+        const int L = (i & 1) * REGION_ROWS + wr * 32 + (lane & 31) + (i >> 1);
+        pa[i] = L * SROW + ((((L >> 1) & 7) ^ kh) << 4);
+    }
+    const int bcol = wc * 64 + (lane & 31);
+    const int pb = 2 * A_BYTES + bcol * SROW + ((((bcol >> 1) & 7) ^ kh) << 4);
+
+    // A stage's work of one wave, in two phases so that ONE temporary pair suffices: phase A accumulates column block 0 over the
+    // slab's four k groups (16 MFMAs on t0), phase B column block 1 (16 MFMAs on t1) re-using the transformed fragments v[0..3];
+    // t0 is folded into the outputs under phase B, t1 under phase A of the next stage -- no MFMA waits for a fold.
+    f32x4 raw[J];                                            // the raw fragments of one k group (only the entries row j of BT reads)
+    f32x4 v[4];                                              // V_j of the four k groups
+    f32x4 b0[2], b1[4];
+    auto load_raw = [&](auto JJ, int abuf, int kk) {
+        constexpr int j = decltype(JJ)::value;
+        auto one = [&](auto II) {
+            constexpr int i = decltype(II)::value;
+            if constexpr (TC::BT[j][i] != 0.f) raw[i] = *reinterpret_cast<const f32x4 *>(lds + ((pa[i] + abuf) ^ (kk << 5)));
+        };
+        static_for<0, J>(one);
+    };
+    auto load_b = [&](int bbase, int kk, int half) -> f32x4 {
+        return *reinterpret_cast<const f32x4 *>(lds + (bbase ^ (kk << 5)) + half * 32 * SROW);
+    };
+    auto xform = [&](auto JJ) -> f32x4 {
+        constexpr int j = decltype(JJ)::value;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+        auto one = [&](auto II) {
+            constexpr int i = decltype(II)::value;
+            constexpr float bt = TC::BT[j][i];
+            if constexpr (bt != 0.f) {
+                if (first) {
+                    first = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = bt == 1.f ? raw[i][e] : bt * raw[i][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(bt, raw[i][e], r[e]);
+                }
+            }
+        };
+        static_for<0, J>(one);
+        return r;
+    };
+
+    f32x16 o00 = {0}, o01 = {0}, o10 = {0}, o11 = {0};      // output rows 2P (o0x) and 2P + 1 (o1x), column blocks 0 / 1
+    f32x16 t0 = {0}, t1 = {0};                              // V_j . U_j of the running stage, column blocks 0 / 1
+    const f32x16 zero16 = {0};
+
+    auto mma4 = [&](const f32x4 a, const f32x4 b, f32x16 &t, bool fresh) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], (fresh && e == 0) ? zero16 : t, 0, 0, 0);
+    };
+    auto fold = [&](auto JJ, const f32x16 &t, f32x16 &oa, f32x16 &ob) {          // oa += AT[0][j] t, ob += AT[1][j] t
+        constexpr int j = decltype(JJ)::value;
+        constexpr float a0 = TC::AT[0][j], a1 = TC::AT[1][j];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if constexpr (a0 == 1.f) oa[e] += t[e];
+            else if constexpr (a0 != 0.f) oa[e] = __builtin_fmaf(a0, t[e], oa[e]);
+            if constexpr (a1 == 1.f) ob[e] += t[e];
+            else if constexpr (a1 == -1.f) ob[e] -= t[e];
+            else if constexpr (a1 != 0.f) ob[e] = __builtin_fmaf(a1, t[e], ob[e]);
+        }
+    };
+    auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+    // (the folds are plain fp32 adds on SSA values: without an anchor in the chain of side effects instruction selection is free to
+    // emit them at the end of the loop body, and every stage's temporaries stay live -- 11 tiles instead of 2)
+    auto anchor = [&](f32x16 &a, f32x16 &b) { asm volatile("" : "+v"(a), "+v"(b)); };
+
+    load_raw(std::integral_constant<int, 0>{}, 0, 0);
+    b0[0] = load_b(pb, 0, 0);
+    int s = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int abuf = (c & 1) * A_BYTES;
+        auto stage = [&](auto JJ) {
+            constexpr int j = decltype(JJ)::value;
+            constexpr int jp = (j + J - 1) % J, jn = (j + 1) % J;
+            const int bb = pb + (s & 1) * B_BYTES;
+            // ---- phase A: column block 0
+            v[0] = xform(JJ);
+            load_raw(JJ, abuf, 1);
+            b0[1] = load_b(bb, 1, 0);
+            mma4(v[0], b0[0], t0, true);
+            fence();
+            v[1] = xform(JJ);
+            load_raw(JJ, abuf, 2);
+            b0[0] = load_b(bb, 2, 0);
+            mma4(v[1], b0[1], t0, false);
+            fold(std::integral_constant<int, jp>{}, t1, o01, o11);      // (stage 0 of slab 0 folds the zero-initialised t1)
+            anchor(o01, o11);
+            fence();
+            v[2] = xform(JJ);
+            load_raw(JJ, abuf, 3);
+            b0[1] = load_b(bb, 3, 0);
+            mma4(v[2], b0[0], t0, false);
+            fence();
+            v[3] = xform(JJ);
+            b1[0] = load_b(bb, 0, 1);
+            b1[1] = load_b(bb, 1, 1);
+            b1[2] = load_b(bb, 2, 1);
+            b1[3] = load_b(bb, 3, 1);
+            mma4(v[3], b0[1], t0, false);
+            fence();
+            // ---- phase B: column block 1
+            mma4(v[0], b1[0], t1, true);
+            fence();
+            mma4(v[1], b1[1], t1, false);
+            fold(JJ, t0, o00, o10);
+            anchor(o00, o10);
+            fence();
+            // every fragment of stage s is in registers, stage s + 1 has landed
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_b(s + 2, s & 1);
+            if constexpr (j < 5) dma_a_slot(c + 1, j);
+            fence();
+            load_raw(std::integral_constant<int, jn>{}, jn == 0 ? A_BYTES - abuf : abuf, 0);
+            b0[0] = load_b(pb + ((s + 1) & 1) * B_BYTES, 0, 0);
+            mma4(v[2], b1[2], t1, false);
+            fence();
+            mma4(v[3], b1[3], t1, false);
+            fence();
+            ++s;
+        };
+        static_for<0, J>(stage);
+    }
+    fold(std::integral_constant<int, J - 1>{}, t1, o01, o11);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the tail's clamped pieces must have landed before the tile below reuses the LDS)
+    __syncthreads();
+
+    // ---- epilogue through an fp32 tile in LDS: D layout of a 32x32 MFMA tile: col = lane & 31, pair = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float *T = reinterpret_cast<float *>(lds);
+    {
+        const int col = wc * 64 + (lane & 31);
+        const int rowb = wr * 64 + 8 * (lane >> 5);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lr = rowb + 2 * ((reg & 3) + 8 * (reg >> 2));
+            T[lr * TLD + col] = o00[reg];
+            T[lr * TLD + col + 32] = o01[reg];
+            T[(lr + 1) * TLD + col] = o10[reg];
+            T[(lr + 1) * TLD + col + 32] = o11[reg];
+        }
+    }
+    __syncthreads();
+    const int cg = tid & 31, rp = tid >> 5;              // 4 columns; rows rp, rp + 8, ...
+    const int gc = n0 + cg * 4;
+    if (gc >= p.cout) return;                             // (cout % 4 == 0: a column group is inside or outside as a whole)
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + gc) : zero;
+    const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + gc) : one;
+    const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + gc) : zero;
+    f32x4 al = zero;
+    if (p.act == XV_ACT_LRELU) al = (f32x4){p.alpha[0], p.alpha[0], p.alpha[0], p.alpha[0]};
+    else if (p.act == XV_ACT_PRELU) al = *reinterpret_cast<const f32x4 *>(p.alpha + gc);
+#pragma unroll 4
+    for (int j = 0; j < BM / 8; ++j) {
+        const int lr = rp + 8 * j;
+        const long gr = m0 + lr;
+        if (gr >= p.R) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(T + lr * TLD + cg * 4);
+        const bool keep = Ms[lr] != 0;
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = apply_act(a[i] + bias[i], p.act, al[i]) * sc[i] + sh[i];
+            v[i] = keep ? t : 0.f;
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p.y + (size_t)gr * p.ldy + gc));   // streamed once: no L2 write-allocate
+    }
+}
+
+// U_j[c][o] = sum_k G[j][k] w[k][c][o] in double, rounded once, laid out as the GEMM's B operand wp[o][j * cin + c]
+template <int KT>
+__global__ void pack_weights_toom_kernel(const float *__restrict__ w, int cin, int cout, float *__restrict__ wp)
+{
+    using TC = Toom<KT>;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)cin * cout) return;
+    const int c = (int)(i / cout), o = (int)(i - (size_t)c * cout);
+    double g[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) g[k] = (double)w[((size_t)k * cin + c) * cout + o];
+#pragma unroll
+    for (int j = 0; j < TC::J; ++j) {
+        double u = 0.0;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) u += TC::G[j][k] * g[k];
+        wp[(size_t)o * (TC::J * cin) + (size_t)j * cin + c] = (float)u;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int xv_toom_supported(int K, int dilation, int cin, int cout)
+{
+    return (K == 5 || K == 7) && dilation == 1 && cin > 0 && cin % BK == 0 && cout > 0 && cout % 4 == 0;
+}
+
+size_t xv_packed_weights_toom_f32_floats(int K, int cin, int cout)
+{
+    if (!xv_toom_supported(K, 1, cin, cout)) return 0;
+    return (size_t)(K + 1) * cin * cout;
+}
+
+int xv_pack_weights_toom_f32(const float *w, int K, int cin, int cout, float *wp, void *stream)
+{
+    if (!w || !wp) return fail(XV_ERR_BAD_ARG, "pack_weights_toom: NULL argument");
+    if (!xv_toom_supported(K, 1, cin, cout)) return fail(XV_ERR_UNSUPPORTED, "pack_weights_toom: needs K in {5, 7}, Cin % 32 == 0, Cout % 4 == 0");
+    const size_t n = (size_t)cin * cout;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (K == 5) hipLaunchKernelGGL(pack_weights_toom_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, w, cin, cout, wp);
+    else hipLaunchKernelGGL(pack_weights_toom_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, w, cin, cout, wp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "pack_weights_toom_kernel launch");
+}
+
+int xv_tdnn_layer_toom_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
+                           const float *bn_shift, int act_kind, const float *act_alpha, int K, int cout, const uint8_t *row_valid,
+                           float *y, int ldy, void *stream)
+{
+    if (!x || !wp || !y) return fail(XV_ERR_BAD_ARG, "tdnn_toom: NULL argument");
+    if (R <= 0) return 0;
+    if (!xv_toom_supported(K, 1, cin, cout)) return fail(XV_ERR_UNSUPPORTED, "tdnn_toom: needs K in {5, 7}, Cin % 32 == 0, Cout % 4 == 0");
+    if (ldx < cin || ldy < cout) return fail(XV_ERR_BAD_ARG, "tdnn_toom: leading dimension too small");
+    if ((act_kind == XV_ACT_LRELU || act_kind == XV_ACT_PRELU) && !act_alpha) return fail(XV_ERR_BAD_ARG, "tdnn_toom: act_alpha is NULL");
+    const uintptr_t bits = (uintptr_t)x | (uintptr_t)wp | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)bn_scale | (uintptr_t)bn_shift |
+                           (act_kind == XV_ACT_PRELU ? (uintptr_t)act_alpha : 0);
+    if (bits % 16 != 0 || ldx % 4 != 0 || ldy % 4 != 0) return fail(XV_ERR_UNSUPPORTED, "tdnn_toom: needs 16-byte aligned rows and per-column parameters");
+    ToomParams p;
+    p.x = x; p.R = R; p.cin = cin; p.ldx = ldx; p.wp = wp; p.kred = (K + 1) * cin;
+    p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha; p.cout = cout;
+    p.valid = row_valid; p.y = y; p.ldy = ldy;
+    p.n_mt = (int)((R + BM - 1) / BM);
+    p.n_nt = (cout + BN - 1) / BN;
+    if ((R + BM + 8) * (long)ldx * 4 >= (1l << 31) || (long)(cout + BN) * p.kred * 4 >= (1l << 31))
+        return fail(XV_ERR_UNSUPPORTED, "tdnn_toom: matrices must stay below 2^31 bytes (32-bit buffer offsets)");
+    typedef void (*kern_t)(const ToomParams);
+    const kern_t k = K == 5 ? tdnn_gemm_toom_kernel<5> : tdnn_gemm_toom_kernel<7>;
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
+        for (kern_t kk : {tdnn_gemm_toom_kernel<5>, tdnn_gemm_toom_kernel<7>}) {
+            hipError_t e = hipFuncSetAttribute((const void *)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        }
+        attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_toom_kernel launch");
+}
+
+}  // extern "C"
