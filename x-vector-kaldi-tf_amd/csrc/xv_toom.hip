@@ -220,12 +220,13 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     const int bcol = wc * 64 + (lane & 31);
     const int pb = 2 * A_BYTES + bcol * SROW + ((((bcol >> 1) & 7) ^ kh) << 4);
 
-    // A stage's work of one wave, in two phases so that ONE temporary pair suffices: phase A accumulates column block 0 over the
-    // slab's four k groups (16 MFMAs on t0), phase B column block 1 (16 MFMAs on t1) re-using the transformed fragments v[0..3];
-    // t0 is folded into the outputs under phase B, t1 under phase A of the next stage -- no MFMA waits for a fold.
+    // A stage's work of one wave: four k groups; in each the raw fragments row j of BT reads become V_j (<= 6 FMAs per channel) and
+    // feed 8 MFMAs that ALTERNATE between the two column blocks' temporaries (no MFMA waits for its predecessor's accumulator).
+    // The temporaries alternate between stages (tA / tB): the pair of stage s - 1 is folded into the outputs under the MFMAs of
+    // stage s.
     f32x4 raw[J];                                            // the raw fragments of one k group (only the entries row j of BT reads)
-    f32x4 v[4];                                              // V_j of the four k groups
-    f32x4 b0[2], b1[4];
+    struct Bf { f32x4 b0, b1; };
+    Bf bf[2];
     auto load_raw = [&](auto JJ, int abuf, int kk) {
         constexpr int j = decltype(JJ)::value;
         auto one = [&](auto II) {
@@ -234,8 +235,9 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
         };
         static_for<0, J>(one);
     };
-    auto load_b = [&](int bbase, int kk, int half) -> f32x4 {
-        return *reinterpret_cast<const f32x4 *>(lds + (bbase ^ (kk << 5)) + half * 32 * SROW);
+    auto load_b = [&](Bf &X, int bbase, int kk) {
+        X.b0 = *reinterpret_cast<const f32x4 *>(lds + (bbase ^ (kk << 5)));
+        X.b1 = *reinterpret_cast<const f32x4 *>(lds + (bbase ^ (kk << 5)) + 32 * SROW);
     };
     auto xform = [&](auto JJ) -> f32x4 {
         constexpr int j = decltype(JJ)::value;
@@ -260,12 +262,15 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     };
 
     f32x16 o00 = {0}, o01 = {0}, o10 = {0}, o11 = {0};      // output rows 2P (o0x) and 2P + 1 (o1x), column blocks 0 / 1
-    f32x16 t0 = {0}, t1 = {0};                              // V_j . U_j of the running stage, column blocks 0 / 1
+    f32x16 tA0 = {0}, tA1 = {0}, tB0 = {0}, tB1 = {0};      // V_j . U_j of a stage, column blocks 0 / 1; A: even j, B: odd j
     const f32x16 zero16 = {0};
 
-    auto mma4 = [&](const f32x4 a, const f32x4 b, f32x16 &t, bool fresh) {
+    auto mma8 = [&](const f32x4 a, const Bf &X, f32x16 &t0, f32x16 &t1, bool fresh) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], (fresh && e == 0) ? zero16 : t, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            t0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], X.b0[e], (fresh && e == 0) ? zero16 : t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], X.b1[e], (fresh && e == 0) ? zero16 : t1, 0, 0, 0);
+        }
     };
     auto fold = [&](auto JJ, const f32x16 &t, f32x16 &oa, f32x16 &ob) {          // oa += AT[0][j] t, ob += AT[1][j] t
         constexpr int j = decltype(JJ)::value;
@@ -281,50 +286,41 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     };
     auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
     // (the folds are plain fp32 adds on SSA values: without an anchor in the chain of side effects instruction selection is free to
-    // emit them at the end of the loop body, and every stage's temporaries stay live -- 11 tiles instead of 2)
+    // emit them at the end of the loop body, and every stage's temporaries stay live -- 11 tiles instead of 4)
     auto anchor = [&](f32x16 &a, f32x16 &b) { asm volatile("" : "+v"(a), "+v"(b)); };
 
     load_raw(std::integral_constant<int, 0>{}, 0, 0);
-    b0[0] = load_b(pb, 0, 0);
+    load_b(bf[0], pb, 0);
     int s = 0;
     for (int c = 0; c < n_chunks; ++c) {
         const int abuf = (c & 1) * A_BYTES;
         auto stage = [&](auto JJ) {
             constexpr int j = decltype(JJ)::value;
             constexpr int jp = (j + J - 1) % J, jn = (j + 1) % J;
+            using JP = std::integral_constant<int, jp>;
+            f32x16 &t0 = (j & 1) ? tB0 : tA0, &t1 = (j & 1) ? tB1 : tA1;
+            f32x16 &u0 = (j & 1) ? tA0 : tB0, &u1 = (j & 1) ? tA1 : tB1;       // the previous stage's products
             const int bb = pb + (s & 1) * B_BYTES;
-            // ---- phase A: column block 0
-            v[0] = xform(JJ);
+            f32x4 v = xform(JJ);
             load_raw(JJ, abuf, 1);
-            b0[1] = load_b(bb, 1, 0);
-            mma4(v[0], b0[0], t0, true);
-            fence();
-            v[1] = xform(JJ);
-            load_raw(JJ, abuf, 2);
-            b0[0] = load_b(bb, 2, 0);
-            mma4(v[1], b0[1], t0, false);
-            fold(std::integral_constant<int, jp>{}, t1, o01, o11);      // (stage 0 of slab 0 folds the zero-initialised t1)
-            anchor(o01, o11);
-            fence();
-            v[2] = xform(JJ);
-            load_raw(JJ, abuf, 3);
-            b0[1] = load_b(bb, 3, 0);
-            mma4(v[2], b0[0], t0, false);
-            fence();
-            v[3] = xform(JJ);
-            b1[0] = load_b(bb, 0, 1);
-            b1[1] = load_b(bb, 1, 1);
-            b1[2] = load_b(bb, 2, 1);
-            b1[3] = load_b(bb, 3, 1);
-            mma4(v[3], b0[1], t0, false);
-            fence();
-            // ---- phase B: column block 1
-            mma4(v[0], b1[0], t1, true);
-            fence();
-            mma4(v[1], b1[1], t1, false);
-            fold(JJ, t0, o00, o10);
+            load_b(bf[1], bb, 1);
+            mma8(v, bf[0], t0, t1, true);
+            fold(JP{}, u0, o00, o10);                    // (stage 0 of slab 0 folds the zero-initialised tB)
             anchor(o00, o10);
             fence();
+            v = xform(JJ);
+            load_raw(JJ, abuf, 2);
+            load_b(bf[0], bb, 2);
+            mma8(v, bf[1], t0, t1, false);
+            fold(JP{}, u1, o01, o11);
+            anchor(o01, o11);
+            fence();
+            v = xform(JJ);
+            load_raw(JJ, abuf, 3);
+            load_b(bf[1], bb, 3);
+            mma8(v, bf[0], t0, t1, false);
+            fence();
+            v = xform(JJ);
             // every fragment of stage s is in registers, stage s + 1 has landed
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -332,16 +328,15 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
             if constexpr (j < 5) dma_a_slot(c + 1, j);
             fence();
             load_raw(std::integral_constant<int, jn>{}, jn == 0 ? A_BYTES - abuf : abuf, 0);
-            b0[0] = load_b(pb + ((s + 1) & 1) * B_BYTES, 0, 0);
-            mma4(v[2], b1[2], t1, false);
-            fence();
-            mma4(v[3], b1[3], t1, false);
+            load_b(bf[0], pb + ((s + 1) & 1) * B_BYTES, 0);
+            mma8(v, bf[1], t0, t1, false);
             fence();
             ++s;
         };
         static_for<0, J>(stage);
     }
-    fold(std::integral_constant<int, J - 1>{}, t1, o01, o11);
+    fold(std::integral_constant<int, J - 1>{}, tB0, o00, o10);
+    fold(std::integral_constant<int, J - 1>{}, tB1, o01, o11);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the tail's clamped pieces must have landed before the tile below reuses the LDS)
     __syncthreads();
 
