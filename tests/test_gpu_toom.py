@@ -48,7 +48,7 @@ def _run(env, mats, w, b, bn, act, alpha, align=8, direct=False):
     (512, 512, 7, "relu"),          # layer 2
     (64, 48, 5, "prelu"),           # ragged column tile, two slabs, PReLU epilogue
     (96, 200, 7, "lrelu"),          # odd slab count, two column tiles
-    (32, 4, 5, "none"),             # one slab, a 4-column layer
+    (32, 4, 5, "none"),             # one slab (odd slab count: the loop's tail), a 4-column layer
 ])
 def test_toom_layer_matches_oracle(env, cin, cout, K, act):
     oracle = env["oracle"]

@@ -16,11 +16,20 @@
 //  * the halo tile of a 32-channel slab (128 + K - 1 rows) goes global -> LDS by buffer_load ... lds, EVEN and ODD rows into two
 //    regions so that the 32 lanes of a fragment read (rows 2P + i for consecutive P) walk consecutive 128-byte LDS rows: the
 //    conflict-free XOR-swizzled pattern of the direct kernel;
-//  * stage = (slab, product j): the wave reads the <= 6 raw fragments row j of BT needs, forms V_j with <= 6 FMAs per channel
-//    (nothing beside a 64-cycle v_mfma_f32_32x32x2_f32) and accumulates V_j . U_j over the slab into a TEMPORARY tile (two of them,
-//    alternating by stage); the temporary of stage s - 1 is folded into the two output-row accumulators (AT's coefficients) under
-//    the MFMAs of stage s;
+//  * stage = (slab, product): the wave reads the <= 6 raw fragments the product's row of BT needs, forms V_j with 2 .. 5 packed
+//    fp32 operations per channel pair and accumulates V_j . U_j over the slab;
 //  * one barrier per stage, weights double-buffered, the next slab's halo pieces dealt over the first stages of the current one.
+// What shapes the inner loop is a measurement (tools/experiments/f32_mfma_valu_probe.hip): beside v_mfma_f32_32x32x2_f32 a VALU
+// instruction of ANY kind is not hidden -- it costs ~4 of the MFMA pipe's cycles, plus ~10 more when it sits alone between two
+// MFMAs (ds_read / s_nop are free) -- so the kernel counts VALU instructions:
+//  * the products of the points 0 and infinity reach ONE output row each (AT has a single non-zero in their columns) and accumulate
+//    straight into that row's tile; the others go to a temporary tile pair (two pairs, alternating by stage) that is folded into
+//    both output rows with packed adds / FMAs under the MFMAs of the NEXT stage; the last temporary of a slab is folded in two
+//    halves, each under the direct stage that does not own the half's output row (no MFMA ever waits for a fold or vice versa);
+//  * rows of BT are scaled (the inverse goes into G) so that every transform is a short chain of packed FMAs without a leading
+//    multiplication, the stage order puts the weight-tile parity and the halo-buffer parity into immediates (the only address
+//    arithmetic left is one XOR per raw fragment), and every step is VALU first, then the next step's ds_reads, then 8 MFMAs
+//    back to back.
 // Row pairs are aligned to EVEN global rows; chunks start on even rows (the host lays batches out with align 8), so a chunk's bits
 // do not depend on its batch neighbours.  Gap rows are zero and masked as everywhere else.
 #include <hip/hip_runtime.h>
@@ -53,16 +62,21 @@ int hip_fail(hipError_t e, const char *where)
     return (int)e;
 }
 
-// ---- F(2, K) matrices (tools/experiments/toomcook_gen.py prints these; exactness checked there) ------------------------------
+// ---- F(2, K) matrices (tools/experiments/toomcook_gen.py prints BT / G / AT and checks them in exact rationals).  Here per
+// product j: the scale SC[j] its row of BT is divided by (G's row is multiplied by it), AT[1][j] (AT[0][j] is 1 except for the
+// point at infinity), and the stage order: the product of point 0 (output row 2P only), the product of infinity (row 2P + 1
+// only), then the +- pairs.  The transforms themselves are written out in xform() below.
 template <int KT>
 struct Toom;
 
 template <>
 struct Toom<5> {                                  // points 0, 1, -1, 2, -2, inf
     static constexpr int J = 6;
-    static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
-                                       {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
-    static constexpr float AT[2][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 1}};
+    // BT = {{4,0,-5,0,1,0}, {0,-4,-4,1,1,0}, {0,4,-4,-1,1,0}, {0,-2,-1,2,1,0}, {0,2,-1,-2,1,0}, {0,4,0,-5,0,1}}
+    static constexpr int ORDER[6] = {0, 5, 1, 2, 3, 4};
+    static constexpr double SC[6] = {1, 1, 1, 1, 1, 1};
+    static constexpr float A1[6] = {0, 1, -1, 2, -2, 1};
+    static constexpr unsigned NEED[6] = {0x15, 0x1e, 0x1e, 0x1e, 0x1e, 0x2a};     // bit i: the product reads input row i
     static constexpr double G[6][5] = {{1. / 4, 0, 0, 0, 0},
                                        {-1. / 6, -1. / 6, -1. / 6, -1. / 6, -1. / 6},
                                        {-1. / 6, 1. / 6, -1. / 6, 1. / 6, -1. / 6},
@@ -74,10 +88,12 @@ struct Toom<5> {                                  // points 0, 1, -1, 2, -2, inf
 template <>
 struct Toom<7> {                                  // points 0, 1, -1, 2, -2, 1/2, -1/2, inf
     static constexpr int J = 8;
-    static constexpr float BT[8][8] = {{-4, 0, 21, 0, -21, 0, 4, 0},  {0, 4, 4, -17, -17, 4, 4, 0},  {0, -4, 4, 17, -17, -4, 4, 0},
-                                       {0, 2, 1, -10, -5, 8, 4, 0},   {0, -2, 1, 10, -5, -8, 4, 0},  {0, 4, 8, -5, -10, 1, 2, 0},
-                                       {0, -4, 8, 5, -10, -1, 2, 0},  {0, -4, 0, 21, 0, -21, 0, 4}};
-    static constexpr float AT[2][8] = {{1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0.5f, -0.5f, 1}};
+    // BT = {{-4,0,21,0,-21,0,4,0}, {0,4,4,-17,-17,4,4,0}, {0,-4,4,17,-17,-4,4,0}, {0,2,1,-10,-5,8,4,0}, {0,-2,1,10,-5,-8,4,0},
+    //       {0,4,8,-5,-10,1,2,0}, {0,-4,8,5,-10,-1,2,0}, {0,-4,0,21,0,-21,0,4}}; rows 0, 1, 2, 7 are used divided by 4, row 6 negated
+    static constexpr int ORDER[8] = {0, 7, 1, 2, 3, 4, 5, 6};
+    static constexpr double SC[8] = {4, 4, 4, 1, 1, 1, -1, 4};
+    static constexpr float A1[8] = {0, 1, -1, 2, -2, 0.5f, -0.5f, 1};
+    static constexpr unsigned NEED[8] = {0x55, 0x7e, 0x7e, 0x7e, 0x7e, 0x7e, 0x7e, 0xaa};
     static constexpr double G[8][7] = {{-1. / 4, 0, 0, 0, 0, 0, 0},
                                        {-1. / 18, -1. / 18, -1. / 18, -1. / 18, -1. / 18, -1. / 18, -1. / 18},
                                        {-1. / 18, 1. / 18, -1. / 18, 1. / 18, -1. / 18, 1. / 18, -1. / 18},
@@ -110,7 +126,7 @@ struct ToomParams {
     const float *x;
     long R;
     int cin, ldx;
-    const float *wp;            // [cout][J * cin]: U_j[c][o] at wp[o][j * cin + c]
+    const float *wp;            // [cout][J * cin]: stage q's transformed tap U_ORDER[q][c][o] at wp[o][q * cin + c]
     int kred;                   // J * cin
     const float *bias, *scale, *shift;
     int act;
@@ -138,6 +154,41 @@ __device__ __forceinline__ float apply_act(float z, int act, float a)
     case XV_ACT_LRELU: return z > 0.0f ? z : a * z;
     case XV_ACT_PRELU: return fmaxf(z, 0.0f) + a * fminf(z, 0.0f);
     default: return z;
+    }
+}
+
+__device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 y)
+{
+    return __builtin_elementwise_fma((f32x4){a, a, a, a}, x, y);
+}
+
+// x - y as a packed FMA: a vector fsub is selected as four scalar v_sub_f32 (and fma(-1, y, x) is canonicalised back into one), so
+// the -1 comes in as a value the compiler cannot see through.  Beside an fp32 MFMA the instruction count is what matters.
+__device__ __forceinline__ f32x4 sub4(f32x4 x, f32x4 y, float m1)
+{
+    return fma4(m1, y, x);
+}
+
+// V_j (divided by SC[j]) from the raw input rows d[0 .. K] of a row pair: one 4-channel fragment.
+template <int KT, int j>
+__device__ __forceinline__ f32x4 xform(const f32x4 (&d)[KT + 1], float m1)
+{
+    if constexpr (KT == 5) {
+        if constexpr (j == 0) return fma4(4.f, d[0], fma4(-5.f, d[2], d[4]));
+        if constexpr (j == 1) return fma4(-4.f, d[2], d[4]) + fma4(-4.f, d[1], d[3]);
+        if constexpr (j == 2) return sub4(fma4(-4.f, d[2], d[4]), fma4(-4.f, d[1], d[3]), m1);
+        if constexpr (j == 3) return fma4(2.f, sub4(d[3], d[1], m1), sub4(d[4], d[2], m1));
+        if constexpr (j == 4) return fma4(-2.f, sub4(d[3], d[1], m1), sub4(d[4], d[2], m1));
+        if constexpr (j == 5) return fma4(4.f, d[1], fma4(-5.f, d[3], d[5]));
+    } else {
+        if constexpr (j == 0) return fma4(5.25f, sub4(d[2], d[4], m1), sub4(d[6], d[0], m1));
+        if constexpr (j == 1) return fma4(-4.25f, d[4], d[2] + d[6]) + fma4(-4.25f, d[3], d[1] + d[5]);
+        if constexpr (j == 2) return sub4(fma4(-4.25f, d[4], d[2] + d[6]), fma4(-4.25f, d[3], d[1] + d[5]), m1);
+        if constexpr (j == 3) return fma4(2.f, fma4(4.f, d[5], fma4(-5.f, d[3], d[1])), fma4(4.f, d[6], fma4(-5.f, d[4], d[2])));
+        if constexpr (j == 4) return fma4(-2.f, fma4(4.f, d[5], fma4(-5.f, d[3], d[1])), fma4(4.f, d[6], fma4(-5.f, d[4], d[2])));
+        if constexpr (j == 5) return fma4(2.f, fma4(4.f, d[2], fma4(-5.f, d[4], d[6])), fma4(4.f, d[1], fma4(-5.f, d[3], d[5])));
+        if constexpr (j == 6) return fma4(-2.f, fma4(4.f, d[2], fma4(-5.f, d[4], d[6])), fma4(4.f, d[1], fma4(-5.f, d[3], d[5])));
+        if constexpr (j == 7) return fma4(5.25f, sub4(d[3], d[5], m1), sub4(d[7], d[1], m1));
     }
 }
 
@@ -218,51 +269,32 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
         pa[i] = L * SROW + ((((L >> 1) & 7) ^ kh) << 4);
     }
     const int bcol = wc * 64 + (lane & 31);
-    const int pb = 2 * A_BYTES + bcol * SROW + ((((bcol >> 1) & 7) ^ kh) << 4);
+    int pbk[4];                                              // weight fragments of k group kk: + buffer and column-block immediates
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) pbk[kk] = (2 * A_BYTES + bcol * SROW + ((((bcol >> 1) & 7) ^ kh) << 4)) ^ (kk << 5);
 
-    // A stage's work of one wave: four k groups; in each the raw fragments row j of BT reads become V_j (<= 6 FMAs per channel) and
-    // feed 8 MFMAs that ALTERNATE between the two column blocks' temporaries (no MFMA waits for its predecessor's accumulator).
-    // The temporaries alternate between stages (tA / tB): the pair of stage s - 1 is folded into the outputs under the MFMAs of
-    // stage s.
-    f32x4 raw[J];                                            // the raw fragments of one k group (only the entries row j of BT reads)
+    float m1 = -1.f;                                         // (see sub4)
+    asm volatile("" : "+s"(m1));
+    f32x4 raw[J];                                            // the raw fragments of one k group (only the rows the product reads)
     struct Bf { f32x4 b0, b1; };
     Bf bf[2];
-    auto load_raw = [&](auto JJ, int abuf, int kk) {
+    auto load_raw = [&](auto JJ, auto CP, int kk) {          // product j, halo buffer CP, k group kk
         constexpr int j = decltype(JJ)::value;
+        constexpr int off = decltype(CP)::value * A_BYTES;
         auto one = [&](auto II) {
             constexpr int i = decltype(II)::value;
-            if constexpr (TC::BT[j][i] != 0.f) raw[i] = *reinterpret_cast<const f32x4 *>(lds + ((pa[i] + abuf) ^ (kk << 5)));
+            if constexpr ((TC::NEED[j] >> i) & 1) raw[i] = *reinterpret_cast<const f32x4 *>(lds + (pa[i] ^ (kk << 5)) + off);
         };
         static_for<0, J>(one);
     };
-    auto load_b = [&](Bf &X, int bbase, int kk) {
-        X.b0 = *reinterpret_cast<const f32x4 *>(lds + (bbase ^ (kk << 5)));
-        X.b1 = *reinterpret_cast<const f32x4 *>(lds + (bbase ^ (kk << 5)) + 32 * SROW);
-    };
-    auto xform = [&](auto JJ) -> f32x4 {
-        constexpr int j = decltype(JJ)::value;
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        bool first = true;
-        auto one = [&](auto II) {
-            constexpr int i = decltype(II)::value;
-            constexpr float bt = TC::BT[j][i];
-            if constexpr (bt != 0.f) {
-                if (first) {
-                    first = false;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r[e] = bt == 1.f ? raw[i][e] : bt * raw[i][e];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(bt, raw[i][e], r[e]);
-                }
-            }
-        };
-        static_for<0, J>(one);
-        return r;
+    auto load_b = [&](Bf &X, auto BP, int kk) {
+        constexpr int off = decltype(BP)::value * B_BYTES;
+        X.b0 = *reinterpret_cast<const f32x4 *>(lds + pbk[kk] + off);
+        X.b1 = *reinterpret_cast<const f32x4 *>(lds + pbk[kk] + off + 32 * SROW);
     };
 
     f32x16 o00 = {0}, o01 = {0}, o10 = {0}, o11 = {0};      // output rows 2P (o0x) and 2P + 1 (o1x), column blocks 0 / 1
-    f32x16 tA0 = {0}, tA1 = {0}, tB0 = {0}, tB1 = {0};      // V_j . U_j of a stage, column blocks 0 / 1; A: even j, B: odd j
+    f32x16 tA0 = {0}, tA1 = {0}, tB0 = {0}, tB1 = {0};      // V_j . U_j of a +- product's stage, column blocks 0 / 1
     const f32x16 zero16 = {0};
 
     auto mma8 = [&](const f32x4 a, const Bf &X, f32x16 &t0, f32x16 &t1, bool fresh) {
@@ -272,71 +304,98 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
             t1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], X.b1[e], (fresh && e == 0) ? zero16 : t1, 0, 0, 0);
         }
     };
-    auto fold = [&](auto JJ, const f32x16 &t, f32x16 &oa, f32x16 &ob) {          // oa += AT[0][j] t, ob += AT[1][j] t
-        constexpr int j = decltype(JJ)::value;
-        constexpr float a0 = TC::AT[0][j], a1 = TC::AT[1][j];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if constexpr (a0 == 1.f) oa[e] += t[e];
-            else if constexpr (a0 != 0.f) oa[e] = __builtin_fmaf(a0, t[e], oa[e]);
-            if constexpr (a1 == 1.f) ob[e] += t[e];
-            else if constexpr (a1 == -1.f) ob[e] -= t[e];
-            else if constexpr (a1 != 0.f) ob[e] = __builtin_fmaf(a1, t[e], ob[e]);
-        }
+    auto add_to = [&](f32x16 &o, const f32x16 &t) { o += t; };                                   // 8 v_pk_add_f32
+    auto fma_to = [&](auto JJ, f32x16 &o, const f32x16 &t) {                                     // o += AT[1][j] t
+        constexpr float a = TC::A1[decltype(JJ)::value];
+        if constexpr (a == 1.f) o += t;
+        else if constexpr (a == -1.f) o = __builtin_elementwise_fma((f32x16){m1, m1, m1, m1, m1, m1, m1, m1, m1, m1, m1, m1, m1, m1, m1, m1}, t, o);
+        else o = __builtin_elementwise_fma((f32x16){a, a, a, a, a, a, a, a, a, a, a, a, a, a, a, a}, t, o);
     };
+    // (a fold is plain arithmetic on SSA values: without an anchor in the chain of side effects instruction selection emits it
+    // at the end of the loop body and every stage's temporaries stay live; the anchors also keep each piece in its step)
+    auto anchor = [&](f32x16 &a) { asm volatile("" : "+v"(a)); };
     auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
-    // (the folds are plain fp32 adds on SSA values: without an anchor in the chain of side effects instruction selection is free to
-    // emit them at the end of the loop body, and every stage's temporaries stay live -- 11 tiles instead of 4)
-    auto anchor = [&](f32x16 &a, f32x16 &b) { asm volatile("" : "+v"(a), "+v"(b)); };
+    auto order_step = [&]() {                                // VALU first, then the next step's fragment reads, then 8 MFMAs back to back
+        __builtin_amdgcn_sched_group_barrier(0x002, 96, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    };
+    // (hipcc's pre-emit peephole UNPACKS v_pk_*_f32 that follow an MFMA within its latency into two scalar instructions, to co-issue
+    // them under the MFMA; under an fp32 MFMA nothing co-issues, the unpacked pair just costs twice.  Its scan stops at an
+    // instruction that names the MFMA's destination: an empty asm on the step's last accumulator is that instruction.)
+    auto end_step = [&](f32x16 &t) { asm volatile("" : "+v"(t)); };
+    using JLAST = std::integral_constant<int, J - 2>;        // the product whose temporary (tB) outlives its slab
 
-    load_raw(std::integral_constant<int, 0>{}, 0, 0);
-    load_b(bf[0], pb, 0);
     int s = 0;
-    for (int c = 0; c < n_chunks; ++c) {
-        const int abuf = (c & 1) * A_BYTES;
-        auto stage = [&](auto JJ) {
-            constexpr int j = decltype(JJ)::value;
-            constexpr int jp = (j + J - 1) % J, jn = (j + 1) % J;
-            using JP = std::integral_constant<int, jp>;
-            f32x16 &t0 = (j & 1) ? tB0 : tA0, &t1 = (j & 1) ? tB1 : tA1;
-            f32x16 &u0 = (j & 1) ? tA0 : tB0, &u1 = (j & 1) ? tA1 : tB1;       // the previous stage's products
-            const int bb = pb + (s & 1) * B_BYTES;
-            f32x4 v = xform(JJ);
-            load_raw(JJ, abuf, 1);
-            load_b(bf[1], bb, 1);
-            mma8(v, bf[0], t0, t1, true);
-            fold(JP{}, u0, o00, o10);                    // (stage 0 of slab 0 folds the zero-initialised tB)
-            anchor(o00, o10);
+    auto slab = [&](auto CP, int c) {
+        constexpr int cp = decltype(CP)::value;
+        auto stage = [&](auto QQ) {
+            constexpr int q = decltype(QQ)::value;
+            constexpr int j = TC::ORDER[q];
+            using JJ = std::integral_constant<int, j>;
+            using BP = std::integral_constant<int, q & 1>;
+            constexpr bool direct = q < 2;
+            f32x16 &t0 = q == 0 ? o00 : q == 1 ? o10 : (q & 1) ? tB0 : tA0;
+            f32x16 &t1 = q == 0 ? o01 : q == 1 ? o11 : (q & 1) ? tB1 : tA1;
+            f32x16 &u0 = (q & 1) ? tA0 : tB0, &u1 = (q & 1) ? tA1 : tB1;       // the previous +- stage's products (q >= 3)
+            using JP = std::integral_constant<int, TC::ORDER[q >= 3 ? q - 1 : 2]>;
+            // ---- step 0
+            f32x4 v = xform<KT, j>(raw, m1);
+            load_raw(JJ{}, CP, 1);
+            load_b(bf[1], BP{}, 1);
+            mma8(v, bf[0], t0, t1, !direct);
+            order_step();
+            end_step(t1);
             fence();
-            v = xform(JJ);
-            load_raw(JJ, abuf, 2);
-            load_b(bf[0], bb, 2);
+            // ---- step 1 (+ the folds into column block 0)
+            v = xform<KT, j>(raw, m1);
+            if constexpr (q == 0) { fma_to(JLAST{}, o10, tB0); anchor(o10); }
+            if constexpr (q == 1) { add_to(o00, tB0); anchor(o00); }
+            if constexpr (q >= 3) { add_to(o00, u0); fma_to(JP{}, o10, u0); anchor(o00); anchor(o10); }
+            load_raw(JJ{}, CP, 2);
+            load_b(bf[0], BP{}, 2);
             mma8(v, bf[1], t0, t1, false);
-            fold(JP{}, u1, o01, o11);
-            anchor(o01, o11);
+            order_step();
+            end_step(t1);
             fence();
-            v = xform(JJ);
-            load_raw(JJ, abuf, 3);
-            load_b(bf[1], bb, 3);
+            // ---- step 2 (+ the folds into column block 1)
+            v = xform<KT, j>(raw, m1);
+            if constexpr (q == 0) { fma_to(JLAST{}, o11, tB1); anchor(o11); }
+            if constexpr (q == 1) { add_to(o01, tB1); anchor(o01); }
+            if constexpr (q >= 3) { add_to(o01, u1); fma_to(JP{}, o11, u1); anchor(o01); anchor(o11); }
+            load_raw(JJ{}, CP, 3);
+            load_b(bf[1], BP{}, 3);
             mma8(v, bf[0], t0, t1, false);
+            order_step();
+            end_step(t1);
             fence();
-            v = xform(JJ);
-            // every fragment of stage s is in registers, stage s + 1 has landed
+            // ---- step 3: every fragment of stage s is in registers, stage s + 1 has landed
+            v = xform<KT, j>(raw, m1);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            dma_b(s + 2, s & 1);
-            if constexpr (j < 5) dma_a_slot(c + 1, j);
+            dma_b(s + 2, q & 1);
+            if constexpr (q < 5) dma_a_slot(c + 1, q);
             fence();
-            load_raw(std::integral_constant<int, jn>{}, jn == 0 ? A_BYTES - abuf : abuf, 0);
-            load_b(bf[0], pb + ((s + 1) & 1) * B_BYTES, 0);
+            if constexpr (q + 1 < J) load_raw(std::integral_constant<int, TC::ORDER[(q + 1) % J]>{}, CP, 0);
+            else load_raw(std::integral_constant<int, TC::ORDER[0]>{}, std::integral_constant<int, 1 - cp>{}, 0);
+            load_b(bf[0], std::integral_constant<int, (q + 1) & 1>{}, 0);
             mma8(v, bf[1], t0, t1, false);
+            end_step(t1);
             fence();
             ++s;
         };
         static_for<0, J>(stage);
+    };
+    load_raw(std::integral_constant<int, TC::ORDER[0]>{}, std::integral_constant<int, 0>{}, 0);
+    load_b(bf[0], std::integral_constant<int, 0>{}, 0);
+    for (int c = 0; c < n_chunks; c += 2) {
+        slab(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < n_chunks) slab(std::integral_constant<int, 1>{}, c + 1);
     }
-    fold(std::integral_constant<int, J - 1>{}, tB0, o00, o10);
-    fold(std::integral_constant<int, J - 1>{}, tB1, o01, o11);
+    fma_to(JLAST{}, o10, tB0);
+    fma_to(JLAST{}, o11, tB1);
+    add_to(o00, tB0);
+    add_to(o01, tB1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the tail's clamped pieces must have landed before the tile below reuses the LDS)
     __syncthreads();
 
@@ -382,7 +441,8 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     }
 }
 
-// U_j[c][o] = sum_k G[j][k] w[k][c][o] in double, rounded once, laid out as the GEMM's B operand wp[o][j * cin + c]
+// U_j[c][o] = SC[j] sum_k G[j][k] w[k][c][o] in double, rounded once, laid out as the GEMM's B operand in STAGE order:
+// wp[o][q * cin + c] = U_ORDER[q][c][o]
 template <int KT>
 __global__ void pack_weights_toom_kernel(const float *__restrict__ w, int cin, int cout, float *__restrict__ wp)
 {
@@ -394,11 +454,12 @@ __global__ void pack_weights_toom_kernel(const float *__restrict__ w, int cin, i
 #pragma unroll
     for (int k = 0; k < KT; ++k) g[k] = (double)w[((size_t)k * cin + c) * cout + o];
 #pragma unroll
-    for (int j = 0; j < TC::J; ++j) {
+    for (int q = 0; q < TC::J; ++q) {
+        const int j = TC::ORDER[q];
         double u = 0.0;
 #pragma unroll
         for (int k = 0; k < KT; ++k) u += TC::G[j][k] * g[k];
-        wp[(size_t)o * (TC::J * cin) + (size_t)j * cin + c] = (float)u;
+        wp[(size_t)o * (TC::J * cin) + (size_t)q * cin + c] = (float)(TC::SC[j] * u);
     }
 }
 
