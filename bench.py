@@ -71,7 +71,7 @@ def parse():
                          "instead of the default ModelWithoutDropout network; implies its own head (softmax-CE)")
     ap.add_argument("--head", choices=["am_softmax", "softmax"], default="am_softmax",
                     help="--mode train: classification head (BASELINE configs[4] names AM-softmax; 'softmax' = the reference's head)")
-    ap.add_argument("--precision", choices=["f16bf8", "bf16x3", "fp32"], default="f16bf8",
+    ap.add_argument("--precision", choices=["f16bf8", "bf16x3", "fp32", "fp32tc"], default="f16bf8",
                     help="GEMM arithmetic: f16bf8 (default) = one fp16 MFMA + one block-scaled bf8 MFMA of the cross terms per "
                          "product in the hidden layers, ~1.3e-5 rel-L2; bf16x3 = split-precision bf16 MFMA, ~5e-6; fp32 = exact "
                          "fp32-input MFMA.  All accumulate in fp32; the parity bar is 1e-4")
@@ -382,12 +382,12 @@ def _cli_job_leg(args, ark_path, scp_path, model_dir, n):
                     "clock of the whole job from outside, second of two runs"}
 
 
-def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
+def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, precision="fp32", oracle_check=None):
     """The same step on the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulate), 1 warm-up + 2
     timed passes over the resident batches -- what the bf16x3 default is traded against."""
     import torch
     from xvector_amd import engine, hiplib, topology as tp
-    model = engine.DeviceModel(weights, topo, dev, precision="fp32")
+    model = engine.DeviceModel(weights, topo, dev, precision=precision)
     model.reserve(max(b["rows"] for b in batches), max(b["n"] for b in batches), max(b["max_len"] for b in batches))
     P = torch.empty((n_utts, model.pooled_dim), dtype=torch.float32, device=dev)
     E = torch.empty((n_utts, model.embed_dim), dtype=torch.float32, device=dev)
@@ -408,12 +408,30 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat):
     dt = (time.perf_counter() - t0) / steps
     t_g = sum(e[0].elapsed_time(e[1]) for si in range(1, steps + 1) for e in ev[si]) * 1e-3
     fl = tp.flops_per_frame(topo, feat) * frames
-    return {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps,
-            "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n_utts) / dt / 1e12,
-            "tdnn_gemm_tflops": fl * steps / t_g / 1e12, "frac": fl * steps / t_g / MFMA_F32_PEAK, "peak_tflops": MFMA_F32_PEAK / 1e12,
-            "kernel": "tdnn_gemm_dma_kernel (layers 1-4: v_mfma_f32_32x32x2_f32 fed by buffer_load ... lds, bit-identical to tdnn_gemm_kernel, "
-                      "which still runs layer 0: Cin = 24 is no whole 32-channel slab); the last layer reduced to 8-row block statistics in its "
-                      "epilogue + stats_pool_blocks_kernel"}
+    out = {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n_utts) / dt / 1e12,
+           "tdnn_gemm_tflops": fl * steps / t_g / 1e12, "frac": fl * steps / t_g / MFMA_F32_PEAK, "peak_tflops": MFMA_F32_PEAK / 1e12,
+           "kernel": "tdnn_gemm_dma_kernel (layers 1-4: v_mfma_f32_32x32x2_f32 fed by buffer_load ... lds, bit-identical to tdnn_gemm_kernel, "
+                     "which still runs layer 0: Cin = 24 is no whole 32-channel slab); the last layer reduced to 8-row block statistics in its "
+                     "epilogue + stats_pool_blocks_kernel"}
+    if precision == "fp32tc":
+        # executed multiplications: a K-tap layer the Toom-Cook kernel takes runs (K + 1) / 2 products per row instead of K
+        in_dims = [feat] + [int(c) for c in topo["layer_sizes"][:-1]]
+        ex = 0.0
+        for k, d, cin, cout in zip(topo["kernel_sizes"], topo["dilations"], in_dims, topo["layer_sizes"]):
+            taps = (k + 1) / 2.0 if hiplib.toom_supported(int(k), int(d), int(cin), int(cout)) else float(k)
+            ex += 2.0 * taps * cin * cout
+        out.update({"dtype": "f32 (exact fp32 products and fp32 accumulation; the K = 5 / K = 7 layers as Toom-Cook F(2, K) over time: "
+                             "not bit-identical to fp32_exact)",
+                    "frac_note": "frac / tdnn_gemm_tflops count the ALGORITHMIC multiplications (2 K Cin Cout per frame) against the "
+                                 "157.3 TF fp32-MFMA peak: above 1 is possible because fewer are executed; executed_frac counts what the MFMAs run",
+                    "executed_tflops": ex * frames * steps / t_g / 1e12, "executed_frac": ex * frames * steps / t_g / MFMA_F32_PEAK,
+                    "executed_over_algorithmic_flops": ex / tp.flops_per_frame(topo, feat),
+                    "kernel": "tdnn_gemm_toom_kernel<5>, <7> (layers 1, 2: 6 / 8 transformed products per row pair on v_mfma_f32_32x32x2_f32, "
+                              "csrc/xv_toom.hip); layers 0, 3, 4, pooling, FC as fp32_exact"})
+    if oracle_check is not None:
+        out["parity_rel_l2_max_vs_fp64_oracle"] = oracle_check(E)
+    return out
 
 
 def _bf16x3_leg(args, weights, topo, dev, batches, n_utts, frames, feat, order, oracle_check):
@@ -865,7 +883,10 @@ def main():
                                              "shape": "nj independent extractor processes x 2 intra-op threads, as run.sh:229-247 / "
                                                       "extract_xvectors.sh:83-88 deploy the reference (models.py:361-363)"}}
     if world == 1 and model.precision != "fp32" and not args.no_fp32_leg:
-        out["fp32_exact"] = _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat)
+        out["fp32_exact"] = _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, "fp32",
+                                      parity_check if args.cpu_budget > 0 else None)
+        out["fp32_toomcook"] = _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, "fp32tc",
+                                         parity_check if args.cpu_budget > 0 else None)
         if getattr(model, "f16bf8", False):
             out["bf16x3"] = _bf16x3_leg(args, weights, topo, dev, batches, n_utts, frames, feat, order,
                                         parity_check if args.cpu_budget > 0 else None)

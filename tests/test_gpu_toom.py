@@ -104,3 +104,76 @@ def test_toom_unsupported_shapes_are_refused(env):
     w = torch.zeros((5, 24, 512), device=dev)
     with pytest.raises(AssertionError):
         hiplib.pack_weights_toom(w)
+
+
+# ---- the whole network in the "fp32tc" arithmetic (engine.DeviceModel(precision="fp32tc")) -----------------------------------
+TOL_XVEC = 2e-6           # x-vector, relative L2 against the fp64 oracle (measured ~3e-7; the exact-fp32 kernels ~2e-7)
+
+
+@pytest.fixture(scope="module")
+def net(oracle_mod):
+    import torch
+    from xvector_amd import engine, hiplib, synthetic, topology
+    hiplib.require_gpu()
+    return dict(torch=torch, hiplib=hiplib, engine=engine, oracle=oracle_mod, synthetic=synthetic, topology=topology)
+
+
+def test_fp32tc_forward_matches_golden(net, golden):
+    """The golden x-vectors of the default topology (tests/golden/forward_default.npz: fp64 oracle on seeded weights / inputs)."""
+    g = golden("forward_default.npz")
+    seed = int(g["seed"])
+    topo = net["topology"].get("ModelWithoutDropout")
+    w = net["synthetic"].trained_like(topo, 23, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    Ts = [25, 200, 400, 1000]
+    mats = [(rng.standard_normal((T, 23)) * 3.0).astype(np.float32) for T in Ts]
+    for emb_idx in (0, 1):
+        model = net["engine"].DeviceModel(w, topo, "cuda:0", embedding_index=emb_idx, precision="fp32tc")
+        assert model.toom and model.arithmetic == "fp32tc" and model.align == 8
+        assert [isinstance(L["wp"], net["hiplib"].PackedToom) for L in model.layers] == [False, True, True, False, False]
+        vecs = net["engine"].Extractor(model, 1, -1).extract(mats)
+        for T, v in zip(Ts, vecs):
+            ref32 = net["oracle"].chunk_average(g["default_T%d_e%d" % (T, emb_idx)].astype(np.float32)[None, :], [T], np.float32)
+            assert net["oracle"].rel_l2(v, ref32) < TOL_XVEC, (T, emb_idx)
+
+
+def test_fp32tc_ragged_batches_chunking_and_bits(net, default_weights):
+    """Config-3 style lengths with chunking on and a small batch budget (several batches) against the fp64 oracle; and the
+    size-independent property: an utterance's x-vector is bit-identical alone, in a batch, in any order."""
+    topo, w = default_weights
+    oracle = net["oracle"]
+    rng = np.random.default_rng(78)
+    lens = [25, 26, 31, 100, 257, 999, 1024, 2300, 24, 0, 613]
+    mats = [(rng.standard_normal((T, 23)) * 3.0).astype(np.float32) for T in lens]
+    model = net["engine"].DeviceModel(w, topo, "cuda:0", precision="fp32tc")
+    ex = net["engine"].Extractor(model, 25, 1000, max_batch_rows=1500)
+    vecs = ex.extract(mats)
+    assert ex.stats["batches"] > 2
+    for T, m, v in zip(lens, mats, vecs):
+        ref = oracle.embed_utterance(m, w, topo, 25, 1000, np.float64)
+        if T < 25:
+            assert v is None and ref is None
+            continue
+        assert oracle.rel_l2(v, ref) < TOL_XVEC, T
+    lens2 = rng.integers(200, 401, size=40)
+    mats2 = [(rng.standard_normal((int(T), 23)) * 3.0).astype(np.float32) for T in lens2]
+    ex2 = net["engine"].Extractor(model, 25, 10000)
+    together = ex2.extract(mats2)
+    perm = rng.permutation(len(mats2))
+    shuffled = ex2.extract([mats2[i] for i in perm])
+    for j, i in enumerate(perm):
+        assert np.array_equal(together[i], shuffled[j])
+    for i in (0, 7, 39):
+        assert np.array_equal(ex2.extract([mats2[i]])[0], together[i])
+
+
+def test_fp32tc_other_topologies_take_what_the_kernel_covers(net):
+    """The dilated topology (kernels [5,3,3,1,1], dilations [1,2,3,1,1]) has no layer the Toom-Cook kernel takes beyond none at
+    all (layer 0 has 23 input channels, the K = 3 layers are dilated): fp32tc then IS the exact-fp32 path, bit for bit."""
+    topo = net["topology"].get("ModelWithoutDropoutTdnn")
+    w = net["synthetic"].trained_like(topo, 23, seed=5)
+    rng = np.random.default_rng(6)
+    mats = [(rng.standard_normal((T, 23)) * 3.0).astype(np.float32) for T in (40, 211)]
+    a = net["engine"].Extractor(net["engine"].DeviceModel(w, topo, "cuda:0", precision="fp32tc"), 25, 10000).extract(mats)
+    b = net["engine"].Extractor(net["engine"].DeviceModel(w, topo, "cuda:0", precision="fp32"), 25, 10000).extract(mats)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))

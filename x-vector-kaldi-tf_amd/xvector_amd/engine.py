@@ -233,12 +233,19 @@ class DeviceModel(object):
         intermediate activation stays in registers."""
         import torch
         hiplib.require_gpu()
-        assert precision in ("fp32", "bf16x3", "f16bf8")
+        assert precision in ("fp32", "fp32tc", "bf16x3", "f16bf8")
+        # "fp32tc": the exact-fp32 path with the K = 5 / K = 7 layers formed as Toom-Cook F(2, K) over time (xv_tdnn_layer_toom_f32:
+        # 6 / 8 transformed products per row PAIR instead of 10 / 14, exact fp32 products; ~3e-7 rel-L2 on the x-vector where the
+        # direct form has ~2e-7).  Every other layer, pooling and the FCs are the "fp32" kernels.  Row pairs sit on even rows:
+        # batches are laid out with chunk starts on even rows (align >= 2; 8 with the fused pooling epilogue).
+        self.toom = precision == "fp32tc"
         # "f16bf8": the hidden frame-level layers form a product as one fp16 MFMA + one block-scaled bf8 MFMA instead of
         # three bf16 MFMAs (xv_tdnn_layer_f16bf8; ~1e-5 rel-L2 on the x-vector).  Everything else (first layer, segment FCs,
         # the pair kernel, pooling) is the bf16x3 path.  A topology the f16bf8 kernels do not cover runs as plain bf16x3;
         # a batch whose activations leave the fp16 range raises ``status`` and is repeated by ``fallback()``.
         self.requested_precision = precision
+        if self.toom:
+            precision = "fp32"
         self.f16bf8 = False
         if precision == "f16bf8":
             precision = "bf16x3"
@@ -258,7 +265,7 @@ class DeviceModel(object):
         self.fused_pool = can_fuse if fused_pool is None else bool(fused_pool)
         assert not (self.fused_pool and precision == "fp32" and int(topo["layer_sizes"][-1]) % 4), "fused fp32 pooling needs Cout % 4 == 0"
         assert not (self.fused_pool and self.attention), "the fused epilogue computes plain statistics, not attention-weighted ones"
-        self.align = hiplib.POOL_BLOCK_ROWS if self.fused_pool else 1
+        self.align = hiplib.POOL_BLOCK_ROWS if self.fused_pool else (2 if self.toom else 1)
         self.torch = torch
         self.device = torch.device(device)
         self.topo = topo
@@ -345,6 +352,11 @@ class DeviceModel(object):
         self._pool_ws = None
         self._a0 = None
 
+    @property
+    def arithmetic(self):
+        """Name of the arithmetic this model runs ("f16bf8" falls back to "bf16x3" on a topology its kernels do not cover)."""
+        return "f16bf8" if self.f16bf8 else ("fp32tc" if self.toom else self.precision)
+
     def probe_vectors(self, batch):
         """x-vectors (host float32 [chunks, E]) of a packed host batch ``(x[R, in_dim], row_start, row_len, row_valid, max_len)``
         in this model's arithmetic (load-time accuracy probe)."""
@@ -381,6 +393,8 @@ class DeviceModel(object):
         layer = _Layer(K=k, dil=d, cin=w3d.shape[1], cout=w3d.shape[2])
         if self.precision == "bf16x3":
             make = lambda: hiplib.pack_weights_bf16x3(self._dev(w3d))                 # tiled hi/lo bf16
+        elif self.toom and hiplib.toom_supported(k, d, w3d.shape[1], w3d.shape[2]):
+            make = lambda: hiplib.pack_weights_toom(self._dev(w3d))                   # transformed taps [Cout, (K+1) Cin]
         else:
             make = lambda: hiplib.pack_weights(self._dev(w3d.reshape(-1, w3d.shape[2])))
         if defer_wp:
@@ -677,7 +691,7 @@ def select_model(weights, topo, device="cuda:0", embedding_index=0, precision="f
     if probe is None:
         probe = os.environ.get("XVECTOR_ACCURACY_PROBE", "1") != "0"
     model = DeviceModel(weights, topo, device, embedding_index, precision)
-    sel = dict(requested=precision, selected=model.requested_precision if model.f16bf8 else model.precision, probed=False)
+    sel = dict(requested=precision, selected=model.arithmetic, probed=False)
     model.selection = sel
     if not probe or not model.f16bf8:
         return model
