@@ -659,6 +659,16 @@ def test_header_only_index_of_an_ark_file(tmp_path):
         whole = list(kaldi_io.read_mat_ark(cpath))
         sub = list(kaldi_io.read_mat_ark(kaldi_io.FileRange(f, coff[13], coff[41])))
         assert [k for k, _ in sub] == ckeys[13:41] and all(np.array_equal(a, b) for (_, a), (_, b) in zip(sub, whole[13:41]))
+    # a short two-byte record ("CM2 ": what Kaldi writes for matrices of < 8 rows; r c elements, NO per-column headers) as the LAST
+    # record of the file: fewer than 8 c bytes are left behind its header, and it is a complete record all the same
+    import struct
+    tpath = str(tmp_path / "tail.ark")
+    with open(tpath, "wb") as f:
+        f.write(encode_cm_record("cm0", cm[0]))
+        f.write(b"short \0BCM2 " + struct.pack("<ffii", -3.0, 7.5, 2, 23) + rng.integers(0, 65536, size=(2, 23)).astype("<u2").tobytes())
+    with open(tpath, "rb") as f:
+        idx = kaldi_io.index_mat_ark_file(f)
+        assert idx is not None and idx[3] == ["cm0", "short"] and idx[1].tolist() == [cm[0].shape[0], 2] and idx[0][-1] == os.path.getsize(tpath)
     with open(path, "ab") as f:
         kaldi_io.write_mat(f, mats[3].astype(np.float64), key="double")
     with open(path, "rb") as f:

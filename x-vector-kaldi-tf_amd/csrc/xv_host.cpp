@@ -79,7 +79,9 @@ int64_t xv_ark_index_fd(int fd, int64_t pos, int64_t end, int64_t max_records, i
             // (payload checked against the range BEFORE it is added: r x c near 2^31 x 2^31 times the element size leaves int64 and
             // "after" would move backwards)
             const uint64_t room = (uint64_t)(end - pos), esz = kind == 2 ? 2 : 1;
-            if ((uint64_t)c * 8 > room || (c != 0 && (uint64_t)r > (room / esz) / (uint64_t)c)) { *stop = 1; break; }
+            // (only "CM " carries the 8-byte per-column headers; CM2 / CM3 -- what Kaldi writes for matrices of < 8 rows -- are r c
+            // elements and nothing else: a short CM2 record at the end of the range is legitimate)
+            if ((kind == 1 && (uint64_t)c * 8 > room) || (c != 0 && (uint64_t)r > (room / esz) / (uint64_t)c)) { *stop = 1; break; }
             after = pos + (int64_t)h + (int64_t)tag + 16 +
                     (kind == 1 ? (int64_t)c * 8 + (int64_t)r * (int64_t)c : (int64_t)r * (int64_t)c * (int64_t)esz);
         } else {

@@ -263,21 +263,29 @@ def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
     files at once, and what is left of a job that dies late are the complete shards of the ranks that finished.  The ranks meet
     through the file system: a part appears under its final name (``<scp>.r.<job>.part``) only when it is complete.  ``<job>`` tells
     the parts of THIS job from what a job that died before its concatenation left behind (a rank 0 that reaches the wait loop first
-    would otherwise take a stale part for rank r's result): XVECTOR_JOB_TOKEN, else the rendezvous port + the launcher's pid,
-    which all ranks of a job share."""
+    would otherwise take a stale part for rank r's result): XVECTOR_JOB_TOKEN (the package's launcher sets it), else torchrun's
+    TORCHELASTIC_RUN_ID; ranks with neither write untokenised parts (``<scp>.r.part``)."""
     import glob
     import time
-    token = os.environ.get("XVECTOR_JOB_TOKEN") or "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+    # a token every rank PROVABLY shares: the launcher's (xvector_amd.launch exports XVECTOR_JOB_TOKEN), torchrun's run id; ranks
+    # started any other way (per-rank shell wrappers, several nodes on one file system) share no parent pid, so without a token
+    # the parts carry none -- and then nothing is swept: a part without a token cannot be told from a sibling's finished one.
+    token = os.environ.get("XVECTOR_JOB_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
     token = "".join(ch if ch.isalnum() or ch in "-_" else "_" for ch in token)
-    if rank == 0:
+    part = ('.%s.part' % token) if token else '.part'
+    if rank == 0 and token:
+        started = time.time()
         for stale in glob.glob(glob.escape(scp) + '.*.part'):        # other jobs' leftovers (also ranks >= world of a larger run)
-            if not stale.endswith('.%s.part' % token):
-                os.remove(stale)
+            try:
+                if not stale.endswith(part) and os.path.getmtime(stale) < started - 1.0:
+                    os.remove(stale)
+            except OSError:
+                pass
     feat_scp, vad_scp, _ = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
     feats = kaldi_io.MatScp(feat_scp)
     vad = kaldi_io.VecScp(vad_scp) if vad_scp is not None else None
     jobclock.mark("tables opened")
-    my_ark, my_scp = '%s.%d' % (ark, rank), '%s.%d.%s.part' % (scp, rank, token)
+    my_ark, my_scp = '%s.%d' % (ark, rank), '%s.%d%s' % (scp, rank, part)
     for stale in (my_ark, my_scp):
         if os.path.exists(stale):
             os.remove(stale)
@@ -290,7 +298,7 @@ def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
     if rank != 0:
         return
     deadline = time.time() + float(os.environ.get("XVECTOR_SHARD_TIMEOUT", "3600"))
-    parts = ['%s.%d.%s.part' % (scp, r, token) for r in range(world)]
+    parts = ['%s.%d%s' % (scp, r, part) for r in range(world)]
     while not all(os.path.exists(p) for p in parts):
         if time.time() > deadline:
             raise RuntimeError("sharded extraction: still waiting for %s" % ", ".join(p for p in parts if not os.path.exists(p)))

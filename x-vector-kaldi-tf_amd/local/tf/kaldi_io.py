@@ -1384,12 +1384,18 @@ class _ScpTable(object):
 
     @property
     def entries(self):
-        if self._entries is None:
+        entries = self._entries
+        if entries is None:
             # key = up to the first whitespace, rxfile = the rest without surrounding whitespace (a line without one raises, as a
-            # malformed table should)
-            self._entries = [(k, r.rstrip()) for k, r in (ln.split(None, 1) for ln in self._lines if ln and not ln.isspace())]
+            # malformed table should -- on FIRST USE, which may be a reader thread, not at construction).  Two threads touching
+            # the table first at the same time both parse the same lines: the list is published before the lines are dropped.
+            lines = self._lines
+            if lines is None:                        # the other thread finished between the two reads
+                return self._entries
+            entries = [(k, r.rstrip()) for k, r in (ln.split(None, 1) for ln in lines if ln and not ln.isspace())]
+            self._entries = entries
             self._lines = None
-        return self._entries
+        return entries
 
     def __len__(self):
         return len(self.entries)

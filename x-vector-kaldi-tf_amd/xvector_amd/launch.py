@@ -35,6 +35,8 @@ def rank_env(rank, nproc, port, base=None):
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: what RCCL needs on this driver
+    # one token per job, the same in every rank: what XVECTOR_SHARD_OUTPUT=files names its parts by (extract_embedding.py)
+    env.setdefault("XVECTOR_JOB_TOKEN", "%s-%d" % (port, os.getpid()))
     return env
 
 

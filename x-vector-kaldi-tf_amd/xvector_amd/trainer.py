@@ -193,8 +193,12 @@ class Trainer(object):
             buf = self._splits[(role, channels)] = hiplib.SplitBuf(max(rows, 28672), channels, self.device)
         return buf
 
-    def _wants_split(self, K, channels):
-        return self.split_k1 and self.precision == "bf16x3" and K == 1 and channels % 32 == 0 and not self.prelu
+    def _wants_split(self, K, channels, other):
+        """A split-format copy of a ``channels``-wide operand for the K = 1 GEMM that reads it?  Only when that GEMM's weights are
+        tiled for the DMA-fed kernel (_pack: both of its dimensions multiples of 4; ``other`` is the one that is not ``channels``) --
+        a layer whose weights stay fp32-packed runs on the fp32 rows."""
+        return (self.split_k1 and self.precision == "bf16x3" and K == 1 and channels % 32 == 0 and other % 4 == 0 and
+                not self.prelu)
 
     def _stage_in(self, x):
         """A contiguous float16 / float32 / int32 host array -> a device tensor of the same dtype, through one of two alternating
@@ -281,7 +285,7 @@ class Trainer(object):
                               self._alpha(sc), K, d, L["rv"], r, z, rows=lay.rows)
             # the next layer's input once more in the split format when that layer is context-free (and nothing rewrites h after BN)
             nxt_split = None
-            if i + 1 < len(self.frame_scopes) and self._wants_split(self.topo["kernel_sizes"][i + 1], C) and \
+            if i + 1 < len(self.frame_scopes) and self._wants_split(self.topo["kernel_sizes"][i + 1], C, self.topo["layer_sizes"][i + 1]) and \
                     not (drop and ("frame", i) in S["seeds"]):
                 nxt_split = self._split_for("h%d" % (i & 1), lay.rows, C)
             h, mean, var = self._bn_scopes_stats(r, sc, L, T, B, train, L["rv"], True, split_out=nxt_split)
@@ -497,7 +501,7 @@ class Trainer(object):
             if S["keep"] < 1.0 and ("frame", i) in S["seeds"]:
                 hiplib.dropout(dh, S["seeds"][("frame", i)], S["keep"])
             Ki = self.topo["kernel_sizes"][i]
-            dzs = self._split_for("dz", S["R"], S["r"][i].shape[1]) if (i > 0 and self._wants_split(Ki, S["r"][i].shape[1])) else None
+            dzs = self._split_for("dz", S["R"], S["r"][i].shape[1]) if (i > 0 and self._wants_split(Ki, S["r"][i].shape[1], S["h"][i].shape[1])) else None
             dz = self._bn_backward(sc, dh, S["r"][i], S["z"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads, split_out=dzs)
             dh = self._dense_backward(sc, S["h"][i], dz, Ki, self.topo["dilations"][i], grads, i > 0, L["rv"], dz_split=dzs)
             if on_bucket is not None and i in fire_after:
