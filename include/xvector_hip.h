@@ -63,11 +63,15 @@ const char *xv_last_error(void);
  *                      16 x 16 MFMA shapes where the shape allows it, else as 0; bf16x3: as 256), 0 = built-in choice.
  *   XV_TUNE_FP32_GEMM  form of the exact-fp32 GEMM where both exist (bit-identical results): 1 = register-staged (tdnn_gemm_kernel),
  *                      2 = fed by LDS-DMA (tdnn_gemm_dma_kernel), 0 = built-in choice (the latter unless XV_FP32_DMA=0).
+ *   XV_TUNE_XCD_COLUMNS  the 256 x 256-tile f16bf8 GEMM on two column tiles (Cout = 512): 1 = XCDs 0-3 work on column tile 0 and
+ *                      XCDs 4-7 on tile 1 (each L2 holds one tile's weights, operand rows are fetched by two XCDs), 0 = every XCD
+ *                      works on both column tiles of a contiguous run of row tiles (built-in).
  *   XV_TUNE_FIRST_TILES  16-frame tiles per wave of the first-layer kernel (xv_tdnn_first_*): 1..4096, 0 = spread the rows evenly
  *                      over one workgroup per CU (tests use small values to walk through several groups of tiles on small inputs). */
 #define XV_TUNE_TILE_ROWS 1
 #define XV_TUNE_FIRST_TILES 2
 #define XV_TUNE_FP32_GEMM 3
+#define XV_TUNE_XCD_COLUMNS 4
 int xv_set_tuning(int key, int value);
 
 /* One-off weight re-layout.  TF stores a conv kernel as w[K, Cin, Cout] == row-major [K*Cin, Cout]

@@ -38,3 +38,22 @@ def default_weights():
     from xvector_amd import synthetic, topology
     topo = topology.get("ModelWithoutDropout")
     return topo, synthetic.trained_like(topo, 23, seed=2024)
+
+
+# Collection order (the driver runs `pytest -m gpu -x`): the kernel-by-kernel and whole-network parity tests against the oracle
+# come FIRST, files that start subprocesses (benches, rehearsals over several ranks, CLIs) LAST -- a hiccup in a bench contract or a
+# rendezvous must not leave every parity row of SURVEY section 8 "untested".  Within a class the order of collection is kept.
+_FIRST = ("test_gpu_kernels.py", "test_gpu_toom.py", "test_gpu_f16bf8.py", "test_gpu_forward.py", "test_gpu_fuzz.py", "test_gpu_hostile.py",
+          "test_gpu_frontend.py", "test_gpu_training.py", "test_gpu_config3.py", "test_gpu_trained_checkpoint.py")
+_LAST = ("test_gpu_two_ranks.py", "test_gpu_eight_ranks.py", "test_gpu_bench_contract.py")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        if name in _FIRST:
+            return _FIRST.index(name)
+        if name in _LAST:
+            return 1000 + _LAST.index(name)
+        return 500
+    items.sort(key=rank)                      # (stable: ties keep their collection order)

@@ -612,17 +612,3 @@ def test_bf16x3_step_with_and_without_split_k1_inputs(env, monkeypatch):
     assert res[0][0] == res[1][0]
     assert all(np.array_equal(res[0][1][n], res[1][1][n]) for n in res[0][1])
 
-
-def test_bf16x3_step_with_a_width_the_tiled_weights_do_not_take(env):
-    """A K = 1 layer whose output width is not a multiple of 4 keeps fp32-packed weights (Trainer._pack) -- it must then be fed
-    the fp32 rows, not a split copy, although its input width (a multiple of 32) alone would ask for one."""
-    topo, w, rng = _setup(env, "ModelWithoutDropout", widths=(64, 64, 64, 50, 96), seed=6)
-    x = (rng.standard_normal((6, 120, 23)) * 3).astype(np.float32)
-    lab = rng.integers(0, 10, 6)
-    tr = env["trainer"].Trainer(w, topo, precision="bf16x3")
-    loss, acc, grads = tr.gradients(x, lab)
-    rl, ra, _, _, rg = env["ref"].train_step(w, {"t": 0, "m": {}, "v": {}}, topo, x, lab, 1e-3)
-    assert abs(loss - rl) < 1e-4 * max(1.0, abs(rl))
-    summed = lambda n: n.endswith("/b:0") or n.endswith("/beta:0")
-    err = {n: _rel(grads[n].cpu().numpy(), rg[n]) for n in rg}
-    assert max(e for n, e in err.items() if not summed(n)) < 5e-3 and max(e for n, e in err.items() if summed(n)) < 2e-2

@@ -93,6 +93,7 @@ struct Gemm8Params {
     float *blk;           // POOL: per-8-row-block (mean, M2) planes
     int *status;          // bit 0 is set when a split8 output had to be clamped (may be NULL)
     int n_mt, n_nt, n_chunks;
+    int colmap;           // wide16, two column tiles: 1 = XCDs 0-3 work on column tile 0, XCDs 4-7 on tile 1 (XV_TUNE_XCD_COLUMNS)
 };
 
 #define XV_GLDS16_OFF(gptr, lptr, imm)                                                                          \
@@ -1012,7 +1013,17 @@ __global__ __launch_bounds__(512, 2) void tdnn_gemm_f16bf8_wide16_kernel(const G
     const int xcd = bid & 7, idx = bid >> 3;
     const int q_ = nwg >> 3, r_ = nwg & 7;
     const int wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx;
-    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    if (p.colmap) {
+        // XCD-aware column placement (two column tiles): an XCD's L2 then holds ONE column tile's weights (3.7 MB of the K = 7
+        // layer's 7.3 MB) and every row tile's operand rows are fetched by two XCDs.  Slot (column tile, quarter x4 of the row tiles)
+        // = XCD 4 nt + x4; the <= 6 blocks the round-robin deals to other XCDs than the slots need take the slots' last tiles.
+        const int q4 = p.n_mt >> 2, r4 = p.n_mt & 3;
+        int x4 = xcd & 3;
+        nt = xcd >> 2;
+        if (idx >= q4) { nt = xcd / r4; x4 = xcd - nt * r4; }
+        mt = x4 * q4 + (x4 < r4 ? x4 : r4) + idx;
+    }
     const long m0 = (long)mt * W_BM;
     const int n0 = nt * W_BN;
 
@@ -1332,6 +1343,7 @@ size_t g8_kernel_lds(const Gemm8Kernel &e) { return e.wm >= 8 ? W_LDS_BYTES : g8
 
 std::atomic<int> g_tile_rows8{0};
 std::atomic<int> g_wide16{1};          // XV_F16BF8_S16=0: the built-in choice keeps the 32 x 32 form of the 256 x 256 tile
+std::atomic<int> g_xcd_columns{0};     // XV_TUNE_XCD_COLUMNS
 
 int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
 {
@@ -1340,6 +1352,8 @@ int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
     static const bool env_once = [] {
         const char *e = std::getenv("XV_F16BF8_S16");
         if (e && e[0] == '0') g_wide16.store(0, std::memory_order_relaxed);
+        const char *x = std::getenv("XV_XCD_COLUMNS");                 // (counter runs: the knob of XV_TUNE_XCD_COLUMNS from outside)
+        if (x && (x[0] == '0' || x[0] == '1')) g_xcd_columns.store(x[0] - '0', std::memory_order_relaxed);
         return true;
     }();
     (void)env_once;
@@ -1399,6 +1413,7 @@ int launch_gemm8(const Gemm8Params &p0, hipStream_t st)
         }
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
+    p.colmap = (wm == 16 && p.n_nt == 2 && p.n_mt >= 8 && g_xcd_columns.load(std::memory_order_relaxed)) ? 1 : 0;
     hipLaunchKernelGGL(k->fn, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(wm >= 8 ? 512 : wm * 128), g8_kernel_lds(*k), st, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_f16bf8_kernel launch");
@@ -1483,6 +1498,7 @@ int check_launch(const char *what)
 extern "C" {
 
 void xv_internal_gemm8_tile_rows(int value) { g_tile_rows8.store(value, std::memory_order_relaxed); }
+void xv_internal_gemm8_xcd_columns(int value) { g_xcd_columns.store(value, std::memory_order_relaxed); }
 
 size_t xv_packed_weights_f16bf8_bytes(int K, int cin, int cout)
 {

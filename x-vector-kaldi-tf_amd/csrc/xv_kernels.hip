@@ -1849,6 +1849,7 @@ int check_launch(const char *what)
 extern "C" {
 
 void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
+void xv_internal_gemm8_xcd_columns(int value);    // xv_gemm8.hip
 void xv_internal_first_tiles(int tiles);          // xv_first.hip
 
 int xv_version(void) { return 16; }
@@ -1869,6 +1870,10 @@ int xv_set_tuning(int key, int value)
     case XV_TUNE_FP32_GEMM:
         if (value < 0 || value > 2) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: fp32 GEMM form must be 0, 1 or 2");
         g_fp32_form.store(value, std::memory_order_relaxed);
+        return 0;
+    case XV_TUNE_XCD_COLUMNS:
+        if (value < 0 || value > 1) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: XCD column placement must be 0 or 1");
+        xv_internal_gemm8_xcd_columns(value);
         return 0;
     default:
         return fail(XV_ERR_BAD_ARG, "xv_set_tuning: unknown key");

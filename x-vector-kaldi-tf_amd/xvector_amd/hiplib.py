@@ -40,6 +40,7 @@ SPLIT_PAD_BEFORE, SPLIT_PAD_AFTER = 8, 264
 TUNE_TILE_ROWS = 1
 TUNE_FIRST_TILES = 2
 TUNE_FP32_GEMM = 3
+TUNE_XCD_COLUMNS = 4
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU = 0, 1, 2, 3
 
