@@ -52,7 +52,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 16). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 17). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -98,6 +98,20 @@ int xv_tdnn_layer_f32(const float *x, int64_t R, int cin, int ldx, const float *
                       const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha,
                       int K, int dilation, int cout, const uint8_t *row_valid, float *y, int ldy,
                       float *y_preact, void *stream);
+
+/* The FIRST frame-level layer (models.py:54-67 on the feature rows) as a K = 1 GEMM over OVERLAPPING rows.  The packed feature rows
+ * x[R, ldx] lie back to back (ldx = the feature dimension padded to a multiple of 4, padding columns zero), so the K-tap window
+ * of frame r IS the contiguous span of K * ldx floats that starts at x + (r - (K-1)/2) * ldx: no im2col, no taps -- the exact-fp32
+ * GEMM kernels read "row r" from there (DMA-fed: rows before the buffer or past its end read as zeros through the buffer
+ * descriptor's range check).  wp = xv_pack_weights_rows_f32(w[K,Cin,Cout]): [Cout][roundup32(K * ldx)] floats with w[k][c][o] at
+ * column k * ldx + c and zeros elsewhere (xv_packed_weights_rows_f32_floats; 0 = unsupported: K odd, Cin <= ldx, ldx % 4 == 0).
+ * Same products as xv_tdnn_layer_f32, summed in another order (tap-major): not bit-identical to it; used by the "fp32tc" path.
+ * x, y and the per-column parameters 16-byte aligned; gap rows must be zero as everywhere (dilation 1 only). */
+size_t xv_packed_weights_rows_f32_floats(int K, int cin, int ldx, int cout);
+int xv_pack_weights_rows_f32(const float *w, int K, int cin, int ldx, int cout, float *wp, void *stream);
+int xv_tdnn_layer_rows_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
+                           const float *bn_shift, int act_kind, const float *act_alpha, int K, int cout, const uint8_t *row_valid,
+                           float *y, int ldy, void *stream);
 
 /* ---- "fp32tc": the wide-context layers with fewer multiplications (Toom-Cook F(2, K) over time; csrc/xv_toom.hip) -------------
  * Same layer as xv_tdnn_layer_f32 (models.py:54-67) for K in {5, 7}, dilation 1 (the default topology's layers 1 and 2, models.py:28

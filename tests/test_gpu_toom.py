@@ -106,6 +106,48 @@ def test_toom_unsupported_shapes_are_refused(env):
         hiplib.pack_weights_toom(w)
 
 
+@pytest.mark.parametrize("feat,K,cout,act", [(23, 5, 512, "relu"), (30, 5, 64, "prelu"), (40, 3, 200, "lrelu"), (13, 7, 32, "none")])
+def test_first_layer_rows_form_matches_oracle(env, feat, K, cout, act):
+    """xv_tdnn_layer_rows_f32: layer 0 as a K = 1 GEMM over the overlapping windows of the packed feature rows, against the fp64
+    oracle of the K-tap contraction -- on a small batch (64-row tiles, register-staged kernel) and on a 26 k-row batch (DMA-fed
+    kernel, rows before the buffer and past its end through the descriptor's range check); the chunks common to both must come
+    out bit-identical, and chunks of 1-3 frames at both ends of the batch exercise the buffer bounds."""
+    torch, hiplib, engine, dev, oracle = env["torch"], env["hiplib"], env["engine"], env["dev"], env["oracle"]
+    rng = np.random.default_rng(feat * 100 + K)
+    ldx = (feat + 3) // 4 * 4
+    w = (rng.standard_normal((K, feat, cout)) / np.sqrt(K * feat)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    bn = _rand_bn(rng, cout)
+    alpha = np.array([0.2], np.float32) if act == "lrelu" else (0.1 + 0.05 * rng.standard_normal(cout)).astype(np.float32) if act == "prelu" else None
+    wpad = np.zeros((K, ldx, cout), np.float32)
+    wpad[:, :feat] = w
+    wp = hiplib.pack_weights_rows(torch.from_numpy(wpad).to(dev), ldx)
+    scale, shift = hiplib.fold_bn(*(torch.from_numpy(a).to(dev) for a in bn), 1e-3)
+    al = None if alpha is None else torch.from_numpy(alpha).to(dev)
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+
+    def run(mats):
+        layout = engine.BatchLayout([m.shape[0] for m in mats], (K - 1) // 2, 8)
+        host = np.zeros((layout.rows, ldx), np.float32)
+        layout.pack(mats, host)
+        x = torch.from_numpy(host).to(dev)
+        rv = torch.from_numpy(layout.row_valid()).to(dev)
+        y = torch.full((layout.rows, cout), float("nan"), dtype=torch.float32, device=dev)
+        hiplib.tdnn_layer(x, wp, torch.from_numpy(b).to(dev), scale, shift, code, al, K, 1, rv, y)
+        torch.cuda.synchronize()
+        yh = y.cpu().numpy()
+        assert (yh[~layout.row_valid().astype(bool)] == 0).all()
+        return [yh[s:s + n] for s, n in zip(layout.row_start, layout.row_len)]
+    small = [(rng.standard_normal((t, feat)) * 3).astype(np.float32) for t in (2, 130, 25, 257, 1)]
+    big = small[:4] + [(rng.standard_normal((300, feat)) * 3).astype(np.float32) for _ in range(85)] + [small[4]]
+    outs_s, outs_b = run(small), run(big)
+    for m, a_, c_ in zip(small, outs_s, outs_b[:4] + outs_b[-1:]):
+        assert oracle.rel_l2(a_, oracle.tdnn_layer(m, w, b, bn, act, alpha, 1, np.float64)) < TOL_GEMM
+        assert np.array_equal(a_, c_)
+    for i in (4, 40, 88):
+        assert oracle.rel_l2(outs_b[i], oracle.tdnn_layer(big[i], w, b, bn, act, alpha, 1, np.float64)) < TOL_GEMM
+
+
 # ---- the whole network in the "fp32tc" arithmetic (engine.DeviceModel(precision="fp32tc")) -----------------------------------
 TOL_XVEC = 2e-6           # x-vector, relative L2 against the fp64 oracle (measured ~3e-7; the exact-fp32 kernels ~2e-7)
 
@@ -131,6 +173,7 @@ def test_fp32tc_forward_matches_golden(net, golden):
         model = net["engine"].DeviceModel(w, topo, "cuda:0", embedding_index=emb_idx, precision="fp32tc")
         assert model.toom and model.arithmetic == "fp32tc" and model.align == 8
         assert [isinstance(L["wp"], net["hiplib"].PackedToom) for L in model.layers] == [False, True, True, False, False]
+        assert isinstance(model.layers[0]["wp"], net["hiplib"].PackedRows)
         vecs = net["engine"].Extractor(model, 1, -1).extract(mats)
         for T, v in zip(Ts, vecs):
             ref32 = net["oracle"].chunk_average(g["default_T%d_e%d" % (T, emb_idx)].astype(np.float32)[None, :], [T], np.float32)

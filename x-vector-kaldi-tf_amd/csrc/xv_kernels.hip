@@ -68,6 +68,8 @@ struct GemmParams {
     float *blk;         // POOL epilogue (no y / ypre): per-8-row-block (mean, M2) planes [ceil(R/8)][2][cout], as Gemm3Params::blk
     int n_mt, n_nt;
     int vec_out;        // outputs take 16-byte stores: cout % 4 == 0, ldy % 4 == 0, y / ypre / per-column parameters 16-byte aligned
+    int lead;           // "rows" form (xv_tdnn_layer_rows_f32): K = 1 over rows that OVERLAP -- virtual row r = the cin floats from
+                        // x + (r - lead) * ldx on, cin > ldx; reads are bounded by the END OF THE BUFFER (R * ldx floats), not by the row
 };
 
 constexpr size_t GEMM_LDS_BYTES = (size_t)(2 * A_ROWS * LDS_LD + 2 * BN * LDS_LD) * sizeof(float) + BM;
@@ -255,10 +257,11 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
     const int n0 = nt * BN;
 
     const int span = (p.K - 1) * p.dil;
-    const int left = span >> 1;
+    const int left = (span >> 1) + p.lead;
     const int rowsA = BMT + span;
     const int n_chunks = (p.cin + BK - 1) / BK;
     const int n_stages = n_chunks * p.K;
+    const long flat_end = p.R * p.ldx;                 // (rows form: what the DMA-fed kernel's buffer descriptor checks)
 
     if (tid < BMT) {
         const long gr = m0 + tid;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
                 const long gr = m0 - left + lr;
                 const int c = c0 + qq * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (lr < rowsA && gr >= 0 && gr < p.R && c < p.cin)
+                if (lr < rowsA && gr >= 0 && c < p.cin && (p.lead ? gr * p.ldx + c + 4 <= flat_end : gr < p.R))
                     v = *reinterpret_cast<const f32x4 *>(p.x + (size_t)gr * p.ldx + c);
                 areg[j] = v;
             } else {
@@ -1301,7 +1304,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_dma_kernel(const GemmParams p
     const int n0 = nt * BN;
 
     const int span = (KT - 1) * p.dil;
-    const int left = span >> 1;
+    const int left = (span >> 1) + p.lead;
     const int n_chunks = p.cin / BK;
     const int n_stages = n_chunks * KT;
 
@@ -1438,7 +1441,7 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
     if (p.R <= 0 || p.cout <= 0) return 0;
     if (p.cin <= 0 || p.K <= 0 || (p.K & 1) == 0 || p.dil <= 0) return fail(XV_ERR_BAD_ARG, "tdnn: K must be odd, dims > 0");
     if ((p.K - 1) * p.dil > MAX_SPAN) return fail(XV_ERR_UNSUPPORTED, "tdnn: (K-1)*dilation > 8 unsupported");
-    if (p.ldx < p.cin || p.ldy < p.cout) return fail(XV_ERR_BAD_ARG, "tdnn: leading dimension too small");
+    if ((p.lead == 0 && p.ldx < p.cin) || p.ldy < p.cout) return fail(XV_ERR_BAD_ARG, "tdnn: leading dimension too small");
     if ((p.act == XV_ACT_LRELU || p.act == XV_ACT_PRELU) && !p.alpha) return fail(XV_ERR_BAD_ARG, "tdnn: act_alpha is NULL");
     p.kred = p.K * p.cin;
     p.n_nt = (p.cout + BN - 1) / BN;
@@ -1447,6 +1450,7 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
     const int bmt = small ? 64 : BM;
     p.n_mt = (int)((p.R + bmt - 1) / bmt);
     const bool vec = (p.cin % 4 == 0) && (p.ldx % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) && (((uintptr_t)p.wp) % 16 == 0);
+    if (p.lead && (!vec || p.K != 1 || p.ypre)) return fail(XV_ERR_UNSUPPORTED, "tdnn_rows: needs 16-byte aligned rows of a multiple of 4 floats");
     const uintptr_t out_bits = (uintptr_t)p.y | (uintptr_t)p.ypre | (uintptr_t)p.bias | (uintptr_t)p.scale | (uintptr_t)p.shift |
                                (p.act == XV_ACT_PRELU ? (uintptr_t)p.alpha : 0);
     p.vec_out = (p.cout % 4 == 0) && (p.ldy % 4 == 0) && (out_bits % 16 == 0) && (p.blk || std::getenv("XV_FP32_SCALAR_EPILOGUE") == nullptr);
@@ -1706,6 +1710,16 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, int kred, int c
     wp[i] = w[(size_t)k * cout + n];
 }
 
+// w[K, cin, cout] -> wp[cout][kpad] for the rows form: column k * ldx + c holds w[k][c][o] (c < cin), every other column zero
+__global__ void pack_weights_rows_kernel(const float *__restrict__ w, int K, int cin, int ldx, int cout, int kpad, float *__restrict__ wp)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)kpad * cout) return;
+    const int o = (int)(i / kpad), col = (int)(i - (size_t)o * kpad);
+    const int k = col / ldx, c = col - k * ldx;
+    wp[i] = (k < K && c < cin) ? w[((size_t)k * cin + c) * cout + o] : 0.f;
+}
+
 // w[K, cin, cout] fp32 -> tiled bf16x3 weights: tile (nt, chunk, tap) = 16 KB [hi 128x64B][lo 128x64B], slots swizzled
 __global__ void pack_weights_bf16x3_kernel(const float *__restrict__ w, int K, int cin, int cout, int n_chunks,
                                            uint8_t *__restrict__ wt, size_t total)
@@ -1852,7 +1866,7 @@ void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
 void xv_internal_gemm8_xcd_columns(int value);    // xv_gemm8.hip
 void xv_internal_first_tiles(int tiles);          // xv_first.hip
 
-int xv_version(void) { return 16; }
+int xv_version(void) { return 17; }
 
 int xv_set_tuning(int key, int value)
 {
@@ -1909,6 +1923,36 @@ int xv_tdnn_layer_f32(const float *x, int64_t R, int cin, int ldx, const float *
     p.x = x; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wp = wp;
     p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
     p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid; p.y = y; p.ldy = ldy; p.ypre = y_preact;
+    return launch_gemm(p, (hipStream_t)stream);
+}
+
+size_t xv_packed_weights_rows_f32_floats(int K, int cin, int ldx, int cout)
+{
+    if (K <= 0 || (K & 1) == 0 || cin <= 0 || ldx < cin || (ldx & 3) || cout <= 0) return 0;
+    return (size_t)cout * (((size_t)K * ldx + BK - 1) / BK * BK);
+}
+
+int xv_pack_weights_rows_f32(const float *w, int K, int cin, int ldx, int cout, float *wp, void *stream)
+{
+    const size_t n = xv_packed_weights_rows_f32_floats(K, cin, ldx, cout);
+    if (!w || !wp || n == 0) return fail(XV_ERR_BAD_ARG, "pack_weights_rows: K odd, cin <= ldx, ldx % 4 == 0");
+    hipLaunchKernelGGL(pack_weights_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, K, cin, ldx, cout,
+                       (int)(n / cout), wp);
+    return check_launch("pack_weights_rows_kernel");
+}
+
+int xv_tdnn_layer_rows_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
+                           const float *bn_shift, int act_kind, const float *act_alpha, int K, int cout, const uint8_t *row_valid,
+                           float *y, int ldy, void *stream)
+{
+    if (!x || !wp || !y) return fail(XV_ERR_BAD_ARG, "tdnn_rows: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_rows: unknown act_kind");
+    const size_t n = xv_packed_weights_rows_f32_floats(K, cin, ldx, cout);
+    if (n == 0) return fail(XV_ERR_BAD_ARG, "tdnn_rows: K odd, cin <= ldx, ldx % 4 == 0");
+    GemmParams p{};
+    p.x = x; p.R = (long)R; p.cin = (int)(n / cout); p.ldx = ldx; p.wp = wp;
+    p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
+    p.K = 1; p.dil = 1; p.cout = cout; p.valid = row_valid; p.y = y; p.ldy = ldy; p.lead = (K - 1) / 2;
     return launch_gemm(p, (hipStream_t)stream);
 }
 

@@ -393,6 +393,10 @@ class DeviceModel(object):
         layer = _Layer(K=k, dil=d, cin=w3d.shape[1], cout=w3d.shape[2])
         if self.precision == "bf16x3":
             make = lambda: hiplib.pack_weights_bf16x3(self._dev(w3d))                 # tiled hi/lo bf16
+        elif self.toom and scope == "frame_level_info_layer-0" and d == 1 and w3d.shape[1] == self.in_dim and \
+                w3d.shape[2] % 4 == 0 and os.environ.get("XVECTOR_ROWS_FIRST", "1") != "0":
+            # layer 0 as a K = 1 GEMM over the overlapping windows of the packed feature rows (xv_tdnn_layer_rows_f32)
+            make = lambda: hiplib.pack_weights_rows(self._dev(w3d), self.in_dim)
         elif self.toom and hiplib.toom_supported(k, d, w3d.shape[1], w3d.shape[2]):
             make = lambda: hiplib.pack_weights_toom(self._dev(w3d))                   # transformed taps [Cout, (K+1) Cin]
         else:

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -18,6 +18,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_pack_weights_bf16x3_many", "xv_split_row_bytes", "xv_split_encode_f32",
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32", "xv_tdnn_layer_pool_f32",
+           "xv_packed_weights_rows_f32_floats", "xv_pack_weights_rows_f32", "xv_tdnn_layer_rows_f32",
            "xv_toom_supported", "xv_packed_weights_toom_f32_floats", "xv_pack_weights_toom_f32", "xv_tdnn_layer_toom_f32",
            "xv_packed_pair_bf16x3_bytes", "xv_pack_pair_bf16x3", "xv_tdnn_pair_pool_bf16x3",
            "xv_packed_first_bf16x3_bytes", "xv_pack_first_bf16x3", "xv_tdnn_first_bf16x3",
@@ -74,6 +75,12 @@ def load():
     lib.xv_fold_bn_f32.argtypes = [vp, vp, vp, vp, cf, ci, vp, vp, vp]
     lib.xv_tdnn_layer_f32.restype = ci
     lib.xv_tdnn_layer_f32.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp, vp]
+    lib.xv_packed_weights_rows_f32_floats.restype = sz
+    lib.xv_packed_weights_rows_f32_floats.argtypes = [ci, ci, ci, ci]
+    lib.xv_pack_weights_rows_f32.restype = ci
+    lib.xv_pack_weights_rows_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+    lib.xv_tdnn_layer_rows_f32.restype = ci
+    lib.xv_tdnn_layer_rows_f32.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, ci, vp]
     lib.xv_toom_supported.restype = ci
     lib.xv_toom_supported.argtypes = [ci, ci, ci, ci]
     lib.xv_packed_weights_toom_f32_floats.restype = sz
@@ -283,6 +290,38 @@ def pack_weights(w2d):
     wp = torch.empty((cout, kred), dtype=torch.float32, device=w2d.device)
     _check(lib.xv_pack_weights_f32(_ptr(w2d), kred, cout, _ptr(wp), _stream()), "xv_pack_weights_f32")
     return wp
+
+
+class PackedRows(object):
+    """Weights of a first layer for the "rows" form (xv_pack_weights_rows_f32): wp[Cout, roundup32(K ldx)] for feature rows of ldx floats."""
+
+    def __init__(self, wp, K, cin, ldx, cout):
+        self.wp, self.K, self.cin, self.ldx, self.cout = wp, K, cin, ldx, cout
+
+
+def pack_weights_rows(w3d, ldx):
+    """w3d: TF layout [K, Cin, Cout] (cuda float32), ldx: floats per packed feature row (>= Cin, a multiple of 4) -> PackedRows."""
+    import torch
+    lib = require_gpu()
+    _f32(w3d, "w")
+    K, cin, cout = w3d.shape
+    n = int(lib.xv_packed_weights_rows_f32_floats(K, cin, int(ldx), cout))
+    assert n > 0, "rows form unsupported for K=%d Cin=%d ldx=%d" % (K, cin, ldx)
+    wp = torch.empty((cout, n // cout), dtype=torch.float32, device=w3d.device)
+    _check(lib.xv_pack_weights_rows_f32(_ptr(w3d), K, cin, int(ldx), cout, _ptr(wp), _stream()), "xv_pack_weights_rows_f32")
+    return PackedRows(wp, K, cin, int(ldx), cout)
+
+
+def tdnn_layer_rows(x, w, bias, scale, shift, act, alpha, row_valid, y, rows=None):
+    """xv_tdnn_layer_rows_f32: x[R, ldx] contiguous feature rows -> y[R, Cout] fp32 rows, w a PackedRows."""
+    lib = require_gpu()
+    _rows2d(x, "x")
+    R = x.shape[0] if rows is None else int(rows)
+    assert x.shape[1] == w.ldx and x.stride(0) == w.ldx and y.shape[1] == w.cout and y.shape[0] >= R
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_layer_rows_f32(_ptr(x), R, w.cin, w.ldx, _ptr(w.wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act), _ptr(alpha),
+                                      w.K, w.cout, _ptr(row_valid), _ptr(y), y.stride(0), _stream()), "xv_tdnn_layer_rows_f32")
 
 
 class PackedToom(object):
@@ -718,6 +757,9 @@ def tdnn_layer(x, wp, bias, scale, shift, act, alpha, K, dilation, row_valid, y,
     if isinstance(wp, PackedToom):
         assert wp.K == K and dilation == 1 and y_preact is None
         return tdnn_layer_toom(x, wp, bias, scale, shift, act, alpha, row_valid, y, rows)
+    if isinstance(wp, PackedRows):
+        assert wp.K == K and dilation == 1 and y_preact is None
+        return tdnn_layer_rows(x, wp, bias, scale, shift, act, alpha, row_valid, y, rows)
     _rows2d(x, "x")
     _f32(wp, "wp")
     R = x.shape[0] if rows is None else int(rows)
