@@ -192,6 +192,30 @@ __device__ __forceinline__ f32x4 xform(const f32x4 (&d)[KT + 1], float m1)
     }
 }
 
+// The two products of a +- pair of points read the same rows and share the even / odd parts of their transforms: both V at once
+// (va for product j, vb for product j + 1), 4 / 6 packed operations per channel pair instead of 6 / 10.
+template <int KT, int j>
+__device__ __forceinline__ void xform_pair(const f32x4 (&d)[KT + 1], float m1, f32x4 &va, f32x4 &vb)
+{
+    if constexpr (KT == 5 && j == 1) {
+        const f32x4 e = fma4(-4.f, d[2], d[4]), o = fma4(-4.f, d[1], d[3]);
+        va = e + o; vb = sub4(e, o, m1);
+    } else if constexpr (KT == 5 && j == 3) {
+        const f32x4 e = sub4(d[4], d[2], m1), o = sub4(d[3], d[1], m1);
+        va = fma4(2.f, o, e); vb = fma4(-2.f, o, e);
+    } else if constexpr (KT == 7 && j == 1) {
+        const f32x4 e = fma4(-4.25f, d[4], d[2] + d[6]), o = fma4(-4.25f, d[3], d[1] + d[5]);
+        va = e + o; vb = sub4(e, o, m1);
+    } else if constexpr (KT == 7 && j == 3) {
+        const f32x4 e = fma4(4.f, d[6], fma4(-5.f, d[4], d[2])), o = fma4(4.f, d[5], fma4(-5.f, d[3], d[1]));
+        va = fma4(2.f, o, e); vb = fma4(-2.f, o, e);
+    } else {
+        static_assert(KT == 7 && j == 5, "pairs: (1, 2), (3, 4), (5, 6)");
+        const f32x4 e = fma4(4.f, d[2], fma4(-5.f, d[4], d[6])), o = fma4(4.f, d[1], fma4(-5.f, d[3], d[5]));
+        va = fma4(2.f, e, o); vb = fma4(-2.f, e, o);
+    }
+}
+
 template <int KT>
 __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams p)
 {
@@ -276,6 +300,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     float m1 = -1.f;                                         // (see sub4)
     asm volatile("" : "+s"(m1));
     f32x4 raw[J];                                            // the raw fragments of one k group (only the rows the product reads)
+    f32x4 vb[4];                                             // V of the second product of a +- pair, four k groups
     struct Bf { f32x4 b0, b1; };
     Bf bf[2];
     auto load_raw = [&](auto JJ, auto CP, int kk) {          // product j, halo buffer CP, k group kk
@@ -339,44 +364,56 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
             f32x16 &t1 = q == 0 ? o01 : q == 1 ? o11 : (q & 1) ? tB1 : tA1;
             f32x16 &u0 = (q & 1) ? tA0 : tB0, &u1 = (q & 1) ? tA1 : tB1;       // the previous +- stage's products (q >= 3)
             using JP = std::integral_constant<int, TC::ORDER[q >= 3 ? q - 1 : 2]>;
+            // stages 2, 3 / 4, 5 / 6, 7 hold the two products of a +- pair: the first forms both V (the second's into vb), the second
+            // reads no raw fragments at all
+            constexpr bool pair_a = q >= 2 && !(q & 1), pair_b = q >= 2 && (q & 1);
+            auto form = [&](int kk) -> f32x4 {
+                if constexpr (pair_b) return vb[kk];
+                else if constexpr (pair_a) {
+                    f32x4 a;
+                    xform_pair<KT, j>(raw, m1, a, vb[kk]);
+                    return a;
+                } else return xform<KT, j>(raw, m1);
+            };
             // ---- step 0
-            f32x4 v = xform<KT, j>(raw, m1);
-            load_raw(JJ{}, CP, 1);
+            f32x4 v = form(0);
+            if constexpr (!pair_b) load_raw(JJ{}, CP, 1);
             load_b(bf[1], BP{}, 1);
             mma8(v, bf[0], t0, t1, !direct);
             order_step();
             end_step(t1);
             fence();
             // ---- step 1 (+ the folds into column block 0)
-            v = xform<KT, j>(raw, m1);
+            v = form(1);
             if constexpr (q == 0) { fma_to(JLAST{}, o10, tB0); anchor(o10); }
             if constexpr (q == 1) { add_to(o00, tB0); anchor(o00); }
             if constexpr (q >= 3) { add_to(o00, u0); fma_to(JP{}, o10, u0); anchor(o00); anchor(o10); }
-            load_raw(JJ{}, CP, 2);
+            if constexpr (!pair_b) load_raw(JJ{}, CP, 2);
             load_b(bf[0], BP{}, 2);
             mma8(v, bf[1], t0, t1, false);
             order_step();
             end_step(t1);
             fence();
             // ---- step 2 (+ the folds into column block 1)
-            v = xform<KT, j>(raw, m1);
+            v = form(2);
             if constexpr (q == 0) { fma_to(JLAST{}, o11, tB1); anchor(o11); }
             if constexpr (q == 1) { add_to(o01, tB1); anchor(o01); }
             if constexpr (q >= 3) { add_to(o01, u1); fma_to(JP{}, o11, u1); anchor(o01); anchor(o11); }
-            load_raw(JJ{}, CP, 3);
+            if constexpr (!pair_b) load_raw(JJ{}, CP, 3);
             load_b(bf[1], BP{}, 3);
             mma8(v, bf[0], t0, t1, false);
             order_step();
             end_step(t1);
             fence();
             // ---- step 3: every fragment of stage s is in registers, stage s + 1 has landed
-            v = xform<KT, j>(raw, m1);
+            v = form(3);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             dma_b(s + 2, q & 1);
             if constexpr (q < 5) dma_a_slot(c + 1, q);
             fence();
-            if constexpr (q + 1 < J) load_raw(std::integral_constant<int, TC::ORDER[(q + 1) % J]>{}, CP, 0);
+            if constexpr (pair_a) { /* the next stage's V are in vb */ }
+            else if constexpr (q + 1 < J) load_raw(std::integral_constant<int, TC::ORDER[(q + 1) % J]>{}, CP, 0);
             else load_raw(std::integral_constant<int, TC::ORDER[0]>{}, std::integral_constant<int, 1 - cp>{}, 0);
             load_b(bf[0], std::integral_constant<int, (q + 1) & 1>{}, 0);
             mma8(v, bf[1], t0, t1, false);
