@@ -933,10 +933,16 @@ def main():
             tr = {}
             for prec in ("fp32", "bf16x3"):
                 tr[prec] = _train_run(args, 0, 1, dev, tp.get("ModelWithoutDropout"), feat, prec, 30, 3)
-            out["train_step"] = dict(tr["bf16x3"], fp32=tr["fp32"],
-                                     product_default="fp32: Model.train_one_iteration (local/tf/models.py, the twin of the reference's "
-                                                     "models.py:216-305) and train_dnn.py run the exact-fp32 step (the `fp32` entry here) unless "
-                                                     "XVECTOR_TRAIN_PRECISION=bf16x3 is set; the top-level figures of this object are the bf16x3 step",
+            from xvector_amd import synthetic as _syn, trainer as _trn
+            _topo = tp.get("ModelWithoutDropoutAMSoftmax")
+            _x, _lab = next(_syn.speaker_minibatches(1, feat, 64, 64, args.tmin, args.tmax, seed=77))
+            _, verdict = _trn.select_trainer(_syn.trained_like(_topo, feat, num_classes=64, seed=1), _topo, dev, None, _x, _lab)
+            out["train_step"] = dict(tr["bf16x3"], fp32=tr["fp32"], product_default_probe=verdict,
+                                     product_default="auto: Model.train_one_iteration (local/tf/models.py, the twin of the reference's "
+                                                     "models.py:216-305) and train_dnn.py compute the FIRST minibatch's gradients in both arithmetics "
+                                                     "and run the bf16x3 step (the top-level figures of this object) when they agree "
+                                                     "(trainer.select_trainer; product_default_probe is that verdict on this workload), else the "
+                                                     "exact-fp32 step (the `fp32` entry); XVECTOR_TRAIN_PRECISION=fp32|bf16x3 forces one",
                                      workload="BASELINE configs[4], one rank's share: 64-chunk minibatches, T ~ U{%d..%d}, 64 speakers, "
                                               "AM-softmax head, Adam; 30 timed steps after 3 (minibatch lengths are drawn per step: ten steps were too few for a steady figure)" % (args.tmin, args.tmax))
         except Exception as e:

@@ -612,3 +612,34 @@ def test_bf16x3_step_with_and_without_split_k1_inputs(env, monkeypatch):
     assert res[0][0] == res[1][0]
     assert all(np.array_equal(res[0][1][n], res[1][1][n]) for n in res[0][1])
 
+
+
+def test_training_arithmetic_is_chosen_by_a_gradient_probe(env, tmp_path, caplog):
+    """trainer.select_trainer: the first minibatch's gradients in bf16x3 and in exact fp32 decide the arithmetic of a training run
+    (train_dnn.py's default, XVECTOR_TRAIN_PRECISION=auto).  A trained-like checkpoint keeps bf16x3 with a margin; a limit of zero
+    (any checkpoint) falls back to fp32; the probe leaves no trace: moving statistics, parameters and the step count of the
+    returned trainer are those of a freshly built one."""
+    import logging
+    torch, trainer = env["torch"], env["trainer"]
+    topo, w, rng = _setup(env, "ModelWithoutDropout", seed=8)
+    x = (rng.standard_normal((8, 160, 23)) * 3).astype(np.float16)
+    lab = rng.integers(0, 10, 8).astype(np.int32)
+    fresh = trainer.Trainer(w, topo, precision="bf16x3")
+    log = logging.getLogger("train_probe")
+    caplog.set_level(logging.INFO, logger="train_probe")
+    tr, verdict = trainer.select_trainer(w, topo, "cuda:0", None, x, lab, log)
+    assert verdict["selected"] == "bf16x3" and tr.precision == "bf16x3"
+    assert 0 < verdict["worst_gradient_rel_l2"] < 0.5 * trainer.TRAIN_PROBE_LIMIT, verdict
+    assert "Training arithmetic: bf16x3" in caplog.text
+    assert tr.t == 0 and torch.equal(tr.flat_moving, fresh.flat_moving) and torch.equal(tr.flat_p, fresh.flat_p)
+    # the first real step of the admitted trainer is the first step of a plain bf16x3 trainer, bit for bit
+    a = tr.step(x, lab, 1e-3)
+    b = fresh.step(x, lab, 1e-3)
+    assert a == b and torch.equal(tr.flat_p, fresh.flat_p)
+    old = trainer.TRAIN_PROBE_LIMIT
+    try:
+        trainer.TRAIN_PROBE_LIMIT = 0.0
+        tr32, v32 = trainer.select_trainer(w, topo, "cuda:0", None, x, lab)
+    finally:
+        trainer.TRAIN_PROBE_LIMIT = old
+    assert v32["selected"] == "fp32" and tr32.precision == "fp32" and tr32.t == 0

@@ -297,15 +297,22 @@ class Model(object):
         return name2weights
 
     # -- training / diagnostics ---------------------------------------------------------
-    def _trainer(self, input_dir, logger):
+    def _trainer(self, input_dir, logger, first_batch=None):
+        """The trainer of a model directory.  XVECTOR_TRAIN_PRECISION: "fp32" | "bf16x3" as given, "auto" (the default): bf16x3 when
+        the gradients of ``first_batch`` = (x, labels) agree with the exact-fp32 ones (trainer.select_trainer), else fp32;
+        without a first batch (eval) "auto" is fp32."""
         from xvector_amd import trainer
         if logger is not None:
             logger.info("Start loading graph ...")
         w, meta = wio.load_model_dir(input_dir)
         self.meta = meta
         self.num_classes = meta["num_classes"]
-        tr = trainer.Trainer(w, meta["topology"], _device(), wio.load_optimizer_state(input_dir),
-                             precision=os.environ.get("XVECTOR_TRAIN_PRECISION", "fp32"))
+        precision = os.environ.get("XVECTOR_TRAIN_PRECISION", "auto")
+        adam = wio.load_optimizer_state(input_dir)
+        if precision == "auto" and first_batch is not None:
+            tr, self.train_precision_verdict = trainer.select_trainer(w, meta["topology"], _device(), adam, first_batch[0], first_batch[1], logger)
+        else:
+            tr = trainer.Trainer(w, meta["topology"], _device(), adam, precision="fp32" if precision == "auto" else precision)
         if logger is not None:
             logger.info("Graph restored from path: %s" % input_dir)
         return tr
@@ -351,15 +358,17 @@ class Model(object):
         from xvector_amd import runstats
         keep_out = float(getattr(args, "dropout_proportion", 0.0) or 0.0)      # keep_prob = 1 - this, models.py:258
         seed = int(getattr(args, "random_seed", 0) or 0)                       # models.py:223,233
-        tr = self._trainer(args.input_dir, logger)
+        tr = None                        # built on the first minibatch: its gradients decide the arithmetic (XVECTOR_TRAIN_PRECISION=auto)
         meter = runstats.Meter(planned=data_loader.count, report_every=args.print_interval)
         for index in range(data_loader.count):
             batch, labels = self._next_batch(data_loader, index, logger, 'the minibatch index', meter)
-            if not self._everyone_has(batch, getattr(tr, 'device', 'cpu')):
+            if not self._everyone_has(batch, _device()):
                 if batch is not None:
                     logger.warning('minibatch index %d skipped: another rank of the group has no batch' % index)
                 meter.skipped(index)
             else:
+                if tr is None:           # every rank of the group is here with a minibatch: the probe's own collective lines up
+                    tr = self._trainer(args.input_dir, logger, (batch, labels))
                 t0 = time.time()
                 loss, accuracy = tr.step(batch, labels, args.learning_rate, keep_out, seed)
                 meter.waited("gpu", time.time() - t0)
@@ -369,6 +378,8 @@ class Model(object):
                 logger.info(line)
         for line in meter.training_summary():
             logger.info(line)
+        if tr is None:                   # not a single minibatch: the model goes out as it came in
+            tr = self._trainer(args.input_dir, logger)
         if getattr(args, "save_model", True):          # data-parallel driver (train_dnn.py): only one rank of the group writes
             w, adam = tr.export()
             # optimizer slots first, the model (whose 'done' marker completes the directory) last

@@ -552,3 +552,55 @@ class Trainer(object):
         w = {k: v.cpu().numpy() for k, v in self.P.items()}
         adam = dict(t=self.t, m={k: v.cpu().numpy() for k, v in self.m.items()}, v={k: v.cpu().numpy() for k, v in self.v.items()})
         return w, adam
+
+
+# ------------------------------------------------------------------------------------------------
+# which arithmetic may this checkpoint TRAIN in?  (first-minibatch gradient probe)
+# ------------------------------------------------------------------------------------------------
+# The bf16x3 step (forward / input-gradient / weight-gradient GEMMs on the split-precision MFMA path) is half the time of the
+# exact-fp32 step and reproduces its gradients to ~1e-4 .. 1e-3 on networks that look like a TDNN in training.  Nothing forces a
+# checkpoint to look like that (cf. engine.select_model for extraction), so the choice is made PER RUN on real data: the first
+# minibatch's gradients are computed in both arithmetics and bf16x3 is kept only when every weight / gamma gradient agrees with the
+# fp32 one to TRAIN_PROBE_LIMIT relative L2 and the losses to 1e-3 (bias / beta gradients are plain sums of signed terms over all
+# frames -- ill-conditioned in ANY arithmetic, see tests/test_gpu_training.py -- and are not part of the verdict).
+TRAIN_PROBE_LIMIT = 2e-2
+
+
+def select_trainer(weights, topo, device, adam, x, labels, logger=None):
+    """(Trainer, verdict dict): the bf16x3 trainer when the first minibatch ``(x, labels)`` admits it, else the fp32 one.  The probe
+    leaves no trace in either trainer (moving statistics restored; no optimizer step).  In a data-parallel group every rank
+    probes its own minibatch and the group takes bf16x3 only if every rank would."""
+    import torch
+    fast = Trainer(weights, topo, device, adam, precision="bf16x3")
+    exact = Trainer(weights, topo, device, adam, precision="fp32")
+    keep = [t.flat_moving.clone() for t in (fast, exact)]
+    l3, _, g3 = fast.gradients(x, labels)
+    l32, _, g32 = exact.gradients(x, labels)
+    worst, worst_name = 0.0, ""
+    for name, ref in g32.items():
+        if name.endswith("/b:0") or name.endswith("/beta:0"):
+            continue
+        den = float(ref.double().norm().item())
+        num = float((g3[name].double() - ref.double()).norm().item())
+        rel = num / den if den > 0 else (0.0 if num == 0 else float("inf"))
+        if not np.isfinite(rel):
+            rel = float("inf")
+        if rel > worst:
+            worst, worst_name = rel, name
+    for t, m in zip((fast, exact), keep):
+        t.flat_moving.copy_(m)
+    ok = bool(np.isfinite(l3) and np.isfinite(l32) and abs(l3 - l32) <= 1e-3 * max(1.0, abs(l32)) and worst <= TRAIN_PROBE_LIMIT)
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=fast.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+    except ImportError:
+        pass
+    verdict = dict(selected="bf16x3" if ok else "fp32", worst_gradient_rel_l2=worst, worst_tensor=worst_name, limit=TRAIN_PROBE_LIMIT,
+                   loss_bf16x3=float(l3), loss_fp32=float(l32))
+    if logger is not None:
+        logger.info("Training arithmetic: %s (first-minibatch gradient probe: bf16x3 vs fp32 %.2e on %s, limit %.0e; loss %.6f vs %.6f)" % (
+            verdict["selected"], worst, worst_name, TRAIN_PROBE_LIMIT, l3, l32))
+    return (fast if ok else exact), verdict
