@@ -92,7 +92,7 @@ SKIP_WORKER = textwrap.dedent("""
             return np.full((2, 7, 3), float(self.i + 1), np.float32), np.zeros(2, np.int32)
 
     tr = Stepper()
-    models.Model._trainer = lambda self, d, lg: tr
+    models.Model._trainer = lambda self, d, lg, first_batch=None: tr
     logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%%(levelname)s %%(message)s")
     args = types.SimpleNamespace(learning_rate=1e-3, print_interval=2, dropout_proportion=0.0, random_seed=0, input_dir="unused",
                                  output_dir="unused", save_model=False)

@@ -92,7 +92,7 @@ def test_reference_train_dnn_one_iteration_drives_the_twin(ref_env, tmp_path, mo
     np.save(tar_path.replace(".tar", ".npy"), labels)
     fake = {}
 
-    def fake_trainer(self, input_dir, logger):
+    def fake_trainer(self, input_dir, logger, first_batch=None):
         w, meta = wio.load_model_dir(input_dir)
         self.meta, self.num_classes = meta, meta["num_classes"]
         fake["tr"] = _FakeTrainer(w)
