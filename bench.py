@@ -131,10 +131,17 @@ def _train_run(args, rank, world, dev, topo, feat, precision, steps, warmup):
     fence()
     t0 = time.perf_counter()
     per_step = []
+    prev = None
     for i in range(warmup, n_total):
         t1 = time.perf_counter()
-        losses.append(tr.step(batches[i][0], batches[i][1], 1e-3)[0])
-        per_step.append(time.perf_counter() - t1)              # (every step ends with the read-back of its loss)
+        # every step's loss is read back, one step late -- as Model.train_one_iteration does (Trainer.step_async): the host stages
+        # minibatch i + 1 while the GPU finishes step i
+        handle = tr.step_async(batches[i][0], batches[i][1], 1e-3)
+        if prev is not None:
+            losses.append(prev.result()[0])
+        prev = handle
+        per_step.append(time.perf_counter() - t1)
+    losses.append(prev.result()[0])
 
     fence()
     dt = time.perf_counter() - t0

@@ -139,6 +139,16 @@ class _Held(object):
         self.buf, self.addr, self._feats, self._off = feats, feats.ctypes.data, feats, offsets
 
 
+class _StepDone(object):
+    """(loss, accuracy) of a trainer that only has the synchronous ``step`` (the duck type of xvector_amd.trainer's handle)."""
+
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
 class Model(object):
     """Default topology: 5 frame-level layers [512,512,512,512,1536], kernels [5,5,7,1,1],
     statistics pooling, 2 segment-level layers (models.py:27-29)."""
@@ -359,20 +369,34 @@ class Model(object):
         keep_out = float(getattr(args, "dropout_proportion", 0.0) or 0.0)      # keep_prob = 1 - this, models.py:258
         seed = int(getattr(args, "random_seed", 0) or 0)                       # models.py:223,233
         tr = None                        # built on the first minibatch: its gradients decide the arithmetic (XVECTOR_TRAIN_PRECISION=auto)
+        pending = None                   # (index, B, T, handle) of the step whose loss has not been read back yet
         meter = runstats.Meter(planned=data_loader.count, report_every=args.print_interval)
         for index in range(data_loader.count):
             batch, labels = self._next_batch(data_loader, index, logger, 'the minibatch index', meter)
-            if not self._everyone_has(batch, _device()):
+            stepped_now = self._everyone_has(batch, _device())
+            if not stepped_now:
                 if batch is not None:
                     logger.warning('minibatch index %d skipped: another rank of the group has no batch' % index)
-                meter.skipped(index)
             else:
                 if tr is None:           # every rank of the group is here with a minibatch: the probe's own collective lines up
                     tr = self._trainer(args.input_dir, logger, (batch, labels))
                 t0 = time.time()
-                loss, accuracy = tr.step(batch, labels, args.learning_rate, keep_out, seed)
+                # the step is enqueued; its loss is read back after the NEXT step has been enqueued (or at the end of the loop): the
+                # GPU does not idle while the host stages a minibatch.  The log lines are averages over intervals of steps, which
+                # the one-step lag does not change (an interval line waits for its own last step, below).
+                launch = getattr(tr, "step_async", None)
+                handle = launch(batch, labels, args.learning_rate, keep_out, seed) if launch is not None else \
+                    _StepDone(tr.step(batch, labels, args.learning_rate, keep_out, seed))
+                now = (index, batch.shape[0], batch.shape[1], handle)
+                if pending is not None:
+                    meter.stepped(pending[0], pending[1], pending[2], *pending[3].result())
+                pending = now
                 meter.waited("gpu", time.time() - t0)
-                meter.stepped(index, batch.shape[0], batch.shape[1], loss, accuracy)
+            if pending is not None and (index == data_loader.count - 1 or meter.interval_due(index)):
+                meter.stepped(pending[0], pending[1], pending[2], *pending[3].result())
+                pending = None
+            if not stepped_now:
+                meter.skipped(index)     # (last word on this index: an index without a step never closes an interval)
             line = meter.interval_line(index)
             if line:
                 logger.info(line)

@@ -52,6 +52,11 @@ class Meter(object):
     def skipped(self, index):
         self._stepped_last = False
 
+    def interval_due(self, index):
+        """Would ``index`` close a progress interval if it produced a step?  (A caller that feeds steps one late asks this to
+        know when it has to catch up before ``interval_line``.)"""
+        return bool(self.report_every) and (index + 1) % self.report_every == 0
+
     # -- lines -------------------------------------------------------------------------------------
     def interval_line(self, index):
         """Progress line when ``index`` closes an interval, else None.  An index without a step never closes one (the

@@ -517,7 +517,18 @@ class Trainer(object):
         return float(la[0]) + self._l2_value(), float(la[1]), grads
 
     def step(self, x, labels, learning_rate, dropout_proportion=0.0, seed=0):
-        """One optimizer step on a minibatch x[B,T,F] (float16/32), labels[B].  Returns (loss, accuracy).
+        """One optimizer step on a minibatch x[B,T,F] (float16/32), labels[B].  Returns (loss, accuracy): ``step_async`` + the
+        read-back, i.e. the host waits for the whole step before it can stage the next minibatch."""
+        return self.step_async(x, labels, learning_rate, dropout_proportion, seed).result()
+
+    def step_async(self, x, labels, learning_rate, dropout_proportion=0.0, seed=0):
+        """The same step with its ONE host synchronisation handed to the caller: everything is enqueued, (loss, accuracy) travel to a
+        pinned slot behind the optimizer update, and ``.result()`` of the returned handle waits for them.  A loop that asks for step
+        i's result AFTER it has enqueued step i + 1 (Model.train_one_iteration, bench.py) keeps the GPU busy across the step
+        boundary: with the read-back at the end of every step the GPU idles ~0.25 ms per step while the host stages the next
+        minibatch (kernel trace: 280 us between the optimizer update and the next step's first GEMM).  At most two steps may be
+        outstanding: the input staging buffers and the result slots alternate.
+
 
         Data parallelism (one process per GPU): the gradients are averaged over the ranks by bucketed, asynchronous RCCL
         all-reduces of ranges of the flat gradient buffer, each issued the moment the backward pass has finished its range
@@ -544,14 +555,44 @@ class Trainer(object):
         lr_t = learning_rate * math.sqrt(1.0 - ADAM_B2 ** self.t) / (1.0 - ADAM_B1 ** self.t)
         hiplib.adam(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS)
         self._packed = None
-        la = pending[0].cpu().numpy()
-        return float(la[0]) + self._l2_read(pending[1]), float(la[1])
+        torch = self.torch
+        slots = self.__dict__.setdefault("_result_slots", [None, None])
+        turn = self.__dict__["_result_turn"] = self.__dict__.get("_result_turn", 0) ^ 1
+        n_l2 = 0 if pending[1] is None else pending[1].numel()
+        if slots[turn] is None or slots[turn][0].numel() < 2 + n_l2:
+            slots[turn] = (torch.empty(2 + n_l2, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+        host, done = slots[turn]
+        host[:2].copy_(pending[0].view(-1)[:2], non_blocking=True)
+        if n_l2:
+            host[2:2 + n_l2].copy_(pending[1].view(-1), non_blocking=True)
+        done.record()
+        return _PendingStep(self, host, done, n_l2)
+
+    def _l2_from_host(self, v):
+        v = np.asarray(v, dtype=np.float64)
+        return float(self.l2_beta * sum(coef * 0.5 * (v[2 * i] + v[2 * i + 1]) for i, (_, coef) in enumerate(self.l2_terms)))
 
     def export(self):
         """-> (weights {tf name: float32 ndarray}, adam {"t", "m", "v"}) for the model directory."""
         w = {k: v.cpu().numpy() for k, v in self.P.items()}
         adam = dict(t=self.t, m={k: v.cpu().numpy() for k, v in self.m.items()}, v={k: v.cpu().numpy() for k, v in self.v.items()})
         return w, adam
+
+
+class _PendingStep(object):
+    """Handle of ``Trainer.step_async``: ``result()`` -> (loss, accuracy) once the step's values have reached the host."""
+
+    def __init__(self, trainer, host, done, n_l2):
+        self._t, self._host, self._done, self._n_l2 = trainer, host, done, n_l2
+        self._value = None
+
+    def result(self):
+        if self._value is None:
+            self._done.synchronize()
+            la = self._host.numpy()
+            l2 = self._t._l2_from_host(la[2:2 + self._n_l2]) if self._n_l2 else 0.0
+            self._value = (float(la[0]) + l2, float(la[1]))
+        return self._value
 
 
 # ------------------------------------------------------------------------------------------------
