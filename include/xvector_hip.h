@@ -52,7 +52,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 17). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 18). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -287,6 +287,15 @@ int xv_stats_pool_f32(const float *h, int64_t ldh, int c, const int32_t *row_sta
 int xv_fc_f32(const float *x, int nrows, int in_dim, const float *wp, const float *bias, const float *bn_scale,
               const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y,
               float *y_preact, void *stream);
+
+/* xv_fc_f32 for a SKINNY problem (a training minibatch's segment level: 64 rows x 3072 -> 512): with <= 128 rows there are only a few
+ * output tiles, and each would walk all In / 32 slabs one after the other.  The slabs are dealt to groups of workgroups that write
+ * raw partial sums to `workspace` (xv_fc_splitk_workspace_bytes bytes; 0 = the shape is not skinny and the call IS xv_fc_f32), a
+ * second kernel adds the groups in order (deterministic) and applies bias / activation / BN.  Same arguments as xv_fc_f32. */
+size_t xv_fc_splitk_workspace_bytes(int nrows, int in_dim, int out_dim);
+int xv_fc_splitk_f32(const float *x, int nrows, int in_dim, const float *wp, const float *bias, const float *bn_scale,
+                     const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y, float *y_preact, void *workspace,
+                     void *stream);
 
 /* Length-weighted average of chunk embeddings.  Replaces the NumPy lines local/tf/models.py:398,
  * 418-421 with the same float32 operation order (product, sum in chunk order, one division):

@@ -834,3 +834,38 @@ def test_attention_pool_uniform_weights_equal_plain_statistics(env):
     hiplib.stats_pool(h, rs, rl, 3, max(lens), 512, 1e-5, p_out, ws2)
     torch.cuda.synchronize()
     assert torch.allclose(a_out, p_out, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("nrows,in_dim,out_dim,act", [(64, 3072, 512, "relu"), (7, 1024, 200, "lrelu"), (128, 608, 64, "none"), (64, 256, 512, "prelu")])
+def test_fc_splitk_matches_oracle_and_the_plain_fc(env, nrows, in_dim, out_dim, act):
+    """xv_fc_splitk_f32 (the training minibatch's skinny segment-level FC: reduction dealt to groups of workgroups, groups added in
+    order): against the float64 product, within fp32 rounding of xv_fc_f32, deterministic; a shape that is not skinny (the last
+    one: 8 slabs) IS xv_fc_f32, bit for bit."""
+    torch, hiplib, dev = env["torch"], env["hiplib"], env["dev"]
+    rng = np.random.default_rng(nrows + in_dim)
+    x = rng.standard_normal((nrows, in_dim)).astype(np.float32)
+    w = (rng.standard_normal((in_dim, out_dim)) / np.sqrt(in_dim)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(out_dim)).astype(np.float32)
+    alpha = np.array([0.2], np.float32) if act == "lrelu" else (0.1 + 0.05 * rng.standard_normal(out_dim)).astype(np.float32) if act == "prelu" else None
+    code = {"none": 0, "relu": 1, "lrelu": 2, "prelu": 3}[act]
+    xd, bd = torch.from_numpy(x).to(dev), torch.from_numpy(b).to(dev)
+    wp = hiplib.pack_weights(torch.from_numpy(w).to(dev))
+    al = None if alpha is None else torch.from_numpy(alpha).to(dev)
+    outs = []
+    for fn in (hiplib.fc_splitk, hiplib.fc_splitk, lambda *a: hiplib.fc(*a)):
+        y = torch.full((nrows, out_dim), float("nan"), device=dev)
+        z = torch.full((nrows, out_dim), float("nan"), device=dev)
+        fn(xd, wp, bd, None, None, code, al, y, z)
+        torch.cuda.synchronize()
+        outs.append((y.cpu().numpy(), z.cpu().numpy()))
+    zref = x.astype(np.float64) @ w.astype(np.float64) + b
+    a = 0.0 if act in ("none", "relu") else alpha
+    yref = zref if act == "none" else np.maximum(zref, 0) + a * np.minimum(zref, 0)
+    rel = lambda g, r: np.linalg.norm(g - r) / np.linalg.norm(r)
+    assert rel(outs[0][1], zref) < TOL_GEMM and rel(outs[0][0], yref) < TOL_GEMM
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])          # deterministic
+    assert rel(outs[0][1], outs[2][1]) < 3e-6          # (the plain form's 3072-term fp32 chain is itself ~1e-6 from fp64)
+    skinny = hiplib.fc_splitk_supported(nrows, in_dim, out_dim)
+    assert skinny == (in_dim >= 512)
+    if not skinny:
+        assert np.array_equal(outs[0][1], outs[2][1])

@@ -68,6 +68,9 @@ struct GemmParams {
     float *blk;         // POOL epilogue (no y / ypre): per-8-row-block (mean, M2) planes [ceil(R/8)][2][cout], as Gemm3Params::blk
     int n_mt, n_nt;
     int vec_out;        // outputs take 16-byte stores: cout % 4 == 0, ldy % 4 == 0, y / ypre / per-column parameters 16-byte aligned
+    int k_splits;       // split-K (xv_fc_splitk_f32, register-staged kernel only): the slabs are dealt to k_splits groups of workgroups, group ks
+    float *part;        //   writes its raw partial sums to part + ks * part_stride ([R, cout] fp32 rows); a second kernel adds them up in order
+    long part_stride;
     int lead;           // "rows" form (xv_tdnn_layer_rows_f32): K = 1 over rows that OVERLAP -- virtual row r = the cin floats from
                         // x + (r - lead) * ldx on, cin > ldx; reads are bounded by the END OF THE BUFFER (R * ldx floats), not by the row
 };
@@ -248,7 +251,11 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
     // XCD-aware tile order: hardware places block b on XCD b%8; give each XCD a contiguous run of
     // logical tiles so that the n_nt tiles sharing one A panel sit on one L2 (bijective form).
     const int nwg = p.n_mt * p.n_nt;
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x, ks = 0;
+    if (p.k_splits > 1) {                              // split-K: blocks [ks * nwg, (ks + 1) * nwg) work on slab group ks
+        ks = bid / nwg;
+        bid -= ks * nwg;
+    }
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -259,7 +266,10 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
     const int span = (p.K - 1) * p.dil;
     const int left = (span >> 1) + p.lead;
     const int rowsA = BMT + span;
-    const int n_chunks = (p.cin + BK - 1) / BK;
+    const int all_chunks = (p.cin + BK - 1) / BK;
+    const int per_split = p.k_splits > 1 ? (all_chunks + p.k_splits - 1) / p.k_splits : all_chunks;
+    const int c_lo = ks * per_split;
+    const int n_chunks = (c_lo + per_split < all_chunks ? c_lo + per_split : all_chunks) - c_lo;      // (the launcher leaves no group empty)
     const int n_stages = n_chunks * p.K;
     const long flat_end = p.R * p.ldx;                 // (rows form: what the DMA-fed kernel's buffer descriptor checks)
 
@@ -347,13 +357,13 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
     // prologue: stage 0
-    load_a(0);
-    load_b(0, 0);
-    store_a(0);
+    load_a(c_lo);
+    load_b(c_lo, 0);
+    store_a(c_lo & 1);
     store_b(0);
     __syncthreads();
 
-    int chunk = 0, tap = 0;
+    int chunk = c_lo, tap = 0;
     for (int s = 0; s < n_stages; ++s) {
         int nchunk = chunk, ntap = tap + 1;
         if (ntap == p.K) { ntap = 0; nchunk = chunk + 1; }
@@ -394,8 +404,39 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_kernel(const GemmParams p)
         tap = ntap;
     }
 
+    if (p.k_splits > 1) {
+        // raw partial sums of this slab group as fp32 rows: the ordinary epilogue with nothing to add (bias, activation and BN
+        // belong to the kernel that adds the groups up)
+        GemmParams qp = p;
+        qp.bias = qp.scale = qp.shift = nullptr;
+        qp.act = XV_ACT_NONE;
+        qp.y = nullptr;
+        qp.blk = nullptr;
+        qp.ypre = p.part + (size_t)ks * p.part_stride;
+        qp.ldy = p.cout;
+        if (p.vec_out) gemm_epilogue_rows<BMT>(qp, smem, Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11);
+        else gemm_epilogue<WROWS>(qp, Ms, m0, n0, wr, wc, lane, acc00, acc01, acc10, acc11);
+        return;
+    }
     if (p.vec_out) gemm_epilogue_rows<BMT>(p, smem, Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11);     // (the loop ended with a barrier)
     else gemm_epilogue<WROWS>(p, Ms, m0, n0, wr, wc, lane, acc00, acc01, acc10, acc11);
+}
+
+// y = act(bias + sum_s part[s]) * scale + shift, ypre = bias + sum: the groups of a split-K launch added in group order (deterministic)
+__global__ void splitk_reduce_kernel(const float *__restrict__ part, long part_stride, int nsplit, int R, int cout, const float *bias,
+                                     const float *scale, const float *shift, int act, const float *alpha, float *y, int ldy, float *ypre,
+                                     int ldpre)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * cout) return;
+    const int r = (int)(i / cout), c = (int)(i - (size_t)r * cout);
+    float z = bias ? bias[c] : 0.f;
+    for (int k = 0; k < nsplit; ++k) z += part[(size_t)k * part_stride + i];
+    if (ypre) ypre[(size_t)r * ldpre + c] = z;
+    if (y) {
+        const float a = act == XV_ACT_LRELU ? alpha[0] : act == XV_ACT_PRELU ? alpha[c] : 0.f;
+        y[(size_t)r * ldy + c] = apply_act(z, act, a) * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1478,7 +1519,7 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
     static const bool dma_env = !(std::getenv("XV_FP32_DMA") != nullptr && std::getenv("XV_FP32_DMA")[0] == '0');
     const int form = g_fp32_form.load(std::memory_order_relaxed);       // XV_TUNE_FP32_GEMM: 0 built-in, 1 register-staged, 2 DMA-fed
     const bool dma_on = form == 2 || (form == 0 && dma_env);
-    const bool dma_ok = dma_on && !small && vec && p.vec_out && (p.cin % BK) == 0 && (p.K == 1 || p.K == 3 || p.K == 5 || p.K == 7) &&
+    const bool dma_ok = dma_on && !small && p.k_splits <= 1 && vec && p.vec_out && (p.cin % BK) == 0 && (p.K == 1 || p.K == 3 || p.K == 5 || p.K == 7) &&
                         (p.R + BM + MAX_SPAN) * (long)p.ldx * 4 < (1l << 31) && (long)(p.cout + BN) * p.kred * 4 < (1l << 31);
     if (dma_ok) {
         const kern_t dk = p.K == 1 ? tdnn_gemm_dma_kernel<1> : p.K == 3 ? tdnn_gemm_dma_kernel<3> : p.K == 5 ? tdnn_gemm_dma_kernel<5>
@@ -1486,6 +1527,11 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
         hipLaunchKernelGGL(dk, grid, dim3(NT), F_LDS_BYTES, st, p);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_dma_kernel launch");
+    }
+    if (p.k_splits > 1) {
+        hipLaunchKernelGGL(all[(small ? 2 : 0) + (vec ? 0 : 1)], dim3((unsigned)(p.n_mt * p.n_nt * p.k_splits)), dim3(NT), GEMM_LDS_BYTES, st, p);
+        hipError_t e2 = hipGetLastError();
+        return e2 == hipSuccess ? 0 : hip_fail(e2, "tdnn_gemm_kernel (split-K) launch");
     }
     hipLaunchKernelGGL(all[(small ? 2 : 0) + (vec ? 0 : 1)], grid, dim3(NT), GEMM_LDS_BYTES, st, p);
     hipError_t e = hipGetLastError();
@@ -1866,7 +1912,7 @@ void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
 void xv_internal_gemm8_xcd_columns(int value);    // xv_gemm8.hip
 void xv_internal_first_tiles(int tiles);          // xv_first.hip
 
-int xv_version(void) { return 17; }
+int xv_version(void) { return 18; }
 
 int xv_set_tuning(int key, int value)
 {
@@ -1976,6 +2022,46 @@ int xv_fc_f32(const float *x, int nrows, int in_dim, const float *wp, const floa
 {
     return xv_tdnn_layer_f32(x, nrows, in_dim, in_dim, wp, bias, bn_scale, bn_shift, act_kind, act_alpha, 1, 1,
                              out_dim, nullptr, y, out_dim, y_preact, stream);
+}
+
+// Split-K plan of a skinny FC: nrows <= 128 (one or two 64-row tiles) and so many slabs that the few tiles would walk them one
+// after the other (embed_layer-0 of a 64-chunk training minibatch: 96 slabs on 4 workgroups = 168 us for 0.2 GFLOP).
+static int splitk_groups(int nrows, int in_dim, int out_dim)
+{
+    if (nrows <= 0 || nrows > 128 || in_dim < 16 * BK) return 1;
+    const int chunks = (in_dim + BK - 1) / BK;
+    const int tiles = ((nrows + 63) / 64) * ((out_dim + BN - 1) / BN);
+    int per = (chunks * tiles + 255) / 256;             // ~ one workgroup per CU
+    if (per < 2) per = 2;
+    return (chunks + per - 1) / per;
+}
+
+size_t xv_fc_splitk_workspace_bytes(int nrows, int in_dim, int out_dim)
+{
+    const int g = splitk_groups(nrows, in_dim, out_dim);
+    return g > 1 ? (size_t)g * nrows * out_dim * sizeof(float) : 0;
+}
+
+int xv_fc_splitk_f32(const float *x, int nrows, int in_dim, const float *wp, const float *bias, const float *bn_scale,
+                     const float *bn_shift, int act_kind, const float *act_alpha, int out_dim, float *y, float *y_preact, void *workspace,
+                     void *stream)
+{
+    const int g = splitk_groups(nrows, in_dim, out_dim);
+    if (g <= 1) return xv_fc_f32(x, nrows, in_dim, wp, bias, bn_scale, bn_shift, act_kind, act_alpha, out_dim, y, y_preact, stream);
+    if (!x || !wp || (!y && !y_preact) || !workspace) return fail(XV_ERR_BAD_ARG, "fc_splitk: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "fc_splitk: unknown act_kind");
+    if ((act_kind == XV_ACT_LRELU || act_kind == XV_ACT_PRELU) && !act_alpha) return fail(XV_ERR_BAD_ARG, "fc_splitk: act_alpha is NULL");
+    GemmParams p{};
+    p.x = x; p.R = nrows; p.cin = in_dim; p.ldx = in_dim; p.wp = wp;
+    p.act = XV_ACT_NONE; p.K = 1; p.dil = 1; p.cout = out_dim; p.ldy = out_dim;
+    p.ypre = (float *)workspace;                        // (launch_gemm wants an output; the split-K epilogue redirects it per group)
+    p.k_splits = g; p.part = (float *)workspace; p.part_stride = (long)nrows * out_dim;
+    int rc = launch_gemm(p, (hipStream_t)stream);
+    if (rc) return rc;
+    const size_t n = (size_t)nrows * out_dim;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float *)workspace,
+                       (long)nrows * out_dim, g, nrows, out_dim, bias, bn_scale, bn_shift, act_kind, act_alpha, y, out_dim, y_preact, out_dim);
+    return check_launch("splitk_reduce_kernel");
 }
 
 

@@ -10,11 +10,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
-           "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_chunk_average_f32",
+           "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_fc_splitk_workspace_bytes", "xv_fc_splitk_f32", "xv_chunk_average_f32",
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_pack_weights_bf16x3_many", "xv_split_row_bytes", "xv_split_encode_f32",
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32", "xv_tdnn_layer_pool_f32",
@@ -95,6 +95,10 @@ def load():
     lib.xv_stats_pool_f32.argtypes = [vp, i64, ci, vp, vp, ci, ci, ci, cf, vp, vp, vp]
     lib.xv_fc_f32.restype = ci
     lib.xv_fc_f32.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp]
+    lib.xv_fc_splitk_workspace_bytes.restype = sz
+    lib.xv_fc_splitk_workspace_bytes.argtypes = [ci, ci, ci]
+    lib.xv_fc_splitk_f32.restype = ci
+    lib.xv_fc_splitk_f32.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp]
     lib.xv_packed_weights_bf16x3_bytes.restype = sz
     lib.xv_packed_weights_bf16x3_bytes.argtypes = [ci, ci, ci]
     lib.xv_pack_weights_bf16x3.restype = ci
@@ -813,6 +817,28 @@ def fc(x, wp, bias, scale, shift, act, alpha, y, y_preact, rows=None):
         return
     _check(lib.xv_fc_f32(_ptr(x), n, in_dim, _ptr(wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act), _ptr(alpha),
                          out_dim, _ptr(y), _ptr(y_preact), _stream()), "xv_fc_f32")
+
+
+def fc_splitk_supported(nrows, in_dim, out_dim):
+    """Is ``[nrows, in_dim] -> out_dim`` skinny enough for the split-K form (xv_fc_splitk_f32)?"""
+    return int(load().xv_fc_splitk_workspace_bytes(int(nrows), int(in_dim), int(out_dim))) > 0
+
+
+def fc_splitk(x, wp, bias, scale, shift, act, alpha, y, y_preact):
+    """xv_fc_splitk_f32: the exact-fp32 FC of a skinny problem with its reduction dealt to groups of workgroups (training
+    minibatches' segment level).  wp: fp32 packed weights [Out, In] (pack_weights).  NOT used by extraction: the sum order
+    differs from xv_fc_f32's, and an utterance's bits must not depend on the batch it is in."""
+    lib = require_gpu()
+    _f32(x, "x"); _f32(wp, "wp")
+    n, in_dim = x.shape
+    out_dim = wp.shape[0]
+    assert wp.shape[1] == in_dim
+    for t in (y, y_preact):
+        if t is not None:
+            _f32(t, "y"); assert t.shape[1] == out_dim and t.shape[0] >= n
+    ws = _ws(lib.xv_fc_splitk_workspace_bytes(n, in_dim, out_dim), x.device)
+    _check(lib.xv_fc_splitk_f32(_ptr(x), n, in_dim, _ptr(wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act), _ptr(alpha), out_dim,
+                                _ptr(y), _ptr(y_preact), _ptr(ws), _stream()), "xv_fc_splitk_f32")
 
 
 def chunk_average(e, seg_start, chunk_len, nutts, out):

@@ -35,6 +35,7 @@ class Trainer(object):
         assert precision in ("fp32", "bf16x3")
         self.attention = tp.is_attention(topo)              # self-attentive pooling (models.py:1036-1050)
         self.precision = precision
+        self.skinny_fc = os.environ.get("XVECTOR_TRAIN_SPLITK_FC", "1") != "0"
         self.torch = torch
         self.device = torch.device(device)
         self.topo = topo
@@ -319,7 +320,15 @@ class Trainer(object):
             C = self.topo["embedding_sizes"][j]
             r = torch.empty((B, C), dtype=torch.float32, device=self.device)
             z = torch.empty_like(r) if (self.prelu and want_grad) else None
-            hiplib.fc(S["e_in"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act, self._alpha(sc), r, z)
+            e_in = S["e_in"][-1]
+            if self.skinny_fc and hiplib.fc_splitk_supported(B, e_in.shape[1], C):
+                # 64 rows x 3072 -> 512: four output tiles would each walk 96 slabs one after the other (168 us); split-K, exact fp32
+                key = sc + "/fc32"
+                if key not in pk:
+                    pk[key] = hiplib.pack_weights(self.P[sc + "/w:0"])
+                hiplib.fc_splitk(e_in, pk[key], self.P[sc + "/b:0"], None, None, self.act, self._alpha(sc), r, z)
+            else:
+                hiplib.fc(e_in, pk[sc], self.P[sc + "/b:0"], None, None, self.act, self._alpha(sc), r, z)
             a, mean, var = self._bn_scopes_stats(r, sc, L, B, 1, train, None, False)
             if drop and ("embed", j) in S["seeds"]:
                 hiplib.dropout(a, S["seeds"][("embed", j)], S["keep"])
