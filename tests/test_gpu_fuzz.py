@@ -290,3 +290,43 @@ def test_random_shapes_through_the_dma_fed_fp32_gemm(oracle_mod, seed):
             if not int(valid[r].item()):
                 v = np.zeros_like(v)
             assert np.linalg.norm(outs[1][r] - v) <= 2e-6 * max(np.linalg.norm(v), 1e-3) + 1e-6, (tag, r)
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_random_topologies_in_the_fp32tc_arithmetic(oracle_mod, seed):
+    """The Toom-Cook path on shapes it was not tuned for: hidden widths that are multiples of 32 (so the K = 5 / 7, dilation-1 layers
+    take tdnn_gemm_toom_kernel) next to layers it does not take (K = 1 / 3, dilated, ragged widths: the direct fp32 kernels),
+    first layers in the rows form for every feature dimension, random activations, lengths from 1 frame up, chunking on and off,
+    batch budgets from a single tile to one batch -- against the fp64 oracle."""
+    import torch  # noqa: F401
+    from xvector_amd import engine, hiplib, synthetic
+    rng = np.random.default_rng(seed)
+    worst, toom_layers = 0.0, 0
+    for case in range(6):
+        F = int(rng.choice([23, 24, 30, 13, 40]))
+        ks = [int(rng.choice([3, 5, 7]))] + [int(rng.choice([1, 3, 5, 7])) for _ in range(3)] + [int(rng.choice([1, 5]))]
+        ds = [1] + [int(rng.choice([1, 1, 2])) if k == 3 else 1 for k in ks[1:]]
+        widths = [int(rng.choice([32, 64, 96, 160])) for _ in range(4)] + [int(rng.choice([64, 100, 192]))]
+        if case == 0:
+            widths[1] = 40                                   # a layer whose input is no whole slab: not a Toom-Cook layer
+        topo = dict(layer_sizes=widths, kernel_sizes=ks, dilations=ds, embedding_sizes=[int(rng.choice([16, 40])), 16],
+                    activation=str(rng.choice(["relu", "lrelu", "prelu"])), lrelu_alpha=0.2, pooling="stats")
+        w = synthetic.trained_like(topo, F, 8, seed=int(rng.integers(1 << 30)))
+        lens = [int(x) for x in rng.integers(1, 700, size=int(rng.integers(1, 9)))]
+        mn, cs = int(rng.choice([1, 10, 25])), int(rng.choice([-1, 100, 333]))
+        mats = [(rng.standard_normal((t, F)) * 3).astype(np.float32) for t in lens]
+        refs = [oracle_mod.embed_utterance(m, w, topo, mn, cs, np.float64) for m in mats]
+        model = engine.DeviceModel(w, topo, "cuda:0", precision="fp32tc")
+        in_dims = [model.in_dim] + widths[:-1]
+        assert isinstance(model.layers[0]["wp"], hiplib.PackedRows)        # (layer 0, dilation 1: the rows form, whatever K and F)
+        for li, (L, k, d, cin, cout) in list(enumerate(zip(model.layers, ks, ds, in_dims, widths)))[1:]:
+            # (the last layer feeds the pooling epilogue of the direct kernel: never a Toom-Cook layer)
+            want = k in (5, 7) and d == 1 and cin % 32 == 0 and cout % 4 == 0 and li < len(ks) - 1
+            assert isinstance(L["wp"], hiplib.PackedToom) == want, (case, k, d, cin, cout)
+            toom_layers += want
+        got = engine.Extractor(model, mn, cs, max_batch_rows=int(rng.choice([64, 700, 262144]))).extract(mats)
+        for g, r in zip(got, refs):
+            assert (g is None) == (r is None), (case, topo, lens, mn, cs)
+            if g is not None:
+                worst = max(worst, oracle_mod.rel_l2(g, r))
+    assert toom_layers >= 4 and worst < 1e-5, (toom_layers, worst)

@@ -287,7 +287,9 @@ class DeviceModel(object):
                     wpad = np.zeros((k, self.in_dim, w.shape[2]), np.float32)
                     wpad[:, :self.feat_dim] = w
                     w = wpad
-                self.layers.append(self._prep(weights, sc, w, k, d, defer_wp=self.f16bf8))
+                # (the last layer's pooling epilogue exists on the direct fp32 kernel only: no Toom-Cook form for it)
+                last = i == len(topo["kernel_sizes"]) - 1
+                self.layers.append(self._prep(weights, sc, w, k, d, defer_wp=self.f16bf8, toom_ok=not (last and self.fused_pool)))
             if self.attention:
                 # models.py:1036-1046: h = [h1 | h2]; u = h1 . attention/w + attention/b is one more K=1 layer.  On the
                 # bf16x3 path the last frame-level layer runs as two launches over the two column halves of its weights so
@@ -386,7 +388,7 @@ class DeviceModel(object):
             self._uploaded[key] = self._dev(weights[key])
         return self._uploaded[key]
 
-    def _prep(self, weights, scope, w3d, k, d, cols=slice(None), defer_wp=False):
+    def _prep(self, weights, scope, w3d, k, d, cols=slice(None), defer_wp=False, toom_ok=True):
         """Kernel-layout parameters of one layer (``cols``: only these output channels; ``defer_wp``: see _Layer)."""
         w3d = w3d[:, :, cols]
         weights = _ColumnView(weights, cols)
@@ -397,7 +399,7 @@ class DeviceModel(object):
                 w3d.shape[2] % 4 == 0 and os.environ.get("XVECTOR_ROWS_FIRST", "1") != "0":
             # layer 0 as a K = 1 GEMM over the overlapping windows of the packed feature rows (xv_tdnn_layer_rows_f32)
             make = lambda: hiplib.pack_weights_rows(self._dev(w3d), self.in_dim)
-        elif self.toom and hiplib.toom_supported(k, d, w3d.shape[1], w3d.shape[2]):
+        elif self.toom and toom_ok and hiplib.toom_supported(k, d, w3d.shape[1], w3d.shape[2]):
             make = lambda: hiplib.pack_weights_toom(self._dev(w3d))                   # transformed taps [Cout, (K+1) Cin]
         else:
             make = lambda: hiplib.pack_weights(self._dev(w3d.reshape(-1, w3d.shape[2])))
