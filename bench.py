@@ -398,7 +398,7 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, precision
     model.reserve(max(b["rows"] for b in batches), max(b["n"] for b in batches), max(b["max_len"] for b in batches))
     P = torch.empty((n_utts, model.pooled_dim), dtype=torch.float32, device=dev)
     E = torch.empty((n_utts, model.embed_dim), dtype=torch.float32, device=dev)
-    steps = 2
+    steps = 4
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in batches] for _ in range(steps + 1)]
 
     def one(si):
@@ -406,16 +406,19 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, precision
             # the batches were laid out with the 8-row chunk alignment of the fused path: a valid layout for this path too
             model.frame_level(b["x"], b["rs"], b["rl"], b["rv"], b["n"], b["max_len"], P[b["lo"]:b["hi"]], events=ev[si][bi])
         model.segment_level(P, E)
-    one(0)
+    one(0)                                              # (warm-up: fresh activation buffers, clock ramp -- ~3 batches' worth)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    passes = []
     for si in range(1, steps + 1):
+        t1 = time.perf_counter()
         one(si)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        passes.append((time.perf_counter() - t1) * 1e3)
     dt = (time.perf_counter() - t0) / steps
     t_g = sum(e[0].elapsed_time(e[1]) for si in range(1, steps + 1) for e in ev[si]) * 1e-3
     fl = tp.flops_per_frame(topo, feat) * frames
-    out = {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps,
+    out = {"value": n_utts / dt, "unit": "utt/s", "ms_per_step": dt * 1e3, "steps": steps, "passes_ms": [round(t, 2) for t in passes],
            "algorithmic_tflops": (fl + tp.flops_per_utt(topo) * n_utts) / dt / 1e12,
            "tdnn_gemm_tflops": fl * steps / t_g / 1e12, "frac": fl * steps / t_g / MFMA_F32_PEAK, "peak_tflops": MFMA_F32_PEAK / 1e12,
            "kernel": "tdnn_gemm_dma_kernel (layers 1-4: v_mfma_f32_32x32x2_f32 fed by buffer_load ... lds, bit-identical to tdnn_gemm_kernel, "
