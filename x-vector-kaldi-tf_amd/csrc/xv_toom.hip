@@ -8,8 +8,10 @@
 // i.e. K + 1 products per row PAIR: 6 instead of 10 (K = 5), 8 instead of 14 (K = 7) -- 0.60 / 0.57 of the MFMA work of the direct
 // form (tdnn_gemm_dma_kernel in xv_kernels.hip), exact fp32 products and fp32 accumulation as there.  Evaluation points 0, +-1, +-2
 // (, +-1/2), infinity; matrices generated and checked in exact rationals by tools/experiments/toomcook_gen.py.  The result is NOT
-// bit-identical to the direct form (different rounding: ~1e-6 relative L2 per layer against fp64 where the direct form has ~3e-7;
-// 3e-7 against 2e-7 on the x-vector), which is why this is a separate arithmetic ("fp32tc") with its own entry point.
+// bit-identical to the direct form (another rounding; measured 5-8e-7 relative L2 per layer against fp64 where the direct form's
+// 2560 / 3584-term fp32 chain has 9e-7 - 1.1e-6, 8.3e-7 against 8.6e-7 on the x-vector, and the smaller error on every one of 22
+// trained / trained-like / hostile checkpoints, profiles/r05_fp32tc_accuracy_sweep.txt), which is why this is a separate arithmetic
+// ("fp32tc") with its own entry point.
 //
 // Kernel = the DMA-fed fp32 GEMM's design with the taps replaced by the transformed products:
 //  * tile 128 output rows (64 row pairs) x 128 columns, 4 waves (2 x 2), a wave owns 32 pairs x 64 columns;
