@@ -87,6 +87,18 @@ __device__ __forceinline__ float apply_act(float z, int act, float a)
     }
 }
 
+// The same with the kind as a compile-time constant: identical expressions, hence identical bits -- but no switch per ELEMENT
+// (the row-wise epilogue below used to evaluate one: ~6 scalar compares / branches around every 4 VALU instructions, nothing
+// packed; beside an fp32 MFMA a co-resident workgroup pays for every one of them, cf. csrc/xv_toom.hip)
+template <int ACT>
+__device__ __forceinline__ float act_t(float z, float a)
+{
+    if constexpr (ACT == XV_ACT_RELU) return fmaxf(z, 0.0f);
+    else if constexpr (ACT == XV_ACT_LRELU) return z > 0.0f ? z : a * z;
+    else if constexpr (ACT == XV_ACT_PRELU) return fmaxf(z, 0.0f) + a * fminf(z, 0.0f);
+    else return z;
+}
+
 // Fused epilogue shared by the fp32 and the bf16x3 GEMM kernels.
 // D layout of a 32x32 MFMA tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 template <int WROWS>      // rows of the tile one wave owns: 64 (two 32-row MFMA blocks) or 32 (one)
@@ -129,27 +141,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, const uint8_t
 // -- 32 lanes cover 512 contiguous bytes of an output row with one 16-byte store each, where the register-direct form above
 // writes two 128-byte segments per 4-byte store instruction (a timing-only build without those stores ran the exact-fp32 step
 // 3.8 % faster).  Element for element the same arithmetic: results are bit-identical to gemm_epilogue.
-template <int BMT>
-__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams &p, float *T, const uint8_t *Ms, long m0, int n0, int wr, int wc,
-                                                   int tid, const f32x16 &acc00, const f32x16 &acc01, const f32x16 &acc10,
-                                                   const f32x16 &acc11)
+template <int BMT, int ACT>
+__device__ __forceinline__ void gemm_epilogue_rows_body(const GemmParams &p, const float *T, const uint8_t *Ms, long m0, int n0, int tid)
 {
-    constexpr int WROWS = BMT / 2;
     constexpr int TLD = BN + 4;
-    const int lane = tid & 63;
-    {
-        const int col = wc * 64 + (lane & 31);
-        const int rowb = wr * WROWS + 4 * (lane >> 5);
-#pragma unroll
-        for (int rb = 0; rb < WROWS / 32; ++rb)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int lr = rowb + rb * 32 + (reg & 3) + 8 * (reg >> 2);
-                T[lr * TLD + col] = rb == 0 ? acc00[reg] : acc10[reg];
-                T[lr * TLD + col + 32] = rb == 0 ? acc01[reg] : acc11[reg];
-            }
-    }
-    __syncthreads();
     const int cg = tid & 31, rp = tid >> 5;              // 4 columns; rows rp, rp + 8, ...
     const int gc = n0 + cg * 4;
     if (gc >= p.cout) return;                             // (cout % 4 == 0: a column group is inside or outside as a whole)
@@ -158,8 +153,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams &p, float *T
     const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + gc) : one;
     const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + gc) : zero;
     f32x4 al = zero;
-    if (p.act == XV_ACT_LRELU) al = (f32x4){p.alpha[0], p.alpha[0], p.alpha[0], p.alpha[0]};
-    else if (p.act == XV_ACT_PRELU) al = *reinterpret_cast<const f32x4 *>(p.alpha + gc);
+    if constexpr (ACT == XV_ACT_LRELU) al = (f32x4){p.alpha[0], p.alpha[0], p.alpha[0], p.alpha[0]};
+    else if constexpr (ACT == XV_ACT_PRELU) al = *reinterpret_cast<const f32x4 *>(p.alpha + gc);
     if (p.blk) {
         // POOL: the layer output is not stored; every 8-row block of the tile is reduced to per-channel (mean, M2) of its valid
         // rows, shifted by the block's first row (as the POOL epilogue of tdnn_gemm_bf16x3_kernel: same planes, same finalize).
@@ -183,7 +178,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams &p, float *T
                 n += keep[j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v = __builtin_fmaf(apply_act(tv[j][i] + bias[i], p.act, al[i]), sc[i], sh[i]);
+                    const float v = __builtin_fmaf(act_t<ACT>(tv[j][i] + bias[i], al[i]), sc[i], sh[i]);
                     if (j == 0) v0[i] = v;
                     else {
                         const float d = keep[j] != 0.f ? v - v0[i] : 0.f;       // (a select: a row past R may hold anything)
@@ -221,11 +216,40 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams &p, float *T
             const bool keep = Ms[lr] != 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float t = apply_act(z[i], p.act, al[i]) * sc[i] + sh[i];
+                const float t = act_t<ACT>(z[i], al[i]) * sc[i] + sh[i];
                 v[i] = keep ? t : 0.f;
             }
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p.y + (size_t)gr * p.ldy + gc));   // streamed once: no L2 write-allocate
         }
+    }
+}
+
+template <int BMT>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams &p, float *T, const uint8_t *Ms, long m0, int n0, int wr, int wc,
+                                                   int tid, const f32x16 &acc00, const f32x16 &acc01, const f32x16 &acc10,
+                                                   const f32x16 &acc11)
+{
+    constexpr int WROWS = BMT / 2;
+    constexpr int TLD = BN + 4;
+    const int lane = tid & 63;
+    {
+        const int col = wc * 64 + (lane & 31);
+        const int rowb = wr * WROWS + 4 * (lane >> 5);
+#pragma unroll
+        for (int rb = 0; rb < WROWS / 32; ++rb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = rowb + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+                T[lr * TLD + col] = rb == 0 ? acc00[reg] : acc10[reg];
+                T[lr * TLD + col + 32] = rb == 0 ? acc01[reg] : acc11[reg];
+            }
+    }
+    __syncthreads();
+    switch (p.act) {                                      // (uniform: one switch per thread, not one per element)
+    case XV_ACT_RELU: gemm_epilogue_rows_body<BMT, XV_ACT_RELU>(p, T, Ms, m0, n0, tid); break;
+    case XV_ACT_LRELU: gemm_epilogue_rows_body<BMT, XV_ACT_LRELU>(p, T, Ms, m0, n0, tid); break;
+    case XV_ACT_PRELU: gemm_epilogue_rows_body<BMT, XV_ACT_PRELU>(p, T, Ms, m0, n0, tid); break;
+    default: gemm_epilogue_rows_body<BMT, XV_ACT_NONE>(p, T, Ms, m0, n0, tid); break;
     }
 }
 

@@ -149,14 +149,14 @@ __device__ __forceinline__ void static_for(F &f)
     }
 }
 
-__device__ __forceinline__ float apply_act(float z, int act, float a)
+// the activation with its kind as a compile-time constant (the same expressions as apply_act of xv_kernels.hip: same bits)
+template <int ACT>
+__device__ __forceinline__ float act_t(float z, float a)
 {
-    switch (act) {
-    case XV_ACT_RELU: return fmaxf(z, 0.0f);
-    case XV_ACT_LRELU: return z > 0.0f ? z : a * z;
-    case XV_ACT_PRELU: return fmaxf(z, 0.0f) + a * fminf(z, 0.0f);
-    default: return z;
-    }
+    if constexpr (ACT == XV_ACT_RELU) return fmaxf(z, 0.0f);
+    else if constexpr (ACT == XV_ACT_LRELU) return z > 0.0f ? z : a * z;
+    else if constexpr (ACT == XV_ACT_PRELU) return fmaxf(z, 0.0f) + a * fminf(z, 0.0f);
+    else return z;
 }
 
 __device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 y)
@@ -215,6 +215,38 @@ __device__ __forceinline__ void xform_pair(const f32x4 (&d)[KT + 1], float m1, f
         static_assert(KT == 7 && j == 5, "pairs: (1, 2), (3, 4), (5, 6)");
         const f32x4 e = fma4(4.f, d[2], fma4(-5.f, d[4], d[6])), o = fma4(4.f, d[1], fma4(-5.f, d[3], d[5]));
         va = fma4(2.f, e, o); vb = fma4(-2.f, e, o);
+    }
+}
+
+// the rows of the finished tile: bias, activation, affine, row mask, one 16-B streamed store per (row, 4 columns).  The
+// activation kind is a template constant (one uniform switch per thread in the caller, none per element)
+template <int ACT>
+__device__ __forceinline__ void toom_store_rows(const ToomParams &p, const float *T, const uint8_t *Ms, long m0, int n0, int tid)
+{
+    const int cg = tid & 31, rp = tid >> 5;              // 4 columns; rows rp, rp + 8, ...
+    const int gc = n0 + cg * 4;
+    if (gc >= p.cout) return;                             // (cout % 4 == 0: a column group is inside or outside as a whole)
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + gc) : zero;
+    const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + gc) : one;
+    const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + gc) : zero;
+    f32x4 al = zero;
+    if constexpr (ACT == XV_ACT_LRELU) al = (f32x4){p.alpha[0], p.alpha[0], p.alpha[0], p.alpha[0]};
+    else if constexpr (ACT == XV_ACT_PRELU) al = *reinterpret_cast<const f32x4 *>(p.alpha + gc);
+#pragma unroll 4
+    for (int j = 0; j < BM / 8; ++j) {
+        const int lr = rp + 8 * j;
+        const long gr = m0 + lr;
+        if (gr >= p.R) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(T + lr * TLD + cg * 4);
+        const bool keep = Ms[lr] != 0;
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = act_t<ACT>(a[i] + bias[i], al[i]) * sc[i] + sh[i];
+            v[i] = keep ? t : 0.f;
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p.y + (size_t)gr * p.ldy + gc));   // streamed once: no L2 write-allocate
     }
 }
 
@@ -453,30 +485,11 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
         }
     }
     __syncthreads();
-    const int cg = tid & 31, rp = tid >> 5;              // 4 columns; rows rp, rp + 8, ...
-    const int gc = n0 + cg * 4;
-    if (gc >= p.cout) return;                             // (cout % 4 == 0: a column group is inside or outside as a whole)
-    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + gc) : zero;
-    const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + gc) : one;
-    const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4 *>(p.shift + gc) : zero;
-    f32x4 al = zero;
-    if (p.act == XV_ACT_LRELU) al = (f32x4){p.alpha[0], p.alpha[0], p.alpha[0], p.alpha[0]};
-    else if (p.act == XV_ACT_PRELU) al = *reinterpret_cast<const f32x4 *>(p.alpha + gc);
-#pragma unroll 4
-    for (int j = 0; j < BM / 8; ++j) {
-        const int lr = rp + 8 * j;
-        const long gr = m0 + lr;
-        if (gr >= p.R) continue;
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(T + lr * TLD + cg * 4);
-        const bool keep = Ms[lr] != 0;
-        f32x4 v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float t = apply_act(a[i] + bias[i], p.act, al[i]) * sc[i] + sh[i];
-            v[i] = keep ? t : 0.f;
-        }
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p.y + (size_t)gr * p.ldy + gc));   // streamed once: no L2 write-allocate
+    switch (p.act) {
+    case XV_ACT_RELU: toom_store_rows<XV_ACT_RELU>(p, T, Ms, m0, n0, tid); break;
+    case XV_ACT_LRELU: toom_store_rows<XV_ACT_LRELU>(p, T, Ms, m0, n0, tid); break;
+    case XV_ACT_PRELU: toom_store_rows<XV_ACT_PRELU>(p, T, Ms, m0, n0, tid); break;
+    default: toom_store_rows<XV_ACT_NONE>(p, T, Ms, m0, n0, tid); break;
     }
 }
 
