@@ -52,7 +52,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 18). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 19). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -166,6 +166,15 @@ int xv_tdnn_layer_bf16x3(const void *x, int x_format, int64_t R, int cin, int ld
                          const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation,
                          int cout, const uint8_t *row_valid, void *y, int y_format, int ldy, float *y_preact, int ldpre,
                          void *stream);
+/* The same layer with fp32 rows out, and the column sums of that output for free: the epilogue also leaves, per 128-row tile,
+ * [sum_rows y | sum_rows y * sum_r] in double in `workspace` (xv_col_sums_workspace_bytes(R, cout) bytes; merged by
+ * xv_col_sums_merge_f32 / xv_bn_act_backward_parts_f32).  The training step calls it as the input-gradient GEMM of a layer
+ * (tf.gradients of conv1d, local/tf/models.py:112): y = dL/dh of the layer below, sum_r = that layer's activation output,
+ * and the two sums are what its BN backward starts from -- no separate pass over y.  cout % 8 == 0. */
+int xv_tdnn_layer_bf16x3_sums(const void *x, int x_format, int64_t R, int cin, int ldx, const void *wt, const float *bias,
+                              const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K,
+                              int dilation, int cout, const uint8_t *row_valid, float *y, int ldy, const float *sum_r,
+                              int ld_sum_r, void *workspace, void *stream);
 /* Last frame-level layer fused with the first half of statistics pooling (models.py:66-76 / 482-486 in one pass):
  * the same GEMM as xv_tdnn_layer_bf16x3, but instead of storing y[R, Cout] the epilogue reduces every block of 8
  * consecutive rows (global rows 8i..8i+7, valid rows only) to per-channel (mean, M2 = sum (v-mean)^2) and writes
@@ -348,6 +357,25 @@ int xv_bn_act_backward_split_f32(const float *dh, const float *r, int ld, int64_
                                  const float *sum_dh_r, const float *mean, const float *var, const float *gamma, float eps,
                                  float n_frames, int act_kind, float act_alpha, const uint8_t *row_valid, float *dgamma,
                                  float *dbeta, float *coef_ws, float *dz, void *dz_split, void *stream);
+/* The same from the PARTIAL column sums a producer left in `sums_workspace` (xv_col_sums_workspace_bytes(R, c) bytes: per 128 rows
+ * [sum dh | sum dh*r] in double -- written by xv_tdnn_layer_bf16x3_sums, the input-gradient GEMM that produced dh): merge and
+ * coefficients in one launch, no pass over dh for the sums.  tf.gradients of tf.layers.batch_normalization(training=True),
+ * local/tf/models.py:66-68,109-113. */
+int xv_bn_act_backward_parts_f32(const float *dh, const float *r, int ld, int64_t R, int c, const void *sums_workspace,
+                                 const float *mean, const float *var, const float *gamma, float eps, float n_frames,
+                                 int act_kind, float act_alpha, const uint8_t *row_valid, float *dgamma, float *dbeta,
+                                 float *coef_ws, float *dz, void *dz_split, void *stream);
+/* Merge of such partial sums alone: sum_a[c], sum_ab[c] (sum_ab may be NULL) -- what xv_col_sums_f32 returns for the same rows. */
+int xv_col_sums_merge_f32(const void *sums_workspace, int64_t R, int c, float *sum_a, float *sum_ab, void *stream);
+/* Backward of [statistics pooling -> BN -> activation] of the LAST frame-level layer in two launches: the gradient that reaches
+ * h = BN(r) comes from the pooling alone (local/tf/models.py:75-76), so the BN backward's column sums follow from per-chunk numbers
+ * (pooled = [mu | sig], dpooled, chunk_moments = xv_chunk_moments_f32 of r: [mean | biased var] per chunk) and dh is formed on the
+ * fly, never stored.  Writes dgamma, dbeta, dz (gap rows and rows outside every chunk zero) and optionally dz in the split format. */
+int xv_pool_bn_act_backward_f32(const float *h, const float *r, int ld, int c, const int32_t *row_start, const int32_t *row_len,
+                                int nchunks, int64_t R, const float *pooled, const float *dpooled, const float *chunk_moments,
+                                const float *mean, const float *var, const float *gamma, float eps, float n_frames,
+                                int act_kind, float act_alpha, float *dgamma, float *dbeta, float *coef_ws, float *dz,
+                                void *dz_split, void *stream);
 /* Gradient of statistics pooling: dh[t,c] = dmu[c]/T + dsig[c]*(h[t,c]-mu[c])/(T*sig[c]); dh gap rows are zeroed. */
 int xv_pool_backward_f32(const float *h, int ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
                          int64_t R, const float *pooled, const float *dpooled, float *dh, void *stream);

@@ -614,6 +614,121 @@ def test_bf16x3_step_with_and_without_split_k1_inputs(env, monkeypatch):
 
 
 
+def test_pool_bn_act_backward_is_the_three_pass_chain(env):
+    """xv_pool_bn_act_backward_f32 (the last frame-level layer's backward: pooling gradient, BN, activation in two launches, the
+    column sums from per-chunk numbers) against the chain it replaces -- pool_backward, col_sums, bn_act_backward -- on a layout
+    with gap rows, ragged chunk lengths and tail rows; split copy included."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(23)
+    for C, lens, gap in ((64, [37, 50, 8, 129], 3), (1536, [211] * 6, 3), (512, [300, 140], 4)):
+        # (a single chunk would be degenerate: BN over the frames the pooling normalises again -- the true dz is zero, both forms noise)
+        starts, pos = [], gap
+        for n in lens:
+            pos = (pos + 7) // 8 * 8
+            starts.append(pos); pos += n + gap
+        R = pos + 5
+        valid = torch.zeros(R, dtype=torch.uint8)
+        for a, n in zip(starts, lens):
+            valid[a:a + n] = 1
+        valid = valid.to(dev)
+        rs, rl = torch.tensor(starts, dtype=torch.int32, device=dev), torch.tensor(lens, dtype=torch.int32, device=dev)
+        B = len(lens)
+        r = torch.relu(torch.randn((R, C), generator=g)).to(dev) * valid[:, None]
+        cm = torch.empty((B, 2 * C), device=dev)
+        hiplib.chunk_moments(r, rs, rl, B, max(lens), cm)
+        mean, var = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        hiplib.merge_moments(cm, rl, B, mean, var)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+        gamma[3] = 0.0                                                    # a dead channel: h constant, sig = sqrt(eps)
+        scale, shift = hiplib.fold_bn(gamma, beta, mean, var, 1e-3)
+        h = torch.empty_like(r)
+        hiplib.rows_affine(r, scale, shift, valid, h)
+        pooled = torch.empty((B, 2 * C), device=dev)
+        hiplib.stats_pool(h, rs, rl, B, max(lens), 512, 1e-5, pooled, hiplib._ws(hiplib.stats_pool_workspace_bytes(C, B, max(lens), 512), dev))
+        dpooled = torch.randn((B, 2 * C), generator=g).to(dev)
+        n_frames = float(sum(lens))
+        # the chain
+        dh = torch.empty_like(h)
+        hiplib.pool_backward(h, rs, rl, B, pooled, dpooled, dh)
+        s1, s2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        hiplib.col_sums(dh, r, s1, s2)
+        dg0, db0, dz0 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty_like(r)
+        hiplib.bn_act_backward(dh, r, s1, s2, mean, var, gamma, 1e-3, n_frames, 1, 0.0, valid, dg0, db0, dz0)
+        # the fused form
+        for split in (None, hiplib.SplitBuf(R + 50, C, dev) if C % 32 == 0 else None):
+            dg1, db1, dz1 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.full_like(r, 7.0)
+            hiplib.pool_bn_act_backward(h, r, rs, rl, B, pooled, dpooled, cm, mean, var, gamma, 1e-3, n_frames, 1, 0.0, dg1, db1, dz1,
+                                        dz_split=split)
+            rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+            assert rel(db1, db0) < 1e-6 and rel(dg1, dg0) < 2e-6 and rel(dz1, dz0) < 2e-6, (C, rel(db1, db0), rel(dg1, dg0), rel(dz1, dz0))
+            assert bool((dz1[valid == 0] == 0).all())
+            if split is not None:
+                ref = hiplib.SplitBuf(R + 50, C, dev)
+                hiplib.split_encode(dz1, ref, rows=R)
+                off, nb = hiplib.SPLIT_PAD_BEFORE * split.row_bytes, R * split.row_bytes
+                assert torch.equal(split.base[off:off + nb], ref.base[off:off + nb])
+
+
+def test_input_gradient_gemm_leaves_the_column_sums(env):
+    """xv_tdnn_layer_bf16x3_sums: the fp32 rows are those of xv_tdnn_layer_bf16x3 bit for bit, and the partial sums its epilogue
+    leaves merge to what xv_col_sums_f32 computes from those rows (fp32 input and split input, K = 1 and K = 5, ragged R)."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(29)
+    for R, cin, cout, K, split_in in ((1000, 64, 512, 5, False), (333, 1536, 512, 1, True), (4100, 512, 24 * 8, 7, False)):
+        x = torch.randn((R, cin), generator=g).to(dev)
+        w = (torch.randn((K, cin, cout), generator=g) / (K * cin) ** 0.5).to(dev)
+        wp = hiplib.pack_weights_bf16x3(w)
+        valid = (torch.rand(R, generator=g) < 0.9).to(torch.uint8).to(dev)
+        rr = torch.relu(torch.randn((R, cout), generator=g)).to(dev)
+        xin = x
+        if split_in:
+            xin = hiplib.SplitBuf(R + 50, cin, dev)
+            hiplib.split_encode(x, xin, rows=R)
+        y0, y1 = torch.empty((R, cout), device=dev), torch.empty((R, cout), device=dev)
+        hiplib.tdnn_layer3(xin, R, wp, None, None, None, 0, None, 1, valid, y0)
+        ws = hiplib.col_sums_workspace(R, cout, dev)
+        hiplib.tdnn_layer3_sums(xin, R, wp, 1, valid, y1, rr, ws)
+        assert torch.equal(y0, y1)
+        a0, b0, a1, b1 = (torch.empty(cout, device=dev) for _ in range(4))
+        hiplib.col_sums(y0, rr, a0, b0)
+        hiplib.col_sums_merge(ws, R, cout, a1, b1)
+        scale = float(y0.abs().double().sum(0).max())
+        assert float((a1.double() - a0.double()).abs().max()) < 1e-6 * scale and float((b1.double() - b0.double()).abs().max()) < 2e-6 * scale
+        # and straight into the BN backward: the same dz as from the merged sums
+        mean, var, gamma = torch.randn(cout, generator=g).to(dev), (torch.rand(cout, generator=g) + 0.1).to(dev), (torch.rand(cout, generator=g) + 0.5).to(dev)
+        outs = []
+        for parts in (False, True):
+            dg, db, dz = torch.empty(cout, device=dev), torch.empty(cout, device=dev), torch.empty((R, cout), device=dev)
+            if parts:
+                hiplib.bn_act_backward_parts(y1, rr, ws, mean, var, gamma, 1e-3, float(R), 1, 0.0, valid, dg, db, dz)
+            else:
+                hiplib.bn_act_backward(y1, rr, a1, b1, mean, var, gamma, 1e-3, float(R), 1, 0.0, valid, dg, db, dz)
+            outs.append((dg, db, dz))
+        assert all(torch.equal(p_, q_) for p_, q_ in zip(*outs))
+
+
+def test_bf16x3_step_with_and_without_fused_column_sums(env, monkeypatch):
+    """A bf16x3 step with the BN-backward sums taken from their producers (default) against the same step with the separate
+    col_sums passes (XVECTOR_TRAIN_FUSED_SUMS=0): same loss, gradients within fp32 rounding of each other; and the fused step
+    still matches fp64 autograd like the unfused one (test_bf16x3_training_gradients runs on the default)."""
+    topo, w, rng = _setup(env, "ModelWithoutDropout", seed=7)
+    x = (rng.standard_normal((8, 157, 23)) * 3).astype(np.float32)
+    lab = rng.integers(0, 10, 8)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("XVECTOR_TRAIN_FUSED_SUMS", flag)
+        tr = env["trainer"].Trainer(w, topo, precision="bf16x3")
+        assert tr.fused_sums == (flag == "1")
+        loss, acc, grads = tr.gradients(x, lab)
+        res.append((loss, {n: g.cpu().numpy().astype(np.float64) for n, g in grads.items()}))
+    assert res[0][0] == res[1][0]
+    for n in res[0][1]:
+        a, b = res[0][1][n], res[1][1][n]
+        assert np.linalg.norm(a - b) <= 2e-5 * max(np.linalg.norm(b), 1e-12), n
+
+
 def test_training_arithmetic_is_chosen_by_a_gradient_probe(env, tmp_path, caplog):
     """trainer.select_trainer: the first minibatch's gradients in bf16x3 and in exact fp32 decide the arithmetic of a training run
     (train_dnn.py's default, XVECTOR_TRAIN_PRECISION=auto).  A trained-like checkpoint keeps bf16x3 with a margin; a limit of zero

@@ -524,6 +524,12 @@ struct Gemm3Params {
     int ldpre;
     float *blk;           // POOL epilogue: per-8-row-block (mean, M2) planes [ceil(R/8)][2][cout]
     int n_mt, n_nt, n_chunks;
+    // column sums of the fp32 output (training: the BN backward of the layer BELOW needs sum y and sum y * r over the rows, y = the
+    // input gradient this launch produces): per row tile partials cs_part[mt][{sum y, sum y r}][cout] in double, merged in order by
+    // xv_col_sums_merge_f32.  cs_r: the other factor, fp32 rows of stride cs_ldr.  NULL = off.
+    const float *cs_r;
+    int cs_ldr;
+    double *cs_part;
 };
 
 #define XV_GLDS16_OFF(gptr, lptr, imm)                                                                          \
@@ -1158,6 +1164,26 @@ __global__ __launch_bounds__(WM * 128, (S16 && WM == 4) ? 1 : 2) void tdnn_gemm_
         else run(std::integral_constant<int, 0>{});
         return;
     }
+    // column sums (training, see Gemm3Params::cs_part): the rows of the other factor are fetched before anything else so that
+    // their latency is paid once; cout % 8 == 0 is the launcher's condition, so a column group is inside or outside as a whole
+    const bool sums = p.cs_part != nullptr;             // (uniform)
+    f32x4 rq[8][2];
+    float cs1[8], cs2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cs1[i] = cs2[i] = 0.f;
+    if (sums) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long gr = m0 + (tid >> 4) + (NT / 16) * j;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            rq[j][0] = rq[j][1] = zero4;
+            if (gr < p.R && full) {
+                const float *rr = p.cs_r + (size_t)gr * p.cs_ldr + gc0;
+                rq[j][0] = *reinterpret_cast<const f32x4 *>(rr);
+                rq[j][1] = *reinterpret_cast<const f32x4 *>(rr + 4);
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int lr = (tid >> 4) + (NT / 16) * j;
@@ -1171,6 +1197,13 @@ __global__ __launch_bounds__(WM * 128, (S16 && WM == 4) ? 1 : 2) void tdnn_gemm_
         for (int i = 0; i < 8; ++i) {
             z[i] = (i < 4 ? t0[i] : t1[i - 4]) + bias[i];
             v[i] = (activate(z[i], al[i]) * sc[i] + sh[i]) * keep;
+        }
+        if (sums) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cs1[i] += v[i];
+                cs2[i] = __builtin_fmaf(v[i], i < 4 ? rq[j][0][i] : rq[j][1][i - 4], cs2[i]);
+            }
         }
         if (p.ypre) {
             float *o = p.ypre + (size_t)gr * p.ldpre + gc0;
@@ -1210,6 +1243,26 @@ __global__ __launch_bounds__(WM * 128, (S16 && WM == 4) ? 1 : 2) void tdnn_gemm_
                         if (gc0 + i < p.cout) o[i] = v[i];
                 }
             }
+        }
+    }
+    if (sums) {
+        // a thread holds 8 rows x 8 columns (fp32); the NT / 16 row groups of a column are added in double, in group order
+        constexpr int NG = NT / 16;
+        __syncthreads();                                // every thread has read its rows of T
+        double *D = reinterpret_cast<double *>(lds);    // [2][NG][BN]
+        const int g = tid >> 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            D[(0 * NG + g) * BN + cg * 8 + i] = (double)cs1[i];
+            D[(1 * NG + g) * BN + cg * 8 + i] = (double)cs2[i];
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid >> 7, col = tid & (BN - 1);
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) a += D[(which * NG + k) * BN + col];
+            if (n0 + col < p.cout) p.cs_part[((size_t)mt * 2 + which) * p.cout + n0 + col] = a;
         }
     }
 }
@@ -1295,6 +1348,7 @@ int launch_gemm3(const Gemm3Params &p0, hipStream_t st)
         const bool big_enough = ((p.R + 255) / 256) * p.n_nt >= 512;          // two rounds of 256 CUs
         if (want == 256 || (want == 0 && p.K >= 5 && big_enough && !s16)) wm = 4;
     }
+    if (p.cs_part) wm = 2;                                   // one partial per 128 rows: the split xv_col_sums_merge_f32 walks
     p.n_mt = (int)((p.R + wm * 64 - 1) / (wm * 64));
     const Gemm3Kernel *k = find_gemm3(kt, p.blk != nullptr, wm, s16);
     if (!k) return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3: no kernel for this configuration");
@@ -1936,7 +1990,7 @@ void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
 void xv_internal_gemm8_xcd_columns(int value);    // xv_gemm8.hip
 void xv_internal_first_tiles(int tiles);          // xv_first.hip
 
-int xv_version(void) { return 18; }
+int xv_version(void) { return 19; }
 
 int xv_set_tuning(int key, int value)
 {
@@ -2177,6 +2231,25 @@ int xv_tdnn_layer_bf16x3(const void *x, int x_format, int64_t R, int cin, int ld
     p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
     p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid;
     p.y = y; p.y_split = y_format == XV_FMT_SPLIT; p.ldy = ldy; p.ypre = y_preact; p.ldpre = ldpre;
+    return launch_gemm3(p, (hipStream_t)stream);
+}
+
+int xv_tdnn_layer_bf16x3_sums(const void *x, int x_format, int64_t R, int cin, int ldx, const void *wt, const float *bias,
+                              const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation,
+                              int cout, const uint8_t *row_valid, float *y, int ldy, const float *sum_r, int ld_sum_r, void *workspace,
+                              void *stream)
+{
+    if (!x || !wt || !y || !sum_r || !workspace) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3_sums: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3_sums: unknown act_kind");
+    if (x_format != XV_FMT_F32 && x_format != XV_FMT_SPLIT) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3_sums: unknown tensor format");
+    if ((cout & 7) || (ldy & 3) || (ld_sum_r & 3) || ld_sum_r < cout || (((uintptr_t)sum_r) & 15) || (((uintptr_t)workspace) & 7))
+        return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3_sums: needs cout % 8 == 0, row strides % 4 == 0 and aligned pointers");
+    Gemm3Params p{};
+    p.x = x; p.x_split = x_format == XV_FMT_SPLIT; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wt = (const uint8_t *)wt;
+    p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
+    p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid;
+    p.y = y; p.y_split = 0; p.ldy = ldy;
+    p.cs_r = sum_r; p.cs_ldr = ld_sum_r; p.cs_part = (double *)workspace;
     return launch_gemm3(p, (hipStream_t)stream);
 }
 

@@ -394,6 +394,47 @@ __global__ void bn_coeffs_kernel(const float *sum_dh, const float *sum_dh_r, con
     coefC[c] = (float)(-g * rstd * db / N + g * rstd * rstd * (double)mean[c] * dg / N);
 }
 
+// col_sums_merge_kernel and bn_coeffs_kernel in one launch: the partial column sums of (dh, dh * r) -- written per 128-row tile by the
+// input-gradient GEMM that produced dh (xv_tdnn_layer_bf16x3_sums) or by col_sums_kernel -- are merged in the same fixed order and the
+// thread that holds a channel's two sums goes on to the BN-backward coefficients.
+__global__ __launch_bounds__(64 * CSM_GROUPS) void col_sums_merge_coeffs_kernel(const double *__restrict__ part, int C, int nsplit,
+                                                                                const float *mean, const float *var, const float *gamma,
+                                                                                float eps, float n_frames, float *dgamma, float *dbeta,
+                                                                                float *coefA, float *coefB, float *coefC)
+{
+    __shared__ double sh[2][CSM_GROUPS][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, sab = 0.0;
+    if (c < C) {
+        for (int j = g; j < nsplit; j += CSM_GROUPS) {
+            s += part[(size_t)j * 2 * C + c];
+            sab += part[(size_t)j * 2 * C + C + c];
+        }
+    }
+    sh[0][g][cl] = s;
+    sh[1][g][cl] = sab;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        double ta = 0.0, tb = 0.0;
+#pragma unroll
+        for (int k = 0; k < CSM_GROUPS; ++k) {
+            ta += sh[0][k][cl];
+            tb += sh[1][k][cl];
+        }
+        // (the sums pass through fp32 exactly as they do between col_sums_merge_kernel and bn_coeffs_kernel: same bits either way)
+        const double db = (double)(float)ta, sdr = (double)(float)tb;
+        const double rstd = 1.0 / sqrt((double)var[c] + (double)eps);
+        const double dg = rstd * (sdr - (double)mean[c] * db);
+        const double gm = gamma[c], N = n_frames;
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+        coefA[c] = (float)(gm * rstd);
+        coefB[c] = (float)(-gm * rstd * rstd * dg / N);
+        coefC[c] = (float)(-gm * rstd * db / N + gm * rstd * rstd * (double)mean[c] * dg / N);
+    }
+}
+
 __global__ void bn_act_backward_kernel(const float *__restrict__ dh, const float *__restrict__ r, long R, int C, int ld,
                                        const float *__restrict__ coefA, const float *__restrict__ coefB,
                                        const float *__restrict__ coefC, int act, float alpha, const uint8_t *__restrict__ valid,
@@ -459,6 +500,85 @@ __global__ void pool_backward_kernel(const float *__restrict__ h, int ldh, int C
         const int t = (int)(i / C), c = (int)(i - (size_t)t * C);
         const size_t o = (base + t) * ldh + c;
         dh[o] = dmu[c] * invT + dsig[c] * (h[o] - mu[c]) * invT / sig[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The last frame-level layer's backward chain in two launches instead of six (memset, pool_backward, col_sums x 2, bn_coeffs,
+// bn_act_backward): the gradient that reaches h = BN(r) of that layer comes from the statistics pooling alone,
+//   dh[t,c] = dmu_b[c]/T + dsig_b[c] (h[t,c] - mu_b[c]) / (T sig_b[c])            (chunk b, T frames),
+// so the two column sums the BN backward needs follow from per-CHUNK numbers the forward pass already holds -- with h = s r + shift,
+// s = gamma rstd, and (m_b, v_b) the chunk moments of r (xv_chunk_moments_f32):
+//   sum_t dh        = sum_b dmu_b                            (the second term sums to zero inside a chunk)
+//   sum_t dh r      = sum_b [ dmu_b m_b + dsig_b s v_b / sig_b ]    (sum_t (h - mu_b) r = s T v_b)
+// -- no pass over the [R, C] matrices -- and dh itself never has to exist: the element-wise kernel forms it on the fly.
+__global__ void pool_bn_coeffs_kernel(const float *__restrict__ pooled, const float *__restrict__ dpooled, const float *__restrict__ cm,
+                                      int nchunks, const float *mean, const float *var, const float *gamma, float eps, float n_frames, int C,
+                                      float *dgamma, float *dbeta, float *coefA, float *coefB, float *coefC)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double rstd = 1.0 / sqrt((double)var[c] + (double)eps);
+    const double g = gamma[c], N = n_frames, s = g * rstd;
+    double db = 0.0, sdr = 0.0;
+    for (int b = 0; b < nchunks; ++b) {                    // fixed order: deterministic
+        const size_t o = (size_t)b * 2 * C + c;
+        const double dmu = dpooled[o], dsig = dpooled[o + C];
+        db += dmu;
+        sdr += dmu * (double)cm[o] + dsig * s * (double)cm[o + C] / (double)pooled[o + C];
+    }
+    const double dg = rstd * (sdr - (double)mean[c] * db);
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+    coefA[c] = (float)(g * rstd);
+    coefB[c] = (float)(-g * rstd * rstd * dg / N);
+    coefC[c] = (float)(-g * rstd * db / N + g * rstd * rstd * (double)mean[c] * dg / N);
+}
+
+// grid (C / 512, chunks, row groups); 128 threads x 4 channels.  A workgroup column also zeroes the gap rows that follow its
+// chunk (and, for chunk 0, the rows in front of it): the input-gradient GEMM reads them as halo.
+template <bool SPLIT>
+__global__ __launch_bounds__(128) void pool_bn_act_backward_kernel(const float *__restrict__ h, const float *__restrict__ r, int ld, int C,
+                                                                   const int *__restrict__ row_start, const int *__restrict__ row_len,
+                                                                   int nchunks, long R, const float *__restrict__ pooled,
+                                                                   const float *__restrict__ dpooled, const float *__restrict__ coefA,
+                                                                   const float *__restrict__ coefB, const float *__restrict__ coefC, int act,
+                                                                   float alpha, float *__restrict__ dz, uint8_t *__restrict__ dzs)
+{
+    const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const int b = blockIdx.y;
+    const long first = row_start[b], T = row_len[b];
+    const long lo = b == 0 ? 0 : first, hi = b + 1 < nchunks ? (long)row_start[b + 1] : R;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(coefA + c), kb = *reinterpret_cast<const f32x4 *>(coefB + c),
+                kc = *reinterpret_cast<const f32x4 *>(coefC + c);
+    const size_t po = (size_t)b * 2 * C + c;
+    const f32x4 mu = *reinterpret_cast<const f32x4 *>(pooled + po), sig = *reinterpret_cast<const f32x4 *>(pooled + po + C),
+                dmu = *reinterpret_cast<const f32x4 *>(dpooled + po), dsig = *reinterpret_cast<const f32x4 *>(dpooled + po + C);
+    const float invT = 1.0f / (float)T;
+    f32x4 g0, g1;                                           // dh = g0 + g1 (h - mu): the expression of pool_backward_kernel, per channel
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        g0[i] = dmu[i] * invT;
+        g1[i] = dsig[i] * invT / sig[i];
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long row = lo + blockIdx.z; row < hi; row += gridDim.z) {
+        const size_t o = (size_t)row * ld + c;
+        f32x4 out = zero;
+        if (row >= first && row < first + T) {
+            const f32x4 hv = *reinterpret_cast<const f32x4 *>(h + o), rv = *reinterpret_cast<const f32x4 *>(r + o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dh = g0[i] + g1[i] * (hv[i] - mu[i]);
+                float dr = a[i] * dh + kb[i] * rv[i] + kc[i];
+                if (act == XV_ACT_RELU) dr = rv[i] > 0.f ? dr : 0.f;
+                else if (act == XV_ACT_LRELU) dr = rv[i] > 0.f ? dr : alpha * dr;
+                out[i] = dr;
+            }
+        }
+        *reinterpret_cast<f32x4 *>(dz + o) = out;
+        if constexpr (SPLIT) store_split4(dzs, row, C, c, out);
     }
 }
 
@@ -698,6 +818,15 @@ int xv_col_sums_f32(const float *a, int lda, const float *b, int ldb, int64_t R,
     return tcheck("col_sums_merge_kernel");
 }
 
+int xv_col_sums_merge_f32(const void *workspace, int64_t R, int c, float *sum_a, float *sum_ab, void *stream)
+{
+    if (!workspace || !sum_a || R <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "col_sums_merge: bad argument");
+    const int splits = (int)((R + CS_ROWS - 1) / CS_ROWS);
+    hipLaunchKernelGGL(col_sums_merge_kernel, dim3((c + 63) / 64), dim3(64 * CSM_GROUPS), 0, (hipStream_t)stream, (const double *)workspace, c,
+                       splits, sum_a, sum_ab);
+    return tcheck("col_sums_merge_kernel");
+}
+
 int xv_merge_moments_f32(const float *chunk_mean_var, const int32_t *row_len, int nchunks, int c, float *mean, float *var, void *stream)
 {
     if (!chunk_mean_var || !row_len || !mean || !var || nchunks <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "merge_moments: bad argument");
@@ -739,19 +868,9 @@ int xv_bn_act_backward_f32(const float *dh, const float *r, int ld, int64_t R, i
                                         dgamma, dbeta, coef_ws, dz, nullptr, stream);
 }
 
-int xv_bn_act_backward_split_f32(const float *dh, const float *r, int ld, int64_t R, int c, const float *sum_dh, const float *sum_dh_r,
-                                 const float *mean, const float *var, const float *gamma, float eps, float n_frames, int act_kind,
-                                 float act_alpha, const uint8_t *row_valid, float *dgamma, float *dbeta, float *coef_ws, float *dz,
-                                 void *dz_split, void *stream)
+static int bn_act_backward_tail(const float *dh, const float *r, int ld, int64_t R, int c, int act_kind, float act_alpha,
+                                const uint8_t *row_valid, float *coef_ws, float *dz, void *dz_split, hipStream_t st)
 {
-    if (!dh || !r || !sum_dh || !sum_dh_r || !mean || !var || !gamma || !dgamma || !dbeta || !coef_ws || !dz || R <= 0 || c <= 0)
-        return tfail(XV_ERR_BAD_ARG, "bn_act_backward: bad argument");
-    if (act_kind == XV_ACT_PRELU) return tfail(XV_ERR_UNSUPPORTED, "bn_act_backward: PReLU training is not implemented");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, st, sum_dh, sum_dh_r, mean, var, gamma, eps, n_frames, c,
-                       dgamma, dbeta, coef_ws, coef_ws + c, coef_ws + 2 * c);
-    int rc = tcheck("bn_coeffs_kernel");
-    if (rc) return rc;
     const bool vec = !(c & 3) && !(ld & 3) && !(((uintptr_t)dh | (uintptr_t)r | (uintptr_t)dz | (uintptr_t)coef_ws) & 15);
     if (dz_split && (!vec || (c & 31) || (((uintptr_t)dz_split) & 15)))
         return tfail(XV_ERR_UNSUPPORTED, "bn_act_backward: the split copy needs c % 32 == 0 and 16-byte aligned fp32 rows");
@@ -768,6 +887,68 @@ int xv_bn_act_backward_split_f32(const float *dh, const float *r, int ld, int64_
     hipLaunchKernelGGL(bn_act_backward_kernel, dim3(gs_blocks((size_t)R * c)), dim3(256), 0, st, dh, r, (long)R, c, ld, coef_ws,
                        coef_ws + c, coef_ws + 2 * c, act_kind, act_alpha, row_valid, dz);
     return tcheck("bn_act_backward_kernel");
+}
+
+int xv_bn_act_backward_split_f32(const float *dh, const float *r, int ld, int64_t R, int c, const float *sum_dh, const float *sum_dh_r,
+                                 const float *mean, const float *var, const float *gamma, float eps, float n_frames, int act_kind,
+                                 float act_alpha, const uint8_t *row_valid, float *dgamma, float *dbeta, float *coef_ws, float *dz,
+                                 void *dz_split, void *stream)
+{
+    if (!dh || !r || !sum_dh || !sum_dh_r || !mean || !var || !gamma || !dgamma || !dbeta || !coef_ws || !dz || R <= 0 || c <= 0)
+        return tfail(XV_ERR_BAD_ARG, "bn_act_backward: bad argument");
+    if (act_kind == XV_ACT_PRELU) return tfail(XV_ERR_UNSUPPORTED, "bn_act_backward: PReLU training is not implemented");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, st, sum_dh, sum_dh_r, mean, var, gamma, eps, n_frames, c,
+                       dgamma, dbeta, coef_ws, coef_ws + c, coef_ws + 2 * c);
+    int rc = tcheck("bn_coeffs_kernel");
+    if (rc) return rc;
+    return bn_act_backward_tail(dh, r, ld, R, c, act_kind, act_alpha, row_valid, coef_ws, dz, dz_split, st);
+}
+
+int xv_bn_act_backward_parts_f32(const float *dh, const float *r, int ld, int64_t R, int c, const void *sums_workspace, const float *mean,
+                                 const float *var, const float *gamma, float eps, float n_frames, int act_kind, float act_alpha,
+                                 const uint8_t *row_valid, float *dgamma, float *dbeta, float *coef_ws, float *dz, void *dz_split,
+                                 void *stream)
+{
+    if (!dh || !r || !sums_workspace || !mean || !var || !gamma || !dgamma || !dbeta || !coef_ws || !dz || R <= 0 || c <= 0)
+        return tfail(XV_ERR_BAD_ARG, "bn_act_backward_parts: bad argument");
+    if (act_kind == XV_ACT_PRELU) return tfail(XV_ERR_UNSUPPORTED, "bn_act_backward: PReLU training is not implemented");
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = (int)((R + CS_ROWS - 1) / CS_ROWS);
+    hipLaunchKernelGGL(col_sums_merge_coeffs_kernel, dim3((c + 63) / 64), dim3(64 * CSM_GROUPS), 0, st, (const double *)sums_workspace, c,
+                       splits, mean, var, gamma, eps, n_frames, dgamma, dbeta, coef_ws, coef_ws + c, coef_ws + 2 * c);
+    int rc = tcheck("col_sums_merge_coeffs_kernel");
+    if (rc) return rc;
+    return bn_act_backward_tail(dh, r, ld, R, c, act_kind, act_alpha, row_valid, coef_ws, dz, dz_split, st);
+}
+
+int xv_pool_bn_act_backward_f32(const float *h, const float *r, int ld, int c, const int32_t *row_start, const int32_t *row_len,
+                                int nchunks, int64_t R, const float *pooled, const float *dpooled, const float *chunk_moments,
+                                const float *mean, const float *var, const float *gamma, float eps, float n_frames, int act_kind,
+                                float act_alpha, float *dgamma, float *dbeta, float *coef_ws, float *dz, void *dz_split, void *stream)
+{
+    if (!h || !r || !row_start || !row_len || !pooled || !dpooled || !chunk_moments || !mean || !var || !gamma || !dgamma || !dbeta ||
+        !coef_ws || !dz || nchunks <= 0 || nchunks > 65535 || R <= 0 || c <= 0)
+        return tfail(XV_ERR_BAD_ARG, "pool_bn_act_backward: bad argument");
+    if (act_kind == XV_ACT_PRELU) return tfail(XV_ERR_UNSUPPORTED, "pool_bn_act_backward: PReLU training is not implemented");
+    if ((c & 3) || (ld & 3) || (((uintptr_t)h | (uintptr_t)r | (uintptr_t)dz | (uintptr_t)coef_ws | (uintptr_t)pooled | (uintptr_t)dpooled) & 15))
+        return tfail(XV_ERR_UNSUPPORTED, "pool_bn_act_backward: needs c % 4 == 0 and 16-byte aligned rows");
+    if (dz_split && ((c & 31) || (((uintptr_t)dz_split) & 15)))
+        return tfail(XV_ERR_UNSUPPORTED, "pool_bn_act_backward: the split copy needs c % 32 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pool_bn_coeffs_kernel, dim3((c + 63) / 64), dim3(64), 0, st, pooled, dpooled, chunk_moments, nchunks, mean, var, gamma,
+                       eps, n_frames, c, dgamma, dbeta, coef_ws, coef_ws + c, coef_ws + 2 * c);
+    int rc = tcheck("pool_bn_coeffs_kernel");
+    if (rc) return rc;
+    const int zs = nchunks >= 2048 ? 1 : (2048 + nchunks - 1) / nchunks < 16 ? (2048 + nchunks - 1) / nchunks : 16;
+    const dim3 grid((unsigned)((c + 511) / 512), (unsigned)nchunks, (unsigned)zs);
+    if (dz_split)
+        hipLaunchKernelGGL(pool_bn_act_backward_kernel<true>, grid, dim3(128), 0, st, h, r, ld, c, row_start, row_len, nchunks, (long)R, pooled,
+                           dpooled, coef_ws, coef_ws + c, coef_ws + 2 * c, act_kind, act_alpha, dz, (uint8_t *)dz_split);
+    else
+        hipLaunchKernelGGL(pool_bn_act_backward_kernel<false>, grid, dim3(128), 0, st, h, r, ld, c, row_start, row_len, nchunks, (long)R, pooled,
+                           dpooled, coef_ws, coef_ws + c, coef_ws + 2 * c, act_kind, act_alpha, dz, (uint8_t *)nullptr);
+    return tcheck("pool_bn_act_backward_kernel");
 }
 
 int xv_pool_backward_f32(const float *h, int ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks, int64_t R,

@@ -10,13 +10,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
            "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_fc_splitk_workspace_bytes", "xv_fc_splitk_f32", "xv_chunk_average_f32",
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_pack_weights_bf16x3_many", "xv_split_row_bytes", "xv_split_encode_f32",
-           "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_fc_bf16x3",
+           "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_tdnn_layer_bf16x3_sums", "xv_fc_bf16x3",
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32", "xv_tdnn_layer_pool_f32",
            "xv_packed_weights_rows_f32_floats", "xv_pack_weights_rows_f32", "xv_tdnn_layer_rows_f32",
            "xv_toom_supported", "xv_packed_weights_toom_f32_floats", "xv_pack_weights_toom_f32", "xv_tdnn_layer_toom_f32",
@@ -28,6 +28,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_rows_affine_split_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_bn_act_backward_split_f32", "xv_pool_backward_f32",
+           "xv_bn_act_backward_parts_f32", "xv_col_sums_merge_f32", "xv_pool_bn_act_backward_f32",
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32", "xv_pack_minibatch_f32",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
@@ -179,6 +180,14 @@ def load():
     lib.xv_bn_act_backward_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp]
     lib.xv_bn_act_backward_split_f32.restype = ci
     lib.xv_bn_act_backward_split_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp, vp]
+    lib.xv_tdnn_layer_bf16x3_sums.restype = ci
+    lib.xv_tdnn_layer_bf16x3_sums.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp, ci, vp, vp]
+    lib.xv_bn_act_backward_parts_f32.restype = ci
+    lib.xv_bn_act_backward_parts_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp, vp]
+    lib.xv_col_sums_merge_f32.restype = ci
+    lib.xv_col_sums_merge_f32.argtypes = [vp, i64, ci, vp, vp, vp]
+    lib.xv_pool_bn_act_backward_f32.restype = ci
+    lib.xv_pool_bn_act_backward_f32.argtypes = [vp, vp, ci, ci, vp, vp, ci, i64, vp, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp]
     lib.xv_pool_backward_f32.restype = ci
     lib.xv_pool_backward_f32.argtypes = [vp, ci, ci, vp, vp, ci, i64, vp, vp, vp, vp]
     lib.xv_softmax_ce_f32.restype = ci
@@ -507,6 +516,36 @@ def tdnn_layer3(x, R, w, bias, scale, shift, act, alpha, dilation, row_valid, y,
     _check(lib.xv_tdnn_layer_bf16x3(xp, FMT_SPLIT if xs else FMT_F32, int(R), w.cin, ldx, _ptr(w.wt), _ptr(bias), _ptr(scale),
                                     _ptr(shift), int(act), _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), yp,
                                     FMT_SPLIT if ys else FMT_F32, ldy, _ptr(y_preact), ldpre, _stream()), "xv_tdnn_layer_bf16x3")
+
+
+def col_sums_workspace(rows, c, device):
+    """Partial-sum workspace of xv_col_sums_f32 / xv_tdnn_layer_bf16x3_sums: [ceil(rows / 128)][2][c] doubles."""
+    return _ws(load().xv_col_sums_workspace_bytes(int(rows), int(c)), device)
+
+
+def tdnn_layer3_sums(x, R, w, dilation, row_valid, y, sum_r, workspace):
+    """xv_tdnn_layer_bf16x3_sums: the plain GEMM y = x * w (no bias / activation: the input-gradient GEMM of the training step),
+    fp32 rows out, and per 128-row tile the partial column sums [sum y | sum y * sum_r] in ``workspace`` (col_sums_workspace)."""
+    lib = require_gpu()
+    assert isinstance(w, Packed3) and supports_sums(w.cout)
+    xs = isinstance(x, SplitBuf)
+    if xs:
+        assert x.fmt == FMT_SPLIT and x.channels == w.cin and x.rows >= R
+        xp, ldx = ctypes.c_void_p(x.ptr), 0
+    else:
+        _rows2d(x, "x"); assert x.shape[1] == w.cin and x.shape[0] >= R
+        xp, ldx = _ptr(x), x.stride(0)
+    _rows2d(y, "y"); assert y.shape[1] == w.cout and y.shape[0] >= R
+    _rows2d(sum_r, "sum_r"); assert sum_r.shape[1] == w.cout and sum_r.shape[0] >= R
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_layer_bf16x3_sums(xp, FMT_SPLIT if xs else FMT_F32, int(R), w.cin, ldx, _ptr(w.wt), None, None, None, ACT_NONE,
+                                         None, w.K, int(dilation), w.cout, _ptr(row_valid), _ptr(y), y.stride(0), _ptr(sum_r),
+                                         sum_r.stride(0), _ptr(workspace), _stream()), "xv_tdnn_layer_bf16x3_sums")
+
+
+def supports_sums(cout):
+    return cout % 8 == 0
 
 
 POOL_BLOCK_ROWS = 8      # chunks fed to tdnn_layer_pool must start on a multiple of this many rows
@@ -922,6 +961,44 @@ def bn_act_backward(dh, r, sum_dh, sum_dh_r, mean, var, gamma, eps, n_frames, ac
                                             _ptr(row_valid), _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_f32(dz, "dz")),
                                             ctypes.c_void_p(dz_split.ptr) if dz_split is not None else None, _stream()),
            "xv_bn_act_backward_split_f32")
+
+
+def bn_act_backward_parts(dh, r, workspace, mean, var, gamma, eps, n_frames, act, alpha, row_valid, dgamma, dbeta, dz, dz_split=None):
+    """bn_act_backward from the partial sums a producer left in ``workspace`` (tdnn_layer3_sums): no col_sums pass."""
+    import torch
+    lib = require_gpu()
+    R, c = dh.shape
+    coef = torch.empty(3 * c, dtype=torch.float32, device=dh.device)
+    if dz_split is not None:
+        assert dz_split.fmt == FMT_SPLIT and dz_split.channels == c and dz_split.rows >= R
+    _check(lib.xv_bn_act_backward_parts_f32(_ptr(_f32(dh, "dh")), _ptr(_f32(r, "r")), dh.stride(0), R, c, _ptr(workspace), _ptr(mean),
+                                            _ptr(var), _ptr(gamma), float(eps), float(n_frames), int(act), float(alpha), _ptr(row_valid),
+                                            _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_f32(dz, "dz")),
+                                            ctypes.c_void_p(dz_split.ptr) if dz_split is not None else None, _stream()),
+           "xv_bn_act_backward_parts_f32")
+
+
+def col_sums_merge(workspace, rows, c, sum_a, sum_ab=None):
+    _check(require_gpu().xv_col_sums_merge_f32(_ptr(workspace), int(rows), int(c), _ptr(sum_a), _ptr(sum_ab), _stream()),
+           "xv_col_sums_merge_f32")
+
+
+def pool_bn_act_backward(h, r, row_start, row_len, nchunks, pooled, dpooled, chunk_moments_r, mean, var, gamma, eps, n_frames, act, alpha,
+                         dgamma, dbeta, dz, dz_split=None):
+    """Backward of [statistics pooling -> BN -> activation] of the last frame-level layer (xv_pool_bn_act_backward_f32)."""
+    import torch
+    lib = require_gpu()
+    R, c = r.shape
+    coef = torch.empty(3 * c, dtype=torch.float32, device=r.device)
+    assert h.shape == r.shape and h.stride(0) == r.stride(0) == dz.stride(0)
+    if dz_split is not None:
+        assert dz_split.fmt == FMT_SPLIT and dz_split.channels == c and dz_split.rows >= R
+    _check(lib.xv_pool_bn_act_backward_f32(_ptr(_f32(h, "h")), _ptr(_f32(r, "r")), r.stride(0), c, _ptr(row_start), _ptr(row_len),
+                                           int(nchunks), R, _ptr(_f32(pooled, "pooled")), _ptr(_f32(dpooled, "dpooled")),
+                                           _ptr(_f32(chunk_moments_r, "chunk_moments")), _ptr(mean), _ptr(var), _ptr(gamma), float(eps),
+                                           float(n_frames), int(act), float(alpha), _ptr(dgamma), _ptr(dbeta), _ptr(coef),
+                                           _ptr(_f32(dz, "dz")), ctypes.c_void_p(dz_split.ptr) if dz_split is not None else None,
+                                           _stream()), "xv_pool_bn_act_backward_f32")
 
 
 def pool_backward(h, row_start, row_len, nchunks, pooled, dpooled, dh):

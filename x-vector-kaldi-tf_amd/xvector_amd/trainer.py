@@ -36,6 +36,9 @@ class Trainer(object):
         self.attention = tp.is_attention(topo)              # self-attentive pooling (models.py:1036-1050)
         self.precision = precision
         self.skinny_fc = os.environ.get("XVECTOR_TRAIN_SPLITK_FC", "1") != "0"
+        # BN-backward column sums from their producers (the input-gradient GEMM's epilogue; the pooling gradient's per-chunk form)
+        # instead of a pass over the gradient: XVECTOR_TRAIN_FUSED_SUMS=0 restores the separate col_sums launches (A/B, tests)
+        self.fused_sums = os.environ.get("XVECTOR_TRAIN_FUSED_SUMS", "1") != "0"
         self.torch = torch
         self.device = torch.device(device)
         self.topo = topo
@@ -242,8 +245,10 @@ class Trainer(object):
             hiplib.chunk_moments(r, rs, rl, nchunks, rows_per_chunk, cm)
             mean, var = self.B[scope + "/mean:0"], self.B[scope + "/variance:0"]      # moving averages: one EMA at step end
             hiplib.merge_moments(cm, rl, nchunks, mean, var)
+            self._last_chunk_moments = cm                  # (the last frame-level layer's feed the fused pooling backward)
         else:
             mean, var = self.P[scope + "/mean:0"], self.P[scope + "/variance:0"]
+            self._last_chunk_moments = None
         scale, shift = hiplib.fold_bn(self.P[scope + "/gamma:0"], self.P[scope + "/beta:0"], mean, var, tp.BN_EPSILON)
         h = torch.empty_like(r)
         hiplib.rows_affine(r, scale, shift, valid, h, y_split=split_out)
@@ -294,6 +299,7 @@ class Trainer(object):
             if drop and ("frame", i) in S["seeds"]:
                 hiplib.dropout(h, S["seeds"][("frame", i)], S["keep"])
             S["r"].append(r); S["z"].append(z); S["h"].append(h); S["mean"].append(mean); S["var"].append(var)
+            S["cm_last"] = self._last_chunk_moments
         Cl = self.topo["layer_sizes"][-1]
         if self.attention:
             # h = [h1 | h2]: u = h1.W + b (one more K=1 GEMM), scores = v.tanh(u), softmax over the frames of each chunk,
@@ -357,8 +363,10 @@ class Trainer(object):
         return float(la[0]) + self._l2_value(), float(la[1])
 
     # -- backward + Adam -------------------------------------------------------------------------------------------
-    def _dense_backward(self, scope, x_in, dz, K, dil, grads, need_dx, valid, dx_out=None, dz_split=None):
-        """dW, db (and dx) of  z = conv(x_in, W) + b  given dz.  dx_out: optional [R, Cin] rows that receive dx."""
+    def _dense_backward(self, scope, x_in, dz, K, dil, grads, need_dx, valid, dx_out=None, dz_split=None, sums=None):
+        """dW, db (and dx) of  z = conv(x_in, W) + b  given dz.  dx_out: optional [R, Cin] rows that receive dx.
+        sums = (r_below, workspace): the input-gradient GEMM also leaves the partial column sums of (dx, dx * r_below) in the
+        workspace (xv_tdnn_layer_bf16x3_sums) -- what the BN backward of the layer below starts from."""
         torch = self.torch
         pk = self._pack()
         R, cin = x_in.shape
@@ -394,6 +402,9 @@ class Trainer(object):
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else torch.empty((R, cin), dtype=torch.float32, device=self.device)
+        if sums is not None:
+            hiplib.tdnn_layer3_sums(dz_split if dz_split is not None else dz, R, pk[scope + "/T"], dil, valid, dx, sums[0], sums[1])
+            return dx
         hiplib.tdnn_layer(dz_split if dz_split is not None else dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid, dx,
                           rows=R)
         return dx
@@ -403,16 +414,29 @@ class Trainer(object):
             self.torch.cuda.current_stream(self.device).wait_stream(self._side)
             self._side_busy = False
 
-    def _bn_backward(self, scope, dh, r, z, mean, var, n_frames, valid, grads, split_out=None):
+    def _bn_backward(self, scope, dh, r, z, mean, var, n_frames, valid, grads, split_out=None, sums_ws=None, pool=None):
+        """dz = dL/d(pre-activation) and dgamma / dbeta, given dh = dL/d(BN output).  The two column sums it starts from come from
+        (a) ``pool`` = (h, row_start, row_len, nchunks, pooled, dpooled, chunk moments of r): the last frame-level layer, whose dh
+        is the pooling's gradient -- sums from per-chunk numbers, dh never materialised (dh is None); (b) ``sums_ws``: partial sums
+        the input-gradient GEMM that produced dh left behind; (c) a pass over dh and r (col_sums)."""
         torch = self.torch
         C = r.shape[1]
-        s1 = torch.empty(C, dtype=torch.float32, device=self.device)
-        s2 = torch.empty_like(s1)
-        hiplib.col_sums(dh, r, s1, s2)
         dgamma, dbeta = self.G[scope + "/gamma:0"], self.G[scope + "/beta:0"]
         dz = torch.empty_like(r)
-        hiplib.bn_act_backward(dh, r, s1, s2, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames,
-                               tp.ACT_NONE if self.prelu else self.act, self.alpha, valid, dgamma, dbeta, dz, dz_split=split_out)
+        act = tp.ACT_NONE if self.prelu else self.act
+        if pool is not None:
+            h, rs, rl, nchunks, pooled, dpooled, cm = pool
+            hiplib.pool_bn_act_backward(h, r, rs, rl, nchunks, pooled, dpooled, cm, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON,
+                                        n_frames, act, self.alpha, dgamma, dbeta, dz, dz_split=split_out)
+        elif sums_ws is not None:
+            hiplib.bn_act_backward_parts(dh, r, sums_ws, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames, act, self.alpha,
+                                         valid, dgamma, dbeta, dz, dz_split=split_out)
+        else:
+            s1 = torch.empty(C, dtype=torch.float32, device=self.device)
+            s2 = torch.empty_like(s1)
+            hiplib.col_sums(dh, r, s1, s2)
+            hiplib.bn_act_backward(dh, r, s1, s2, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames, act, self.alpha, valid,
+                                   dgamma, dbeta, dz, dz_split=split_out)
         if self.prelu:
             # dz holds dL/d(act output); z the pre-activation: -> dz = dL/dz, z = dr*min(z,0) whose column sums are dalpha
             hiplib.prelu_backward(dz, z, self.P[scope + "/prelu/prelu:0"])
@@ -485,6 +509,7 @@ class Trainer(object):
             dz = self._bn_backward(sc, d, S["e_r"][j], S["e_z"][j], S["e_mean"][j], S["e_var"][j], float(B), None, grads)
             d = self._dense_backward(sc, S["e_in"][j], dz, 1, 1, grads, True, None)
             self._l2_grad(sc, grads)
+        pool = None
         if self.attention:
             hl = S["h"][-1]
             A = hl.shape[1] // 2
@@ -498,10 +523,14 @@ class Trainer(object):
             hiplib.col_sums(S["nl"], None, self.G["attention/v:0"])
             grads["attention/v:0"] = self.G["attention/v:0"]
             self._dense_backward("attention", hl[:, :A], du, 1, 1, grads, True, None, dx_out=dh[:, :A])
+        elif self.fused_sums and S.get("cm_last") is not None and S["h"][-1].shape[1] % 4 == 0:
+            # the pooling's gradient is consumed where it is formed (xv_pool_bn_act_backward_f32): no dh, no pass for its sums
+            dh, pool = None, (S["h"][-1], L["rs"], L["rl"], B, S["pooled"], d, S["cm_last"])
         else:
             dh = torch.empty_like(S["h"][-1])
             hiplib.pool_backward(S["h"][-1], L["rs"], L["rl"], B, S["pooled"], d, dh)
         fire_after = {after: k for k, (_, _, after) in enumerate(self._ready_ranges())}     # frame layer -> bucket final after it
+        sums_ws = None
         if on_bucket is not None:
             self._join_side()
             on_bucket(fire_after[None])                                    # segment-level tail (embed / attention / output)
@@ -511,8 +540,16 @@ class Trainer(object):
                 hiplib.dropout(dh, S["seeds"][("frame", i)], S["keep"])
             Ki = self.topo["kernel_sizes"][i]
             dzs = self._split_for("dz", S["R"], S["r"][i].shape[1]) if (i > 0 and self._wants_split(Ki, S["r"][i].shape[1], S["h"][i].shape[1])) else None
-            dz = self._bn_backward(sc, dh, S["r"][i], S["z"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads, split_out=dzs)
-            dh = self._dense_backward(sc, S["h"][i], dz, Ki, self.topo["dilations"][i], grads, i > 0, L["rv"], dz_split=dzs)
+            dz = self._bn_backward(sc, dh, S["r"][i], S["z"][i], S["mean"][i], S["var"][i], float(B * T), L["rv"], grads, split_out=dzs,
+                                   sums_ws=sums_ws, pool=pool)
+            pool = sums_ws = sums = None
+            # the input-gradient GEMM leaves the column sums the layer below starts its BN backward from -- unless dropout rewrites
+            # that gradient in between, or the GEMM is not the bf16x3 one
+            if i > 0 and self.fused_sums and self.precision == "bf16x3" and hiplib.supports_sums(S["r"][i - 1].shape[1]) and \
+                    not (S["keep"] < 1.0 and ("frame", i - 1) in S["seeds"]):
+                sums_ws = hiplib.col_sums_workspace(S["R"], S["r"][i - 1].shape[1], self.device)
+                sums = (S["r"][i - 1], sums_ws)
+            dh = self._dense_backward(sc, S["h"][i], dz, Ki, self.topo["dilations"][i], grads, i > 0, L["rv"], dz_split=dzs, sums=sums)
             if on_bucket is not None and i in fire_after:
                 self._join_side()
                 on_bucket(fire_after[i])
