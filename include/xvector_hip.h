@@ -175,6 +175,14 @@ int xv_tdnn_layer_bf16x3_sums(const void *x, int x_format, int64_t R, int cin, i
                               const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K,
                               int dilation, int cout, const uint8_t *row_valid, float *y, int ldy, const float *sum_r,
                               int ld_sum_r, void *workspace, void *stream);
+/* xv_tdnn_layer_bf16x3 (fp32 rows out, optional y_preact) whose epilogue also leaves, per 128-row tile, [sum_rows y | sum_rows y^2]
+ * in double in `workspace` (xv_col_sums_workspace_bytes(R, cout) bytes): the batch moments tf.layers.batch_normalization(training=
+ * True) takes of the layer's activation output (local/tf/models.py:66-68) without a pass over it -- xv_bn_moments_fold_f32 turns
+ * them into mean / var / the folded affine.  cout % 8 == 0. */
+int xv_tdnn_layer_bf16x3_moments(const void *x, int x_format, int64_t R, int cin, int ldx, const void *wt, const float *bias,
+                                 const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K,
+                                 int dilation, int cout, const uint8_t *row_valid, float *y, int ldy, float *y_preact, int ldpre,
+                                 void *workspace, void *stream);
 /* Last frame-level layer fused with the first half of statistics pooling (models.py:66-76 / 482-486 in one pass):
  * the same GEMM as xv_tdnn_layer_bf16x3, but instead of storing y[R, Cout] the epilogue reduces every block of 8
  * consecutive rows (global rows 8i..8i+7, valid rows only) to per-channel (mean, M2 = sum (v-mean)^2) and writes
@@ -365,6 +373,11 @@ int xv_bn_act_backward_parts_f32(const float *dh, const float *r, int ld, int64_
                                  const float *mean, const float *var, const float *gamma, float eps, float n_frames,
                                  int act_kind, float act_alpha, const uint8_t *row_valid, float *dgamma, float *dbeta,
                                  float *coef_ws, float *dz, void *dz_split, void *stream);
+/* Batch moments + BN fold from the partial sums of xv_tdnn_layer_bf16x3_moments, one launch: mean = S1 / n_frames,
+ * var = S2 / n_frames - mean^2 (biased: tf.nn.moments), scale = gamma / sqrt(var + eps), shift = beta - mean * scale (the
+ * operations of xv_fold_bn_f32).  Replaces xv_chunk_moments_f32 + xv_merge_moments_f32 + xv_fold_bn_f32 of a training forward. */
+int xv_bn_moments_fold_f32(const void *sums_workspace, int64_t R, int c, float n_frames, const float *gamma, const float *beta,
+                           float eps, float *mean, float *var, float *scale, float *shift, void *stream);
 /* Merge of such partial sums alone: sum_a[c], sum_ab[c] (sum_ab may be NULL) -- what xv_col_sums_f32 returns for the same rows. */
 int xv_col_sums_merge_f32(const void *sums_workspace, int64_t R, int c, float *sum_a, float *sum_ab, void *stream);
 /* Backward of [statistics pooling -> BN -> activation] of the LAST frame-level layer in two launches: the gradient that reaches

@@ -526,7 +526,8 @@ struct Gemm3Params {
     int n_mt, n_nt, n_chunks;
     // column sums of the fp32 output (training: the BN backward of the layer BELOW needs sum y and sum y * r over the rows, y = the
     // input gradient this launch produces): per row tile partials cs_part[mt][{sum y, sum y r}][cout] in double, merged in order by
-    // xv_col_sums_merge_f32.  cs_r: the other factor, fp32 rows of stride cs_ldr.  NULL = off.
+    // xv_col_sums_merge_f32.  cs_r: the other factor, fp32 rows of stride cs_ldr; NULL = the output itself (sum y, sum y^2: the
+    // batch moments BN(training) takes of a forward layer's activation output, accumulated in double).  cs_part NULL = off.
     const float *cs_r;
     int cs_ldr;
     double *cs_part;
@@ -1167,11 +1168,16 @@ __global__ __launch_bounds__(WM * 128, (S16 && WM == 4) ? 1 : 2) void tdnn_gemm_
     // column sums (training, see Gemm3Params::cs_part): the rows of the other factor are fetched before anything else so that
     // their latency is paid once; cout % 8 == 0 is the launcher's condition, so a column group is inside or outside as a whole
     const bool sums = p.cs_part != nullptr;             // (uniform)
+    const bool sums_self = sums && p.cs_r == nullptr;   // (uniform)
     f32x4 rq[8][2];
     float cs1[8], cs2[8];
+    double ds1[8], ds2[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) cs1[i] = cs2[i] = 0.f;
-    if (sums) {
+    for (int i = 0; i < 8; ++i) {
+        cs1[i] = cs2[i] = 0.f;
+        ds1[i] = ds2[i] = 0.0;
+    }
+    if (sums && !sums_self) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const long gr = m0 + (tid >> 4) + (NT / 16) * j;
@@ -1198,7 +1204,14 @@ __global__ __launch_bounds__(WM * 128, (S16 && WM == 4) ? 1 : 2) void tdnn_gemm_
             z[i] = (i < 4 ? t0[i] : t1[i - 4]) + bias[i];
             v[i] = (activate(z[i], al[i]) * sc[i] + sh[i]) * keep;
         }
-        if (sums) {
+        if (sums_self) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double d = (double)v[i];
+                ds1[i] += d;
+                ds2[i] = __builtin_fma(d, d, ds2[i]);
+            }
+        } else if (sums) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 cs1[i] += v[i];
@@ -1253,8 +1266,8 @@ __global__ __launch_bounds__(WM * 128, (S16 && WM == 4) ? 1 : 2) void tdnn_gemm_
         const int g = tid >> 4;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            D[(0 * NG + g) * BN + cg * 8 + i] = (double)cs1[i];
-            D[(1 * NG + g) * BN + cg * 8 + i] = (double)cs2[i];
+            D[(0 * NG + g) * BN + cg * 8 + i] = sums_self ? ds1[i] : (double)cs1[i];
+            D[(1 * NG + g) * BN + cg * 8 + i] = sums_self ? ds2[i] : (double)cs2[i];
         }
         __syncthreads();
         if (tid < 2 * BN) {
@@ -2250,6 +2263,25 @@ int xv_tdnn_layer_bf16x3_sums(const void *x, int x_format, int64_t R, int cin, i
     p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid;
     p.y = y; p.y_split = 0; p.ldy = ldy;
     p.cs_r = sum_r; p.cs_ldr = ld_sum_r; p.cs_part = (double *)workspace;
+    return launch_gemm3(p, (hipStream_t)stream);
+}
+
+int xv_tdnn_layer_bf16x3_moments(const void *x, int x_format, int64_t R, int cin, int ldx, const void *wt, const float *bias,
+                                 const float *bn_scale, const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation,
+                                 int cout, const uint8_t *row_valid, float *y, int ldy, float *y_preact, int ldpre, void *workspace,
+                                 void *stream)
+{
+    if (!x || !wt || !y || !workspace) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3_moments: NULL pointer");
+    if (act_kind < XV_ACT_NONE || act_kind > XV_ACT_PRELU) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3_moments: unknown act_kind");
+    if (x_format != XV_FMT_F32 && x_format != XV_FMT_SPLIT) return fail(XV_ERR_BAD_ARG, "tdnn_bf16x3_moments: unknown tensor format");
+    if ((cout & 7) || (ldy & 3) || (((uintptr_t)workspace) & 7))
+        return fail(XV_ERR_UNSUPPORTED, "tdnn_bf16x3_moments: needs cout % 8 == 0, ldy % 4 == 0 and an 8-byte aligned workspace");
+    Gemm3Params p{};
+    p.x = x; p.x_split = x_format == XV_FMT_SPLIT; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.wt = (const uint8_t *)wt;
+    p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha;
+    p.K = K; p.dil = dilation; p.cout = cout; p.valid = row_valid;
+    p.y = y; p.y_split = 0; p.ldy = ldy; p.ypre = y_preact; p.ldpre = ldpre;
+    p.cs_r = nullptr; p.cs_part = (double *)workspace;
     return launch_gemm3(p, (hipStream_t)stream);
 }
 

@@ -237,6 +237,50 @@ __global__ __launch_bounds__(64 * CSM_GROUPS) void col_sums_merge_kernel(const d
     }
 }
 
+// Batch moments of a forward layer from the partial sums its GEMM left behind (xv_tdnn_layer_bf16x3_moments: per 128-row tile
+// [sum y | sum y^2] in double), and the BN fold that follows, in one launch: mean = S1 / N, var = S2 / N - mean^2 (biased, what
+// tf.nn.moments returns), scale = gamma / sqrt(var + eps), shift = beta - mean * scale -- the last two with the operations and the
+// rounding order of fold_bn_kernel (xv_kernels.hip), so that a checkpoint's eval-mode fold and this one share their bits for equal
+// moments.  Replaces chunk_moments + merge_moments + fold_bn (three launches and a pass over the activations) for the layers whose
+// forward GEMM is the bf16x3 one.
+__global__ __launch_bounds__(64 * CSM_GROUPS) void moments_fold_kernel(const double *__restrict__ part, int C, int nsplit, float n_frames,
+                                                                       const float *gamma, const float *beta, float eps, float *mean,
+                                                                       float *var, float *scale, float *shift)
+{
+#pragma clang fp contract(off)
+    __shared__ double sh[2][CSM_GROUPS][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, sq = 0.0;
+    if (c < C) {
+        for (int j = g; j < nsplit; j += CSM_GROUPS) {
+            s += part[(size_t)j * 2 * C + c];
+            sq += part[(size_t)j * 2 * C + C + c];
+        }
+    }
+    sh[0][g][cl] = s;
+    sh[1][g][cl] = sq;
+    __syncthreads();
+    if (g != 0 || c >= C) return;
+    double ta = 0.0, tb = 0.0;
+#pragma unroll
+    for (int k = 0; k < CSM_GROUPS; ++k) {                   // fixed order: deterministic
+        ta += sh[0][k][cl];
+        tb += sh[1][k][cl];
+    }
+    const double N = n_frames;
+    const double m = ta / N;
+    const double v = fmax(tb / N - m * m, 0.0);
+    const float mf = (float)m, vf = (float)v;
+    mean[c] = mf;
+    var[c] = vf;
+    const float sc = gamma[c] * (1.0f / sqrtf(vf + eps));
+    float ms = mf * sc;
+    asm volatile("" : "+v"(ms));
+    scale[c] = sc;
+    shift[c] = beta[c] - ms;
+}
+
 // per-chunk (mean, biased var) -> moments over all frames of all chunks, fp64, two passes over the chunk table:
 // mu = sum_b n_b m_b / N, then var = sum_b n_b (v_b + (m_b - mu)^2) / N -- the definition, no cancellation.  64 channels x 16 groups of
 // chunks per workgroup (a serial Chan merge of 64 chunks with its fp64 divisions was 17 us on the handful of workgroups a launch has).
@@ -512,21 +556,42 @@ __global__ void pool_backward_kernel(const float *__restrict__ h, int ldh, int C
 //   sum_t dh        = sum_b dmu_b                            (the second term sums to zero inside a chunk)
 //   sum_t dh r      = sum_b [ dmu_b m_b + dsig_b s v_b / sig_b ]    (sum_t (h - mu_b) r = s T v_b)
 // -- no pass over the [R, C] matrices -- and dh itself never has to exist: the element-wise kernel forms it on the fly.
-__global__ void pool_bn_coeffs_kernel(const float *__restrict__ pooled, const float *__restrict__ dpooled, const float *__restrict__ cm,
-                                      int nchunks, const float *mean, const float *var, const float *gamma, float eps, float n_frames, int C,
-                                      float *dgamma, float *dbeta, float *coefA, float *coefB, float *coefC)
+// 64 channels x CSM_GROUPS groups of chunks per workgroup, the group sums added in group order (as col_sums_merge_kernel: a thread
+// per channel walking all chunks alone was 37 us of dependent loads for a few kilobytes)
+__global__ __launch_bounds__(64 * CSM_GROUPS) void pool_bn_coeffs_kernel(const float *__restrict__ pooled, const float *__restrict__ dpooled,
+                                                                         const float *__restrict__ cm, int nchunks, const float *mean,
+                                                                         const float *var, const float *gamma, float eps, float n_frames,
+                                                                         int C, float *dgamma, float *dbeta, float *coefA, float *coefB,
+                                                                         float *coefC)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double rstd = 1.0 / sqrt((double)var[c] + (double)eps);
-    const double g = gamma[c], N = n_frames, s = g * rstd;
-    double db = 0.0, sdr = 0.0;
-    for (int b = 0; b < nchunks; ++b) {                    // fixed order: deterministic
-        const size_t o = (size_t)b * 2 * C + c;
-        const double dmu = dpooled[o], dsig = dpooled[o + C];
-        db += dmu;
-        sdr += dmu * (double)cm[o] + dsig * s * (double)cm[o + C] / (double)pooled[o + C];
+    __shared__ double sh[2][CSM_GROUPS][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double rstd = 0.0, g = 0.0, s = 0.0;
+    if (c < C) {
+        rstd = 1.0 / sqrt((double)var[c] + (double)eps);
+        g = gamma[c];
+        s = g * rstd;
     }
+    double db = 0.0, sdr = 0.0;
+    if (c < C)
+        for (int b = grp; b < nchunks; b += CSM_GROUPS) {
+            const size_t o = (size_t)b * 2 * C + c;
+            const double dmu = dpooled[o], dsig = dpooled[o + C];
+            db += dmu;
+            sdr += dmu * (double)cm[o] + dsig * s * (double)cm[o + C] / (double)pooled[o + C];
+        }
+    sh[0][grp][cl] = db;
+    sh[1][grp][cl] = sdr;
+    __syncthreads();
+    if (grp != 0 || c >= C) return;
+    db = sdr = 0.0;
+#pragma unroll
+    for (int k = 0; k < CSM_GROUPS; ++k) {                 // fixed order: deterministic
+        db += sh[0][k][cl];
+        sdr += sh[1][k][cl];
+    }
+    const double N = n_frames;
     const double dg = rstd * (sdr - (double)mean[c] * db);
     dgamma[c] = (float)dg;
     dbeta[c] = (float)db;
@@ -827,6 +892,17 @@ int xv_col_sums_merge_f32(const void *workspace, int64_t R, int c, float *sum_a,
     return tcheck("col_sums_merge_kernel");
 }
 
+int xv_bn_moments_fold_f32(const void *sums_workspace, int64_t R, int c, float n_frames, const float *gamma, const float *beta, float eps,
+                           float *mean, float *var, float *scale, float *shift, void *stream)
+{
+    if (!sums_workspace || !gamma || !beta || !mean || !var || !scale || !shift || R <= 0 || c <= 0 || !(n_frames > 0.f))
+        return tfail(XV_ERR_BAD_ARG, "bn_moments_fold: bad argument");
+    const int splits = (int)((R + CS_ROWS - 1) / CS_ROWS);
+    hipLaunchKernelGGL(moments_fold_kernel, dim3((c + 63) / 64), dim3(64 * CSM_GROUPS), 0, (hipStream_t)stream, (const double *)sums_workspace,
+                       c, splits, n_frames, gamma, beta, eps, mean, var, scale, shift);
+    return tcheck("moments_fold_kernel");
+}
+
 int xv_merge_moments_f32(const float *chunk_mean_var, const int32_t *row_len, int nchunks, int c, float *mean, float *var, void *stream)
 {
     if (!chunk_mean_var || !row_len || !mean || !var || nchunks <= 0 || c <= 0) return tfail(XV_ERR_BAD_ARG, "merge_moments: bad argument");
@@ -936,7 +1012,7 @@ int xv_pool_bn_act_backward_f32(const float *h, const float *r, int ld, int c, c
     if (dz_split && ((c & 31) || (((uintptr_t)dz_split) & 15)))
         return tfail(XV_ERR_UNSUPPORTED, "pool_bn_act_backward: the split copy needs c % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pool_bn_coeffs_kernel, dim3((c + 63) / 64), dim3(64), 0, st, pooled, dpooled, chunk_moments, nchunks, mean, var, gamma,
+    hipLaunchKernelGGL(pool_bn_coeffs_kernel, dim3((c + 63) / 64), dim3(64 * CSM_GROUPS), 0, st, pooled, dpooled, chunk_moments, nchunks, mean, var, gamma,
                        eps, n_frames, c, dgamma, dbeta, coef_ws, coef_ws + c, coef_ws + 2 * c);
     int rc = tcheck("pool_bn_coeffs_kernel");
     if (rc) return rc;

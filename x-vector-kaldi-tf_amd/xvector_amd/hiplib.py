@@ -16,7 +16,7 @@ ABI_VERSION = 19
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
            "xv_stats_pool_workspace_bytes", "xv_stats_pool_f32", "xv_fc_f32", "xv_fc_splitk_workspace_bytes", "xv_fc_splitk_f32", "xv_chunk_average_f32",
            "xv_packed_weights_bf16x3_bytes", "xv_pack_weights_bf16x3", "xv_pack_weights_bf16x3_many", "xv_split_row_bytes", "xv_split_encode_f32",
-           "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_tdnn_layer_bf16x3_sums", "xv_fc_bf16x3",
+           "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_tdnn_layer_bf16x3_sums", "xv_tdnn_layer_bf16x3_moments", "xv_fc_bf16x3",
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32", "xv_tdnn_layer_pool_f32",
            "xv_packed_weights_rows_f32_floats", "xv_pack_weights_rows_f32", "xv_tdnn_layer_rows_f32",
            "xv_toom_supported", "xv_packed_weights_toom_f32_floats", "xv_pack_weights_toom_f32", "xv_tdnn_layer_toom_f32",
@@ -28,7 +28,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_rows_affine_split_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_bn_act_backward_split_f32", "xv_pool_backward_f32",
-           "xv_bn_act_backward_parts_f32", "xv_col_sums_merge_f32", "xv_pool_bn_act_backward_f32",
+           "xv_bn_act_backward_parts_f32", "xv_col_sums_merge_f32", "xv_pool_bn_act_backward_f32", "xv_bn_moments_fold_f32",
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32", "xv_pack_minibatch_f32",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
@@ -182,6 +182,10 @@ def load():
     lib.xv_bn_act_backward_split_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp, vp]
     lib.xv_tdnn_layer_bf16x3_sums.restype = ci
     lib.xv_tdnn_layer_bf16x3_sums.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp, ci, vp, vp]
+    lib.xv_tdnn_layer_bf16x3_moments.restype = ci
+    lib.xv_tdnn_layer_bf16x3_moments.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp, ci, vp, vp]
+    lib.xv_bn_moments_fold_f32.restype = ci
+    lib.xv_bn_moments_fold_f32.argtypes = [vp, i64, ci, cf, vp, vp, cf, vp, vp, vp, vp, vp]
     lib.xv_bn_act_backward_parts_f32.restype = ci
     lib.xv_bn_act_backward_parts_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp, vp]
     lib.xv_col_sums_merge_f32.restype = ci
@@ -546,6 +550,43 @@ def tdnn_layer3_sums(x, R, w, dilation, row_valid, y, sum_r, workspace):
 
 def supports_sums(cout):
     return cout % 8 == 0
+
+
+def tdnn_layer3_moments(x, R, w, bias, act, alpha, dilation, row_valid, y, y_preact, workspace):
+    """xv_tdnn_layer_bf16x3_moments: the forward layer r = act(conv(x, w) + b) with fp32 rows out (+ the pre-activation), and per
+    128-row tile the partial sums [sum r | sum r^2] in ``workspace`` (col_sums_workspace) -- BN's batch moments (bn_moments_fold)."""
+    lib = require_gpu()
+    assert isinstance(w, Packed3) and supports_sums(w.cout)
+    xs = isinstance(x, SplitBuf)
+    if xs:
+        assert x.fmt == FMT_SPLIT and x.channels == w.cin and x.rows >= R
+        xp, ldx = ctypes.c_void_p(x.ptr), 0
+    else:
+        _rows2d(x, "x"); assert x.shape[1] == w.cin and x.shape[0] >= R
+        xp, ldx = _ptr(x), x.stride(0)
+    _rows2d(y, "y"); assert y.shape[1] == w.cout and y.shape[0] >= R
+    ldpre = 0
+    if y_preact is not None:
+        _f32(y_preact, "y_preact"); assert y_preact.shape[1] == w.cout and y_preact.shape[0] >= R
+        ldpre = y_preact.stride(0)
+    if row_valid is not None:
+        assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
+    _check(lib.xv_tdnn_layer_bf16x3_moments(xp, FMT_SPLIT if xs else FMT_F32, int(R), w.cin, ldx, _ptr(w.wt), _ptr(bias), None, None, int(act),
+                                            _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), _ptr(y), y.stride(0), _ptr(y_preact),
+                                            ldpre, _ptr(workspace), _stream()), "xv_tdnn_layer_bf16x3_moments")
+
+
+def bn_moments_fold(workspace, rows, n_frames, gamma, beta, eps, mean, var):
+    """(scale, shift) of the BN fold and the batch moments (into mean, var) from the partial sums of tdnn_layer3_moments."""
+    import torch
+    lib = require_gpu()
+    c = gamma.numel()
+    scale = torch.empty(c, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty(c, dtype=torch.float32, device=gamma.device)
+    _check(lib.xv_bn_moments_fold_f32(_ptr(workspace), int(rows), c, float(n_frames), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),
+                                      float(eps), _ptr(_f32(mean, "mean")), _ptr(_f32(var, "var")), _ptr(scale), _ptr(shift), _stream()),
+           "xv_bn_moments_fold_f32")
+    return scale, shift
 
 
 POOL_BLOCK_ROWS = 8      # chunks fed to tdnn_layer_pool must start on a multiple of this many rows

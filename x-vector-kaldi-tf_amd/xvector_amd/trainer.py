@@ -226,19 +226,33 @@ class Trainer(object):
         if key not in self._layouts:
             torch = self.torch
             lay = BatchLayout([T] * B, self.gap)
-            # (pageable copies, i.e. host synchronisations -- but once per distinct T and at the very start of a step, where the
-            # stream is empty anyway; pinning three small arrays per new T costs more than it saves)
-            self._layouts[key] = dict(lay=lay, rs=torch.from_numpy(lay.row_start).to(self.device),
-                                      rl=torch.from_numpy(lay.row_len).to(self.device),
-                                      rv=torch.from_numpy(lay.row_valid()).to(self.device),
+            # The three index arrays of a minibatch of B equal chunks are arithmetic: they are generated ON the device.  (Copies
+            # of pageable host arrays are host synchronisations; with the loss read back one step late the stream is NOT empty at
+            # the head of a step, and a run that draws its length per minibatch -- 201 lengths -- met a new one, and with it a
+            # full stop of the host, in most of its first few hundred steps.)
+            slot, lead = T + self.gap, lay.lead
+            assert lay.align == 1 and lay.rows == lead + B * slot
+            idx = torch.arange(lay.rows, dtype=torch.int32, device=self.device) - lead
+            self._layouts[key] = dict(lay=lay, rs=torch.arange(B, dtype=torch.int32, device=self.device) * slot + lead,
+                                      rl=torch.full((B,), T, dtype=torch.int32, device=self.device),
+                                      rv=((idx >= 0) & (torch.remainder(idx, slot) < T)).to(torch.uint8),
                                       one_start=torch.zeros(1, dtype=torch.int32, device=self.device),
                                       one_len=torch.full((1,), B, dtype=torch.int32, device=self.device))
         return self._layouts[key]
 
-    def _bn_scopes_stats(self, r, scope, L, rows_per_chunk, nchunks, train, valid, frame_level, split_out=None):
-        """BN (train: batch statistics + moving-average update; eval: moving statistics) applied to r -> h."""
+    def _bn_scopes_stats(self, r, scope, L, rows_per_chunk, nchunks, train, valid, frame_level, split_out=None, moments_ws=None):
+        """BN (train: batch statistics + moving-average update; eval: moving statistics) applied to r -> h.
+        moments_ws: the partial sums (r, r^2) the layer's GEMM left behind -- moments and fold in one launch, no pass over r."""
         torch = self.torch
         C = r.shape[1]
+        if train and moments_ws is not None:
+            mean, var = self.B[scope + "/mean:0"], self.B[scope + "/variance:0"]
+            scale, shift = hiplib.bn_moments_fold(moments_ws, r.shape[0], float(rows_per_chunk * nchunks), self.P[scope + "/gamma:0"],
+                                                  self.P[scope + "/beta:0"], tp.BN_EPSILON, mean, var)
+            self._last_chunk_moments = None
+            h = torch.empty_like(r)
+            hiplib.rows_affine(r, scale, shift, valid, h, y_split=split_out)
+            return h, mean, var
         if train:
             cm = torch.empty((nchunks, 2 * C), dtype=torch.float32, device=self.device)
             rs, rl = (L["rs"], L["rl"]) if frame_level else (L["one_start"], L["one_len"])
@@ -287,14 +301,22 @@ class Trainer(object):
             C = self.topo["layer_sizes"][i]
             r = torch.empty((lay.rows, C), dtype=torch.float32, device=self.device)
             z = torch.empty_like(r) if (self.prelu and want_grad) else None            # PReLU backward needs the pre-activation
-            hiplib.tdnn_layer(S["hs"] if S["hs"] is not None else S["h"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act,
-                              self._alpha(sc), K, d, L["rv"], r, z, rows=lay.rows)
+            # BN's batch moments from the GEMM's own epilogue (per-tile sums of r and r^2 in double) for every layer but the last,
+            # whose per-chunk moments feed the fused pooling backward
+            moments_ws = None
+            if train and self.fused_sums and self.precision == "bf16x3" and i + 1 < len(self.frame_scopes) and hiplib.supports_sums(C):
+                moments_ws = hiplib.col_sums_workspace(lay.rows, C, self.device)
+                hiplib.tdnn_layer3_moments(S["hs"] if S["hs"] is not None else S["h"][-1], lay.rows, pk[sc], self.P[sc + "/b:0"], self.act,
+                                           self._alpha(sc), d, L["rv"], r, z, moments_ws)
+            else:
+                hiplib.tdnn_layer(S["hs"] if S["hs"] is not None else S["h"][-1], pk[sc], self.P[sc + "/b:0"], None, None, self.act,
+                                  self._alpha(sc), K, d, L["rv"], r, z, rows=lay.rows)
             # the next layer's input once more in the split format when that layer is context-free (and nothing rewrites h after BN)
             nxt_split = None
             if i + 1 < len(self.frame_scopes) and self._wants_split(self.topo["kernel_sizes"][i + 1], C, self.topo["layer_sizes"][i + 1]) and \
                     not (drop and ("frame", i) in S["seeds"]):
                 nxt_split = self._split_for("h%d" % (i & 1), lay.rows, C)
-            h, mean, var = self._bn_scopes_stats(r, sc, L, T, B, train, L["rv"], True, split_out=nxt_split)
+            h, mean, var = self._bn_scopes_stats(r, sc, L, T, B, train, L["rv"], True, split_out=nxt_split, moments_ws=moments_ws)
             S["hs"] = nxt_split
             if drop and ("frame", i) in S["seeds"]:
                 hiplib.dropout(h, S["seeds"][("frame", i)], S["keep"])
