@@ -154,15 +154,15 @@ def _train_run(args, rank, world, dev, topo, feat, precision, steps, warmup):
         dt = float(tmax.item())
     frames = sum(b[0].shape[1] for b in batches[warmup:]) * B
     fwd = tp.flops_per_frame(topo, feat) * frames + B * steps * (tp.flops_per_utt(topo, 1) + 2 * 512 * n_spk)
-    # MFMA-pipe time of a step at nominal rates: forward and input-gradient GEMMs in the chosen arithmetic (bf16x3: 3 bf16 MFMAs
-    # per product at 2.5 PF), the weight-gradient GEMM always on the exact fp32 MFMA (157.3 TF)
-    pipe = (2.0 * fwd * (3.0 / MFMA_BF16_PEAK if precision == "bf16x3" else 1.0 / MFMA_F32_PEAK) + fwd / MFMA_F32_PEAK)
+    # MFMA-pipe time of a step at nominal rates: forward, input-gradient and weight-gradient GEMMs in the chosen arithmetic
+    # (bf16x3: 3 bf16 MFMAs per product at 2.5 PF -- xv_wgrad_bf16x3 since round 4; fp32: the 157.3 TF fp32 MFMA)
+    pipe = 3.0 * fwd * (3.0 / MFMA_BF16_PEAK if precision == "bf16x3" else 1.0 / MFMA_F32_PEAK)
     return {"chunks_per_s": B * world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
             "steps_per_s": steps / dt, "frames_per_s": frames * world / dt, "approx_tflops_fwd_bwd": 3.0 * fwd * world / dt / 1e12,
             "mfma_time_over_time": pipe / dt,
-            "peak_note": "3 x forward FLOPs (forward, input gradient, weight gradient); MFMA-pipe time = forward + input gradient "
-                         "at %s + weight gradient at the 157.3 TF fp32 MFMA peak" % ("2.5 PF / 3 (bf16x3)" if precision == "bf16x3" else
-                                                                                    "the 157.3 TF fp32 MFMA peak"),
+            "peak_note": "3 x forward FLOPs (forward, input gradient, weight gradient); MFMA-pipe time = all three at %s"
+                         % ("2.5 PF / 3 (bf16x3: three bf16 MFMAs per product)" if precision == "bf16x3" else "the 157.3 TF fp32 MFMA peak"),
+            "fused_bn_sums": bool(tr.fused_sums),
             "precision": precision, "head": head, "class": args.train_class or "ModelWithoutDropout",
             "first_loss": losses[0], "last_loss": losses[-1]}
 

@@ -20,6 +20,15 @@ variants = {
     "noepi": rep(base, EPI, "    if (acc00[0] + acc01[1] + acc10[2] + acc11[3] == 12345.f) p.y[tid] = 1.f;\n}\n\nstd::atomic<int> g_fp32_form{0};"),
     # the prologue does not wait for its DMA (stale LDS): the first-fetch latency of a tile
     "noprowait": rep(base, "    if (KT == 1) dma_a_all(1);\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    __syncthreads();", "    if (KT == 1) dma_a_all(1);\n    __syncthreads();"),
+    # the epilogue's arithmetic and LDS traffic without its global stores (a store that never happens)
+    "nostore": rep(base, "            __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p.y + (size_t)gr * p.ldy + gc));   // streamed once: no L2 write-allocate",
+                   "            if (v[0] == 12345.f) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p.y + (size_t)gr * p.ldy + gc));"),
+    # ordinary stores instead of nontemporal ones
+    "plainstore": rep(base, "            __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p.y + (size_t)gr * p.ldy + gc));   // streamed once: no L2 write-allocate",
+                      "            *reinterpret_cast<f32x4 *>(p.y + (size_t)gr * p.ldy + gc) = v;"),
+    # the stores without the arithmetic between the LDS tile and them
+    "nomath": rep(base, "                const float t = act_t<ACT>(z[i], al[i]) * sc[i] + sh[i];\n                v[i] = keep ? t : 0.f;",
+                  "                v[i] = z[i];"),
 }
 
 
