@@ -359,11 +359,16 @@ def _cli_job_leg(args, ark_path, scp_path, model_dir, n):
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "x-vector-kaldi-tf_amd"), os.environ.get("PYTHONPATH", "")]))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
-    runs = []
+    runs = {}
     try:
-        for attempt in range(3):                               # 0, 1: the RCCL gather (cold, warm); 2: XVECTOR_SHARD_OUTPUT=files
-            o_ark, o_scp = os.path.join(out_dir, "xvector%d.ark" % attempt), os.path.join(out_dir, "xvector%d.scp" % attempt)
-            env["XVECTOR_SHARD_OUTPUT"] = "files" if attempt == 2 else "gather"
+        # in this order: the product default on a box that has run nothing yet, RCCL cold, RCCL warm, shard files, the default warm
+        for name, backend, shard in (("default_first", None, "gather"), ("rccl_first", "nccl", "gather"), ("rccl", "nccl", "gather"),
+                                     ("files", None, "files"), ("default", None, "gather")):
+            o_ark, o_scp = os.path.join(out_dir, "xvector_%s.ark" % name), os.path.join(out_dir, "xvector_%s.scp" % name)
+            env["XVECTOR_SHARD_OUTPUT"] = shard
+            env.pop("XVECTOR_DIST_BACKEND", None)
+            if backend:
+                env["XVECTOR_DIST_BACKEND"] = backend
             cmd = [sys.executable, "-m", "xvector_amd.launch", "--nproc", "1",
                    os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf", "extract_embedding.py"), "--use-gpu", "yes",
                    "--min-chunk-size", "25", "--chunk-size", "10000", "--feature-rspecifier", "scp:" + scp_path,
@@ -378,15 +383,22 @@ def _cli_job_leg(args, ark_path, scp_path, model_dir, n):
             parts = dict((k.strip(" ;["), float(v)) for k, v in re.findall(r"([^,;\[\]]+?) (\d+\.\d+) s", clock[-1].split("Job wall clock:", 1)[1])) if clock else {}
             with open(o_scp) as f:
                 written = sum(1 for _ in f)
-            runs.append({"wall_s": wall, "utt_per_s": n / wall, "vectors_written": written, "breakdown_s": parts})
+            group = [ln for ln in log.splitlines() if "process group (" in ln]
+            runs[name] = {"wall_s": wall, "utt_per_s": n / wall, "vectors_written": written, "breakdown_s": parts,
+                          "transport": re.search(r"process group \((\w+)\)", group[-1]).group(1) if group else None}
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
-    return {"value": runs[1]["utt_per_s"], "unit": "utt/s", "utterances": n, "wall_s": runs[1]["wall_s"],
-            "breakdown_s": runs[1]["breakdown_s"], "first_job_on_this_box": runs[0],
-            "shard_files": dict(runs[2], note="XVECTOR_SHARD_OUTPUT=files: one ark per rank + a concatenated scp (the reference's "
-                                              "own protocol, extract_xvectors.sh:83-95), no process group"),
-            "path": "python -m xvector_amd.launch --nproc 1 extract_embedding.py scp: -> ark,scp: (tmpfs), forced 1-rank RCCL group; wall "
-                    "clock of the whole job from outside, second of two runs"}
+    return {"value": runs["default"]["utt_per_s"], "unit": "utt/s", "utterances": n, "wall_s": runs["default"]["wall_s"],
+            "transport": runs["default"]["transport"], "breakdown_s": runs["default"]["breakdown_s"],
+            "first_job_on_this_box": runs["default_first"],
+            "rccl_gather": dict(runs["rccl"], first_job=runs["rccl_first"],
+                                note="XVECTOR_DIST_BACKEND=nccl: the gather over RCCL, what every job did up to round 4 and what a job "
+                                     "above XVECTOR_HOST_GATHER_MAX_MB (512 MB of vectors) still does; `first_job`: librccl's device code cold"),
+            "shard_files": dict(runs["files"], note="XVECTOR_SHARD_OUTPUT=files: one ark per rank + a concatenated scp (the reference's "
+                                                    "own protocol, extract_xvectors.sh:83-95), no process group"),
+            "path": "python -m xvector_amd.launch --nproc 1 extract_embedding.py scp: -> ark,scp: (tmpfs), forced 1-rank group; wall clock of "
+                    "the whole job from outside.  Product default: the one gather of the job (x-vectors that already lie in host memory) "
+                    "goes over the transport xvector_amd.dist.gather_backend picks from its size -- gloo up to 512 MB, RCCL above"}
 
 
 def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, precision="fp32", oracle_check=None):

@@ -12,6 +12,35 @@ from conftest import PKG
 from xvector_amd import dist as xdist
 
 
+def test_gather_transport_follows_the_payload(monkeypatch):
+    """dist.gather_backend: the transport of a job whose one exchange is the final gather -- forced by XVECTOR_DIST_BACKEND, gloo
+    without a GPU, and with one gloo up to XVECTOR_HOST_GATHER_MAX_MB of vectors (default 512), RCCL above; a pending asynchronous
+    bring-up takes the choice as long as its start mark has not fired."""
+    import torch
+    monkeypatch.delenv("XVECTOR_DIST_BACKEND", raising=False)
+    monkeypatch.delenv("XVECTOR_HOST_GATHER_MAX_MB", raising=False)
+    assert xdist.gather_backend(10 ** 12) == "gloo"                 # no GPU here
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    assert xdist.gather_backend(50000 * 513 * 4) == "gloo" and xdist.gather_backend(10 ** 6 * 513 * 4) == "nccl"
+    assert xdist.gather_backend(512 * 10 ** 6) == "gloo" and xdist.gather_backend(512 * 10 ** 6 + 1) == "nccl"
+    monkeypatch.setenv("XVECTOR_HOST_GATHER_MAX_MB", "0")
+    assert xdist.gather_backend(4) == "nccl"
+    monkeypatch.setenv("XVECTOR_DIST_BACKEND", "gloo")
+    assert xdist.gather_backend(10 ** 12) == "gloo"
+    monkeypatch.delenv("XVECTOR_DIST_BACKEND")
+    monkeypatch.delenv("XVECTOR_HOST_GATHER_MAX_MB")
+    import threading
+    go = threading.Event()
+    monkeypatch.setattr(xdist, "_ASYNC", dict(thread=object(), box={}, go=go))
+    xdist.set_gather_payload(1000)
+    assert xdist._ASYNC["backend"] == "gloo"
+    xdist.set_gather_payload(10 ** 10)
+    assert xdist._ASYNC["backend"] == "nccl"
+    go.set()                                                        # the bring-up has started: too late to change its transport
+    xdist.set_gather_payload(1000)
+    assert xdist._ASYNC["backend"] == "nccl"
+
+
 def test_partition_lpt_is_balanced_and_deterministic():
     lens = np.random.default_rng(0).integers(25, 10001, size=1000)
     for world in (1, 2, 4, 8):

@@ -64,6 +64,9 @@ def test_extraction_bench_line():
     assert j["utterances"] == 700 and j["first_job_on_this_box"]["vectors_written"] == 700 and 0 < j["wall_s"] < 60
     assert j["breakdown_s"]["total"] <= j["wall_s"] and "import torch" in j["breakdown_s"] and "gather" in j["breakdown_s"]
     assert j["shard_files"]["vectors_written"] == 700 and "gather" not in j["shard_files"]["breakdown_s"]
+    # the product default sends this job's 1.4 MB of vectors over gloo (dist.gather_backend); the RCCL gather is timed beside it
+    assert j["transport"] == "gloo" and j["rccl_gather"]["transport"] == "nccl" and j["rccl_gather"]["vectors_written"] == 700
+    assert j["rccl_gather"]["first_job"]["vectors_written"] == 700
 
 
 def test_two_ranks_through_the_self_launcher_on_one_gpu():

@@ -216,6 +216,8 @@ def eval_dnn(args):
     model = Model()
     if presharded:
         feat_scp, vad_scp, shard_keys = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
+        # the job's one exchange is known now: [emitted? | x-vector] rows of every utterance, from host memory to rank 0's host memory
+        xdist.set_gather_payload(sum(len(k) for k in shard_keys) * 513 * 4)
         feats = kaldi_io.MatScp(feat_scp)
         vad = kaldi_io.VecScp(vad_scp) if vad_scp is not None else None
     else:

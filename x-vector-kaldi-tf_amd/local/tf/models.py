@@ -102,7 +102,9 @@ def gather_shard_vectors(device_model, collector, shard_keys, rank, world):
         block[rows, 1:] = np.concatenate(collector.blocks)
     xdist.wait_process_group()
     jobclock.mark("wait for the process group")
-    blocks = xdist.gather_blocks(torch.from_numpy(block).to(dev), [len(k) for k in shard_keys], 0)
+    import torch.distributed as dist
+    host = dist.is_initialized() and dist.get_backend() == "gloo"          # (the block is host memory: no device round trip then)
+    blocks = xdist.gather_blocks(torch.from_numpy(block) if host else torch.from_numpy(block).to(dev), [len(k) for k in shard_keys], 0)
     jobclock.mark("gather")
     if rank != 0:
         return None

@@ -68,6 +68,29 @@ def init_process_group(backend=None):
 
 
 _ASYNC = {}
+HOST_GATHER_MAX_MB = 512.0
+
+
+def gather_backend(payload_bytes):
+    """Transport of a job whose ONLY exchange is the final gather of ``payload_bytes`` (all ranks together) of x-vectors that already
+    lie in host memory: XVECTOR_DIST_BACKEND if set; else "gloo" up to XVECTOR_HOST_GATHER_MAX_MB (default 512) -- the first RCCL
+    communicator of a process loads ~1 s of device code under the HIP runtime's lock (2.4 s more when librccl is cold on the box),
+    which a 50 k-utterance job's 100 MB of vectors never earn back over loopback; above it "nccl" (RCCL over xGMI: a configs[3]
+    share is 2 GB into rank 0).  Every rank computes the same answer from the same shard table."""
+    import torch
+    forced = os.environ.get("XVECTOR_DIST_BACKEND")
+    if forced:
+        return forced
+    if not torch.cuda.is_available():
+        return "gloo"
+    limit = float(os.environ.get("XVECTOR_HOST_GATHER_MAX_MB", HOST_GATHER_MAX_MB))
+    return "gloo" if payload_bytes <= limit * 1e6 else "nccl"
+
+
+def set_gather_payload(payload_bytes):
+    """Tell a pending ``init_process_group_async`` what the job will gather (before its start mark fires): picks the transport."""
+    if "box" in _ASYNC and "thread" in _ASYNC and not _ASYNC["go"].is_set():
+        _ASYNC["backend"] = gather_backend(payload_bytes)
 
 
 def init_process_group_async(backend=None, after_mark=None):
@@ -96,8 +119,9 @@ def init_process_group_async(backend=None, after_mark=None):
         go.wait()
         t0 = time.time()
         try:
-            box["value"] = init_process_group(backend)
-            jobclock.note("process group up on its side thread after", time.time() - t0)
+            chosen = _ASYNC.get("backend") or backend
+            box["value"] = init_process_group(chosen)
+            jobclock.note("process group (%s) up on its side thread after" % (chosen or "default"), time.time() - t0)
         except BaseException as e:          # noqa: B902 -- re-raised by wait_process_group
             box["error"] = e
     t = threading.Thread(target=run, name="xv-process-group", daemon=True)
