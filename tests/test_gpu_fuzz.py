@@ -165,6 +165,42 @@ def test_random_topologies_gradients_match_autograd(seed):
         assert not bad, ("kink margin %.1e" % train_ref.kink_margin[0], case, topo, bad)
 
 
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_topologies_bf16x3_step_with_reductions_from_their_producers(seed, monkeypatch):
+    """The bf16x3 training step with its BN reductions taken from the GEMM epilogues / the pooling gradient's per-chunk form (default)
+    against the same step with the separate passes (XVECTOR_TRAIN_FUSED_SUMS=0), on random topologies whose widths let the fused forms
+    apply (multiples of 8; ragged last row tiles, dilations, K = 1 layers on split copies, leaky ReLU, both poolings): loss to 2e-5,
+    every gradient tensor to 5e-2 of its norm (or of a tenth of the median norm).  That bound is the conditioning of these small
+    random problems, not of the reductions: over 120 soaked cases (tools/fuzz_many.py) both forms sit 1e-2 ... 5e-2 from float64
+    autograd in their worst tensor (fp32: 1e-5) and up to 2e-2 from each other -- batch moments that differ in the last bit move a
+    pre-activation across the activation's kink (margins of 5e-7) as readily as the split products do.  The reductions themselves are
+    pinned to 1e-6 / 2e-6 by the kernel-level tests of tests/test_gpu_training.py; a wrong sum here would be an O(1) error."""
+    from xvector_amd import hiplib, synthetic, trainer
+    hiplib.require_gpu()
+    rng = np.random.default_rng(seed)
+    for case in range(4):
+        width = lambda lo, hi: int(rng.integers(lo, hi)) // 8 * 8                        # noqa: E731
+        ks = [int(rng.choice([1, 3, 5, 7])) for _ in range(5)]
+        ds = [int(rng.choice([1, 2])) if 1 < k < 7 else 1 for k in ks]
+        topo = dict(layer_sizes=[width(16, 140), width(32, 140), width(32, 140), width(16, 140), width(16, 200)],
+                    kernel_sizes=ks, dilations=ds, embedding_sizes=[width(8, 48), width(8, 48)],
+                    activation=str(rng.choice(["relu", "lrelu"])), lrelu_alpha=0.2, l2_beta=0.0,
+                    dropout=False, head=None, pooling="attention" if rng.random() < 0.3 else "stats")
+        F, classes, B, T = int(rng.choice([23, 24])), 7, int(rng.integers(3, 12)), int(rng.integers(40, 330))
+        w = synthetic.trained_like(topo, F, classes, seed=int(rng.integers(1 << 30)))
+        x = (rng.standard_normal((B, T, F)) * 3).astype(np.float32)
+        lab = rng.integers(0, classes, B)
+        res = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("XVECTOR_TRAIN_FUSED_SUMS", flag)
+            loss, acc, grads = trainer.Trainer(w, topo, precision="bf16x3").gradients(x, lab)
+            res.append((loss, {n: g.cpu().numpy().astype(np.float64) for n, g in grads.items()}))
+        assert abs(res[0][0] - res[1][0]) <= 2e-5 * max(1.0, abs(res[1][0])), (case, topo)
+        floor = 0.1 * float(np.median([np.linalg.norm(v) for v in res[1][1].values()]))
+        bad = {n: e for n, e in ((n, float(np.linalg.norm(res[0][1][n] - v) / max(np.linalg.norm(v), floor))) for n, v in res[1][1].items()) if e > 5e-2}
+        assert not bad, (case, topo, bad)
+
+
 @pytest.mark.parametrize("seed", [61, 62, 63])
 def test_random_shapes_through_the_16x16_f16bf8_kernel(oracle_mod, seed):
     """The 256 x 256 f16bf8 tile on the 16 x 16 MFMA shapes (round 4) at kernel level: random K in {3, 5, 7}, dilations up to a span

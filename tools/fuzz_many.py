@@ -40,4 +40,27 @@ for seed in range(lo, hi):                       # the training step against the
         bad += 0 if near else 1
         print("test_random_topologies_gradients_match_autograd", seed, "NEAR-KINK" if near else "FAIL", str(e)[:400])
 print("test_random_topologies_gradients_match_autograd seeds %d..%d done" % (lo, hi - 1))
+
+
+class _Env(object):                              # (the monkeypatch fixture's setenv, for the test below)
+    def setenv(self, k, v):
+        os.environ[k] = v
+
+
+for seed in range(lo, hi):
+    try:
+        tf.test_random_topologies_bf16x3_step_with_reductions_from_their_producers(seed, _Env())
+    except AssertionError as e:
+        bad += 1
+        print("test_random_topologies_bf16x3_step_with_reductions_from_their_producers", seed, "FAIL", str(e)[:400])
+os.environ.pop("XVECTOR_TRAIN_FUSED_SUMS", None)
+print("test_random_topologies_bf16x3_step_with_reductions_from_their_producers seeds %d..%d done" % (lo, hi - 1))
+if not only_grad:
+    for seed in range(lo, hi):
+        try:
+            tf.test_random_topologies_in_the_fp32tc_arithmetic(oracle, seed)
+        except AssertionError as e:
+            bad += 1
+            print("test_random_topologies_in_the_fp32tc_arithmetic", seed, "FAIL", str(e)[:300])
+    print("test_random_topologies_in_the_fp32tc_arithmetic seeds %d..%d done" % (lo, hi - 1))
 print("failures:", bad)
