@@ -78,8 +78,8 @@ class VectorCollector(object):
 
 
 def gather_shard_vectors(device_model, collector, shard_keys, rank, world):
-    """The single exchange of a sharded job (extract_xvectors.sh:92-95 concatenates the jobs' outputs; here ONE RCCL gather
-    does).  Every rank knows every shard's key list -- the line ranges of an scp, or the byte ranges of an indexed ark, are
+    """The single exchange of a sharded job (extract_xvectors.sh:92-95 concatenates the jobs' outputs; here ONE gather does --
+    over RCCL, or over gloo straight from host memory when xvector_amd.dist.gather_backend chose that for a small payload).  Every rank knows every shard's key list -- the line ranges of an scp, or the byte ranges of an indexed ark, are
     deterministic -- so only numbers travel: rank r sends one row per utterance of ITS shard, in input order,
     ``[emitted? | x-vector]``; the blocks are padded to the largest shard so that a single fixed-shape ``dist.gather`` moves
     everything (xvector_amd.dist).  On rank 0 returns ``[(keys, vectors)]`` per shard in rank order = input order, with the

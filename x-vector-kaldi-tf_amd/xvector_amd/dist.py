@@ -6,6 +6,9 @@ MI355X equivalent: one process per GPU (``torch.distributed``, backend "nccl" ==
 deterministic frame-balanced partition every rank can recompute, NO collective on the data path, and
 ONE gather of the ``[N_r, E]`` fp32 embedding blocks to rank 0, which restores input order and writes
 the ark.  Keys and rejected-utterance flags need no communication: they follow from the lengths.
+An scp-sharded CLI job, whose vectors already lie in host memory when the gather starts, picks the transport of
+that one gather by its size (``gather_backend``: gloo for a few hundred MB, RCCL above); everything else -- the
+training step's all-reduces, bench.py, the stream / byte-range modes -- is RCCL.
 """
 import heapq
 import os
