@@ -52,7 +52,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 19). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 20). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -389,6 +389,16 @@ int xv_pool_bn_act_backward_f32(const float *h, const float *r, int ld, int c, c
                                 const float *mean, const float *var, const float *gamma, float eps, float n_frames,
                                 int act_kind, float act_alpha, float *dgamma, float *dbeta, float *coef_ws, float *dz,
                                 void *dz_split, void *stream);
+/* tf.layers.batch_normalization(training=True) of a SMALL matrix (1 .. 1024 rows, every row a sample: the segment-level layers of
+ * a training step, local/tf/models.py:88-91) in one launch each way.  Forward: batch mean / biased variance into mean, var, and
+ * y = x * scale + shift with the fold of xv_fold_bn_f32 (what xv_chunk_moments_f32 + xv_merge_moments_f32 + xv_fold_bn_f32 +
+ * xv_rows_affine_f32 do in four).  Backward: dgamma, dbeta and dz through the activation (NONE / RELU / LRELU), as xv_col_sums_f32
+ * + xv_bn_act_backward_f32. */
+int xv_bn_small_forward_f32(const float *x, int ldx, int nrows, int c, const float *gamma, const float *beta, float eps, float *mean,
+                            float *var, float *y, int ldy, void *stream);
+int xv_bn_small_backward_f32(const float *dh, const float *r, int ld, int nrows, int c, const float *mean, const float *var,
+                             const float *gamma, float eps, int act_kind, float act_alpha, float *dgamma, float *dbeta, float *dz,
+                             void *stream);
 /* Gradient of statistics pooling: dh[t,c] = dmu[c]/T + dsig[c]*(h[t,c]-mu[c])/(T*sig[c]); dh gap rows are zeroed. */
 int xv_pool_backward_f32(const float *h, int ldh, int c, const int32_t *row_start, const int32_t *row_len, int nchunks,
                          int64_t R, const float *pooled, const float *dpooled, float *dh, void *stream);

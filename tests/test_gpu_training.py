@@ -709,6 +709,39 @@ def test_input_gradient_gemm_leaves_the_column_sums(env):
         assert all(torch.equal(p_, q_) for p_, q_ in zip(*outs))
 
 
+def test_small_matrix_batch_norm_in_one_launch_each_way(env):
+    """xv_bn_small_forward_f32 / xv_bn_small_backward_f32 (the segment level's 64 rows) against the four-launch chains they replace:
+    moments to 1e-6 (the variance of a channel with a large mean included), rows to 2e-6, dgamma / dbeta bit for bit, dz to 1e-6."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(41)
+    for n, C in ((64, 512), (7, 24), (1000, 136)):
+        x = torch.randn((n, C), generator=g).to(dev)
+        x[:, 3] += 200.0
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+        one_s, one_l = torch.zeros(1, dtype=torch.int32, device=dev), torch.full((1,), n, dtype=torch.int32, device=dev)
+        cm, m0, v0 = torch.empty((1, 2 * C), device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        hiplib.chunk_moments(x, one_s, one_l, 1, n, cm)
+        hiplib.merge_moments(cm, one_l, 1, m0, v0)
+        s0, h0 = hiplib.fold_bn(gamma, beta, m0, v0, 1e-3)
+        y0 = torch.empty_like(x)
+        hiplib.rows_affine(x, s0, h0, None, y0)
+        m1, v1, y1 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty_like(x)
+        hiplib.bn_small_forward(x, gamma, beta, 1e-3, m1, v1, y1)
+        x64 = x.double()
+        assert float((m1.double() - x64.mean(0)).abs().max()) < 1e-6 * 200 and bool(((v1.double() - x64.var(0, unbiased=False)).abs() <= 2e-6 * x64.var(0, unbiased=False)).all())
+        assert float((y1.double() - y0.double()).norm() / y0.double().norm()) < 2e-6
+        dh, r = torch.randn((n, C), generator=g).to(dev), torch.relu(x)
+        a, b = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        hiplib.col_sums(dh, r, a, b)
+        dg0, db0, dz0 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty_like(x)
+        hiplib.bn_act_backward(dh, r, a, b, m1, v1, gamma, 1e-3, float(n), 1, 0.0, None, dg0, db0, dz0)
+        dg1, db1, dz1 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty_like(x)
+        hiplib.bn_small_backward(dh, r, m1, v1, gamma, 1e-3, 1, 0.0, dg1, db1, dz1)
+        assert torch.equal(db0, db1) and torch.equal(dg0, dg1)
+        assert float((dz1.double() - dz0.double()).norm() / dz0.double().norm()) < 1e-6          # (same coefficients; the compiler contracts a * dh + b * r + k differently)
+
+
 def test_bf16x3_step_with_and_without_fused_column_sums(env, monkeypatch):
     """A bf16x3 step with the BN-backward sums taken from their producers (default) against the same step with the separate
     col_sums / chunk-moment passes (XVECTOR_TRAIN_FUSED_SUMS=0): loss and gradients agree far inside the arithmetic's own error;

@@ -647,6 +647,115 @@ __global__ __launch_bounds__(128) void pool_bn_act_backward_kernel(const float *
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batch normalisation of a SMALL matrix (the segment level of a training step: 64 rows) in ONE launch each way.  The general path is
+// chunk moments -> merge -> fold -> affine forward and column sums -> merge -> coefficients -> element-wise backward: four dependent
+// launches of ~4.7 us each for a few kilobytes of work, twice per embedding layer, in the middle of the step where nothing overlaps
+// them.  64 channels x 16 row groups per workgroup; a group's rows are r = g, g + 16, ...; sums in double, merged in group order.
+// ------------------------------------------------------------------------------------------------
+constexpr int BNS_GROUPS = 16;
+constexpr int BNS_MAX_ROWS = 1024;
+
+__global__ __launch_bounds__(64 * BNS_GROUPS) void bn_small_forward_kernel(const float *__restrict__ x, int ldx, int R, int C,
+                                                                           const float *gamma, const float *beta, float eps,
+                                                                           float *mean_out, float *var_out, float *__restrict__ y, int ldy)
+{
+#pragma clang fp contract(off)
+    __shared__ double sh[BNS_GROUPS][64];
+    __shared__ float bc[2][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool ok = c < C;
+    double s = 0.0;
+    if (ok)
+        for (int r = g; r < R; r += BNS_GROUPS) s += (double)x[(size_t)r * ldx + c];
+    sh[g][cl] = s;
+    __syncthreads();
+    double m = 0.0;
+#pragma unroll
+    for (int k = 0; k < BNS_GROUPS; ++k) m += sh[k][cl];
+    m /= (double)R;
+    __syncthreads();
+    double q = 0.0;
+    if (ok)
+        for (int r = g; r < R; r += BNS_GROUPS) {
+            const double d = (double)x[(size_t)r * ldx + c] - m;
+            q += d * d;
+        }
+    sh[g][cl] = q;
+    __syncthreads();
+    if (g == 0 && ok) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < BNS_GROUPS; ++k) v += sh[k][cl];
+        const float mf = (float)m, vf = (float)(v / (double)R);
+        mean_out[c] = mf;
+        var_out[c] = vf;
+        // (the operations and rounding order of fold_bn_kernel)
+        const float sc = gamma[c] * (1.0f / sqrtf(vf + eps));
+        float ms = mf * sc;
+        asm volatile("" : "+v"(ms));
+        bc[0][cl] = sc;
+        bc[1][cl] = beta[c] - ms;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const float sc = bc[0][cl], sf = bc[1][cl];
+    for (int r = g; r < R; r += BNS_GROUPS) {
+        y[(size_t)r * ldy + c] = __builtin_fmaf(x[(size_t)r * ldx + c], sc, sf);       // (rows_affine_kernel's contracted x * scale + shift)
+    }
+}
+
+__global__ __launch_bounds__(64 * BNS_GROUPS) void bn_small_backward_kernel(const float *__restrict__ dh, const float *__restrict__ r, int ld,
+                                                                            int R, int C, const float *mean, const float *var,
+                                                                            const float *gamma, float eps, int act, float alpha,
+                                                                            float *dgamma, float *dbeta, float *__restrict__ dz)
+{
+    __shared__ double sh[2][BNS_GROUPS][64];
+    __shared__ float bc[3][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool ok = c < C;
+    double s1 = 0.0, s2 = 0.0;
+    if (ok)
+        for (int i = g; i < R; i += BNS_GROUPS) {
+            const double a = dh[(size_t)i * ld + c];
+            s1 += a;
+            s2 += a * (double)r[(size_t)i * ld + c];
+        }
+    sh[0][g][cl] = s1;
+    sh[1][g][cl] = s2;
+    __syncthreads();
+    if (g == 0 && ok) {
+        double ta = 0.0, tb = 0.0;
+#pragma unroll
+        for (int k = 0; k < BNS_GROUPS; ++k) {
+            ta += sh[0][k][cl];
+            tb += sh[1][k][cl];
+        }
+        const double db = (double)(float)ta, sdr = (double)(float)tb;      // (through fp32 as between col_sums and bn_coeffs)
+        const double rstd = 1.0 / sqrt((double)var[c] + (double)eps);
+        const double dg = rstd * (sdr - (double)mean[c] * db);
+        const double gm = gamma[c], N = R;
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
+        bc[0][cl] = (float)(gm * rstd);
+        bc[1][cl] = (float)(-gm * rstd * rstd * dg / N);
+        bc[2][cl] = (float)(-gm * rstd * db / N + gm * rstd * rstd * (double)mean[c] * dg / N);
+    }
+    __syncthreads();
+    if (!ok) return;
+    const float A = bc[0][cl], B = bc[1][cl], K = bc[2][cl];
+    for (int i = g; i < R; i += BNS_GROUPS) {
+        const size_t o = (size_t)i * ld + c;
+        const float rv = r[o];
+        float dr = A * dh[o] + B * rv + K;
+        if (act == XV_ACT_RELU) dr = rv > 0.f ? dr : 0.f;
+        else if (act == XV_ACT_LRELU) dr = rv > 0.f ? dr : alpha * dr;
+        dz[o] = dr;
+    }
+}
+
 // one wave64 per row of logits
 __global__ __launch_bounds__(64) void softmax_ce_kernel(const float *__restrict__ logits, const int *__restrict__ labels, int B,
                                                         int N, float *__restrict__ row_loss, float *__restrict__ row_correct,
@@ -996,6 +1105,28 @@ int xv_bn_act_backward_parts_f32(const float *dh, const float *r, int ld, int64_
     int rc = tcheck("col_sums_merge_coeffs_kernel");
     if (rc) return rc;
     return bn_act_backward_tail(dh, r, ld, R, c, act_kind, act_alpha, row_valid, coef_ws, dz, dz_split, st);
+}
+
+int xv_bn_small_forward_f32(const float *x, int ldx, int nrows, int c, const float *gamma, const float *beta, float eps, float *mean,
+                            float *var, float *y, int ldy, void *stream)
+{
+    if (!x || !gamma || !beta || !mean || !var || !y || nrows <= 0 || nrows > BNS_MAX_ROWS || c <= 0 || ldx < c || ldy < c)
+        return tfail(XV_ERR_BAD_ARG, "bn_small_forward: bad argument (1 .. 1024 rows)");
+    hipLaunchKernelGGL(bn_small_forward_kernel, dim3((c + 63) / 64), dim3(64 * BNS_GROUPS), 0, (hipStream_t)stream, x, ldx, nrows, c, gamma, beta,
+                       eps, mean, var, y, ldy);
+    return tcheck("bn_small_forward_kernel");
+}
+
+int xv_bn_small_backward_f32(const float *dh, const float *r, int ld, int nrows, int c, const float *mean, const float *var,
+                             const float *gamma, float eps, int act_kind, float act_alpha, float *dgamma, float *dbeta, float *dz,
+                             void *stream)
+{
+    if (!dh || !r || !mean || !var || !gamma || !dgamma || !dbeta || !dz || nrows <= 0 || nrows > BNS_MAX_ROWS || c <= 0 || ld < c)
+        return tfail(XV_ERR_BAD_ARG, "bn_small_backward: bad argument (1 .. 1024 rows)");
+    if (act_kind == XV_ACT_PRELU) return tfail(XV_ERR_UNSUPPORTED, "bn_small_backward: PReLU training is not implemented");
+    hipLaunchKernelGGL(bn_small_backward_kernel, dim3((c + 63) / 64), dim3(64 * BNS_GROUPS), 0, (hipStream_t)stream, dh, r, ld, nrows, c, mean,
+                       var, gamma, eps, act_kind, act_alpha, dgamma, dbeta, dz);
+    return tcheck("bn_small_backward_kernel");
 }
 
 int xv_pool_bn_act_backward_f32(const float *h, const float *r, int ld, int c, const int32_t *row_start, const int32_t *row_len,

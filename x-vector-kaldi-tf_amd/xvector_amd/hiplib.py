@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -28,7 +28,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_rows_affine_split_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_bn_act_backward_split_f32", "xv_pool_backward_f32",
-           "xv_bn_act_backward_parts_f32", "xv_col_sums_merge_f32", "xv_pool_bn_act_backward_f32", "xv_bn_moments_fold_f32",
+           "xv_bn_act_backward_parts_f32", "xv_col_sums_merge_f32", "xv_pool_bn_act_backward_f32", "xv_bn_moments_fold_f32", "xv_bn_small_forward_f32", "xv_bn_small_backward_f32",
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32", "xv_pack_minibatch_f32",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
@@ -186,6 +186,10 @@ def load():
     lib.xv_tdnn_layer_bf16x3_moments.argtypes = [vp, ci, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp, ci, vp, vp]
     lib.xv_bn_moments_fold_f32.restype = ci
     lib.xv_bn_moments_fold_f32.argtypes = [vp, i64, ci, cf, vp, vp, cf, vp, vp, vp, vp, vp]
+    lib.xv_bn_small_forward_f32.restype = ci
+    lib.xv_bn_small_forward_f32.argtypes = [vp, ci, ci, ci, vp, vp, cf, vp, vp, vp, ci, vp]
+    lib.xv_bn_small_backward_f32.restype = ci
+    lib.xv_bn_small_backward_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, cf, ci, cf, vp, vp, vp, vp]
     lib.xv_bn_act_backward_parts_f32.restype = ci
     lib.xv_bn_act_backward_parts_f32.argtypes = [vp, vp, ci, i64, ci, vp, vp, vp, vp, cf, cf, ci, cf, vp, vp, vp, vp, vp, vp, vp]
     lib.xv_col_sums_merge_f32.restype = ci
@@ -1017,6 +1021,30 @@ def bn_act_backward_parts(dh, r, workspace, mean, var, gamma, eps, n_frames, act
                                             _ptr(dgamma), _ptr(dbeta), _ptr(coef), _ptr(_f32(dz, "dz")),
                                             ctypes.c_void_p(dz_split.ptr) if dz_split is not None else None, _stream()),
            "xv_bn_act_backward_parts_f32")
+
+
+BN_SMALL_MAX_ROWS = 1024
+
+
+def bn_small_forward(x, gamma, beta, eps, mean, var, y):
+    """xv_bn_small_forward_f32: training-mode BN of a matrix of <= 1024 rows in one launch (moments into mean / var, y = BN(x))."""
+    lib = require_gpu()
+    _rows2d(x, "x"); _rows2d(y, "y")
+    n, c = x.shape
+    assert n <= BN_SMALL_MAX_ROWS and y.shape == x.shape and gamma.numel() == c
+    _check(lib.xv_bn_small_forward_f32(_ptr(x), x.stride(0), n, c, _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), float(eps),
+                                       _ptr(_f32(mean, "mean")), _ptr(_f32(var, "var")), _ptr(y), y.stride(0), _stream()),
+           "xv_bn_small_forward_f32")
+
+
+def bn_small_backward(dh, r, mean, var, gamma, eps, act, alpha, dgamma, dbeta, dz):
+    """xv_bn_small_backward_f32: the BN + activation backward of a matrix of <= 1024 rows in one launch."""
+    lib = require_gpu()
+    _rows2d(dh, "dh"); _rows2d(r, "r"); _rows2d(dz, "dz")
+    n, c = dh.shape
+    assert n <= BN_SMALL_MAX_ROWS and r.shape == dh.shape == dz.shape and dh.stride(0) == r.stride(0) == dz.stride(0)
+    _check(lib.xv_bn_small_backward_f32(_ptr(dh), _ptr(r), dh.stride(0), n, c, _ptr(mean), _ptr(var), _ptr(gamma), float(eps), int(act),
+                                        float(alpha), _ptr(dgamma), _ptr(dbeta), _ptr(dz), _stream()), "xv_bn_small_backward_f32")
 
 
 def col_sums_merge(workspace, rows, c, sum_a, sum_ab=None):

@@ -253,6 +253,12 @@ class Trainer(object):
             h = torch.empty_like(r)
             hiplib.rows_affine(r, scale, shift, valid, h, y_split=split_out)
             return h, mean, var
+        if train and not frame_level and self.fused_sums and r.shape[0] <= hiplib.BN_SMALL_MAX_ROWS and valid is None and split_out is None:
+            # the segment level (64 rows): moments, fold and affine in ONE launch instead of four dependent ones
+            mean, var = self.B[scope + "/mean:0"], self.B[scope + "/variance:0"]
+            h = torch.empty_like(r)
+            hiplib.bn_small_forward(r, self.P[scope + "/gamma:0"], self.P[scope + "/beta:0"], tp.BN_EPSILON, mean, var, h)
+            return h, mean, var
         if train:
             cm = torch.empty((nchunks, 2 * C), dtype=torch.float32, device=self.device)
             rs, rl = (L["rs"], L["rl"]) if frame_level else (L["one_start"], L["one_len"])
@@ -450,6 +456,8 @@ class Trainer(object):
             h, rs, rl, nchunks, pooled, dpooled, cm = pool
             hiplib.pool_bn_act_backward(h, r, rs, rl, nchunks, pooled, dpooled, cm, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON,
                                         n_frames, act, self.alpha, dgamma, dbeta, dz, dz_split=split_out)
+        elif self.fused_sums and valid is None and split_out is None and r.shape[0] <= hiplib.BN_SMALL_MAX_ROWS and float(r.shape[0]) == n_frames:
+            hiplib.bn_small_backward(dh, r, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, act, self.alpha, dgamma, dbeta, dz)
         elif sums_ws is not None:
             hiplib.bn_act_backward_parts(dh, r, sums_ws, mean, var, self.P[scope + "/gamma:0"], tp.BN_EPSILON, n_frames, act, self.alpha,
                                          valid, dgamma, dbeta, dz, dz_split=split_out)
