@@ -52,7 +52,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 20). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 21). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -419,6 +419,10 @@ int xv_sumsq_f32(const float *x, int64_t n, float *out, void *workspace, void *s
  * 1/keep_prob) iff the top 32 bits of splitmix64(seed ^ 0x9E3779B97F4A7C15*(r*C + c + 1)) < keep_prob*2^32, else zeroed.
  * Stateless: the same call on the gradient buffer is the backward pass.  keep_prob == 1 is a no-op. */
 int xv_dropout_f32(float *x, int ldx, int64_t R, int c, uint64_t seed, float keep_prob, void *stream);
+/* Index arrays of a training minibatch in the packed-rows layout (B chunks of T frames, `gap` zero rows in front of, between and
+ * behind them; rows >= gap + B (T + gap)): row_start[B], row_len[B], row_valid[rows] -- generated on the device (a host copy of
+ * them is a host synchronisation, and a run meets a new length in most of its first few hundred steps). */
+int xv_minibatch_layout(int B, int T, int gap, int64_t rows, int32_t *row_start, int32_t *row_len, uint8_t *row_valid, void *stream);
 /* A training minibatch src[B, T, F] (float16 when src_is_f16, else float32; DEVICE pointer like everything else) -> the packed
  * rows-with-gaps matrix dst[rows, in_dim] of the header comment: chunk b at rows gap + b*(T+gap), all other rows and the columns
  * F..in_dim-1 zero; rows >= gap + B*(T+gap).  Replaces the feed_dict hand-over of models.py:255-262 (the egs hold float16). */

@@ -709,6 +709,18 @@ def test_input_gradient_gemm_leaves_the_column_sums(env):
         assert all(torch.equal(p_, q_) for p_, q_ in zip(*outs))
 
 
+def test_minibatch_layout_generated_on_the_device(env):
+    """xv_minibatch_layout == engine.BatchLayout of B equal chunks (row_start, row_len, row_valid), tail rows past the last gap zero."""
+    torch, hiplib = env["torch"], env["hiplib"]
+    from xvector_amd.engine import BatchLayout
+    dev = torch.device("cuda:0")
+    for B, T, gap, extra in ((64, 300, 3, 0), (1, 25, 4, 0), (7, 157, 0, 0), (5, 40, 3, 9)):
+        lay = BatchLayout([T] * B, gap)
+        rs, rl, rv = hiplib.minibatch_layout(B, T, gap, lay.rows + extra, dev)
+        assert np.array_equal(rs.cpu().numpy(), lay.row_start) and np.array_equal(rl.cpu().numpy(), lay.row_len)
+        assert np.array_equal(rv.cpu().numpy()[:lay.rows], lay.row_valid()) and not rv.cpu().numpy()[lay.rows:].any()
+
+
 def test_small_matrix_batch_norm_in_one_launch_each_way(env):
     """xv_bn_small_forward_f32 / xv_bn_small_backward_f32 (the segment level's 64 rows) against the four-launch chains they replace:
     moments to 1e-6 (the variance of a channel with a large mean included), rows to 2e-6, dgamma / dbeta bit for bit, dz to 1e-6."""

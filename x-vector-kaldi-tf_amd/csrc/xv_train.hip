@@ -1222,6 +1222,31 @@ int xv_sumsq_f32(const float *x, int64_t n, float *out, void *workspace, void *s
     return tcheck("sumsq_final_kernel");
 }
 
+// the three index arrays of a minibatch of B equal chunks of T frames with `gap` zero rows in front of, between and behind them
+__global__ void minibatch_layout_kernel(int B, int T, int gap, long rows, int *__restrict__ row_start, int *__restrict__ row_len,
+                                        uint8_t *__restrict__ row_valid)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = T + gap;
+    if (i < B) {
+        row_start[i] = gap + (int)i * slot;
+        row_len[i] = T;
+    }
+    if (i < rows) {
+        const long j = i - gap;
+        row_valid[i] = (j >= 0 && j % slot < T && j / slot < B) ? 1 : 0;
+    }
+}
+
+int xv_minibatch_layout(int B, int T, int gap, int64_t rows, int32_t *row_start, int32_t *row_len, uint8_t *row_valid, void *stream)
+{
+    if (!row_start || !row_len || !row_valid || B <= 0 || T <= 0 || gap < 0 || rows < (int64_t)gap + (int64_t)B * (T + gap) || rows < B)
+        return tfail(XV_ERR_BAD_ARG, "minibatch_layout: bad argument");
+    hipLaunchKernelGGL(minibatch_layout_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, T, gap, (long)rows,
+                       row_start, row_len, row_valid);
+    return tcheck("minibatch_layout_kernel");
+}
+
 int xv_pack_minibatch_f32(const void *src, int src_is_f16, int B, int T, int F, int gap, int in_dim, float *dst, int64_t rows,
                           void *stream)
 {

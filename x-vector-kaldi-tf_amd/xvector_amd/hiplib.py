@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -29,7 +29,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_rows_affine_split_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_bn_act_backward_split_f32", "xv_pool_backward_f32",
            "xv_bn_act_backward_parts_f32", "xv_col_sums_merge_f32", "xv_pool_bn_act_backward_f32", "xv_bn_moments_fold_f32", "xv_bn_small_forward_f32", "xv_bn_small_backward_f32",
-           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32", "xv_pack_minibatch_f32",
+           "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32", "xv_pack_minibatch_f32", "xv_minibatch_layout",
            "xv_prelu_backward_f32", "xv_l2_normalize_rows_f32", "xv_l2_normalize_backward_f32", "xv_am_margin_f32",
            # feature front-end
            "xv_cmn_sliding_scatter_f32",
@@ -212,6 +212,8 @@ def load():
     lib.xv_sumsq_f32.argtypes = [vp, i64, vp, vp, vp]
     lib.xv_dropout_f32.restype = ci
     lib.xv_dropout_f32.argtypes = [vp, ci, i64, ci, ctypes.c_uint64, cf, vp]
+    lib.xv_minibatch_layout.restype = ci
+    lib.xv_minibatch_layout.argtypes = [ci, ci, ci, i64, vp, vp, vp, vp]
     lib.xv_pack_minibatch_f32.restype = ci
     lib.xv_pack_minibatch_f32.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, i64, vp]
     lib.xv_prelu_backward_f32.restype = ci
@@ -1111,6 +1113,17 @@ def sumsq(x, out):
     assert x.is_contiguous()
     ws = _ws(lib.xv_sumsq_workspace_bytes(x.numel()), x.device)
     _check(lib.xv_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _ptr(ws), _stream()), "xv_sumsq_f32")
+
+
+def minibatch_layout(B, T, gap, rows, device):
+    """(row_start[B] int32, row_len[B] int32, row_valid[rows] uint8) of a minibatch of B chunks of T frames, generated on the device."""
+    import torch
+    lib = require_gpu()
+    rs = torch.empty(B, dtype=torch.int32, device=device)
+    rl = torch.empty(B, dtype=torch.int32, device=device)
+    rv = torch.empty(rows, dtype=torch.uint8, device=device)
+    _check(lib.xv_minibatch_layout(int(B), int(T), int(gap), int(rows), _ptr(rs), _ptr(rl), _ptr(rv), _stream()), "xv_minibatch_layout")
+    return rs, rl, rv
 
 
 def pack_minibatch(src, B, T, F, gap, dst):

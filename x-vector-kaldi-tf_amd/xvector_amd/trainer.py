@@ -103,6 +103,8 @@ class Trainer(object):
         self._packed = None
         self._plan = None
         self._layouts = {}
+        self._one_start = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._one_len = {}
         self._side_busy = False
         self.two_streams = os.environ.get("XVECTOR_TRAIN_STREAMS", "2") != "1"
         self._splits = {}                                          # split-format copies for the K = 1 layers' GEMMs (bf16x3)
@@ -230,14 +232,11 @@ class Trainer(object):
             # of pageable host arrays are host synchronisations; with the loss read back one step late the stream is NOT empty at
             # the head of a step, and a run that draws its length per minibatch -- 201 lengths -- met a new one, and with it a
             # full stop of the host, in most of its first few hundred steps.)
-            slot, lead = T + self.gap, lay.lead
-            assert lay.align == 1 and lay.rows == lead + B * slot
-            idx = torch.arange(lay.rows, dtype=torch.int32, device=self.device) - lead
-            self._layouts[key] = dict(lay=lay, rs=torch.arange(B, dtype=torch.int32, device=self.device) * slot + lead,
-                                      rl=torch.full((B,), T, dtype=torch.int32, device=self.device),
-                                      rv=((idx >= 0) & (torch.remainder(idx, slot) < T)).to(torch.uint8),
-                                      one_start=torch.zeros(1, dtype=torch.int32, device=self.device),
-                                      one_len=torch.full((1,), B, dtype=torch.int32, device=self.device))
+            assert lay.align == 1 and lay.lead == self.gap and lay.rows == self.gap + B * (T + self.gap)
+            rs, rl, rv = hiplib.minibatch_layout(B, T, self.gap, lay.rows, self.device)
+            if B not in self._one_len:
+                self._one_len[B] = torch.full((1,), B, dtype=torch.int32, device=self.device)
+            self._layouts[key] = dict(lay=lay, rs=rs, rl=rl, rv=rv, one_start=self._one_start, one_len=self._one_len[B])
         return self._layouts[key]
 
     def _bn_scopes_stats(self, r, scope, L, rows_per_chunk, nchunks, train, valid, frame_level, split_out=None, moments_ws=None):
@@ -511,7 +510,18 @@ class Trainer(object):
         the others, as in the reference where only class Model wires the keep-prob placeholder into the graph."""
         torch = self.torch
         S = self._forward(x, labels, train=True, want_grad=True, keep_prob=1.0 - float(dropout_proportion), seed=seed)
-        hiplib.ema(self.flat_moving, self.flat_batch, BN_DECAY)     # moving <- 0.95*moving + 0.05*batch, all scopes at once
+        # moving <- 0.95*moving + 0.05*batch, all scopes at once -- beside the backward pass, not in front of it (every launch of the
+        # segment level is a ~5 us link of one dependent chain); the stream is joined in front of the optimizer update
+        if self.two_streams:
+            main = torch.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                hiplib.ema(self.flat_moving, self.flat_batch, BN_DECAY)
+            self._side_busy = True
+        else:
+            hiplib.ema(self.flat_moving, self.flat_batch, BN_DECAY)
         L, B, T = S["L"], S["B"], S["T"]
         grads = {}
         if self.am:
@@ -521,7 +531,7 @@ class Trainer(object):
             hiplib.axpy(g, g, float(self.am["scale"]) - 1.0)
             E = S["xh"].shape[1]
             dwh = torch.empty((1, E, self.num_classes), dtype=torch.float32, device=self.device)
-            self.G["output/b:0"].zero_()
+            # (output/b is not part of this head: its gradient segment of flat_g is zero from the start and nothing ever writes it)
             hiplib.wgrad(S["xh"], g, 1, 1, dwh, self.precision)
             dxh = torch.empty_like(S["xh"])
             hiplib.tdnn_layer(g, hiplib.pack_weights(S["wh_t"]), None, None, None, tp.ACT_NONE, None, 1, 1, None, dxh)
