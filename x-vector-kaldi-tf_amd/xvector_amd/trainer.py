@@ -372,8 +372,9 @@ class Trainer(object):
             S["xh"], S["xnorm"] = hiplib.l2_normalize_rows(S["e_in"][-1])
             wt = self.P["output/w:0"].t().contiguous()                                   # [classes, E]: class vectors as rows
             S["wh_t"], S["wnorm"] = hiplib.l2_normalize_rows(wt)
-            S["wh"] = S["wh_t"].t().contiguous()                                         # [E, classes]
-            hiplib.fc(S["xh"], hiplib.pack_weights(S["wh"]), None, None, None, tp.ACT_NONE, None, None, logits)
+            # the FC takes its weights as [Out, In] rows (xv_pack_weights_f32 is that transposition of [In, Out]): the normalised
+            # class vectors ARE that matrix -- no transpose-and-pack-back pair of launches
+            hiplib.fc(S["xh"], S["wh_t"], None, None, None, tp.ACT_NONE, None, None, logits)
             hiplib.am_margin(logits, lab, self.am["scale"], self.am["margin"])
         else:
             hiplib.fc(S["e_in"][-1], pk["output"], self.P["output/b:0"], None, None, tp.ACT_NONE, None, None, logits)
@@ -534,7 +535,8 @@ class Trainer(object):
             # (output/b is not part of this head: its gradient segment of flat_g is zero from the start and nothing ever writes it)
             hiplib.wgrad(S["xh"], g, 1, 1, dwh, self.precision)
             dxh = torch.empty_like(S["xh"])
-            hiplib.tdnn_layer(g, hiplib.pack_weights(S["wh_t"]), None, None, None, tp.ACT_NONE, None, 1, 1, None, dxh)
+            wh = S["wh_t"].t().contiguous()                                  # [E, classes] = the packed form of wh_t as GEMM weights
+            hiplib.tdnn_layer(g, wh, None, None, None, tp.ACT_NONE, None, 1, 1, None, dxh)
             d = hiplib.l2_normalize_backward(dxh, S["xh"], S["xnorm"])
             dwt = hiplib.l2_normalize_backward(dwh[0].t().contiguous(), S["wh_t"], S["wnorm"])       # [classes, E]
             self.G["output/w:0"].copy_(dwt.t())
