@@ -17,9 +17,14 @@ Two implementations live here: a thin ctypes binding of ``libxv_oracle.so`` (pla
 ``oracle/xv_oracle.c``; fp32 and fp64) and an independent pure-NumPy fp64 version
 (``forward_numpy``) used to cross-check the C one.
 
-PARITY STATUS: see the header of ``oracle/xv_oracle.c`` -- TensorFlow is absent, so the forward
-arithmetic is unpinned against TF itself and pinned against an independent torch-CPU
-implementation + the reference's own control flow (tests/golden/make_golden.py).
+PARITY STATUS (details in the header of ``oracle/xv_oracle.c``): ``forward`` / ``forward_numpy`` / ``attention_pool`` /
+``embed_utterance`` are pinned against the reference's own graph code EXECUTED -- every ``build_model`` + ``load_model`` +
+``make_embedding`` of local/tf/models.py run under tests/golden/numpy_tf1.py; tests/golden/forward_refgraph.npz holds what they
+return and tests/test_oracle.py::test_oracle_matches_the_reference_graph requires < 1e-12 on all 8 classes, every layer, the pooled
+vector and both embeddings.  Statements here that are now reference-executed: layer op order (bias -> activation -> BN), BN_EPSILON,
+VAR2STD_EPSILON, SAME padding incl. dilation, the PReLU / leaky-ReLU forms, the attention split and softmax axis, which tensors
+embedding[0] / [1] are, the variable names.  What stays by definition: the numerics of each TF op (TensorFlow itself is absent),
+and ``sliding_cmn`` / ``select_voiced`` (Kaldi is absent: PARITY UNPINNED, said where they are defined).
 """
 import ctypes
 import os

@@ -12,8 +12,14 @@ dropout, following the TF op definitions at its call sites:
                                 (models.py:112): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMAs; var -= lr_t*m/(sqrt(v)+eps)
 * eval phase                    same graph with the moving statistics (tf_block.py:25-26), models.py:307-354
 
-PARITY STATUS: TensorFlow is absent, so this is pinned only by construction from the op definitions (and, for the
-eval-phase frame-level part, by agreeing with the extraction oracle oracle/oracle.py); stated in DESIGN.md.
+PARITY STATUS: pinned against the reference's own training loop EXECUTED: ``train_one_iteration`` (models.py:216-305) and ``eval``
+(:307-354) of all 8 classes run under tests/golden/numpy_tf1.py on graphs their own build_model made (batch-norm train branch, decay,
+the L2 terms, class Model's dropout sites with the masks it drew, AdamOptimizer with its slots saved and restored through the
+checkpoint); tests/golden/train_refgraph.npz holds three steps' losses, the step-0 gradients, weights / moving statistics / Adam slots
+after the steps and the eval losses, and tests/test_oracle.py::test_training_oracle_matches_the_reference_graph requires this module
+to reproduce them to 1e-9.  The numerics of each TF op and of reverse mode are numpy_tf1's (documented definitions, checked against
+finite differences in tests/test_numpy_tf1.py); TensorFlow itself never runs.  The AM-softmax head is build-defined (not in the
+reference): unpinned.
 """
 import numpy as np
 import torch

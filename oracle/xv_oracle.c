@@ -9,14 +9,22 @@
  * path (x-vector-kaldi-tf_amd/) never calls it and fails loudly without its HIP
  * library.
  *
- * PARITY STATUS: the reference's arithmetic is executed by TensorFlow 1.x, which
- * is un-vendored, unpinned (README.md:28-32) and not installable here, and the
- * reference ships no tests or golden vectors for this path.  So the forward
- * arithmetic is "parity unpinned" against TF itself; it is pinned instead
- * (tests/test_oracle.py) against an independent torch-CPU implementation of the
- * same TF op definitions, and the control flow / ark framing is pinned against
- * the reference's own Python (make_embedding, kaldi_io) executed in the build
- * container -- see tests/golden/make_golden.py.
+ * PARITY STATUS: pinned in two layers (tests/test_oracle.py, fixtures written by
+ * tests/golden/make_golden.py in the build container):
+ *   GRAPH WIRING -- reference-executed.  Every build_model of the reference's
+ *   local/tf/models.py (+ tf_block.py), its load_model, make_embedding,
+ *   train_one_iteration and eval run UNMODIFIED under tests/golden/numpy_tf1.py
+ *   (a NumPy float64 evaluator registered as `tensorflow`); what those graphs
+ *   return for embedding[0] / [1], the pooled vector and every layer's output is
+ *   tests/golden/forward_refgraph.npz, and this oracle agrees with it to < 1e-12
+ *   on all 8 classes.  Op order, both epsilons, SAME / dilation arguments, the
+ *   variable names, which tensor is the x-vector are therefore the reference's
+ *   code's decisions, not a reading of it.
+ *   OP NUMERICS -- by cited definition.  TensorFlow 1.x itself (un-vendored,
+ *   version-unpinned README.md:28-32, not installable here) never runs: each op
+ *   in numpy_tf1.py is the documented TF definition, checked on its own by
+ *   tests/test_numpy_tf1.py (index-arithmetic convolution, finite differences).
+ *   Control flow / ark framing: the reference's own Python, byte for byte.
  */
 #include <math.h>
 #include <stdlib.h>

@@ -9,7 +9,8 @@
  *
  * The arithmetic of the reference lives in TensorFlow 1.x (un-vendored, version
  * unpinned, absent from this image), so these functions follow the TF op
- * DEFINITIONS at the reference's call sites:
+ * DEFINITIONS at the reference's call sites; how they are WIRED is checked
+ * against the reference's graph code executed (header of xv_oracle.c):
  *   conv1d / convolution  local/tf/models.py:60, :476, :579-580
  *   bias_add              local/tf/models.py:61
  *   relu / leaky / prelu  local/tf/models.py:64, :912 ; local/tf/tf_block.py:38-47

@@ -50,3 +50,32 @@ def encode_cm_record(key, mat):
     u = np.where(v < p25, lo, np.where(v < p75, mid, hi)).astype(np.uint8)
     return key.encode() + b" \0BCM " + struct.pack("<ffii", float(gmin), float(grange), rows, cols) + q.tobytes() + \
         np.ascontiguousarray(u.T).tobytes()
+
+
+def refgraph_training_case(g, cls):
+    """Inputs of one class's record in tests/golden/train_refgraph.npz, regenerated from its seed: (topology, weights, batches,
+    dropout masks per step or None)."""
+    from xvector_amd import synthetic, topology
+    seed, nc = int(g["seed"]), int(g["num_classes"])
+    topo = topology.get(cls)
+    w = synthetic.trained_like(topo, 23, num_classes=nc, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    batches = [((rng.standard_normal((6, 40 + 5 * i, 23)) * 3).astype(np.float16), rng.integers(0, nc, 6).astype(np.int32)) for i in range(3)]
+    masks = None
+    if cls == "Model":
+        masks = []
+        widths = topo["layer_sizes"][:4] + topo["embedding_sizes"][:1]
+        for step in range(3):
+            per = {}
+            for site in range(5):
+                key = [k for k in g.files if k.startswith("Model/dropout/%d/%d/" % (step, site))][0]
+                scope = key.split("/")[-1].split("|")[0]
+                shape = (6, 40 + 5 * step, widths[site]) if site < 4 else (6, widths[site])
+                per[scope] = (np.unpackbits(g[key])[:int(np.prod(shape))].reshape(shape).astype(np.float64), 0.8)
+            masks.append(per)
+    return topo, w, batches, masks
+
+
+def compact(a, stride, small_stride=1):
+    a = np.asarray(a, np.float64).reshape(-1)
+    return a[::small_stride] if a.size <= 1536 else a[::stride]

@@ -1,5 +1,7 @@
-"""GPU parity of the whole path: DeviceModel / Extractor / Model.make_embedding vs golden fixtures
-(fp64 oracle, generated by tests/golden/make_golden.py) and vs the oracle run live on small cases.
+"""GPU parity of the whole path: DeviceModel / Extractor / Model.make_embedding vs golden fixtures and vs the oracle run live on
+small cases.  The golden x-vectors (tests/golden/forward_refgraph.npz) are what the REFERENCE'S OWN GRAPHS return: every build_model
+of local/tf/models.py executed under tests/golden/numpy_tf1.py (NumPy float64 evaluation of the TF ops), loaded by the reference's
+load_model, fed as make_embedding feeds it (tests/golden/make_golden.py).
 
 Bar (BASELINE.json north_star): embeddings within 1e-4 relative L2 of the CPU reference on identical
 inputs.  The tests assert the much tighter 1e-5 that exact-fp32 MFMA accumulation delivers.
@@ -25,10 +27,12 @@ def env(oracle_mod):
 
 @pytest.mark.parametrize("tname,cls", [("default", "ModelWithoutDropout"), ("dilated", "ModelWithoutDropoutTdnn"),
                                        ("prelu", "ModelWithoutDropoutPRelu"), ("lrelu", "ModelL2LossWithoutDropoutLRelu"),
-                                       ("attention", "ModelL2LossWithoutDropoutLReluAttention")])
+                                       ("attention", "ModelL2LossWithoutDropoutLReluAttention"), ("dropout", "Model"),
+                                       ("l2prelu", "ModelL2LossWithoutDropoutPRelu"), ("heinit", "ModelL2LossWithoutDropoutReluHeInit")])
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_forward_matches_golden(env, golden, tname, cls, precision):
-    g = golden("forward_default.npz")
+    """All 8 classes of local/tf/models.py: the HIP path vs the vectors the reference's own graph returned."""
+    g = golden("forward_refgraph.npz")
     seed = int(g["seed"])
     topo = env["topology"].get(cls)
     w = env["synthetic"].trained_like(topo, 23, seed=seed)
@@ -50,7 +54,7 @@ def test_forward_matches_golden(env, golden, tname, cls, precision):
 def test_layer_intermediates_T25(env, golden, precision):
     """Per-layer tensors for a T=25 utterance: localises edge-padding bugs (SURVEY §7.3 hard part 1)."""
     torch = env["torch"]
-    g = golden("forward_default.npz")
+    g = golden("forward_refgraph.npz")
     seed = int(g["seed"])
     topo = env["topology"].get("ModelWithoutDropout")
     w = env["synthetic"].trained_like(topo, 23, seed=seed)
@@ -159,6 +163,39 @@ def test_make_embedding_end_to_end_control_flow(env, golden, tmp_path, precision
         assert len(out.getvalue()) == len(g["out_ark_%d" % si])
         for (k, a), (_, b) in zip(got, ref):
             assert a.dtype == np.float32 and a.shape == b.shape
+            assert env["oracle"].rel_l2(a, b) < TOL[precision], (k, min_chunk, chunk)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS + ["fp32tc"])
+def test_make_embedding_matches_the_reference_graph_stream(env, golden, tmp_path, precision, monkeypatch):
+    """ark bytes in -> ark bytes out, the reference on both ends: forward_refgraph.npz embed_out_ark_* is the stream the reference's
+    make_embedding (models.py:356-432) wrote while driving the reference's own ModelWithoutDropout graph (numpy_tf1 evaluation) on a
+    model directory its own build_model created.  The twin's make_embedding on the HIP path: same keys, same order, same framing, same
+    length, vectors within the asserted tolerance -- the whole chain with no statement of mine between the reference and the check."""
+    import logging
+    import kaldi_io
+    import models
+    monkeypatch.setenv("XVECTOR_PRECISION", precision)
+    g = golden("forward_refgraph.npz")
+    seed = int(g["seed"])
+    topo = env["topology"].get("ModelWithoutDropout")
+    w = env["synthetic"].trained_like(topo, 23, seed=seed)
+    mdir = str(tmp_path / "model_default")
+    models.Model.save_model(dict(weights=w, topology=topo, model_class="ModelWithoutDropout", num_classes=64, feat_dim=23), mdir, None)
+    rng = np.random.default_rng(seed + 2)
+    bio = io.BytesIO()
+    for i, T in enumerate(g["embed_lengths"]):
+        kaldi_io.write_mat(bio, (rng.standard_normal((int(T), 23)) * 3.0).astype(np.float32), key="rg%02d-T%d" % (i, T))
+    log = logging.getLogger("test_refgraph_stream")
+    for si, (min_chunk, chunk) in enumerate(g["embed_settings"]):
+        out = io.BytesIO()
+        models.ModelWithoutDropout().make_embedding(io.BytesIO(bio.getvalue()), out, mdir, int(min_chunk), int(chunk), False, log)
+        want = g["embed_out_ark_%d" % si].tobytes()
+        got = list(kaldi_io.read_vec_flt_ark(io.BytesIO(out.getvalue())))
+        ref = list(kaldi_io.read_vec_flt_ark(io.BytesIO(want)))
+        assert [k for k, _ in got] == [k for k, _ in ref] and len(out.getvalue()) == len(want)
+        for (k, a), (_, b) in zip(got, ref):
+            assert a.dtype == b.dtype == np.float32
             assert env["oracle"].rel_l2(a, b) < TOL[precision], (k, min_chunk, chunk)
 
 

@@ -161,8 +161,9 @@ def net(oracle_mod):
 
 
 def test_fp32tc_forward_matches_golden(net, golden):
-    """The golden x-vectors of the default topology (tests/golden/forward_default.npz: fp64 oracle on seeded weights / inputs)."""
-    g = golden("forward_default.npz")
+    """The golden x-vectors of the default topology (tests/golden/forward_refgraph.npz: what the reference's own graph returned under
+    tests/golden/numpy_tf1.py, on seeded weights / inputs)."""
+    g = golden("forward_refgraph.npz")
     seed = int(g["seed"])
     topo = net["topology"].get("ModelWithoutDropout")
     w = net["synthetic"].trained_like(topo, 23, seed=seed)

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def env():
+def env(oracle_mod):
     import torch
     from oracle import train_ref
     from xvector_amd import hiplib, synthetic, topology, trainer
@@ -193,6 +193,52 @@ def test_three_adam_steps_follow_the_oracle(env):
         err = np.abs(got[n] - ref_w[n])[m]
         assert np.linalg.norm(err) < 0.02 * np.linalg.norm(delta) + 1e-7, (n, np.linalg.norm(err), np.linalg.norm(delta))
         assert _rel(adam["m"][n][m], ref_adam["m"][n][m]) < 1e-3 and _rel(adam["v"][n][m], ref_adam["v"][n][m]) < 1e-3, n
+
+
+@pytest.mark.parametrize("cls", ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelWithoutDropoutPRelu", "ModelL2LossWithoutDropoutPRelu",
+                                 "ModelL2LossWithoutDropoutLRelu", "ModelL2LossWithoutDropoutLReluAttention",
+                                 "ModelL2LossWithoutDropoutReluHeInit"])
+def test_three_steps_follow_the_reference_training_loop(env, golden, cls):
+    """tests/golden/train_refgraph.npz: what the REFERENCE'S OWN train_one_iteration (models.py:216-305) did on its own graph over three
+    float16 minibatches (executed under tests/golden/numpy_tf1.py: batch-norm train branch tf_block.py:18-23, AdamOptimizer, the L2 terms)
+    and what its eval (models.py:307-354) then returned.  The GPU trainer at full width, exact-fp32 arithmetic: the three losses, the
+    step-0 gradients, the moving statistics and Adam's first-moment slots after the steps, the weights (on the elements whose gradient is
+    not at rounding-noise level: Adam divides by it), and the eval-phase losses of the trained model."""
+    from fixture_inputs import compact, refgraph_training_case
+    g = golden("train_refgraph.npz")
+    stride, lr = int(g["stride"]), float(g["lr"])
+    topo, w, batches, _ = refgraph_training_case(g, cls)
+    tr = env["trainer"].Trainer(w, topo, precision="fp32")
+    names = env["ref"].trainable_names(topo)
+    loss0, _, grads0 = env["trainer"].Trainer(w, topo, precision="fp32").gradients(batches[0][0], batches[0][1])
+    assert abs(loss0 - g["%s/loss" % cls][0]) < 1e-5 * max(1.0, abs(loss0))
+    bad = {}
+    for n in names:
+        e = _rel(compact(grads0[n].cpu().numpy(), stride), g["%s/grad0/%s" % (cls, n)])
+        if e > 3e-4:
+            bad[n] = e
+    assert not bad, bad
+    for bi, (x, labels) in enumerate(batches):
+        loss, acc = tr.step(x, labels, lr)
+        assert abs(loss - g["%s/loss" % cls][bi]) < 2e-4 * max(1.0, abs(loss)), (bi, loss, g["%s/loss" % cls][bi])
+        assert acc == pytest.approx(g["%s/accuracy" % cls][bi])
+    got, adam = tr.export()
+    assert adam["t"] == 3 and abs(float(g["%s/after/beta1_power:0" % cls][0]) - 0.9 ** 4) < 1e-15
+    for n in got:
+        want = g["%s/after/%s" % (cls, n)]
+        mine = compact(got[n], stride)
+        if n.endswith(("/mean:0", "/variance:0")):
+            assert _rel(mine, want) < 1e-5, n
+            continue
+        g0 = g["%s/grad0/%s" % (cls, n)]
+        ok = np.abs(g0) > 1e-2 * np.sqrt(np.mean(g0 ** 2))
+        delta = (want - compact(w[n], stride))[ok]
+        assert np.linalg.norm((mine - want)[ok]) < 0.05 * np.linalg.norm(delta) + 1e-7, n
+        m = compact(adam["m"][n], stride, 8)
+        assert _rel(m, g["%s/after/%s/Adam:0" % (cls, n[:-2])]) < 2e-3, n
+    for bi, (x, labels) in enumerate(batches[:2]):
+        loss, acc = tr.eval_batch(x.astype(np.float32), labels)
+        assert abs(loss - g["%s/eval_loss" % cls][bi]) < 2e-3 * max(1.0, abs(loss)), (bi, loss)
 
 
 def test_wgrad_and_reductions_unit(env):

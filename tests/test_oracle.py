@@ -2,7 +2,8 @@
 
 * forward arithmetic: C fp64 oracle == independent NumPy fp64 restatement == torch-CPU ops
   (conv1d / batch_norm / var) evaluating the TF op definitions; C fp32 oracle within fp32 round-off
-* committed golden x-vectors (tests/golden/forward_default.npz) reproduce
+* THE PIN: the fp64 oracle == what the reference's own graphs compute (tests/golden/forward_refgraph.npz, train_refgraph.npz: every
+  build_model / load_model / make_embedding / train_one_iteration / eval of local/tf/models.py executed under tests/golden/numpy_tf1.py)
 * control flow + ark framing: the oracle's make_embedding restatement reproduces, BYTE FOR BYTE, the
   output stream the reference's own Model.make_embedding wrote (tests/golden/make_embedding.npz)
 """
@@ -12,7 +13,8 @@ import numpy as np
 import pytest
 
 import kaldi_io
-from fixture_inputs import CONTROL_FEAT, CONTROL_LENGTHS, CONTROL_SEED, CONTROL_SETTINGS, FWD_SEED, control_inputs
+from fixture_inputs import (CONTROL_FEAT, CONTROL_LENGTHS, CONTROL_SEED, CONTROL_SETTINGS, FWD_SEED, compact, control_inputs,
+                            refgraph_training_case)
 from xvector_amd import synthetic, topology
 
 
@@ -94,25 +96,132 @@ def test_reference_init_weights_forward(oracle_mod):
     assert oracle_mod.rel_l2(a, _torch_forward(x, w, topo)) < 1e-12
 
 
-def test_golden_forward_vectors_reproduce(oracle_mod, golden):
-    """Default-topology goldens: regenerate the weights/inputs from the seed, compare the fp64 oracle
-    with the committed vectors (guards the oracle AND the seeded generators against drift)."""
-    g = golden("forward_default.npz")
+REF_CLASSES = [("default", "ModelWithoutDropout", [25, 200, 400, 1000]), ("dilated", "ModelWithoutDropoutTdnn", [25, 200, 400, 1000]),
+               ("prelu", "ModelWithoutDropoutPRelu", [25, 200]), ("lrelu", "ModelL2LossWithoutDropoutLRelu", [25, 200]),
+               ("attention", "ModelL2LossWithoutDropoutLReluAttention", [25, 200, 1000]), ("dropout", "Model", [25, 200]),
+               ("l2prelu", "ModelL2LossWithoutDropoutPRelu", [25, 200]), ("heinit", "ModelL2LossWithoutDropoutReluHeInit", [25, 200])]
+
+
+@pytest.mark.parametrize("tname,cls,Ts", REF_CLASSES)
+def test_oracle_matches_the_reference_graph(oracle_mod, golden, tname, cls, Ts):
+    """THE PIN of the forward arithmetic: tests/golden/forward_refgraph.npz holds what the reference's own build_model graphs
+    (local/tf/models.py, tf_block.py -- executed under tests/golden/numpy_tf1.py, loaded through the reference's load_model) return
+    for embedding[0], embedding[1], the pooled vector and every layer's output.  The fp64 oracle must agree to round-off, for all 8
+    classes; the fp32 C oracle (the cpu_baseline arithmetic) within fp32 round-off."""
+    g = golden("forward_refgraph.npz")
     assert int(g["seed"]) == FWD_SEED
+    topo = topology.get(cls)
+    w = synthetic.trained_like(topo, 23, seed=FWD_SEED)
+    rng = np.random.default_rng(FWD_SEED + 1)
+    for T in Ts:
+        x = (rng.standard_normal((T, 23)) * 3.0).astype(np.float32)
+        e1, inter = oracle_mod.forward(x, w, topo, np.float64, embedding_index=1, return_intermediates=True)
+        assert oracle_mod.rel_l2(inter[6], g["%s_T%d_e0" % (tname, T)]) < 1e-12
+        assert oracle_mod.rel_l2(e1, g["%s_T%d_e1" % (tname, T)]) < 1e-12
+        assert oracle_mod.rel_l2(oracle_mod.forward_numpy(x, w, topo, 0), g["%s_T%d_e0" % (tname, T)]) < 1e-12
+        if T == 25:
+            for li in range(5):
+                assert oracle_mod.rel_l2(inter[li][:, ::16], g["%s_T25_layer%d_sub" % (tname, li)]) < 1e-12, li
+            assert oracle_mod.rel_l2(inter[5], g["%s_T25_pooled" % tname]) < 1e-12
+        if T <= 200:
+            assert oracle_mod.rel_l2(oracle_mod.forward(x, w, topo, np.float32), g["%s_T%d_e0" % (tname, T)]) < 5e-6
+
+
+@pytest.mark.parametrize("tname,cls,Ts", REF_CLASSES)
+def test_variable_names_shapes_and_initial_values_are_the_reference_graphs(golden, tname, cls, Ts, tmp_path):
+    """The variables the reference's scopes produce (names, shapes; with the optimizer's slots) and the law of its initial values, against
+    the twin's build_model: same names and shapes; constants equal; random tensors with the same bounds and spread."""
+    import models as twin
+    from xvector_amd import weights as wio
+    g = golden("forward_refgraph.npz")
+    names = [str(n) for n in g["%s_var_names" % tname]]
+    shapes = dict(zip(names, [tuple(int(d) for d in str(s).split(",") if d) for s in g["%s_var_shapes" % tname]]))
+    stats = dict(zip(names, g["%s_init_stats" % tname]))
+    model_vars = [n for n in names if "/Adam" not in n and not n.startswith("beta")]
+    trainable = [n for n in model_vars if not n.endswith(("/mean:0", "/variance:0"))]
+    assert sorted(n for n in names if n.endswith("/Adam:0")) == sorted(n[:-2] + "/Adam:0" for n in trainable)       # slots exist for exactly the trainables
+    assert sorted(n for n in names if n.endswith("/Adam_1:0")) == sorted(n[:-2] + "/Adam_1:0" for n in trainable)
+    assert stats["beta1_power:0"][0] == 0.9 and stats["beta2_power:0"][0] == 0.999
+    getattr(twin, cls)().build_model(64, 23, str(tmp_path / "m"))
+    w, meta = wio.load_model_dir(str(tmp_path / "m"))
+    assert sorted(w) == sorted(model_vars)
+    from oracle import train_ref
+    assert sorted(train_ref.trainable_names(meta["topology"])) == sorted(trainable)
+    for n in model_vars:
+        assert tuple(w[n].shape) == shapes[n], n
+        lo, hi, mean, std = stats[n]
+        if std == 0.0:                                                   # a constant initialiser: b = 0.1, gamma 1, beta 0, mean 0, variance 1, alpha 0.1
+            assert np.all(w[n] == np.float32(lo)), (n, lo)
+        else:
+            a = np.asarray(w[n], np.float64)
+            assert abs(a.std() - std) < 0.08 * std + 1e-3, (n, a.std(), std)
+            bound = max(abs(lo), abs(hi))
+            assert np.abs(a).max() <= bound * 1.05 + 1e-6 and np.abs(a).max() >= bound * 0.8, (n, np.abs(a).max(), bound)
+            assert abs(a.mean() - mean) < 4 * std / np.sqrt(a.size) + 1e-3 * std + abs(mean) * 0.5, n
+
+
+def test_oracle_make_embedding_reproduces_the_reference_graph_stream(oracle_mod, golden):
+    """ark in -> the reference's make_embedding driving the reference's graph -> ark out (forward_refgraph.npz embed_*): the oracle's
+    restatement of the driver over the oracle's forward writes the same records -- the same keys, and vectors equal to the last bit
+    except where a float64 difference of 1e-15 straddles a float32 rounding boundary (at most 1 ulp, counted)."""
+    g = golden("forward_refgraph.npz")
     topo = topology.get("ModelWithoutDropout")
     w = synthetic.trained_like(topo, 23, seed=FWD_SEED)
-    rng = np.random.default_rng(FWD_SEED + 1)
-    for T in (25, 200):
-        x = (rng.standard_normal((T, 23)) * 3.0).astype(np.float32)
-        e0 = oracle_mod.forward(x, w, topo, np.float64)
-        assert oracle_mod.rel_l2(e0, g["default_T%d_e0" % T]) < 1e-9
-        e32 = oracle_mod.forward(x, w, topo, np.float32)
-        assert oracle_mod.rel_l2(e32, g["default_T%d_e0" % T]) < 5e-6
-    topo = topology.get("ModelL2LossWithoutDropoutLReluAttention")
-    w = synthetic.trained_like(topo, 23, seed=FWD_SEED)
-    rng = np.random.default_rng(FWD_SEED + 1)
-    x = (rng.standard_normal((25, 23)) * 3.0).astype(np.float32)
-    assert oracle_mod.rel_l2(oracle_mod.forward(x, w, topo, np.float64), g["attention_T25_e0"]) < 1e-9
+    rng = np.random.default_rng(FWD_SEED + 2)
+    utts = [("rg%02d-T%d" % (i, T), (rng.standard_normal((T, 23)) * 3.0).astype(np.float32)) for i, T in enumerate(g["embed_lengths"])]
+    flips = total = 0
+    for si, (min_chunk, chunk) in enumerate(g["embed_settings"]):
+        want = list(kaldi_io.read_vec_flt_ark(io.BytesIO(g["embed_out_ark_%d" % si].tobytes())))
+        got = []
+        for key, mat in utts:
+            v = oracle_mod.embed_utterance(mat, w, topo, int(min_chunk), int(chunk), np.float64)
+            if v is not None:
+                got.append((key, v))
+        assert [k for k, _ in got] == [k for k, _ in want]
+        assert [k for k, _ in want] == [k for k, m in utts if m.shape[0] >= min_chunk]
+        for (_, a), (_, b) in zip(got, want):
+            assert a.dtype == b.dtype == np.float32
+            ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+            assert ulp.max() <= 1
+            flips += int((ulp > 0).sum())
+            total += a.size
+    assert flips <= total * 1e-3, (flips, total)
+
+
+TRAIN_CLASSES = ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelWithoutDropoutPRelu", "ModelL2LossWithoutDropoutPRelu",
+                 "ModelL2LossWithoutDropoutLRelu", "ModelL2LossWithoutDropoutLReluAttention", "ModelL2LossWithoutDropoutReluHeInit", "Model"]
+
+
+@pytest.mark.parametrize("cls", TRAIN_CLASSES)
+def test_training_oracle_matches_the_reference_graph(oracle_mod, golden, cls):
+    """THE PIN of the training arithmetic (f1): tests/golden/train_refgraph.npz holds what the reference's own train_one_iteration
+    (models.py:216-305; tf_block.py:18-23 train branch; AdamOptimizer; the L2 terms; class Model's dropout sites with the masks drawn)
+    and eval (models.py:307-354) did over three minibatches, executed under numpy_tf1 with reverse-mode gradients checked against
+    finite differences (tests/test_numpy_tf1.py).  oracle/train_ref.py (torch float64 autograd) must reproduce the losses, the
+    step-0 gradients, the weights, moving statistics and Adam slots after the steps, and the eval-phase losses."""
+    from oracle import train_ref
+    g = golden("train_refgraph.npz")
+    stride, lr = int(g["stride"]), float(g["lr"])
+    topo, w, batches, masks = refgraph_training_case(g, cls)
+    ww = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    adam = {"t": 0, "m": {}, "v": {}}
+    for bi, (x, labels) in enumerate(batches):
+        loss, acc, ww, adam, grads = train_ref.train_step(ww, adam, topo, x.astype(np.float64), labels, lr, dropout=masks[bi] if masks else None)
+        assert abs(loss - g["%s/loss" % cls][bi]) < 1e-10 * max(1.0, abs(loss)), bi
+        assert acc == g["%s/accuracy" % cls][bi]
+        if bi == 0:
+            for n, gr in grads.items():
+                assert oracle_mod.rel_l2(compact(gr, stride), g["%s/grad0/%s" % (cls, n)]) < 1e-9, n
+    for n, v in ww.items():
+        assert oracle_mod.rel_l2(compact(v, stride), g["%s/after/%s" % (cls, n)]) < 1e-9, n
+    for n in adam["m"]:
+        assert oracle_mod.rel_l2(compact(adam["m"][n], stride, 8), g["%s/after/%s/Adam:0" % (cls, n[:-2])]) < 1e-9, n
+        assert oracle_mod.rel_l2(compact(adam["v"][n], stride, 8), g["%s/after/%s/Adam_1:0" % (cls, n[:-2])]) < 1e-9, n
+    assert abs(float(g["%s/after/beta1_power:0" % cls][0]) - 0.9 ** (adam["t"] + 1)) < 1e-15
+    for bi, (x, labels) in enumerate(batches[:2]):
+        loss, acc, _ = train_ref.eval_batch(ww, topo, x.astype(np.float64), labels)
+        assert abs(loss - g["%s/eval_loss" % cls][bi]) < 1e-9 * max(1.0, abs(loss))
+        assert acc == g["%s/eval_accuracy" % cls][bi]
 
 
 def test_chunk_plan_matches_reference_driver(oracle_mod, golden):
