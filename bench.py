@@ -361,14 +361,19 @@ def _cli_job_leg(args, ark_path, scp_path, model_dir, n):
         env.pop(k, None)
     runs = {}
     try:
-        # in this order: the product default on a box that has run nothing yet, RCCL cold, RCCL warm, shard files, the default warm
-        for name, backend, shard in (("default_first", None, "gather"), ("rccl_first", "nccl", "gather"), ("rccl", "nccl", "gather"),
-                                     ("files", None, "files"), ("default", None, "gather")):
+        # in this order: the product default (RCCL, device code pre-loaded under `import torch`) on a box that has run nothing yet, the
+        # same warm, RCCL without the pre-load (what rounds 1-4 ran), the gloo gather (round 5's default), shard files
+        for name, backend, shard, prewarm in (("default_first", None, "gather", None), ("default", None, "gather", None),
+                                              ("rccl_no_prewarm", "nccl", "gather", "0"), ("gloo", "gloo", "gather", None),
+                                              ("files", None, "files", None)):
             o_ark, o_scp = os.path.join(out_dir, "xvector_%s.ark" % name), os.path.join(out_dir, "xvector_%s.scp" % name)
             env["XVECTOR_SHARD_OUTPUT"] = shard
             env.pop("XVECTOR_DIST_BACKEND", None)
+            env.pop("XVECTOR_RCCL_PREWARM", None)
             if backend:
                 env["XVECTOR_DIST_BACKEND"] = backend
+            if prewarm is not None:
+                env["XVECTOR_RCCL_PREWARM"] = prewarm
             cmd = [sys.executable, "-m", "xvector_amd.launch", "--nproc", "1",
                    os.path.join(ROOT, "x-vector-kaldi-tf_amd", "local", "tf", "extract_embedding.py"), "--use-gpu", "yes",
                    "--min-chunk-size", "25", "--chunk-size", "10000", "--feature-rspecifier", "scp:" + scp_path,
@@ -391,14 +396,17 @@ def _cli_job_leg(args, ark_path, scp_path, model_dir, n):
     return {"value": runs["default"]["utt_per_s"], "unit": "utt/s", "utterances": n, "wall_s": runs["default"]["wall_s"],
             "transport": runs["default"]["transport"], "breakdown_s": runs["default"]["breakdown_s"],
             "first_job_on_this_box": runs["default_first"],
-            "rccl_gather": dict(runs["rccl"], first_job=runs["rccl_first"],
-                                note="XVECTOR_DIST_BACKEND=nccl: the gather over RCCL, what every job did up to round 4 and what a job "
-                                     "above XVECTOR_HOST_GATHER_MAX_MB (512 MB of vectors) still does; `first_job`: librccl's device code cold"),
+            "rccl_gather": dict(runs["default"], first_job=runs["default_first"],
+                                note="the product default since round 6: ONE RCCL gather; the worker pre-loads RCCL's device code under "
+                                     "`import torch` (xvector_amd/rccl_prewarm.py).  `first_job`: librccl cold in the box's page cache"),
+            "rccl_without_prewarm": dict(runs["rccl_no_prewarm"], note="XVECTOR_RCCL_PREWARM=0 XVECTOR_DIST_BACKEND=nccl: the communicator's device "
+                                         "code loaded when the group comes up (rounds 1-4)"),
+            "gloo_gather": dict(runs["gloo"], note="XVECTOR_DIST_BACKEND=gloo: the gather of the host-resident vectors over TCP loopback "
+                                                   "(round 5's default for payloads up to 512 MB)"),
             "shard_files": dict(runs["files"], note="XVECTOR_SHARD_OUTPUT=files: one ark per rank + a concatenated scp (the reference's "
                                                     "own protocol, extract_xvectors.sh:83-95), no process group"),
             "path": "python -m xvector_amd.launch --nproc 1 extract_embedding.py scp: -> ark,scp: (tmpfs), forced 1-rank group; wall clock of "
-                    "the whole job from outside.  Product default: the one gather of the job (x-vectors that already lie in host memory) "
-                    "goes over the transport xvector_amd.dist.gather_backend picks from its size -- gloo up to 512 MB, RCCL above"}
+                    "the whole job from outside"}
 
 
 def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, precision="fp32", oracle_check=None):
@@ -445,8 +453,11 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, precision
             ex += 2.0 * taps * cin * cout
         out.update({"dtype": "f32 (exact fp32 products and fp32 accumulation; the K = 5 / K = 7 layers as Toom-Cook F(2, K) over time: "
                              "not bit-identical to fp32_exact)",
-                    "frac_note": "frac / tdnn_gemm_tflops count the ALGORITHMIC multiplications (2 K Cin Cout per frame) against the "
-                                 "157.3 TF fp32-MFMA peak: above 1 is possible because fewer are executed; executed_frac counts what the MFMAs run",
+                    "frac": ex * frames * steps / t_g / MFMA_F32_PEAK,
+                    "algorithmic_over_peak": fl * steps / t_g / MFMA_F32_PEAK,
+                    "frac_note": "frac = EXECUTED multiplications (what the MFMAs run) against the 157.3 TF fp32-MFMA peak; "
+                                 "algorithmic_over_peak / tdnn_gemm_tflops count the ALGORITHMIC multiplications (2 K Cin Cout per frame): "
+                                 "above 1 is possible because fewer are executed -- a speed-up over the direct form's ceiling, not a roofline fraction",
                     "executed_tflops": ex * frames * steps / t_g / 1e12, "executed_frac": ex * frames * steps / t_g / MFMA_F32_PEAK,
                     "executed_over_algorithmic_flops": ex / tp.flops_per_frame(topo, feat),
                     "kernel": "tdnn_gemm_toom_kernel<5>, <7> (layers 1, 2: 6 / 8 transformed products per row pair on v_mfma_f32_32x32x2_f32, "
@@ -823,7 +834,9 @@ def main():
                    "batch_rows": args.batch_rows, "precision": selection.get("selected", args.precision),
                    "precision_requested": args.precision, "fused_pool": bool(model.fused_pool),
                    "pair_kernel": paired, "dist_initialized": bool(dist.is_initialized()),
-                   "parallelism": "utterance-sharded x%d, one %s gather" % (world, "RCCL" if not dist.is_initialized() or dist.get_backend() == "nccl" else dist.get_backend() + " (TEST MODE, ranks share a GPU)")},
+                   "parallelism": ("one rank holds every utterance: no exchange at N = 1" if world == 1 else
+                                   "utterance-sharded x%d, one %s gather per step" % (world, "RCCL (nccl backend over xGMI)" if dist.get_backend() == "nccl"
+                                                                                       else dist.get_backend() + " (TEST MODE, ranks share a GPU)"))},
         "frames_per_s": frames * world * args.steps / dt,
         "algorithmic_tflops": fl_total * world * args.steps / dt / 1e12,
         "roofline": dict({"bound": "mfma", "achieved": fl_gemm / t_gemm / 1e12, "unit": "TFLOP/s", "traffic": traffic,
@@ -973,6 +986,28 @@ def main():
             out["trained_checkpoint"] = _trained_checkpoint_leg(dev, feat)
         except Exception as e:
             out["trained_checkpoint"] = {"error": repr(e)}
+    # the exact-fp32 legs are the ones in the reference's own arithmetic (models.py:60 is an fp32 conv1d): a compact copy inside
+    # `roofline` so that a record which keeps only the contract's objects still carries them
+    same = {}
+    for key in ("fp32_toomcook", "fp32_exact"):
+        leg = out.get(key)
+        if isinstance(leg, dict) and "value" in leg:
+            same[key] = {"utt_s": round(leg["value"], 1), "ms_per_step": round(leg["ms_per_step"], 3), "frac_of_157.3TF_executed": round(leg["frac"], 4),
+                         "parity_rel_l2_max_vs_fp64_oracle": leg.get("parity_rel_l2_max_vs_fp64_oracle")}
+            if "algorithmic_over_peak" in leg:
+                same[key]["algorithmic_over_peak"] = round(leg["algorithmic_over_peak"], 4)
+    if same:
+        same["note"] = "same workload, same bench.py run; IEEE fp32 products + fp32 accumulation = the reference's arithmetic (models.py:60); the headline `value` is the tolerance-contract f16bf8 path"
+        tr = out.get("train_step")
+        if isinstance(tr, dict) and "ms_per_step" in tr:
+            same["train_step_ms"] = {"bf16x3": round(tr["ms_per_step"], 3), "fp32": round(tr.get("fp32", {}).get("ms_per_step", float("nan")), 3)}
+        cv = out.get("config2_varlen")
+        if isinstance(cv, dict) and "value" in cv:
+            same["config2_varlen_utt_s"] = round(cv["value"], 1)
+        cj = out.get("cli_job")
+        if isinstance(cj, dict):
+            same["cli_job"] = {k: cj[k] for k in ("wall_s", "transport", "utterances") if k in cj}
+        out["roofline"]["same_arithmetic"] = same
     print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

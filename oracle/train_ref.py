@@ -127,8 +127,11 @@ def forward(params, stats, topo, x, labels, train, dropout=None):
     beta = topo.get("l2_beta", 0.0)
     if beta:                                                           # models.py:811-842: tf.nn.l2_loss(t) = sum(t**2)/2
         l2 = 0.0
+        am = bool(topo.get("head")) and topo["head"].get("type") == "am_softmax"
         for sc, coef in (("embed_layer-0", 0.1), ("embed_layer-1", 1.0), ("output", 1.0)):
-            l2 = l2 + coef * 0.5 * ((params[sc + "/w:0"] ** 2).sum() + (params[sc + "/b:0"] ** 2).sum())
+            l2 = l2 + coef * 0.5 * (params[sc + "/w:0"] ** 2).sum()
+            if not (am and sc == "output"):            # the build-defined AM head has no bias: output/b is not part of its model or penalty
+                l2 = l2 + coef * 0.5 * (params[sc + "/b:0"] ** 2).sum()
         loss = loss + beta * l2
     acc = (logits.argmax(dim=1) == labels).double().mean()
     return loss, acc, new_stats, e0

@@ -22,7 +22,7 @@ Fixtures
                         graphs (all 8 classes, eval phase) produce for trained-like weights from a seed, T in {25,200,400,1000};
                         the variable name / shape table and the initial-value law of each build_model; the output ark of the
                         reference's make_embedding driving its own graph (every value asserted <= 1e-12 from the fp64 oracle)
-  train_refgraph.npz    the reference's train_one_iteration (3 Adam steps, lr 0.002; class Model with dropout 0.2 and the
+  train_refgraph.npz    the reference's train_one_iteration (3 Adam steps, lr 1e-4; class Model with dropout 0.2 and the
                         masks drawn) and eval on every class: per-step loss / accuracy, step-0 gradients, weights, moving
                         statistics and Adam slots after the steps (small tensors whole, large ones strided)
 Usage:  python tests/golden/make_golden.py
@@ -275,7 +275,7 @@ def golden_forward_refgraph(ref_io, ref_models, out):
 
 TRAIN_CLASSES = ["ModelWithoutDropout", "ModelWithoutDropoutTdnn", "ModelWithoutDropoutPRelu", "ModelL2LossWithoutDropoutPRelu",
                  "ModelL2LossWithoutDropoutLRelu", "ModelL2LossWithoutDropoutLReluAttention", "ModelL2LossWithoutDropoutReluHeInit", "Model"]
-TRAIN_SEED, TRAIN_CLASSES_N, TRAIN_LR, TRAIN_STRIDE = 77, 7, 0.002, 1999
+TRAIN_SEED, TRAIN_CLASSES_N, TRAIN_LR, TRAIN_STRIDE = 77, 7, 0.0001, 1999
 
 
 class _Batches(object):

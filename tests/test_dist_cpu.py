@@ -2,6 +2,7 @@
 xvector_amd.dist with a stand-in per-utterance function (the GPU forward itself is covered by -m gpu)."""
 import os
 import subprocess
+import time
 import sys
 import textwrap
 
@@ -431,11 +432,19 @@ def test_two_rank_gloo_cli_shards_an_scp_table(tmp_path):
     # XVECTOR_SHARD_OUTPUT=files: the reference's own protocol (extract_xvectors.sh:83-95) -- every rank writes its own ark while
     # it extracts, rank 0 concatenates the scp parts; no process group, no collective at all; same keys, order and vectors
     port += 1
+    # ... and what an earlier job with the same output paths left behind when it died before its concatenation: a complete-looking part
+    # of rank 1 (these ranks share no job token).  Rank 0 must wait for THIS job's part, not concatenate the old one.
+    stale = str(tmp_path / "three.scp.1.part")
+    with open(stale, "wt") as f:
+        f.write("ghost %s:7\n" % (tmp_path / "nowhere.ark.1"))
+    os.utime(stale, (1e9, 1e9))
     procs = []
-    for r in range(2):
+    for r in (0, 1):
         env = dict(base_env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    XVECTOR_SHARD_OUTPUT="files")
         procs.append(subprocess.Popen([sys.executable, str(script)] + flags("three"), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        if r == 0:
+            time.sleep(1.5)             # rank 0 is at its wait loop before rank 1 even starts
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("CLI_OK collectives=\n" in o for o in outs), outs

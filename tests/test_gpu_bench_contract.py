@@ -64,9 +64,19 @@ def test_extraction_bench_line():
     assert j["utterances"] == 700 and j["first_job_on_this_box"]["vectors_written"] == 700 and 0 < j["wall_s"] < 60
     assert j["breakdown_s"]["total"] <= j["wall_s"] and "import torch" in j["breakdown_s"] and "gather" in j["breakdown_s"]
     assert j["shard_files"]["vectors_written"] == 700 and "gather" not in j["shard_files"]["breakdown_s"]
-    # the product default sends this job's 1.4 MB of vectors over gloo (dist.gather_backend); the RCCL gather is timed beside it
-    assert j["transport"] == "gloo" and j["rccl_gather"]["transport"] == "nccl" and j["rccl_gather"]["vectors_written"] == 700
-    assert j["rccl_gather"]["first_job"]["vectors_written"] == 700
+    # the product default is ONE RCCL gather (the worker pre-loads RCCL's device code under `import torch`); RCCL without the pre-load
+    # and the gloo gather are timed beside it
+    assert j["transport"] == "nccl" and j["rccl_gather"]["transport"] == "nccl" and j["rccl_gather"]["vectors_written"] == 700
+    assert j["rccl_gather"]["first_job"]["vectors_written"] == 700 and "RCCL pre-load (ok) joined after" in j["breakdown_s"]
+    assert j["rccl_without_prewarm"]["transport"] == "nccl" and not any("pre-load" in k for k in j["rccl_without_prewarm"]["breakdown_s"])
+    assert j["gloo_gather"]["transport"] == "gloo" and j["gloo_gather"]["vectors_written"] == 700
+    # what a record that keeps only the contract's objects still carries: the exact-fp32 legs (the reference's arithmetic), compactly
+    sa = r["same_arithmetic"]
+    assert sa["fp32_exact"]["utt_s"] == pytest.approx(f["value"], rel=1e-3) and 0 < sa["fp32_toomcook"]["frac_of_157.3TF_executed"] < 1
+    assert sa["fp32_toomcook"]["algorithmic_over_peak"] > sa["fp32_toomcook"]["frac_of_157.3TF_executed"]
+    assert sa["train_step_ms"]["bf16x3"] == pytest.approx(t["ms_per_step"], rel=1e-3) and sa["cli_job"]["transport"] == "nccl"
+    assert 0 < d["fp32_toomcook"]["frac"] < 1 and d["fp32_toomcook"]["frac"] == d["fp32_toomcook"]["executed_frac"]
+    assert "no exchange at N = 1" in d["config"]["parallelism"]
 
 
 def test_two_ranks_through_the_self_launcher_on_one_gpu():

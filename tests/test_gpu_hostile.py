@@ -81,7 +81,7 @@ def test_hostile_checkpoints_stay_inside_the_bar(env, cls, seed):
         assert worst < TIGHT, (sel, worst)
     else:
         assert sel["f16bf8_vs_bf16x3"] > env["engine"].PROBE_LIMIT_F16BF8 or sel["probe_left_fp16_range"] or ex.demoted
-        assert model.precision in ("bf16x3", "fp32") or ex.demoted
+        assert model.arithmetic in ("bf16x3", "fp32tc") or ex.demoted
     assert forced["fp32"] < 3e-5                      # the exact-fp32 kernels are the reference's own arithmetic (measured: <= 1.3e-5)
 
 
@@ -116,8 +116,9 @@ def test_run_time_probe_demotes_the_extractor(env, monkeypatch):
 
 
 def test_load_time_probe_steps_down_and_reports(env, monkeypatch):
-    """select_model with limits forced to zero walks the whole ladder f16bf8 -> bf16x3 -> fp32 and reports each measurement;
-    with the probe disabled it takes the request as given."""
+    """select_model with limits forced to zero walks the whole ladder f16bf8 -> bf16x3 -> fp32tc (the exact rung: exact fp32 products,
+    Toom-Cook on the layers it covers; XVECTOR_EXACT_RUNG=fp32 keeps the direct contraction) and reports each measurement; with the
+    probe disabled it takes the request as given."""
     engine = env["engine"]
     topo = env["topology"].get("ModelWithoutDropout")
     w = env["synthetic"].trained_like(topo, 23, seed=22)
@@ -129,9 +130,13 @@ def test_load_time_probe_steps_down_and_reports(env, monkeypatch):
     assert 0 < m.selection["f16bf8_vs_bf16x3"] < 3e-5 and 0 < m.selection["bf16x3_vs_fp32"] < 2e-5
     monkeypatch.setattr(engine, "PROBE_LIMIT_BF16X3", 0.0)
     m = engine.select_model(w, topo, "cuda:0", precision="f16bf8")
-    assert m.precision == "fp32" and m.selection["selected"] == "fp32"
-    for req in ("bf16x3", "fp32"):                     # nothing faster than the request is ever selected
-        assert engine.select_model(w, topo, "cuda:0", precision=req).precision == req
+    assert m.arithmetic == "fp32tc" and m.toom and m.selection["selected"] == "fp32tc" and m.selection["exact_rung"] == "fp32tc"
+    monkeypatch.setenv("XVECTOR_EXACT_RUNG", "fp32")
+    m = engine.select_model(w, topo, "cuda:0", precision="f16bf8")
+    assert m.arithmetic == "fp32" and not m.toom and m.selection["selected"] == "fp32"
+    monkeypatch.delenv("XVECTOR_EXACT_RUNG")
+    for req in ("bf16x3", "fp32", "fp32tc"):           # nothing faster than the request is ever selected
+        assert engine.select_model(w, topo, "cuda:0", precision=req).arithmetic == req
 
 
 def test_make_embedding_reports_the_selected_arithmetic(env, tmp_path, monkeypatch):

@@ -184,6 +184,16 @@ def _scp_shard(spec, rank, world, vad_spec=None):
     return mine, [table[k] for k in shard_keys[rank] if k in table], shard_keys
 
 
+def _embedding_dim(model_dir):
+    """Width of the x-vector this model directory produces (embed_layer-0: models.py:82-86), from its meta alone."""
+    try:
+        import json
+        with open(os.path.join(model_dir, 'model.meta'), 'rb') as fid:
+            return int(json.loads(fid.read().decode('utf-8'))["topology"]["embedding_sizes"][0])
+    except Exception:          # a TensorFlow-written directory: every class of the reference has 512 (models.py:29)
+        return 512
+
+
 def _is_scp_table(rspecifier):
     spec = rspecifier.strip()
     return spec.split(':', 1)[0].replace(' ', '').split(',')[0] == 'scp' and not spec.endswith('|')
@@ -217,7 +227,7 @@ def eval_dnn(args):
     if presharded:
         feat_scp, vad_scp, shard_keys = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
         # the job's one exchange is known now: [emitted? | x-vector] rows of every utterance, from host memory to rank 0's host memory
-        xdist.set_gather_payload(sum(len(k) for k in shard_keys) * 513 * 4)
+        xdist.set_gather_payload(sum(len(k) for k in shard_keys) * (1 + _embedding_dim(args.model_dir)) * 4)
         feats = kaldi_io.MatScp(feat_scp)
         vad = kaldi_io.VecScp(vad_scp) if vad_scp is not None else None
     else:
@@ -266,7 +276,9 @@ def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
     through the file system: a part appears under its final name (``<scp>.r.<job>.part``) only when it is complete.  ``<job>`` tells
     the parts of THIS job from what a job that died before its concatenation left behind (a rank 0 that reaches the wait loop first
     would otherwise take a stale part for rank r's result): XVECTOR_JOB_TOKEN (the package's launcher sets it), else torchrun's
-    TORCHELASTIC_RUN_ID; ranks with neither write untokenised parts (``<scp>.r.part``)."""
+    TORCHELASTIC_RUN_ID; ranks with neither write untokenised parts (``<scp>.r.part``), and rank 0 then accepts a part only if it was
+    written after rank 0's own process was born -- a part an earlier, dead job left behind is older than that and is waited out (the
+    job fails loudly on XVECTOR_SHARD_TIMEOUT if rank r never delivers) instead of being concatenated."""
     import glob
     import time
     # a token every rank PROVABLY shares: the launcher's (xvector_amd.launch exports XVECTOR_JOB_TOKEN), torchrun's run id; ranks
@@ -275,6 +287,7 @@ def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
     token = os.environ.get("XVECTOR_JOB_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
     token = "".join(ch if ch.isalnum() or ch in "-_" else "_" for ch in token)
     part = ('.%s.part' % token) if token else '.part'
+    job_started = time.time()
     if rank == 0 and token:
         started = time.time()
         for stale in glob.glob(glob.escape(scp) + '.*.part'):        # other jobs' leftovers (also ranks >= world of a larger run)
@@ -301,9 +314,16 @@ def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
         return
     deadline = time.time() + float(os.environ.get("XVECTOR_SHARD_TIMEOUT", "3600"))
     parts = ['%s.%d%s' % (scp, r, part) for r in range(world)]
-    while not all(os.path.exists(p) for p in parts):
+    born = None if token else (jobclock.process_birth() or job_started)
+
+    def delivered(p):
+        try:
+            return os.path.getmtime(p) >= born if born is not None else os.path.exists(p)
+        except OSError:
+            return False
+    while not all(delivered(p) for p in parts):
         if time.time() > deadline:
-            raise RuntimeError("sharded extraction: still waiting for %s" % ", ".join(p for p in parts if not os.path.exists(p)))
+            raise RuntimeError("sharded extraction: still waiting for %s" % ", ".join(p for p in parts if not delivered(p)))
         time.sleep(0.02)
     jobclock.mark("wait for the other ranks' shards")
     with open(scp + '.tmp', 'wb') as fid_out:
@@ -342,10 +362,24 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    # RCCL's device code starts loading NOW, in front of `import torch` (xvector_amd/rccl_prewarm.py: only here, in the worker's own
+    # process, which leaves through os._exit on every path below -- a process that opened librccl before torch must not run its exit
+    # handlers).  The job's one exchange is then "a single RCCL gather" again without paying a second of bring-up for it.
+    from xvector_amd import rccl_prewarm
+    rccl_prewarm.start()
+    code = 0
+    try:
+        main()
+    except SystemExit as e:            # argparse's usage errors (2), main()'s sys.exit(1) after a traceback
+        code = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+        if e.code is not None and not isinstance(e.code, int):
+            print(e.code, file=sys.stderr)
+    except BaseException:              # what the reference lets escape main() (process_args' exception): traceback, exit status 1
+        traceback.print_exc()
+        code = 1
     # a finished worker has nothing left to tear down in order: the outputs are closed and renamed.  Leaving through the
     # interpreter's shutdown (torch, the HIP runtime, RCCL's proxy threads) costs ~0.4 s of every job
     logging.shutdown()
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    os._exit(code)

@@ -312,7 +312,9 @@ class Model(object):
     def _trainer(self, input_dir, logger, first_batch=None):
         """The trainer of a model directory.  XVECTOR_TRAIN_PRECISION: "fp32" | "bf16x3" as given, "auto" (the default): bf16x3 when
         the gradients of ``first_batch`` = (x, labels) agree with the exact-fp32 ones (trainer.select_trainer), else fp32;
-        without a first batch (eval) "auto" is fp32."""
+        without a first batch (eval) "auto" is fp32.  The verdict travels with the model (weights.save_train_verdict): the next
+        iterations reuse it -- "fp32" for good (also after a non-finite bf16x3 loss, see train_one_iteration), "bf16x3" for ten
+        iterations, then the probe runs again on that iteration's first minibatch."""
         from xvector_amd import trainer
         if logger is not None:
             logger.info("Start loading graph ...")
@@ -321,8 +323,17 @@ class Model(object):
         self.num_classes = meta["num_classes"]
         precision = os.environ.get("XVECTOR_TRAIN_PRECISION", "auto")
         adam = wio.load_optimizer_state(input_dir)
-        if precision == "auto" and first_batch is not None:
-            tr, self.train_precision_verdict = trainer.select_trainer(w, meta["topology"], _device(), adam, first_batch[0], first_batch[1], logger)
+        self.train_precision_auto = precision == "auto"
+        kept = wio.load_train_verdict(input_dir) if precision == "auto" and first_batch is not None else None
+        if kept is not None:
+            self.train_precision_verdict = dict(kept, iterations_since_probe=int(kept.get("iterations_since_probe", 0)) + 1, reused=True)
+            tr = trainer.Trainer(w, meta["topology"], _device(), adam, precision=kept["selected"])
+            if logger is not None:
+                logger.info("Training arithmetic: %s (verdict of %d iteration(s) ago, kept with the model)" % (
+                    kept["selected"], self.train_precision_verdict["iterations_since_probe"]))
+        elif precision == "auto" and first_batch is not None:
+            tr, verdict = trainer.select_trainer(w, meta["topology"], _device(), adam, first_batch[0], first_batch[1], logger)
+            self.train_precision_verdict = dict(verdict, iterations_since_probe=0)
         else:
             tr = trainer.Trainer(w, meta["topology"], _device(), adam, precision="fp32" if precision == "auto" else precision)
         if logger is not None:
@@ -391,11 +402,11 @@ class Model(object):
                     _StepDone(tr.step(batch, labels, args.learning_rate, keep_out, seed))
                 now = (index, batch.shape[0], batch.shape[1], handle)
                 if pending is not None:
-                    meter.stepped(pending[0], pending[1], pending[2], *pending[3].result())
+                    meter.stepped(pending[0], pending[1], pending[2], *self._finite(pending, tr, args.input_dir, logger))
                 pending = now
                 meter.waited("gpu", time.time() - t0)
             if pending is not None and (index == data_loader.count - 1 or meter.interval_due(index)):
-                meter.stepped(pending[0], pending[1], pending[2], *pending[3].result())
+                meter.stepped(pending[0], pending[1], pending[2], *self._finite(pending, tr, args.input_dir, logger))
                 pending = None
             if not stepped_now:
                 meter.skipped(index)     # (last word on this index: an index without a step never closes an interval)
@@ -411,9 +422,31 @@ class Model(object):
             # optimizer slots first, the model (whose 'done' marker completes the directory) last
             os.makedirs(args.output_dir, exist_ok=True)
             wio.save_optimizer_state(args.output_dir, adam)
+            if getattr(self, "train_precision_verdict", None) is not None:
+                wio.save_train_verdict(args.output_dir, self.train_precision_verdict)
             self.save_model(dict(weights=w, topology=self.meta["topology"], model_class=self.meta["model_class"],
                                  num_classes=self.meta["num_classes"], feat_dim=self.meta["feat_dim"]), args.output_dir, logger)
         logger.info(meter.elapsed_line())
+
+    def _finite(self, pending, tr, input_dir, logger):
+        """(loss, accuracy) of a finished step.  A non-finite loss of the bf16x3 step that the gradient probe admitted ("auto") is
+        this build's doing, not the reference's arithmetic: the iteration stops, nothing is saved, and the INPUT model's verdict is
+        set to fp32 -- a rerun of this iteration (and every later one) trains in the exact-fp32 step.  A non-finite loss in fp32, or
+        in an arithmetic the user forced, is reported as the reference would report it (it appears in the log lines)."""
+        loss, accuracy = pending[3].result()
+        if not np.isfinite(loss) and getattr(self, "train_precision_auto", False) and getattr(tr, "precision", "fp32") == "bf16x3":
+            verdict = dict(getattr(self, "train_precision_verdict", None) or {}, selected="fp32", iterations_since_probe=0,
+                           demoted="non-finite loss at minibatch %d of a bf16x3 iteration" % pending[0])
+            try:
+                wio.save_train_verdict(input_dir, verdict)
+            except OSError:
+                pass
+            msg = ("non-finite training loss at minibatch %d in the bf16x3 arithmetic: iteration stopped, no model written; "
+                   "'%s' is now marked for the exact-fp32 step -- rerun this iteration" % (pending[0], input_dir))
+            if logger is not None:
+                logger.error(msg)
+            raise FloatingPointError(msg)
+        return loss, accuracy
 
     def eval(self, data_loader, input_dir, use_gpu, logger):
         """Twin of models.py:307-354: loss / accuracy over ``data_loader`` in the eval phase (moving BN statistics)."""

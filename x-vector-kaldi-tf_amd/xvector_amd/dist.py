@@ -6,9 +6,11 @@ MI355X equivalent: one process per GPU (``torch.distributed``, backend "nccl" ==
 deterministic frame-balanced partition every rank can recompute, NO collective on the data path, and
 ONE gather of the ``[N_r, E]`` fp32 embedding blocks to rank 0, which restores input order and writes
 the ark.  Keys and rejected-utterance flags need no communication: they follow from the lengths.
-An scp-sharded CLI job, whose vectors already lie in host memory when the gather starts, picks the transport of
-that one gather by its size (``gather_backend``: gloo for a few hundred MB, RCCL above); everything else -- the
-training step's all-reduces, bench.py, the stream / byte-range modes -- is RCCL.
+The CLI worker's gather is RCCL too (round 6): ``extract_embedding.py`` pre-loads RCCL's device code under ``import torch``
+(``rccl_prewarm``), which removed the ~1 s bring-up that had made gloo the better transport for small jobs.  A process that
+could not pre-load (a library user of ``Model.make_embedding``, XVECTOR_RCCL_PREWARM=0) still picks the transport of that
+one gather by its size (``gather_backend``: gloo for a few hundred MB, RCCL above); everything else -- the training step's
+all-reduces, bench.py, the stream / byte-range modes -- is RCCL.
 """
 import heapq
 import os
@@ -86,13 +88,22 @@ def gather_backend(payload_bytes):
         return forced
     if not torch.cuda.is_available():
         return "gloo"
+    from . import rccl_prewarm
+    if os.environ.get(rccl_prewarm.ENV_FLAG) == "1":
+        # the worker pre-loaded RCCL's device code under `import torch` (rccl_prewarm): the bring-up that made gloo the better choice
+        # for small payloads is gone.  Decided from the environment alone -- the same on every rank, whatever became of its pre-load
+        return "nccl"
     limit = float(os.environ.get("XVECTOR_HOST_GATHER_MAX_MB", HOST_GATHER_MAX_MB))
     return "gloo" if payload_bytes <= limit * 1e6 else "nccl"
 
 
 def set_gather_payload(payload_bytes):
     """Tell a pending ``init_process_group_async`` what the job will gather (before its start mark fires): picks the transport."""
-    if "box" in _ASYNC and "thread" in _ASYNC and not _ASYNC["go"].is_set():
+    if "box" in _ASYNC and "thread" in _ASYNC:
+        if _ASYNC["go"].is_set():
+            # a rank whose bring-up has started keeps the default transport while its peers may pick another: a rendezvous that hangs.
+            # The callers state the payload before the first window is launched; anything else is a programming error, said loudly
+            raise RuntimeError("set_gather_payload after the process group's bring-up has started: the ranks could disagree on the transport")
         _ASYNC["backend"] = gather_backend(payload_bytes)
 
 
@@ -123,6 +134,13 @@ def init_process_group_async(backend=None, after_mark=None):
         t0 = time.time()
         try:
             chosen = _ASYNC.get("backend") or backend
+            from . import rccl_prewarm
+            if rccl_prewarm.started():                  # torch's communicator after the throw-away one: it finds the device code resident
+                state = rccl_prewarm.join(60.0)
+                jobclock.note("RCCL pre-load (%s) joined after" % state, time.time() - t0)
+                if state != "ok":
+                    import logging
+                    logging.getLogger("xvector_amd.dist").warning("RCCL pre-load: %s -- the group comes up the plain way", rccl_prewarm.report())
             box["value"] = init_process_group(chosen)
             jobclock.note("process group (%s) up on its side thread after" % (chosen or "default"), time.time() - t0)
         except BaseException as e:          # noqa: B902 -- re-raised by wait_process_group

@@ -691,8 +691,12 @@ def _max_rel_l2(a, b):
 def select_model(weights, topo, device="cuda:0", embedding_index=0, precision="f16bf8", probe=None):
     """``DeviceModel`` in the fastest arithmetic, not faster than ``precision``, that the accuracy probe admits for THESE weights:
     f16bf8 -> (its x-vectors of the probe batch differ from bf16x3's by more than PROBE_LIMIT_F16BF8, or are not finite, or left
-    the fp16 range) -> bf16x3 -> (differs from the exact-fp32 kernels by more than PROBE_LIMIT_BF16X3) -> fp32.  The second step
-    only runs when the first one failed: a model that passes as f16bf8 loads exactly as before plus two small forwards.
+    the fp16 range) -> bf16x3 -> (differs from the exact-fp32 kernels by more than PROBE_LIMIT_BF16X3) -> the exact rung.  The
+    second step only runs when the first one failed: a model that passes as f16bf8 loads exactly as before plus two small forwards.
+    The exact rung is ``fp32tc`` (exact fp32 products, the K = 5 / 7 layers as Toom-Cook F(2, K): more accurate than the direct form
+    on all 22 checkpoints of profiles/r05_fp32tc_accuracy_sweep.txt and 1.3x faster; bit-identical to ``fp32`` on a topology the
+    Toom-Cook kernel does not cover) -- a demoted model does not fall to the slowest form.  XVECTOR_EXACT_RUNG=fp32 (or a request
+    of ``precision="fp32"``) keeps the direct contraction, the literal statement of local/tf/models.py:60.
     ``model.selection`` reports what was measured.  ``probe=False`` (or XVECTOR_ACCURACY_PROBE=0) takes ``precision`` as given."""
     if probe is None:
         probe = os.environ.get("XVECTOR_ACCURACY_PROBE", "1") != "0"
@@ -712,11 +716,12 @@ def select_model(weights, topo, device="cuda:0", embedding_index=0, precision="f
                probe_frames=int(np.sum(batch[2])))
     if err <= PROBE_LIMIT_F16BF8 and not clamped:
         return model
-    exact = DeviceModel(weights, topo, device, embedding_index, "fp32")
+    rung = "fp32" if os.environ.get("XVECTOR_EXACT_RUNG", "fp32tc") == "fp32" else "fp32tc"
+    exact = DeviceModel(weights, topo, device, embedding_index, rung)
     err3 = _max_rel_l2(ref, exact.probe_vectors(batch))
-    sel.update(bf16x3_vs_fp32=err3, bf16x3_limit=PROBE_LIMIT_BF16X3)
+    sel.update(bf16x3_vs_fp32=err3, bf16x3_limit=PROBE_LIMIT_BF16X3, exact_rung=exact.arithmetic)
     chosen = twin if err3 <= PROBE_LIMIT_BF16X3 else exact
-    sel["selected"] = chosen.precision
+    sel["selected"] = chosen.arithmetic
     chosen.selection = sel
     return chosen
 

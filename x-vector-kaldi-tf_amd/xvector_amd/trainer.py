@@ -143,7 +143,7 @@ class Trainer(object):
         if out is None:
             return 0.0
         v = out.cpu().numpy().astype(np.float64)
-        return float(self.l2_beta * sum(coef * 0.5 * (v[2 * i] + v[2 * i + 1]) for i, (_, coef) in enumerate(self.l2_terms)))
+        return self._l2_from_host(v)
 
     def _l2_value(self):
         """beta * sum coef * tf.nn.l2_loss(t) over the penalised tensors (0 for classes without the L2 term)."""
@@ -209,19 +209,25 @@ class Trainer(object):
     def _stage_in(self, x):
         """A contiguous float16 / float32 / int32 host array -> a device tensor of the same dtype, through one of two alternating
         pinned buffers per dtype (the copy is asynchronous -- a pageable ``.to(device)`` in the middle of a step makes the host
-        wait for everything enqueued before it; the buffer of step i is not touched again before step i+2, and every step ends
-        with a read-back of its loss)."""
+        wait for everything enqueued before it).  The buffer of step i is written again by step i + 2: an event recorded behind
+        each copy is waited for before the host overwrites the buffer, so a caller that keeps more than two steps in flight
+        (step_async) waits here instead of corrupting a minibatch whose copy has not run yet."""
         torch = self.torch
         dt = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32}[x.dtype]
         slots = self.__dict__.setdefault("_in_stage", {})
         turns = self.__dict__.setdefault("_in_turn", {})
         turn = turns[dt] = turns.get(dt, 0) ^ 1
-        pin = slots.get((dt, turn))
+        pin, copied = slots.get((dt, turn), (None, None))
         if pin is None or pin.numel() < x.size:
-            pin = slots[(dt, turn)] = torch.empty(max(x.size, 1) * 5 // 4 + 64, dtype=dt).pin_memory()
+            pin, copied = torch.empty(max(x.size, 1) * 5 // 4 + 64, dtype=dt).pin_memory(), torch.cuda.Event()
+            slots[(dt, turn)] = (pin, copied)
+        else:
+            copied.synchronize()                        # (returns at once when the copy of two steps ago has run, the normal case)
         host = pin[:x.size]
         host.numpy()[:] = x.reshape(-1)
-        return host.to(self.device, non_blocking=True)
+        dev = host.to(self.device, non_blocking=True)
+        copied.record()
+        return dev
 
     def _layout(self, B, T):
         key = (B, T)
@@ -501,6 +507,10 @@ class Trainer(object):
             for sc, coef in self.l2_terms:
                 if sc == scope:
                     for suffix in ("/w:0", "/b:0"):
+                        if self.am and sc == "output" and suffix == "/b:0":
+                            # the AM head has no bias: its gradient segment is zero from the start and never re-zeroed (gradients()),
+                            # so an L2 term added here would ACCUMULATE over the steps.  The bias is not part of that head's model.
+                            continue
                         hiplib.axpy(grads[sc + suffix], self.P[sc + suffix], self.l2_beta * coef)
 
     def gradients(self, x, labels, dropout_proportion=0.0, seed=0, on_bucket=None, defer_loss=False):
@@ -647,6 +657,11 @@ class Trainer(object):
         slots = self.__dict__.setdefault("_result_slots", [None, None])
         turn = self.__dict__["_result_turn"] = self.__dict__.get("_result_turn", 0) ^ 1
         n_l2 = 0 if pending[1] is None else pending[1].numel()
+        # the slot of step i is reused by step i + 2: the handle that still points at it takes its values out first (a handle awaited
+        # late returns ITS step's loss, not a later one's)
+        owners = self.__dict__.setdefault("_result_owner", [None, None])
+        if owners[turn] is not None:
+            owners[turn].result()
         if slots[turn] is None or slots[turn][0].numel() < 2 + n_l2:
             slots[turn] = (torch.empty(2 + n_l2, dtype=torch.float32).pin_memory(), torch.cuda.Event())
         host, done = slots[turn]
@@ -654,11 +669,15 @@ class Trainer(object):
         if n_l2:
             host[2:2 + n_l2].copy_(pending[1].view(-1), non_blocking=True)
         done.record()
-        return _PendingStep(self, host, done, n_l2)
+        owners[turn] = _PendingStep(self, host, done, n_l2)
+        return owners[turn]
 
     def _l2_from_host(self, v):
+        """beta * sum coef * (sumsq(w) + sumsq(b)) / 2 from the [w, b] sums of squares per penalised scope; the AM head has no bias, so
+        output/b is no part of its penalty (value here, gradient in _l2_grad)."""
         v = np.asarray(v, dtype=np.float64)
-        return float(self.l2_beta * sum(coef * 0.5 * (v[2 * i] + v[2 * i + 1]) for i, (_, coef) in enumerate(self.l2_terms)))
+        return float(self.l2_beta * sum(coef * 0.5 * (v[2 * i] + (0.0 if (self.am and sc == "output") else v[2 * i + 1]))
+                                        for i, (sc, coef) in enumerate(self.l2_terms)))
 
     def export(self):
         """-> (weights {tf name: float32 ndarray}, adam {"t", "m", "v"}) for the model directory."""
@@ -680,6 +699,7 @@ class _PendingStep(object):
             la = self._host.numpy()
             l2 = self._t._l2_from_host(la[2:2 + self._n_l2]) if self._n_l2 else 0.0
             self._value = (float(la[0]) + l2, float(la[1]))
+            self._host = self._done = None              # the pinned slot belongs to a later step from now on
         return self._value
 
 
@@ -732,4 +752,6 @@ def select_trainer(weights, topo, device, adam, x, labels, logger=None):
     if logger is not None:
         logger.info("Training arithmetic: %s (first-minibatch gradient probe: bf16x3 vs fp32 %.2e on %s, limit %.0e; loss %.6f vs %.6f)" % (
             verdict["selected"], worst, worst_name, TRAIN_PROBE_LIMIT, l3, l32))
-    return (fast if ok else exact), verdict
+    chosen = fast if ok else exact
+    del fast, exact, g3, g32, keep                    # the rejected trainer (weights, Adam slots, flat buffers) is freed here, not at some later collection
+    return chosen, verdict

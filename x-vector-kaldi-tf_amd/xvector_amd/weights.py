@@ -98,6 +98,30 @@ def load_optimizer_state(input_dir):
     return adam
 
 
+TRAIN_VERDICT = "train_arithmetic.json"
+TRAIN_VERDICT_REPROBE_EVERY = 10
+
+
+def save_train_verdict(model_dir, verdict):
+    """The arithmetic the training of this model runs in (trainer.select_trainer's verdict + how many iterations ago it was probed)."""
+    with open(os.path.join(model_dir, TRAIN_VERDICT), "wt") as fid:
+        json.dump(verdict, fid)
+
+
+def load_train_verdict(model_dir):
+    """-> verdict dict or None (no verdict, unreadable, or due for a fresh probe)."""
+    try:
+        with open(os.path.join(model_dir, TRAIN_VERDICT), "rt") as fid:
+            v = json.load(fid)
+        if v.get("selected") not in ("fp32", "bf16x3"):
+            return None
+        if v["selected"] == "bf16x3" and int(v.get("iterations_since_probe", 0)) >= TRAIN_VERDICT_REPROBE_EVERY:
+            return None                                  # the weights have moved: admit bf16x3 again on real gradients
+        return v
+    except Exception:
+        return None
+
+
 def is_correct_model_dir(model_dir):
     """Same predicate as the reference's ``ze_utils.is_correct_model_dir`` (ze_utils.py:561-567)."""
     for name in (META, DONE):
