@@ -37,9 +37,13 @@ def test_gather_transport_follows_the_payload(monkeypatch):
     assert xdist._ASYNC["backend"] == "gloo"
     xdist.set_gather_payload(10 ** 10)
     assert xdist._ASYNC["backend"] == "nccl"
-    go.set()                                                        # the bring-up has started: too late to change its transport
-    xdist.set_gather_payload(1000)
+    go.set()                                                        # the bring-up has started: too late to change its transport,
+    with pytest.raises(RuntimeError, match="bring-up has started"):  # and said loudly (the ranks could otherwise disagree and hang)
+        xdist.set_gather_payload(1000)
     assert xdist._ASYNC["backend"] == "nccl"
+    monkeypatch.setenv("XVECTOR_RCCL_PREWARMED", "1")              # the CLI worker pre-loaded RCCL's device code: RCCL whatever the size
+    from xvector_amd import rccl_prewarm
+    assert rccl_prewarm.ENV_FLAG == "XVECTOR_RCCL_PREWARMED" and xdist.gather_backend(4) == "nccl"
 
 
 def test_partition_lpt_is_balanced_and_deterministic():

@@ -56,7 +56,7 @@ open("profiles/%s_pmc.txt" % tag, "w").write(hdr2 + "\n".join(keep) + "\n")
 fs = sum(v["FETCH_SIZE"][2] for k, v in vals.items() if k.startswith(GEMM) and "FETCH_SIZE" in v)
 ws = sum(v["WRITE_SIZE"][2] for k, v in vals.items() if k.startswith(GEMM) and "WRITE_SIZE" in v)
 n = sum(v["FETCH_SIZE"][0] for k, v in vals.items() if k.startswith(GEMM) and "FETCH_SIZE" in v)
-json.dump({"round": 5, "kernel": "GEMM kernels of a step (tdnn_first_kernel, tdnn_gemm_f16bf8_wide16_kernel, tdnn_pair_pool_f16bf8_kernel, tdnn_gemm_bf16x3_kernel; launch-weighted mean)",
+json.dump({"round": 6, "kernel": "GEMM kernels of a step (tdnn_first_kernel, tdnn_gemm_f16bf8_wide16_kernel, tdnn_pair_pool_f16bf8_kernel, tdnn_gemm_bf16x3_kernel; launch-weighted mean)",
            "source": "profiles/%s_pmc.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, default bench.py workload)" % tag,
            "kernel_sha": sha, "commit": commit, "batch_rows": under["config"]["batch_rows"], "launches": n,
            "gemm_fetch_kib_raw": round(fs / n, 1), "gemm_write_kib": round(ws / n, 1),
