@@ -52,7 +52,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 21). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 22). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -114,20 +114,27 @@ int xv_tdnn_layer_rows_f32(const float *x, int64_t R, int cin, int ldx, const fl
                            float *y, int ldy, void *stream);
 
 /* ---- "fp32tc": the wide-context layers with fewer multiplications (Toom-Cook F(2, K) over time; csrc/xv_toom.hip) -------------
- * Same layer as xv_tdnn_layer_f32 (models.py:54-67) for K in {5, 7}, dilation 1 (the default topology's layers 1 and 2, models.py:28
- * -- 74 % of the network's multiplications): the two output rows (2P, 2P+1) are formed from K + 1 products of TRANSFORMED input rows
- * and TRANSFORMED taps instead of 2 K products (0.60 / 0.57 of the MFMA work), exact fp32 products, fp32 accumulation.  Not
- * bit-identical to xv_tdnn_layer_f32 (~1e-6 relative L2 per layer against fp64 instead of ~3e-7), hence its own entry points.
+ * Same layer as xv_tdnn_layer_f32 (models.py:54-67) for K in {3, 5, 7} (the default topology's layers 1 and 2, models.py:28 -- 74 % of
+ * the network's multiplications; the dilated class's K = 3 layers, models.py:545-548,579-585): two output rows are formed from K + 1
+ * products of TRANSFORMED input rows and TRANSFORMED taps instead of 2 K products (0.67 / 0.60 / 0.57 of the MFMA work), exact fp32
+ * products, fp32 accumulation.  Not bit-identical to xv_tdnn_layer_f32 (another rounding, same accuracy class), hence its own
+ * entry points.
  *   wp = xv_pack_weights_toom_f32(w[K,Cin,Cout]): [Cout][(K+1)*Cin] floats (xv_packed_weights_toom_f32_floats; 0 = unsupported);
- *   xv_toom_supported: K in {5,7}, dilation 1, Cin % 32 == 0, Cout % 4 == 0; the layer call additionally needs 16-byte aligned
+ *   xv_toom_supported: K in {3,5,7}, dilation 1..8, Cin % 32 == 0, Cout % 4 == 0; the layer call additionally needs 16-byte aligned
  *   x / y rows and per-column parameters (else XV_ERR_UNSUPPORTED: use xv_tdnn_layer_f32).
- * Row pairs sit on even global rows: chunks should start on even rows (then a chunk's bits do not depend on its neighbours). */
+ * xv_tdnn_layer_toom_dilated_f32: tf.nn.convolution(dilation_rate = d) (models.py:579-585) as d independent undilated problems over
+ * the rows sub, sub + d, sub + 2 d, ... (one launch); its row pairs are rows (r, r + d) with floor(r / d) even.
+ * Row pairs sit on fixed global rows: chunks should start on multiples of 2 d rows (then a chunk's bits do not depend on its
+ * neighbours); xv_tdnn_layer_toom_f32 is the d = 1 call. */
 int xv_toom_supported(int K, int dilation, int cin, int cout);
 size_t xv_packed_weights_toom_f32_floats(int K, int cin, int cout);
 int xv_pack_weights_toom_f32(const float *w, int K, int cin, int cout, float *wp, void *stream);
 int xv_tdnn_layer_toom_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
                            const float *bn_shift, int act_kind, const float *act_alpha, int K, int cout, const uint8_t *row_valid,
                            float *y, int ldy, void *stream);
+int xv_tdnn_layer_toom_dilated_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
+                                   const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                                   const uint8_t *row_valid, float *y, int ldy, void *stream);
 
 /* ---- bf16x3 split-precision twins (same contraction, fp32-class accuracy, bf16 matrix cores) ----------------
  *

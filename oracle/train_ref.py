@@ -137,10 +137,10 @@ def forward(params, stats, topo, x, labels, train, dropout=None):
     return loss, acc, new_stats, e0
 
 
-def to_torch(weights, requires_grad_names=()):
+def to_torch(weights, requires_grad_names=(), dtype=np.float64):
     out = {}
     for k, v in weights.items():
-        t = torch.tensor(np.asarray(v, dtype=np.float64))
+        t = torch.tensor(np.asarray(v, dtype=dtype))
         if k in requires_grad_names:
             t.requires_grad_(True)
         out[k] = t
@@ -155,20 +155,23 @@ def eval_batch(weights, topo, x, labels):
     return float(loss), float(acc), e0.numpy()
 
 
-def train_step(weights, adam, topo, x, labels, lr, dropout=None):
+def train_step(weights, adam, topo, x, labels, lr, dropout=None, dtype=np.float64):
     """One optimizer step.  weights: {name: ndarray} (all variables incl. moving stats); adam: {"t": int, "m": {...},
-    "v": {...}} (t = number of steps already taken).  Returns (loss, acc, new_weights, new_adam, grads)."""
+    "v": {...}} (t = number of steps already taken).  Returns (loss, acc, new_weights, new_adam, grads).
+    ``dtype=np.float32`` runs the same autograd in IEEE single precision: not an oracle, a yardstick -- how far ANY fp32 evaluation of
+    the step lands from the float64 one (activation kinks, batch-norm backward over a few hundred rows); tests that follow a
+    trajectory over several Adam steps size their bars with it."""
     names = trainable_names(topo)
-    p = to_torch(weights, names)
+    p = to_torch(weights, names, dtype)
     if dropout:
-        dropout = {k: (torch.tensor(np.asarray(m, np.float64)), float(keep)) for k, (m, keep) in dropout.items()}
-    loss, acc, new_stats, _ = forward(p, p, topo, torch.tensor(np.asarray(x, np.float64)),
+        dropout = {k: (torch.tensor(np.asarray(m, dtype)), float(keep)) for k, (m, keep) in dropout.items()}
+    loss, acc, new_stats, _ = forward(p, p, topo, torch.tensor(np.asarray(x, dtype)),
                                       torch.tensor(np.asarray(labels, np.int64)), train=True, dropout=dropout)
     grads = torch.autograd.grad(loss, [p[n] for n in names], allow_unused=True)      # AM-softmax head: output/b is unused
     grads = [g if g is not None else torch.zeros_like(p[n]) for g, n in zip(grads, names)]
     t = adam["t"] + 1
     lr_t = lr * np.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
-    new_w = {k: np.array(v, dtype=np.float64) for k, v in weights.items()}
+    new_w = {k: np.array(v, dtype=dtype) for k, v in weights.items()}
     new_adam = {"t": t, "m": {}, "v": {}}
     gout = {}
     for n, g in zip(names, grads):

@@ -63,7 +63,7 @@ def test_host_library_loads_and_scans():
     import numpy as np
     import kaldi_io
     lib = kaldi_io._host_lib()
-    assert lib is not None and lib.xv_host_version() == 10 and hasattr(lib, "xv_raw_row_plan") and hasattr(lib, "xv_ark_decode_cm") and hasattr(lib, "xv_ark_index_fd") and hasattr(lib, "xv_copy_bytes") and hasattr(lib, "xv_ark_keys") and hasattr(lib, "xv_ark_gather_fm") and hasattr(lib, "xv_pack_rows_f32")
+    assert lib is not None and lib.xv_host_version() == 11 and hasattr(lib, "xv_scp_line_index") and hasattr(lib, "xv_vec_records_write_fd") and hasattr(lib, "xv_raw_row_plan") and hasattr(lib, "xv_ark_decode_cm") and hasattr(lib, "xv_ark_index_fd") and hasattr(lib, "xv_copy_bytes") and hasattr(lib, "xv_ark_keys") and hasattr(lib, "xv_ark_gather_fm") and hasattr(lib, "xv_pack_rows_f32")
     rng = np.random.default_rng(0)
     bio = io.BytesIO()
     mats = [("k%d" % i, rng.standard_normal((int(rng.integers(0, 40)), 23)).astype(np.float32)) for i in range(50)]

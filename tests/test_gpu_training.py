@@ -261,6 +261,15 @@ def test_three_steps_follow_the_reference_training_loop(env, golden, cls):
     # rounding noise (a different sign in fp32 and fp64).  The fixture's learning rate is 1e-4 so that those elements move the later
     # steps little (at 2e-3 the second loss differs by 5e-4 and Adam's m by 10 % between ANY two arithmetics): later losses 2e-4, the
     # quantities linear in the gradients (Adam's m, the moving statistics) 2e-2 / 2e-3, the weights where the gradient is not noise
+    # ... and Adam's m on the tensors where no fp32 evaluation does better: the same three steps by torch-CPU autograd in IEEE single
+    # precision (oracle/train_ref.py, dtype float32) land 3-6 % from the float64 trajectory on the hidden layers' bias sums of the ReLU
+    # classes (activation kinks + batch-norm backward over 240-290 rows; 0.3 % on the PReLU classes): the bar of a tensor is 2e-2 or
+    # 1.5 x that yardstick, whichever is larger
+    yard, ww, ad = {}, {k: np.asarray(v) for k, v in w.items()}, {"t": 0, "m": {}, "v": {}}
+    for x, labels in batches:
+        _, _, ww, ad, _ = env["ref"].train_step(ww, ad, topo, x.astype(np.float32), labels, lr, dtype=np.float32)
+    for n in names:
+        yard[n] = _rel(compact(ad["m"][n], stride, 8), g["%s/after/%s/Adam:0" % (cls, n[:-2])])
     off = []
     for bi, (x, labels) in enumerate(batches):
         loss, acc = tr.step(x, labels, lr)
@@ -285,8 +294,8 @@ def test_three_steps_follow_the_reference_training_loop(env, golden, cls):
         if ok.sum() >= 8 and e > 0.25:
             off.append(("weights", n, e))
         m = _rel(compact(adam["m"][n], stride, 8), g["%s/after/%s/Adam:0" % (cls, n[:-2])])
-        if m > 2e-2:
-            off.append(("adam m", n, m))
+        if m > max(2e-2, 1.5 * yard.get(n, 0.0)):
+            off.append(("adam m", n, m, yard.get(n)))
     for bi, (x, labels) in enumerate(batches[:2]):
         loss, acc = tr.eval_batch(x.astype(np.float32), labels)
         want = float(g["%s/eval_loss" % cls][bi])

@@ -340,7 +340,7 @@ def test_cli_scp_sharding_helpers(tmp_path):
         for r in range(world):
             f, v, all_keys = cli._scp_shard("scp:%s" % feats, r, world, "scp:%s" % vad)
             fk = [ln.split()[0] for ln in f]                             # the shard's lines (kaldi_io.MatScp takes them as they are)
-            assert all_keys[r] == fk and sum(all_keys, []) == keys       # every rank knows every shard's keys: no key exchange
+            assert all_keys[r] == fk and sum((list(k) for k in all_keys), []) == keys   # every rank knows every shard's keys: no key exchange
             vk = [ln.split()[0] for ln in v]
             assert vk == [k for k in fk if k != "utt04"]                  # same order as the feature shard
             got += fk

@@ -175,6 +175,88 @@ def test_write_vec_flt_batch_equals_per_key_writes(g):
         kaldi_io.write_vec_flt_batch(io.BytesIO(), ["x"], [np.zeros(3)])
 
 
+def test_native_record_writer_writes_the_bytes_of_write_vec_flt(tmp_path, monkeypatch):
+    """xv_vec_records_write_fd (csrc/xv_host.cpp) behind write_vec_flt_batch: into a TableWriter (ark + scp) and into a plain file,
+    from a block with a row stride (the gathered [emitted? | x-vector] rows), with an emitted mask, keys as a list and as a
+    KeyRange over an scp's text, ragged key lengths, an empty key, more records than one 4 MB piece -- byte for byte what the
+    per-key write_vec_flt (the reference's framing, pinned by ark_io.npz elsewhere in this file) and the Python batch path write."""
+    rng = np.random.default_rng(3)
+    n, dim = 5000, 512                                                  # 10 MB of records: three pieces
+    keys = ["spk%04d-u%d" % (i // 7, i * 37) for i in range(n)]          # ragged lengths
+    block = rng.standard_normal((n, dim + 1)).astype(np.float32)
+    emitted = rng.random(n) > 0.1
+    block[:, 0] = emitted
+
+    def python_way(path_ark, path_scp, with_mask):
+        monkeypatch.setenv("XVECTOR_NATIVE_WRITER", "0")
+        with kaldi_io.TableWriter(str(path_ark), str(path_scp), scp_ark_name="final.ark") as out:
+            out.write(b"")
+            kaldi_io.write_vec_flt(out, block[0, 1:4].copy(), key="first")   # the table already holds a record: offsets continue
+            kaldi_io.write_vec_flt_batch(out, keys, block[:, 1:], emitted if with_mask else None)
+        monkeypatch.delenv("XVECTOR_NATIVE_WRITER")
+        return open(path_ark, "rb").read(), open(path_scp, "rb").read()
+
+    for with_mask in (True, False):
+        want_ark, want_scp = python_way(tmp_path / "p.ark", tmp_path / "p.scp", with_mask)
+        for as_range in (False, True):
+            k = kaldi_io.KeyRange.from_keys(keys) if as_range else keys
+            with kaldi_io.TableWriter(str(tmp_path / "n.ark"), str(tmp_path / "n.scp"), scp_ark_name="final.ark") as out:
+                kaldi_io.write_vec_flt(out, block[0, 1:4].copy(), key="first")
+                kaldi_io.write_vec_flt_batch(out, k, block[:, 1:], emitted if with_mask else None)
+                assert out._pos == len(want_ark)
+            assert open(tmp_path / "n.ark", "rb").read() == want_ark and open(tmp_path / "n.scp", "rb").read() == want_scp
+    # the scp's offsets are the ones the reader seeks to
+    table = dict(ln.split() for ln in want_scp.decode().splitlines())
+    pos = int(table[keys[-1]].split(":")[1])
+    assert np.array_equal(kaldi_io.read_vec_flt(io.BytesIO(want_ark[pos:])), block[-1, 1:])
+    # a plain file (no scp), per-key writes as the yardstick, an empty key among them
+    some, vec = ["a", "", "ccc"], block[:3, 1:9]
+    with open(tmp_path / "plain.ark", "wb") as f:
+        kaldi_io.write_vec_flt_batch(f, some, vec)
+    ref = io.BytesIO()
+    for kk, v in zip(some, vec):
+        kaldi_io.write_vec_flt(ref, np.ascontiguousarray(v), key=kk)
+    assert open(tmp_path / "plain.ark", "rb").read() == ref.getvalue()
+    # and a sink that is neither (BytesIO) still goes the Python way, mask included
+    bio = io.BytesIO()
+    kaldi_io.write_vec_flt_batch(bio, keys[:50], block[:50, 1:], emitted[:50])
+    ref = io.BytesIO()
+    for kk, v, ok in zip(keys[:50], block[:50, 1:], emitted[:50]):
+        if ok:
+            kaldi_io.write_vec_flt(ref, np.ascontiguousarray(v), key=kk)
+    assert bio.getvalue() == ref.getvalue()
+
+
+@pytest.mark.parametrize("no_host_lib", [False, True])
+def test_scp_text_line_index_follows_the_python_split(tmp_path, monkeypatch, no_host_lib):
+    """kaldi_io.ScpText (xv_scp_line_index): the lines / keys of a table by position -- the same lines the Python split yields
+    (blank lines dropped, CRLF and non-ASCII texts handed to the Python rule), keys decoded lazily, ranges and masks as views."""
+    if no_host_lib:
+        monkeypatch.setenv("XVECTOR_NO_HOST_LIB", "1")
+    monkeypatch.setattr(kaldi_io, "_HOST_LIB", False)
+    keys = ["utt%03d-%s" % (i, "x" * (i % 5)) for i in range(101)]
+    text = "".join("%s /data/f.ark:%d\n" % (k, 17 + 31 * i) + ("\n" if i % 13 == 0 else "   \n" if i % 17 == 0 else "") for i, k in enumerate(keys))
+    path = tmp_path / "t.scp"
+    path.write_text(text[:-1])                                          # no newline at the end of the file
+    t = kaldi_io.ScpText(str(path))
+    assert len(t) == 101 and t.native == (not no_host_lib)
+    assert t.keys() == keys and list(t.keys(10, 20)) == keys[10:20] and len(t.keys(5, 5)) == 0
+    want = [ln + "\n" for ln in text.splitlines() if ln.strip()]
+    assert t.lines(0, 101) == want and t.lines(30, 61) == want[30:61] and t.lines(7, 7) == []
+    mask = np.arange(101) % 3 == 0
+    assert t.keys()[mask] == [k for k, m in zip(keys, mask) if m] and t.keys()[5:9] == keys[5:9] and t.keys()[100] == keys[100]
+    assert kaldi_io.KeyRange.from_keys(keys)[mask] == t.keys()[mask]
+    (tmp_path / "crlf.scp").write_bytes(b"a x.ark:1\r\nb x.ark:2\r\n")
+    c = kaldi_io.ScpText(str(tmp_path / "crlf.scp"))
+    assert not c.native and c.keys() == ["a", "b"] and c.lines(0, 2) == ["a x.ark:1\n", "b x.ark:2\n"]
+    (tmp_path / "lead.scp").write_bytes(b"  a x.ark:1\nb\tx.ark:2\n")
+    c = kaldi_io.ScpText(str(tmp_path / "lead.scp"))
+    assert c.keys() == ["a", "b"] and [ln.split() for ln in c.lines(0, 2)] == [["a", "x.ark:1"], ["b", "x.ark:2"]]
+    (tmp_path / "empty.scp").write_bytes(b"")
+    assert len(kaldi_io.ScpText(str(tmp_path / "empty.scp"))) == 0
+    monkeypatch.setattr(kaldi_io, "_HOST_LIB", False)
+
+
 def test_pipe_and_large_stream_through_buffered_reader(tmp_path):
     rng = np.random.default_rng(1)
     mats = {"u%05d" % i: rng.standard_normal((int(rng.integers(1, 400)), 23)).astype(np.float32) for i in range(300)}

@@ -14,9 +14,12 @@
 // xv_ark_index_fd (header-only index of an ark FILE: byte-range sharding across ranks), xv_ark_decode_cm (Kaldi's
 // CompressedMatrix records decoded into arenas, Kaldi's float32 arithmetic), xv_ark_keys / xv_ark_gather_fm (keys and
 // matrices of a scanned block gathered into one array each), xv_copy_bytes (a memcpy outside the interpreter lock),
-// xv_raw_row_plan (destination row of every raw frame of a batch: the recipe's CMN + VAD mode).
+// xv_raw_row_plan (destination row of every raw frame of a batch: the recipe's CMN + VAD mode), xv_scp_line_index (where the lines
+// and keys of an scp table lie: a rank of a sharded job cuts its line range out of the text without splitting the other ranks'
+// lines), xv_vec_records_write_fd (the x-vector table of a job, ark records + scp lines, written from the gathered block as it lies).
 // An internal helper library of the Python host side (ctypes, local/tf/kaldi_io.py and xvector_amd/engine.py) -- the drop-in
 // boundary of the compute path is libxvector_hip.so (include/xvector_hip.h).  Built for x86-64-v3 (AVX2).
+#include <errno.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -28,7 +31,7 @@
 
 extern "C" {
 
-int xv_host_version(void) { return 10; }
+int xv_host_version(void) { return 11; }
 
 // Index pass over an ark FILE of binary float-matrix records (plain "FM " or compressed "CM ") without reading the matrices: per
 // record one pread of the header ("<key> \0BFM \4<rows>\4<cols>" / "<key> \0BCM <min><range><rows><cols>"), then a hop over the payload.  This is what lets the ranks of a job split a
@@ -496,6 +499,133 @@ int xv_pack_rows_f32(const uint64_t *src, const int32_t *len, const int32_t *dst
     }
     for (auto &th : pool) th.join();
     return 0;
+}
+
+// Where the non-blank lines of an scp table ("<key> <rxfilename>\n", extract_xvectors.sh:63-65 splits such a file per job) lie in
+// its text: start[i] = offset of line i's first byte, end[i] = offset behind its last byte (the '\n' excluded), key_len[i] = bytes up to
+// the first blank of the line (leading blanks belong to no key: such a line is reported as unusual).  One memchr-speed pass instead
+// of decode + splitlines + split of every line on every rank of a job (1 M lines: 0.5 s of Python per rank).  Returns the number of
+// lines (writes at most cap of them: call with cap = 0 to count), or -2 when the text holds a byte Python's str.splitlines would
+// ALSO break lines at or that is not ASCII (\r, \v, \f, \x1c-\x1e, >= 0x80): the caller then takes the Python path, whose
+// splitting rule is the documented one.
+int64_t xv_scp_line_index(const uint8_t *buf, int64_t len, int64_t *start, int64_t *end, int32_t *key_len, int64_t cap)
+{
+    int64_t n = 0, pos = 0;
+    while (pos < len) {
+        const uint8_t *nl = static_cast<const uint8_t *>(memchr(buf + pos, '\n', (size_t)(len - pos)));
+        const int64_t stop = nl ? (int64_t)(nl - buf) : len;
+        bool blank = true;
+        int32_t klen = -1;
+        for (int64_t i = pos; i < stop; ++i) {
+            const uint8_t c = buf[i];
+            if (c >= 0x80 || c == '\r' || c == 0x0b || c == 0x0c || (c >= 0x1c && c <= 0x1e)) return -2;
+            const bool ws = c == ' ' || c == '\t';
+            if (!ws) blank = false;
+            else if (klen < 0 && !blank) klen = (int32_t)(i - pos);
+        }
+        if (!blank) {
+            if (buf[pos] == ' ' || buf[pos] == '\t') return -2;   // a line that starts with a blank: left to the Python path
+            if (n < cap) {
+                start[n] = pos;
+                end[n] = stop;
+                key_len[n] = klen < 0 ? (int32_t)(stop - pos) : klen;
+            }
+            ++n;
+        }
+        pos = stop + 1;
+    }
+    return n;
+}
+
+namespace {
+
+bool write_all(int fd, const uint8_t *p, size_t n)
+{
+    while (n) {
+        const ssize_t w = write(fd, p, n);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        p += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+
+inline size_t put_u64(uint8_t *dst, uint64_t v)
+{
+    uint8_t tmp[20];
+    size_t k = 0;
+    do { tmp[k++] = (uint8_t)('0' + v % 10); v /= 10; } while (v);
+    for (size_t i = 0; i < k; ++i) dst[i] = tmp[k - 1 - i];
+    return k;
+}
+
+}  // namespace
+
+// The x-vector table of a job written from the block it was gathered into: for every row i of n with emitted[i] != 0 (all rows when
+// emitted is NULL) the ark record "<key> " + "\0B" + "FV " + "\4" + uint32 dim + dim little-endian float32 -- the bytes of
+// write_vec_flt (local/tf/kaldi_io.py:339-372 of the reference) -- goes to ark_fd and the line "<key> <ark_name>:<offset of the
+// \0>\n" (what copy-vector ark,scp: prints, extract_xvectors.sh:74-88) to scp_fd (skipped when scp_fd < 0).  Key i = key_len[i]
+// bytes at keys + key_off[i] (the scp text of the job's input, or keys joined in Python); vector i = dim floats at
+// vecs + i * row_stride (the gathered [emitted? | x-vector] rows are read in place: row_stride = dim + 1, vecs = block + 1).
+// pos0 = the ark's length so far.  Records are assembled in 4 MB pieces, one write(2) each: no second and third copy of a 2 GB
+// table (NumPy row assembly + tobytes), no per-record Python.  Returns the number of records written and *pos_out = the ark's new
+// length; -errno when a write fails.
+int64_t xv_vec_records_write_fd(int ark_fd, int scp_fd, const uint8_t *keys, const int64_t *key_off, const int32_t *key_len, int64_t n,
+                                const float *vecs, int dim, int64_t row_stride, const uint8_t *emitted, const char *ark_name,
+                                int64_t pos0, int64_t *pos_out)
+{
+    const size_t cap = 4u << 20;
+    const size_t name_len = strlen(ark_name);
+    const size_t body = 10 + 4 * (size_t)dim;                       // "\0BFV " + "\4" + dim + payload
+    std::vector<uint8_t> ark(cap + body + 4096), scp(scp_fd >= 0 ? cap / 4 + name_len + 4096 : 0);
+    size_t aw = 0, sw = 0;
+    int64_t pos = pos0, written = 0;
+    const uint32_t d32 = (uint32_t)dim;
+    for (int64_t i = 0; i < n; ++i) {
+        if (emitted && !emitted[i]) continue;
+        const size_t kl = (size_t)key_len[i];
+        if (aw + kl + 1 + body > cap) {
+            if (!write_all(ark_fd, ark.data(), aw)) return -(int64_t)errno;
+            aw = 0;
+            if (kl + 1 + body > ark.size()) ark.resize(kl + 1 + body);
+        }
+        const uint8_t *k = keys + key_off[i];
+        uint8_t *a = ark.data() + aw;
+        if (kl) {                                                    // (write_vec_flt: an empty key writes no key and no blank)
+            memcpy(a, k, kl);
+            a[kl] = ' ';
+            a += kl + 1;
+            pos += (int64_t)kl + 1;
+        }
+        if (scp_fd >= 0) {
+            if (sw + kl + name_len + 24 > scp.size() - 64) {
+                if (!write_all(scp_fd, scp.data(), sw)) return -(int64_t)errno;
+                sw = 0;
+                if (kl + name_len + 128 > scp.size()) scp.resize(kl + name_len + 4096);
+            }
+            uint8_t *t = scp.data() + sw;
+            memcpy(t, k, kl); t += kl;
+            *t++ = ' ';
+            memcpy(t, ark_name, name_len); t += name_len;
+            *t++ = ':';
+            t += put_u64(t, (uint64_t)pos);
+            *t++ = '\n';
+            sw = (size_t)(t - scp.data());
+        }
+        a[0] = 0; a[1] = 'B'; a[2] = 'F'; a[3] = 'V'; a[4] = ' '; a[5] = 4;
+        memcpy(a + 6, &d32, 4);
+        memcpy(a + 10, vecs + i * row_stride, 4 * (size_t)dim);
+        aw = (size_t)(a + body - ark.data());
+        pos += (int64_t)body;
+        ++written;
+    }
+    if (aw && !write_all(ark_fd, ark.data(), aw)) return -(int64_t)errno;
+    if (sw && !write_all(scp_fd, scp.data(), sw)) return -(int64_t)errno;
+    if (pos_out) *pos_out = pos;
+    return written;
 }
 
 }  // extern "C"

@@ -72,6 +72,17 @@ template <int KT>
 struct Toom;
 
 template <>
+struct Toom<3> {                                  // points 0, 1, -1, inf: Winograd's F(2, 3)
+    static constexpr int J = 4;
+    // BT = {{1,0,-1,0}, {0,1,1,0}, {0,-1,1,0}, {0,-1,0,1}} (the last row negated against the textbook form: AT[1][3] = +1)
+    static constexpr int ORDER[4] = {0, 3, 1, 2};
+    static constexpr double SC[4] = {1, 1, 1, 1};
+    static constexpr float A1[4] = {0, 1, -1, 1};
+    static constexpr unsigned NEED[4] = {0x5, 0x6, 0x6, 0xa};
+    static constexpr double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+};
+
+template <>
 struct Toom<5> {                                  // points 0, 1, -1, 2, -2, inf
     static constexpr int J = 6;
     // BT = {{4,0,-5,0,1,0}, {0,-4,-4,1,1,0}, {0,4,-4,-1,1,0}, {0,-2,-1,2,1,0}, {0,2,-1,-2,1,0}, {0,4,0,-5,0,1}}
@@ -138,6 +149,7 @@ struct ToomParams {
     float *y;
     int ldy;
     int n_mt, n_nt;
+    int dil;                    // dilation d: the launch runs d independent undilated problems, rows sub, sub + d, sub + 2 d, ...
 };
 
 template <int I, int N, class F>
@@ -175,7 +187,12 @@ __device__ __forceinline__ f32x4 sub4(f32x4 x, f32x4 y, float m1)
 template <int KT, int j>
 __device__ __forceinline__ f32x4 xform(const f32x4 (&d)[KT + 1], float m1)
 {
-    if constexpr (KT == 5) {
+    if constexpr (KT == 3) {
+        if constexpr (j == 0) return sub4(d[0], d[2], m1);
+        if constexpr (j == 1) return d[1] + d[2];
+        if constexpr (j == 2) return sub4(d[2], d[1], m1);
+        if constexpr (j == 3) return sub4(d[3], d[1], m1);
+    } else if constexpr (KT == 5) {
         if constexpr (j == 0) return fma4(4.f, d[0], fma4(-5.f, d[2], d[4]));
         if constexpr (j == 1) return fma4(-4.f, d[2], d[4]) + fma4(-4.f, d[1], d[3]);
         if constexpr (j == 2) return sub4(fma4(-4.f, d[2], d[4]), fma4(-4.f, d[1], d[3]), m1);
@@ -199,7 +216,10 @@ __device__ __forceinline__ f32x4 xform(const f32x4 (&d)[KT + 1], float m1)
 template <int KT, int j>
 __device__ __forceinline__ void xform_pair(const f32x4 (&d)[KT + 1], float m1, f32x4 &va, f32x4 &vb)
 {
-    if constexpr (KT == 5 && j == 1) {
+    if constexpr (KT == 3) {
+        static_assert(j == 1, "pair: (1, 2)");
+        va = d[1] + d[2]; vb = sub4(d[2], d[1], m1);
+    } else if constexpr (KT == 5 && j == 1) {
         const f32x4 e = fma4(-4.f, d[2], d[4]), o = fma4(-4.f, d[1], d[3]);
         va = e + o; vb = sub4(e, o, m1);
     } else if constexpr (KT == 5 && j == 3) {
@@ -221,7 +241,7 @@ __device__ __forceinline__ void xform_pair(const f32x4 (&d)[KT + 1], float m1, f
 // the rows of the finished tile: bias, activation, affine, row mask, one 16-B streamed store per (row, 4 columns).  The
 // activation kind is a template constant (one uniform switch per thread in the caller, none per element)
 template <int ACT>
-__device__ __forceinline__ void toom_store_rows(const ToomParams &p, const float *T, const uint8_t *Ms, long m0, int n0, int tid)
+__device__ __forceinline__ void toom_store_rows(const ToomParams &p, const float *T, const uint8_t *Ms, long m0, int sub, int n0, int tid)
 {
     const int cg = tid & 31, rp = tid >> 5;              // 4 columns; rows rp, rp + 8, ...
     const int gc = n0 + cg * 4;
@@ -236,7 +256,7 @@ __device__ __forceinline__ void toom_store_rows(const ToomParams &p, const float
 #pragma unroll 4
     for (int j = 0; j < BM / 8; ++j) {
         const int lr = rp + 8 * j;
-        const long gr = m0 + lr;
+        const long gr = sub + (m0 + lr) * p.dil;
         if (gr >= p.R) continue;
         const f32x4 a = *reinterpret_cast<const f32x4 *>(T + lr * TLD + cg * 4);
         const bool keep = Ms[lr] != 0;
@@ -265,12 +285,17 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
-    const int nwg = p.n_mt * p.n_nt;
+    // A dilated layer (tap offsets 0, +-d, ...) is d independent UNDILATED problems: sub-problem `sub` owns the rows sub, sub + d,
+    // sub + 2 d, ... of x and of y -- its row n is row sub + n d, its leading dimensions d ldx / d ldy.  Row pairs are pairs of a
+    // sub-problem's consecutive rows (rows r, r + d of the matrix); the host lays chunks out on multiples of 2 d rows, so the pairing
+    // of a chunk's rows does not depend on where in the batch it lies.  m0 below counts a sub-problem's rows.
+    const int nwg = p.n_mt * p.n_nt * p.dil;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const int ms = wg / p.n_nt, nt = wg - ms * p.n_nt;
+    const int mt = ms / p.dil, sub = ms - mt * p.dil;
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
 
@@ -279,7 +304,7 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     const int n_stages = n_chunks * J;
 
     if (tid < BM) {
-        const long gr = m0 + tid;
+        const long gr = sub + (m0 + tid) * p.dil;
         Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
     }
 
@@ -287,10 +312,11 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     // (tile row lr = global row m0 - left + lr).  Wave w moves pieces w, w + 4, ...: their parity is the wave's, and with it bit 2
     // of (LDS row >> 1) & 7 -- the swizzle of the row a lane moves is a per-lane constant.  Row part of an address in the VGPR
     // offset (range-checked: rows outside [0, R) come back as zeros), slab part in the scalar offset.
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)(p.R * p.ldx * 4), RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x) + (size_t)sub * p.ldx, 0,
+                                                                         (int)((p.R - sub) * p.ldx * 4), RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, (int)((long)p.cout * p.kred * 4), RSRC_FLAGS);
     const int slotb = ((lane & 7) ^ (((wave & 1) * 4 + (lane >> 4)) & 7)) << 4;
-    const int arow_bytes = p.ldx * 4, brow_bytes = p.kred * 4;
+    const int arow_bytes = p.dil * p.ldx * 4, brow_bytes = p.kred * 4;
     const int va0 = (int)(m0 - left + 2 * (lane >> 3)) * arow_bytes + slotb;
     const int vb0 = (n0 + 8 * wave + (lane >> 3)) * brow_bytes + slotb;
     auto dma_b = [&](int stage, int buf) {              // the weight tile of (slab, product) = stage, four pieces per wave
@@ -445,6 +471,10 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
             __builtin_amdgcn_s_barrier();
             dma_b(s + 2, q & 1);
             if constexpr (q < 5) dma_a_slot(c + 1, q);
+            if constexpr (J < 5 && q == J - 1) {                        // (F(2, 3): four stages for the five slots)
+#pragma unroll
+                for (int t = J; t < 5; ++t) dma_a_slot(c + 1, t);
+            }
             fence();
             if constexpr (pair_a) { /* the next stage's V are in vb */ }
             else if constexpr (q + 1 < J) load_raw(std::integral_constant<int, TC::ORDER[(q + 1) % J]>{}, CP, 0);
@@ -486,10 +516,10 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_toom_kernel(const ToomParams 
     }
     __syncthreads();
     switch (p.act) {
-    case XV_ACT_RELU: toom_store_rows<XV_ACT_RELU>(p, T, Ms, m0, n0, tid); break;
-    case XV_ACT_LRELU: toom_store_rows<XV_ACT_LRELU>(p, T, Ms, m0, n0, tid); break;
-    case XV_ACT_PRELU: toom_store_rows<XV_ACT_PRELU>(p, T, Ms, m0, n0, tid); break;
-    default: toom_store_rows<XV_ACT_NONE>(p, T, Ms, m0, n0, tid); break;
+    case XV_ACT_RELU: toom_store_rows<XV_ACT_RELU>(p, T, Ms, m0, sub, n0, tid); break;
+    case XV_ACT_LRELU: toom_store_rows<XV_ACT_LRELU>(p, T, Ms, m0, sub, n0, tid); break;
+    case XV_ACT_PRELU: toom_store_rows<XV_ACT_PRELU>(p, T, Ms, m0, sub, n0, tid); break;
+    default: toom_store_rows<XV_ACT_NONE>(p, T, Ms, m0, sub, n0, tid); break;
     }
 }
 
@@ -521,7 +551,7 @@ extern "C" {
 
 int xv_toom_supported(int K, int dilation, int cin, int cout)
 {
-    return (K == 5 || K == 7) && dilation == 1 && cin > 0 && cin % BK == 0 && cout > 0 && cout % 4 == 0;
+    return (K == 3 || K == 5 || K == 7) && dilation >= 1 && dilation <= 8 && cin > 0 && cin % BK == 0 && cout > 0 && cout % 4 == 0;
 }
 
 size_t xv_packed_weights_toom_f32_floats(int K, int cin, int cout)
@@ -533,22 +563,24 @@ size_t xv_packed_weights_toom_f32_floats(int K, int cin, int cout)
 int xv_pack_weights_toom_f32(const float *w, int K, int cin, int cout, float *wp, void *stream)
 {
     if (!w || !wp) return fail(XV_ERR_BAD_ARG, "pack_weights_toom: NULL argument");
-    if (!xv_toom_supported(K, 1, cin, cout)) return fail(XV_ERR_UNSUPPORTED, "pack_weights_toom: needs K in {5, 7}, Cin % 32 == 0, Cout % 4 == 0");
+    if (!xv_toom_supported(K, 1, cin, cout)) return fail(XV_ERR_UNSUPPORTED, "pack_weights_toom: needs K in {3, 5, 7}, Cin % 32 == 0, Cout % 4 == 0");
     const size_t n = (size_t)cin * cout;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (K == 5) hipLaunchKernelGGL(pack_weights_toom_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, w, cin, cout, wp);
+    if (K == 3) hipLaunchKernelGGL(pack_weights_toom_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, w, cin, cout, wp);
+    else if (K == 5) hipLaunchKernelGGL(pack_weights_toom_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, w, cin, cout, wp);
     else hipLaunchKernelGGL(pack_weights_toom_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, w, cin, cout, wp);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "pack_weights_toom_kernel launch");
 }
 
-int xv_tdnn_layer_toom_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
-                           const float *bn_shift, int act_kind, const float *act_alpha, int K, int cout, const uint8_t *row_valid,
-                           float *y, int ldy, void *stream)
+int xv_tdnn_layer_toom_dilated_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
+                                   const float *bn_shift, int act_kind, const float *act_alpha, int K, int dilation, int cout,
+                                   const uint8_t *row_valid, float *y, int ldy, void *stream)
 {
     if (!x || !wp || !y) return fail(XV_ERR_BAD_ARG, "tdnn_toom: NULL argument");
     if (R <= 0) return 0;
-    if (!xv_toom_supported(K, 1, cin, cout)) return fail(XV_ERR_UNSUPPORTED, "tdnn_toom: needs K in {5, 7}, Cin % 32 == 0, Cout % 4 == 0");
+    if (!xv_toom_supported(K, dilation, cin, cout))
+        return fail(XV_ERR_UNSUPPORTED, "tdnn_toom: needs K in {3, 5, 7}, dilation 1 .. 8, Cin % 32 == 0, Cout % 4 == 0");
     if (ldx < cin || ldy < cout) return fail(XV_ERR_BAD_ARG, "tdnn_toom: leading dimension too small");
     if ((act_kind == XV_ACT_LRELU || act_kind == XV_ACT_PRELU) && !act_alpha) return fail(XV_ERR_BAD_ARG, "tdnn_toom: act_alpha is NULL");
     const uintptr_t bits = (uintptr_t)x | (uintptr_t)wp | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)bn_scale | (uintptr_t)bn_shift |
@@ -558,25 +590,35 @@ int xv_tdnn_layer_toom_f32(const float *x, int64_t R, int cin, int ldx, const fl
     p.x = x; p.R = R; p.cin = cin; p.ldx = ldx; p.wp = wp; p.kred = (K + 1) * cin;
     p.bias = bias; p.scale = bn_scale; p.shift = bn_shift; p.act = act_kind; p.alpha = act_alpha; p.cout = cout;
     p.valid = row_valid; p.y = y; p.ldy = ldy;
-    p.n_mt = (int)((R + BM - 1) / BM);
+    p.dil = dilation;
+    const long rows_sub = (R + dilation - 1) / dilation;            // rows of the largest sub-problem (sub = 0)
+    p.n_mt = (int)((rows_sub + BM - 1) / BM);
     p.n_nt = (cout + BN - 1) / BN;
-    if ((R + BM + 8) * (long)ldx * 4 >= (1l << 31) || (long)(cout + BN) * p.kred * 4 >= (1l << 31))
+    if ((R + (long)(BM + 8) * dilation) * (long)ldx * 4 >= (1l << 31) || (long)(cout + BN) * p.kred * 4 >= (1l << 31))
         return fail(XV_ERR_UNSUPPORTED, "tdnn_toom: matrices must stay below 2^31 bytes (32-bit buffer offsets)");
     typedef void (*kern_t)(const ToomParams);
-    const kern_t k = K == 5 ? tdnn_gemm_toom_kernel<5> : tdnn_gemm_toom_kernel<7>;
+    const kern_t k = K == 3 ? tdnn_gemm_toom_kernel<3> : K == 5 ? tdnn_gemm_toom_kernel<5> : tdnn_gemm_toom_kernel<7>;
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!((attr_done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull)) {
-        for (kern_t kk : {tdnn_gemm_toom_kernel<5>, tdnn_gemm_toom_kernel<7>}) {
+        for (kern_t kk : {tdnn_gemm_toom_kernel<3>, tdnn_gemm_toom_kernel<5>, tdnn_gemm_toom_kernel<7>}) {
             hipError_t e = hipFuncSetAttribute((const void *)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
         }
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)(p.n_mt * p.n_nt)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)(p.n_mt * p.n_nt * dilation)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_toom_kernel launch");
+}
+
+int xv_tdnn_layer_toom_f32(const float *x, int64_t R, int cin, int ldx, const float *wp, const float *bias, const float *bn_scale,
+                           const float *bn_shift, int act_kind, const float *act_alpha, int K, int cout, const uint8_t *row_valid,
+                           float *y, int ldy, void *stream)
+{
+    return xv_tdnn_layer_toom_dilated_f32(x, R, cin, ldx, wp, bias, bn_scale, bn_shift, act_kind, act_alpha, K, 1, cout, row_valid, y, ldy,
+                                          stream);
 }
 
 }  // extern "C"

@@ -447,6 +447,16 @@ class TableWriter(object):
         self._scp.write("".join(lines))
         self._pos += len(blob)
 
+    def native_targets(self):
+        """(ark fd, scp fd, ark name in the scp, ark length so far) for xv_vec_records_write_fd, the Python-side buffers flushed;
+        ``advance(new_length)`` afterwards."""
+        self._ark.flush()
+        self._scp.flush()
+        return self._ark.fileno(), self._scp.fileno(), self._name, self._pos
+
+    def advance(self, pos):
+        self._pos = pos
+
     def close(self):
         self._ark.close()
         self._scp.close()
@@ -457,6 +467,108 @@ class TableWriter(object):
     def __exit__(self, *exc):
         self.close()
         return False
+
+
+class KeyRange(object):
+    """Keys as they lie in some text (an scp table's, or keys joined for the purpose): ``klen[i]`` bytes at ``buf[off[i]]``.  A
+    sequence of str -- decoded on first use, which a rank needs for its OWN shard only; the writer of a sharded job's table hands
+    ``buf / off / klen`` of the other ranks' keys to the native record writer as they are (1 M keys never become Python objects)."""
+
+    def __init__(self, buf, off, klen):
+        self.buf, self.off, self.klen, self._list = buf, np.ascontiguousarray(off, np.int64), np.ascontiguousarray(klen, np.int32), None
+
+    @classmethod
+    def from_keys(cls, keys):
+        enc = [k.encode() for k in keys]
+        klen = np.fromiter((len(e) for e in enc), np.int32, len(enc))
+        off = np.zeros(len(enc), np.int64)
+        if len(enc) > 1:
+            np.cumsum(klen[:-1].astype(np.int64) + 1, out=off[1:])
+        out = cls(np.frombuffer(b"\n".join(enc), np.uint8), off, klen)
+        out._list = list(keys)
+        return out
+
+    def tolist(self):
+        if self._list is None:
+            if len(self.off) == 0:
+                self._list = []
+            else:
+                lo = int(self.off.min())
+                span = self.buf[lo:int((self.off + self.klen).max())].tobytes()
+                self._list = [span[o:o + l].decode() for o, l in zip((self.off - lo).tolist(), self.klen.tolist())]
+        return self._list
+
+    def __len__(self):
+        return len(self.off)
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            return self.tolist()[i]
+        sub = KeyRange(self.buf, self.off[i], self.klen[i])            # slices, index arrays, boolean masks
+        if self._list is not None and isinstance(i, slice):
+            sub._list = self._list[i]
+        return sub
+
+    def __eq__(self, other):
+        return self.tolist() == (other.tolist() if isinstance(other, KeyRange) else list(other))
+
+    def __ne__(self, other):
+        return not self == other
+
+    __hash__ = None
+
+
+class ScpText(object):
+    """The text of an scp table and where its lines and keys lie in it (xv_scp_line_index; without the host library, or for a text
+    that str.splitlines would cut differently, the same arrays from the Python split).  What a rank of a sharded job needs of a 1 M
+    line table is its line COUNT (the cuts are by line number: extract_embedding._scp_shard), the lines of its own range and, on the
+    rank that writes, the other ranges' keys as bytes."""
+
+    def __init__(self, rxfilename):
+        fid = open_or_fd(rxfilename, "rb")
+        try:
+            raw = fid.read()
+        finally:
+            fid.close()
+        self.buf = np.frombuffer(raw, np.uint8)
+        lib = _host_lib()
+        n = -2
+        if lib is not None and hasattr(lib, "xv_scp_line_index"):
+            n = int(lib.xv_scp_line_index(self.buf.ctypes.data if len(raw) else None, len(raw), None, None, None, 0))
+        if n >= 0:
+            self.start, self.end, self.klen = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int32)
+            if n:
+                lib.xv_scp_line_index(self.buf.ctypes.data, len(raw), self.start.ctypes.data, self.end.ctypes.data, self.klen.ctypes.data, n)
+            self.native = True
+            return
+        # the documented rule, in Python: str.splitlines, blank lines dropped, key = up to the first whitespace
+        lines = [ln.strip() for ln in raw.decode().splitlines() if ln.strip()]
+        enc = [ln.encode() for ln in lines]
+        self.buf = np.frombuffer(b"\n".join(enc), np.uint8)
+        size = np.fromiter((len(e) for e in enc), np.int64, len(enc))
+        self.start = np.zeros(len(enc), np.int64)
+        if len(enc) > 1:
+            np.cumsum(size[:-1] + 1, out=self.start[1:])
+        self.end = self.start + size
+        self.klen = np.fromiter((len(ln.split(None, 1)[0].encode()) for ln in lines), np.int32, len(lines))
+        self.native = False
+
+    def __len__(self):
+        return len(self.start)
+
+    def lines(self, lo, hi):
+        """Lines [lo, hi) as str, each with its newline (what MatScp / VecScp take as 'the table's lines, already read')."""
+        if hi <= lo:
+            return []
+        text = self.buf[int(self.start[lo]):int(self.end[hi - 1])].tobytes().decode()
+        return [ln + "\n" for ln in text.split("\n") if ln and not ln.isspace()]
+
+    def keys(self, lo=0, hi=None):
+        hi = len(self) if hi is None else hi
+        return KeyRange(self.buf, self.start[lo:hi], self.klen[lo:hi])
 
 
 def write_vec_flt(file_or_fd, v, key=""):
@@ -479,15 +591,60 @@ def write_vec_flt(file_or_fd, v, key=""):
             fd.close()
 
 
-def write_vec_flt_batch(file_or_fd, keys, vecs):
+def _write_vec_records_native(fd, keys, mat, emitted):
+    """The records of ``write_vec_flt_batch`` by xv_vec_records_write_fd (csrc/xv_host.cpp): straight from ``mat``'s rows (any row
+    stride: the gathered ``[emitted? | x-vector]`` block is read in place) into the ark file and, for a TableWriter, its scp.  False when
+    this sink / these arrays are not its case (the caller then serialises in Python: same bytes)."""
+    lib = _host_lib()
+    if lib is None or not hasattr(lib, "xv_vec_records_write_fd") or mat is None or mat.dtype != np.float32 or mat.shape[1] == 0 or \
+            mat.strides[1] != 4 or mat.strides[0] % 4 or mat.strides[0] < 0 or not mat.dtype.isnative or np.little_endian is False:
+        return False
+    table = hasattr(fd, "native_targets")
+    try:
+        if table:
+            ark_fd, scp_fd, name, pos = fd.native_targets()
+        elif isinstance(fd, io.BufferedWriter) and isinstance(fd.raw, io.FileIO):
+            fd.flush()
+            ark_fd, scp_fd, name, pos = fd.fileno(), -1, "", 0
+        else:
+            return False
+    except (OSError, ValueError, io.UnsupportedOperation):
+        return False
+    kr = keys if isinstance(keys, KeyRange) else KeyRange.from_keys(keys)
+    mask = None if emitted is None else np.ascontiguousarray(emitted, np.uint8)
+    new_pos = ctypes.c_int64(0)
+    got = lib.xv_vec_records_write_fd(ark_fd, scp_fd, kr.buf.ctypes.data if len(kr.buf) else None, kr.off.ctypes.data, kr.klen.ctypes.data,
+                                      len(kr), mat.ctypes.data, mat.shape[1], mat.strides[0] // 4,
+                                      None if mask is None else mask.ctypes.data, name.encode(), pos, ctypes.byref(new_pos))
+    if got < 0:
+        raise IOError(-int(got), "write_vec_flt_batch: %s" % os.strerror(-int(got)))
+    if table:
+        fd.advance(int(new_pos.value))
+    return True
+
+
+def write_vec_flt_batch(file_or_fd, keys, vecs, emitted=None):
     """Write many float32 vectors as consecutive binary records (same bytes as write_vec_flt per key) with one ``write``
     call per batch.  ``vecs``: a float32 ``[n, D]`` array or a sequence of float32 vectors.  Equal-length vectors are
-    serialised without per-record NumPy calls (and without any per-record Python when the keys have one length too)."""
+    serialised without per-record NumPy calls (and without any per-record Python when the keys have one length too).
+    ``emitted`` (bool [n], optional): only these rows are written (a sharded job's gathered block carries a row per input
+    utterance).  Into a file or a TableWriter the records are assembled by the host library from the rows as they lie."""
     if hasattr(file_or_fd, "write_vectors"):                 # an in-memory sink (extract_embedding.py, sharded mode)
+        if emitted is not None:
+            emitted = np.asarray(emitted, bool)
+            keys, vecs = [k for k, ok in zip(keys, emitted.tolist()) if ok], np.asarray(vecs)[emitted]
         file_or_fd.write_vectors(keys, vecs)
         return
     fd = open_or_fd(file_or_fd, mode="wb")
     try:
+        if len(keys) and isinstance(vecs, np.ndarray) and vecs.ndim == 2 and vecs.shape[0] == len(keys) and \
+                os.environ.get("XVECTOR_NATIVE_WRITER", "1") != "0" and _write_vec_records_native(fd, keys, vecs, emitted):
+            return
+        if emitted is not None:
+            emitted = np.asarray(emitted, bool)
+            keys, vecs = [k for k, ok in zip(keys, emitted.tolist()) if ok], np.asarray(vecs)[emitted]
+        elif isinstance(keys, KeyRange):
+            keys = keys.tolist()
         n = len(keys)
         if n == 0:
             return
@@ -668,6 +825,15 @@ def _host_lib():
                     lib.xv_ark_decode_cm.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
                                                      ctypes.c_size_t] + [ctypes.c_void_p] * 5 + \
                         [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+                if hasattr(lib, "xv_scp_line_index"):
+                    lib.xv_scp_line_index.restype = ctypes.c_int64
+                    lib.xv_scp_line_index.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_int64]
+                if hasattr(lib, "xv_vec_records_write_fd"):
+                    lib.xv_vec_records_write_fd.restype = ctypes.c_int64
+                    lib.xv_vec_records_write_fd.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                                            ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
                 _HOST_LIB = lib
             except OSError:
                 _HOST_LIB = None

@@ -82,24 +82,33 @@ def gather_shard_vectors(device_model, collector, shard_keys, rank, world):
     over RCCL, or over gloo straight from host memory when xvector_amd.dist.gather_backend chose that for a small payload).  Every rank knows every shard's key list -- the line ranges of an scp, or the byte ranges of an indexed ark, are
     deterministic -- so only numbers travel: rank r sends one row per utterance of ITS shard, in input order,
     ``[emitted? | x-vector]``; the blocks are padded to the largest shard so that a single fixed-shape ``dist.gather`` moves
-    everything (xvector_amd.dist).  On rank 0 returns ``[(keys, vectors)]`` per shard in rank order = input order, with the
-    utterances that emitted nothing (rejected for their length or by the VAD) dropped; None on the other ranks."""
+    everything (xvector_amd.dist).  On rank 0 returns ``[(keys, vectors, emitted)]`` per shard in rank order = input order:
+    the shard's keys and one row per key as they lie in the gathered block (a view, nothing is copied), and the mask of the
+    utterances that emitted a vector (the others were rejected for their length or by the VAD) -- what
+    ``kaldi_io.write_vec_flt_batch(fd, keys, vectors, emitted)`` takes; None on the other ranks."""
     import torch
     from xvector_amd import dist as xdist, jobclock
     dim, dev = device_model.embed_dim, device_model.device
     mine = shard_keys[rank]
     block = np.zeros((len(mine), dim + 1), np.float32)
     if collector.keys:
-        # the emitted keys are a subsequence of the shard's keys (make_embedding keeps input order)
-        rows, j = np.empty(len(collector.keys), np.int64), 0
-        for i, k in enumerate(mine):
-            if j < len(rows) and collector.keys[j] == k:
-                rows[j] = i
-                j += 1
-        if j != len(rows):
-            raise RuntimeError("sharded extraction: emitted keys are not a subsequence of the shard's keys")
+        whole = len(collector.keys) == len(mine) and mine == collector.keys    # nothing was rejected: the usual case
+        if whole:
+            rows = slice(None)
+        else:
+            # the emitted keys are a subsequence of the shard's keys (make_embedding keeps input order)
+            rows, j = np.empty(len(collector.keys), np.int64), 0
+            for i, k in enumerate(mine):
+                if j < len(rows) and collector.keys[j] == k:
+                    rows[j] = i
+                    j += 1
+            if j != len(rows):
+                raise RuntimeError("sharded extraction: emitted keys are not a subsequence of the shard's keys")
         block[rows, 0] = 1.0
-        block[rows, 1:] = np.concatenate(collector.blocks)
+        if whole and len(collector.blocks) == 1:
+            block[:, 1:] = collector.blocks[0]
+        else:
+            block[rows, 1:] = np.concatenate(collector.blocks)
     xdist.wait_process_group()
     jobclock.mark("wait for the process group")
     import torch.distributed as dist
@@ -111,8 +120,7 @@ def gather_shard_vectors(device_model, collector, shard_keys, rank, world):
     out = []
     for r in range(world):
         got = blocks[r].cpu().numpy()
-        emitted = got[:, 0] > 0.5
-        out.append(([k for k, ok in zip(shard_keys[r], emitted.tolist()) if ok], np.ascontiguousarray(got[emitted, 1:])))
+        out.append((shard_keys[r], got[:, 1:], got[:, 0] > 0.5))
     return out
 
 
@@ -516,8 +524,8 @@ class Model(object):
         input_stream.seek(last)                                     # the caller's stream is consumed, as after a full read
         shards = gather_shard_vectors(self.device_model, collector, shard_keys, rank, world)
         if shards is not None:
-            for skeys, vecs in shards:
-                kaldi_io.write_vec_flt_batch(output_stream, skeys, vecs)
+            for skeys, vecs, emitted in shards:
+                kaldi_io.write_vec_flt_batch(output_stream, skeys, vecs, emitted)
         return True
 
     # -- the hot path ------------------------------------------------------------------------------

@@ -234,9 +234,9 @@ class DeviceModel(object):
         import torch
         hiplib.require_gpu()
         assert precision in ("fp32", "fp32tc", "bf16x3", "f16bf8")
-        # "fp32tc": the exact-fp32 path with the K = 5 / K = 7 layers formed as Toom-Cook F(2, K) over time (xv_tdnn_layer_toom_f32:
-        # 6 / 8 transformed products per row PAIR instead of 10 / 14, exact fp32 products; ~3e-7 rel-L2 on the x-vector where the
-        # direct form has ~2e-7).  Every other layer, pooling and the FCs are the "fp32" kernels.  Row pairs sit on even rows:
+        # "fp32tc": the exact-fp32 path with the K = 3 / 5 / 7 layers formed as Toom-Cook F(2, K) over time (xv_tdnn_layer_toom_f32,
+        # _dilated_f32: 4 / 6 / 8 transformed products per row PAIR instead of 6 / 10 / 14, exact fp32 products; same accuracy class
+        # as the direct form).  Every other layer, pooling and the FCs are the "fp32" kernels.  Row pairs sit on even rows:
         # batches are laid out with chunk starts on even rows (align >= 2; 8 with the fused pooling epilogue).
         self.toom = precision == "fp32tc"
         # "f16bf8": the hidden frame-level layers form a product as one fp16 MFMA + one block-scaled bf8 MFMA instead of
@@ -290,6 +290,11 @@ class DeviceModel(object):
                 # (the last layer's pooling epilogue exists on the direct fp32 kernel only: no Toom-Cook form for it)
                 last = i == len(topo["kernel_sizes"]) - 1
                 self.layers.append(self._prep(weights, sc, w, k, d, defer_wp=self.f16bf8, toom_ok=not (last and self.fused_pool)))
+                if isinstance(self.layers[-1].get("wp"), hiplib.PackedToom) and d > 1:
+                    # a dilated Toom-Cook layer pairs the rows (r, r + d) with floor(r / d) even: chunks on multiples of 2 d rows, so
+                    # that a chunk's pairing -- its bits -- does not depend on where in a batch it lies (d = 3: 24-row alignment)
+                    import math
+                    self.align = math.lcm(self.align, 2 * int(d))
             if self.attention:
                 # models.py:1036-1046: h = [h1 | h2]; u = h1 . attention/w + attention/b is one more K=1 layer.  On the
                 # bf16x3 path the last frame-level layer runs as two launches over the two column halves of its weights so

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -19,7 +19,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_split_decode_f32", "xv_tdnn_layer_bf16x3", "xv_tdnn_layer_bf16x3_sums", "xv_tdnn_layer_bf16x3_moments", "xv_fc_bf16x3",
            "xv_block_stats_bytes", "xv_tdnn_layer_pool_bf16x3", "xv_stats_pool_blocks_f32", "xv_tdnn_layer_pool_f32",
            "xv_packed_weights_rows_f32_floats", "xv_pack_weights_rows_f32", "xv_tdnn_layer_rows_f32",
-           "xv_toom_supported", "xv_packed_weights_toom_f32_floats", "xv_pack_weights_toom_f32", "xv_tdnn_layer_toom_f32",
+           "xv_toom_supported", "xv_packed_weights_toom_f32_floats", "xv_pack_weights_toom_f32", "xv_tdnn_layer_toom_f32", "xv_tdnn_layer_toom_dilated_f32",
            "xv_packed_pair_bf16x3_bytes", "xv_pack_pair_bf16x3", "xv_tdnn_pair_pool_bf16x3",
            "xv_packed_first_bf16x3_bytes", "xv_pack_first_bf16x3", "xv_tdnn_first_bf16x3",
            "xv_packed_weights_f16bf8_bytes", "xv_pack_weights_f16bf8", "xv_split8_encode_f32", "xv_split8_decode_f32",
@@ -90,6 +90,8 @@ def load():
     lib.xv_pack_weights_toom_f32.argtypes = [vp, ci, ci, ci, vp, vp]
     lib.xv_tdnn_layer_toom_f32.restype = ci
     lib.xv_tdnn_layer_toom_f32.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, ci, vp]
+    lib.xv_tdnn_layer_toom_dilated_f32.restype = ci
+    lib.xv_tdnn_layer_toom_dilated_f32.argtypes = [vp, i64, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp]
     lib.xv_stats_pool_workspace_bytes.restype = sz
     lib.xv_stats_pool_workspace_bytes.argtypes = [ci, ci, ci, ci]
     lib.xv_stats_pool_f32.restype = ci
@@ -348,7 +350,7 @@ def tdnn_layer_rows(x, w, bias, scale, shift, act, alpha, row_valid, y, rows=Non
 
 
 class PackedToom(object):
-    """Transformed taps of one K in {5, 7} layer for the Toom-Cook F(2, K) kernel (xv_pack_weights_toom_f32): wp[Cout, (K+1) Cin]."""
+    """Transformed taps of one K in {3, 5, 7} layer for the Toom-Cook F(2, K) kernel (xv_pack_weights_toom_f32): wp[Cout, (K+1) Cin]."""
 
     def __init__(self, wp, K, cin, cout):
         self.wp, self.K, self.cin, self.cout = wp, K, cin, cout
@@ -371,17 +373,22 @@ def pack_weights_toom(w3d):
     return PackedToom(wp, K, cin, cout)
 
 
-def tdnn_layer_toom(x, w, bias, scale, shift, act, alpha, row_valid, y, rows=None):
-    """xv_tdnn_layer_toom_f32: x[R, Cin] -> y[R, Cout] fp32 rows, w a PackedToom."""
+def tdnn_layer_toom(x, w, bias, scale, shift, act, alpha, row_valid, y, rows=None, dilation=1):
+    """xv_tdnn_layer_toom_dilated_f32: x[R, Cin] -> y[R, Cout] fp32 rows, w a PackedToom (chunks on multiples of 2 * dilation rows)."""
     lib = require_gpu()
     _rows2d(x, "x")
     R = x.shape[0] if rows is None else int(rows)
     assert x.shape[1] == w.cin and y.shape[1] == w.cout and y.shape[0] >= R
     if row_valid is not None:
         assert row_valid.is_cuda and row_valid.numel() >= R and row_valid.element_size() == 1
-    _check(lib.xv_tdnn_layer_toom_f32(_ptr(x), R, w.cin, x.stride(0), _ptr(w.wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
-                                      _ptr(alpha), w.K, w.cout, _ptr(row_valid), _ptr(y), y.stride(0), _stream()),
-           "xv_tdnn_layer_toom_f32")
+    if int(dilation) == 1:
+        _check(lib.xv_tdnn_layer_toom_f32(_ptr(x), R, w.cin, x.stride(0), _ptr(w.wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+                                          _ptr(alpha), w.K, w.cout, _ptr(row_valid), _ptr(y), y.stride(0), _stream()),
+               "xv_tdnn_layer_toom_f32")
+        return
+    _check(lib.xv_tdnn_layer_toom_dilated_f32(_ptr(x), R, w.cin, x.stride(0), _ptr(w.wp), _ptr(bias), _ptr(scale), _ptr(shift), int(act),
+                                              _ptr(alpha), w.K, int(dilation), w.cout, _ptr(row_valid), _ptr(y), y.stride(0), _stream()),
+           "xv_tdnn_layer_toom_dilated_f32")
 
 
 class Packed3(object):
@@ -845,8 +852,8 @@ def tdnn_layer(x, wp, bias, scale, shift, act, alpha, K, dilation, row_valid, y,
         R = int(rows) if rows is not None else (x.rows if isinstance(x, SplitBuf) else x.shape[0])
         return tdnn_layer3(x, R, wp, bias, scale, shift, act, alpha, dilation, row_valid, y, y_preact)
     if isinstance(wp, PackedToom):
-        assert wp.K == K and dilation == 1 and y_preact is None
-        return tdnn_layer_toom(x, wp, bias, scale, shift, act, alpha, row_valid, y, rows)
+        assert wp.K == K and y_preact is None
+        return tdnn_layer_toom(x, wp, bias, scale, shift, act, alpha, row_valid, y, rows, dilation)
     if isinstance(wp, PackedRows):
         assert wp.K == K and dilation == 1 and y_preact is None
         return tdnn_layer_rows(x, wp, bias, scale, shift, act, alpha, row_valid, y, rows)
