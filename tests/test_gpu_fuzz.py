@@ -330,8 +330,8 @@ def test_random_shapes_through_the_dma_fed_fp32_gemm(oracle_mod, seed):
 
 @pytest.mark.parametrize("seed", [41, 42])
 def test_random_topologies_in_the_fp32tc_arithmetic(oracle_mod, seed):
-    """The Toom-Cook path on shapes it was not tuned for: hidden widths that are multiples of 32 (so the K = 5 / 7, dilation-1 layers
-    take tdnn_gemm_toom_kernel) next to layers it does not take (K = 1 / 3, dilated, ragged widths: the direct fp32 kernels),
+    """The Toom-Cook path on shapes it was not tuned for: hidden widths that are multiples of 32 (so the K = 3 / 5 / 7 layers, dilated
+    or not, take tdnn_gemm_toom_kernel) next to layers it does not take (K = 1, ragged widths: the direct fp32 kernels),
     first layers in the rows form for every feature dimension, random activations, lengths from 1 frame up, chunking on and off,
     batch budgets from a single tile to one batch -- against the fp64 oracle."""
     import torch  # noqa: F401
@@ -341,7 +341,7 @@ def test_random_topologies_in_the_fp32tc_arithmetic(oracle_mod, seed):
     for case in range(6):
         F = int(rng.choice([23, 24, 30, 13, 40]))
         ks = [int(rng.choice([3, 5, 7]))] + [int(rng.choice([1, 3, 5, 7])) for _ in range(3)] + [int(rng.choice([1, 5]))]
-        ds = [1] + [int(rng.choice([1, 1, 2])) if k == 3 else 1 for k in ks[1:]]
+        ds = [1] + [int(rng.choice([1, 1, 2, 3])) if k > 1 else 1 for k in ks[1:]]
         widths = [int(rng.choice([32, 64, 96, 160])) for _ in range(4)] + [int(rng.choice([64, 100, 192]))]
         if case == 0:
             widths[1] = 40                                   # a layer whose input is no whole slab: not a Toom-Cook layer
@@ -357,9 +357,11 @@ def test_random_topologies_in_the_fp32tc_arithmetic(oracle_mod, seed):
         assert isinstance(model.layers[0]["wp"], hiplib.PackedRows)        # (layer 0, dilation 1: the rows form, whatever K and F)
         for li, (L, k, d, cin, cout) in list(enumerate(zip(model.layers, ks, ds, in_dims, widths)))[1:]:
             # (the last layer feeds the pooling epilogue of the direct kernel: never a Toom-Cook layer)
-            want = k in (5, 7) and d == 1 and cin % 32 == 0 and cout % 4 == 0 and li < len(ks) - 1
+            want = k in (3, 5, 7) and cin % 32 == 0 and cout % 4 == 0 and li < len(ks) - 1
             assert isinstance(L["wp"], hiplib.PackedToom) == want, (case, k, d, cin, cout)
             toom_layers += want
+            if want and d > 1:
+                assert model.align % (2 * d) == 0 and model.align % 8 == 0      # chunks on multiples of 2 d rows (and of the pooling block)
         got = engine.Extractor(model, mn, cs, max_batch_rows=int(rng.choice([64, 700, 262144]))).extract(mats)
         for g, r in zip(got, refs):
             assert (g is None) == (r is None), (case, topo, lens, mn, cs)

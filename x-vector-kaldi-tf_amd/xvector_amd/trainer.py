@@ -107,6 +107,7 @@ class Trainer(object):
         self._one_len = {}
         self._side_busy = False
         self.two_streams = os.environ.get("XVECTOR_TRAIN_STREAMS", "2") != "1"
+        self.wgrad_after = os.environ.get("XVECTOR_TRAIN_WGRAD_AFTER", "1") != "0"
         self._splits = {}                                          # split-format copies for the K = 1 layers' GEMMs (bf16x3)
         self.split_k1 = os.environ.get("XVECTOR_TRAIN_SPLIT_K1", "1") != "0"
         self._side = None                                          # second stream: weight gradients beside the input-gradient GEMMs
@@ -423,14 +424,15 @@ class Trainer(object):
         # whoever reads the gradients next (a bucket's all-reduce, Adam) waits for that stream (_join_side)
         if need_dx and self.two_streams:
             main = torch.cuda.current_stream(self.device)
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                weight_side()
-            dz.record_stream(self._side)
-            x_in.record_stream(self._side)
-            self._side_busy = True
+            side = self._side_stream()
+            ready = None
+            if self.wgrad_after:
+                ready = torch.cuda.Event()
+                ready.record(main)                                     # dz (and x_in) are final here
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    weight_side()
         else:
             weight_side()
         if not need_dx:
@@ -438,10 +440,28 @@ class Trainer(object):
         dx = dx_out if dx_out is not None else torch.empty((R, cin), dtype=torch.float32, device=self.device)
         if sums is not None:
             hiplib.tdnn_layer3_sums(dz_split if dz_split is not None else dz, R, pk[scope + "/T"], dil, valid, dx, sums[0], sums[1])
-            return dx
-        hiplib.tdnn_layer(dz_split if dz_split is not None else dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid, dx,
-                          rows=R)
+        else:
+            hiplib.tdnn_layer(dz_split if dz_split is not None else dz, pk[scope + "/T"], None, None, None, tp.ACT_NONE, None, K, dil, valid,
+                              dx, rows=R)
+        if need_dx and self.two_streams:
+            if self.wgrad_after:
+                # the weight side is queued BEHIND the input-gradient GEMM it runs beside (it waits for dz, not for that GEMM): when
+                # both are ready the hardware takes the critical path's workgroups first
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    weight_side()
+            dz.record_stream(side)
+            x_in.record_stream(side)
+            self._side_busy = True
         return dx
+
+    def _side_stream(self):
+        """The second stream (weight gradients, bias sums, the moving-average update).  (Stream priorities were tried: the device
+        offers 0 and -1 only, so the side stream cannot go below the default, and the step on a -1 stream is 2 % SLOWER --
+        profiles/r06_train_stream_ab.txt.)"""
+        if self._side is None:
+            self._side = self.torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _join_side(self):
         if self._side_busy:
@@ -525,9 +545,7 @@ class Trainer(object):
         # segment level is a ~5 us link of one dependent chain); the stream is joined in front of the optimizer update
         if self.two_streams:
             main = torch.cuda.current_stream(self.device)
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            self._side.wait_stream(main)
+            self._side_stream().wait_stream(main)
             with torch.cuda.stream(self._side):
                 hiplib.ema(self.flat_moving, self.flat_batch, BN_DECAY)
             self._side_busy = True
