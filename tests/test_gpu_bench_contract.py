@@ -10,15 +10,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
+def _run(*flags, **env):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), cwd=ROOT, stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, timeout=600, check=True).stdout.decode().strip().splitlines()
+                         stderr=subprocess.PIPE, timeout=600, check=True, env=dict(os.environ, **env)).stdout.decode().strip().splitlines()
     assert len(out) == 1, out
     return json.loads(out[0])
 
 
 def test_extraction_bench_line():
-    d = _run("--utts", "600", "--steps", "2", "--warmup", "1", "--cpu-budget", "6", "--parity-utts", "2", "--e2e-utts", "700")
+    d = _run("--utts", "600", "--steps", "2", "--warmup", "1", "--cpu-budget", "6", "--parity-utts", "2", "--e2e-utts", "700",
+             XV_BENCH_REHEARSAL_UTTS="1500")                        # (the 8-rank job rehearsal at 8 x 1500 instead of 8 x 125 k utterances)
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
         assert isinstance(d[k], t), k
@@ -70,6 +71,13 @@ def test_extraction_bench_line():
     assert j["rccl_gather"]["first_job"]["vectors_written"] == 700 and "RCCL pre-load (ok) joined after" in j["breakdown_s"]
     assert j["rccl_without_prewarm"]["transport"] == "nccl" and not any("pre-load" in k for k in j["rccl_without_prewarm"]["breakdown_s"])
     assert j["gloo_gather"]["transport"] == "gloo" and j["gloo_gather"]["vectors_written"] == 700
+    # BASELINE configs[3] rehearsed at 8 ranks on this one GPU (scp line ranges, ONE gather, rank 0 writes every record), with the node's
+    # per-rank job predicted piece by piece from it and from the single-rank job above
+    h = j["rehearsal_8x125k"]
+    assert h["ranks"] == 8 and h["utterances"] == 12000 == h["vectors_written"] and h["breakdown_s_rank0"]["gather"] >= 0
+    assert set(h["predicted_breakdown_s"]["from_this_rehearsal"]) == {"tables opened", "gather", "write", "rename"}
+    assert 0 < h["predicted_per_rank_job_s"] < 60 and h["predicted_8gpu_utt_per_s"] == pytest.approx(12000 / h["predicted_per_rank_job_s"])
+    assert r["same_arithmetic"]["cli_job"]["rehearsal_8x125k"]["predicted_per_rank_job_s"] == pytest.approx(h["predicted_per_rank_job_s"], abs=1e-3)
     # what a record that keeps only the contract's objects still carries: the exact-fp32 legs (the reference's arithmetic), compactly
     sa = r["same_arithmetic"]
     assert sa["fp32_exact"]["utt_s"] == pytest.approx(f["value"], rel=1e-3) and 0 < sa["fp32_toomcook"]["frac_of_157.3TF_executed"] < 1

@@ -341,7 +341,8 @@ def test_random_topologies_in_the_fp32tc_arithmetic(oracle_mod, seed):
     for case in range(6):
         F = int(rng.choice([23, 24, 30, 13, 40]))
         ks = [int(rng.choice([3, 5, 7]))] + [int(rng.choice([1, 3, 5, 7])) for _ in range(3)] + [int(rng.choice([1, 5]))]
-        ds = [1] + [int(rng.choice([1, 1, 2, 3])) if k > 1 else 1 for k in ks[1:]]
+        # (the direct kernels -- the last layer's pooling form among them -- take (K - 1) d <= 8)
+        ds = [1] + [int(rng.choice([d for d in (1, 1, 2, 3) if (k - 1) * d <= 8])) if k > 1 else 1 for k in ks[1:]]
         widths = [int(rng.choice([32, 64, 96, 160])) for _ in range(4)] + [int(rng.choice([64, 100, 192]))]
         if case == 0:
             widths[1] = 40                                   # a layer whose input is no whole slab: not a Toom-Cook layer
