@@ -1,11 +1,14 @@
 """Per-layer timing of the exact-fp32 GEMM (xv_tdnn_layer_f32) on random data: every layer shape of the default topology against
-the 157.3 TF fp32-MFMA peak.  argv[1] = rows per batch (default 262144), argv[2] = one layer only (0..4; for counter runs)."""
+the 157.3 TF fp32-MFMA peak.  argv[1] = rows per batch (default 262144), argv[2] = one layer only (0..4; for counter runs).
+XV_BENCH_PERSIST=0 / 1: one workgroup per tile / the persistent launch form (XV_TUNE_FP32_PERSIST; bit-identical: see `bits`)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-tf_amd"))
 import torch
 from xvector_amd import hiplib
 dev = torch.device("cuda:0"); R = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+if os.environ.get("XV_BENCH_PERSIST") and hasattr(hiplib, "TUNE_FP32_PERSIST"):     # (only with tools/experiments/fp32_persistent.patch applied)
+    hiplib.set_tuning(hiplib.TUNE_FP32_PERSIST, int(os.environ["XV_BENCH_PERSIST"]))
 tot_ms = tot_fl = 0.0
 SHAPES = ((24, 512, 5), (512, 512, 5), (512, 512, 7), (512, 512, 1), (512, 1536, 1))
 for (cin, cout, K) in (SHAPES if len(sys.argv) < 3 else SHAPES[int(sys.argv[2]):int(sys.argv[2]) + 1]):
