@@ -225,6 +225,7 @@ def eval_dnn(args):
     presharded = grouped and _is_scp_table(args.feature_rspecifier) and \
         (not args.vad_rspecifier or _is_scp_table(args.vad_rspecifier))
     model = Model()
+    model.prepin_staging = True            # a worker job: the staging sets are pinned while the weights load (models.load_model)
     if presharded:
         feat_scp, vad_scp, shard_keys = _scp_shard(args.feature_rspecifier, rank, world, args.vad_rspecifier or None)
         # the job's one exchange is known now: [emitted? | x-vector] rows of every utterance, from host memory to rank 0's host memory
@@ -306,7 +307,9 @@ def _extract_into_shard_files(args, use_gpu, ark, scp, rank, world):
         if os.path.exists(stale):
             os.remove(stale)
     with kaldi_io.TableWriter(my_ark + '.tmp.ark', my_scp + '.tmp', scp_ark_name=my_ark) as out:
-        Model().make_embedding(feats, out, args.model_dir, args.min_chunk_size, args.chunk_size, use_gpu, logger, vad_stream=vad,
+        worker = Model()
+        worker.prepin_staging = True
+        worker.make_embedding(feats, out, args.model_dir, args.min_chunk_size, args.chunk_size, use_gpu, logger, vad_stream=vad,
                                cmn_window=args.cmn_window, cmn_center=args.cmn_center == 'yes', distributed=False)
     os.rename(my_ark + '.tmp.ark', my_ark)
     os.rename(my_scp + '.tmp', my_scp)

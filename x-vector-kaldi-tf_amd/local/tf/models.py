@@ -225,6 +225,12 @@ class Model(object):
         jobclock.once("import torch")
         torch.cuda.init()
         jobclock.once("hip runtime up")
+        if getattr(self, "prepin_staging", False) and os.environ.get("XVECTOR_PREPIN", "1") != "0":
+            # the CLI worker: its pinned staging sets come up beside the weights (engine.prewarm_staging), not in front of its first window
+            try:
+                engine.prewarm_staging((int(w["frame_level_info_layer-0/w:0"].shape[1]) + 3) // 4 * 4, self.max_batch_rows)
+            except Exception:
+                pass
         self.meta = meta
         self.num_classes = meta["num_classes"]
         self.embedding_index = int(os.environ.get("XVECTOR_EMBEDDING_INDEX", "0"))   # models.py:159-160

@@ -758,6 +758,39 @@ _STAGE_CACHE = {}          # (in_dim, NBUF) -> parked pinned staging sets of fin
 _STAGE_LOCK = __import__("threading").Lock()
 
 
+_STAGE_PENDING = {}        # (in_dim, NBUF) -> side thread that is pinning a set for the cache (prewarm_staging)
+
+
+def _new_stage(torch, in_dim, rows, nchunks, nbuf):
+    return [dict(x=torch.zeros((rows, in_dim), dtype=torch.float32).pin_memory(), rv=torch.zeros(rows, dtype=torch.uint8).pin_memory(),
+                 meta=torch.zeros((2, nchunks), dtype=torch.int32).pin_memory(), event=None) for _ in range(nbuf)]
+
+
+def prewarm_staging(in_dim, rows=262144, nchunks=8192):
+    """Pin the staging sets of a full-size extractor on a side thread and park them where ``Extractor._staging`` looks first.
+    Page-pinning is a host-wide serial resource: 400 MB take 0.27 s in a lone process and 3.7-4.4 s in EACH of eight that start
+    together (tools/experiments/startup_contention_probe.py) -- the ranks of a node's job do start together.  Called by the CLI
+    worker as soon as the HIP runtime is up, the ~100 MB of a worker are pinned while its weights are read, packed and probed
+    instead of in front of its first window."""
+    import threading
+    import torch
+    key = (int(in_dim), Extractor.NBUF)
+    with _STAGE_LOCK:
+        if key in _STAGE_PENDING or any(st[0]["x"].shape[0] >= rows for st in _STAGE_CACHE.get(key, [])):
+            return
+
+        def run():
+            try:
+                stage = _new_stage(torch, key[0], rows, nchunks, key[1])
+                with _STAGE_LOCK:
+                    _STAGE_CACHE.setdefault(key, []).append(stage)
+            except Exception:          # the extractor pins its own set then, and reports what goes wrong
+                pass
+        th = threading.Thread(target=run, name="xv-pin-staging", daemon=True)
+        _STAGE_PENDING[key] = th
+    th.start()
+
+
 def _park_stage(holder):
     if len(holder) == 2 and holder[1] is not None:
         key, stage = holder
@@ -821,15 +854,15 @@ class Extractor(object):
             if self._stage is not None:
                 _park_stage(self._holder)
             with _STAGE_LOCK:
+                pending = _STAGE_PENDING.pop((self.model.in_dim, self.NBUF), None)
+            if pending is not None:
+                pending.join()                                      # (prewarm_staging: a set is being pinned for us right now)
+            with _STAGE_LOCK:
                 parked = _STAGE_CACHE.get((self.model.in_dim, self.NBUF), [])
                 hit = next((i for i, st in enumerate(parked) if st[0]["x"].shape[0] >= rows and st[0]["meta"].shape[1] >= nchunks), None)
                 self._stage = parked.pop(hit) if hit is not None else None
             if self._stage is None:
-                self._stage = []
-                for _ in range(self.NBUF):
-                    self._stage.append(dict(x=torch.zeros((rows, self.model.in_dim), dtype=torch.float32).pin_memory(),
-                                            rv=torch.zeros(rows, dtype=torch.uint8).pin_memory(),
-                                            meta=torch.zeros((2, nchunks), dtype=torch.int32).pin_memory(), event=None))
+                self._stage = _new_stage(torch, self.model.in_dim, rows, nchunks, self.NBUF)
             if self._finalizer is None:
                 import weakref
                 self._finalizer = weakref.finalize(self, _park_stage, self._holder)
@@ -855,7 +888,15 @@ class Extractor(object):
         need = int(np.prod(shape))
         free = self._pin_free.setdefault((kind, dtype), [])
         best = next((i for i, t in enumerate(free) if t.numel() >= need), None)
-        flat = free.pop(best) if best is not None else torch.empty(max(need, 1) * 5 // 4 + 64, dtype=dtype).pin_memory()
+        if best is None:
+            # torch's pinned allocator hands out power-of-two blocks: ask for the whole block the request lands in (the slack that lets
+            # the next, slightly larger window reuse it) and not for 5/4 of it, which doubled every block just above a power of two --
+            # and pinning is what N workers starting together queue for (prewarm_staging)
+            size = torch.empty(0, dtype=dtype).element_size()
+            want = 1 << max(int(need * size - 1).bit_length(), 9)
+            flat = torch.empty(want // size, dtype=dtype).pin_memory()
+        else:
+            flat = free.pop(best)
         return flat, flat[:need].view(shape)
 
     def _unpin(self, kind, flat):
