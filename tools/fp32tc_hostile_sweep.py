@@ -1,6 +1,7 @@
 """The Toom-Cook arithmetic on checkpoints nothing forbids (synthetic.hostile: Student-t weights, channel scales over three decades,
 near-dead channels) next to trained-like draws and a trained checkpoint: worst relative L2 of six MFCC-like utterances against the
-fp64 oracle, forced fp32 (direct K-tap form) and forced fp32tc, per checkpoint.   python tools/fp32tc_hostile_sweep.py [n_seeds]"""
+fp64 oracle, forced fp32 (direct K-tap form) and forced fp32tc, per checkpoint.   python tools/fp32tc_hostile_sweep.py [n_seeds [model class]]
+(model class: ModelWithoutDropout (default) or e.g. ModelWithoutDropoutTdnn, whose K = 3 layers run as F(2, 3) on dilation-strided rows)"""
 import os
 import sys
 
@@ -14,7 +15,8 @@ from xvector_amd import engine, synthetic, topology           # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 oracle.build()
-topo = topology.get("ModelWithoutDropout")
+topo = topology.get(sys.argv[2] if len(sys.argv) > 2 else "ModelWithoutDropout")
+print("model class:", sys.argv[2] if len(sys.argv) > 2 else "ModelWithoutDropout")
 print("%-13s %4s | %10s %10s | ratio" % ("weights", "seed", "fp32", "fp32tc"))
 worst_ratio, worst_tc = 0.0, 0.0
 for kind in ("trained", "trained_like", "hostile"):
