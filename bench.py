@@ -458,10 +458,18 @@ def _job_rehearsal_leg(args, model_dir, feat, cli):
                "--min-chunk-size", "25", "--chunk-size", "10000", "--feature-rspecifier", "scp:" + spath,
                "--vector-wspecifier", "ark,scp:%s,%s" % (o_ark, o_scp), "--model-dir", model_dir]
         t0 = time.perf_counter()
-        run = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        # (its own session: a job that overruns is stopped as a GROUP -- the launcher's ranks must not outlive it on the GPU)
+        job = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+        try:
+            raw, _ = job.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(job.pid, signal.SIGKILL)
+            job.communicate()
+            return {"error": "the 8-rank rehearsal did not finish within 240 s (stopped)"}
         wall = time.perf_counter() - t0
-        log = run.stdout.decode(errors="replace")
-        if run.returncode != 0:
+        log = raw.decode(errors="replace")
+        if job.returncode != 0:
             return {"error": log[-800:]}
         clock = [ln for ln in log.splitlines() if "Job wall clock:" in ln]
         parts = dict((k.strip(" ;["), float(v)) for k, v in re.findall(r"([^,;\[\]]+?) (\d+\.\d+) s", clock[-1].split("Job wall clock:", 1)[1])) if clock else {}
