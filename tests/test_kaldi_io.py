@@ -193,6 +193,7 @@ def test_native_record_writer_writes_the_bytes_of_write_vec_flt(tmp_path, monkey
             out.write(b"")
             kaldi_io.write_vec_flt(out, block[0, 1:4].copy(), key="first")   # the table already holds a record: offsets continue
             kaldi_io.write_vec_flt_batch(out, keys, block[:, 1:], emitted if with_mask else None)
+            kaldi_io.write_vec_flt(out, block[1, 1:6].copy(), key="last")    # ... and per-key writes go on behind the batch
         monkeypatch.delenv("XVECTOR_NATIVE_WRITER")
         return open(path_ark, "rb").read(), open(path_scp, "rb").read()
 
@@ -203,12 +204,14 @@ def test_native_record_writer_writes_the_bytes_of_write_vec_flt(tmp_path, monkey
             with kaldi_io.TableWriter(str(tmp_path / "n.ark"), str(tmp_path / "n.scp"), scp_ark_name="final.ark") as out:
                 kaldi_io.write_vec_flt(out, block[0, 1:4].copy(), key="first")
                 kaldi_io.write_vec_flt_batch(out, k, block[:, 1:], emitted if with_mask else None)
+                kaldi_io.write_vec_flt(out, block[1, 1:6].copy(), key="last")
                 assert out._pos == len(want_ark)
             assert open(tmp_path / "n.ark", "rb").read() == want_ark and open(tmp_path / "n.scp", "rb").read() == want_scp
     # the scp's offsets are the ones the reader seeks to
     table = dict(ln.split() for ln in want_scp.decode().splitlines())
     pos = int(table[keys[-1]].split(":")[1])
     assert np.array_equal(kaldi_io.read_vec_flt(io.BytesIO(want_ark[pos:])), block[-1, 1:])
+    assert np.array_equal(kaldi_io.read_vec_flt(io.BytesIO(want_ark[int(table["last"].split(":")[1]):])), block[1, 1:6])
     # a plain file (no scp), per-key writes as the yardstick, an empty key among them
     some, vec = ["a", "", "ccc"], block[:3, 1:9]
     with open(tmp_path / "plain.ark", "wb") as f:
