@@ -61,8 +61,9 @@ const char *xv_last_error(void);
  *   XV_TUNE_TILE_ROWS  rows per workgroup tile of the bf16x3 / f16bf8 GEMMs with split-format input: 128 (4 waves, two
  *                      workgroups per CU), 256 (8 waves, one per CU), 512 / 1024 (f16bf8: the 256 x 256 tile on the 32 x 32 /
  *                      16 x 16 MFMA shapes where the shape allows it, else as 0; bf16x3: as 256), 0 = built-in choice.
- *   XV_TUNE_FP32_GEMM  form of the exact-fp32 GEMM where both exist (bit-identical results): 1 = register-staged (tdnn_gemm_kernel),
- *                      2 = fed by LDS-DMA (tdnn_gemm_dma_kernel), 0 = built-in choice (the latter unless XV_FP32_DMA=0).
+ *   XV_TUNE_FP32_GEMM  form of the exact-fp32 GEMM where several exist (bit-identical results): 1 = register-staged (tdnn_gemm_kernel),
+ *                      2 = fed by LDS-DMA on 32-channel slabs (tdnn_gemm_dma_kernel), 3 = as 2 with the K = 1 layers on 16-channel
+ *                      slabs, three workgroups per CU (tdnn_gemm_k1_kernel), 0 = built-in choice (3 unless XV_FP32_K1=0 / XV_FP32_DMA=0).
  *   XV_TUNE_XCD_COLUMNS  the 256 x 256-tile f16bf8 GEMM on two column tiles (Cout = 512): 1 = XCDs 0-3 work on column tile 0 and
  *                      XCDs 4-7 on tile 1 (each L2 holds one tile's weights, operand rows are fetched by two XCDs), 0 = every XCD
  *                      works on both column tiles of a contiguous run of row tiles (built-in).

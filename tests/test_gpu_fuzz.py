@@ -276,7 +276,8 @@ def test_random_shapes_through_the_16x16_f16bf8_kernel(oracle_mod, seed):
 @pytest.mark.parametrize("seed", [71, 72])
 def test_random_shapes_through_the_dma_fed_fp32_gemm(oracle_mod, seed):
     """The exact-fp32 GEMM fed by LDS-DMA (round 4) against its register-staged form: random K, dilation, Cin a multiple of 32, ragged
-    Cout, row counts that are no multiple of anything, random gap rows -- the two forms agree BIT FOR BIT (XV_TUNE_FP32_GEMM), rows past
+    Cout, row counts that are no multiple of anything, random gap rows -- the forms (incl. the K = 1 kernel on 16-channel slabs, rows and
+    pooling epilogues) agree BIT FOR BIT (XV_TUNE_FP32_GEMM), rows past
     the end and columns past Cout come back as zeros from the descriptors' range check; a sample of rows against the fp64 oracle."""
     import torch
     from xvector_amd import hiplib
@@ -284,7 +285,7 @@ def test_random_shapes_through_the_dma_fed_fp32_gemm(oracle_mod, seed):
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
     for case in range(4):
-        K = int(rng.choice([1, 3, 5, 7]))
+        K = 1 if case == 0 else int(rng.choice([1, 3, 5, 7]))       # (K = 1 has a form of its own: 16-channel slabs, XV_TUNE_FP32_GEMM 3)
         dil = 1 if K == 1 else int(rng.integers(1, 8 // (K - 1) + 1))
         cin = 32 * int(rng.integers(1, 9))
         cout = int(rng.choice([128, 200, 512, 516, 640]))
@@ -300,18 +301,23 @@ def test_random_shapes_through_the_dma_fed_fp32_gemm(oracle_mod, seed):
         scale = 1 + 0.1 * torch.randn(cout, device=dev)
         shift = 0.1 * torch.randn(cout, device=dev)
         alpha = torch.full((1,), 0.2, device=dev) if act == 2 else (0.1 + 0.05 * torch.randn(cout, device=dev)) if act == 3 else None
-        outs = []
-        for form in (1, 2):
+        outs, pools = [], []
+        for form in (1, 2, 3, 0):                       # register-staged, DMA-fed, DMA-fed with K = 1 on 16-channel slabs, built-in choice
             hiplib.set_tuning(hiplib.TUNE_FP32_GEMM, form)
             try:
                 y = torch.full((R, cout), float("nan"), device=dev)
                 hiplib.tdnn_layer(x, wp, bias, scale, shift, act, alpha, K, dil, valid, y)
                 outs.append(y.cpu().numpy())
+                if cout % 4 == 0:                       # the same layer with the pooling epilogue (8-row block statistics instead of rows)
+                    blk = torch.full((hiplib.block_stats_floats(R, cout),), float("nan"), device=dev)
+                    hiplib.tdnn_layer_pool(x, R, wp, bias, scale, shift, act, alpha, dil, valid, blk, K=K)
+                    pools.append(blk.cpu().numpy()[:(R + 7) // 8 * 2 * cout])
             finally:
                 hiplib.set_tuning(hiplib.TUNE_FP32_GEMM, 0)
         tag = (seed, case, K, dil, cin, cout, R, act)
         assert np.isfinite(outs[1]).all(), tag
-        assert np.array_equal(outs[0], outs[1]), tag
+        assert all(np.array_equal(outs[0], o) for o in outs[1:]), tag
+        assert all(np.array_equal(pools[0], q, equal_nan=True) for q in pools[1:]), tag
         # the first, the last and a few random rows against the fp64 definition (zero rows outside [0, R))
         xh, wh = x.cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64).reshape(K, cin, cout)
         a = None if alpha is None else alpha.cpu().numpy().astype(np.float64)

@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "x-vector-kaldi-
 import torch
 from xvector_amd import hiplib
 dev = torch.device("cuda:0"); R = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+if os.environ.get("XV_BENCH_FORM"):                  # XV_TUNE_FP32_GEMM: 1 register-staged, 2 DMA-fed, 3 DMA-fed + K = 1 layers on 16-channel slabs
+    hiplib.set_tuning(hiplib.TUNE_FP32_GEMM, int(os.environ["XV_BENCH_FORM"]))
 if os.environ.get("XV_BENCH_PERSIST") and hasattr(hiplib, "TUNE_FP32_PERSIST"):     # (only with tools/experiments/fp32_persistent.patch applied)
     hiplib.set_tuning(hiplib.TUNE_FP32_PERSIST, int(os.environ["XV_BENCH_PERSIST"]))
 tot_ms = tot_fl = 0.0

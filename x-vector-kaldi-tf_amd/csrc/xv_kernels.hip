@@ -161,9 +161,9 @@ __device__ __forceinline__ void gemm_epilogue_rows_body(const GemmParams &p, con
         // Thread = (4 channels, blocks rp and rp + 8).  Explicit fma: the two unrolled instances must round alike, a block's
         // statistics may not depend on where it sits in the tile.
 #pragma unroll
-        for (int bb = 0; bb < BMT / 64; ++bb) {
+        for (int bb = 0; bb < (BMT / 8 + 7) / 8; ++bb) {
             const int blk = rp + 8 * bb;
-            if (m0 + blk * 8 >= p.R) continue;
+            if (blk >= BMT / 8 || m0 + blk * 8 >= p.R) continue;          // (a 32-row pass has four blocks: rp < 4)
             f32x4 tv[8];
             float keep[8];
 #pragma unroll
@@ -1565,6 +1565,162 @@ __global__ __launch_bounds__(NT, 2) void tdnn_gemm_dma_kernel(const GemmParams p
     gemm_epilogue_rows<BM>(p, reinterpret_cast<float *>(flds), Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The K = 1 layers of the exact-fp32 path on 16-CHANNEL slabs (round 6): the same MFMA sequence on the same fragments in the same
+// order as tdnn_gemm_dma_kernel<1> (bit-identical), but an LDS row is 64 bytes, a stage 8 + 8 KB, and the epilogue goes through a
+// 64-row tile in two passes -- 34 KB of LDS per workgroup instead of 68, THREE workgroups per CU instead of two (four fit the LDS; at 128 VGPRs the epilogue spills).  A K = 1 tile is
+// 16 (here 32) stages and pays ~2.1 of the old stages at its boundary (epilogue, then the first DMA's latency; fitted from K = 1 / 5 / 7:
+// DESIGN 9.6) with ONE other workgroup on the CU to cover it; a persistent launch changed nothing (profiles/r06_fp32_persistent.txt),
+// two other workgroups do: 0.85 -> 0.89-0.91 of the fp32-MFMA peak.
+//  * piece = 16 rows x 64 bytes; lane l of a piece moves row l >> 2, 16-byte slot l & 3; physical slot = logical ^ ((row >> 2) & 3),
+//    applied on the global side of the DMA: the 16 lanes of a ds_read_b128 group (16 consecutive rows, one logical slot) hit 16
+//    different bank quads;
+//  * stage = 2 k groups = 32 MFMAs per wave, one barrier per stage, the DMA of stage s + 2 behind it.
+// ------------------------------------------------------------------------------------------------
+constexpr int G_BK = 16;
+constexpr int G_SROW = 64;
+constexpr int G_A_BYTES = BM * G_SROW;                 // 8192
+constexpr int G_B_BYTES = BN * G_SROW;                 // 8192
+constexpr int G_TROWS = 64;                            // the epilogue's tile: two passes of 64 rows (33.8 KB; three or four workgroups per CU)
+constexpr int G_TILE = G_TROWS * (BN + 4) * 4;
+constexpr int G_OPER = 2 * G_A_BYTES + 2 * G_B_BYTES;  // 32768
+constexpr int G_MS = G_TILE > G_OPER ? G_TILE : G_OPER;
+constexpr size_t G_LDS_BYTES = (size_t)G_MS + BM;
+
+template <int ACT>
+__device__ __forceinline__ void k1_epilogue(const GemmParams &p, char *lds, const uint8_t *Ms, long m0, int n0, int wr, int wc, int tid,
+                                            const f32x16 &acc00, const f32x16 &acc01, const f32x16 &acc10, const f32x16 &acc11)
+{
+    constexpr int TLD = BN + 4;
+    float *T = reinterpret_cast<float *>(lds);
+    const int lane = tid & 63;
+    const int col = wc * 64 + (lane & 31);
+#pragma unroll
+    for (int pass = 0; pass < BM / G_TROWS; ++pass) {
+        if (wr == pass) {                                  // the waves that own rows [64 pass, 64 pass + 64)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lr = 4 * (lane >> 5) + (reg & 3) + 8 * (reg >> 2);
+                T[lr * TLD + col] = acc00[reg];
+                T[lr * TLD + col + 32] = acc01[reg];
+                T[(lr + 32) * TLD + col] = acc10[reg];
+                T[(lr + 32) * TLD + col + 32] = acc11[reg];
+            }
+        }
+        __syncthreads();
+        gemm_epilogue_rows_body<G_TROWS, ACT>(p, T, Ms + G_TROWS * pass, m0 + G_TROWS * pass, n0, tid);
+        __syncthreads();
+    }
+}
+
+template <int OCC>                                     // workgroups per CU the register budget is cut for (3: 168 VGPRs, no spills; 4: 128, the epilogue spills)
+__global__ __launch_bounds__(NT, OCC) void tdnn_gemm_k1_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char glds[];
+    char *Abuf = glds;                                 // [2][BM rows][64 B]
+    char *Bbuf = glds + 2 * G_A_BYTES;                 // [2][BN cols][64 B]
+    uint8_t *Ms = reinterpret_cast<uint8_t *>(glds + G_MS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int nwg = p.n_mt * p.n_nt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = wg / p.n_nt, nt = wg - mt * p.n_nt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+    const int n_stages = p.cin / G_BK;
+
+    if (tid < BM) {
+        const long gr = m0 + tid;
+        Ms[tid] = (gr < p.R) ? (p.valid ? p.valid[gr] : (uint8_t)1) : (uint8_t)0;
+    }
+
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, (int)(p.R * p.ldx * 4), XV_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, (int)((long)p.cout * p.kred * 4), XV_RSRC_FLAGS);
+    // piece pc = 16 rows (columns); wave w moves pieces w and w + 4 of each operand and stage
+    const int slotb = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    const int arow_bytes = p.ldx * 4, brow_bytes = p.kred * 4;
+    const int va0 = (int)(m0 - p.lead + 16 * wave + (lane >> 2)) * arow_bytes + slotb;
+    const int vb0 = (n0 + 16 * wave + (lane >> 2)) * brow_bytes + slotb;
+    auto dma = [&](int stage, int buf) {
+        const int st = stage < n_stages ? stage : n_stages - 1;          // (the tail rewrites identical bytes)
+        const int so = st * G_BK * 4;
+        char *da = Abuf + buf * G_A_BYTES + wave * 1024, *db = Bbuf + buf * G_B_BYTES + wave * 1024;
+        XV_BLDS16(ars, da, va0, so, 0);
+        XV_BLDS16(ars, da + 4096, va0 + 64 * arow_bytes, so, 0);
+        XV_BLDS16(brs, db, vb0, so, 0);
+        XV_BLDS16(brs, db + 4096, vb0 + 64 * brow_bytes, so, 0);
+    };
+    dma(0, 0);
+    dma(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    struct Fr { f32x4 a0, a1, b0, b1; };
+    // lane (row l & 31, k half kh = l >> 5) reads channels 8 kk + 4 kh .. + 3 of the slab = logical slot 2 kk + kh of its row
+    const int kh = lane >> 5;
+    const int ar = wr * 64 + (lane & 31), bc = wc * 64 + (lane & 31);
+    const int pa = ar * G_SROW + ((kh ^ ((ar >> 2) & 3)) << 4);          // + 32 rows: + 2048, the same swizzle; k group 1: ^ 32
+    const int pb = 2 * G_A_BYTES + bc * G_SROW + ((kh ^ ((bc >> 2) & 3)) << 4);
+    auto load = [&](Fr &X, int buf, int kk) {
+        const int ab = (pa ^ (kk << 5)) + buf * G_A_BYTES, bb = (pb ^ (kk << 5)) + buf * G_B_BYTES;
+        X.a0 = *reinterpret_cast<const f32x4 *>(glds + ab);
+        X.a1 = *reinterpret_cast<const f32x4 *>(glds + ab + 32 * G_SROW);
+        X.b0 = *reinterpret_cast<const f32x4 *>(glds + bb);
+        X.b1 = *reinterpret_cast<const f32x4 *>(glds + bb + 32 * G_SROW);
+    };
+    auto mma = [&](const Fr &X) {                        // (the order of tdnn_gemm_kernel / tdnn_gemm_dma_kernel: results are bit-identical)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.a0[j], X.b0[j], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.a0[j], X.b1[j], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.a1[j], X.b0[j], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(X.a1[j], X.b1[j], acc11, 0, 0, 0);
+        }
+    };
+    auto pin = [&]() {                                   // 16 MFMAs, the four fragment reads behind the first four
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Fr F, G;
+    load(F, 0, 0);
+    for (int s = 0; s < n_stages; ++s) {
+        load(G, s & 1, 1);
+        mma(F);
+        pin();
+        // both fragment sets of stage s are in registers, stage s + 1 has landed.  (A third stage buffer -- the DMA two stages ahead,
+        // counted waits -- was measured: +-0, profiles/r06_fp32_k1_slab16.txt.)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        dma(s + 2, s & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load(F, (s + 1) & 1, 0);                         // (tail: harmless)
+        mma(G);
+        pin();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the tail's clamped pieces must have landed before the tile below reuses the LDS)
+    __syncthreads();
+    switch (p.act) {                                      // (uniform: one switch per thread, not one per element)
+    case XV_ACT_RELU: k1_epilogue<XV_ACT_RELU>(p, glds, Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11); break;
+    case XV_ACT_LRELU: k1_epilogue<XV_ACT_LRELU>(p, glds, Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11); break;
+    case XV_ACT_PRELU: k1_epilogue<XV_ACT_PRELU>(p, glds, Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11); break;
+    default: k1_epilogue<XV_ACT_NONE>(p, glds, Ms, m0, n0, wr, wc, tid, acc00, acc01, acc10, acc11); break;
+    }
+}
+
+constexpr bool FP32_K1_DEFAULT = true;                // (profiles/r06_fp32_k1_slab16.txt: 1.03 -> 0.98 ms, 3.06 -> 2.90 ms; XV_FP32_K1=0 turns it off)
 std::atomic<int> g_fp32_form{0};
 
 int launch_gemm(const GemmParams &p0, hipStream_t st)
@@ -1603,15 +1759,27 @@ int launch_gemm(const GemmParams &p0, hipStream_t st)
             hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
         }
+        for (kern_t k : {tdnn_gemm_k1_kernel<3>, tdnn_gemm_k1_kernel<4>}) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G_LDS_BYTES);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        }
         attr_done.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     const dim3 grid((unsigned)(p.n_mt * p.n_nt));
     // the DMA-fed form (128-row tiles): whole 32-channel slabs, 16-byte aligned rows, byte offsets that fit the descriptors' 32 bits
     static const bool dma_env = !(std::getenv("XV_FP32_DMA") != nullptr && std::getenv("XV_FP32_DMA")[0] == '0');
-    const int form = g_fp32_form.load(std::memory_order_relaxed);       // XV_TUNE_FP32_GEMM: 0 built-in, 1 register-staged, 2 DMA-fed
-    const bool dma_on = form == 2 || (form == 0 && dma_env);
+    const int form = g_fp32_form.load(std::memory_order_relaxed);       // XV_TUNE_FP32_GEMM: 0 built-in, 1 register-staged, 2 DMA-fed, 3 DMA-fed with the K = 1 layers on 16-channel slabs
+    const bool dma_on = form >= 2 || (form == 0 && dma_env);
+    static const int k1_env = std::getenv("XV_FP32_K1") ? atoi(std::getenv("XV_FP32_K1")) : -1;
+    const bool k1_on = form == 3 || (form == 0 && (k1_env < 0 ? FP32_K1_DEFAULT : k1_env != 0));
     const bool dma_ok = dma_on && !small && p.k_splits <= 1 && vec && p.vec_out && (p.cin % BK) == 0 && (p.K == 1 || p.K == 3 || p.K == 5 || p.K == 7) &&
                         (p.R + BM + MAX_SPAN) * (long)p.ldx * 4 < (1l << 31) && (long)(p.cout + BN) * p.kred * 4 < (1l << 31);
+    if (dma_ok && k1_on && p.K == 1 && p.cin >= 2 * G_BK) {
+        if (k1_env == 4) hipLaunchKernelGGL(tdnn_gemm_k1_kernel<4>, grid, dim3(NT), G_LDS_BYTES, st, p);
+        else hipLaunchKernelGGL(tdnn_gemm_k1_kernel<3>, grid, dim3(NT), G_LDS_BYTES, st, p);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : hip_fail(e, "tdnn_gemm_k1_kernel launch");
+    }
     if (dma_ok) {
         const kern_t dk = p.K == 1 ? tdnn_gemm_dma_kernel<1> : p.K == 3 ? tdnn_gemm_dma_kernel<3> : p.K == 5 ? tdnn_gemm_dma_kernel<5>
                                                                                                              : tdnn_gemm_dma_kernel<7>;
@@ -2019,7 +2187,7 @@ int xv_set_tuning(int key, int value)
         xv_internal_first_tiles(value);
         return 0;
     case XV_TUNE_FP32_GEMM:
-        if (value < 0 || value > 2) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: fp32 GEMM form must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(XV_ERR_BAD_ARG, "xv_set_tuning: fp32 GEMM form must be 0, 1, 2 or 3");
         g_fp32_form.store(value, std::memory_order_relaxed);
         return 0;
     case XV_TUNE_XCD_COLUMNS:
