@@ -52,7 +52,7 @@ extern "C" {
 #define XV_ERR_BAD_ARG (-1)
 #define XV_ERR_UNSUPPORTED (-2)
 
-/* Library / ABI version (increments whenever an entry point is added or changed; currently 22). */
+/* Library / ABI version (increments whenever an entry point is added or changed; currently 23). */
 int xv_version(void);
 /* Thread-local description of the last non-zero return. */
 const char *xv_last_error(void);
@@ -357,6 +357,13 @@ int xv_wgrad_f32(const float *x, int ldx, const float *dz, int lddz, int64_t R, 
  * same deterministic split merge; falls back to xv_wgrad_f32 when R * ld * 4 >= 2^31 (32-bit buffer offsets). */
 int xv_wgrad_bf16x3(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation,
                     float *dw, void *workspace, void *stream);
+/* xv_wgrad_bf16x3 that also leaves db[co] = sum_r dz[r, co], the bias gradient of the same layer (models.py:61 under minimize()): the
+ * workgroups of tap 0 / input tile 0 sum the dz rows they stream anyway (fp32 inside a 16-row step, double across steps and row
+ * splits, merged in split order: deterministic) -- no separate pass over dz (xv_col_sums_f32).  workspace: xv_wgrad_bias_workspace_bytes
+ * (always required).  No fp32 fallback: XV_ERR_UNSUPPORTED when R * ld * 4 >= 2^31. */
+size_t xv_wgrad_bias_workspace_bytes(int64_t R, int cin, int cout, int K);
+int xv_wgrad_bias_bf16x3(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation,
+                         float *dw, float *db, void *workspace, void *stream);
 /* sum_a[c] = sum_r a[r,c];  sum_ab[c] = sum_r a[r,c]*b[r,c]  (b, sum_ab may be NULL). */
 size_t xv_col_sums_workspace_bytes(int64_t R, int c);
 int xv_col_sums_f32(const float *a, int lda, const float *b, int ldb, int64_t R, int c, float *sum_a, float *sum_ab,

@@ -305,7 +305,7 @@ def test_three_steps_follow_the_reference_training_loop(env, golden, cls):
 
 
 def test_wgrad_and_reductions_unit(env):
-    """xv_wgrad_f32 / xv_col_sums_f32 on their own, incl. the split + ordered-merge path (R > 4096) and a ragged Cin."""
+    """xv_wgrad_f32 / xv_wgrad_bf16x3 / xv_wgrad_bias_bf16x3 / xv_col_sums_f32 on their own, incl. the split + ordered-merge path (R > 4096) and ragged Cin / Cout."""
     torch, hiplib = env["torch"], env["hiplib"]
     rng = np.random.default_rng(11)
     for (R, cin, cout, K, d) in ((300, 24, 64, 5, 1), (9000, 64, 96, 3, 2), (70, 96, 10, 1, 1), (19000, 512, 512, 7, 1), (4097, 130, 257, 3, 3)):
@@ -324,6 +324,17 @@ def test_wgrad_and_reductions_unit(env):
         dw3 = torch.full((K, cin, cout), float("nan"), dtype=torch.float32, device="cuda:0")
         hiplib.wgrad(torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda(), K, d, dw3, "bf16x3")
         assert _rel(dw3.cpu().numpy(), ref) < 2e-5, (R, cin, cout, K, d)
+        # ... and with the bias gradient out of the rows it streams (xv_wgrad_bias_bf16x3): dw bit for bit the plain kernel's, db = the
+        # column sums of dz (fp32 inside a 16-row step, double across steps and row splits), NaN-poisoned outputs, twice the same bits
+        dwb = torch.full((K, cin, cout), float("nan"), dtype=torch.float32, device="cuda:0")
+        dbb = torch.full((cout,), float("nan"), dtype=torch.float32, device="cuda:0")
+        assert hiplib.wgrad_takes_bias("bf16x3", torch.from_numpy(x), torch.from_numpy(dz)) and not hiplib.wgrad_takes_bias("fp32", torch.from_numpy(x), torch.from_numpy(dz))
+        hiplib.wgrad(torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda(), K, d, dwb, "bf16x3", db=dbb)
+        assert np.array_equal(dwb.cpu().numpy(), dw3.cpu().numpy()), (R, cin, cout, K, d)
+        assert _rel(dbb.cpu().numpy(), dz.astype(np.float64).sum(0)) < 1e-6, (R, cin, cout, K, d)
+        again = torch.full((cout,), float("nan"), dtype=torch.float32, device="cuda:0")
+        hiplib.wgrad(torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda(), K, d, dwb, "bf16x3", db=again)
+        assert np.array_equal(again.cpu().numpy(), dbb.cpu().numpy())
         sa = torch.empty(cout, dtype=torch.float32, device="cuda:0"); sab = torch.empty_like(sa)
         b = rng.standard_normal((R, cout)).astype(np.float32)
         hiplib.col_sums(torch.from_numpy(dz).cuda(), torch.from_numpy(b).cuda(), sa, sab)

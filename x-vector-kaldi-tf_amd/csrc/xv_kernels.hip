@@ -2171,7 +2171,7 @@ void xv_internal_gemm8_tile_rows(int value);      // xv_gemm8.hip
 void xv_internal_gemm8_xcd_columns(int value);    // xv_gemm8.hip
 void xv_internal_first_tiles(int tiles);          // xv_first.hip
 
-int xv_version(void) { return 22; }
+int xv_version(void) { return 23; }
 
 int xv_set_tuning(int key, int value)
 {

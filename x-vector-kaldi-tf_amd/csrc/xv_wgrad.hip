@@ -45,8 +45,13 @@ struct WgradParams {
     int n_ct, n_ot;      // tiles along cin / cout
     long rows_per_split;
     float *out;          // [nsplit][K][cin][cout] (or dw itself when nsplit == 1)
+    double *db_part;     // BIAS: [nsplit][cout] partial column sums of dz (the bias gradient), written by the workgroups with k == 0, ct == 0
 };
 
+// BIAS: the workgroups of tap 0 / input tile 0 also leave the column sums of the dz rows they stream anyway -- db = sum_r dz[r, :], the bias
+// gradient of the same layer (models.py:61 bias_add under minimize()) -- per row split, in double: the separate pass over dz that
+// xv_col_sums_f32 made for it was 4 % of a training step (tools/experiments/train_bias_sums_ablation.py).
+template <bool BIAS>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const WgradParams p)
 {
     __shared__ __attribute__((aligned(16))) char lds[4 * PLANE];       // [x hi | x lo | dz hi | dz lo]
@@ -106,8 +111,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const WgradParams 
     const char *afrag = lds + (wi * 64 + (lane & 31)) * CH_STRIDE + 16 * (lane >> 5);
     const char *bfrag = lds + 2 * PLANE + (wj * 64 + (lane & 31)) * CH_STRIDE + 16 * (lane >> 5);
 
+    const bool sums = BIAS && k == 0 && ct == 0;                        // (uniform per workgroup)
+    double bsum = 0.0;
     load(r_begin);
     for (long r0 = r_begin; r0 < r_end; r0 += WR) {
+        if (BIAS && sums) {                                             // 16 rows of this thread's channel: fp32 inside the step, double across steps
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += vz[i];
+            bsum += (double)t;
+        }
         stage(vx, xc_ok, lds);
         stage(vz, zc_ok, lds + 2 * PLANE);
         __syncthreads();
@@ -138,6 +151,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(const WgradParams 
         }
         __syncthreads();
     }
+    if (BIAS && sums) {                                                 // the two row halves of a channel, in a fixed order
+        double *sh = reinterpret_cast<double *>(lds);                   // (the operand images are dead: the loop ended on a barrier)
+        if (half) sh[ch] = bsum;
+        __syncthreads();
+        if (!half && zc_ok) p.db_part[(size_t)blockIdx.y * p.cout + o0 + ch] = bsum + sh[ch];
+    }
     // D: col = lane & 31 (cout), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (cin)
     float *out = p.out + ((size_t)blockIdx.y * p.K + k) * (size_t)p.cin * p.cout;
 #pragma unroll
@@ -163,21 +182,62 @@ __global__ void sum_splits_kernel(const float *__restrict__ part, size_t n, int 
     out[i] = s;
 }
 
+__global__ void bias_splits_kernel(const double *__restrict__ part, int cout, int nsplit, float *__restrict__ db)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cout) return;
+    double s = 0.0;
+    for (int j = 0; j < nsplit; ++j) s += part[(size_t)j * cout + c];   // fixed order: deterministic
+    db[c] = (float)s;
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t xv_wgrad_workspace_bytes(int64_t R, int cin, int cout, int K);       // (xv_train.hip: the split rule is shared)
 
+static int wgrad_bf16x3_impl(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation, float *dw,
+                             float *db, void *workspace, void *stream);
+
 int xv_wgrad_bf16x3(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation, float *dw,
                     void *workspace, void *stream)
+{
+    return wgrad_bf16x3_impl(x, ldx, dz, lddz, R, cin, cout, K, dilation, dw, nullptr, workspace, stream);
+}
+
+size_t xv_wgrad_bias_workspace_bytes(int64_t R, int cin, int cout, int K)
+{
+    if (R <= 0 || cin <= 0 || cout <= 0 || K <= 0) return 0;
+    const size_t base = xv_wgrad_workspace_bytes(R, cin, cout, K);
+    const size_t splits = base ? base / ((size_t)K * cin * (size_t)cout * sizeof(float)) : 1;
+    return (base + 7) / 8 * 8 + splits * (size_t)cout * sizeof(double);
+}
+
+int xv_wgrad_bias_bf16x3(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation, float *dw,
+                         float *db, void *workspace, void *stream)
+{
+    if (!db || !workspace) {
+        xv_internal_set_error("wgrad_bias_bf16x3: db and the workspace of xv_wgrad_bias_workspace_bytes are required");
+        return XV_ERR_BAD_ARG;
+    }
+    return wgrad_bf16x3_impl(x, ldx, dz, lddz, R, cin, cout, K, dilation, dw, db, workspace, stream);
+}
+
+static int wgrad_bf16x3_impl(const float *x, int ldx, const float *dz, int lddz, int64_t R, int cin, int cout, int K, int dilation, float *dw,
+                             float *db, void *workspace, void *stream)
 {
     if (!x || !dz || !dw || R <= 0 || cin <= 0 || cout <= 0 || K <= 0 || !(K & 1) || dilation <= 0 || ldx < cin || lddz < cout) {
         xv_internal_set_error("wgrad_bf16x3: bad argument");
         return XV_ERR_BAD_ARG;
     }
-    if ((double)R * ldx * 4 >= 2147483648.0 || (double)R * lddz * 4 >= 2147483648.0)     // 32-bit buffer offsets
+    if ((double)R * ldx * 4 >= 2147483648.0 || (double)R * lddz * 4 >= 2147483648.0) {   // 32-bit buffer offsets
+        if (db) {
+            xv_internal_set_error("wgrad_bias_bf16x3: matrices must stay below 2^31 bytes (use xv_wgrad_bf16x3 + xv_col_sums_f32)");
+            return XV_ERR_UNSUPPORTED;
+        }
         return xv_wgrad_f32(x, ldx, dz, lddz, R, cin, cout, K, dilation, dw, workspace, stream);
+    }
     WgradParams p{};
     p.x = x; p.dz = dz; p.R = (long)R; p.cin = cin; p.ldx = ldx; p.cout = cout; p.lddz = lddz; p.K = K; p.dil = dilation;
     p.n_ct = (cin + WT - 1) / WT; p.n_ot = (cout + WT - 1) / WT;
@@ -189,9 +249,15 @@ int xv_wgrad_bf16x3(const float *x, int ldx, const float *dz, int lddz, int64_t 
         return XV_ERR_BAD_ARG;
     }
     p.out = splits > 1 ? (float *)workspace : dw;
+    p.db_part = db ? reinterpret_cast<double *>((char *)workspace + (ws_bytes + 7) / 8 * 8) : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_bf16x3_kernel, dim3((unsigned)(K * p.n_ct * p.n_ot), (unsigned)splits), dim3(256), 0, st, p);
+    if (db) hipLaunchKernelGGL(wgrad_bf16x3_kernel<true>, dim3((unsigned)(K * p.n_ct * p.n_ot), (unsigned)splits), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(wgrad_bf16x3_kernel<false>, dim3((unsigned)(K * p.n_ct * p.n_ot), (unsigned)splits), dim3(256), 0, st, p);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && db) {
+        hipLaunchKernelGGL(bias_splits_kernel, dim3((unsigned)((cout + 255) / 256)), dim3(256), 0, st, (const double *)p.db_part, cout, (int)splits, db);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess && splits > 1) {
         const size_t n = (size_t)K * cin * cout;
         hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)workspace, n,

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("XVECTOR_HIP_LIB") or os.path.join(_HERE, "libxvector_hip.so")     # override: kernel experiments
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 # every symbol include/xvector_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32", "xv_fold_bn_f32", "xv_tdnn_layer_f32",
@@ -27,6 +27,7 @@ SYMBOLS = ("xv_version", "xv_last_error", "xv_set_tuning", "xv_pack_weights_f32"
            "xv_packed_pair_f16bf8_bytes", "xv_pack_pair_f16bf8", "xv_tdnn_pair_pool_f16bf8",
            # training step
            "xv_chunk_moments_f32", "xv_merge_moments_f32", "xv_rows_affine_f32", "xv_rows_affine_split_f32", "xv_wgrad_workspace_bytes", "xv_wgrad_f32", "xv_wgrad_bf16x3",
+           "xv_wgrad_bias_workspace_bytes", "xv_wgrad_bias_bf16x3",
            "xv_col_sums_workspace_bytes", "xv_col_sums_f32", "xv_bn_act_backward_f32", "xv_bn_act_backward_split_f32", "xv_pool_backward_f32",
            "xv_bn_act_backward_parts_f32", "xv_col_sums_merge_f32", "xv_pool_bn_act_backward_f32", "xv_bn_moments_fold_f32", "xv_bn_small_forward_f32", "xv_bn_small_backward_f32",
            "xv_softmax_ce_f32", "xv_adam_f32", "xv_ema_f32", "xv_axpy_f32", "xv_sumsq_workspace_bytes", "xv_sumsq_f32", "xv_dropout_f32", "xv_pack_minibatch_f32", "xv_minibatch_layout",
@@ -174,6 +175,10 @@ def load():
     lib.xv_wgrad_f32.argtypes = [vp, ci, vp, ci, i64, ci, ci, ci, ci, vp, vp, vp]
     lib.xv_wgrad_bf16x3.restype = ci
     lib.xv_wgrad_bf16x3.argtypes = lib.xv_wgrad_f32.argtypes
+    lib.xv_wgrad_bias_workspace_bytes.restype = sz
+    lib.xv_wgrad_bias_workspace_bytes.argtypes = [i64, ci, ci, ci]
+    lib.xv_wgrad_bias_bf16x3.restype = ci
+    lib.xv_wgrad_bias_bf16x3.argtypes = [vp, ci, vp, ci, i64, ci, ci, ci, ci, vp, vp, vp, vp]
     lib.xv_col_sums_workspace_bytes.restype = sz
     lib.xv_col_sums_workspace_bytes.argtypes = [i64, ci]
     lib.xv_col_sums_f32.restype = ci
@@ -981,14 +986,26 @@ def rows_affine(x, scale, shift, row_valid, y, rows=None, y_split=None):
                                         _stream()), "xv_rows_affine_split_f32")
 
 
-def wgrad(x, dz, K, dilation, dw, precision="fp32"):
-    """dw[K, Cin, Cout] (contiguous) = sum_r x[r + tap shift] (x) dz[r]; precision "fp32" (exact fp32 MFMA) or "bf16x3"."""
+def wgrad_takes_bias(precision, x, dz):
+    """Whether ``wgrad(..., db=)`` can leave the bias gradient too (xv_wgrad_bias_bf16x3: bf16x3, 32-bit buffer offsets)."""
+    return precision == "bf16x3" and x.shape[0] * x.stride(0) * 4 < 2 ** 31 and dz.shape[0] * dz.stride(0) * 4 < 2 ** 31
+
+
+def wgrad(x, dz, K, dilation, dw, precision="fp32", db=None):
+    """dw[K, Cin, Cout] (contiguous) = sum_r x[r + tap shift] (x) dz[r]; precision "fp32" (exact fp32 MFMA) or "bf16x3".
+    ``db`` (bf16x3 only, see wgrad_takes_bias): also db[Cout] = sum_r dz[r], out of the rows the kernel streams anyway."""
     lib = require_gpu()
     fn, name = (lib.xv_wgrad_bf16x3, "xv_wgrad_bf16x3") if precision == "bf16x3" else (lib.xv_wgrad_f32, "xv_wgrad_f32")
     _rows2d(x, "x"); _f32(dz, "dz"); _f32(dw, "dw")
     R, cin = x.shape
     cout = dz.shape[1]
     assert dz.shape[0] == R and tuple(dw.shape) == (K, cin, cout)
+    if db is not None:
+        assert wgrad_takes_bias(precision, x, dz) and _f32(db, "db").numel() == cout
+        ws = _ws(lib.xv_wgrad_bias_workspace_bytes(R, cin, cout, K), x.device)
+        _check(lib.xv_wgrad_bias_bf16x3(_ptr(x), x.stride(0), _ptr(dz), dz.stride(0), R, cin, cout, int(K), int(dilation), _ptr(dw), _ptr(db),
+                                        _ptr(ws), _stream()), "xv_wgrad_bias_bf16x3")
+        return
     ws = _ws(lib.xv_wgrad_workspace_bytes(R, cin, cout, K), x.device)
     _check(fn(_ptr(x), x.stride(0), _ptr(dz), dz.stride(0), R, cin, cout, int(K), int(dilation), _ptr(dw), _ptr(ws), _stream()), name)
 

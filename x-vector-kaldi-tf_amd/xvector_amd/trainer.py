@@ -108,6 +108,7 @@ class Trainer(object):
         self._side_busy = False
         self.two_streams = os.environ.get("XVECTOR_TRAIN_STREAMS", "2") != "1"
         self.wgrad_after = os.environ.get("XVECTOR_TRAIN_WGRAD_AFTER", "1") != "0"
+        self.fused_bias = os.environ.get("XVECTOR_TRAIN_FUSED_BIAS", "1") != "0"
         self._splits = {}                                          # split-format copies for the K = 1 layers' GEMMs (bf16x3)
         self.split_k1 = os.environ.get("XVECTOR_TRAIN_SPLIT_K1", "1") != "0"
         self._side = None                                          # second stream: weight gradients beside the input-gradient GEMMs
@@ -409,13 +410,17 @@ class Trainer(object):
         gw, db = self.G[scope + "/w:0"], self.G[scope + "/b:0"]
 
         def weight_side():
+            # (bf16x3: the bias gradient comes out of the weight-gradient kernel, which streams dz anyway -- xv_wgrad_bias_bf16x3; the
+            # separate pass over dz was 4 % of a step.  XVECTOR_TRAIN_FUSED_BIAS=0: xv_col_sums_f32 as before)
+            fused = self.fused_bias and hiplib.wgrad_takes_bias(self.precision, x_in, dz)
             if scope == self.frame_scopes[0] and self.in_dim != self.feat_dim:
                 dw = torch.empty((K, cin, cout), dtype=torch.float32, device=self.device)
-                hiplib.wgrad(x_in, dz, K, dil, dw, self.precision)
+                hiplib.wgrad(x_in, dz, K, dil, dw, self.precision, db=db if fused else None)
                 gw.copy_(dw[:, :self.feat_dim, :])                          # drop the padding column
             else:
-                hiplib.wgrad(x_in, dz, K, dil, gw.view(K, cin, cout), self.precision)
-            hiplib.col_sums(dz, None, db)
+                hiplib.wgrad(x_in, dz, K, dil, gw.view(K, cin, cout), self.precision, db=db if fused else None)
+            if not fused:
+                hiplib.col_sums(dz, None, db)
 
         grads[scope + "/w:0"] = gw
         grads[scope + "/b:0"] = db
