@@ -553,7 +553,8 @@ def _fp32_leg(args, weights, topo, dev, batches, n_utts, frames, feat, precision
                     "executed_tflops": ex * frames * steps / t_g / 1e12, "executed_frac": ex * frames * steps / t_g / MFMA_F32_PEAK,
                     "executed_over_algorithmic_flops": ex / tp.flops_per_frame(topo, feat),
                     "kernel": "tdnn_gemm_toom_kernel<5>, <7> (layers 1, 2: 6 / 8 transformed products per row pair on v_mfma_f32_32x32x2_f32, "
-                              "csrc/xv_toom.hip); layers 0, 3, 4, pooling, FC as fp32_exact"})
+                              "csrc/xv_toom.hip); layers 0 (rows form), 3, 4 (+ pooling epilogue): tdnn_gemm_k1_kernel (K = 1 on 16-channel slabs, three "
+                              "workgroups per CU, csrc/xv_kernels.hip); FC as fp32_exact"})
     if oracle_check is not None:
         out["parity_rel_l2_max_vs_fp64_oracle"] = oracle_check(E)
     return out
